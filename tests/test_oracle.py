@@ -1,0 +1,204 @@
+"""CPU tests pinning the oracle itself.
+
+The reference has no golden vectors for the MU path, so the
+oracle is pinned by three independently written restatements agreeing with each
+other (C, numpy per-lag GEMM, index-level brute force), by the algebraic
+properties the reference's notebooks rely on, and by committed fixtures.
+"""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rand_problem(rng, N, T, K, L):
+    W = rng.random((K, N, L))
+    H = rng.random((K, T))
+    X = rng.random((N, T))
+    return W, H, X
+
+
+SHAPES = [
+    (7, 23, 3, 4),
+    (5, 9, 1, 1),     # K=1, L=1
+    (1, 17, 2, 5),    # N=1
+    (6, 3, 2, 5),     # T < L
+    (4, 5, 3, 5),     # T == L
+    (33, 70, 5, 10),
+]
+
+
+@pytest.mark.parametrize("N,T,K,L", SHAPES)
+def test_conv_three_way(oracle, N, T, K, L):
+    rng = np.random.default_rng(N * 1000 + T)
+    W, H, _ = _rand_problem(rng, N, T, K, L)
+    a = oracle.tensor_conv(W, H)
+    b = oracle.c_tensor_conv(W, H)
+    c = oracle.brute_conv(W, H)
+    np.testing.assert_allclose(a, c, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(b, c, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("N,T,K,L", SHAPES)
+def test_transconv_three_way(oracle, N, T, K, L):
+    rng = np.random.default_rng(N * 1000 + T + 1)
+    W, _, X = _rand_problem(rng, N, T, K, L)
+    a = oracle.tensor_transconv(W, X)
+    b = oracle.c_tensor_transconv(W, X)
+    c = oracle.brute_transconv(W, X)
+    np.testing.assert_allclose(a, c, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(b, c, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("N,T,K,L", SHAPES)
+def test_hxt_matches_reference_slices(oracle, N, T, K, L):
+    """mult.jl:31-34: numW[:,:,lag] = H[:, :T-lag] @ X[:, lag:]'."""
+    rng = np.random.default_rng(7)
+    _, H, X = _rand_problem(rng, N, T, K, L)
+    out = oracle.c_hxt(H, X, L)
+    for lag in range(L):
+        ref = H[:, : T - lag] @ X[:, lag:].T if lag < T else np.zeros((K, N))
+        np.testing.assert_allclose(out[:, :, lag], ref, rtol=1e-13, atol=1e-13)
+
+
+def test_adjointness(oracle):
+    """<conv(W,H), X> == <H, transconv(W,X)>."""
+    rng = np.random.default_rng(11)
+    W, H, X = _rand_problem(rng, 19, 57, 4, 6)
+    lhs = np.sum(oracle.tensor_conv(W, H) * X)
+    rhs = np.sum(H * oracle.tensor_transconv(W, X))
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs)
+
+
+def test_conv_equals_unfolded_gemm(oracle):
+    """conv(W,H) = W_unfold * shift_and_stack(H, L) (common.jl:133-142; notebooks/benchmarks.ipynb tconv3)."""
+    rng = np.random.default_rng(12)
+    W, H, _ = _rand_problem(rng, 13, 41, 3, 7)
+    K, N, L = W.shape
+    W_unf = np.concatenate([W[:, :, l].T for l in range(L)], axis=1)  # N x (L*K), col = K*lag + k
+    np.testing.assert_allclose(W_unf @ oracle.shift_and_stack(H, L), oracle.tensor_conv(W, H), rtol=1e-13, atol=1e-13)
+
+
+def test_conv_equals_fft(oracle):
+    """notebooks/test_fft.ipynb cells 6-7: direct conv == FFT conv to ~1e-15."""
+    rng = np.random.default_rng(13)
+    W, H, _ = _rand_problem(rng, 6, 64, 3, 9)
+    K, N, L = W.shape
+    T = H.shape[1]
+    nfft = T + L
+    est = np.zeros((N, T))
+    Hf = np.fft.rfft(H, nfft, axis=1)
+    for n in range(N):
+        Wf = np.fft.rfft(W[:, n, :], nfft, axis=1)
+        est[n] = np.fft.irfft((Wf * Hf).sum(0), nfft)[:T]
+    np.testing.assert_allclose(est, oracle.tensor_conv(W, H), rtol=1e-12, atol=1e-12)
+
+
+def test_converged_semantics(oracle):
+    """model.jl:91-107."""
+    import ctypes
+
+    def both(lh, patience, tol):
+        a = oracle.converged(lh, patience, tol)
+        arr = np.asarray(lh, dtype=np.float64)
+        b = bool(oracle.c_lib().oracle_converged(arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(arr), patience, tol))
+        assert a == b
+        return a
+
+    assert not both([1.0, 1.0, 1.0], 3, 1e-4)            # length <= patience
+    assert both([1.0, 1.0, 1.0, 1.0], 3, 1e-4)           # 3 diffs, all < tol
+    assert not both([2.0, 1.0, 1.0, 1.0], 3, 1e-4)       # first of the 3 diffs too big
+    assert both([5.0, 2.0, 1.0, 1.0, 1.0, 1.0], 3, 1e-4)
+    assert both([1.0, 1.00005], 1, 1e-4)
+    assert not both([1.0, 1.0002], 1, 1e-4)
+
+
+@pytest.mark.parametrize("reg", [dict(), dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2)])
+def test_fit_c_vs_numpy(oracle, reg):
+    data, _, _ = oracle.c_gen_synthetic(N=40, T=150, K=3, L=8, seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=6, K=4, seed=0)
+    Wa, Ha, la, ta = oracle.fit_mult(data, W0, H0, max_itr=25, check_convergence=False, **reg)
+    Wb, Hb, lb, tb = oracle.c_fit_mult(data, W0, H0, max_itr=25, check_convergence=False, **reg)
+    assert len(la) == len(lb) == 26 and ta[0] == 0.0 and tb[0] == 0.0
+    np.testing.assert_allclose(la, lb, rtol=1e-10)
+    np.testing.assert_allclose(Wa, Wb, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(Ha, Hb, rtol=1e-8, atol=1e-12)
+
+
+def test_unregularised_loss_nonincreasing(oracle):
+    data, _, _ = oracle.c_gen_synthetic(N=30, T=200, K=3, L=8, seed=5)
+    W0, H0 = oracle.c_init_rand(data, L=8, K=3, seed=1)
+    _, _, lh, _ = oracle.fit_mult(data, W0, H0, max_itr=40, check_convergence=False)
+    assert np.all(np.diff(lh) <= 1e-12)
+
+
+def test_exactly_factorisable_drives_loss_down(oracle):
+    """datasets/toy.jl-style noiseless data: MU should fit it well."""
+    data, Wt, Ht = oracle.c_gen_synthetic(N=20, T=300, K=2, L=5, noise_scale=0.0, seed=3)
+    np.testing.assert_allclose(data, oracle.tensor_conv(Wt, Ht), rtol=1e-12, atol=1e-12)
+    W0, H0 = oracle.c_init_rand(data, L=5, K=2, seed=2)
+    _, _, lh, _ = oracle.fit_mult(data, W0, H0, max_itr=300, check_convergence=False)
+    assert lh[-1] < 0.25 * lh[0]
+
+
+def test_early_stop_and_eval_mode(oracle):
+    data, _, _ = oracle.c_gen_synthetic(N=25, T=120, K=3, L=6, seed=9)
+    W0, H0 = oracle.c_init_rand(data, L=6, K=3, seed=0)
+    Wa, Ha, la, _ = oracle.fit_mult(data, W0, H0, max_itr=500, tol=1e-3, patience=2)
+    Wb, Hb, lb, _ = oracle.c_fit_mult(data, W0, H0, max_itr=500, tol=1e-3, patience=2)
+    assert len(la) == len(lb) < 501
+    np.testing.assert_allclose(la, lb, rtol=1e-10)
+    # eval_mode: W untouched (alternating.jl:51-53)
+    Wc, Hc, lc, _ = oracle.c_fit_mult(data, W0, H0, max_itr=5, eval_mode=True, check_convergence=False)
+    np.testing.assert_array_equal(Wc, W0)
+    assert lc[-1] < lc[0]
+
+
+def test_init_rand_scale_is_least_squares(oracle):
+    """model.jl:113-125: after scaling by sqrt|alpha| each, <data - est, est> == 0."""
+    data, _, _ = oracle.c_gen_synthetic(N=30, T=100, K=3, L=7, seed=21)
+    W, H = oracle.c_init_rand(data, L=5, K=4, seed=0)
+    est = oracle.tensor_conv(W, H)
+    assert abs(np.sum((data - est) * est)) <= 1e-9 * np.sum(est * est)
+    assert W.min() >= 0 and H.min() >= 0
+
+
+def test_gen_synthetic_statistics(oracle):
+    """datasets/synthetic.jl:29-61 semantics."""
+    data, W, H = oracle.c_gen_synthetic(N=200, T=4000, K=3, L=20, seed=1234)
+    assert data.shape == (200, 4000) and data.min() >= 0.0
+    frac = np.mean(H > 0)
+    assert 0.45 < frac < 0.55                       # Bernoulli(p_h=0.5)
+    assert 0.9 < H[H > 0].mean() < 1.1              # Exponential(1)
+    # W[k,n,:] = mW[n,k] * pdf(Normal(cent, sigma)) on linspace(-1,1,L); Dirichlet rows sum to 1
+    assert np.all(W >= 0)
+    resid = data - np.maximum(0.0, oracle.tensor_conv(W, H))
+    assert abs(resid.std() - 1.0) < 0.2             # noise_scale=1 (rectified, so loose)
+
+
+def test_rng_known_answers(oracle):
+    """Known answers of the portable RNG spec (pins it across rebuilds / platforms)."""
+    lib = oracle.c_lib()
+    got = [lib.oracle_rng_u01(1234, 0, i) for i in range(4)]
+    path = os.path.join(GOLDEN, "rng_kat.npz")
+    kat = np.load(path)
+    np.testing.assert_array_equal(np.asarray(got), kat["u01_seed1234_stream0"][:4])
+    gotn = [lib.oracle_rng_normal(1234, 16, i) for i in range(4)]
+    np.testing.assert_allclose(np.asarray(gotn), kat["normal_seed1234_stream16"][:4], rtol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["mu_small", "mu_small_reg", "mu_k5"])
+def test_golden_fixtures(oracle, name):
+    """Both restatements reproduce the committed fixtures (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    kw = dict(max_itr=int(g["max_itr"]), check_convergence=False,
+              l1W=float(g["l1W"]), l2W=float(g["l2W"]), l1H=float(g["l1H"]), l2H=float(g["l2H"]))
+    for fit in (oracle.fit_mult, oracle.c_fit_mult):
+        W, H, lh, _ = fit(g["data"], g["W0"], g["H0"], **kw)
+        np.testing.assert_allclose(lh, g["loss_hist"], rtol=1e-9)
+        np.testing.assert_allclose(W, g["W"], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(H, g["H"], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(oracle.tensor_conv(g["W0"], g["H0"]), g["conv0"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(oracle.tensor_transconv(g["W0"], g["data"]), g["transconv0"], rtol=1e-12, atol=1e-12)
