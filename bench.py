@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- MU iterations/sec of the MI355X hot path on BASELINE.json's config 2
+(N=2000, T=50000, K=32, L=20, fp32, alg=:mult), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full MU iteration (update_motifs! + update_feature_maps!, including the
+per-iteration loss scalar read-back; for N > 1 also the RCCL all-reduce of [numW|denomW], the
+H halo exchange and the loss all-reduce).  Inputs (data, W, H) are resident in HBM when the
+timed region starts.  For N > 1 the T axis of the SAME problem is sharded over the ranks
+("scaling": "strong").  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+CONFIGS = {
+    1: dict(N=500, T=2000, K=5, L=10),
+    2: dict(N=2000, T=50000, K=32, L=20),
+    3: dict(N=2000, T=400000, K=32, L=20),
+    4: dict(N=2000, T=50000, K=32, L=20, l1_H=0.1, l2_H=0.2, l1_W=0.1, l2_W=0.5),
+}
+
+
+def flops_per_iter(N, T, K, L):
+    S = L * T - L * (L - 1) / 2
+    return 14.0 * K * N * S  # 7 contractions x 2*K*N*S
+
+
+def cpu_baseline(data, W0, H0, budget_s):
+    """The oracle (numpy/OpenBLAS fp64, the reference's per-lag GEMM structure) timed on this
+    host's cores on a bounded sample: whole iterations at the bench workload until ~budget_s."""
+    import numpy as np
+    from oracle import cmf_oracle as oracle
+
+    cores = os.cpu_count() or 1
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas = [p for p in threadpool_info() if p.get("user_api") == "blas"]
+        if blas:
+            cores = int(blas[0].get("num_threads", cores))
+    except Exception:
+        pass
+    W = np.array(W0, dtype=np.float64, order="F", copy=True)
+    H = np.array(H0, dtype=np.float64, order="F", copy=True)
+    t0 = time.perf_counter()
+    rule = oracle.MultUpdate(data, W, H)
+    n = 0
+    t1 = time.perf_counter()
+    while True:
+        oracle.update_motifs(rule, data, W, H)
+        oracle.update_feature_maps(rule, data, W, H)
+        n += 1
+        el = time.perf_counter() - t1
+        if el + el / n > budget_s or n >= 3:
+            break
+    return dict(value=n / el, unit="iter/s", cores=cores, kind="port",
+                sample=f"{n} full MU iteration(s) (update_motifs!+update_feature_maps!) on the bench workload, "
+                       f"fp64 numpy/OpenBLAS per-lag dgemm as in the reference; {el:.1f} s "
+                       f"(+{t1 - t0:.1f} s rule setup)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--T", type=int, default=0, help="override T (debugging only; invalidates the metric)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import numpy as np
+
+    import __graft_entry__
+
+    if rank == 0:
+        __graft_entry__.build()
+    import cmf_jl_amd as cmf
+
+    cfg = dict(CONFIGS[args.config])
+    if args.T:
+        cfg["T"] = args.T
+    N, T, K, L = cfg["N"], cfg["T"], cfg["K"], cfg["L"]
+    reg = {k: v for k, v in cfg.items() if k.startswith("l")}
+    reg_kw = dict(l1W=reg.get("l1_W", 0.0), l2W=reg.get("l2_W", 0.0), l1H=reg.get("l1_H", 0.0), l2H=reg.get("l2_H", 0.0))
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    cmf.load_library()
+
+    # ---- synthetic inputs: gen_synthetic(seed 1234) + init_rand(seed 0), SURVEY.md section 8d ----
+    # Every rank generates the same arrays (counter-based RNG) and keeps its own T block.
+    data = cmf.gen_synthetic(N=N, T=T, seed=1234, device=local_rank)
+    W0, H0 = cmf.init_rand(data, L=L, K=K, seed=0, device=local_rank)
+
+    if world == 1:
+        rule = cmf.MultUpdate(data, W0, H0, device=local_rank)
+
+        def step():
+            rule.update_motifs(l1W=reg_kw["l1W"], l2W=reg_kw["l2W"])
+            return rule.update_feature_maps(l1H=reg_kw["l1H"], l2H=reg_kw["l2H"])
+
+        def sync():
+            pass  # update_feature_maps returns the loss: the stream is already drained
+    else:
+        from cmf_jl_amd.sharded import ShardedMultUpdate
+
+        rule = ShardedMultUpdate(data, W0, H0, device=local_rank)
+
+        def step():
+            rule.update_motifs(l1W=reg_kw["l1W"], l2W=reg_kw["l2W"])
+            return rule.update_feature_maps(l1H=reg_kw["l1H"], l2H=reg_kw["l2H"])
+
+        def sync():
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    loss0 = rule.compute_loss()
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    losses = []
+    for _ in range(args.steps):
+        losses.append(step())
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch
+
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    out = None
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        iters_per_s = args.steps / dt
+        F_iter = flops_per_iter(N, T, K, L)
+        out = {
+            "metric": "MU iterations/sec (convolutive NMF multiplicative update)",
+            "value": iters_per_s, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[{args.config - 1}]: N={N} T={T} K={K} L={L} fp32 alg=:mult"
+                                   + (" regularised " + json.dumps(reg) if reg else "")
+                                   + (f", T sharded over {world} GPUs, RCCL all-reduce on W" if world > 1 else " on 1xMI355X"),
+                       "N": N, "T": T, "K": K, "L": L, "parallelism": f"t-shard{world}",
+                       "gen_synthetic_seed": 1234, "init_rand_seed": 0,
+                       "loss_first": loss0, "loss_last": losses[-1] if losses else loss0},
+            "flops_per_iter": F_iter,
+            "whole_iteration_tflops": F_iter * iters_per_s / 1e12,
+            "whole_iteration_mfma_frac": F_iter * iters_per_s / (world * PEAK_FP32_MFMA_TFLOPS * 1e12),
+        }
+
+    # ---- roofline of the dominant kernel (conv: 3 of the 7 contractions), HIP events on the
+    # kernel's own stream, rank 0's shard ----
+    if world == 1 and rank == 0:
+        kern = {}
+        for name in ("conv", "conv_t", "conv_loss", "hxt", "transconv"):
+            kms, kfl = rule.time_kernel(name, reps=5)
+            kern[name] = {"avg_ms": kms, "tflops": kfl / kms / 1e9, "frac": kfl / kms / 1e9 / PEAK_FP32_MFMA_TFLOPS}
+        ach = kern["conv"]["tflops"]
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_kernel<0,16> (tensor_conv, est[t][n])",
+                           "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None}
+        out["kernels"] = kern
+
+    if rank == 0:
+        if args.cpu_seconds > 0:
+            try:
+                out["cpu_baseline"] = cpu_baseline(data, W0, H0, args.cpu_seconds)
+            except Exception as e:  # the baseline is a reported extra; never lose the GPU line for it
+                out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    rule.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

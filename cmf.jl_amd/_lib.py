@@ -1,0 +1,113 @@
+"""ctypes binding of libcmf_hip.so (include/cmf_hip.h), one Python function per C entry.
+
+This is the Python twin of the Julia ``ccall`` layer shown in INTEGRATION.md: the
+same symbols, the same argument order, Julia's column-major Float64 arrays
+(``order='F'`` here).  There is no fallback: if the shared library is missing or a
+call fails, a :class:`CMFError` is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcmf_hip.so")
+
+CMF_OK, CMF_ERR_ARG, CMF_ERR_HIP, CMF_ERR_STATE, CMF_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+
+# every symbol include/cmf_hip.h declares (tests check the library exports each one)
+SYMBOLS = [
+    "cmf_version", "cmf_last_error", "cmf_device_count",
+    "cmf_create", "cmf_create_shard", "cmf_destroy", "cmf_set_stream",
+    "cmf_get_data_sumsq", "cmf_set_data_norm",
+    "cmf_set_factors", "cmf_get_factors",
+    "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_fit", "cmf_converged",
+    "cmf_w_partial", "cmf_w_apply", "cmf_h_update", "cmf_loss_partial",
+    "cmf_numden_ptr", "cmf_halo_ptr", "cmf_halo_pack", "cmf_halo_unpack",
+    "cmf_tensor_conv", "cmf_tensor_transconv", "cmf_init_rand", "cmf_gen_synthetic",
+    "cmf_time_kernel",
+]
+
+
+class CMFError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcmf_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libcmf_hip.so; raises CMFError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CMFError(CMF_ERR_HIP, f"{LIB_PATH} not found: build it with `python cmf.jl_amd/build.py` "
+                                    "(the HIP path is the only implementation)")
+    lib = ctypes.CDLL(LIB_PATH)
+    i64, u64, dbl, cint = ctypes.c_int64, ctypes.c_uint64, ctypes.c_double, ctypes.c_int
+    pd, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
+    pvp, pi64 = ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)
+
+    def sig(name, argtypes, restype=cint):
+        f = getattr(lib, name)
+        f.argtypes = argtypes
+        f.restype = restype
+
+    sig("cmf_version", [], ctypes.c_char_p)
+    sig("cmf_last_error", [], ctypes.c_char_p)
+    sig("cmf_device_count", [])
+    sig("cmf_create", [pvp, cint, i64, i64, i64, i64, pd])
+    sig("cmf_create_shard", [pvp, cint, i64, i64, i64, i64, pd, i64, i64])
+    sig("cmf_destroy", [vp])
+    sig("cmf_set_stream", [vp, vp])
+    sig("cmf_get_data_sumsq", [vp, pd])
+    sig("cmf_set_data_norm", [vp, dbl])
+    sig("cmf_set_factors", [vp, pd, pd])
+    sig("cmf_get_factors", [vp, pd, pd])
+    sig("cmf_update_motifs", [vp, dbl, dbl])
+    sig("cmf_update_feature_maps", [vp, dbl, dbl, pd])
+    sig("cmf_compute_loss", [vp, pd])
+    sig("cmf_fit", [vp, i64, dbl, cint, i64, dbl, cint, dbl, dbl, dbl, dbl, pd, pd, pi64, ctypes.POINTER(cint)])
+    sig("cmf_converged", [pd, i64, i64, dbl])
+    sig("cmf_w_partial", [vp])
+    sig("cmf_w_apply", [vp, dbl, dbl])
+    sig("cmf_h_update", [vp, dbl, dbl])
+    sig("cmf_loss_partial", [vp, pd])
+    sig("cmf_numden_ptr", [vp, pvp, pi64])
+    sig("cmf_halo_ptr", [vp, cint, pvp, pi64])
+    sig("cmf_halo_pack", [vp])
+    sig("cmf_halo_unpack", [vp, cint, cint])
+    sig("cmf_tensor_conv", [cint, i64, i64, i64, i64, pd, pd, pd])
+    sig("cmf_tensor_transconv", [cint, i64, i64, i64, i64, pd, pd, pd])
+    sig("cmf_init_rand", [cint, i64, i64, i64, i64, u64, pd, pd, pd])
+    sig("cmf_gen_synthetic", [cint, i64, i64, i64, i64, dbl, dbl, dbl, dbl, u64, pd, pd, pd])
+    sig("cmf_time_kernel", [vp, ctypes.c_char_p, cint, pd, pd])
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != CMF_OK:
+        raise CMFError(rc, load().cmf_last_error().decode("utf-8", "replace"))
+
+
+def farr(a, shape=None):
+    """Float64, Fortran-contiguous (Julia memory order) view/copy of `a`."""
+    a = np.asarray(a)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def default_device():
+    """One process per GPU: LOCAL_RANK picks the device (0 when unset)."""
+    return int(os.environ.get("CMF_DEVICE", os.environ.get("LOCAL_RANK", "0")))

@@ -1,0 +1,798 @@
+// cmf_api.hip -- host side of libcmf_hip.so: the C ABI of include/cmf_hip.h over the gfx950
+// kernels in cmf_kernels.h.  No CPU fallback exists: every compute entry needs a HIP device.
+#include "cmf_hip.h"
+#include "cmf_kernels.h"
+#include "cmf_rng.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(CMF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define KCHK(name)                                                                                \
+    do {                                                                                          \
+        hipError_t e_ = hipGetLastError();                                                        \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(CMF_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_));     \
+    } while (0)
+#define CMFTRY(expr)              \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != CMF_OK) return rc_; \
+    } while (0)
+
+static inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------
+struct cmf_handle_s {
+    int device = 0;
+    CmfDims d{};
+    int64_t t_offset = 0, T_global = 0;
+    int halo_r = 0;       // data / H right halo columns actually present (0 on the last shard)
+    bool has_left = false; // a left neighbour exists (t_offset > 0)
+    bool sharded = false;
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    float *H = nullptr, *Ht = nullptr, *Wt = nullptr, *Wn = nullptr;
+    float *X = nullptr, *XT = nullptr, *est = nullptr, *estT = nullptr;
+    float *wslabs = nullptr; // [nchunks][2][L][K32][Np]
+    float *numden = nullptr; // [2][L][K32][Np]   (summed; the all-reduce buffer)
+    float *hslabs = nullptr; // [S][2][Tl][K32]
+    float *halo[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *partial = nullptr; // loss partials
+    double *d_scalar = nullptr; // device double[4]
+    double *h_scalar = nullptr; // pinned host double[4]
+    double *stage = nullptr;    // fp64 staging for layout conversion
+    size_t stage_elems = 0;
+
+    // launch plans
+    int hxt_LP = 1, hxt_groups = 1, hxt_nchunks = 1, hxt_chunk_len = 2;
+    int tc_LT = 4, tc_S = 1, tc_nr = 8;
+    int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
+
+    double data_sumsq = 0.0, data_norm = 0.0;
+    bool factors_set = false;
+    bool have_data = false;
+};
+
+static size_t n_partial(const cmf_handle_s *h) { return (size_t)h->conv_gx * (size_t)std::max(h->conv_gy, h->conv_gy_ext); }
+
+static int ensure_stage(cmf_handle_s *h, size_t elems)
+{
+    if (h->stage_elems >= elems) return CMF_OK;
+    if (h->stage) HIPCHK(hipFree(h->stage));
+    h->stage = nullptr;
+    h->stage_elems = 0;
+    HIPCHK(hipMalloc(&h->stage, elems * sizeof(double)));
+    h->stage_elems = elems;
+    return CMF_OK;
+}
+
+template <typename T>
+static int dalloc_zero(T **p, size_t n)
+{
+    HIPCHK(hipMalloc(p, n * sizeof(T)));
+    HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+    return CMF_OK;
+}
+
+static const int kHxtLP[] = {1, 2, 3, 4, 5, 6, 8}; // 2*LP*16 accumulator registers must fit the 256 AGPRs
+
+static void plan(cmf_handle_s *h, int n_cu)
+{
+    const CmfDims &d = h->d;
+    // C2 (hxt): lags per launch group = 2*LP; pick the LP that wastes the fewest padded lags
+    int best = 1;
+    int64_t bestP = 1 << 30;
+    for (int lp : kHxtLP) {
+        int64_t P = rup(d.L, 2 * lp);
+        if (P < bestP || (P == bestP && lp > best)) { bestP = P; best = lp; }
+    }
+    h->hxt_LP = best;
+    h->hxt_groups = (int)(bestP / (2 * best));
+    const int wave_slots = 4 * n_cu * (best <= 5 ? 2 : 1); // resident waves (register-limited)
+    int64_t waves_per_chunk = (int64_t)(d.Np / 32) * 2 * d.KB * h->hxt_groups;
+    int nch = (int)std::max<int64_t>(1, (wave_slots + waves_per_chunk / 2) / waves_per_chunk);
+    int64_t clen = rup((d.Tl + nch - 1) / nch, 2 * best);
+    h->hxt_chunk_len = (int)clen;
+    h->hxt_nchunks = (int)((d.Tl + clen - 1) / clen);
+    // C3 (transconv): S n-ranges so that (t tiles) x 2 x KB x S ~ 2 workgroups per CU x 2 rounds
+    h->tc_LT = d.L <= 32 ? (int)rup(d.L, 4) : 32;
+    int64_t base = (int64_t)((d.Tl + 511) / 512) * 2 * d.KB;
+    int64_t n8 = rup(d.N, 8);
+    int S = (int)std::max<int64_t>(1, (4 * n_cu) / base);
+    S = (int)std::min<int64_t>(S, n8 / 8);
+    h->tc_nr = (int)rup((n8 + S - 1) / S, 8);
+    h->tc_S = (int)((n8 + h->tc_nr - 1) / h->tc_nr);
+    // C1 (conv)
+    h->conv_gx = d.Np / 128;
+    h->conv_gy = (d.Tl + 127) / 128;
+    h->conv_gy_ext = (d.Tl + h->halo_r + 127) / 128;
+}
+
+static void destroy_impl(cmf_handle_s *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden, h->hslabs,
+                      h->halo[0], h->halo[1], h->halo[2], h->halo[3]};
+    for (float *p : fbufs)
+        if (p) (void)hipFree(p);
+    if (h->partial) (void)hipFree(h->partial);
+    if (h->d_scalar) (void)hipFree(h->d_scalar);
+    if (h->h_scalar) (void)hipHostFree(h->h_scalar);
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+// upload `ncols` columns (fp64, N x ncols column-major) starting at local column tc
+static int upload_cols(cmf_handle_s *h, const double *src, int64_t tc, int64_t ncols, bool rows_layout, bool accumulate_sumsq)
+{
+    const CmfDims &d = h->d;
+    const int64_t chunk = std::max<int64_t>(32, (int64_t)(32u << 20) / std::max<int64_t>(1, d.N) / 8 / 32 * 32); // ~32 MiB
+    CMFTRY(ensure_stage(h, (size_t)std::min(chunk, rup(ncols, 32)) * d.N + 1024));
+    for (int64_t c0 = 0; c0 < ncols; c0 += chunk) {
+        int64_t nc = std::min(chunk, ncols - c0);
+        HIPCHK(hipMemcpyAsync(h->stage, src + (size_t)c0 * d.N, (size_t)nc * d.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        dim3 grid((d.N + 31) / 32, (unsigned)((nc + 31) / 32)), block(32, 8);
+        hipLaunchKernelGGL(pack_cols_kernel, grid, block, 0, h->stream, h->stage, d.N, (int)(tc + c0), (int)nc,
+                           rows_layout ? h->X : nullptr, h->XT, d.Np, d.TP, d.PADL);
+        KCHK("pack_cols_kernel");
+        if (accumulate_sumsq) {
+            double *acc = h->stage + (size_t)nc * d.N; // 256 spare doubles
+            hipLaunchKernelGGL(sumsq_f64_kernel, dim3(256), dim3(256), 0, h->stream, h->stage, (size_t)nc * d.N, acc);
+            KCHK("sumsq_f64_kernel");
+            std::vector<double> part(256);
+            HIPCHK(hipMemcpyAsync(part.data(), acc, 256 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (double v : part) h->data_sumsq += v;
+        } else {
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+    }
+    return CMF_OK;
+}
+
+static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64_t K, int64_t L,
+                       const double *data, int64_t t_offset, int64_t T_global, bool sharded)
+{
+    if (!out) return fail(CMF_ERR_ARG, "handle pointer is NULL");
+    *out = nullptr;
+    if (N < 1 || Tl < 1 || K < 1 || L < 1) return fail(CMF_ERR_ARG, "N, T, K, L must all be >= 1 (got N=%lld T=%lld K=%lld L=%lld)",
+                                                       (long long)N, (long long)Tl, (long long)K, (long long)L);
+    if (t_offset < 0 || t_offset + Tl > T_global) return fail(CMF_ERR_ARG, "shard [%lld, %lld) is outside [0, %lld)",
+                                                               (long long)t_offset, (long long)(t_offset + Tl), (long long)T_global);
+    if (N > (1 << 24) || Tl > (1 << 28) || K > 4096 || L > 4096) return fail(CMF_ERR_UNSUPPORTED, "problem size out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(CMF_ERR_HIP, "no HIP device available (libcmf_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(CMF_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+
+    cmf_handle_s *h = new cmf_handle_s();
+    h->device = device;
+    h->t_offset = t_offset;
+    h->T_global = T_global;
+    h->sharded = sharded;
+    h->has_left = t_offset > 0;
+    h->halo_r = (int)std::min<int64_t>(L - 1, T_global - t_offset - Tl);
+    CmfDims &d = h->d;
+    d.N = (int)N; d.Tl = (int)Tl; d.K = (int)K; d.L = (int)L;
+    d.Np = (int)rup(N, 128);
+    d.KB = (int)((K + 31) / 32);
+    d.K32 = 32 * d.KB;
+    d.PADL = (int)rup(L - 1, 32) + 32;
+    d.TP = d.PADL + (int)rup(Tl + L, 512) + 256;
+    d.Lp = L <= 32 ? (int)rup(L, 4) : (int)rup(L, 32);
+    plan(h, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+
+    auto bail = [&](int rc) { destroy_impl(h); return rc; };
+#define TRYB(expr) do { int rc__ = (expr); if (rc__ != CMF_OK) return bail(rc__); } while (0)
+#define HIPB(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(fail(CMF_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__))); } while (0)
+    HIPB(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    HIPB(hipEventCreate(&h->ev0));
+    HIPB(hipEventCreate(&h->ev1));
+    const size_t TPNp = (size_t)d.TP * d.Np;
+    TRYB(dalloc_zero(&h->H, (size_t)d.TP * d.K32));
+    TRYB(dalloc_zero(&h->Ht, (size_t)d.K32 * d.TP));
+    TRYB(dalloc_zero(&h->Wt, (size_t)d.Lp * d.K32 * d.Np));
+    TRYB(dalloc_zero(&h->Wn, (size_t)d.Lp * d.Np * d.K32));
+    TRYB(dalloc_zero(&h->X, TPNp));
+    TRYB(dalloc_zero(&h->XT, TPNp));
+    TRYB(dalloc_zero(&h->est, TPNp));
+    TRYB(dalloc_zero(&h->estT, TPNp));
+    TRYB(dalloc_zero(&h->wslabs, (size_t)h->hxt_nchunks * 2 * d.L * d.K32 * d.Np));
+    TRYB(dalloc_zero(&h->numden, (size_t)2 * d.L * d.K32 * d.Np));
+    TRYB(dalloc_zero(&h->hslabs, (size_t)h->tc_S * 2 * d.Tl * d.K32));
+    for (int w = 0; w < 4; ++w) TRYB(dalloc_zero(&h->halo[w], (size_t)std::max(1, d.L - 1) * d.K32));
+    TRYB(dalloc_zero(&h->partial, n_partial(h)));
+    TRYB(dalloc_zero(&h->d_scalar, 4));
+    HIPB(hipHostMalloc(&h->h_scalar, 4 * sizeof(double)));
+    if (data) {
+        TRYB(upload_cols(h, data, 0, Tl, true, true));
+        if (h->halo_r > 0) TRYB(upload_cols(h, data + (size_t)Tl * N, Tl, h->halo_r, false, false));
+        h->data_norm = std::sqrt(h->data_sumsq);
+        h->have_data = true;
+    }
+#undef TRYB
+#undef HIPB
+    *out = h;
+    return CMF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel launchers
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy)
+{
+    const CmfDims &d = h->d;
+    ConvParams p;
+    p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = h->X; p.partial = h->partial;
+    p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = T_store;
+    dim3 grid(h->conv_gx, gy), block(256);
+    if (d.K % 32 == 0) hipLaunchKernelGGL((conv_kernel<MODE, 16>), grid, block, 0, h->stream, p);
+    else hipLaunchKernelGGL((conv_kernel<MODE, 0>), grid, block, 0, h->stream, p);
+    KCHK("conv_kernel");
+    return CMF_OK;
+}
+
+static int launch_hxt(cmf_handle_s *h)
+{
+    const CmfDims &d = h->d;
+    HxtParams p;
+    p.H = h->H; p.X0 = h->X; p.X1 = h->est; p.slabs = h->wslabs;
+    p.Np = d.Np; p.K32 = d.K32; p.KB = d.KB; p.PADL = d.PADL; p.L = d.L; p.Tl = d.Tl; p.chunk_len = h->hxt_chunk_len;
+    p.G = h->hxt_groups;
+    dim3 grid((d.Np / 128) * h->hxt_groups, h->hxt_nchunks, 2 * d.KB), block(256);
+    switch (h->hxt_LP) {
+#define CASE(LP_) case LP_: hipLaunchKernelGGL((hxt_kernel<LP_>), grid, block, 0, h->stream, p); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(8)
+#undef CASE
+    default: return fail(CMF_ERR_STATE, "internal: bad hxt LP %d", h->hxt_LP);
+    }
+    KCHK("hxt_kernel");
+    return CMF_OK;
+}
+
+static int launch_transconv(cmf_handle_s *h, int nsrc)
+{
+    const CmfDims &d = h->d;
+    TcParams p;
+    p.Wn = h->Wn; p.XT0 = h->XT; p.XT1 = h->estT; p.slabs = h->hslabs;
+    p.NpW = d.Np;
+    p.Nlim = (int)rup(d.N, 8); // rows >= N are zero: stop at the last 8-row chunk that holds data
+    p.TP = d.TP; p.PADL = d.PADL; p.K32 = d.K32; p.KB = d.KB; p.L = d.L; p.Tl = d.Tl;
+    p.nr = h->tc_nr; p.nsrc = nsrc;
+    dim3 grid((d.Tl + 511) / 512, h->tc_S, nsrc * d.KB), block(256);
+    switch (h->tc_LT) {
+#define CASE(LT_) case LT_: hipLaunchKernelGGL((transconv_kernel<LT_>), grid, block, 0, h->stream, p); break;
+        CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
+#undef CASE
+    default: return fail(CMF_ERR_STATE, "internal: bad transconv LT %d", h->tc_LT);
+    }
+    KCHK("transconv_kernel");
+    return CMF_OK;
+}
+
+static int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nslabs, size_t stride)
+{
+    size_t n4 = stride / 4;
+    int blocks = (int)std::min<size_t>(2048, (n4 + 255) / 256);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, h->stream, out, in, nslabs, stride, n4);
+    KCHK("slab_sum_kernel");
+    return CMF_OK;
+}
+
+static int read_scalar(cmf_handle_s *h, int slot, double *v)
+{
+    HIPCHK(hipMemcpyAsync(h->h_scalar + slot, h->d_scalar + slot, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *v = h->h_scalar[slot];
+    return CMF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// phases
+// ------------------------------------------------------------------------------------------
+static int check_ready(cmf_handle_s *h, bool need_data)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->factors_set) return fail(CMF_ERR_STATE, "factors not set: call cmf_set_factors first");
+    if (need_data && !h->have_data) return fail(CMF_ERR_STATE, "handle was created without data");
+    return CMF_OK;
+}
+
+static int w_partial_impl(cmf_handle_s *h)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy));   // mult.jl:28
+    CMFTRY(launch_hxt(h));                                  // mult.jl:31-34
+    return launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks, (size_t)2 * d.L * d.K32 * d.Np);
+}
+
+static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W)
+{
+    const CmfDims &d = h->d;
+    dim3 grid(d.Np / 64, d.KB, d.L);
+    hipLaunchKernelGGL(w_update_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden, 1,
+                       d.N, d.K, d.L, d.Np, d.K32, (float)l1W, (float)(2.0 * l2W)); // mult.jl:37-38
+    KCHK("w_update_kernel");
+    return CMF_OK;
+}
+
+static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext)); // mult.jl:44 (est with the new W)
+    CMFTRY(launch_transconv(h, 2));                                         // mult.jl:47-48
+    dim3 grid((d.Tl + 63) / 64, d.KB);
+    hipLaunchKernelGGL(h_update_kernel, grid, dim3(256), 0, h->stream, h->H, h->Ht, h->hslabs, h->tc_S,
+                       d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
+    KCHK("h_update_kernel");
+    return CMF_OK;
+}
+
+static int loss_partial_impl(cmf_handle_s *h, double *sumsq)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(launch_conv<2>(h, nullptr, d.Tl, h->conv_gy)); // mult.jl:55-57
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_gx * h->conv_gy, h->d_scalar);
+    KCHK("loss_reduce_kernel");
+    return read_scalar(h, 0, sumsq);
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *cmf_version(void) { return "cmf_hip gfx950 0.1.0"; }
+const char *cmf_last_error(void) { return g_err.c_str(); }
+
+int cmf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cmf_create(cmf_handle *h, int device, int64_t N, int64_t T, int64_t K, int64_t L, const double *data)
+{
+    if (!data) return fail(CMF_ERR_ARG, "data is NULL");
+    return create_impl(h, device, N, T, K, L, data, 0, T, false);
+}
+
+int cmf_create_shard(cmf_handle *h, int device, int64_t N, int64_t T_local, int64_t K, int64_t L,
+                     const double *data_local, int64_t t_offset, int64_t T_global)
+{
+    if (!data_local) return fail(CMF_ERR_ARG, "data_local is NULL");
+    if (T_local < L - 1 && T_local != T_global)
+        return fail(CMF_ERR_UNSUPPORTED, "a shard must hold at least L-1 = %lld columns (got %lld)", (long long)(L - 1), (long long)T_local);
+    return create_impl(h, device, N, T_local, K, L, data_local, t_offset, T_global, true);
+}
+
+int cmf_destroy(cmf_handle h)
+{
+    destroy_impl(h);
+    return CMF_OK;
+}
+
+int cmf_set_stream(cmf_handle h, void *hip_stream)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return CMF_OK;
+}
+
+int cmf_get_data_sumsq(cmf_handle h, double *sumsq)
+{
+    if (!h || !sumsq) return fail(CMF_ERR_ARG, "NULL argument");
+    *sumsq = h->data_sumsq;
+    return CMF_OK;
+}
+
+int cmf_set_data_norm(cmf_handle h, double data_norm)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (!(data_norm >= 0.0)) return fail(CMF_ERR_ARG, "data_norm must be >= 0");
+    h->data_norm = data_norm;
+    return CMF_OK;
+}
+
+int cmf_set_factors(cmf_handle h, const double *W, const double *H)
+{
+    if (!h || !W || !H) return fail(CMF_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    const CmfDims &d = h->d;
+    const size_t nW = (size_t)d.L * d.N * d.K, nH = (size_t)d.Tl * d.K;
+    CMFTRY(ensure_stage(h, std::max(nW, nH)));
+    // padding must be zero: clear, then scatter the valid entries
+    HIPCHK(hipMemsetAsync(h->Wt, 0, (size_t)d.Lp * d.K32 * d.Np * sizeof(float), h->stream));
+    HIPCHK(hipMemsetAsync(h->Wn, 0, (size_t)d.Lp * d.Np * d.K32 * sizeof(float), h->stream));
+    HIPCHK(hipMemsetAsync(h->H, 0, (size_t)d.TP * d.K32 * sizeof(float), h->stream));
+    HIPCHK(hipMemsetAsync(h->Ht, 0, (size_t)d.K32 * d.TP * sizeof(float), h->stream));
+    HIPCHK(hipMemcpyAsync(h->stage, W, nW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(pack_W_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.N, d.K, d.L, h->Wt, h->Wn, d.Np, d.K32);
+    KCHK("pack_W_kernel");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(h->stage, H, nH * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(pack_H_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.Tl, d.K, h->H, h->Ht, d.K32, d.TP, d.PADL);
+    KCHK("pack_H_kernel");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->factors_set = true;
+    return CMF_OK;
+}
+
+int cmf_get_factors(cmf_handle h, double *W, double *H)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    CMFTRY(check_ready(h, false));
+    const CmfDims &d = h->d;
+    const size_t nW = (size_t)d.L * d.N * d.K, nH = (size_t)d.Tl * d.K;
+    CMFTRY(ensure_stage(h, std::max(nW, nH)));
+    if (W) {
+        hipLaunchKernelGGL(unpack_W_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.N, d.K, d.L, h->Wn, d.Np, d.K32);
+        KCHK("unpack_W_kernel");
+        HIPCHK(hipMemcpyAsync(W, h->stage, nW * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (H) {
+        hipLaunchKernelGGL(unpack_H_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.Tl, d.K, h->H, d.K32, d.PADL);
+        KCHK("unpack_H_kernel");
+        HIPCHK(hipMemcpyAsync(H, h->stage, nH * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return CMF_OK;
+}
+
+int cmf_w_partial(cmf_handle h)
+{
+    CMFTRY(check_ready(h, true));
+    return w_partial_impl(h);
+}
+
+int cmf_w_apply(cmf_handle h, double l1W, double l2W)
+{
+    CMFTRY(check_ready(h, true));
+    return w_apply_impl(h, l1W, l2W);
+}
+
+int cmf_h_update(cmf_handle h, double l1H, double l2H)
+{
+    CMFTRY(check_ready(h, true));
+    return h_update_impl(h, l1H, l2H);
+}
+
+int cmf_loss_partial(cmf_handle h, double *sumsq)
+{
+    if (!sumsq) return fail(CMF_ERR_ARG, "sumsq is NULL");
+    CMFTRY(check_ready(h, true));
+    return loss_partial_impl(h, sumsq);
+}
+
+int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
+{
+    CMFTRY(check_ready(h, true));
+    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: use the phase-split entries");
+    CMFTRY(w_partial_impl(h));
+    return w_apply_impl(h, l1W, l2W);
+}
+
+int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
+{
+    if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
+    CMFTRY(check_ready(h, true));
+    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: use the phase-split entries");
+    CMFTRY(h_update_impl(h, l1H, l2H));
+    double ss = 0.0;
+    CMFTRY(loss_partial_impl(h, &ss));
+    *loss = std::sqrt(ss) / h->data_norm;
+    return CMF_OK;
+}
+
+int cmf_compute_loss(cmf_handle h, double *loss)
+{
+    if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
+    CMFTRY(check_ready(h, true));
+    double ss = 0.0;
+    CMFTRY(loss_partial_impl(h, &ss));
+    *loss = std::sqrt(ss) / h->data_norm;
+    return CMF_OK;
+}
+
+int cmf_converged(const double *loss_hist, int64_t len, int64_t patience, double tol)
+{
+    // src/model.jl:91-107
+    if (!loss_hist || len <= patience) return 0;
+    for (int64_t i = len - patience; i < len; ++i)
+        if (!(std::fabs(loss_hist[i] - loss_hist[i - 1]) < tol)) return 0;
+    return 1;
+}
+
+int cmf_fit(cmf_handle h, int64_t max_itr, double max_time, int check_convergence, int64_t patience, double tol,
+            int eval_mode, double l1W, double l2W, double l1H, double l2H,
+            double *loss_hist, double *time_hist, int64_t *n_hist, int *converged_early)
+{
+    if (!loss_hist || !time_hist || !n_hist) return fail(CMF_ERR_ARG, "NULL output argument");
+    if (patience < 1) return fail(CMF_ERR_ARG, "patience must be >= 1 (alternating.jl:30)");
+    if (max_itr < 0) return fail(CMF_ERR_ARG, "max_itr must be >= 0");
+    CMFTRY(check_ready(h, true));
+    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "cmf_fit needs an unsharded handle");
+    if (converged_early) *converged_early = 0;
+    int64_t len = 0;
+    CMFTRY(cmf_compute_loss(h, &loss_hist[0])); // alternating.jl:37
+    time_hist[0] = 0.0;                        // :38
+    len = 1;
+    int64_t itr = 1;
+    while (itr <= max_itr && time_hist[len - 1] <= max_time) { // :45
+        itr += 1;
+        auto t0 = std::chrono::steady_clock::now();
+        if (!eval_mode) CMFTRY(cmf_update_motifs(h, l1W, l2W));          // :51-53
+        double loss = 0.0;
+        CMFTRY(cmf_update_feature_maps(h, l1H, l2H, &loss));              // :54
+        double dur = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        time_hist[len] = time_hist[len - 1] + dur;                        // :58
+        loss_hist[len] = loss;                                            // :59
+        ++len;
+        if (check_convergence && cmf_converged(loss_hist, len, patience, tol)) { // :63-66
+            if (converged_early) *converged_early = 1;
+            break;
+        }
+    }
+    *n_hist = len;
+    return CMF_OK;
+}
+
+int cmf_numden_ptr(cmf_handle h, void **dev_ptr, int64_t *count)
+{
+    if (!h || !dev_ptr || !count) return fail(CMF_ERR_ARG, "NULL argument");
+    *dev_ptr = h->numden;
+    *count = (int64_t)2 * h->d.L * h->d.K32 * h->d.Np;
+    return CMF_OK;
+}
+
+int cmf_halo_ptr(cmf_handle h, int which, void **dev_ptr, int64_t *count)
+{
+    if (!h || !dev_ptr || !count) return fail(CMF_ERR_ARG, "NULL argument");
+    if (which < 0 || which > 3) return fail(CMF_ERR_ARG, "which must be 0..3");
+    *dev_ptr = h->halo[which];
+    *count = (int64_t)(h->d.L - 1) * h->d.K32;
+    return CMF_OK;
+}
+
+int cmf_halo_pack(cmf_handle h)
+{
+    CMFTRY(check_ready(h, false));
+    const CmfDims &d = h->d;
+    const int rows = d.L - 1;
+    if (rows < 1) return CMF_OK;
+    hipLaunchKernelGGL(halo_copy_kernel, dim3(64), dim3(256), 0, h->stream, h->H, h->Ht, h->halo[0], d.PADL, rows, d.K32, d.TP, 0);
+    KCHK("halo_copy_kernel");
+    hipLaunchKernelGGL(halo_copy_kernel, dim3(64), dim3(256), 0, h->stream, h->H, h->Ht, h->halo[1], d.PADL + d.Tl - rows, rows, d.K32, d.TP, 0);
+    KCHK("halo_copy_kernel");
+    return CMF_OK;
+}
+
+int cmf_halo_unpack(cmf_handle h, int has_left, int has_right)
+{
+    CMFTRY(check_ready(h, false));
+    const CmfDims &d = h->d;
+    const int rows = d.L - 1;
+    if (rows < 1) return CMF_OK;
+    if (has_left) {
+        hipLaunchKernelGGL(halo_copy_kernel, dim3(64), dim3(256), 0, h->stream, h->H, h->Ht, h->halo[2], d.PADL - rows, rows, d.K32, d.TP, 1);
+        KCHK("halo_copy_kernel");
+    }
+    if (has_right) {
+        hipLaunchKernelGGL(halo_copy_kernel, dim3(64), dim3(256), 0, h->stream, h->H, h->Ht, h->halo[3], d.PADL + d.Tl, rows, d.K32, d.TP, 1);
+        KCHK("halo_copy_kernel");
+    }
+    return CMF_OK;
+}
+
+// ---- stand-alone primitives ----------------------------------------------------------------
+static int download_rows(cmf_handle_s *h, double *out, const float *buf, int row0, int64_t nrows, int width, int stride)
+{
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)(32u << 20) / 8 / std::max(1, width));
+    CMFTRY(ensure_stage(h, (size_t)std::min(chunk, nrows) * width));
+    for (int64_t c0 = 0; c0 < nrows; c0 += chunk) {
+        int64_t nc = std::min(chunk, nrows - c0);
+        hipLaunchKernelGGL(unpack_rows_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, buf, row0, (int)c0, (int)nc, width, stride);
+        KCHK("unpack_rows_kernel");
+        HIPCHK(hipMemcpyAsync(out + (size_t)c0 * width, h->stage, (size_t)nc * width * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return CMF_OK;
+}
+
+int cmf_tensor_conv(int device, int64_t N, int64_t T, int64_t K, int64_t L, const double *W, const double *H, double *est)
+{
+    if (!W || !H || !est) return fail(CMF_ERR_ARG, "NULL argument");
+    cmf_handle h = nullptr;
+    CMFTRY(create_impl(&h, device, N, T, K, L, nullptr, 0, T, false));
+    int rc = cmf_set_factors(h, W, H);
+    if (rc == CMF_OK) rc = launch_conv<0>(h, h->est, h->d.Tl, h->conv_gy);
+    if (rc == CMF_OK) rc = download_rows(h, est, h->est, h->d.PADL, T, (int)N, h->d.Np);
+    destroy_impl(h);
+    return rc;
+}
+
+int cmf_tensor_transconv(int device, int64_t N, int64_t T, int64_t K, int64_t L, const double *W, const double *X, double *out)
+{
+    if (!W || !X || !out) return fail(CMF_ERR_ARG, "NULL argument");
+    cmf_handle h = nullptr;
+    CMFTRY(create_impl(&h, device, N, T, K, L, X, 0, T, false));
+    std::vector<double> H0((size_t)K * T, 0.0);
+    int rc = cmf_set_factors(h, W, H0.data());
+    if (rc == CMF_OK) rc = launch_transconv(h, 1);
+    // sum the S n-range slabs ([S][1][Tl][K32])
+    float *sum = nullptr;
+    if (rc == CMF_OK && hipMalloc(&sum, (size_t)h->d.Tl * h->d.K32 * sizeof(float)) != hipSuccess)
+        rc = fail(CMF_ERR_HIP, "hipMalloc failed in cmf_tensor_transconv");
+    if (rc == CMF_OK) rc = launch_slab_sum(h, sum, h->hslabs, h->tc_S, (size_t)h->d.Tl * h->d.K32);
+    if (rc == CMF_OK) rc = download_rows(h, out, sum, 0, T, (int)K, h->d.K32);
+    if (sum) (void)hipFree(sum);
+    destroy_impl(h);
+    return rc;
+}
+
+// ---- init_rand / gen_synthetic -----------------------------------------------------------------
+static void parallel_for(size_t n, const std::function<void(size_t, size_t)> &fn)
+{
+    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if (n < (1u << 16)) nt = 1;
+    std::vector<std::thread> th;
+    size_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        size_t a = t * per, b = std::min(n, a + per);
+        if (a >= b) break;
+        th.emplace_back(fn, a, b);
+    }
+    for (auto &x : th) x.join();
+}
+
+int cmf_init_rand(int device, int64_t N, int64_t T, int64_t K, int64_t L, uint64_t seed, const double *data, double *W, double *H)
+{
+    // src/model.jl:113-125
+    if (!data || !W || !H) return fail(CMF_ERR_ARG, "NULL argument");
+    if (N < 1 || T < 1 || K < 1 || L < 1) return fail(CMF_ERR_ARG, "N, T, K, L must all be >= 1");
+    const size_t nW = (size_t)K * N * L, nH = (size_t)K * T, NT = (size_t)N * T;
+    const uint64_t bW = cmfrng::base(seed, 0), bH = cmfrng::base(seed, 1);
+    for (size_t i = 0; i < nW; ++i) W[i] = cmfrng::u01(bW, i); // :116 rand(K, N, L)
+    for (size_t i = 0; i < nH; ++i) H[i] = cmfrng::u01(bH, i); // :117 rand(K, T)
+    std::vector<double> est(NT);
+    CMFTRY(cmf_tensor_conv(device, N, T, K, L, W, H, est.data())); // :119
+    std::vector<double> pd(64, 0.0), pn(64, 0.0);
+    {   // :120 alpha = <data, est> / norm(est)^2
+        const size_t per = (NT + 63) / 64;
+        parallel_for(64, [&](size_t a, size_t b) {
+            for (size_t c = a; c < b; ++c) {
+                double sd = 0.0, sn = 0.0;
+                for (size_t i = c * per; i < std::min(NT, (c + 1) * per); ++i) { sd += data[i] * est[i]; sn += est[i] * est[i]; }
+                pd[c] = sd; pn[c] = sn;
+            }
+        });
+    }
+    double dot = 0.0, nn = 0.0;
+    for (int c = 0; c < 64; ++c) { dot += pd[c]; nn += pn[c]; }
+    const double s = std::sqrt(std::fabs(dot / nn)); // :121-122
+    for (size_t i = 0; i < nW; ++i) W[i] *= s;
+    for (size_t i = 0; i < nH; ++i) H[i] *= s;
+    return CMF_OK;
+}
+
+int cmf_gen_synthetic(int device, int64_t N, int64_t T, int64_t K, int64_t L, double alpha, double p_h, double sigma,
+                      double noise_scale, uint64_t seed, double *data, double *Wout, double *Hout)
+{
+    // datasets/synthetic.jl:29-61
+    if (!data) return fail(CMF_ERR_ARG, "data is NULL");
+    if (N < 1 || T < 1 || K < 1 || L < 1) return fail(CMF_ERR_ARG, "N, T, K, L must all be >= 1");
+    if (!(alpha > 0.0) || !(sigma > 0.0)) return fail(CMF_ERR_ARG, "alpha and sigma must be > 0");
+    const uint64_t bga = cmfrng::base(seed, 10), bgb = cmfrng::base(seed, 11), bgu = cmfrng::base(seed, 12);
+    const uint64_t bc = cmfrng::base(seed, 13), be = cmfrng::base(seed, 14), bb = cmfrng::base(seed, 15);
+    const uint64_t bna = cmfrng::base(seed, 16), bnb = cmfrng::base(seed, 17);
+    std::vector<double> W((size_t)K * N * L), H((size_t)K * T), mW((size_t)N * K);
+    for (int64_t n = 0; n < N; ++n) { // :42 Dirichlet(alpha) rows
+        double s = 0.0;
+        for (int64_t k = 0; k < K; ++k) { double g = cmfrng::gamma(bga, bgb, bgu, (uint64_t)(n * K + k), alpha); mW[n * K + k] = g; s += g; }
+        if (!(s > 0.0)) { for (int64_t k = 0; k < K; ++k) mW[n * K + k] = (k == n % K) ? 1.0 : 0.0; s = 1.0; }
+        for (int64_t k = 0; k < K; ++k) mW[n * K + k] /= s;
+    }
+    const double inv_s2pi = 0.39894228040143267793994605993438;
+    for (int64_t k = 0; k < K; ++k) // :47-51 Gaussian bump at a random lag
+        for (int64_t n = 0; n < N; ++n) {
+            const double cent = -1.0 + 2.0 * cmfrng::u01(bc, (uint64_t)(k + K * n));
+            for (int64_t l = 0; l < L; ++l) {
+                const double x = (L > 1) ? (-1.0 + 2.0 * (double)l / (double)(L - 1)) : -1.0;
+                const double z = (x - cent) / sigma;
+                W[k + K * (n + N * l)] = mW[n * K + k] * (inv_s2pi / sigma) * std::exp(-0.5 * z * z);
+            }
+        }
+    for (size_t i = 0; i < (size_t)K * T; ++i) { // :54
+        const double e = -std::log(cmfrng::u01o(be, i));
+        H[i] = (cmfrng::u01(bb, i) < p_h) ? e : 0.0;
+    }
+    CMFTRY(cmf_tensor_conv(device, N, T, K, L, W.data(), H.data(), data)); // :58 (fp32 on the device)
+    parallel_for((size_t)N * T, [&](size_t a, size_t b) {                  // :57-58
+        for (size_t i = a; i < b; ++i) {
+            const double v = data[i] + noise_scale * cmfrng::normal(bna, bnb, i);
+            data[i] = v > 0.0 ? v : 0.0;
+        }
+    });
+    if (Wout) std::memcpy(Wout, W.data(), W.size() * sizeof(double));
+    if (Hout) std::memcpy(Hout, H.data(), H.size() * sizeof(double));
+    return CMF_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------
+int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, double *flops)
+{
+    if (!name || !avg_ms || !flops || reps < 1) return fail(CMF_ERR_ARG, "bad argument");
+    CMFTRY(check_ready(h, true));
+    const CmfDims &d = h->d;
+    const double S = (double)d.L * d.Tl - 0.5 * (double)d.L * (d.L - 1);
+    const double f1 = 2.0 * d.K * d.N * S; // one contraction
+    std::string nm(name);
+    int which = nm == "conv" ? 0 : nm == "hxt" ? 1 : nm == "transconv" ? 2 : nm == "conv_t" ? 3 : nm == "conv_loss" ? 4 : -1;
+    if (which < 0) return fail(CMF_ERR_ARG, "unknown kernel '%s'", name);
+    auto run = [&]() -> int {
+        switch (which) {
+        case 0: return launch_conv<0>(h, h->est, d.Tl, h->conv_gy);
+        case 1: return launch_hxt(h);
+        case 2: return launch_transconv(h, 2);
+        case 3: return launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext);
+        default: return launch_conv<2>(h, nullptr, d.Tl, h->conv_gy);
+        }
+    };
+    CMFTRY(run()); // warm-up
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int r = 0; r < reps; ++r) CMFTRY(run());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *avg_ms = (double)ms / reps;
+    *flops = (which == 1 || which == 2) ? 2.0 * f1 : f1;
+    return CMF_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,677 @@
+// cmf_kernels.h -- hand-written gfx950 (CDNA4, wave64) kernels of the MU hot path.
+//
+// Device layouts (all fp32; r = PADL + t is the padded time row):
+//   H   [TP][K32]        H[t][k]      (Julia's K x T memory order, padded)      primary
+//   Ht  [K32][TP]        H^T                                                     copy for conv
+//   Wt  [Lp][K32][Np]    W[l][k][n]   (n fastest)                                primary
+//   Wn  [Lp][Np][K32]    W[l][n][k]   (Julia's K x N x L memory order, padded)   copy for transconv
+//   X   [TP][Np]         data[t][n]   (Julia's N x T memory order, padded)
+//   XT  [Np][TP]         data^T
+//   est [TP][Np] / estT [Np][TP]      same shapes as X / XT
+// All padding (k >= K, n >= N, rows outside [PADL, PADL+Tl) except halos) is zero and is
+// kept zero by every kernel, so the MFMA loops need no bounds checks.
+//
+// The three contractions of the reference are each one kernel built on
+// v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles per SIMD):
+//   conv_kernel       C1  est[t][n]   = sum_{l,k} H[t-l][k] W[l][k][n]   (common.jl:24-34)
+//   hxt_kernel        C2  out[l][k][n]= sum_t H[t-l][k] X[t][n]          (mult.jl:31-34)
+//   transconv_kernel  C3  out[t][k]   = sum_{l,n} X[t+l][n] W[l][n][k]   (common.jl:71-81)
+// MFMA operand maps (32x32x2 f32): lane = 32*h + i.  A: A[row i][kk h], B: B[kk h][col i],
+// C/D: col = i, row = (reg&3) + 8*(reg>>2) + 4*h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CMF_EPS_F 2.220446049250313e-16f
+
+struct CmfDims {
+    int N, Tl, K, L;
+    int Np;   // roundup(N, 128)
+    int KB;   // ceil(K / 32)
+    int K32;  // 32 * KB
+    int PADL; // roundup(L-1, 32) + 32   left time padding (halo + slack)
+    int TP;   // PADL + roundup(Tl, 512) + 256   padded time rows
+    int Lp;   // lags allocated in Wt/Wn: roundup(L,4) if L <= 32 else roundup(L,32)
+};
+
+__device__ __forceinline__ int cmf_crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------------------------
+// C1: tensor_conv.  One workgroup = 128 (t) x 128 (n) output tile, 4 waves as 2x2, each wave a
+// 64x64 sub-tile = 2x2 MFMA blocks.  The K-row H strip of the tile (with its left lag halo) is
+// staged once per 32-lag block in LDS; the W slab streams through a double-buffered LDS chunk,
+// one lag at a time (reduction order: k-block, lag, k).
+//   MODE 0: store est[t][n]      (A operand = H, B = W)
+//   MODE 1: store estT[n][t]     (A operand = W, B = H; same registers, swapped MFMA roles)
+//   MODE 2: no store; per-workgroup sum of (est - data)^2 -> partial[]  (mult.jl:55-57 fused)
+//   MODE 3: MODE 0 + MODE 2
+// ---------------------------------------------------------------------------------------------
+struct ConvParams {
+    const float *Ht;
+    const float *Wt;
+    float *out;
+    const float *data; // X [TP][Np] (modes 2, 3)
+    double *partial;   // [gridDim.x * gridDim.y]
+    int Np, TP, PADL, K, KB, L;
+    int T_store; // rows t < T_store are stored / counted
+};
+
+#define CONV_HS_STRIDE 160
+#define CONV_HS_FLOATS (32 * CONV_HS_STRIDE)
+#define CONV_WS_FLOATS (32 * 128)
+
+template <int MODE, int NKP_CT>
+__global__ __launch_bounds__(256) void conv_kernel(ConvParams p)
+{
+    __shared__ __attribute__((aligned(16))) float smem[CONV_HS_FLOATS + 2 * CONV_WS_FLOATS];
+    float *Hs = smem;
+    float *Ws = smem + CONV_HS_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wt = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * 128;
+    const int t0 = blockIdx.y * 128;
+    const int Np = p.Np, TP = p.TP;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int LB = (p.L + 31) >> 5;
+    // W chunk loader mapping: 32 rows (k) x 128 floats (n); thread -> row = tid/32 + 8q, col4 = tid%32
+    const int wrow = tid >> 5, wcol = (tid & 31) * 4;
+
+    int buf = 0;
+    for (int kb = 0; kb < p.KB; ++kb) {
+        int nkp = NKP_CT;
+        if (NKP_CT == 0) {
+            int krem = p.K - 32 * kb;
+            nkp = krem >= 32 ? 16 : ((krem + 1) >> 1);
+        }
+        for (int lb = 0; lb < LB; ++lb) {
+            const int lbeg = lb * 32;
+            const int lend = (p.L < lbeg + 32) ? p.L : (lbeg + 32);
+            __syncthreads(); // everyone is done with Hs / Ws of the previous block
+            {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,160)
+                const float *src = p.Ht + (size_t)(kb * 32) * TP + (p.PADL + t0 - lbeg - 32);
+                for (int idx = tid; idx < 32 * 40; idx += 256) {
+                    int r = idx / 40, c4 = idx - r * 40;
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)r * TP + c4 * 4);
+                    *reinterpret_cast<f32x4 *>(Hs + r * CONV_HS_STRIDE + c4 * 4) = v;
+                }
+            }
+            f32x4 wreg[4];
+            {   // first W chunk of this block straight into Ws[buf]
+                const float *src = p.Wt + ((size_t)lbeg * p.KB * 32 + kb * 32) * Np + n0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    wreg[q] = *reinterpret_cast<const f32x4 *>(src + (size_t)(wrow + 8 * q) * Np + wcol);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4 *>(Ws + buf * CONV_WS_FLOATS + (wrow + 8 * q) * 128 + wcol) = wreg[q];
+            }
+            __syncthreads();
+            for (int l = lbeg; l < lend; ++l) {
+                const bool more = (l + 1 < lend);
+                {   // prefetch the next lag's W chunk into registers (clamped on the last lag)
+                    const int ln = more ? l + 1 : l;
+                    const float *src = p.Wt + ((size_t)ln * p.KB * 32 + kb * 32) * Np + n0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        wreg[q] = *reinterpret_cast<const f32x4 *>(src + (size_t)(wrow + 8 * q) * Np + wcol);
+                }
+                // operands of lag l: H window shifted left by (l - lbeg)
+                const float *hsb = Hs + h * CONV_HS_STRIDE + 32 + wt * 64 + i - (l - lbeg);
+                const float *wsb = Ws + buf * CONV_WS_FLOATS + h * 128 + wn * 64 + i;
+                if (NKP_CT != 0) {
+#pragma unroll
+                    for (int kp = 0; kp < NKP_CT; ++kp) {
+                        float a0 = hsb[kp * 2 * CONV_HS_STRIDE], a1 = hsb[kp * 2 * CONV_HS_STRIDE + 32];
+                        float b0 = wsb[kp * 256], b1 = wsb[kp * 256 + 32];
+                        if (MODE == 1) {
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
+                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[0][1], 0, 0, 0);
+                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[1][0], 0, 0, 0);
+                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
+                        } else {
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    for (int kp = 0; kp < nkp; ++kp) {
+                        float a0 = hsb[kp * 2 * CONV_HS_STRIDE], a1 = hsb[kp * 2 * CONV_HS_STRIDE + 32];
+                        float b0 = wsb[kp * 256], b1 = wsb[kp * 256 + 32];
+                        if (MODE == 1) {
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
+                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[0][1], 0, 0, 0);
+                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[1][0], 0, 0, 0);
+                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
+                        } else {
+                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                        }
+                    }
+                }
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4 *>(Ws + (buf ^ 1) * CONV_WS_FLOATS + (wrow + 8 * q) * 128 + wcol) = wreg[q];
+                    __syncthreads();
+                    buf ^= 1;
+                }
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    if (MODE == 0 || MODE == 3 || MODE == 2) {
+        // acc[ti][ni][r]: t = t0 + wt*64 + ti*32 + crow(r,h), n = n0 + wn*64 + ni*32 + i
+        float lsum = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int t = t0 + wt * 64 + ti * 32 + cmf_crow(r, h);
+                    int n = n0 + wn * 64 + ni * 32 + i;
+                    if (t < p.T_store) {
+                        size_t o = (size_t)(p.PADL + t) * Np + n;
+                        float v = acc[ti][ni][r];
+                        if (MODE == 0 || MODE == 3) p.out[o] = v;
+                        if (MODE == 2 || MODE == 3) {
+                            float d = v - p.data[o];
+                            lsum = fmaf(d, d, lsum);
+                        }
+                    }
+                }
+        if (MODE == 2 || MODE == 3) {
+            double ds = (double)lsum;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ds += __shfl_down(ds, off, 64);
+            __shared__ double red[4];
+            if (lane == 0) red[wave] = ds;
+            __syncthreads();
+            if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        }
+    } else {
+        // MODE 1: acc[ni][ti][r]: n = n0 + wn*64 + ni*32 + crow(r,h), t = t0 + wt*64 + ti*32 + i
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int n = n0 + wn * 64 + ni * 32 + cmf_crow(r, h);
+                    int t = t0 + wt * 64 + ti * 32 + i;
+                    if (t < p.T_store) p.out[(size_t)n * TP + p.PADL + t] = acc[ni][ti][r];
+                }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C2: out[l][k][n] = sum_t H[t-l][k] * X[t][n]   (numW with X=data, denomW with X=est).
+// One wave = one 32-wide n block, one 32-wide k block, one time chunk, 2*LP lags; every operand
+// is loaded from global memory directly in MFMA layout (H rows and X rows are both 128-byte
+// contiguous per half-wave), so there is no LDS and no barrier.  The A operand of lag l at
+// step s (t = 2s, 2s+1) is the row pair R(2s-l); even lags reuse E(s-m) = R(2(s-m)), odd lags
+// O(s-m) = R(2(s-m)-1), so each step loads just E(s), O(s) and the X pair and issues 2*LP
+// MFMAs from a register ring.  Partial sums go to a per-chunk slab (deterministic; summed by
+// slab_sum_kernel / the W update).
+// ---------------------------------------------------------------------------------------------
+struct HxtParams {
+    const float *H;  // [TP][K32]
+    const float *X0; // data [TP][Np]
+    const float *X1; // est  [TP][Np]
+    float *slabs;    // [nchunks][2][L][K32][Np]
+    int Np, K32, KB, PADL, L, Tl;
+    int chunk_len;   // multiple of 2*LP
+    int G;           // lag groups of 2*LP lags (fastest-varying part of blockIdx.x, so the groups
+                     // that re-read the same X rows are dispatched together)
+};
+
+template <int LP>
+__global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int nb = (blockIdx.x / p.G) * 4 + wave;
+    const int c = blockIdx.y;
+    const int src = blockIdx.z & 1;
+    const int kb = blockIdx.z >> 1;
+    const int lag0 = (blockIdx.x % p.G) * 2 * LP;
+    const int Np = p.Np, K32 = p.K32;
+    const float *X = src ? p.X1 : p.X0;
+
+    const int tc0 = c * p.chunk_len;
+    int tc1 = tc0 + p.chunk_len;
+    if (tc1 > p.Tl) tc1 = p.Tl;
+    const int ngroups = (tc1 > tc0) ? (tc1 - tc0 + 2 * LP - 1) / (2 * LP) : 0;
+
+    // R(q)[lane] = H[PADL + tc0 + q + h - lag0][kb*32 + i]
+    const float *hp = p.H + (size_t)(p.PADL + tc0 + h - lag0) * K32 + kb * 32 + i;
+    // B(s)[lane] = X[PADL + tc0 + 2s + h][nb*32 + i]
+    const float *xp = X + (size_t)(p.PADL + tc0 + h) * Np + nb * 32 + i;
+
+    f32x16 acc[2 * LP];
+#pragma unroll
+    for (int a = 0; a < 2 * LP; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    float Ep[LP], Op[LP], Ec[LP], Oc[LP], Bc[LP], En[LP], On[LP], Bn[LP];
+    if (ngroups > 0) {
+#pragma unroll
+        for (int u = 0; u < LP; ++u) {
+            Ep[u] = hp[(ptrdiff_t)(2 * (u - LP)) * K32];
+            Op[u] = hp[(ptrdiff_t)(2 * (u - LP) - 1) * K32];
+            Ec[u] = hp[(ptrdiff_t)(2 * u) * K32];
+            Oc[u] = hp[(ptrdiff_t)(2 * u - 1) * K32];
+            Bc[u] = xp[(size_t)(2 * u) * Np];
+        }
+    }
+    for (int g = 0; g < ngroups; ++g) {
+        if (g + 1 < ngroups) {
+            const float *hq = hp + (size_t)(2 * LP) * (g + 1) * K32;
+            const float *xq = xp + (size_t)(2 * LP) * (g + 1) * Np;
+#pragma unroll
+            for (int u = 0; u < LP; ++u) {
+                En[u] = hq[(ptrdiff_t)(2 * u) * K32];
+                On[u] = hq[(ptrdiff_t)(2 * u - 1) * K32];
+                Bn[u] = xq[(size_t)(2 * u) * Np];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LP; ++u) {
+#pragma unroll
+            for (int m = 0; m < LP; ++m) {
+                float ae = (u - m >= 0) ? Ec[(u - m >= 0) ? (u - m) : 0] : Ep[(u - m >= 0) ? 0 : (u - m + LP)];
+                float ao = (u - m >= 0) ? Oc[(u - m >= 0) ? (u - m) : 0] : Op[(u - m >= 0) ? 0 : (u - m + LP)];
+                acc[2 * m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, Bc[u], acc[2 * m], 0, 0, 0);
+                acc[2 * m + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, Bc[u], acc[2 * m + 1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LP; ++u) {
+            Ep[u] = Ec[u]; Op[u] = Oc[u];
+            Ec[u] = En[u]; Oc[u] = On[u]; Bc[u] = Bn[u];
+        }
+    }
+
+    // store: acc[a][r] -> lag lag0+a, k = kb*32 + crow(r,h), n = nb*32 + i
+    float *slab = p.slabs + (size_t)(c * 2 + src) * p.L * K32 * Np;
+#pragma unroll
+    for (int a = 0; a < 2 * LP; ++a) {
+        int l = lag0 + a;
+        if (l < p.L) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int k = kb * 32 + cmf_crow(r, h);
+                slab[((size_t)l * K32 + k) * Np + nb * 32 + i] = acc[a][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C3: out[t][k] = sum_{l,n} XT[n][t+l] * Wn[l][n][k]   (numH with X=data, denomH with X=est).
+// One wave = 128 consecutive t (4 MFMA blocks) x one 32-wide k block x one n range.  The wave
+// stages 8 rows (n) x 160 columns (t, incl. the right lag halo) of XT in its own LDS region
+// (wave-private: no workgroup barrier anywhere), reads the 20 lag-shifted windows from LDS as
+// the A operand, and streams the W operand (128-byte rows of Wn) straight from L2 into
+// registers one n pair ahead.  Partial sums over the n ranges go to slabs.
+// ---------------------------------------------------------------------------------------------
+struct TcParams {
+    const float *Wn;  // [Lp][Np][K32]
+    const float *XT0; // dataT [Np][TP]
+    const float *XT1; // estT  [Np][TP]
+    float *slabs;     // [S][2][Tl][K32]
+    int NpW;          // rows per lag in Wn (= Np)
+    int Nlim;         // roundup(N, 8): XT rows >= Nlim are all zero and are skipped
+    int TP, PADL, K32, KB, L, Tl;
+    int nr;           // n rows per range (multiple of 8)
+    int nsrc;         // 1: only XT0 (stand-alone transconv), 2: both
+};
+
+#define TC_ROW 160
+#define TC_CHUNK (8 * TC_ROW)
+
+template <int LT>
+__global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
+{
+    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * TC_CHUNK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    float *S = smem + wave * (2 * TC_CHUNK);
+
+    const int t0 = (blockIdx.x * 4 + wave) * 128;
+    const int s = blockIdx.y;
+    const int src = blockIdx.z % p.nsrc;
+    const int kb = blockIdx.z / p.nsrc;
+    const int Np = p.NpW, TP = p.TP, K32 = p.K32;
+    const float *XT = src ? p.XT1 : p.XT0;
+    const int nlo = s * p.nr;
+    int nhi = nlo + p.nr;
+    if (nhi > p.Nlim) nhi = p.Nlim;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    if (t0 < p.Tl && nlo < nhi) {
+        const int LB = (p.L + 31) >> 5;
+        const int npairs = (nhi - nlo) >> 1;
+        const size_t lagstride = (size_t)Np * K32;
+        for (int lb = 0; lb < LB; ++lb) {
+            const float *xsrc = XT + (size_t)nlo * TP + (p.PADL + t0 + 32 * lb);
+            f32x4 xr[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                int idx = lane + 64 * q, row = idx / 40, c4 = idx - row * 40;
+                xr[q] = *reinterpret_cast<const f32x4 *>(xsrc + (size_t)row * TP + c4 * 4);
+            }
+            // W operand for n pair `it`: Wn[lb*32 + l][nlo + 2*it + h][kb*32 + i]
+            const float *wb = p.Wn + ((size_t)(lb * 32) * Np + nlo + h) * K32 + kb * 32 + i;
+            float bc[LT], bn[LT];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) bc[l] = wb[l * lagstride];
+            int buf = 0;
+            for (int it = 0; it < npairs; ++it) {
+                const int np = it & 3;
+                if (np == 0) {
+                    float *Sb = S + buf * TC_CHUNK;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+                        *reinterpret_cast<f32x4 *>(Sb + (lane + 64 * q) * 4) = xr[q];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    {   // next 8-row chunk into registers (clamped at the end of the range)
+                        const int itn = (it + 4 < npairs) ? it + 4 : it;
+                        const float *xs2 = xsrc + (size_t)(2 * itn) * TP;
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) {
+                            int idx = lane + 64 * q, row = idx / 40, c4 = idx - row * 40;
+                            xr[q] = *reinterpret_cast<const f32x4 *>(xs2 + (size_t)row * TP + c4 * 4);
+                        }
+                    }
+                }
+                {   // W operand of the next n pair (clamped)
+                    const int itn = (it + 1 < npairs) ? it + 1 : it;
+                    const float *wq = wb + (size_t)(2 * itn) * K32;
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) bn[l] = wq[l * lagstride];
+                }
+                const float *sa = S + buf * TC_CHUNK + (2 * np + h) * TC_ROW + i;
+#pragma unroll
+                for (int l = 0; l < LT; ++l) {
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb) {
+                        float a = sa[tb * 32 + l];
+                        acc[tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc[l], acc[tb], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < LT; ++l) bc[l] = bn[l];
+                if (np == 3) buf ^= 1;
+            }
+        }
+    }
+    if (t0 < p.Tl) {
+        float *slab = p.slabs + (size_t)(s * p.nsrc + src) * p.Tl * K32;
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int t = t0 + tb * 32 + cmf_crow(r, h);
+                if (t < p.Tl) slab[(size_t)t * K32 + kb * 32 + i] = acc[tb][r];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Element-wise MU updates (mult.jl:37-38 and :51-52) with the slab sums folded in.
+//   x <- max(eps, x * (num / (((den + l1) + (2*l2)*x) + eps)))      padding stays exactly 0
+// Each also refreshes the transposed copy of its factor through an LDS tile.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cmf_mu(float x, float num, float den, float l1, float two_l2)
+{
+    float d = ((den + l1) + two_l2 * x) + CMF_EPS_F;
+    float y = x * (num / d);
+    return (y != y) ? y : fmaxf(CMF_EPS_F, y);
+}
+
+// grid: (Np/64, KB, L), block 256.  numden: [nslabs][2][L][K32][Np]
+__global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, const float *numden, int nslabs,
+                                                        int N, int K, int L, int Np, int K32, float l1, float two_l2)
+{
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * 64, kb = blockIdx.y, l = blockIdx.z;
+    const size_t LKN = (size_t)L * K32 * Np;
+    {
+        const int nn = tid & 63;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int kk = q * 4 + (tid >> 6);
+            int k = kb * 32 + kk, n = n0 + nn;
+            size_t idx = ((size_t)l * K32 + k) * Np + n;
+            float num = 0.f, den = 0.f;
+            for (int s = 0; s < nslabs; ++s) {
+                num += numden[(size_t)(2 * s) * LKN + idx];
+                den += numden[(size_t)(2 * s + 1) * LKN + idx];
+            }
+            float w = Wt[idx];
+            float wn = (k < K && n < N) ? cmf_mu(w, num, den, l1, two_l2) : 0.f;
+            Wt[idx] = wn;
+            tile[kk][nn] = wn;
+        }
+    }
+    __syncthreads();
+    {
+        const int kk = tid & 31;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int nn = q * 8 + (tid >> 5);
+            Wn[((size_t)l * Np + n0 + nn) * K32 + kb * 32 + kk] = tile[kk][nn];
+        }
+    }
+}
+
+// grid: (ceil(Tl/64), KB), block 256.  slabs: [S][2][Tl][K32]
+__global__ __launch_bounds__(256) void h_update_kernel(float *H, float *Ht, const float *slabs, int S,
+                                                        int Tl, int K, int K32, int PADL, int TP, float l1, float two_l2)
+{
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * 64, kb = blockIdx.y;
+    const size_t TK = (size_t)Tl * K32;
+    {
+        const int kk = tid & 31;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int tt = q * 8 + (tid >> 5);
+            int t = t0 + tt, k = kb * 32 + kk;
+            float hn = 0.f;
+            if (t < Tl) {
+                size_t idx = (size_t)t * K32 + k;
+                float num = 0.f, den = 0.f;
+                for (int s = 0; s < S; ++s) {
+                    num += slabs[(size_t)(2 * s) * TK + idx];
+                    den += slabs[(size_t)(2 * s + 1) * TK + idx];
+                }
+                size_t hidx = (size_t)(PADL + t) * K32 + k;
+                float x = H[hidx];
+                hn = (k < K) ? cmf_mu(x, num, den, l1, two_l2) : 0.f;
+                H[hidx] = hn;
+            }
+            tile[kk][tt] = hn;
+        }
+    }
+    __syncthreads();
+    {
+        const int tt = tid & 63;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int kk = q * 4 + (tid >> 6);
+            int t = t0 + tt;
+            if (t < Tl) Ht[(size_t)(kb * 32 + kk) * TP + PADL + t] = tile[kk][tt];
+        }
+    }
+}
+
+// out[i] = sum_s in[s*stride + i]  (deterministic slab combine; float4 lanes)
+__global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *in, int nslabs, size_t stride, size_t n4)
+{
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4 *>(in)[idx];
+        for (int s = 1; s < nslabs; ++s) {
+            float4 b = reinterpret_cast<const float4 *>(in + (size_t)s * stride)[idx];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4 *>(out)[idx] = a;
+    }
+}
+
+// *out = sum(partial[0..n))   one block
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial, int n, double *out)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int idx = threadIdx.x; idx < n; idx += 256) s += partial[idx];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layout conversion (fp64 Julia order on the host side <-> padded fp32 device layouts)
+// ---------------------------------------------------------------------------------------------
+// in: cols [tc, tc+ncols) of an N x * column-major fp64 matrix (in[n + N*(t - tc)]).
+// Writes X[(PADL+t)][n] and XT[n][PADL+t].  grid (ceil(N/32), ceil(ncols/32)), block (32, 8)
+__global__ void pack_cols_kernel(const double *in, int N, int tc, int ncols, float *X, float *XT, int Np, int TP, int PADL)
+{
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int q = threadIdx.y; q < 32; q += 8) {
+        int c = c0 + q, n = n0 + threadIdx.x;
+        float v = 0.f;
+        if (c < ncols && n < N) {
+            v = (float)in[(size_t)c * N + n];
+            if (X) X[(size_t)(PADL + tc + c) * Np + n] = v;
+        }
+        tile[q][threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (XT) {
+        for (int q = threadIdx.y; q < 32; q += 8) {
+            int n = n0 + q, c = c0 + threadIdx.x;
+            if (c < ncols && n < N) XT[(size_t)n * TP + PADL + tc + c] = tile[threadIdx.x][q];
+        }
+    }
+}
+
+// W fp64 [L][N][K] (k fastest) -> Wt[l][k][n], Wn[l][n][k]
+__global__ void pack_W_kernel(const double *in, int N, int K, int L, float *Wt, float *Wn, int Np, int K32)
+{
+    size_t total = (size_t)L * N * K;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int k = (int)(idx % K);
+        size_t r = idx / K;
+        int n = (int)(r % N), l = (int)(r / N);
+        float v = (float)in[idx];
+        Wt[((size_t)l * K32 + k) * Np + n] = v;
+        Wn[((size_t)l * Np + n) * K32 + k] = v;
+    }
+}
+__global__ void unpack_W_kernel(double *out, int N, int K, int L, const float *Wn, int Np, int K32)
+{
+    size_t total = (size_t)L * N * K;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int k = (int)(idx % K);
+        size_t r = idx / K;
+        int n = (int)(r % N), l = (int)(r / N);
+        out[idx] = (double)Wn[((size_t)l * Np + n) * K32 + k];
+    }
+}
+// H fp64 [T][K] (k fastest) -> H[(PADL+t)][k], Ht[k][PADL+t]
+__global__ void pack_H_kernel(const double *in, int Tl, int K, float *H, float *Ht, int K32, int TP, int PADL)
+{
+    size_t total = (size_t)Tl * K;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int k = (int)(idx % K);
+        int t = (int)(idx / K);
+        float v = (float)in[idx];
+        H[(size_t)(PADL + t) * K32 + k] = v;
+        Ht[(size_t)k * TP + PADL + t] = v;
+    }
+}
+__global__ void unpack_H_kernel(double *out, int Tl, int K, const float *H, int K32, int PADL)
+{
+    size_t total = (size_t)Tl * K;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int k = (int)(idx % K);
+        int t = (int)(idx / K);
+        out[idx] = (double)H[(size_t)(PADL + t) * K32 + k];
+    }
+}
+// rows [tc, tc+ncols) of a [*][stride] fp32 row-major buffer (row offset row0) -> fp64 out[c*width + j]
+__global__ void unpack_rows_kernel(double *out, const float *in, int row0, int tc, int ncols, int width, int stride)
+{
+    size_t total = (size_t)ncols * width;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int j = (int)(idx % width);
+        int c = (int)(idx / width);
+        out[idx] = (double)in[(size_t)(row0 + tc + c) * stride + j];
+    }
+}
+
+// H halo rows <-> contiguous staging buffers ((L-1) x K32 floats)
+// dir 0: buf <- H rows [r0, r0+rows)   dir 1: H rows <- buf (and Ht columns)
+__global__ void halo_copy_kernel(float *H, float *Ht, float *buf, int r0, int rows, int K32, int TP, int dir)
+{
+    int total = rows * K32;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int k = idx % K32, r = idx / K32;
+        if (dir == 0) buf[idx] = H[(size_t)(r0 + r) * K32 + k];
+        else {
+            float v = buf[idx];
+            H[(size_t)(r0 + r) * K32 + k] = v;
+            Ht[(size_t)k * TP + r0 + r] = v;
+        }
+    }
+}
+
+// sum of squares of a fp64 array -> *out (one block; used for data_norm on a staged chunk)
+__global__ __launch_bounds__(256) void sumsq_f64_kernel(const double *in, size_t n, double *out_accum)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) s += in[idx] * in[idx];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_accum[blockIdx.x] = red[0];
+}

@@ -1,0 +1,377 @@
+"""Host-side mirror of CMF.jl's interface for the multiplicative-update path.
+
+The reference host language is Julia, which is not available where this is built,
+so the host layer above the C ABI is written in Python with the reference's own
+names, argument meaning and loop semantics (the Julia ``ccall`` twin of this file
+is cmf.jl_amd/julia/CMFHip.jl, shown in INTEGRATION.md).  Citations are relative to
+the reference checkout.
+
+    fit_cnmf(data; L, K, alg=:mult, max_itr, max_time, l1_*, l2_*, seed, ...)   src/model.jl:58-85
+    CNMF_results(data, W, H, time_hist, loss_hist)                                src/model.jl:11-30
+    init_rand(data, L, K)                                                         src/model.jl:113-125
+    converged(loss_hist, patience, tol)                                           src/model.jl:91-107
+    AlternatingOptimizer / fit                                                    src/algs/alternating.jl:10-71
+    MultUpdate: ctor, update_motifs!, update_feature_maps!                        src/algs/mult.jl:1-58
+    tensor_conv / tensor_transconv / compute_loss                                 src/common.jl:17-81
+    gen_synthetic                                                                 README.md:14, datasets/synthetic.jl:29-61
+
+Arrays use Julia's index order: ``data[n, t]`` (N,T), ``W[k, n, l]`` (K,N,L), ``H[k, t]`` (K,T).
+All arithmetic runs on the GPU through libcmf_hip.so; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import time
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import CMFError, check, farr, ptr
+
+EPSILON = float(np.finfo(np.float64).eps)  # src/CMF.jl:20
+
+
+# --------------------------------------------------------------------------------------
+# results
+# --------------------------------------------------------------------------------------
+class CNMF_results:
+    """Holds results from a single CNMF fit (src/model.jl:11-17)."""
+
+    def __init__(self, data, W, H, time_hist, loss_hist):
+        self.data = data
+        self.W = W
+        self.H = H
+        self.time_hist = time_hist
+        self.loss_hist = loss_hist
+
+    # accessors: src/model.jl:21-30
+    def num_lags(self):
+        return self.W.shape[2]
+
+    def num_units(self):
+        return self.W.shape[1]
+
+    def num_components(self):
+        return self.W.shape[0]
+
+    def num_iter(self):
+        return len(self.loss_hist)
+
+
+# --------------------------------------------------------------------------------------
+# stand-alone primitives (src/common.jl)
+# --------------------------------------------------------------------------------------
+def _dims(W, H=None, X=None):
+    K, N, L = W.shape
+    T = H.shape[1] if H is not None else X.shape[1]
+    return N, T, K, L
+
+
+def tensor_conv(W, H, device=None):
+    """tensor_conv(W, H) -> est (N x T): src/common.jl:17-34."""
+    lib = _lib.load()
+    W = farr(W)
+    N, T, K, L = _dims(W, H=np.asarray(H))
+    H = farr(H, (K, T))
+    est = np.zeros((N, T), order="F")
+    check(lib.cmf_tensor_conv(_dev(device), N, T, K, L, ptr(W), ptr(H), ptr(est)))
+    return est
+
+
+def tensor_transconv(W, X, device=None):
+    """tensor_transconv(W, X) -> (K x T): src/common.jl:62-81."""
+    lib = _lib.load()
+    W = farr(W)
+    N, T, K, L = _dims(W, X=np.asarray(X))
+    X = farr(X, (N, T))
+    out = np.zeros((K, T), order="F")
+    check(lib.cmf_tensor_transconv(_dev(device), N, T, K, L, ptr(W), ptr(X), ptr(out)))
+    return out
+
+
+def compute_loss(data, W, H, device=None):
+    """compute_loss(data, W, H): src/common.jl:54-59."""
+    rule = MultUpdate(data, W, H, device=device)
+    try:
+        return rule.compute_loss()
+    finally:
+        rule.close()
+
+
+def converged(loss_hist, patience, tol):
+    """Check for model convergence: src/model.jl:91-107."""
+    lib = _lib.load()
+    lh = np.ascontiguousarray(loss_hist, dtype=np.float64)
+    return bool(lib.cmf_converged(ptr(lh), len(lh), int(patience), float(tol)))
+
+
+def _dev(device):
+    return _lib.default_device() if device is None else int(device)
+
+
+# --------------------------------------------------------------------------------------
+# update rules (the plugin boundary: abstract type AbstractCFUpdate, alternating.jl:1-8)
+# --------------------------------------------------------------------------------------
+class AbstractCFUpdate:
+    """An update rule that updates both W and H (src/algs/alternating.jl:1-8).
+
+    Must implement ``Rule(data, W, H)``, ``update_motifs(data, W, H, **kwargs)`` and
+    ``update_feature_maps(data, W, H, **kwargs) -> loss``.
+    """
+
+
+class MultUpdate(AbstractCFUpdate):
+    """MultUpdate on MI355X: drop-in for src/algs/mult.jl behind the rule interface.
+
+    ``MultUpdate(data, W, H)`` mirrors the reference constructor (mult.jl:11-20): it
+    uploads ``data`` and the factors and owns the rule's scratch (est, numW, denomW,
+    numH, denomH) on the device.  The working copies of W and H stay device-resident
+    between calls; ``update_motifs`` / ``update_feature_maps`` advance them, and
+    :meth:`download` writes them back into the caller's arrays (``fit`` does this
+    once at the end, which is observably the same as the reference's in-place
+    mutation for every caller that only reads W and H after ``fit`` returns).  If the
+    caller changes W or H on the host between calls, it must call :meth:`upload`.
+    """
+
+    def __init__(self, data, W, H, device=None):
+        lib = _lib.load()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        data = farr(data)
+        if data.ndim != 2:
+            raise ValueError("data must be a matrix (N x T)")
+        W = farr(W)
+        if W.ndim != 3:
+            raise ValueError("W must be a K x N x L tensor")
+        K, N, L = W.shape
+        if data.shape[0] != N:
+            raise ValueError(f"DimensionMismatch: data has {data.shape[0]} rows, W has N={N}")
+        T = data.shape[1]
+        H = farr(H, (K, T))
+        self.N, self.T, self.K, self.L = N, T, K, L
+        self.device = _dev(device)
+        check(lib.cmf_create(ctypes.byref(self._h), self.device, N, T, K, L, ptr(data)))
+        try:
+            check(lib.cmf_set_factors(self._h, ptr(W), ptr(H)))
+        except Exception:
+            self.close()
+            raise
+        ss = ctypes.c_double()
+        check(lib.cmf_get_data_sumsq(self._h, ctypes.byref(ss)))
+        self.data_norm = math.sqrt(ss.value)  # mult.jl:13
+
+    # -- the two rule methods -----------------------------------------------------------
+    def update_motifs(self, data=None, W=None, H=None, l1W=0, l2W=0, **kwargs):
+        """update_motifs!(rule, data, W, H; l1W=0, l2W=0): src/algs/mult.jl:23-39."""
+        check(self._lib.cmf_update_motifs(self._h, float(l1W), float(l2W)))
+
+    def update_feature_maps(self, data=None, W=None, H=None, l1H=0, l2H=0, **kwargs):
+        """update_feature_maps!(rule, data, W, H; l1H=0, l2H=0) -> loss: src/algs/mult.jl:42-58."""
+        loss = ctypes.c_double()
+        check(self._lib.cmf_update_feature_maps(self._h, float(l1H), float(l2H), ctypes.byref(loss)))
+        return loss.value
+
+    # -- helpers ------------------------------------------------------------------------
+    def compute_loss(self):
+        """compute_loss(data, W, H) on the resident factors: src/common.jl:54-59."""
+        loss = ctypes.c_double()
+        check(self._lib.cmf_compute_loss(self._h, ctypes.byref(loss)))
+        return loss.value
+
+    def upload(self, W, H):
+        W = farr(W, (self.K, self.N, self.L))
+        H = farr(H, (self.K, self.T))
+        check(self._lib.cmf_set_factors(self._h, ptr(W), ptr(H)))
+
+    def download(self, W=None, H=None):
+        """Write the resident factors into W, H (in place when given) and return them."""
+        Wf = np.zeros((self.K, self.N, self.L), order="F")
+        Hf = np.zeros((self.K, self.T), order="F")
+        check(self._lib.cmf_get_factors(self._h, ptr(Wf), ptr(Hf)))
+        if W is not None:
+            W[...] = Wf
+            Wf = W
+        if H is not None:
+            H[...] = Hf
+            Hf = H
+        return Wf, Hf
+
+    def fit_native(self, max_itr, max_time, check_convergence, patience, tol, eval_mode,
+                   l1W=0.0, l2W=0.0, l1H=0.0, l2H=0.0):
+        """The whole alternating.jl:16-71 loop inside the library (one ccall)."""
+        lh = np.zeros(int(max_itr) + 1)
+        th = np.zeros(int(max_itr) + 1)
+        n = ctypes.c_int64(0)
+        early = ctypes.c_int(0)
+        check(self._lib.cmf_fit(self._h, int(max_itr), float(max_time), int(bool(check_convergence)), int(patience),
+                                float(tol), int(bool(eval_mode)), float(l1W), float(l2W), float(l1H), float(l2H),
+                                ptr(lh), ptr(th), ctypes.byref(n), ctypes.byref(early)))
+        return lh[: n.value].copy(), th[: n.value].copy(), bool(early.value)
+
+    def time_kernel(self, name, reps=5):
+        """(avg ms, algorithmic flops per launch) of one hot kernel, timed with HIP events."""
+        ms, fl = ctypes.c_double(), ctypes.c_double()
+        check(self._lib.cmf_time_kernel(self._h, name.encode(), int(reps), ctypes.byref(ms), ctypes.byref(fl)))
+        return ms.value, fl.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.cmf_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+HIPMultUpdate = MultUpdate
+
+
+def _resolve_alg(alg):
+    """alg may be a rule type (HEAD, model.jl:60) or a README-style symbol (README.md:30-33)."""
+    if isinstance(alg, str):
+        name = alg.lstrip(":").lower()
+        if name in ("mult", "mu"):
+            return MultUpdate
+        if name in ("hals", "anls", "admm", "pgd", "sep"):
+            raise NotImplementedError(f"alg=:{name} is outside the MI355X hot path built here (only :mult)")
+        raise ValueError(f"unknown algorithm {alg!r}")
+    if isinstance(alg, type) and issubclass(alg, AbstractCFUpdate):
+        return alg
+    raise TypeError(f"alg must be an update-rule type or a name like ':mult', got {alg!r}")
+
+
+# --------------------------------------------------------------------------------------
+# driver (src/algs/alternating.jl)
+# --------------------------------------------------------------------------------------
+class AlternatingOptimizer:
+    """AlternatingOptimizer(update_rule, max_itr, max_time): src/algs/alternating.jl:10-14."""
+
+    def __init__(self, update_rule, max_itr, max_time):
+        self.update_rule = update_rule
+        self.max_itr = max_itr
+        self.max_time = max_time
+
+
+def fit(alg, data, L, K, W_init, H_init, verbose=False, **kwargs):
+    """fit(alg::AlternatingOptimizer, data, L, K, W_init, H_init; kwargs...): alternating.jl:16-71."""
+    # Load keyword args (:23-31)
+    check_convergence = kwargs.get("check_convergence", True)
+    patience = kwargs.get("patience", 3)
+    eval_mode = kwargs.get("eval_mode", False)
+    assert patience >= 1
+    tol = kwargs.get("tol", 1e-4)
+
+    W = np.array(W_init, dtype=np.float64, order="F", copy=True)  # :33-34 deepcopy
+    H = np.array(H_init, dtype=np.float64, order="F", copy=True)
+    rule = alg.update_rule
+    device_resident = hasattr(rule, "download")
+
+    # Set up optimization tracking (:37-38)
+    loss_hist = [rule.compute_loss() if device_resident else compute_loss(data, W, H)]
+    time_hist = [0.0]
+
+    if verbose:
+        print("Starting ", end="", flush=True)
+
+    itr = 1
+    while itr <= alg.max_itr and time_hist[-1] <= alg.max_time:  # :45
+        itr += 1
+        t0 = time.time()
+        if not eval_mode:  # Skip motif update in evaluation mode (:51-53)
+            rule.update_motifs(data, W, H, **kwargs)
+        loss = rule.update_feature_maps(data, W, H, **kwargs)  # :54 (synchronises)
+        dur = time.time() - t0
+        time_hist.append(time_hist[-1] + dur)  # :57-59
+        loss_hist.append(loss)
+        if verbose:
+            print(".", end="", flush=True)
+        if check_convergence and converged(loss_hist, patience, tol):  # :63-66
+            print("Converged early.")
+            break
+    if verbose:
+        print(" fit!")
+
+    if device_resident:
+        rule.download(W, H)
+    return CNMF_results(data, W, H, np.asarray(time_hist), np.asarray(loss_hist))  # :70
+
+
+# --------------------------------------------------------------------------------------
+# public API (src/model.jl)
+# --------------------------------------------------------------------------------------
+_REG_ALIASES = {"l1_W": "l1W", "l2_W": "l2W", "l1_H": "l1H", "l2_H": "l2H"}  # README.md:44-52 -> mult.jl:23,42
+_KNOWN_KW = {"seed", "W_init", "H_init", "check_convergence", "patience", "eval_mode", "tol", "verbose",
+             "l1W", "l2W", "l1H", "l2H", "device"}
+
+
+def init_rand(data, L, K, seed=None, device=None):
+    """Initialize randomly, scaling to minimize square error: src/model.jl:113-125.
+
+    Uses the library's portable counter RNG (Julia's MersenneTwister streams are not
+    reproducible across Julia versions); ``seed=None`` draws a fresh seed.
+    """
+    lib = _lib.load()
+    data = farr(data)
+    N, T = data.shape
+    if seed is None:
+        seed = int.from_bytes(os.urandom(8), "little")
+    W = np.zeros((K, N, L), order="F")
+    H = np.zeros((K, T), order="F")
+    check(lib.cmf_init_rand(_dev(device), N, T, K, L, int(seed) & (2**64 - 1), ptr(data), ptr(W), ptr(H)))
+    return W, H
+
+
+def fit_cnmf(data, L=10, K=5, alg=MultUpdate, max_itr=100, max_time=math.inf, **kwargs):
+    """fit_cnmf(data; L=10, K=5, alg=MultUpdate, max_itr=100, max_time=Inf, kwargs...): src/model.jl:58-85.
+
+    Accepts both HEAD's rule types and the README's symbols (``alg=":mult"``), and both
+    spellings of the regularisers (``l1_W`` of README.md:44-52 and ``l1W`` of mult.jl:23,42),
+    which HEAD silently drops.
+    """
+    kw = {}
+    for k, v in kwargs.items():
+        k2 = _REG_ALIASES.get(k, k)
+        if k2 in kw:
+            raise TypeError(f"regulariser given twice: {k} and {k2}")
+        kw[k2] = v
+    unknown = set(kw) - _KNOWN_KW
+    if unknown:
+        warnings.warn(f"fit_cnmf: ignoring unknown keyword arguments {sorted(unknown)} "
+                      "(the reference ignores them silently)", stacklevel=2)
+    device = kw.pop("device", None)
+    rule_type = _resolve_alg(alg)
+    data = farr(data)
+
+    seed = kw.get("seed", None)  # :64-67
+    # Initialize (:70) -- always runs, like the reference (it consumes the RNG even when inits are given)
+    W_init, H_init = init_rand(data, L, K, seed=seed, device=device)
+    W_init = kw.get("W_init", W_init)  # :72-73
+    H_init = kw.get("H_init", H_init)
+
+    rule = rule_type(data, W_init, H_init, device=device) if rule_type is MultUpdate else rule_type(data, W_init, H_init)
+    try:
+        opt = AlternatingOptimizer(rule, max_itr, max_time)  # :78-82
+        loop_kw = {k: v for k, v in kw.items() if k not in ("seed", "W_init", "H_init")}
+        return fit(opt, data, L, K, W_init, H_init, **loop_kw)  # :84
+    finally:
+        if hasattr(rule, "close"):
+            rule.close()
+
+
+def gen_synthetic(N=100, T=500, K=3, L=20, alpha=0.1, p_h=0.5, sigma=0.2, noise_scale=1.0, seed=1234,
+                  return_factors=False, device=None):
+    """gen_synthetic(N=, T=) -> data (README.md:14), following synthetic_sequences
+    (datasets/synthetic.jl:29-61; same defaults).  ``return_factors=True`` also returns (W, H)."""
+    lib = _lib.load()
+    data = np.zeros((N, T), order="F")
+    W = np.zeros((K, N, L), order="F")
+    H = np.zeros((K, T), order="F")
+    check(lib.cmf_gen_synthetic(_dev(device), N, T, K, L, float(alpha), float(p_h), float(sigma), float(noise_scale),
+                                int(seed) & (2**64 - 1), ptr(data), ptr(W), ptr(H)))
+    return (data, W, H) if return_factors else data

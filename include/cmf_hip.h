@@ -1,0 +1,172 @@
+/*
+ * cmf_hip.h -- C ABI of libcmf_hip.so: the MI355X (gfx950) implementation of
+ * CMF.jl's convolutive-NMF multiplicative-update (MU) hot path.
+ *
+ * This is the drop-in boundary.  The reference is pure
+ * Julia, so what a maintainer binds is a `ccall` per entry point
+ * (INTEGRATION.md shows the Julia side: `struct HIPMultUpdate <: AbstractCFUpdate`).
+ * Every entry cites the reference interface it replaces (paths relative to
+ * the reference checkout).
+ *
+ * Conventions
+ *   - All host arrays are Julia's own memory layout (column-major, first
+ *     index fastest), Float64:
+ *         data[n + N*t]          N x T      (Matrix{Float64})
+ *         W[k + K*(n + N*l)]     K x N x L  (Array{Float64,3}, "Tensor")
+ *         H[k + K*t]             K x T
+ *     The device computes in fp32; conversion happens on upload/download.
+ *   - Host pointers are borrowed for the duration of the call only.
+ *   - Every entry returns 0 on success or a CMF_ERR_* code; the message is
+ *     available from cmf_last_error() (thread-local).
+ *   - A handle is not re-entrant: one host thread at a time.
+ *   - There is no CPU fallback: without a usable HIP device every compute
+ *     entry fails with CMF_ERR_HIP.
+ */
+#ifndef CMF_HIP_H
+#define CMF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMF_OK 0
+#define CMF_ERR_ARG 1         /* bad argument (null pointer, non-positive size, patience < 1 ...) */
+#define CMF_ERR_HIP 2         /* HIP runtime error / no device */
+#define CMF_ERR_STATE 3       /* call sequence error (e.g. factors not set) */
+#define CMF_ERR_UNSUPPORTED 4 /* shape outside what the kernels implement */
+
+typedef struct cmf_handle_s *cmf_handle;
+
+/* Library / build identification ("cmf_hip gfx950 <version>"). */
+const char *cmf_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char *cmf_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unusable). */
+int cmf_device_count(void);
+
+/* ---- rule construction -------------------------------------------------
+ * Replaces the MultUpdate constructor `MultUpdate(data, W, H)`
+ * (src/algs/mult.jl:11-20, called at src/model.jl:79): uploads `data`
+ * (N x T), allocates the rule's scratch (est, numW, denomW, numH, denomH)
+ * on `device`, and computes data_norm = norm(data).
+ * cmf_create is the single-GPU form of cmf_create_shard. */
+int cmf_create(cmf_handle *h, int device, int64_t N, int64_t T, int64_t K, int64_t L,
+               const double *data);
+
+/* T-sharded form: this handle owns global columns
+ * [t_offset, t_offset + T_local) of a T_global-column problem.
+ * `data_local` holds columns [t_offset, t_offset + T_local + halo_r) where
+ * halo_r = min(L-1, T_global - t_offset - T_local) (the static right halo of
+ * `data` that tensor_transconv needs).  data_norm is the LOCAL sum of squares
+ * root until cmf_set_data_norm() installs the global one. */
+int cmf_create_shard(cmf_handle *h, int device, int64_t N, int64_t T_local, int64_t K, int64_t L,
+                     const double *data_local, int64_t t_offset, int64_t T_global);
+
+int cmf_destroy(cmf_handle h);
+
+/* Run all work of this handle on an existing HIP stream (hipStream_t passed
+ * as void*), e.g. torch's current stream; NULL = the handle's own stream. */
+int cmf_set_stream(cmf_handle h, void *hip_stream);
+
+/* sum(data.^2) over the columns this handle owns (fp64); and the setter used
+ * by the sharded host after it all-reduced the per-shard values
+ * (data_norm: src/algs/mult.jl:13). */
+int cmf_get_data_sumsq(cmf_handle h, double *sumsq);
+int cmf_set_data_norm(cmf_handle h, double data_norm);
+
+/* ---- factors -------------------------------------------------------------
+ * W (K x N x L) and H (K x T_local) in / out.  `fit` deep-copies the
+ * initial factors and the rule mutates them in place
+ * (src/algs/alternating.jl:33-34, src/algs/mult.jl:37-38,51-52): here the
+ * working copies live on the device between calls. */
+int cmf_set_factors(cmf_handle h, const double *W, const double *H);
+int cmf_get_factors(cmf_handle h, double *W, double *H);
+
+/* ---- the update rule -------------------------------------------------------
+ * update_motifs!(rule::MultUpdate, data, W, H; l1W=0, l2W=0)
+ *   src/algs/mult.jl:23-39  (called at src/algs/alternating.jl:52). */
+int cmf_update_motifs(cmf_handle h, double l1W, double l2W);
+/* update_feature_maps!(rule::MultUpdate, data, W, H; l1H=0, l2H=0) -> loss
+ *   src/algs/mult.jl:42-58  (called at src/algs/alternating.jl:54).
+ * Synchronises: *loss is valid on return. */
+int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss);
+/* compute_loss(data, W, H) = norm(tensor_conv(W,H) - data) / norm(data)
+ *   src/common.jl:54-59 (loss_hist[1], src/algs/alternating.jl:37). */
+int cmf_compute_loss(cmf_handle h, double *loss);
+
+/* The whole loop of fit(::AlternatingOptimizer, ...) with W, H device-resident:
+ *   src/algs/alternating.jl:16-71.  loss_hist/time_hist must hold max_itr+1
+ * doubles; *n_hist receives the number of entries written (iterations + 1);
+ * *converged_early is 1 when the loop stopped on `converged` (:63-66; the
+ * host wrapper prints "Converged early." like the reference).
+ * Only valid on an unsharded handle. */
+int cmf_fit(cmf_handle h, int64_t max_itr, double max_time,
+            int check_convergence, int64_t patience, double tol, int eval_mode,
+            double l1W, double l2W, double l1H, double l2H,
+            double *loss_hist, double *time_hist, int64_t *n_hist, int *converged_early);
+
+/* converged(loss_hist, patience, tol): src/model.jl:91-107 (host arithmetic). */
+int cmf_converged(const double *loss_hist, int64_t len, int64_t patience, double tol);
+
+/* ---- phase-split form of the same iteration, for the T-sharded host ------
+ * One MU iteration on R ranks is, per rank:
+ *   cmf_w_partial            est = conv(W,H); local [numW|denomW] partial sums
+ *   <all-reduce(sum) over cmf_numden_ptr, 2*cmf_numden_count floats>
+ *   cmf_w_apply              W update (mult.jl:37-38), identical on every rank
+ *   cmf_h_update             est (new W) on own columns + right halo, numH, denomH, H update
+ *   <exchange (L-1)-column H halos with both neighbours: cmf_halo_*>
+ *   cmf_loss_partial         sum((conv(W,H) - data).^2) over own columns
+ *   <all-reduce the scalar>; loss = sqrt(sum) / data_norm
+ * cmf_update_motifs == cmf_w_partial + cmf_w_apply on one rank. */
+int cmf_w_partial(cmf_handle h);
+int cmf_w_apply(cmf_handle h, double l1W, double l2W);
+int cmf_h_update(cmf_handle h, double l1H, double l2H);
+int cmf_loss_partial(cmf_handle h, double *sumsq);
+/* Device pointer (fp32) of the contiguous [numW | denomW] buffer and its
+ * length in floats (same on every rank: 2 * L * Kpad * Npad). */
+int cmf_numden_ptr(cmf_handle h, void **dev_ptr, int64_t *count);
+/* H halo staging buffers (device, fp32, (L-1) * Kpad floats each):
+ *   which = 0: send-to-left  (own first L-1 columns)   -> left rank's right halo
+ *   which = 1: send-to-right (own last  L-1 columns)   -> right rank's left halo
+ *   which = 2: recv-from-left  (becomes own left halo)
+ *   which = 3: recv-from-right (becomes own right halo)
+ * cmf_halo_pack fills the send buffers from H; cmf_halo_unpack installs the
+ * recv buffers (has_left/has_right say which were actually received). */
+int cmf_halo_ptr(cmf_handle h, int which, void **dev_ptr, int64_t *count);
+int cmf_halo_pack(cmf_handle h);
+int cmf_halo_unpack(cmf_handle h, int has_left, int has_right);
+
+/* ---- stand-alone primitives ------------------------------------------------
+ * tensor_conv(W, H) -> est (N x T): src/common.jl:17-34. */
+int cmf_tensor_conv(int device, int64_t N, int64_t T, int64_t K, int64_t L,
+                    const double *W, const double *H, double *est);
+/* tensor_transconv(W, X) -> out (K x T): src/common.jl:62-81. */
+int cmf_tensor_transconv(int device, int64_t N, int64_t T, int64_t K, int64_t L,
+                         const double *W, const double *X, double *out);
+
+/* ---- initialisation / synthetic inputs -------------------------------------
+ * init_rand(data, L, K): src/model.jl:113-125, with a portable counter-based
+ * RNG in place of Julia's MersenneTwister (seed: fit_cnmf's `seed` kwarg,
+ * src/model.jl:64-67).  Writes W (K x N x L), H (K x T). */
+int cmf_init_rand(int device, int64_t N, int64_t T, int64_t K, int64_t L, uint64_t seed,
+                  const double *data, double *W, double *H);
+/* gen_synthetic (README.md:14) following synthetic_sequences
+ * (datasets/synthetic.jl:29-61).  Writes data (N x T) and, when non-NULL,
+ * the ground-truth W (K x N x L) and H (K x T). */
+int cmf_gen_synthetic(int device, int64_t N, int64_t T, int64_t K, int64_t L,
+                      double alpha, double p_h, double sigma, double noise_scale, uint64_t seed,
+                      double *data, double *W, double *H);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------
+ * Times `reps` launches of one named hot kernel with HIP events on the
+ * handle's stream and returns the average duration in milliseconds plus the
+ * algorithmic flop count of one launch.  name: "conv", "hxt", "transconv". */
+int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, double *flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMF_HIP_H */

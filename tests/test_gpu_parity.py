@@ -1,0 +1,261 @@
+"""GPU parity tests: the HIP path (through the C ABI of libcmf_hip.so) against the CPU oracle.
+
+Tolerances (north_star: W, H, loss_hist within 1e-4 relative of the fp64 CPU reference,
+fp32 on the device; defined norm-wise per BASELINE.md section 4):
+    REL_FACTORS = 1e-4   Frobenius-relative error of W and of H
+    REL_LOSS    = 1e-4   per-entry relative error of loss_hist
+    REL_PRIM    = 2e-6   Frobenius-relative error of a single conv / transconv (one fp32 contraction)
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_FACTORS = 1e-4
+REL_LOSS = 1e-4
+REL_PRIM = 2e-6
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def cmf():
+    import cmf_jl_amd as m
+
+    lib = m.load_library()
+    assert lib.cmf_device_count() >= 1, "no HIP device: the gpu tests need a real MI355X"
+    return m
+
+
+def frob_rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def rand_problem(seed, N, T, K, L):
+    rng = np.random.default_rng(seed)
+    return rng.random((K, N, L)), rng.random((K, T)), rng.random((N, T))
+
+
+# (N, T, K, L): odd sizes, K/L edge cases, multi k-block (K>32), multi lag-block (L>32), T<L
+PRIM_SHAPES = [
+    (48, 300, 4, 8),
+    (7, 23, 3, 4),
+    (5, 9, 1, 1),
+    (1, 17, 2, 5),
+    (6, 3, 2, 5),       # T < L
+    (4, 5, 3, 5),       # T == L
+    (70, 257, 5, 10),   # config-1 K, L
+    (130, 700, 32, 20), # config-2 K, L; N crosses a 128 tile
+    (37, 150, 33, 7),   # two k blocks
+    (20, 200, 6, 40),   # two lag blocks
+    (9, 1100, 2, 3),    # several 512-wide t tiles
+]
+
+
+@pytest.mark.parametrize("N,T,K,L", PRIM_SHAPES)
+def test_tensor_conv(cmf, oracle, N, T, K, L):
+    W, H, _ = rand_problem(1, N, T, K, L)
+    got = cmf.tensor_conv(W, H)
+    ref = oracle.tensor_conv(W, H)
+    assert got.shape == (N, T)
+    assert frob_rel(got, ref) < REL_PRIM
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("N,T,K,L", PRIM_SHAPES)
+def test_tensor_transconv(cmf, oracle, N, T, K, L):
+    W, _, X = rand_problem(2, N, T, K, L)
+    got = cmf.tensor_transconv(W, X)
+    ref = oracle.tensor_transconv(W, X)
+    assert got.shape == (K, T)
+    assert frob_rel(got, ref) < REL_PRIM
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+
+
+def test_conv_truncation_at_edges(cmf):
+    """common.jl:29-31: terms with t-l < 1 are dropped; impulses in H make that visible exactly."""
+    K, N, L, T = 2, 3, 4, 10
+    W = np.arange(1, K * N * L + 1, dtype=np.float64).reshape(K, N, L)
+    H = np.zeros((K, T))
+    H[1, 0] = 1.0      # est[:, l] = W[1, :, l] for l < L
+    H[0, T - 2] = 2.0  # only lags 0 and 1 fit before the right edge
+    expect = np.zeros((N, T))
+    expect[:, :L] = W[1]
+    expect[:, T - 2] = 2 * W[0, :, 0]
+    expect[:, T - 1] = 2 * W[0, :, 1]
+    np.testing.assert_array_equal(cmf.tensor_conv(W, H), expect)
+    # transconv drops t+l > T (common.jl:76-78): an impulse in X at the last column reaches
+    # out[:, T-1-l] through lag l only
+    X = np.zeros((N, T))
+    X[2, T - 1] = 1.0
+    out = cmf.tensor_transconv(W, X)
+    expect_t = np.zeros((K, T))
+    for l in range(L):
+        expect_t[:, T - 1 - l] = W[:, 2, l]
+    np.testing.assert_array_equal(out, expect_t)
+
+
+@pytest.mark.parametrize("N,T,K,L", [(48, 300, 4, 8), (130, 700, 32, 20), (37, 150, 33, 7), (20, 200, 6, 40), (6, 3, 2, 5)])
+@pytest.mark.parametrize("reg", [dict(), dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2)])
+def test_single_iteration(cmf, oracle, N, T, K, L, reg):
+    """One update_motifs! + update_feature_maps! (mult.jl:23-58) against the oracle."""
+    W0, H0, data = rand_problem(3, N, T, K, L)
+    rule = cmf.MultUpdate(data, W0, H0)
+    rule.update_motifs(l1W=reg.get("l1W", 0), l2W=reg.get("l2W", 0))
+    Wg, _ = rule.download()
+    loss = rule.update_feature_maps(l1H=reg.get("l1H", 0), l2H=reg.get("l2H", 0))
+    Wg2, Hg = rule.download()
+    rule.close()
+    Wr, Hr = W0.copy(), H0.copy()
+    orule = oracle.MultUpdate(data, Wr, Hr)
+    oracle.update_motifs(orule, data, Wr, Hr, l1W=reg.get("l1W", 0), l2W=reg.get("l2W", 0))
+    assert frob_rel(Wg, Wr) < 1e-5
+    lr = oracle.update_feature_maps(orule, data, Wr, Hr, l1H=reg.get("l1H", 0), l2H=reg.get("l2H", 0))
+    np.testing.assert_array_equal(Wg, Wg2)  # update_feature_maps! does not touch W
+    assert frob_rel(Hg, Hr) < 1e-5
+    assert abs(loss - lr) <= 1e-5 * lr
+
+
+@pytest.mark.parametrize("name", ["mu_small", "mu_small_reg", "mu_k5"])
+def test_golden_fit(cmf, name):
+    """Full fits against the committed fixtures (tests/golden/make_golden.py)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    data, W0, H0 = g["data"], g["W0"], g["H0"]
+    K, N, L = W0.shape
+    res = cmf.fit_cnmf(data, L=L, K=K, alg=":mult", max_itr=int(g["max_itr"]), check_convergence=False,
+                       W_init=W0, H_init=H0, l1_W=float(g["l1W"]), l2_W=float(g["l2W"]),
+                       l1_H=float(g["l1H"]), l2_H=float(g["l2H"]))
+    assert len(res.loss_hist) == int(g["max_itr"]) + 1 and res.time_hist[0] == 0.0
+    np.testing.assert_allclose(res.loss_hist, g["loss_hist"], rtol=REL_LOSS)
+    assert frob_rel(res.W, g["W"]) < REL_FACTORS
+    assert frob_rel(res.H, g["H"]) < REL_FACTORS
+    assert frob_rel(cmf.tensor_conv(W0, H0), g["conv0"]) < REL_PRIM
+    assert frob_rel(cmf.tensor_transconv(W0, data), g["transconv0"]) < REL_PRIM
+
+
+def test_fit_k32_l20_against_oracle(cmf, oracle):
+    """Config-2 K and L at a size the oracle finishes in seconds; gen_synthetic inputs, init seed 0."""
+    data, _, _ = oracle.c_gen_synthetic(N=200, T=3000, K=3, L=20, seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=20, K=32, seed=0)
+    res = cmf.fit_cnmf(data, L=20, K=32, alg=cmf.MultUpdate, max_itr=30, check_convergence=False, W_init=W0, H_init=H0)
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=30, check_convergence=False)
+    np.testing.assert_allclose(res.loss_hist, lr, rtol=REL_LOSS)
+    assert frob_rel(res.W, Wr) < REL_FACTORS
+    assert frob_rel(res.H, Hr) < REL_FACTORS
+    assert np.all(np.diff(res.loss_hist) <= 1e-6)  # un-regularised MU is monotone
+
+
+def test_fit_regularised_k32(cmf, oracle):
+    """Config-4 regularisers (README.md:52) on the same problem."""
+    data, _, _ = oracle.c_gen_synthetic(N=150, T=2000, K=3, L=20, seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=20, K=32, seed=0)
+    reg = dict(l1_H=0.1, l2_H=0.2, l1_W=0.1, l2_W=0.5)
+    res = cmf.fit_cnmf(data, L=20, K=32, alg=":mult", max_itr=20, check_convergence=False, W_init=W0, H_init=H0, **reg)
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=20, check_convergence=False, l1H=0.1, l2H=0.2, l1W=0.1, l2W=0.5)
+    np.testing.assert_allclose(res.loss_hist, lr, rtol=REL_LOSS)
+    assert frob_rel(res.W, Wr) < REL_FACTORS
+    assert frob_rel(res.H, Hr) < REL_FACTORS
+
+
+def test_early_stop_eval_mode_and_native_loop(cmf, oracle):
+    data, _, _ = oracle.c_gen_synthetic(N=40, T=400, K=3, L=8, seed=9)
+    W0, H0 = oracle.c_init_rand(data, L=8, K=4, seed=0)
+    # early stop (alternating.jl:63-66): same stopping iteration as the oracle
+    res = cmf.fit_cnmf(data, L=8, K=4, max_itr=500, tol=1e-3, patience=2, W_init=W0, H_init=H0)
+    _, _, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=500, tol=1e-3, patience=2)
+    assert len(res.loss_hist) == len(lr) < 501
+    np.testing.assert_allclose(res.loss_hist, lr, rtol=REL_LOSS)
+    # eval_mode (alternating.jl:51-53): W untouched
+    res2 = cmf.fit_cnmf(data, L=8, K=4, max_itr=5, eval_mode=True, check_convergence=False, W_init=W0, H_init=H0)
+    assert frob_rel(res2.W, W0) < 1e-7  # fp32 round trip only
+    assert res2.loss_hist[-1] < res2.loss_hist[0]
+    # the in-library loop (cmf_fit) reproduces the host loop bit for bit
+    rule = cmf.MultUpdate(data, W0, H0)
+    lh, th, early = rule.fit_native(25, np.inf, False, 3, 1e-4, False)
+    rule.close()
+    res3 = cmf.fit_cnmf(data, L=8, K=4, max_itr=25, check_convergence=False, W_init=W0, H_init=H0)
+    np.testing.assert_array_equal(lh, res3.loss_hist)
+    assert th[0] == 0.0 and not early and np.all(np.diff(th) > 0)
+
+
+def test_deterministic(cmf, oracle):
+    """Slab reductions instead of atomics: two runs agree bit for bit."""
+    data, _, _ = oracle.c_gen_synthetic(N=130, T=1500, K=3, L=20, seed=4)
+    W0, H0 = oracle.c_init_rand(data, L=20, K=32, seed=0)
+    a = cmf.fit_cnmf(data, L=20, K=32, max_itr=5, check_convergence=False, W_init=W0, H_init=H0)
+    b = cmf.fit_cnmf(data, L=20, K=32, max_itr=5, check_convergence=False, W_init=W0, H_init=H0)
+    np.testing.assert_array_equal(a.loss_hist, b.loss_hist)
+    np.testing.assert_array_equal(a.W, b.W)
+    np.testing.assert_array_equal(a.H, b.H)
+
+
+def test_init_rand_and_gen_synthetic_match_oracle(cmf, oracle):
+    """Same RNG spec on both sides; the product's conv runs in fp32 on the device."""
+    data, W, H = cmf.gen_synthetic(N=60, T=500, K=3, L=20, seed=1234, return_factors=True)
+    d2, W2, H2 = oracle.c_gen_synthetic(N=60, T=500, K=3, L=20, seed=1234)
+    np.testing.assert_allclose(W, W2, rtol=1e-13)
+    np.testing.assert_allclose(H, H2, rtol=1e-13)
+    assert frob_rel(data, d2) < 1e-6
+    Wi, Hi = cmf.init_rand(d2, L=10, K=5, seed=0)
+    Wo, Ho = oracle.c_init_rand(d2, L=10, K=5, seed=0)
+    assert frob_rel(Wi, Wo) < 1e-6 and frob_rel(Hi, Ho) < 1e-6
+    # seeded fit_cnmf is reproducible and equals explicit init (model.jl:64-73)
+    r1 = cmf.fit_cnmf(d2, L=10, K=5, max_itr=3, seed=0, check_convergence=False)
+    r2 = cmf.fit_cnmf(d2, L=10, K=5, max_itr=3, check_convergence=False, W_init=Wi, H_init=Hi)
+    np.testing.assert_array_equal(r1.loss_hist, r2.loss_hist)
+
+
+def test_errors(cmf):
+    lib = cmf.load_library()
+    h = ctypes.c_void_p()
+    d = np.zeros((4, 4), order="F")
+    rc = lib.cmf_create(ctypes.byref(h), 0, 0, 4, 2, 2, d.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    assert rc == 1 and b">= 1" in lib.cmf_last_error()
+    rc = lib.cmf_create(ctypes.byref(h), 0, 4, 4, 2, 2, None)
+    assert rc == 1
+    rc = lib.cmf_create(ctypes.byref(h), 9999, 4, 4, 2, 2, d.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    assert rc == 1
+    with pytest.raises(ValueError):
+        cmf.MultUpdate(np.zeros((4, 6)), np.zeros((2, 5, 3)), np.zeros((2, 6)))  # N mismatch
+    with pytest.raises(NotImplementedError):
+        cmf.fit_cnmf(np.ones((4, 6)), alg=":hals")
+    rule = cmf.MultUpdate(np.ones((4, 6)), np.ones((2, 4, 3)), np.ones((2, 6)))
+    with pytest.raises(cmf.CMFError):
+        rule.fit_native(3, np.inf, True, 0, 1e-4, False)  # patience >= 1 (alternating.jl:30)
+    rule.close()
+
+
+# ---- full-size (BASELINE.json config 2) size-independent properties --------------------------
+@pytest.fixture(scope="module")
+def config2(cmf):
+    N, T, K, L = 2000, 50000, 32, 20
+    data = cmf.gen_synthetic(N=N, T=T, seed=1234)
+    W0, H0 = cmf.init_rand(data, L=L, K=K, seed=0)
+    return data, W0, H0
+
+
+def test_config2_adjointness(cmf, config2):
+    """<conv(W,H), X> == <H, transconv(W,X)> at N=2000, T=50000, K=32, L=20."""
+    data, W0, H0 = config2
+    est = cmf.tensor_conv(W0, H0)
+    lhs = float(np.vdot(est, data))
+    del est
+    tc = cmf.tensor_transconv(W0, data)
+    rhs = float(np.vdot(H0, tc))
+    assert abs(lhs - rhs) <= 2e-6 * abs(lhs)
+
+
+def test_config2_iterations(cmf, config2):
+    """Monotone loss, bitwise repeatability and linearity of conv in H at full size."""
+    data, W0, H0 = config2
+    a = cmf.fit_cnmf(data, L=20, K=32, max_itr=4, check_convergence=False, W_init=W0, H_init=H0)
+    assert len(a.loss_hist) == 5 and np.all(np.diff(a.loss_hist) < 0)
+    assert np.all(a.W >= cmf.EPSILON) and np.all(a.H >= cmf.EPSILON)  # clamp floor (mult.jl:38,52)
+    b = cmf.fit_cnmf(data, L=20, K=32, max_itr=4, check_convergence=False, W_init=W0, H_init=H0)
+    np.testing.assert_array_equal(a.loss_hist, b.loss_hist)
+    np.testing.assert_array_equal(a.H, b.H)
+    # init_rand scaling is the least-squares one: <data - est, est> ~ 0 (model.jl:120)
+    est = cmf.tensor_conv(W0, H0)
+    assert abs(np.vdot(data - est, est)) <= 1e-5 * np.vdot(est, est)

@@ -1,0 +1,60 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads and exports every
+symbol include/cmf_hip.h declares, and fails loudly (no fallback) without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cmf():
+    import __graft_entry__
+
+    __graft_entry__.build()
+    import cmf_jl_amd as m
+
+    return m
+
+
+def test_header_symbols_all_exported(cmf):
+    hdr = open(os.path.join(ROOT, "include", "cmf_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(cmf_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(cmf.SYMBOLS), "binding table and header disagree"
+    lib = ctypes.CDLL(cmf.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/cmf_hip.h but not exported"
+
+
+def test_version_and_host_only_entries(cmf):
+    lib = cmf.load_library()
+    assert lib.cmf_version().startswith(b"cmf_hip gfx950")
+    # converged is pure host arithmetic (model.jl:91-107)
+    assert not cmf.converged([1.0, 1.0, 1.0], 3, 1e-4)
+    assert cmf.converged([1.0, 1.0, 1.0, 1.0], 3, 1e-4)
+    assert not cmf.converged([2.0, 1.0, 1.0, 1.0], 3, 1e-4)
+    assert cmf.converged([1.0, 1.00005], 1, 1e-4)
+
+
+def test_no_cpu_fallback(cmf):
+    """Without a HIP device every compute entry must raise, never silently compute on the CPU."""
+    lib = cmf.load_library()
+    if lib.cmf_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(cmf.CMFError) as ei:
+        cmf.tensor_conv(np.ones((2, 3, 2)), np.ones((2, 5)))
+    assert ei.value.code == 2
+    with pytest.raises(cmf.CMFError):
+        cmf.fit_cnmf(np.ones((4, 16)), L=2, K=2, max_itr=1)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under cmf.jl_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "cmf.jl_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".jl")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in txt.lower(), f"{f} mentions the oracle"
