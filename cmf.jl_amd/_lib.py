@@ -25,7 +25,7 @@ SYMBOLS = [
     "cmf_set_factors", "cmf_get_factors",
     "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_fit", "cmf_converged",
     "cmf_w_partial", "cmf_w_apply", "cmf_h_update", "cmf_loss_partial",
-    "cmf_numden_ptr", "cmf_halo_ptr", "cmf_halo_pack", "cmf_halo_unpack",
+    "cmf_numden_ptr", "cmf_set_numden_buffer", "cmf_halo_ptr", "cmf_set_halo_buffer", "cmf_halo_pack", "cmf_halo_unpack",
     "cmf_tensor_conv", "cmf_tensor_transconv", "cmf_init_rand", "cmf_gen_synthetic",
     "cmf_time_kernel",
 ]
@@ -79,7 +79,9 @@ def load():
     sig("cmf_h_update", [vp, dbl, dbl])
     sig("cmf_loss_partial", [vp, pd])
     sig("cmf_numden_ptr", [vp, pvp, pi64])
+    sig("cmf_set_numden_buffer", [vp, vp])
     sig("cmf_halo_ptr", [vp, cint, pvp, pi64])
+    sig("cmf_set_halo_buffer", [vp, cint, vp])
     sig("cmf_halo_pack", [vp])
     sig("cmf_halo_unpack", [vp, cint, cint])
     sig("cmf_tensor_conv", [cint, i64, i64, i64, i64, pd, pd, pd])

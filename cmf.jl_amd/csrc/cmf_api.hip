@@ -69,8 +69,10 @@ struct cmf_handle_s {
     float *X = nullptr, *XT = nullptr, *est = nullptr, *estT = nullptr;
     float *wslabs = nullptr; // [nchunks][2][L][K32][Np]
     float *numden = nullptr; // [2][L][K32][Np]   (summed; the all-reduce buffer)
+    float *numden_own = nullptr;
     float *hslabs = nullptr; // [S][2][Tl][K32]
     float *halo[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *halo_own[4] = {nullptr, nullptr, nullptr, nullptr};
     double *partial = nullptr; // loss partials
     double *d_scalar = nullptr; // device double[4]
     double *h_scalar = nullptr; // pinned host double[4]
@@ -146,8 +148,8 @@ static void destroy_impl(cmf_handle_s *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden, h->hslabs,
-                      h->halo[0], h->halo[1], h->halo[2], h->halo[3]};
+    float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
+                      h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3]};
     for (float *p : fbufs)
         if (p) (void)hipFree(p);
     if (h->partial) (void)hipFree(h->partial);
@@ -239,9 +241,13 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     TRYB(dalloc_zero(&h->est, TPNp));
     TRYB(dalloc_zero(&h->estT, TPNp));
     TRYB(dalloc_zero(&h->wslabs, (size_t)h->hxt_nchunks * 2 * d.L * d.K32 * d.Np));
-    TRYB(dalloc_zero(&h->numden, (size_t)2 * d.L * d.K32 * d.Np));
+    TRYB(dalloc_zero(&h->numden_own, (size_t)2 * d.L * d.K32 * d.Np));
+    h->numden = h->numden_own;
     TRYB(dalloc_zero(&h->hslabs, (size_t)h->tc_S * 2 * d.Tl * d.K32));
-    for (int w = 0; w < 4; ++w) TRYB(dalloc_zero(&h->halo[w], (size_t)std::max(1, d.L - 1) * d.K32));
+    for (int w = 0; w < 4; ++w) {
+        TRYB(dalloc_zero(&h->halo_own[w], (size_t)std::max(1, d.L - 1) * d.K32));
+        h->halo[w] = h->halo_own[w];
+    }
     TRYB(dalloc_zero(&h->partial, n_partial(h)));
     TRYB(dalloc_zero(&h->d_scalar, 4));
     HIPB(hipHostMalloc(&h->h_scalar, 4 * sizeof(double)));
@@ -419,7 +425,7 @@ int cmf_destroy(cmf_handle h)
 int cmf_set_stream(cmf_handle h, void *hip_stream)
 {
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->stream = (hipStream_t)hip_stream;
     return CMF_OK;
 }
 
@@ -587,6 +593,21 @@ int cmf_numden_ptr(cmf_handle h, void **dev_ptr, int64_t *count)
     if (!h || !dev_ptr || !count) return fail(CMF_ERR_ARG, "NULL argument");
     *dev_ptr = h->numden;
     *count = (int64_t)2 * h->d.L * h->d.K32 * h->d.Np;
+    return CMF_OK;
+}
+
+int cmf_set_numden_buffer(cmf_handle h, void *dev_ptr)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    h->numden = dev_ptr ? (float *)dev_ptr : h->numden_own;
+    return CMF_OK;
+}
+
+int cmf_set_halo_buffer(cmf_handle h, int which, void *dev_ptr)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (which < 0 || which > 3) return fail(CMF_ERR_ARG, "which must be 0..3");
+    h->halo[which] = dev_ptr ? (float *)dev_ptr : h->halo_own[which];
     return CMF_OK;
 }
 

@@ -287,6 +287,8 @@ def fit(alg, data, L, K, W_init, H_init, verbose=False, **kwargs):
             rule.update_motifs(data, W, H, **kwargs)
         loss = rule.update_feature_maps(data, W, H, **kwargs)  # :54 (synchronises)
         dur = time.time() - t0
+        if hasattr(rule, "agree_scalar"):
+            dur = rule.agree_scalar(dur)  # sharded rule: all ranks follow rank 0's clock, so they stop together
         time_hist.append(time_hist[-1] + dur)  # :57-59
         loss_hist.append(loss)
         if verbose:

@@ -68,7 +68,9 @@ int cmf_create_shard(cmf_handle *h, int device, int64_t N, int64_t T_local, int6
 int cmf_destroy(cmf_handle h);
 
 /* Run all work of this handle on an existing HIP stream (hipStream_t passed
- * as void*), e.g. torch's current stream; NULL = the handle's own stream. */
+ * as void*), e.g. torch's current stream.  NULL is the HIP null (legacy
+ * default) stream -- which is what torch's default "current stream" is.
+ * A new handle runs on a private non-blocking stream until this is called. */
 int cmf_set_stream(cmf_handle h, void *hip_stream);
 
 /* sum(data.^2) over the columns this handle owns (fp64); and the setter used
@@ -128,6 +130,10 @@ int cmf_loss_partial(cmf_handle h, double *sumsq);
 /* Device pointer (fp32) of the contiguous [numW | denomW] buffer and its
  * length in floats (same on every rank: 2 * L * Kpad * Npad). */
 int cmf_numden_ptr(cmf_handle h, void **dev_ptr, int64_t *count);
+/* Use a caller-owned device buffer of the same length for [numW | denomW] instead (e.g. the
+ * storage of a torch tensor, so torch.distributed can all-reduce it in place); NULL restores
+ * the handle's own buffer.  The caller keeps the buffer alive while the handle uses it. */
+int cmf_set_numden_buffer(cmf_handle h, void *dev_ptr);
 /* H halo staging buffers (device, fp32, (L-1) * Kpad floats each):
  *   which = 0: send-to-left  (own first L-1 columns)   -> left rank's right halo
  *   which = 1: send-to-right (own last  L-1 columns)   -> right rank's left halo
@@ -136,6 +142,8 @@ int cmf_numden_ptr(cmf_handle h, void **dev_ptr, int64_t *count);
  * cmf_halo_pack fills the send buffers from H; cmf_halo_unpack installs the
  * recv buffers (has_left/has_right say which were actually received). */
 int cmf_halo_ptr(cmf_handle h, int which, void **dev_ptr, int64_t *count);
+/* Caller-owned replacement for staging buffer `which` (same length; NULL restores the handle's own). */
+int cmf_set_halo_buffer(cmf_handle h, int which, void *dev_ptr);
 int cmf_halo_pack(cmf_handle h);
 int cmf_halo_unpack(cmf_handle h, int has_left, int has_right);
 

@@ -1,0 +1,95 @@
+"""Multi-process tests of the T-sharded path.
+
+CPU (gloo, world_size 2 and 3): the orchestration in cmf_jl_amd.sharded against the unsharded
+oracle, with a numpy stand-in for the per-rank engine.
+GPU (gloo between two processes that share the one GPU of the test box): the same orchestration
+on the real HIP engine, so the kernels' halo handling is checked against the oracle too.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_ranks(world, engine, out, N, T, K, L, iters, reg, timeout=300):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), engine, out,
+                                       str(N), str(T), str(K), str(L), str(iters), str(int(reg))],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=timeout)
+            logs.append(o.decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    return np.load(out)
+
+
+def frob_rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def test_partition():
+    from cmf_jl_amd.sharded import partition
+
+    assert partition(10, 1, 4) == [(0, 10)]
+    assert partition(10, 2, 4) == [(0, 5), (5, 10)]
+    b = partition(50000, 8, 20)
+    assert b[0] == (0, 6250) and b[-1] == (43750, 50000) and all(t1 - t0 == 6250 for t0, t1 in b)
+    assert partition(11, 3, 3) == [(0, 4), (4, 8), (8, 11)]
+    with pytest.raises(ValueError):
+        partition(10, 8, 20)
+
+
+@pytest.mark.parametrize("world,reg", [(2, 0), (3, 1)])
+def test_sharded_protocol_cpu_gloo(oracle, tmp_path, world, reg):
+    N, T, K, L, iters = 17, 101, 3, 6, 8
+    out = str(tmp_path / "res.npz")
+    got = run_ranks(world, "cpu", out, N, T, K, L, iters, reg)
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=L, seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2) if reg else {}
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False, **kw)
+    assert len(got["bounds"]) == world
+    np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-10)
+    np.testing.assert_allclose(got["W"], Wr, rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(got["H"], Hr, rtol=1e-8, atol=1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,N,T,K,L,reg", [(2, 130, 900, 32, 20, 0), (3, 40, 333, 5, 10, 1), (1, 48, 300, 4, 8, 0)])
+def test_sharded_hip_engine_gloo(oracle, tmp_path, world, N, T, K, L, reg):
+    """Ranks share GPU 0; collectives go through the host (gloo).  fp32 tolerances as in test_gpu_parity."""
+    iters = 6
+    out = str(tmp_path / "res.npz")
+    got = run_ranks(world, "hip", out, N, T, K, L, iters, reg)
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2) if reg else {}
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False, **kw)
+    np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
+    assert frob_rel(got["W"], Wr) < 1e-4
+    assert frob_rel(got["H"], Hr) < 1e-4
