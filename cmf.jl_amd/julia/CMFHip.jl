@@ -1,0 +1,118 @@
+# CMFHip.jl -- the reference-side binding: a `ccall` layer over libcmf_hip.so (include/cmf_hip.h)
+# that plugs the MI355X multiplicative-update rule into CMF.jl's own plugin boundary
+# (`abstract type AbstractCFUpdate`, src/algs/alternating.jl:1-8).
+#
+# NOT EXECUTED IN THIS REPO'S CI: the build container has no Julia.  The tested twin of this file
+# is cmf.jl_amd/host.py (same entry points, same argument order, same array layouts).  Julia
+# arrays are already in the layout the C ABI expects (column-major Float64), so every call is a
+# plain pointer hand-off.
+#
+# Usage inside CMF.jl (after `include("CMFHip.jl")` in src/CMF.jl, next to algs/mult.jl):
+#
+#     results = fit_cnmf(data; L=20, K=32, alg=HIPMultUpdate, max_itr=100)
+#
+module CMFHip
+
+import ..CMF: AbstractCFUpdate, Tensor
+import ..CMF: update_motifs!, update_feature_maps!
+
+const LIBCMF = get(ENV, "LIBCMF_HIP", "libcmf_hip.so")
+
+function check(rc::Cint)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:cmf_last_error, LIBCMF), Cstring, ()))
+    error("libcmf_hip error $rc: $msg")
+end
+
+"""
+    HIPMultUpdate(data, W, H; device=0)
+
+Drop-in for `MultUpdate(data, W, H)` (src/algs/mult.jl:11-20).  Uploads `data`, `W`, `H`; the
+rule's scratch (est, numW, denomW, numH, denomH) lives on the GPU.  W and H stay device-resident
+between calls and are written back into the caller's arrays after every `update_feature_maps!`
+(the reference mutates W and H in place; mult.jl:37-38, :51-52).
+"""
+mutable struct HIPMultUpdate <: AbstractCFUpdate
+    handle::Ptr{Cvoid}
+    data_norm::Float64
+    sync_every_call::Bool
+end
+
+function HIPMultUpdate(data::Matrix{Float64}, W::Tensor{Float64}, H::Matrix{Float64};
+                       device::Integer=parse(Int, get(ENV, "LOCAL_RANK", "0")), sync_every_call::Bool=true)
+    K, N, L = size(W)
+    T = size(data, 2)
+    size(data, 1) == N || throw(DimensionMismatch("data has $(size(data,1)) rows, W has N=$N"))
+    size(H) == (K, T) || throw(DimensionMismatch("H must be $K x $T"))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:cmf_create, LIBCMF), Cint,
+                (Ref{Ptr{Cvoid}}, Cint, Int64, Int64, Int64, Int64, Ptr{Float64}),
+                h, device, N, T, K, L, data))
+    check(ccall((:cmf_set_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], W, H))
+    ss = Ref{Float64}(0.0)
+    check(ccall((:cmf_get_data_sumsq, LIBCMF), Cint, (Ptr{Cvoid}, Ref{Float64}), h[], ss))
+    rule = HIPMultUpdate(h[], sqrt(ss[]), sync_every_call)
+    finalizer(r -> (r.handle != C_NULL && ccall((:cmf_destroy, LIBCMF), Cint, (Ptr{Cvoid},), r.handle); r.handle = C_NULL), rule)
+    return rule
+end
+
+# update_motifs!(rule, data, W, H; l1W=0, l2W=0)  -- src/algs/mult.jl:23-39, called at alternating.jl:52
+function update_motifs!(rule::HIPMultUpdate, data, W, H; l1W=0, l2W=0, kwargs...)
+    check(ccall((:cmf_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64), rule.handle, l1W, l2W))
+    return W
+end
+
+# update_feature_maps!(rule, data, W, H; l1H=0, l2H=0) -> loss  -- src/algs/mult.jl:42-58, alternating.jl:54
+function update_feature_maps!(rule::HIPMultUpdate, data, W, H; l1H=0, l2H=0, kwargs...)
+    loss = Ref{Float64}(0.0)
+    check(ccall((:cmf_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
+                rule.handle, l1H, l2H, loss))
+    if rule.sync_every_call   # keep the reference's in-place semantics for arbitrary callers
+        check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.handle, W, H))
+    end
+    return loss[]
+end
+
+"Write the device-resident factors into W and H (needed only with `sync_every_call=false`)."
+function download!(rule::HIPMultUpdate, W::Tensor{Float64}, H::Matrix{Float64})
+    check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.handle, W, H))
+    return W, H
+end
+
+# Stand-alone primitives: src/common.jl:17-34, :62-81
+function tensor_conv(W::Tensor{Float64}, H::Matrix{Float64}; device::Integer=0)
+    K, N, L = size(W); T = size(H, 2)
+    est = zeros(N, T)
+    check(ccall((:cmf_tensor_conv, LIBCMF), Cint,
+                (Cint, Int64, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), device, N, T, K, L, W, H, est))
+    return est
+end
+
+function tensor_transconv(W::Tensor{Float64}, X::Matrix{Float64}; device::Integer=0)
+    K, N, L = size(W); T = size(X, 2)
+    out = zeros(K, T)
+    check(ccall((:cmf_tensor_transconv, LIBCMF), Cint,
+                (Cint, Int64, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), device, N, T, K, L, W, X, out))
+    return out
+end
+
+# init_rand(data, L, K): src/model.jl:113-125 (portable RNG; `seed` as in fit_cnmf's kwarg)
+function init_rand(data::Matrix{Float64}, L::Integer, K::Integer; seed::Integer=rand(UInt64), device::Integer=0)
+    N, T = size(data)
+    W = zeros(K, N, L); H = zeros(K, T)
+    check(ccall((:cmf_init_rand, LIBCMF), Cint,
+                (Cint, Int64, Int64, Int64, Int64, UInt64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                device, N, T, K, L, seed % UInt64, data, W, H))
+    return W, H
+end
+
+# gen_synthetic(N=, T=): README.md:14 / datasets/synthetic.jl:29-61
+function gen_synthetic(; N=100, T=500, K=3, L=20, alpha=0.1, p_h=0.5, sigma=0.2, noise_scale=1.0, seed=1234, device::Integer=0)
+    data = zeros(N, T)
+    check(ccall((:cmf_gen_synthetic, LIBCMF), Cint,
+                (Cint, Int64, Int64, Int64, Int64, Float64, Float64, Float64, Float64, UInt64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                device, N, T, K, L, alpha, p_h, sigma, noise_scale, seed % UInt64, data, C_NULL, C_NULL))
+    return data
+end
+
+end # module
