@@ -127,7 +127,7 @@ static void plan(cmf_handle_s *h, int n_cu)
     const int wave_slots = 4 * n_cu * (best <= 5 ? 2 : 1); // resident waves (register-limited)
     int64_t waves_per_chunk = (int64_t)(d.Np / 32) * 2 * d.KB * h->hxt_groups;
     int nch = (int)std::max<int64_t>(1, (wave_slots + waves_per_chunk / 2) / waves_per_chunk);
-    int64_t clen = rup((d.Tl + nch - 1) / nch, 2 * best);
+    int64_t clen = rup((d.Tl + nch - 1) / nch, 6 * best);
     h->hxt_chunk_len = (int)clen;
     h->hxt_nchunks = (int)((d.Tl + clen - 1) / clen);
     // C3 (transconv): S n-ranges so that (t tiles) x 2 x KB x S ~ 2 workgroups per CU x 2 rounds

@@ -39,6 +39,18 @@ struct CmfDims {
 
 __device__ __forceinline__ int cmf_crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// Buffer (SRSRC) loads: a wave-uniform base + one per-lane VGPR offset + a scalar offset per load,
+// instead of a 64-bit per-lane address per load (saves the address VGPRs of long unrolled streams).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cmf_rsrc(const void *base, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0,
+                                             (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes), 0x00020000);
+}
+__device__ __forceinline__ float cmf_bload(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
+}
+
 // ---------------------------------------------------------------------------------------------
 // C1: tensor_conv.  One workgroup = 128 (t) x 128 (n) output tile, 4 waves as 2x2, each wave a
 // 64x64 sub-tile = 2x2 MFMA blocks.  The K-row H strip of the tile (with its left lag halo) is
@@ -129,43 +141,50 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p)
                     for (int q = 0; q < 4; ++q)
                         wreg[q] = *reinterpret_cast<const f32x4 *>(src + (size_t)(wrow + 8 * q) * Np + wcol);
                 }
+                // keep the global prefetch ahead of the MFMA stream (the scheduler otherwise sinks it
+                // below the 64 MFMAs and exposes the whole L2 latency before the barrier)
+                __builtin_amdgcn_sched_barrier(0);
                 // operands of lag l: H window shifted left by (l - lbeg)
                 const float *hsb = Hs + h * CONV_HS_STRIDE + 32 + wt * 64 + i - (l - lbeg);
                 const float *wsb = Ws + buf * CONV_WS_FLOATS + h * 128 + wn * 64 + i;
+#define CONV_MFMA4(A0, A1, B0, B1)                                                                  \
+    if (MODE == 1) {                                                                                \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(B0, A0, acc[0][0], 0, 0, 0);               \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(B0, A1, acc[0][1], 0, 0, 0);               \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(B1, A0, acc[1][0], 0, 0, 0);               \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(B1, A1, acc[1][1], 0, 0, 0);               \
+    } else {                                                                                        \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, acc[0][0], 0, 0, 0);               \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B1, acc[0][1], 0, 0, 0);               \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B0, acc[1][0], 0, 0, 0);               \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, acc[1][1], 0, 0, 0);               \
+    }
                 if (NKP_CT != 0) {
+                    // software-pipelined: the LDS reads of step kp+1 are issued before the MFMAs of step kp
+                    float a0 = hsb[0], a1 = hsb[32], b0 = wsb[0], b1 = wsb[32];
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); // the two ds_read2 of step 0
 #pragma unroll
                     for (int kp = 0; kp < NKP_CT; ++kp) {
-                        float a0 = hsb[kp * 2 * CONV_HS_STRIDE], a1 = hsb[kp * 2 * CONV_HS_STRIDE + 32];
-                        float b0 = wsb[kp * 256], b1 = wsb[kp * 256 + 32];
-                        if (MODE == 1) {
-                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
-                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[0][1], 0, 0, 0);
-                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[1][0], 0, 0, 0);
-                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
-                        } else {
-                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+                        if (kp + 1 < NKP_CT) {
+                            na0 = hsb[(kp + 1) * 2 * CONV_HS_STRIDE];
+                            na1 = hsb[(kp + 1) * 2 * CONV_HS_STRIDE + 32];
+                            nb0 = wsb[(kp + 1) * 256];
+                            nb1 = wsb[(kp + 1) * 256 + 32];
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); // reads of step kp+1 ...
                         }
+                        CONV_MFMA4(a0, a1, b0, b1)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // ... ahead of the MFMAs of step kp
+                        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
                     }
                 } else {
                     for (int kp = 0; kp < nkp; ++kp) {
                         float a0 = hsb[kp * 2 * CONV_HS_STRIDE], a1 = hsb[kp * 2 * CONV_HS_STRIDE + 32];
                         float b0 = wsb[kp * 256], b1 = wsb[kp * 256 + 32];
-                        if (MODE == 1) {
-                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
-                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[0][1], 0, 0, 0);
-                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[1][0], 0, 0, 0);
-                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
-                        } else {
-                            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                        }
+                        CONV_MFMA4(a0, a1, b0, b1)
                     }
                 }
+#undef CONV_MFMA4
                 if (more) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
@@ -239,10 +258,41 @@ struct HxtParams {
     const float *X1; // est  [TP][Np]
     float *slabs;    // [nchunks][2][L][K32][Np]
     int Np, K32, KB, PADL, L, Tl;
-    int chunk_len;   // multiple of 2*LP
+    int chunk_len;   // multiple of 6*LP
     int G;           // lag groups of 2*LP lags (fastest-varying part of blockIdx.x, so the groups
                      // that re-read the same X rows are dispatched together)
 };
+
+// E[u] = R(2u), O[u] = R(2u-1), B[u] = X rows (2u, 2u+1) of the group that starts `row` rows after the
+// bases of the two buffer descriptors (hoff/xoff: per-lane byte offsets; rows as scalar offsets)
+template <int LP>
+__device__ __forceinline__ void hxt_load(float (&E)[LP], float (&O)[LP], float (&B)[LP], __amdgpu_buffer_rsrc_t hr,
+                                         __amdgpu_buffer_rsrc_t xr, int hoff, int xoff, int row, int K32, int Np)
+{
+#pragma unroll
+    for (int u = 0; u < LP; ++u) {
+        E[u] = cmf_bload(hr, hoff, (row + 2 * u + 1) * K32 * 4);
+        O[u] = cmf_bload(hr, hoff, (row + 2 * u) * K32 * 4);
+        B[u] = cmf_bload(xr, xoff, (row + 2 * u) * Np * 4);
+    }
+}
+
+// the 2*LP*LP MFMAs of one group: step u, lag pair m uses E/O of step u-m (previous group's ring when u < m)
+template <int LP>
+__device__ __forceinline__ void hxt_group(f32x16 (&acc)[2 * LP], const float (&Ep)[LP], const float (&Op)[LP],
+                                          const float (&Ec)[LP], const float (&Oc)[LP], const float (&Bc)[LP])
+{
+#pragma unroll
+    for (int u = 0; u < LP; ++u) {
+#pragma unroll
+        for (int m = 0; m < LP; ++m) {
+            const float ae = (u - m >= 0) ? Ec[(u - m >= 0) ? (u - m) : 0] : Ep[(u - m >= 0) ? 0 : (u - m + LP)];
+            const float ao = (u - m >= 0) ? Oc[(u - m >= 0) ? (u - m) : 0] : Op[(u - m >= 0) ? 0 : (u - m + LP)];
+            acc[2 * m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, Bc[u], acc[2 * m], 0, 0, 0);
+            acc[2 * m + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, Bc[u], acc[2 * m + 1], 0, 0, 0);
+        }
+    }
+}
 
 template <int LP>
 __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
@@ -260,12 +310,16 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
     const int tc0 = c * p.chunk_len;
     int tc1 = tc0 + p.chunk_len;
     if (tc1 > p.Tl) tc1 = p.Tl;
-    const int ngroups = (tc1 > tc0) ? (tc1 - tc0 + 2 * LP - 1) / (2 * LP) : 0;
+    const int ngroups = (tc1 > tc0) ? (tc1 - tc0 + 6 * LP - 1) / (6 * LP) * 3 : 0;
 
-    // R(q)[lane] = H[PADL + tc0 + q + h - lag0][kb*32 + i]
-    const float *hp = p.H + (size_t)(p.PADL + tc0 + h - lag0) * K32 + kb * 32 + i;
-    // B(s)[lane] = X[PADL + tc0 + 2s + h][nb*32 + i]
-    const float *xp = X + (size_t)(p.PADL + tc0 + h) * Np + nb * 32 + i;
+    // Descriptor bases (wave-uniform).  H: row (PADL + tc0 - lag0 - 2*LP - 1), so that R(q) of the text
+    // is row offset q + 2*LP + 1 >= 0;  X: row (PADL + tc0 - 2*LP) for the same group numbering.
+    const float *hbase = p.H + (size_t)(p.PADL + tc0 - lag0 - 2 * LP - 1) * K32;
+    const float *xbase = X + (size_t)(p.PADL + tc0 - 2 * LP) * Np;
+    const __amdgpu_buffer_rsrc_t hr = cmf_rsrc(hbase, (size_t)(p.chunk_len + 12 * LP + 8) * K32 * 4);
+    const __amdgpu_buffer_rsrc_t xr = cmf_rsrc(xbase, (size_t)(p.chunk_len + 12 * LP + 8) * Np * 4);
+    const int hoff = (h * K32 + kb * 32 + i) * 4;
+    const int xoff = (h * Np + nb * 32 + i) * 4;
 
     f32x16 acc[2 * LP];
 #pragma unroll
@@ -273,42 +327,26 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    float Ep[LP], Op[LP], Ec[LP], Oc[LP], Bc[LP], En[LP], On[LP], Bn[LP];
+    // Three register sets rotate through the roles (previous group's ring, current group, prefetch
+    // of the next group), so no register copies exist and the loads issued at the top of one group
+    // are first needed a whole group (2*LP*LP MFMAs) later.
+    float E0[LP], O0[LP], B0[LP], E1[LP], O1[LP], B1[LP], E2[LP], O2[LP], B2[LP];
     if (ngroups > 0) {
-#pragma unroll
-        for (int u = 0; u < LP; ++u) {
-            Ep[u] = hp[(ptrdiff_t)(2 * (u - LP)) * K32];
-            Op[u] = hp[(ptrdiff_t)(2 * (u - LP) - 1) * K32];
-            Ec[u] = hp[(ptrdiff_t)(2 * u) * K32];
-            Oc[u] = hp[(ptrdiff_t)(2 * u - 1) * K32];
-            Bc[u] = xp[(size_t)(2 * u) * Np];
-        }
-    }
-    for (int g = 0; g < ngroups; ++g) {
-        if (g + 1 < ngroups) {
-            const float *hq = hp + (size_t)(2 * LP) * (g + 1) * K32;
-            const float *xq = xp + (size_t)(2 * LP) * (g + 1) * Np;
-#pragma unroll
-            for (int u = 0; u < LP; ++u) {
-                En[u] = hq[(ptrdiff_t)(2 * u) * K32];
-                On[u] = hq[(ptrdiff_t)(2 * u - 1) * K32];
-                Bn[u] = xq[(size_t)(2 * u) * Np];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LP; ++u) {
-#pragma unroll
-            for (int m = 0; m < LP; ++m) {
-                float ae = (u - m >= 0) ? Ec[(u - m >= 0) ? (u - m) : 0] : Ep[(u - m >= 0) ? 0 : (u - m + LP)];
-                float ao = (u - m >= 0) ? Oc[(u - m >= 0) ? (u - m) : 0] : Op[(u - m >= 0) ? 0 : (u - m + LP)];
-                acc[2 * m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, Bc[u], acc[2 * m], 0, 0, 0);
-                acc[2 * m + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, Bc[u], acc[2 * m + 1], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LP; ++u) {
-            Ep[u] = Ec[u]; Op[u] = Oc[u];
-            Ec[u] = En[u]; Oc[u] = On[u]; Bc[u] = Bn[u];
+        hxt_load<LP>(E0, O0, B0, hr, xr, hoff, xoff, 0, K32, Np);      // ring of group -1 (its B is unused)
+        hxt_load<LP>(E1, O1, B1, hr, xr, hoff, xoff, 2 * LP, K32, Np); // group 0
+        // ngroups is a multiple of 3 (chunk_len is a multiple of 6*LP; a ragged last chunk is rounded
+        // up and reads zero rows of X), so the body is straight-line code: no exits inside a rotation.
+        for (int g = 0; g < ngroups; g += 3) {
+            const int g3 = (g + 3 < ngroups) ? g + 3 : g;
+            hxt_load<LP>(E2, O2, B2, hr, xr, hoff, xoff, 2 * LP * (g + 2), K32, Np);
+            __builtin_amdgcn_sched_barrier(0);
+            hxt_group<LP>(acc, E0, O0, E1, O1, B1);
+            hxt_load<LP>(E0, O0, B0, hr, xr, hoff, xoff, 2 * LP * (g + 3), K32, Np);
+            __builtin_amdgcn_sched_barrier(0);
+            hxt_group<LP>(acc, E1, O1, E2, O2, B2);
+            hxt_load<LP>(E1, O1, B1, hr, xr, hoff, xoff, 2 * LP * (g3 + 1), K32, Np);
+            __builtin_amdgcn_sched_barrier(0);
+            hxt_group<LP>(acc, E2, O2, E0, O0, B0);
         }
     }
 
@@ -351,6 +389,35 @@ struct TcParams {
 #define TC_CHUNK (8 * TC_ROW)
 
 template <int LT>
+__device__ __forceinline__ void tc_load_w(float (&b)[LT], __amdgpu_buffer_rsrc_t wr, int woff, int row, int K32, int lagbytes)
+{
+#pragma unroll
+    for (int l = 0; l < LT; ++l) b[l] = cmf_bload(wr, woff, row * K32 * 4 + l * lagbytes);
+}
+
+// one n pair: LT lags x 4 t blocks; the LDS reads of lag l+1 are issued ahead of the MFMAs of lag l
+template <int LT>
+__device__ __forceinline__ void tc_pair(f32x16 (&acc)[4], const float *sa, const float (&b)[LT])
+{
+    float a0 = sa[0], a1 = sa[32], a2 = sa[64], a3 = sa[96];
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
+        if (l + 1 < LT) {
+            n0 = sa[l + 1]; n1 = sa[l + 33]; n2 = sa[l + 65]; n3 = sa[l + 97];
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[l], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[l], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b[l], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b[l], acc[3], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+    }
+}
+
+template <int LT>
 __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
 {
     __shared__ __attribute__((aligned(16))) float smem[4 * 2 * TC_CHUNK];
@@ -386,49 +453,45 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
                 int idx = lane + 64 * q, row = idx / 40, c4 = idx - row * 40;
                 xr[q] = *reinterpret_cast<const f32x4 *>(xsrc + (size_t)row * TP + c4 * 4);
             }
-            // W operand for n pair `it`: Wn[lb*32 + l][nlo + 2*it + h][kb*32 + i]
-            const float *wb = p.Wn + ((size_t)(lb * 32) * Np + nlo + h) * K32 + kb * 32 + i;
-            float bc[LT], bn[LT];
-#pragma unroll
-            for (int l = 0; l < LT; ++l) bc[l] = wb[l * lagstride];
+            // W operand for n pair `it`: Wn[lb*32 + l][nlo + 2*it + h][kb*32 + i]  (descriptor base: lag lb*32)
+            const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wn + (size_t)(lb * 32) * lagstride, (size_t)LT * lagstride * 4);
+            const int woff = (h * K32 + kb * 32 + i) * 4;
+            const int lagbytes = (int)(lagstride * 4);
+            float b0[LT], b1[LT]; // ping-pong: no register copies, so a load is first needed one pair later
+            tc_load_w<LT>(b0, wr, woff, nlo, K32, lagbytes);
+            const int nchunks = npairs >> 2;
             int buf = 0;
-            for (int it = 0; it < npairs; ++it) {
-                const int np = it & 3;
-                if (np == 0) {
-                    float *Sb = S + buf * TC_CHUNK;
+            for (int c = 0; c < nchunks; ++c) {
+                float *Sb = S + buf * TC_CHUNK;
 #pragma unroll
-                    for (int q = 0; q < 5; ++q)
-                        *reinterpret_cast<f32x4 *>(Sb + (lane + 64 * q) * 4) = xr[q];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    {   // next 8-row chunk into registers (clamped at the end of the range)
-                        const int itn = (it + 4 < npairs) ? it + 4 : it;
-                        const float *xs2 = xsrc + (size_t)(2 * itn) * TP;
+                for (int q = 0; q < 5; ++q)
+                    *reinterpret_cast<f32x4 *>(Sb + (lane + 64 * q) * 4) = xr[q];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                {   // next 8-row chunk into registers (clamped at the end of the range)
+                    const int cn = (c + 1 < nchunks) ? c + 1 : c;
+                    const float *xs2 = xsrc + (size_t)(8 * cn) * TP;
 #pragma unroll
-                        for (int q = 0; q < 5; ++q) {
-                            int idx = lane + 64 * q, row = idx / 40, c4 = idx - row * 40;
-                            xr[q] = *reinterpret_cast<const f32x4 *>(xs2 + (size_t)row * TP + c4 * 4);
-                        }
+                    for (int q = 0; q < 5; ++q) {
+                        int idx = lane + 64 * q, row = idx / 40, c4 = idx - row * 40;
+                        xr[q] = *reinterpret_cast<const f32x4 *>(xs2 + (size_t)row * TP + c4 * 4);
                     }
                 }
-                {   // W operand of the next n pair (clamped)
-                    const int itn = (it + 1 < npairs) ? it + 1 : it;
-                    const float *wq = wb + (size_t)(2 * itn) * K32;
-#pragma unroll
-                    for (int l = 0; l < LT; ++l) bn[l] = wq[l * lagstride];
-                }
-                const float *sa = S + buf * TC_CHUNK + (2 * np + h) * TC_ROW + i;
-#pragma unroll
-                for (int l = 0; l < LT; ++l) {
-#pragma unroll
-                    for (int tb = 0; tb < 4; ++tb) {
-                        float a = sa[tb * 32 + l];
-                        acc[tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc[l], acc[tb], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int l = 0; l < LT; ++l) bc[l] = bn[l];
-                if (np == 3) buf ^= 1;
+                const int nrow = nlo + 8 * c;
+                const float *sa = Sb + h * TC_ROW + i;
+                tc_load_w<LT>(b1, wr, woff, nrow + 2, K32, lagbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                tc_pair<LT>(acc, sa, b0);
+                tc_load_w<LT>(b0, wr, woff, nrow + 4, K32, lagbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                tc_pair<LT>(acc, sa + 2 * TC_ROW, b1);
+                tc_load_w<LT>(b1, wr, woff, nrow + 6, K32, lagbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                tc_pair<LT>(acc, sa + 4 * TC_ROW, b0);
+                tc_load_w<LT>(b0, wr, woff, nrow + ((c + 1 < nchunks) ? 8 : 0), K32, lagbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                tc_pair<LT>(acc, sa + 6 * TC_ROW, b1);
+                buf ^= 1;
             }
         }
     }
