@@ -21,7 +21,7 @@ CMF_OK, CMF_ERR_ARG, CMF_ERR_HIP, CMF_ERR_STATE, CMF_ERR_UNSUPPORTED = 0, 1, 2, 
 SYMBOLS = [
     "cmf_version", "cmf_last_error", "cmf_device_count",
     "cmf_create", "cmf_create_shard", "cmf_destroy", "cmf_set_stream",
-    "cmf_get_data_sumsq", "cmf_set_data_norm",
+    "cmf_set_option", "cmf_get_data_sumsq", "cmf_set_data_norm",
     "cmf_set_factors", "cmf_get_factors",
     "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_fit", "cmf_converged",
     "cmf_w_partial", "cmf_w_apply", "cmf_h_update", "cmf_loss_partial",
@@ -65,6 +65,7 @@ def load():
     sig("cmf_create_shard", [pvp, cint, i64, i64, i64, i64, pd, i64, i64])
     sig("cmf_destroy", [vp])
     sig("cmf_set_stream", [vp, vp])
+    sig("cmf_set_option", [vp, ctypes.c_char_p, cint])
     sig("cmf_get_data_sumsq", [vp, pd])
     sig("cmf_set_data_norm", [vp, dbl])
     sig("cmf_set_factors", [vp, pd, pd])

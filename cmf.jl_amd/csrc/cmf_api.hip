@@ -87,6 +87,8 @@ struct cmf_handle_s {
     double data_sumsq = 0.0, data_norm = 0.0;
     bool factors_set = false;
     bool have_data = false;
+    bool reuse_est = true;  // option "reuse_est"
+    bool est_valid = false; // est[t][n] == tensor_conv(W, H) for the resident W, H
 };
 
 static size_t n_partial(const cmf_handle_s *h) { return (size_t)h->conv_gx * (size_t)std::max(h->conv_gy, h->conv_gy_ext); }
@@ -274,7 +276,7 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy)
     p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = h->X; p.partial = h->partial;
     p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = T_store;
     dim3 grid(h->conv_gx, gy), block(256);
-    if (d.K % 32 == 0) hipLaunchKernelGGL((conv_kernel<MODE, 16>), grid, block, 0, h->stream, p);
+    if (d.K % 32 == 0) hipLaunchKernelGGL((conv2_kernel<MODE>), grid, block, 0, h->stream, p);
     else hipLaunchKernelGGL((conv_kernel<MODE, 0>), grid, block, 0, h->stream, p);
     KCHK("conv_kernel");
     return CMF_OK;
@@ -350,7 +352,9 @@ static int check_ready(cmf_handle_s *h, bool need_data)
 static int w_partial_impl(cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
-    CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy));   // mult.jl:28
+    if (!(h->reuse_est && h->est_valid))
+        CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
+    h->est_valid = true;
     CMFTRY(launch_hxt(h));                                  // mult.jl:31-34
     return launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks, (size_t)2 * d.L * d.K32 * d.Np);
 }
@@ -362,6 +366,7 @@ static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W)
     hipLaunchKernelGGL(w_update_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden, 1,
                        d.N, d.K, d.L, d.Np, d.K32, (float)l1W, (float)(2.0 * l2W)); // mult.jl:37-38
     KCHK("w_update_kernel");
+    h->est_valid = false;
     return CMF_OK;
 }
 
@@ -374,13 +379,19 @@ static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
     hipLaunchKernelGGL(h_update_kernel, grid, dim3(256), 0, h->stream, h->H, h->Ht, h->hslabs, h->tc_S,
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
     KCHK("h_update_kernel");
+    h->est_valid = false;
     return CMF_OK;
 }
 
 static int loss_partial_impl(cmf_handle_s *h, double *sumsq)
 {
     const CmfDims &d = h->d;
-    CMFTRY(launch_conv<2>(h, nullptr, d.Tl, h->conv_gy)); // mult.jl:55-57
+    if (h->reuse_est) {
+        CMFTRY(launch_conv<3>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:55-57, est kept for the next update_motifs!
+        h->est_valid = true;
+    } else {
+        CMFTRY(launch_conv<2>(h, nullptr, d.Tl, h->conv_gy)); // mult.jl:55-57
+    }
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_gx * h->conv_gy, h->d_scalar);
     KCHK("loss_reduce_kernel");
     return read_scalar(h, 0, sumsq);
@@ -429,6 +440,17 @@ int cmf_set_stream(cmf_handle h, void *hip_stream)
     return CMF_OK;
 }
 
+int cmf_set_option(cmf_handle h, const char *name, int value)
+{
+    if (!h || !name) return fail(CMF_ERR_ARG, "NULL argument");
+    if (std::strcmp(name, "reuse_est") == 0) {
+        h->reuse_est = value != 0;
+        h->est_valid = false;
+        return CMF_OK;
+    }
+    return fail(CMF_ERR_ARG, "unknown option '%s'", name);
+}
+
 int cmf_get_data_sumsq(cmf_handle h, double *sumsq)
 {
     if (!h || !sumsq) return fail(CMF_ERR_ARG, "NULL argument");
@@ -465,6 +487,7 @@ int cmf_set_factors(cmf_handle h, const double *W, const double *H)
     KCHK("pack_H_kernel");
     HIPCHK(hipStreamSynchronize(h->stream));
     h->factors_set = true;
+    h->est_valid = false;
     return CMF_OK;
 }
 
@@ -793,7 +816,8 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
     const double S = (double)d.L * d.Tl - 0.5 * (double)d.L * (d.L - 1);
     const double f1 = 2.0 * d.K * d.N * S; // one contraction
     std::string nm(name);
-    int which = nm == "conv" ? 0 : nm == "hxt" ? 1 : nm == "transconv" ? 2 : nm == "conv_t" ? 3 : nm == "conv_loss" ? 4 : -1;
+    int which = nm == "conv" ? 0 : nm == "hxt" ? 1 : nm == "transconv" ? 2 : nm == "conv_t" ? 3 : nm == "conv_loss" ? 4
+              : nm == "conv_loss_store" ? 5 : -1;
     if (which < 0) return fail(CMF_ERR_ARG, "unknown kernel '%s'", name);
     auto run = [&]() -> int {
         switch (which) {
@@ -801,7 +825,8 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
         case 1: return launch_hxt(h);
         case 2: return launch_transconv(h, 2);
         case 3: return launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext);
-        default: return launch_conv<2>(h, nullptr, d.Tl, h->conv_gy);
+        case 4: return launch_conv<2>(h, nullptr, d.Tl, h->conv_gy);
+        default: return launch_conv<3>(h, h->est, d.Tl, h->conv_gy);
         }
     };
     CMFTRY(run()); // warm-up

@@ -75,6 +75,75 @@ struct ConvParams {
 #define CONV_HS_FLOATS (32 * CONV_HS_STRIDE)
 #define CONV_WS_FLOATS (32 * 128)
 
+template <int MODE>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvParams &p, int t0, int n0, int wt, int wn,
+                                              int i, int h, int lane, int wave, int tid)
+{
+    const int Np = p.Np, TP = p.TP;
+    // Tiles that lie entirely below T_store (all but the last row of tiles) take a branch-free path:
+    // per-element exec-mask branches serialise the epilogue (one L2 round trip per data load).
+    const bool full = (t0 + 128 <= p.T_store); // workgroup-uniform
+    if (MODE == 0 || MODE == 3 || MODE == 2) {
+        // acc[ti][ni][r]: t = t0 + wt*64 + ti*32 + crow(r,h), n = n0 + wn*64 + ni*32 + i
+        float lsum = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const size_t o0 = (size_t)(p.PADL + t0 + wt * 64 + ti * 32 + 4 * h) * Np + n0 + wn * 64 + ni * 32 + i;
+                float dv[16];
+                if (MODE == 2 || MODE == 3) {
+                    // the rows of a partial tile beyond T_store are padding rows of X: in bounds
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dv[r] = p.data[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np];
+                }
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[ti][ni][r];
+                        if (MODE == 0 || MODE == 3) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = v;
+                        if (MODE == 2 || MODE == 3) { const float d = v - dv[r]; lsum = fmaf(d, d, lsum); }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int t = t0 + wt * 64 + ti * 32 + cmf_crow(r, h);
+                        const float v = acc[ti][ni][r];
+                        if (MODE == 0 || MODE == 3) {
+                            if (t < p.T_store) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = v;
+                        }
+                        if (MODE == 2 || MODE == 3) { const float d = (t < p.T_store) ? v - dv[r] : 0.f; lsum = fmaf(d, d, lsum); }
+                    }
+                }
+            }
+        if (MODE == 2 || MODE == 3) {
+            double ds = (double)lsum;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ds += __shfl_down(ds, off, 64);
+            __shared__ double red[4];
+            if (lane == 0) red[wave] = ds;
+            __syncthreads();
+            if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        }
+    } else {
+        // MODE 1: acc[ni][ti][r]: n = n0 + wn*64 + ni*32 + crow(r,h), t = t0 + wt*64 + ti*32 + i
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int t = t0 + wt * 64 + ti * 32 + i;
+                const size_t o0 = (size_t)(n0 + wn * 64 + ni * 32 + 4 * h) * TP + p.PADL + t;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] = acc[ni][ti][r];
+                } else if (t < p.T_store) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] = acc[ni][ti][r];
+                }
+            }
+    }
+}
+
 template <int MODE, int NKP_CT>
 __global__ __launch_bounds__(256) void conv_kernel(ConvParams p)
 {
@@ -196,50 +265,112 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p)
         }
     }
 
-    // ---- epilogue ----
-    if (MODE == 0 || MODE == 3 || MODE == 2) {
-        // acc[ti][ni][r]: t = t0 + wt*64 + ti*32 + crow(r,h), n = n0 + wn*64 + ni*32 + i
-        float lsum = 0.f;
+    conv_epilogue<MODE>(acc, p, t0, n0, wt, wn, i, h, lane, wave, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C1, fast path for K a multiple of 32: same tile and wave layout as conv_kernel, but the W operand
+// is not staged in LDS.  Each wave streams its own W rows (128 contiguous bytes per half-wave,
+// L2-resident: the 320 KB slab of an n tile is shared by every workgroup of that tile) straight into
+// registers with buffer loads, one lag ahead (two ping-pong register sets), so the lag loop has NO
+// workgroup barrier; only the H strip is shared through LDS (one barrier per 32-lag block).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void conv2_load_w(float (&w)[16][2], __amdgpu_buffer_rsrc_t wr, int woff, int lag, int lagbytes, int rowbytes)
+{
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int t = t0 + wt * 64 + ti * 32 + cmf_crow(r, h);
-                    int n = n0 + wn * 64 + ni * 32 + i;
-                    if (t < p.T_store) {
-                        size_t o = (size_t)(p.PADL + t) * Np + n;
-                        float v = acc[ti][ni][r];
-                        if (MODE == 0 || MODE == 3) p.out[o] = v;
-                        if (MODE == 2 || MODE == 3) {
-                            float d = v - p.data[o];
-                            lsum = fmaf(d, d, lsum);
-                        }
-                    }
-                }
-        if (MODE == 2 || MODE == 3) {
-            double ds = (double)lsum;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) ds += __shfl_down(ds, off, 64);
-            __shared__ double red[4];
-            if (lane == 0) red[wave] = ds;
-            __syncthreads();
-            if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-        }
-    } else {
-        // MODE 1: acc[ni][ti][r]: n = n0 + wn*64 + ni*32 + crow(r,h), t = t0 + wt*64 + ti*32 + i
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int n = n0 + wn * 64 + ni * 32 + cmf_crow(r, h);
-                    int t = t0 + wt * 64 + ti * 32 + i;
-                    if (t < p.T_store) p.out[(size_t)n * TP + p.PADL + t] = acc[ni][ti][r];
-                }
+    for (int kp = 0; kp < 16; ++kp) {
+        w[kp][0] = cmf_bload(wr, woff, lag * lagbytes + kp * 2 * rowbytes);
+        w[kp][1] = cmf_bload(wr, woff + 128, lag * lagbytes + kp * 2 * rowbytes);
     }
+}
+
+template <int MODE>
+__device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb, const float (&w)[16][2])
+{
+    float a0 = hsb[0], a1 = hsb[32];
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int kp = 0; kp < 16; ++kp) {
+        float na0 = 0.f, na1 = 0.f;
+        if (kp + 1 < 16) {
+            na0 = hsb[(kp + 1) * 2 * CONV_HS_STRIDE];
+            na1 = hsb[(kp + 1) * 2 * CONV_HS_STRIDE + 32];
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (MODE == 1) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a1, acc[1][1], 0, 0, 0);
+        } else {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[kp][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[kp][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[kp][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[kp][1], acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        a0 = na0; a1 = na1;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
+{
+    __shared__ __attribute__((aligned(16))) float Hs[CONV_HS_FLOATS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wt = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * 128;
+    const int t0 = blockIdx.y * 128;
+    const int Np = p.Np, TP = p.TP;
+    const int K32 = p.KB * 32;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int LB = (p.L + 31) >> 5;
+    const int rowbytes = Np * 4;
+    const int lagbytes = K32 * Np * 4;
+    const int woff = (h * Np + n0 + wn * 64 + i) * 4; // per-lane part of the W address
+    float wA[16][2], wB[16][2];
+
+    for (int kb = 0; kb < p.KB; ++kb) {
+        for (int lb = 0; lb < LB; ++lb) {
+            const int lbeg = lb * 32;
+            const int lend = (p.L < lbeg + 32) ? p.L : (lbeg + 32);
+            const int npair = (lend - lbeg + 1) >> 1; // lags are processed in pairs; Wt is zero-padded to Lp
+            // descriptor base: Wt[lbeg][kb*32][0]
+            const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wt + ((size_t)lbeg * K32 + kb * 32) * Np, (size_t)(2 * npair) * lagbytes);
+            conv2_load_w(wA, wr, woff, 0, lagbytes, rowbytes);
+            __syncthreads(); // everyone is done with Hs of the previous block
+            {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,160)
+                const float *src = p.Ht + (size_t)(kb * 32) * TP + (p.PADL + t0 - lbeg - 32);
+                for (int idx = tid; idx < 32 * 40; idx += 256) {
+                    int r = idx / 40, c4 = idx - r * 40;
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)r * TP + c4 * 4);
+                    *reinterpret_cast<f32x4 *>(Hs + r * CONV_HS_STRIDE + c4 * 4) = v;
+                }
+            }
+            __syncthreads();
+            const float *hsb = Hs + h * CONV_HS_STRIDE + 32 + wt * 64 + i;
+            for (int pr = 0; pr < npair; ++pr) {
+                const int l0 = 2 * pr; // lag offsets inside the block
+                conv2_load_w(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                conv2_lag<MODE>(acc, hsb - l0, wA);
+                conv2_load_w(wA, wr, woff, (pr + 1 < npair) ? l0 + 2 : l0, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                conv2_lag<MODE>(acc, hsb - l0 - 1, wB);
+            }
+        }
+    }
+    conv_epilogue<MODE>(acc, p, t0, n0, wt, wn, i, h, lane, wave, tid);
 }
 
 // ---------------------------------------------------------------------------------------------

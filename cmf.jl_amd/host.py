@@ -181,6 +181,10 @@ class MultUpdate(AbstractCFUpdate):
         check(self._lib.cmf_compute_loss(self._h, ctypes.byref(loss)))
         return loss.value
 
+    def set_option(self, name, value):
+        """Library option, e.g. ``set_option("reuse_est", 0)`` to recompute est in update_motifs! like the reference."""
+        check(self._lib.cmf_set_option(self._h, name.encode(), int(value)))
+
     def upload(self, W, H):
         W = farr(W, (self.K, self.N, self.L))
         H = farr(H, (self.K, self.T))

@@ -73,6 +73,13 @@ int cmf_destroy(cmf_handle h);
  * A new handle runs on a private non-blocking stream until this is called. */
 int cmf_set_stream(cmf_handle h, void *hip_stream);
 
+/* Options (name, value):
+ *   "reuse_est" (default 1): the est = tensor_conv(W, H) that closes update_feature_maps!
+ *       (mult.jl:55) is kept, and the next update_motifs! (mult.jl:28), which would recompute the
+ *       same est from the same W and H, reuses it (6 instead of 7 contractions per iteration,
+ *       identical results).  0 = recompute it like the reference does. */
+int cmf_set_option(cmf_handle h, const char *name, int value);
+
 /* sum(data.^2) over the columns this handle owns (fp64); and the setter used
  * by the sharded host after it all-reduced the per-shard values
  * (data_norm: src/algs/mult.jl:13). */

@@ -51,6 +51,9 @@ PRIM_SHAPES = [
     (37, 150, 33, 7),   # two k blocks
     (20, 200, 6, 40),   # two lag blocks
     (9, 1100, 2, 3),    # several 512-wide t tiles
+    (50, 400, 32, 7),   # K multiple of 32 (barrier-free conv path), odd L
+    (40, 300, 32, 33),  # ... two lag blocks, odd remainder
+    (260, 600, 64, 20), # ... two k blocks, three n tiles
 ]
 
 
@@ -189,6 +192,38 @@ def test_deterministic(cmf, oracle):
     np.testing.assert_array_equal(a.loss_hist, b.loss_hist)
     np.testing.assert_array_equal(a.W, b.W)
     np.testing.assert_array_equal(a.H, b.H)
+
+
+def test_est_reuse_is_bitwise_neutral(cmf, oracle):
+    """Option "reuse_est": skipping the redundant conv of update_motifs! must not change a single bit."""
+    data, _, _ = oracle.c_gen_synthetic(N=140, T=1300, K=3, L=20, seed=6)
+    W0, H0 = oracle.c_init_rand(data, L=20, K=32, seed=0)
+    outs = []
+    for reuse in (1, 0):
+        rule = cmf.MultUpdate(data, W0, H0)
+        rule.set_option("reuse_est", reuse)
+        lh = [rule.compute_loss()]
+        for _ in range(4):
+            rule.update_motifs(l1W=0.1, l2W=0.5)
+            lh.append(rule.update_feature_maps(l1H=0.1, l2H=0.2))
+        W, H = rule.download()
+        rule.close()
+        outs.append((np.asarray(lh), W, H))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    # and a caller that re-uploads factors in between invalidates the kept est
+    rule = cmf.MultUpdate(data, W0, H0)
+    rule.compute_loss()
+    rule.upload(outs[0][1], outs[0][2])
+    rule.update_motifs()
+    Wa, _ = rule.download()
+    rule.close()
+    rule = cmf.MultUpdate(data, outs[0][1], outs[0][2])
+    rule.update_motifs()
+    Wb, _ = rule.download()
+    rule.close()
+    np.testing.assert_array_equal(Wa, Wb)
 
 
 def test_init_rand_and_gen_synthetic_match_oracle(cmf, oracle):
