@@ -90,10 +90,6 @@ def main():
 
     import __graft_entry__
 
-    if rank == 0:
-        __graft_entry__.build()
-    import cmf_jl_amd as cmf
-
     cfg = dict(CONFIGS[args.config])
     if args.T:
         cfg["T"] = args.T
@@ -106,9 +102,20 @@ def main():
         import torch
         import torch.distributed as dist
 
+        # CMF_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+        backend = os.environ.get("CMF_DIST_BACKEND", "nccl")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    if rank == 0:
+        __graft_entry__.build()  # no-op when the in-tree .so files are current
+    if world > 1:
         dist.barrier()
+    import cmf_jl_amd as cmf
+
     cmf.load_library()
 
     # ---- synthetic inputs: gen_synthetic(seed 1234) + init_rand(seed 0), SURVEY.md section 8d ----
@@ -153,7 +160,7 @@ def main():
         if world > 1:
             import torch
 
-            tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
         return el, ls
@@ -196,19 +203,21 @@ def main():
 
     # ---- roofline of the dominant kernel (conv: 3 of the 7 contractions), HIP events on the
     # kernel's own stream, rank 0's shard ----
-    if world == 1 and rank == 0:
+    if rank == 0:
         kern = {}
+        timer = rule if world == 1 else rule.engine
         for name in ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv"):
-            kms, kfl = rule.time_kernel(name, reps=5)
+            kms, kfl = timer.time_kernel(name, reps=5)
             kern[name] = {"avg_ms": kms, "tflops": kfl / kms / 1e9, "frac": kfl / kms / 1e9 / PEAK_FP32_MFMA_TFLOPS}
         ach = kern["conv"]["tflops"]
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_kernel<0,16> (tensor_conv, est[t][n])",
+        out["roofline"] = {"bound": "mfma", "kernel": "conv2_kernel<0> (tensor_conv, est[t][n])"
+                                                       + ("" if world == 1 else f" on rank 0's shard of {T // world} columns"),
                            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None}
         out["kernels"] = kern
 
     if rank == 0:
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(data, W0, H0, args.cpu_seconds)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line for it

@@ -25,6 +25,7 @@ SYMBOLS = [
     "cmf_set_factors", "cmf_get_factors",
     "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_fit", "cmf_converged",
     "cmf_w_partial", "cmf_w_apply", "cmf_h_update", "cmf_loss_partial",
+    "cmf_loss_partial_async", "cmf_scalar_ptr", "cmf_set_scalar_buffer",
     "cmf_numden_ptr", "cmf_set_numden_buffer", "cmf_halo_ptr", "cmf_set_halo_buffer", "cmf_halo_pack", "cmf_halo_unpack",
     "cmf_tensor_conv", "cmf_tensor_transconv", "cmf_init_rand", "cmf_gen_synthetic",
     "cmf_time_kernel",
@@ -79,6 +80,9 @@ def load():
     sig("cmf_w_apply", [vp, dbl, dbl])
     sig("cmf_h_update", [vp, dbl, dbl])
     sig("cmf_loss_partial", [vp, pd])
+    sig("cmf_loss_partial_async", [vp])
+    sig("cmf_scalar_ptr", [vp, pvp])
+    sig("cmf_set_scalar_buffer", [vp, vp])
     sig("cmf_numden_ptr", [vp, pvp, pi64])
     sig("cmf_set_numden_buffer", [vp, vp])
     sig("cmf_halo_ptr", [vp, cint, pvp, pi64])

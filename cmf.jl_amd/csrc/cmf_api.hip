@@ -75,6 +75,7 @@ struct cmf_handle_s {
     float *halo_own[4] = {nullptr, nullptr, nullptr, nullptr};
     double *partial = nullptr; // loss partials
     double *d_scalar = nullptr; // device double[4]
+    double *d_scalar_own = nullptr;
     double *h_scalar = nullptr; // pinned host double[4]
     double *stage = nullptr;    // fp64 staging for layout conversion
     size_t stage_elems = 0;
@@ -155,7 +156,7 @@ static void destroy_impl(cmf_handle_s *h)
     for (float *p : fbufs)
         if (p) (void)hipFree(p);
     if (h->partial) (void)hipFree(h->partial);
-    if (h->d_scalar) (void)hipFree(h->d_scalar);
+    if (h->d_scalar_own) (void)hipFree(h->d_scalar_own);
     if (h->h_scalar) (void)hipHostFree(h->h_scalar);
     if (h->stage) (void)hipFree(h->stage);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -251,7 +252,8 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
         h->halo[w] = h->halo_own[w];
     }
     TRYB(dalloc_zero(&h->partial, n_partial(h)));
-    TRYB(dalloc_zero(&h->d_scalar, 4));
+    TRYB(dalloc_zero(&h->d_scalar_own, 4));
+    h->d_scalar = h->d_scalar_own;
     HIPB(hipHostMalloc(&h->h_scalar, 4 * sizeof(double)));
     if (data) {
         TRYB(upload_cols(h, data, 0, Tl, true, true));
@@ -383,7 +385,7 @@ static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
     return CMF_OK;
 }
 
-static int loss_partial_impl(cmf_handle_s *h, double *sumsq)
+static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = true)
 {
     const CmfDims &d = h->d;
     if (h->reuse_est) {
@@ -394,7 +396,7 @@ static int loss_partial_impl(cmf_handle_s *h, double *sumsq)
     }
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_gx * h->conv_gy, h->d_scalar);
     KCHK("loss_reduce_kernel");
-    return read_scalar(h, 0, sumsq);
+    return readback ? read_scalar(h, 0, sumsq) : CMF_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -536,6 +538,26 @@ int cmf_loss_partial(cmf_handle h, double *sumsq)
     if (!sumsq) return fail(CMF_ERR_ARG, "sumsq is NULL");
     CMFTRY(check_ready(h, true));
     return loss_partial_impl(h, sumsq);
+}
+
+int cmf_loss_partial_async(cmf_handle h)
+{
+    CMFTRY(check_ready(h, true));
+    return loss_partial_impl(h, nullptr, false);
+}
+
+int cmf_scalar_ptr(cmf_handle h, void **dev_ptr)
+{
+    if (!h || !dev_ptr) return fail(CMF_ERR_ARG, "NULL argument");
+    *dev_ptr = h->d_scalar;
+    return CMF_OK;
+}
+
+int cmf_set_scalar_buffer(cmf_handle h, void *dev_ptr)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    h->d_scalar = dev_ptr ? (double *)dev_ptr : h->d_scalar_own;
+    return CMF_OK;
 }
 
 int cmf_update_motifs(cmf_handle h, double l1W, double l2W)

@@ -73,6 +73,8 @@ class HipShardEngine:
         self.halo = [torch.zeros(max(n.value, 1), dtype=torch.float32, device=dev) for _ in range(4)]
         for w in range(4):
             check(lib.cmf_set_halo_buffer(self._h, w, ctypes.c_void_p(self.halo[w].data_ptr())))
+        self.scalar = torch.zeros(4, dtype=torch.float64, device=dev)  # [0] = local sum of squared residuals
+        check(lib.cmf_set_scalar_buffer(self._h, ctypes.c_void_p(self.scalar.data_ptr())))
         self.set_factors(W, H_local)
 
     def data_sumsq(self):
@@ -113,6 +115,16 @@ class HipShardEngine:
         v = ctypes.c_double()
         check(self._lib.cmf_loss_partial(self._h, ctypes.byref(v)))
         return v.value
+
+    def loss_partial_tensor(self):
+        """Enqueue the local sum of squared residuals; returns the 1-element device tensor holding it."""
+        check(self._lib.cmf_loss_partial_async(self._h))
+        return self.scalar[:1]
+
+    def time_kernel(self, name, reps=5):
+        ms, fl = ctypes.c_double(), ctypes.c_double()
+        check(self._lib.cmf_time_kernel(self._h, name.encode(), int(reps), ctypes.byref(ms), ctypes.byref(fl)))
+        return ms.value, fl.value
 
     def close(self):
         if self._h:
@@ -217,7 +229,13 @@ class ShardedMultUpdate(AbstractCFUpdate):
         return self.compute_loss()
 
     def compute_loss(self):
-        ss = self._allreduce_scalar(self.engine.loss_partial())
+        if hasattr(self.engine, "loss_partial_tensor"):
+            # stays on the device until the single .item() below: one host sync per iteration
+            t = self.engine.loss_partial_tensor()
+            self._allreduce(t)
+            ss = float(t.item())
+        else:
+            ss = self._allreduce_scalar(self.engine.loss_partial())
         return math.sqrt(ss) / self.data_norm
 
     def agree_scalar(self, x):

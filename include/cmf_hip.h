@@ -134,6 +134,12 @@ int cmf_w_partial(cmf_handle h);
 int cmf_w_apply(cmf_handle h, double l1W, double l2W);
 int cmf_h_update(cmf_handle h, double l1H, double l2H);
 int cmf_loss_partial(cmf_handle h, double *sumsq);
+/* Same, without the host read-back: the fp64 sum is left in the handle's device scalar
+ * (cmf_scalar_ptr; replaceable by a caller-owned device double via cmf_set_scalar_buffer) so a
+ * device-side all-reduce can consume it and the host synchronises once per iteration. */
+int cmf_loss_partial_async(cmf_handle h);
+int cmf_scalar_ptr(cmf_handle h, void **dev_ptr);
+int cmf_set_scalar_buffer(cmf_handle h, void *dev_ptr);
 /* Device pointer (fp32) of the contiguous [numW | denomW] buffer and its
  * length in floats (same on every rank: 2 * L * Kpad * Npad). */
 int cmf_numden_ptr(cmf_handle h, void **dev_ptr, int64_t *count);
