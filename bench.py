@@ -210,10 +210,20 @@ def main():
             kms, kfl = timer.time_kernel(name, reps=5)
             kern[name] = {"avg_ms": kms, "tflops": kfl / kms / 1e9, "frac": kfl / kms / 1e9 / PEAK_FP32_MFMA_TFLOPS}
         ach = kern["conv"]["tflops"]
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload, same kernel)
+            if args.config in (2, 4) and world == 1 and not args.T:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_summary.json")))
+                traffic = pm["void conv2_kernel<0>"]["hbm_bytes_corrected"]
+                traffic_src = "profiles/r01b_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes"
+        except Exception:
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": "conv2_kernel<0> (tensor_conv, est[t][n])"
                                                        + ("" if world == 1 else f" on rank 0's shard of {T // world} columns"),
                            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None}
+                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                           "algorithmic_flops_per_launch": 2.0 * K * N * (L * (T // world) - L * (L - 1) / 2),
+                           "avg_launch_ms": kern["conv"]["avg_ms"]}
         out["kernels"] = kern
 
     if rank == 0:
