@@ -5,7 +5,7 @@ repo root:  ``import cmf_jl_amd as cmf``.
 """
 from ._lib import CMFError, LIB_PATH, SYMBOLS, load as load_library  # noqa: F401
 from .host import (  # noqa: F401
-    EPSILON, AbstractCFUpdate, AlternatingOptimizer, CNMF_results, HIPMultUpdate, MultUpdate,
+    EPSILON, AbstractCFUpdate, AlternatingOptimizer, CNMF_results, HALSUpdate, HIPHALSUpdate, HIPMultUpdate, MultUpdate,
     compute_loss, converged, fit, fit_cnmf, gen_synthetic, init_rand, tensor_conv, tensor_transconv,
 )
 

@@ -24,6 +24,7 @@ SYMBOLS = [
     "cmf_set_option", "cmf_get_data_sumsq", "cmf_set_data_norm",
     "cmf_set_factors", "cmf_get_factors",
     "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_fit", "cmf_converged",
+    "cmf_hals_update_motifs", "cmf_hals_update_feature_maps",
     "cmf_w_partial", "cmf_w_apply", "cmf_h_update", "cmf_loss_partial",
     "cmf_loss_partial_async", "cmf_scalar_ptr", "cmf_set_scalar_buffer",
     "cmf_numden_ptr", "cmf_set_numden_buffer", "cmf_halo_ptr", "cmf_set_halo_buffer", "cmf_halo_pack", "cmf_halo_unpack",
@@ -76,6 +77,8 @@ def load():
     sig("cmf_compute_loss", [vp, pd])
     sig("cmf_fit", [vp, i64, dbl, cint, i64, dbl, cint, dbl, dbl, dbl, dbl, pd, pd, pi64, ctypes.POINTER(cint)])
     sig("cmf_converged", [pd, i64, i64, dbl])
+    sig("cmf_hals_update_motifs", [vp, dbl, dbl])
+    sig("cmf_hals_update_feature_maps", [vp, dbl, dbl, pd])
     sig("cmf_w_partial", [vp])
     sig("cmf_w_apply", [vp, dbl, dbl])
     sig("cmf_h_update", [vp, dbl, dbl])

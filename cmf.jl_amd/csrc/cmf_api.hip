@@ -85,12 +85,21 @@ struct cmf_handle_s {
     int tc_LT = 4, tc_S = 1, tc_nr = 8;
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
 
+    // HALS scratch (allocated on first use)
+    bool hals_ready = false;
+    int hals_NpH = 0, hals_TPp = 0, hals_ne = 0, hals_t_edge0 = 0, hals_nch = 1, hals_clen = 6;
+    float *hals_HuT = nullptr, *hals_hhslabs = nullptr, *hals_HH = nullptr, *hals_PT = nullptr, *hals_D = nullptr;
+    float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr;
+
     double data_sumsq = 0.0, data_norm = 0.0;
     bool factors_set = false;
     bool have_data = false;
     bool reuse_est = true;  // option "reuse_est"
     bool est_valid = false; // est[t][n] == tensor_conv(W, H) for the resident W, H
 };
+
+static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
+static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H);
 
 static size_t n_partial(const cmf_handle_s *h) { return (size_t)h->conv_gx * (size_t)std::max(h->conv_gy, h->conv_gy_ext); }
 
@@ -152,7 +161,8 @@ static void destroy_impl(cmf_handle_s *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
-                      h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3]};
+                      h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3],
+                      h->hals_HuT, h->hals_hhslabs, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE};
     for (float *p : fbufs)
         if (p) (void)hipFree(p);
     if (h->partial) (void)hipFree(h->partial);
@@ -284,14 +294,14 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy)
     return CMF_OK;
 }
 
-static int launch_hxt(cmf_handle_s *h)
+static int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int NpX, int nsrc, float *slabs, int nchunks, int chunk_len)
 {
     const CmfDims &d = h->d;
     HxtParams p;
-    p.H = h->H; p.X0 = h->X; p.X1 = h->est; p.slabs = h->wslabs;
-    p.Np = d.Np; p.K32 = d.K32; p.KB = d.KB; p.PADL = d.PADL; p.L = d.L; p.Tl = d.Tl; p.chunk_len = h->hxt_chunk_len;
-    p.G = h->hxt_groups;
-    dim3 grid((d.Np / 128) * h->hxt_groups, h->hxt_nchunks, 2 * d.KB), block(256);
+    p.H = h->H; p.X0 = X0; p.X1 = X1; p.slabs = slabs;
+    p.Np = NpX; p.K32 = d.K32; p.KB = d.KB; p.PADL = d.PADL; p.L = d.L; p.Tl = d.Tl; p.chunk_len = chunk_len;
+    p.G = h->hxt_groups; p.nsrc = nsrc;
+    dim3 grid((NpX / 128) * h->hxt_groups, nchunks, nsrc * d.KB), block(256);
     switch (h->hxt_LP) {
 #define CASE(LP_) case LP_: hipLaunchKernelGGL((hxt_kernel<LP_>), grid, block, 0, h->stream, p); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(8)
@@ -300,6 +310,11 @@ static int launch_hxt(cmf_handle_s *h)
     }
     KCHK("hxt_kernel");
     return CMF_OK;
+}
+
+static int launch_hxt(cmf_handle_s *h)
+{
+    return launch_hxt_on(h, h->X, h->est, h->d.Np, 2, h->wslabs, h->hxt_nchunks, h->hxt_chunk_len);
 }
 
 static int launch_transconv(cmf_handle_s *h, int nsrc)
@@ -590,6 +605,23 @@ int cmf_compute_loss(cmf_handle h, double *loss)
     return CMF_OK;
 }
 
+int cmf_hals_update_motifs(cmf_handle h, double l1W, double l2W)
+{
+    CMFTRY(check_ready(h, true));
+    return hals_w_impl(h, l1W, l2W);
+}
+
+int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
+{
+    if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
+    CMFTRY(check_ready(h, true));
+    CMFTRY(hals_h_impl(h, l1H, l2H));
+    double ss = 0.0;
+    CMFTRY(loss_partial_impl(h, &ss)); // hals.jl:41: norm(resids)/data_norm with resids = est - data
+    *loss = std::sqrt(ss) / h->data_norm;
+    return CMF_OK;
+}
+
 int cmf_converged(const double *loss_hist, int64_t len, int64_t patience, double tol)
 {
     // src/model.jl:91-107
@@ -692,6 +724,99 @@ int cmf_halo_unpack(cmf_handle h, int has_left, int has_right)
         hipLaunchKernelGGL(halo_copy_kernel, dim3(64), dim3(256), 0, h->stream, h->H, h->Ht, h->halo[3], d.PADL + d.Tl, rows, d.K32, d.TP, 1);
         KCHK("halo_copy_kernel");
     }
+    return CMF_OK;
+}
+
+// ---- HALS (src/algs/hals.jl) -------------------------------------------------------------------
+static int hals_ensure(cmf_handle_s *h)
+{
+    if (h->hals_ready) return CMF_OK;
+    const CmfDims &d = h->d;
+    if (h->sharded && h->T_global != d.Tl) return fail(CMF_ERR_STATE, "HALS needs an unsharded handle (the H sweep is sequential along T)");
+    if (d.L > 64) return fail(CMF_ERR_UNSUPPORTED, "HALS path supports L <= 64 (got %d)", d.L);
+    const int E = 2 * d.L - 1;
+    h->hals_NpH = (int)rup((int64_t)d.L * d.K32, 128);
+    h->hals_TPp = (int)rup(d.Tl, 64) + 256;
+    h->hals_t_edge0 = std::max(0, d.Tl - d.L + 1);
+    h->hals_ne = d.Tl - h->hals_t_edge0;
+    {   // time chunks of the H_unfold Gram launch: fill the resident wave slots
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, h->device));
+        const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const int slots = 4 * n_cu * (h->hxt_LP <= 5 ? 2 : 1);
+        int64_t wpc = (int64_t)(h->hals_NpH / 32) * d.KB * h->hxt_groups;
+        int nch = (int)std::max<int64_t>(1, (slots + wpc / 2) / wpc);
+        int64_t clen = rup((d.Tl + nch - 1) / nch, 6 * h->hxt_LP);
+        h->hals_clen = (int)clen;
+        h->hals_nch = (int)((d.Tl + clen - 1) / clen);
+    }
+    const size_t LKN = (size_t)d.L * d.K32 * h->hals_NpH;
+    CMFTRY(dalloc_zero(&h->hals_HuT, (size_t)d.TP * h->hals_NpH));
+    CMFTRY(dalloc_zero(&h->hals_hhslabs, (size_t)h->hals_nch * LKN));
+    CMFTRY(dalloc_zero(&h->hals_HH, LKN));
+    CMFTRY(dalloc_zero(&h->hals_PT, (size_t)d.K32 * h->hals_TPp));
+    CMFTRY(dalloc_zero(&h->hals_D, (size_t)h->hals_TPp));
+    CMFTRY(dalloc_zero(&h->hals_PW, (size_t)d.L * d.L * d.K32 * d.K32));
+    CMFTRY(dalloc_zero(&h->hals_GW, (size_t)d.K32 * d.K32 * E));
+    CMFTRY(dalloc_zero(&h->hals_GE, (size_t)d.K32 * std::max(1, h->hals_ne) * d.K32 * E));
+    h->hals_ready = true;
+    return CMF_OK;
+}
+
+static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(hals_ensure(h));
+    // G = resid * H_unfold' = denomW - numW: the MU partial sums (hals.jl:104-110 needs resid * h)
+    if (!(h->reuse_est && h->est_valid)) CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy));
+    CMFTRY(launch_hxt(h));
+    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks, (size_t)2 * d.L * d.K32 * d.Np));
+    // HH = H_unfold * H_unfold' (hals.jl:56-60: row norms are its diagonal) with the same C2 kernel
+    hipLaunchKernelGGL(hals_build_hut_kernel, dim3(2048), dim3(256), 0, h->stream, h->H, h->hals_HuT, d.Tl, d.L, d.K32, h->hals_NpH, d.PADL);
+    KCHK("hals_build_hut_kernel");
+    CMFTRY(launch_hxt_on(h, h->hals_HuT, h->hals_HuT, h->hals_NpH, 1, h->hals_hhslabs, h->hals_nch, h->hals_clen));
+    CMFTRY(launch_slab_sum(h, h->hals_HH, h->hals_hhslabs, h->hals_nch, (size_t)d.L * d.K32 * h->hals_NpH));
+    // the K*L sequential column updates, k outer / lag inner (hals.jl:90-97)
+    const size_t per_wave = ((size_t)HALS_NG * d.L * d.K32 + 64) * sizeof(float);
+    int wpb = (int)std::min<size_t>(4, (size_t)(96 * 1024) / per_wave);
+    if (wpb < 1) return fail(CMF_ERR_UNSUPPORTED, "HALS W sweep: L*K too large for the LDS-resident state (%zu bytes per wave)", per_wave);
+    const int units_per_block = wpb * HALS_NG;
+    dim3 grid((d.N + units_per_block - 1) / units_per_block), block(64 * wpb);
+    hipLaunchKernelGGL(hals_w_sweep_kernel, grid, block, per_wave * wpb, h->stream, h->Wt, h->Wn, h->numden, h->hals_HH,
+                       d.N, d.K, d.L, d.Np, d.K32, h->hals_NpH, (float)l1W, (float)l2W);
+    KCHK("hals_w_sweep_kernel");
+    h->est_valid = false;
+    return CMF_OK;
+}
+
+static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(hals_ensure(h));
+    // P = transconv(W, resid) = denomH - numH (hals.jl:152 needs <W_k window, resid window>)
+    CMFTRY(launch_conv<1>(h, h->estT, d.Tl, h->conv_gy));
+    CMFTRY(launch_transconv(h, 2));
+    hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, h->tc_S, d.Tl, d.K32, h->hals_TPp);
+    KCHK("hals_p_init_kernel");
+    hipLaunchKernelGGL(hals_pw_kernel, dim3(d.L * d.L, d.KB * d.KB), dim3(32, 32), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
+    KCHK("hals_pw_kernel");
+    hipLaunchKernelGGL(hals_gw_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_PW, h->hals_GW, h->hals_GE, d.L, d.K32, h->hals_ne, d.Tl, h->hals_t_edge0);
+    KCHK("hals_gw_kernel");
+    HalsRowParams q;
+    q.PT = h->hals_PT; q.H = h->H; q.Ht = h->Ht; q.D = h->hals_D; q.GW = h->hals_GW; q.GE = h->hals_GE;
+    q.Tl = d.Tl; q.L = d.L; q.K32 = d.K32; q.TP = d.TP; q.TPp = h->hals_TPp; q.PADL = d.PADL; q.ne = h->hals_ne; q.t_edge0 = h->hals_t_edge0;
+    q.l1 = (float)l1H; q.l2 = (float)l2H;
+    for (int k = 0; k < d.K; ++k) { // hals.jl:124 (k outer); the t loop (:125) is inside the row kernel
+        q.k = k;
+        hipLaunchKernelGGL(hals_h_row_kernel, dim3(1), dim3(64), 0, h->stream, q);
+        KCHK("hals_h_row_kernel");
+        if (k + 1 < d.K) {
+            hipLaunchKernelGGL(hals_h_push_kernel, dim3((d.Tl + 255) / 256, d.K), dim3(256), 0, h->stream, h->hals_PT, h->hals_D, h->hals_GW,
+                               h->hals_GE, k, d.K, d.Tl, d.L, d.K32, h->hals_TPp, h->hals_ne, h->hals_t_edge0);
+            KCHK("hals_h_push_kernel");
+        }
+    }
+    h->est_valid = false;
     return CMF_OK;
 }
 

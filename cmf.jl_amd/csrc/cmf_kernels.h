@@ -387,11 +387,12 @@ struct HxtParams {
     const float *H;  // [TP][K32]
     const float *X0; // data [TP][Np]
     const float *X1; // est  [TP][Np]
-    float *slabs;    // [nchunks][2][L][K32][Np]
+    float *slabs;    // [nchunks][nsrc][L][K32][Np]
     int Np, K32, KB, PADL, L, Tl;
     int chunk_len;   // multiple of 6*LP
     int G;           // lag groups of 2*LP lags (fastest-varying part of blockIdx.x, so the groups
                      // that re-read the same X rows are dispatched together)
+    int nsrc;        // 2: X0 and X1 (numW, denomW);  1: X0 only (HALS Gram of H_unfold)
 };
 
 // E[u] = R(2u), O[u] = R(2u-1), B[u] = X rows (2u, 2u+1) of the group that starts `row` rows after the
@@ -432,8 +433,8 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
     const int i = lane & 31, h = lane >> 5;
     const int nb = (blockIdx.x / p.G) * 4 + wave;
     const int c = blockIdx.y;
-    const int src = blockIdx.z & 1;
-    const int kb = blockIdx.z >> 1;
+    const int src = blockIdx.z % p.nsrc;
+    const int kb = blockIdx.z / p.nsrc;
     const int lag0 = (blockIdx.x % p.G) * 2 * LP;
     const int Np = p.Np, K32 = p.K32;
     const float *X = src ? p.X1 : p.X0;
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
     }
 
     // store: acc[a][r] -> lag lag0+a, k = kb*32 + crow(r,h), n = nb*32 + i
-    float *slab = p.slabs + (size_t)(c * 2 + src) * p.L * K32 * Np;
+    float *slab = p.slabs + (size_t)(c * p.nsrc + src) * p.L * K32 * Np;
 #pragma unroll
     for (int a = 0; a < 2 * LP; ++a) {
         int l = lag0 + a;
@@ -755,6 +756,271 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial,
         __syncthreads();
     }
     if (threadIdx.x == 0) *out = red[0];
+}
+
+
+// =============================================================================================
+// HALS rule (BASELINE config 5; src/algs/hals.jl).  The reference performs K*L rank-1 residual
+// sweeps for W and K*T dependent window updates for H on the N x T residual.  Here the same
+// Gauss-Seidel recurrences (same visiting order: k outer / lag inner for W, k outer / t inner for H)
+// run on Gram-projected state instead, which is algebraically identical:
+//   W:  G[n][j] = <resid[n,:], h_j> (= denomW - numW of the MU kernels),  HH = H_unfold H_unfold'
+//       step j=(k,l): v = G[:,j] - w_old*HH[j][j];  w_new = max((-v - l1)/(HH[j][j]+eps+l2), 0);
+//                     G += (w_new - w_old) (x) HH[j][:]                       (hals.jl:100-112)
+//   H:  P[k][t] = <W_k window, resid[:, t:t+L-1]> (= denomH - numH),  GW[k][k'][e] = sum_l <W[k,:,l], W[k',:,l-e]>
+//       step (k,t): x = max((h_old*nrm - P[k][t] - l1)/(nrm+eps+l2), 0);  P[k'][t+e] += (x - h_old) GW[k][k'][e]
+//       with the window truncated at the right edge exactly like hals.jl:136-146.
+// =============================================================================================
+
+// HuT[PADL+t][l*K32+k] = H[PADL+t-l][k]  (shift_and_stack transposed, common.jl:133-142), t < Tl
+__global__ void hals_build_hut_kernel(const float *H, float *HuT, int Tl, int L, int K32, int NpH, int PADL)
+{
+    const int LK = L * K32;
+    size_t total = (size_t)Tl * LK;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(idx % LK), t = (int)(idx / LK);
+        int l = c / K32, k = c - l * K32;
+        HuT[(size_t)(PADL + t) * NpH + c] = H[(size_t)(PADL + t - l) * K32 + k];
+    }
+}
+
+// W sweep: one wave = NG units n; state g[NG][LK] in LDS (wave-private).  numden = [num | den] in Wt layout.
+#define HALS_NG 4
+__global__ void hals_w_sweep_kernel(float *Wt, float *Wn, const float *numden, const float *HH,
+                                                            int N, int K, int L, int Np, int K32, int NpH, float l1, float l2)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int LK = L * K32;
+    float *g = smem_dyn + (size_t)wave * (HALS_NG * LK + 64);
+    float *dl = g + HALS_NG * LK; // deltas of this step
+    const int n0 = (blockIdx.x * (blockDim.x >> 6) + wave) * HALS_NG;
+    if (n0 >= N) return;
+    const size_t LKN = (size_t)L * K32 * Np;
+    // G = den - num for the wave's units (zero for padded units)
+    for (int j = lane; j < LK; j += 64)
+#pragma unroll
+        for (int u = 0; u < HALS_NG; ++u) {
+            int n = n0 + u;
+            g[u * LK + j] = (n < N) ? (numden[LKN + (size_t)j * Np + n] - numden[(size_t)j * Np + n]) : 0.f;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < K; ++k)
+        for (int l = 0; l < L; ++l) {
+            const int pidx = l * K32 + k;
+            const float *hrow = HH + (size_t)pidx * NpH;
+            const float hpp = hrow[pidx];
+            if (lane < HALS_NG) {
+                const int n = n0 + lane;
+                float d = 0.f;
+                if (n < N) {
+                    const size_t wi = (size_t)pidx * Np + n;
+                    const float wo = Wt[wi];
+                    const float v = g[lane * LK + pidx] - wo * hpp;
+                    float wn = (-v - l1) / (hpp + CMF_EPS_F + l2);
+                    wn = fmaxf(wn, 0.f);
+                    Wt[wi] = wn;
+                    Wn[((size_t)l * Np + n) * K32 + k] = wn;
+                    d = wn - wo;
+                }
+                dl[lane] = d;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float du[HALS_NG];
+#pragma unroll
+            for (int u = 0; u < HALS_NG; ++u) du[u] = dl[u];
+            for (int j = lane; j < LK; j += 64) {
+                const float hv = hrow[j];
+#pragma unroll
+                for (int u = 0; u < HALS_NG; ++u) g[u * LK + j] = fmaf(du[u], hv, g[u * LK + j]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
+// PT[k][t] = sum_s (den - num) of the transconv slabs [S][2][Tl][K32]; grid (ceil(Tl/64), KB), block 256
+__global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float *slabs, int S, int Tl, int K32, int TPp)
+{
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * 64, kb = blockIdx.y;
+    const size_t TK = (size_t)Tl * K32;
+    {
+        const int kk = tid & 31;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int tt = q * 8 + (tid >> 5), t = t0 + tt;
+            float v = 0.f;
+            if (t < Tl) {
+                size_t idx = (size_t)t * K32 + kb * 32 + kk;
+                float num = 0.f, den = 0.f;
+                for (int s = 0; s < S; ++s) {
+                    num += slabs[(size_t)(2 * s) * TK + idx];
+                    den += slabs[(size_t)(2 * s + 1) * TK + idx];
+                }
+                v = den - num;
+            }
+            tile[kk][tt] = v;
+        }
+    }
+    __syncthreads();
+    {
+        const int tt = tid & 63;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int kk = q * 4 + (tid >> 6);
+            PT[(size_t)(kb * 32 + kk) * TPp + t0 + tt] = tile[kk][tt]; // t0 + tt < TPp (padded)
+        }
+    }
+}
+
+// PW[l][l'][k][k'] = sum_n Wn[l][n][k] * Wn[l'][n][k'];  grid (L*L, KB*KB), block (32, 32)
+__global__ void hals_pw_kernel(const float *Wn, float *PW, int N, int L, int Np, int K32, int KB)
+{
+    const int l = blockIdx.x / L, lp = blockIdx.x % L;
+    const int kb = blockIdx.y / KB, kbp = blockIdx.y % KB;
+    const int k = kb * 32 + threadIdx.y, kp = kbp * 32 + threadIdx.x;
+    const float *a = Wn + (size_t)l * Np * K32 + k;
+    const float *b = Wn + (size_t)lp * Np * K32 + kp;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int n = 0;
+    for (; n + 4 <= N; n += 4) {
+        s0 = fmaf(a[(size_t)n * K32], b[(size_t)n * K32], s0);
+        s1 = fmaf(a[(size_t)(n + 1) * K32], b[(size_t)(n + 1) * K32], s1);
+        s2 = fmaf(a[(size_t)(n + 2) * K32], b[(size_t)(n + 2) * K32], s2);
+        s3 = fmaf(a[(size_t)(n + 3) * K32], b[(size_t)(n + 3) * K32], s3);
+    }
+    for (; n < N; ++n) s0 = fmaf(a[(size_t)n * K32], b[(size_t)n * K32], s0);
+    PW[(((size_t)l * L + lp) * K32 + k) * K32 + kp] = (s0 + s1) + (s2 + s3);
+}
+
+// GW[k][k'][e+L-1] = sum_l PW[l][l-e][k][k'], e in (-L, L)        (full-window taps)
+// GE[k][i][k'][e+L-1]: the same with only lags l < Lt(i) = ne - i ... (truncated window of edge column
+// t = t_edge0 + i, Lt = Tl - t), i in [0, ne).  One thread per output.
+__global__ void hals_gw_kernel(const float *PW, float *GW, float *GE, int L, int K32, int ne, int Tl, int t_edge0)
+{
+    const int E = 2 * L - 1;
+    const size_t nfull = (size_t)K32 * K32 * E;
+    const size_t total = nfull + (size_t)K32 * ne * K32 * E;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int k, kp, ei, Lt;
+        float *dst;
+        if (idx < nfull) {
+            ei = (int)(idx % E);
+            kp = (int)((idx / E) % K32);
+            k = (int)(idx / ((size_t)E * K32));
+            Lt = L;
+            dst = GW + idx;
+        } else {
+            size_t r = idx - nfull;
+            ei = (int)(r % E);
+            kp = (int)((r / E) % K32);
+            int i = (int)((r / ((size_t)E * K32)) % ne);
+            k = (int)(r / ((size_t)E * K32 * ne));
+            Lt = Tl - (t_edge0 + i);
+            if (Lt > L) Lt = L;
+            dst = GE + r;
+        }
+        const int e = ei - (L - 1);
+        float s = 0.f;
+        for (int l = 0; l < Lt; ++l) {
+            int lp = l - e;
+            if (lp >= 0 && lp < L) s += PW[(((size_t)l * L + lp) * K32 + k) * K32 + kp];
+        }
+        *dst = s;
+    }
+}
+
+// Serial Gauss-Seidel sweep of ONE row k of H (hals.jl:121-148) by ONE wave.  Lane j holds the
+// pending P value of the column t' with t' % 64 == j inside the window [t, t+64); the same-row taps
+// rotate one lane per step (DPP wave_ror), so a step is: 2 readlanes, 4 dependent VALU ops, 1 FMA.
+// Writes the new H row (both layouts) and the per-column change D[t] for the cross-row push.
+struct HalsRowParams {
+    float *PT;        // [K32][TPp]
+    float *H, *Ht;    // [TP][K32], [K32][TP]
+    float *D;         // [TPp]
+    const float *GW;  // [K32][K32][2L-1]
+    const float *GE;  // [K32][ne][K32][2L-1]
+    int k, Tl, L, K32, TP, TPp, PADL, ne, t_edge0;
+    float l1, l2;
+};
+
+__global__ __launch_bounds__(64) void hals_h_row_kernel(HalsRowParams q)
+{
+    const int lane = threadIdx.x;
+    const int L = q.L, E = 2 * L - 1, k = q.k;
+    float *Prow = q.PT + (size_t)k * q.TPp;
+    const float *gk = q.GW + ((size_t)k * q.K32 + k) * E + (L - 1); // gk[e], e >= 0
+    const float nrm = gk[0];
+    const float inv_den = 1.0f / (nrm + CMF_EPS_F + q.l2);
+    // taps: lane j holds g[(j - t) mod 64]; at t = 0 that is g[j] for 1 <= j < L
+    float grot = (lane >= 1 && lane < L) ? gk[lane] : 0.f;
+    float p = Prow[lane];                 // columns 0..63 (PT is padded with zeros beyond Tl)
+    float pn = Prow[64 + lane];           // refill for the next 64 columns
+    float hreg = q.Ht[(size_t)k * q.TP + q.PADL + lane];
+    float hnew = 0.f, dreg = 0.f;
+    const int nfull = q.t_edge0;          // columns [0, t_edge0) have the full window
+    for (int t = 0; t < q.Tl; ++t) {
+        const int idx = t & 63;
+        const float s_p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), idx));
+        const float s_h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg), idx));
+        float x, d;
+        if (t < nfull) {
+            x = fmaxf((s_h * nrm - s_p - q.l1) * inv_den, 0.f);
+            d = x - s_h;
+            p = fmaf(d, grot, p);
+        } else {
+            // right edge (hals.jl:136): truncated window -> per-column norm and taps from the GE table
+            const float *ge = q.GE + (((size_t)k * q.ne + (t - nfull)) * q.K32 + k) * E + (L - 1);
+            const float nrm_e = ge[0];
+            x = fmaxf((s_h * nrm_e - s_p - q.l1) / (nrm_e + CMF_EPS_F + q.l2), 0.f);
+            d = x - s_h;
+            const int e = (lane - t) & 63;
+            const float ge_l = (e >= 1 && e < L) ? ge[e] : 0.f;
+            p = fmaf(d, ge_l, p);
+        }
+        if (lane == idx) { hnew = x; dreg = d; p = pn; }
+        // rotate the taps one lane to the right: lane j <- lane j-1
+        grot = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, grot), 0x13C, 0xf, 0xf, false));
+        if (idx == 63 || t == q.Tl - 1) {
+            const int tb = t - idx; // block start
+            if (tb + lane < q.Tl) {
+                q.Ht[(size_t)k * q.TP + q.PADL + tb + lane] = hnew;
+                q.H[(size_t)(q.PADL + tb + lane) * q.K32 + k] = hnew;
+                q.D[tb + lane] = dreg;
+            }
+            if (idx == 63) {
+                pn = Prow[tb + 128 + lane];
+                hreg = q.Ht[(size_t)k * q.TP + q.PADL + tb + 64 + lane];
+            }
+        }
+    }
+}
+
+// Cross-row push of row k's changes: PT[k'][t'] += sum_e D[t'-e] * taps(t'-e)[k][k'][e] for k' > k.
+// grid (ceil(Tl/256), K32), block 256; rows k' <= k exit.
+__global__ __launch_bounds__(256) void hals_h_push_kernel(float *PT, const float *D, const float *GW, const float *GE,
+                                                          int k, int K, int Tl, int L, int K32, int TPp, int ne, int t_edge0)
+{
+    const int kp = blockIdx.y;
+    if (kp <= k || kp >= K) return;
+    const int tp = blockIdx.x * 256 + threadIdx.x;
+    if (tp >= Tl) return;
+    const int E = 2 * L - 1;
+    const float *gw = GW + ((size_t)k * K32 + kp) * E + (L - 1);
+    float s = 0.f;
+    for (int e = -(L - 1); e <= L - 1; ++e) {
+        const int t = tp - e;
+        if (t < 0 || t >= Tl) continue;
+        float tap;
+        if (t < t_edge0) tap = gw[e];
+        else tap = GE[(((size_t)k * ne + (t - t_edge0)) * K32 + kp) * E + (L - 1) + e];
+        s = fmaf(D[t], tap, s);
+    }
+    PT[(size_t)kp * TPp + tp] += s;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -236,14 +236,43 @@ class MultUpdate(AbstractCFUpdate):
 HIPMultUpdate = MultUpdate
 
 
+class HALSUpdate(MultUpdate):
+    """HALSUpdate on MI355X: drop-in for src/algs/hals.jl behind the same rule interface.
+
+    ``HALSUpdate(data, W, H)`` mirrors hals.jl:18-28.  The residual the reference carries in the
+    rule (``resids = tensor_conv(W, H) - data``) is kept implicitly (est on the device); the K*L column
+    updates of W (hals.jl:90-112) and the K*T entry updates of H (hals.jl:121-154) run in the
+    reference's Gauss-Seidel order on Gram-projected state (see cmf_kernels.h).  Clamp at 0,
+    ``+ l2`` regularisation and the incremental-residual loss are the reference's.
+    """
+
+    def update_motifs(self, data=None, W=None, H=None, l1W=0, l2W=0, **kwargs):
+        """update_motifs!(rule::HALSUpdate, data, W, H; l1W=0, l2W=0): src/algs/hals.jl:31-34."""
+        check(self._lib.cmf_hals_update_motifs(self._h, float(l1W), float(l2W)))
+
+    def update_feature_maps(self, data=None, W=None, H=None, l1H=0, l2H=0, **kwargs):
+        """update_feature_maps!(rule::HALSUpdate, data, W, H; l1H=0, l2H=0) -> loss: src/algs/hals.jl:37-42."""
+        loss = ctypes.c_double()
+        check(self._lib.cmf_hals_update_feature_maps(self._h, float(l1H), float(l2H), ctypes.byref(loss)))
+        return loss.value
+
+    def fit_native(self, *a, **kw):
+        raise NotImplementedError("cmf_fit runs the multiplicative-update rule; drive HALSUpdate with fit()")
+
+
+HIPHALSUpdate = HALSUpdate
+
+
 def _resolve_alg(alg):
     """alg may be a rule type (HEAD, model.jl:60) or a README-style symbol (README.md:30-33)."""
     if isinstance(alg, str):
         name = alg.lstrip(":").lower()
         if name in ("mult", "mu"):
             return MultUpdate
-        if name in ("hals", "anls", "admm", "pgd", "sep"):
-            raise NotImplementedError(f"alg=:{name} is outside the MI355X hot path built here (only :mult)")
+        if name == "hals":
+            return HALSUpdate
+        if name in ("anls", "admm", "pgd", "sep"):
+            raise NotImplementedError(f"alg=:{name} is outside the MI355X hot path built here (:mult and :hals)")
         raise ValueError(f"unknown algorithm {alg!r}")
     if isinstance(alg, type) and issubclass(alg, AbstractCFUpdate):
         return alg
@@ -360,7 +389,8 @@ def fit_cnmf(data, L=10, K=5, alg=MultUpdate, max_itr=100, max_time=math.inf, **
     W_init = kw.get("W_init", W_init)  # :72-73
     H_init = kw.get("H_init", H_init)
 
-    rule = rule_type(data, W_init, H_init, device=device) if rule_type is MultUpdate else rule_type(data, W_init, H_init)
+    rule = (rule_type(data, W_init, H_init, device=device) if issubclass(rule_type, MultUpdate)
+            else rule_type(data, W_init, H_init))
     try:
         opt = AlternatingOptimizer(rule, max_itr, max_time)  # :78-82
         loop_kw = {k: v for k, v in kw.items() if k not in ("seed", "W_init", "H_init")}

@@ -117,6 +117,16 @@ int cmf_fit(cmf_handle h, int64_t max_itr, double max_time,
             double l1W, double l2W, double l1H, double l2H,
             double *loss_hist, double *time_hist, int64_t *n_hist, int *converged_early);
 
+/* ---- HALS rule (BASELINE config 5) ----------------------------------------------
+ * update_motifs!(rule::HALSUpdate, data, W, H; l1W=0, l2W=0)            src/algs/hals.jl:31-34, 90-112
+ * update_feature_maps!(rule::HALSUpdate, data, W, H; l1H=0, l2H=0) -> loss   src/algs/hals.jl:37-42, 121-154
+ * on the same handle (the HALSUpdate constructor, hals.jl:18-28, needs nothing beyond cmf_create +
+ * cmf_set_factors: the residual it carries is est - data, kept implicitly).  Same Gauss-Seidel visiting
+ * order as the reference; clamp at 0 and "+ l2" regularisation as in hals.jl:110,153.
+ * Unsharded handles only (the H sweep is sequential along T); L <= 64. */
+int cmf_hals_update_motifs(cmf_handle h, double l1W, double l2W);
+int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss);
+
 /* converged(loss_hist, patience, tol): src/model.jl:91-107 (host arithmetic). */
 int cmf_converged(const double *loss_hist, int64_t len, int64_t patience, double tol);
 

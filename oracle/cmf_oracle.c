@@ -309,6 +309,116 @@ int oracle_fit_mult(int64_t N, int64_t T, int64_t K, int64_t L,
 }
 
 /* ------------------------------------------------------------------ */
+/* HALS rule (BASELINE config 5): src/algs/hals.jl                      */
+/* resids (N*T) is the rule's state, carried across iterations.        */
+/* ------------------------------------------------------------------ */
+
+/* update_motifs!(::HALSUpdate): hals.jl:31-34, :53-61, :90-112.
+ * Row ind = K*lag + k of H_unfold (common.jl:133-142) is H[k, :] shifted right by lag. */
+void oracle_hals_update_motifs(int64_t N, int64_t T, int64_t K, int64_t L,
+                               double *W, const double *H, double *resids, double l1W, double l2W)
+{
+    for (int64_t k = 0; k < K; ++k)          /* :92 k outer */
+        for (int64_t l = 0; l < L; ++l) {    /* :93 lag inner */
+            double nrm2 = 0.0;               /* H_norms[ind]^2, :57-60 */
+            for (int64_t t = l; t < T; ++t) { double h = H[k + K * (t - l)]; nrm2 += h * h; }
+            double nrm = sqrt(nrm2);
+            double *w = W + k + K * N * l;   /* W[k, n, l] at stride K over n */
+            double den = nrm * nrm + CMF_EPS + l2W;
+#pragma omp parallel for schedule(static)
+            for (int64_t n = 0; n < N; ++n) {
+                double wo = w[K * n], dot = 0.0;
+                /* :104 resids -= w_old * h' ; then :110 dot = (resids * h)[n] */
+                for (int64_t t = l; t < T; ++t) {
+                    double h = H[k + K * (t - l)];
+                    double r = resids[n + N * t] - wo * h;
+                    resids[n + N * t] = r;
+                    dot += r * h;
+                }
+                double wn = (-dot - l1W) / den;
+                wn = wn > 0.0 ? wn : 0.0;
+                w[K * n] = wn;
+                for (int64_t t = l; t < T; ++t)   /* :106 */
+                    resids[n + N * t] += wn * H[k + K * (t - l)];
+            }
+        }
+}
+
+/* update_feature_maps!(::HALSUpdate): hals.jl:37-42, :64-80, :121-154.  Returns the loss. */
+double oracle_hals_update_feature_maps(int64_t N, int64_t T, int64_t K, int64_t L,
+                                       const double *W, double *H, double *resids,
+                                       double data_norm, double l1H, double l2H)
+{
+    double *wn2 = (double *)calloc((size_t)K * L, sizeof(double)); /* W_norms[k,l]^2, :67-72 */
+    for (int64_t l = 0; l < L; ++l)
+        for (int64_t n = 0; n < N; ++n)
+            for (int64_t k = 0; k < K; ++k) {
+                double v = W[k + K * (n + N * l)];
+                wn2[k + K * l] += v * v;
+            }
+    for (int64_t k = 0; k < K; ++k)          /* :124 */
+        for (int64_t t = 0; t < T; ++t) {    /* :125 */
+            int64_t Lt = (T - t < L) ? (T - t) : L;   /* :136 */
+            double nrm2 = 0.0;
+            for (int64_t l = 0; l < Lt; ++l) nrm2 += wn2[k + K * l];
+            double nrm = sqrt(nrm2);
+            double ho = H[k + K * t], trace = 0.0;
+            for (int64_t l = 0; l < Lt; ++l) {
+                const double *w = W + k + K * N * l;
+                double *r = resids + N * (t + l);
+                for (int64_t n = 0; n < N; ++n) {
+                    double rv = r[n] - ho * w[K * n];   /* :139-140 remove factor */
+                    r[n] = rv;
+                    trace -= w[K * n] * rv;             /* :152 dot(Wkt, -remainder) */
+                }
+            }
+            double hn = (trace - l1H) / (nrm * nrm + CMF_EPS + l2H);  /* :153 */
+            hn = hn > 0.0 ? hn : 0.0;
+            H[k + K * t] = hn;
+            for (int64_t l = 0; l < Lt; ++l) {           /* :146 add back */
+                const double *w = W + k + K * N * l;
+                double *r = resids + N * (t + l);
+                for (int64_t n = 0; n < N; ++n) r[n] += hn * w[K * n];
+            }
+        }
+    free(wn2);
+    return frob_norm(resids, (size_t)N * T) / data_norm;   /* :41 */
+}
+
+int oracle_fit_hals(int64_t N, int64_t T, int64_t K, int64_t L,
+                    const double *data, double *W, double *H,
+                    int64_t max_itr, double max_time,
+                    int check_convergence, int64_t patience, double tol, int eval_mode,
+                    double l1W, double l2W, double l1H, double l2H,
+                    double *loss_hist, double *time_hist, int64_t *n_hist)
+{
+    size_t NT = (size_t)N * T;
+    double *resids = (double *)malloc(sizeof(double) * NT);
+    double data_norm = frob_norm(data, NT);                    /* hals.jl:23 */
+    oracle_tensor_conv(N, T, K, L, W, H, resids);              /* hals.jl:22 */
+    for (size_t i = 0; i < NT; ++i) resids[i] -= data[i];
+    int stopped = 0;
+    int64_t len = 0;
+    loss_hist[len] = frob_norm(resids, NT) / data_norm;        /* alternating.jl:37 (same value) */
+    time_hist[len] = 0.0;
+    ++len;
+    int64_t itr = 1;
+    while (itr <= max_itr && time_hist[len - 1] <= max_time) {
+        itr += 1;
+        double t0 = now_s();
+        if (!eval_mode) oracle_hals_update_motifs(N, T, K, L, W, H, resids, l1W, l2W);
+        double loss = oracle_hals_update_feature_maps(N, T, K, L, W, H, resids, data_norm, l1H, l2H);
+        time_hist[len] = time_hist[len - 1] + (now_s() - t0);
+        loss_hist[len] = loss;
+        ++len;
+        if (check_convergence && oracle_converged(loss_hist, len, patience, tol)) { stopped = 1; break; }
+    }
+    *n_hist = len;
+    free(resids);
+    return stopped;
+}
+
+/* ------------------------------------------------------------------ */
 /* init_rand(data, L, K): src/model.jl:113-125                          */
 /* W = rand(K,N,L); H = rand(K,T) with the portable RNG (streams 0, 1)  */
 /* in Julia memory order; alpha = <data,est>/||est||^2; both *= sqrt|a|. */

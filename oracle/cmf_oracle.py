@@ -155,6 +155,76 @@ def fit_mult(data, W_init, H_init, max_itr=100, max_time=np.inf, check_convergen
 
 
 # --------------------------------------------------------------------------
+# HALS rule (BASELINE config 5): src/algs/hals.jl
+# --------------------------------------------------------------------------
+class HALSUpdate:
+    """HALSUpdate state + ctor: src/algs/hals.jl:6-28 (resids is carried across iterations)."""
+
+    def __init__(self, data, W, H):
+        self.resids = tensor_conv(W, H) - data
+        self.data_norm = np.linalg.norm(data)
+
+
+def hals_update_motifs(rule, data, W, H, l1W=0.0, l2W=0.0):
+    """update_motifs!(::HALSUpdate): hals.jl:31-34, :53-61, :90-112.  W and rule.resids in place."""
+    K, N, L = W.shape
+    H_unfold = shift_and_stack(H, L)  # :56  row = K*lag + k
+    H_norms = np.linalg.norm(H_unfold, axis=1)  # :57-60
+    R = rule.resids
+    for k in range(K):  # :92  k outer
+        for l in range(L):  # :93  lag inner
+            ind = l * K + k  # :102 (0-based)
+            h = H_unfold[ind]
+            R -= np.outer(W[k, :, l], h)  # :104
+            # :110 _next_W_col: max.((-resid * Hkl .- l1_W) ./ (norm_Hkl^2 + EPSILON + l2_W), 0.0)
+            W[k, :, l] = np.maximum((-(R @ h) - l1W) / (H_norms[ind] ** 2 + EPS + l2W), 0.0)
+            R += np.outer(W[k, :, l], h)  # :106
+    return W
+
+
+def hals_update_feature_maps(rule, data, W, H, l1H=0.0, l2H=0.0):
+    """update_feature_maps!(::HALSUpdate): hals.jl:37-42, :64-80, :121-154.  H and rule.resids in place."""
+    K, N, L = W.shape
+    T = H.shape[1]
+    W_norms = np.linalg.norm(W, axis=1)  # :67-72  (K, L)
+    R = rule.resids
+    for k in range(K):  # :124
+        Wk = W[k]  # N x L (:76-79)
+        for t in range(T):  # :125
+            Lt = min(T - t, L)  # :136 (1-based min(T-t+1, L))
+            norm_Wkt = np.linalg.norm(W_norms[k, :Lt])  # :136
+            rem = R[:, t: t + Lt]
+            rem += (-H[k, t]) * Wk[:, :Lt]  # :139-140
+            trace = np.sum(Wk[:, :Lt] * (-rem))  # :152
+            H[k, t] = max((trace - l1H) / (norm_Wkt ** 2 + EPS + l2H), 0.0)  # :153
+            rem += H[k, t] * Wk[:, :Lt]  # :146
+    return np.linalg.norm(R) / rule.data_norm  # :41
+
+
+def fit_hals(data, W_init, H_init, max_itr=100, max_time=np.inf, check_convergence=True,
+             patience=3, tol=1e-4, eval_mode=False, l1W=0.0, l2W=0.0, l1H=0.0, l2H=0.0):
+    """fit(::AlternatingOptimizer{HALSUpdate}): src/algs/alternating.jl:16-71."""
+    assert patience >= 1
+    W = np.array(W_init, dtype=np.float64, copy=True)
+    H = np.array(H_init, dtype=np.float64, copy=True)
+    rule = HALSUpdate(data, W, H)
+    loss_hist = [compute_loss(data, W, H)]
+    time_hist = [0.0]
+    itr = 1
+    while itr <= max_itr and time_hist[-1] <= max_time:
+        itr += 1
+        t0 = time.time()
+        if not eval_mode:
+            hals_update_motifs(rule, data, W, H, l1W=l1W, l2W=l2W)
+        loss = hals_update_feature_maps(rule, data, W, H, l1H=l1H, l2H=l2H)
+        time_hist.append(time_hist[-1] + (time.time() - t0))
+        loss_hist.append(loss)
+        if check_convergence and converged(loss_hist, patience, tol):
+            break
+    return W, H, np.asarray(loss_hist), np.asarray(time_hist)
+
+
+# --------------------------------------------------------------------------
 # index-level brute force (tiny sizes only; third, independent statement)
 # --------------------------------------------------------------------------
 def brute_conv(W, H):
@@ -222,6 +292,9 @@ def c_lib():
         lib.oracle_fit_mult.argtypes = ([i64] * 4 + [pd] * 3 + [i64, dbl, ctypes.c_int, i64, dbl, ctypes.c_int]
                                         + [dbl] * 4 + [pd, pd, ctypes.POINTER(i64)])
         lib.oracle_fit_mult.restype = ctypes.c_int
+        lib.oracle_fit_hals.argtypes = ([i64] * 4 + [pd] * 3 + [i64, dbl, ctypes.c_int, i64, dbl, ctypes.c_int]
+                                        + [dbl] * 4 + [pd, pd, ctypes.POINTER(i64)])
+        lib.oracle_fit_hals.restype = ctypes.c_int
         lib.oracle_init_rand.argtypes = [i64] * 4 + [u64] + [pd] * 3
         lib.oracle_init_rand.restype = None
         lib.oracle_gen_synthetic.argtypes = [i64] * 4 + [dbl] * 4 + [u64] + [pd] * 3
@@ -272,6 +345,22 @@ def c_fit_mult(data, W_init, H_init, max_itr=100, max_time=np.inf, check_converg
     th = np.zeros(max_itr + 1)
     n = ctypes.c_int64(0)
     c_lib().oracle_fit_mult(N, T, K, L, _p(d), _p(W), _p(H), max_itr, float(max_time),
+                            int(check_convergence), patience, tol, int(eval_mode),
+                            l1W, l2W, l1H, l2H, _p(lh), _p(th), ctypes.byref(n))
+    return W, H, lh[: n.value].copy(), th[: n.value].copy()
+
+
+def c_fit_hals(data, W_init, H_init, max_itr=100, max_time=np.inf, check_convergence=True,
+               patience=3, tol=1e-4, eval_mode=False, l1W=0.0, l2W=0.0, l1H=0.0, l2H=0.0):
+    K, N, L = W_init.shape
+    d = _f(data)
+    W = np.array(W_init, dtype=np.float64, order="F", copy=True)
+    H = np.array(H_init, dtype=np.float64, order="F", copy=True)
+    T = H.shape[1]
+    lh = np.zeros(max_itr + 1)
+    th = np.zeros(max_itr + 1)
+    n = ctypes.c_int64(0)
+    c_lib().oracle_fit_hals(N, T, K, L, _p(d), _p(W), _p(H), max_itr, float(max_time),
                             int(check_convergence), patience, tol, int(eval_mode),
                             l1W, l2W, l1H, l2H, _p(lh), _p(th), ctypes.byref(n))
     return W, H, lh[: n.value].copy(), th[: n.value].copy()

@@ -1,0 +1,64 @@
+"""TEST INFRASTRUCTURE: numpy statement of the Gram-projected HALS sweeps the GPU kernels implement
+(cmf.jl_amd/csrc/cmf_kernels.h, "HALS rule").  tests/test_oracle.py checks it against the literal
+residual-form restatement of src/algs/hals.jl in the oracle."""
+import numpy as np
+
+
+def w_sweep(o, W, H, data, l1, l2):
+    """hals.jl:90-112 on G = resid * H_unfold' and HH = H_unfold * H_unfold'."""
+    K, N, L = W.shape
+    R = o.tensor_conv(W, H) - data
+    Hu = o.shift_and_stack(H, L)  # row = l*K + k
+    G = R @ Hu.T                  # (= denomW - numW of the MU path)
+    HH = Hu @ Hu.T
+    W = W.copy()
+    for k in range(K):
+        for l in range(L):
+            j = l * K + k
+            wo = W[k, :, l].copy()
+            v = G[:, j] - wo * HH[j, j]
+            wn = np.maximum((-v - l1) / (HH[j, j] + o.EPS + l2), 0.0)
+            G += np.outer(wn - wo, HH[j])
+            W[k, :, l] = wn
+    return W
+
+
+def h_sweep(o, W, H, data, l1, l2):
+    """hals.jl:121-154 on P = transconv(W, resid) and the lag-Gram taps of W."""
+    K, N, L = W.shape
+    T = H.shape[1]
+    R = o.tensor_conv(W, H) - data
+    P = o.tensor_transconv(W, R)  # (= denomH - numH of the MU path)
+    PW = np.einsum("knl,jnm->lmkj", W, W)  # PW[l, l', k, k'] = <W[k,:,l], W[k',:,l']>
+
+    def taps(k, Lt):  # g[k', e+L-1] = sum_{l < Lt} PW[l, l-e, k, k']
+        g = np.zeros((K, 2 * L - 1))
+        for e in range(-(L - 1), L):
+            for l in range(Lt):
+                if 0 <= l - e < L:
+                    g[:, e + L - 1] += PW[l, l - e, k, :]
+        return g
+
+    H = H.copy()
+    for k in range(K):
+        full = taps(k, L)
+        D = np.zeros(T)
+        gs = {}
+        for t in range(T):
+            Lt = min(L, T - t)
+            g = full if Lt == L else gs.setdefault(t, taps(k, Lt))
+            nrm = g[k, L - 1]
+            ho = H[k, t]
+            hn = max((ho * nrm - P[k, t] - l1) / (nrm + o.EPS + l2), 0.0)
+            D[t] = hn - ho
+            H[k, t] = hn
+            for e in range(1, L):           # same row, later columns
+                if t + e < T:
+                    P[k, t + e] += D[t] * g[k, e + L - 1]
+        for t in range(T):                   # later rows
+            Lt = min(L, T - t)
+            g = full if Lt == L else gs[t]
+            for e in range(-(L - 1), L):
+                if 0 <= t + e < T:
+                    P[k + 1:, t + e] += D[t] * g[k + 1:, e + L - 1]
+    return H

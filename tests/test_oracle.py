@@ -202,3 +202,34 @@ def test_golden_fixtures(oracle, name):
         np.testing.assert_allclose(H, g["H"], rtol=1e-7, atol=1e-12)
     np.testing.assert_allclose(oracle.tensor_conv(g["W0"], g["H0"]), g["conv0"], rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(oracle.tensor_transconv(g["W0"], g["data"]), g["transconv0"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("reg", [dict(), dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2)])
+def test_hals_c_vs_numpy(oracle, reg):
+    """hals.jl restated twice (literal residual form), plus the Gram-projected form the GPU kernels use."""
+    data, _, _ = oracle.c_gen_synthetic(N=30, T=120, K=3, L=8, seed=7)
+    W0, H0 = oracle.c_init_rand(data, L=6, K=4, seed=0)
+    Wa, Ha, la, _ = oracle.fit_hals(data, W0, H0, max_itr=6, check_convergence=False, **reg)
+    Wb, Hb, lb, _ = oracle.c_fit_hals(data, W0, H0, max_itr=6, check_convergence=False, **reg)
+    np.testing.assert_allclose(la, lb, rtol=1e-11)
+    np.testing.assert_allclose(Wa, Wb, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(Ha, Hb, rtol=1e-9, atol=1e-13)
+    assert np.all(np.diff(la) <= 1e-12) and Wa.min() >= 0.0 and Ha.min() >= 0.0
+    assert np.mean(Ha == 0.0) > 0.05  # HALS produces exact zeros (clamp at 0)
+
+
+def test_hals_gram_form_equals_residual_form(oracle):
+    """The algebra behind the GPU HALS kernels: sweeping on G = resid*H_unfold' / P = transconv(W, resid)
+    with Gram updates reproduces the reference's residual sweeps exactly (incl. the right-edge truncation)."""
+    from hals_gram_form import h_sweep, w_sweep
+
+    data, _, _ = oracle.c_gen_synthetic(N=12, T=40, K=3, L=6, seed=3)
+    W0, H0 = oracle.c_init_rand(data, L=5, K=3, seed=0)
+    for l1, l2 in ((0.0, 0.0), (0.1, 0.3)):
+        W, H = W0.copy(), H0.copy()
+        rule = oracle.HALSUpdate(data, W, H)
+        oracle.hals_update_motifs(rule, data, W, H, l1W=l1, l2W=l2)
+        np.testing.assert_allclose(w_sweep(oracle, W0, H0, data, l1, l2), W, rtol=1e-10, atol=1e-13)
+        Hn = H.copy()
+        oracle.hals_update_feature_maps(rule, data, W, Hn, l1H=l1, l2H=l2)
+        np.testing.assert_allclose(h_sweep(oracle, W, H0, data, l1, l2), Hn, rtol=1e-10, atol=1e-13)
