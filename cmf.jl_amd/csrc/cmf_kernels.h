@@ -948,22 +948,75 @@ struct HalsRowParams {
     float l1, l2;
 };
 
+// lane i <- lane i+1; lane 63 keeps `fill`
+__device__ __forceinline__ float cmf_wave_shl1(float v, float fill)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+// lane i <- lane i+1, lane 63 <- lane 0
+__device__ __forceinline__ float cmf_wave_rol1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xf, 0xf, false));
+}
+// lane i <- lane i-1, lane 0 <- lane 63
+__device__ __forceinline__ float cmf_wave_ror1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float cmf_lane0(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
 __global__ __launch_bounds__(64) void hals_h_row_kernel(HalsRowParams q)
 {
     const int lane = threadIdx.x;
     const int L = q.L, E = 2 * L - 1, k = q.k;
     float *Prow = q.PT + (size_t)k * q.TPp;
+    float *Hrow = q.Ht + (size_t)k * q.TP + q.PADL;
     const float *gk = q.GW + ((size_t)k * q.K32 + k) * E + (L - 1); // gk[e], e >= 0
     const float nrm = gk[0];
     const float inv_den = 1.0f / (nrm + CMF_EPS_F + q.l2);
-    // taps: lane j holds g[(j - t) mod 64]; at t = 0 that is g[j] for 1 <= j < L
-    float grot = (lane >= 1 && lane < L) ? gk[lane] : 0.f;
-    float p = Prow[lane];                 // columns 0..63 (PT is padded with zeros beyond Tl)
-    float pn = Prow[64 + lane];           // refill for the next 64 columns
-    float hreg = q.Ht[(size_t)k * q.TP + q.PADL + lane];
+    const float g = (lane >= 1 && lane < L) ? gk[lane] : 0.f; // same-row taps, lane = column offset
+    const int nfull = q.t_edge0;                              // columns [0, nfull) have the full lag window
+    float p = Prow[lane];      // pending P of columns tb + lane (PT is zero-padded beyond Tl)
+    float pn = Prow[64 + lane]; // columns tb + 64 + lane: enter the window one per step
+    float hreg = Hrow[lane];   // H_old of columns tb + lane
+    int tb = 0;
+    // ---- fast path: whole 64-column blocks with the full window.  The window slides one lane per step
+    // (DPP wave shift), so the active column is always lane 0 and the taps never move.
+    for (; tb + 64 <= nfull; tb += 64) {
+        const float pn2 = Prow[tb + 128 + lane];
+        const float hreg2 = Hrow[tb + 64 + lane];
+        float creg = (hreg * nrm - q.l1) * inv_den; // (h_old*nrm - l1)/(nrm+eps+l2) per column
+        float pnr = cmf_wave_rol1(pn);              // lane 63 holds the column that enters next (pn[0] first)
+        float hnew = 0.f, dreg = 0.f;
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) {
+            const float s_p = cmf_lane0(p);
+            const float s_c = cmf_lane0(creg);
+            const float s_h = cmf_lane0(hreg);
+            const float x = fmaxf(fmaf(-inv_den, s_p, s_c), 0.f); // hals.jl:152-153
+            const float d = x - s_h;
+            p = fmaf(d, g, p);                                    // hals.jl:146 on the projected state
+            p = cmf_wave_shl1(p, pnr);
+            pnr = cmf_wave_rol1(pnr);
+            hnew = cmf_wave_shl1(hnew, x);
+            dreg = cmf_wave_shl1(dreg, d);
+            hreg = cmf_wave_shl1(hreg, 0.f);
+            creg = cmf_wave_shl1(creg, 0.f);
+        }
+        Hrow[tb + lane] = hnew;
+        q.H[(size_t)(q.PADL + tb + lane) * q.K32 + k] = hnew;
+        q.D[tb + lane] = dreg;
+        pn = pn2;
+        hreg = hreg2;
+    }
+    // ---- generic path (right-edge columns, hals.jl:136, and what is left of the last block): lane j
+    // holds the column t' with t' % 64 == j; the taps rotate instead of the window.
+    float grot = g;
     float hnew = 0.f, dreg = 0.f;
-    const int nfull = q.t_edge0;          // columns [0, t_edge0) have the full window
-    for (int t = 0; t < q.Tl; ++t) {
+    for (int t = tb; t < q.Tl; ++t) {
         const int idx = t & 63;
         const float s_p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), idx));
         const float s_h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg), idx));
@@ -973,7 +1026,6 @@ __global__ __launch_bounds__(64) void hals_h_row_kernel(HalsRowParams q)
             d = x - s_h;
             p = fmaf(d, grot, p);
         } else {
-            // right edge (hals.jl:136): truncated window -> per-column norm and taps from the GE table
             const float *ge = q.GE + (((size_t)k * q.ne + (t - nfull)) * q.K32 + k) * E + (L - 1);
             const float nrm_e = ge[0];
             x = fmaxf((s_h * nrm_e - s_p - q.l1) / (nrm_e + CMF_EPS_F + q.l2), 0.f);
@@ -983,18 +1035,17 @@ __global__ __launch_bounds__(64) void hals_h_row_kernel(HalsRowParams q)
             p = fmaf(d, ge_l, p);
         }
         if (lane == idx) { hnew = x; dreg = d; p = pn; }
-        // rotate the taps one lane to the right: lane j <- lane j-1
-        grot = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, grot), 0x13C, 0xf, 0xf, false));
+        grot = cmf_wave_ror1(grot);
         if (idx == 63 || t == q.Tl - 1) {
-            const int tb = t - idx; // block start
-            if (tb + lane < q.Tl) {
-                q.Ht[(size_t)k * q.TP + q.PADL + tb + lane] = hnew;
-                q.H[(size_t)(q.PADL + tb + lane) * q.K32 + k] = hnew;
-                q.D[tb + lane] = dreg;
+            const int t0 = t - idx;
+            if (t0 + lane < q.Tl) {
+                Hrow[t0 + lane] = hnew;
+                q.H[(size_t)(q.PADL + t0 + lane) * q.K32 + k] = hnew;
+                q.D[t0 + lane] = dreg;
             }
             if (idx == 63) {
-                pn = Prow[tb + 128 + lane];
-                hreg = q.Ht[(size_t)k * q.TP + q.PADL + tb + 64 + lane];
+                pn = Prow[t0 + 128 + lane];
+                hreg = Hrow[t0 + 64 + lane];
             }
         }
     }

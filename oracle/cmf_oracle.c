@@ -115,7 +115,7 @@ void oracle_tensor_conv(int64_t N, int64_t T, int64_t K, int64_t L,
     memset(est, 0, sizeof(double) * (size_t)N * (size_t)T);
     for (int64_t lag = 0; lag < L && lag < T; ++lag) {
         const double *Wl = W + (size_t)K * N * lag;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N * K * (T - lag) > 2000000)
         for (int64_t t = lag; t < T; ++t) {
             const double *h = H + (size_t)K * (t - lag);
             double *e = est + (size_t)N * t;
@@ -137,7 +137,7 @@ void oracle_tensor_transconv(int64_t N, int64_t T, int64_t K, int64_t L,
     memset(out, 0, sizeof(double) * (size_t)K * (size_t)T);
     for (int64_t lag = 0; lag < L && lag < T; ++lag) {
         const double *Wl = W + (size_t)K * N * lag;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N * K * (T - lag) > 2000000)
         for (int64_t t = 0; t < T - lag; ++t) {
             const double *x = X + (size_t)N * (t + lag);
             double *o = out + (size_t)K * t;
@@ -153,7 +153,7 @@ void oracle_tensor_transconv(int64_t N, int64_t T, int64_t K, int64_t L,
 static double frob_norm(const double *x, size_t n)
 {
     double s = 0.0;
-#pragma omp parallel for reduction(+ : s) schedule(static)
+#pragma omp parallel for reduction(+ : s) schedule(static) if (n > 2000000)
     for (int64_t i = 0; i < (int64_t)n; ++i) s += x[i] * x[i];
     return sqrt(s);
 }
@@ -179,7 +179,7 @@ void oracle_hxt(int64_t N, int64_t T, int64_t K, int64_t L,
                 const double *H, const double *X, double *out)
 {
     memset(out, 0, sizeof(double) * (size_t)K * N * L);
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) if (N * K * T > 2000000)
     for (int64_t lag = 0; lag < L; ++lag) {
         double *o = out + (size_t)K * N * lag;
         for (int64_t t = 0; t < T - lag; ++t) {
@@ -325,7 +325,7 @@ void oracle_hals_update_motifs(int64_t N, int64_t T, int64_t K, int64_t L,
             double nrm = sqrt(nrm2);
             double *w = W + k + K * N * l;   /* W[k, n, l] at stride K over n */
             double den = nrm * nrm + CMF_EPS + l2W;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (N * (T - l) > 2000000)
             for (int64_t n = 0; n < N; ++n) {
                 double wo = w[K * n], dot = 0.0;
                 /* :104 resids -= w_old * h' ; then :110 dot = (resids * h)[n] */

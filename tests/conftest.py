@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# the oracle's OpenMP regions are small: a thread per visible core (64+ on the GPU box, of which the
+# container may use a fraction) only adds spinning
+os.environ.setdefault("OMP_NUM_THREADS", str(min(8, os.cpu_count() or 1)))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
