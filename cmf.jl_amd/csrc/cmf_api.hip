@@ -90,6 +90,7 @@ struct cmf_handle_s {
     int hals_NpH = 0, hals_TPp = 0, hals_ne = 0, hals_t_edge0 = 0, hals_nch = 1, hals_clen = 6;
     float *hals_HuT = nullptr, *hals_hhslabs = nullptr, *hals_HH = nullptr, *hals_PT = nullptr, *hals_D = nullptr;
     float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr;
+    int hals_seg = 256, hals_nseg = 1;      // column segments of the pipelined H sweep
 
     double data_sumsq = 0.0, data_norm = 0.0;
     bool factors_set = false;
@@ -755,10 +756,18 @@ static int hals_ensure(cmf_handle_s *h)
     CMFTRY(dalloc_zero(&h->hals_hhslabs, (size_t)h->hals_nch * LKN));
     CMFTRY(dalloc_zero(&h->hals_HH, LKN));
     CMFTRY(dalloc_zero(&h->hals_PT, (size_t)d.K32 * h->hals_TPp));
-    CMFTRY(dalloc_zero(&h->hals_D, (size_t)h->hals_TPp));
+    CMFTRY(dalloc_zero(&h->hals_D, (size_t)d.K32 * h->hals_TPp)); // per row: rows run concurrently
     CMFTRY(dalloc_zero(&h->hals_PW, (size_t)d.L * d.L * d.K32 * d.K32));
     CMFTRY(dalloc_zero(&h->hals_GW, (size_t)d.K32 * d.K32 * E));
     CMFTRY(dalloc_zero(&h->hals_GE, (size_t)d.K32 * std::max(1, h->hals_ne) * d.K32 * E));
+    {   // row pipeline: segment length (multiple of 64, >= 256 so that the sweeps and pushes of one stage
+        // touch disjoint columns: see hals_h_stage_kernel)
+        const char *env = getenv("CMF_HALS_SEG");
+        int seg = env ? atoi(env) : 256;
+        seg = (int)rup(std::max(seg, 256), 64);
+        h->hals_seg = seg;
+        h->hals_nseg = (d.Tl + seg - 1) / seg;
+    }
     h->hals_ready = true;
     return CMF_OK;
 }
@@ -806,15 +815,19 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
     q.PT = h->hals_PT; q.H = h->H; q.Ht = h->Ht; q.D = h->hals_D; q.GW = h->hals_GW; q.GE = h->hals_GE;
     q.Tl = d.Tl; q.L = d.L; q.K32 = d.K32; q.TP = d.TP; q.TPp = h->hals_TPp; q.PADL = d.PADL; q.ne = h->hals_ne; q.t_edge0 = h->hals_t_edge0;
     q.l1 = (float)l1H; q.l2 = (float)l2H;
-    for (int k = 0; k < d.K; ++k) { // hals.jl:124 (k outer); the t loop (:125) is inside the row kernel
-        q.k = k;
-        hipLaunchKernelGGL(hals_h_row_kernel, dim3(1), dim3(64), 0, h->stream, q);
-        KCHK("hals_h_row_kernel");
-        if (k + 1 < d.K) {
-            hipLaunchKernelGGL(hals_h_push_kernel, dim3((d.Tl + 255) / 256, d.K), dim3(256), 0, h->stream, h->hals_PT, h->hals_D, h->hals_GW,
-                               h->hals_GE, k, d.K, d.Tl, d.L, d.K32, h->hals_TPp, h->hals_ne, h->hals_t_edge0);
-            KCHK("hals_h_push_kernel");
-        }
+    // hals.jl:124-125: k outer, t inner, as a software pipeline over the rows: one launch per stage
+    // (see hals_h_stage_kernel); the order of every update is the reference's.
+    HalsStageParams sp;
+    sp.row = q;
+    sp.Dall = h->hals_D;
+    sp.K = d.K; sp.seg = h->hals_seg; sp.nseg = h->hals_nseg;
+    sp.CB = (h->hals_seg + 2 * (d.L - 1) + 255) / 256;
+    const int nstages = h->hals_nseg + 3 * (d.K - 1) + 1; // +1: the pushes of the last sweeps (no-ops for the last row)
+    dim3 grid(d.K + d.K * sp.CB, std::max(1, d.K - 1));
+    for (int stage = 0; stage < nstages; ++stage) {
+        sp.stage = stage;
+        hipLaunchKernelGGL(hals_h_stage_kernel, grid, dim3(256), 0, h->stream, sp);
+        KCHK("hals_h_stage_kernel");
     }
     h->est_valid = false;
     return CMF_OK;

@@ -945,6 +945,7 @@ struct HalsRowParams {
     const float *GW;  // [K32][K32][2L-1]
     const float *GE;  // [K32][ne][K32][2L-1]
     int k, Tl, L, K32, TP, TPp, PADL, ne, t_edge0;
+    int t_begin, t_end; // column segment of this launch (t_begin multiple of 64; t_end multiple of 64 or Tl)
     float l1, l2;
 };
 
@@ -968,9 +969,8 @@ __device__ __forceinline__ float cmf_lane0(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
-__global__ __launch_bounds__(64) void hals_h_row_kernel(HalsRowParams q)
+__device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lane)
 {
-    const int lane = threadIdx.x;
     const int L = q.L, E = 2 * L - 1, k = q.k;
     float *Prow = q.PT + (size_t)k * q.TPp;
     float *Hrow = q.Ht + (size_t)k * q.TP + q.PADL;
@@ -979,13 +979,14 @@ __global__ __launch_bounds__(64) void hals_h_row_kernel(HalsRowParams q)
     const float inv_den = 1.0f / (nrm + CMF_EPS_F + q.l2);
     const float g = (lane >= 1 && lane < L) ? gk[lane] : 0.f; // same-row taps, lane = column offset
     const int nfull = q.t_edge0;                              // columns [0, nfull) have the full lag window
-    float p = Prow[lane];      // pending P of columns tb + lane (PT is zero-padded beyond Tl)
-    float pn = Prow[64 + lane]; // columns tb + 64 + lane: enter the window one per step
-    float hreg = Hrow[lane];   // H_old of columns tb + lane
-    int tb = 0;
+    int tb = q.t_begin;
+    float p = Prow[tb + lane];       // pending P of columns tb + lane (PT is zero-padded beyond Tl)
+    float pn = Prow[tb + 64 + lane]; // columns tb + 64 + lane: enter the window one per step
+    float hreg = Hrow[tb + lane];    // H_old of columns tb + lane
+    const int t_stop = q.t_end < q.Tl ? q.t_end : q.Tl;
     // ---- fast path: whole 64-column blocks with the full window.  The window slides one lane per step
     // (DPP wave shift), so the active column is always lane 0 and the taps never move.
-    for (; tb + 64 <= nfull; tb += 64) {
+    for (; tb + 64 <= nfull && tb + 64 <= t_stop; tb += 64) {
         const float pn2 = Prow[tb + 128 + lane];
         const float hreg2 = Hrow[tb + 64 + lane];
         float creg = (hreg * nrm - q.l1) * inv_den; // (h_old*nrm - l1)/(nrm+eps+l2) per column
@@ -1014,9 +1015,15 @@ __global__ __launch_bounds__(64) void hals_h_row_kernel(HalsRowParams q)
     }
     // ---- generic path (right-edge columns, hals.jl:136, and what is left of the last block): lane j
     // holds the column t' with t' % 64 == j; the taps rotate instead of the window.
+    if (tb >= t_stop) {
+        // segment ends on a block boundary: hand the pending window (same-row pushes applied) to the
+        // launch that continues this row
+        if (t_stop < q.Tl) Prow[tb + lane] = p;
+        return;
+    }
     float grot = g;
     float hnew = 0.f, dreg = 0.f;
-    for (int t = tb; t < q.Tl; ++t) {
+    for (int t = tb; t < t_stop; ++t) {
         const int idx = t & 63;
         const float s_p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), idx));
         const float s_h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg), idx));
@@ -1036,7 +1043,7 @@ __global__ __launch_bounds__(64) void hals_h_row_kernel(HalsRowParams q)
         }
         if (lane == idx) { hnew = x; dreg = d; p = pn; }
         grot = cmf_wave_ror1(grot);
-        if (idx == 63 || t == q.Tl - 1) {
+        if (idx == 63 || t == t_stop - 1) {
             const int t0 = t - idx;
             if (t0 + lane < q.Tl) {
                 Hrow[t0 + lane] = hnew;
@@ -1049,29 +1056,69 @@ __global__ __launch_bounds__(64) void hals_h_row_kernel(HalsRowParams q)
             }
         }
     }
+    if (t_stop < q.Tl) Prow[t_stop + lane] = p; // (t_stop is a multiple of 64 here) window for the next launch
 }
 
 // Cross-row push of row k's changes: PT[k'][t'] += sum_e D[t'-e] * taps(t'-e)[k][k'][e] for k' > k.
-// grid (ceil(Tl/256), K32), block 256; rows k' <= k exit.
-__global__ __launch_bounds__(256) void hals_h_push_kernel(float *PT, const float *D, const float *GW, const float *GE,
-                                                          int k, int K, int Tl, int L, int K32, int TPp, int ne, int t_edge0)
+// sources: columns [s_begin, s_end) of row k; targets: [s_begin-(L-1), s_end+L-1) of one later row kp;
+// cb = 256-column block of the target range, tid = thread in the block
+__device__ __forceinline__ void hals_h_push(float *PT, const float *D, const float *GW, const float *GE,
+                                            int k, int kp, int Tl, int L, int K32, int TPp, int ne, int t_edge0,
+                                            int s_begin, int s_end, int cb, int tid)
 {
-    const int kp = blockIdx.y;
-    if (kp <= k || kp >= K) return;
-    const int tp = blockIdx.x * 256 + threadIdx.x;
-    if (tp >= Tl) return;
+    const int tp = s_begin - (L - 1) + cb * 256 + tid;
+    if (tp < 0 || tp >= Tl || tp >= s_end + L - 1) return;
     const int E = 2 * L - 1;
     const float *gw = GW + ((size_t)k * K32 + kp) * E + (L - 1);
     float s = 0.f;
     for (int e = -(L - 1); e <= L - 1; ++e) {
         const int t = tp - e;
-        if (t < 0 || t >= Tl) continue;
+        if (t < s_begin || t >= s_end) continue;
         float tap;
         if (t < t_edge0) tap = gw[e];
         else tap = GE[(((size_t)k * ne + (t - t_edge0)) * K32 + kp) * E + (L - 1) + e];
         s = fmaf(D[t], tap, s);
     }
     PT[(size_t)kp * TPp + tp] += s;
+}
+
+
+// One pipeline stage of the H sweep (hals.jl:121-154).  Row k sweeps column segment sg = stage - 3k, and
+// the changes of the segments swept in the previous stage are pushed to the later rows.  The lag of 3
+// stages per row guarantees that (a) everything that influences a segment has been pushed before it is
+// swept and (b) the sweeps and pushes of one launch touch disjoint columns (segments are >= 256 columns),
+// so the update order is exactly the reference's while up to ceil(nseg/3) rows are in flight.
+// grid: (K + K*CB, max(1, K-1)), block 256.   blockIdx.x < K: sweep of row blockIdx.x (wave 0 only).
+struct HalsStageParams {
+    HalsRowParams row;  // k, D, t_begin, t_end filled per block
+    float *Dall;        // [K32][TPp]
+    int K, seg, nseg, CB, stage;
+};
+
+__global__ __launch_bounds__(256) void hals_h_stage_kernel(HalsStageParams sp)
+{
+    const int bx = blockIdx.x;
+    if (bx < sp.K) {
+        if (blockIdx.y != 0 || threadIdx.x >= 64) return;
+        const int k = bx, sg = sp.stage - 3 * k;
+        if (sg < 0 || sg >= sp.nseg) return;
+        HalsRowParams q = sp.row;
+        q.k = k;
+        q.D = sp.Dall + (size_t)k * q.TPp;
+        q.t_begin = sg * sp.seg;
+        q.t_end = (sg + 1) * sp.seg < q.Tl ? (sg + 1) * sp.seg : q.Tl;
+        hals_h_row_sweep(q, threadIdx.x);
+    } else {
+        const int k = (bx - sp.K) / sp.CB, cb = (bx - sp.K) % sp.CB;
+        const int sg = sp.stage - 1 - 3 * k; // swept in the previous stage
+        const int kp = k + 1 + blockIdx.y;
+        if (sg < 0 || sg >= sp.nseg || kp >= sp.K) return;
+        const HalsRowParams &r = sp.row;
+        const int s_begin = sg * sp.seg;
+        const int s_end = (sg + 1) * sp.seg < r.Tl ? (sg + 1) * sp.seg : r.Tl;
+        hals_h_push(r.PT, sp.Dall + (size_t)k * r.TPp, r.GW, r.GE, k, kp, r.Tl, r.L, r.K32, r.TPp, r.ne, r.t_edge0,
+                    s_begin, s_end, cb, threadIdx.x);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
