@@ -27,12 +27,31 @@ CONFIGS = {
     2: dict(N=2000, T=50000, K=32, L=20),
     3: dict(N=2000, T=400000, K=32, L=20),
     4: dict(N=2000, T=50000, K=32, L=20, l1_H=0.1, l2_H=0.2, l1_W=0.1, l2_W=0.5),
+    5: dict(N=2000, T=50000, K=32, L=20, alg="hals"),
 }
 
 
 def flops_per_iter(N, T, K, L):
     S = L * T - L * (L - 1) / 2
     return 14.0 * K * N * S  # 7 contractions x 2*K*N*S
+
+
+def cpu_baseline_hals(data, W0, H0, budget_s):
+    """HALS (src/algs/hals.jl) has no BLAS structure; the oracle's C restatement is timed on the first
+    columns of the workload (one full iteration costs minutes on a CPU) and scaled to the full T."""
+    import numpy as np
+    from oracle import cmf_oracle as oracle
+
+    T = data.shape[1]
+    Ts = min(T, 1000)
+    d = np.asfortranarray(data[:, :Ts])
+    H = np.asfortranarray(H0[:, :Ts])
+    t1 = time.perf_counter()
+    oracle.c_fit_hals(d, W0, H, max_itr=1, check_convergence=False)
+    el = time.perf_counter() - t1
+    return dict(value=(Ts / T) / el, unit="iter/s", cores=int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), kind="port",
+                sample=f"1 HALS iteration (hals.jl update_motifs!+update_feature_maps!, oracle C restatement, fp64) on the "
+                       f"first {Ts} of {T} columns: {el:.1f} s, scaled by {Ts}/{T} (both HALS sweeps are linear in T)")
 
 
 def cpu_baseline(data, W0, H0, budget_s):
@@ -70,6 +89,8 @@ def cpu_baseline(data, W0, H0, budget_s):
 
 
 def main():
+    # the oracle's OpenMP loops (HALS baseline) are short: one thread per visible core only adds spinning
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -94,6 +115,7 @@ def main():
     if args.T:
         cfg["T"] = args.T
     N, T, K, L = cfg["N"], cfg["T"], cfg["K"], cfg["L"]
+    alg = cfg.pop("alg", "mult")
     reg = {k: v for k, v in cfg.items() if k.startswith("l")}
     reg_kw = dict(l1W=reg.get("l1_W", 0.0), l2W=reg.get("l2_W", 0.0), l1H=reg.get("l1_H", 0.0), l2H=reg.get("l2_H", 0.0))
 
@@ -123,8 +145,10 @@ def main():
     data = cmf.gen_synthetic(N=N, T=T, seed=1234, device=local_rank)
     W0, H0 = cmf.init_rand(data, L=L, K=K, seed=0, device=local_rank)
 
+    if alg == "hals" and world > 1:
+        raise SystemExit("config 5 (HALS) does not shard: its H sweep is sequential along T (replicas only)")
     if world == 1:
-        rule = cmf.MultUpdate(data, W0, H0, device=local_rank)
+        rule = (cmf.HALSUpdate if alg == "hals" else cmf.MultUpdate)(data, W0, H0, device=local_rank)
 
         def step():
             rule.update_motifs(l1W=reg_kw["l1W"], l2W=reg_kw["l2W"])
@@ -170,7 +194,7 @@ def main():
     # Same loop with the reference's redundant est recomputation left in (7 executed contractions
     # instead of 6): reported beside the headline so both numbers come from one run.
     dt_noreuse = None
-    if world == 1:
+    if world == 1 and alg == "mult":
         rule.set_option("reuse_est", 0)
         dt_noreuse, _ = timed(1, max(3, args.steps // 2))
         dt_noreuse /= max(3, args.steps // 2)
@@ -181,19 +205,24 @@ def main():
         ms = 1e3 * dt / args.steps
         iters_per_s = args.steps / dt
         F_iter = flops_per_iter(N, T, K, L)
+        if alg == "hals":
+            # executed MFMA work of one HALS iteration: hxt (2 sources) + Gram of H_unfold (L*K32 columns instead
+            # of N) + conv_t + transconv (2 sources) + loss conv; the sweeps themselves are latency-bound VALU work
+            F_iter = (6.0 + (L * 32.0 * ((K + 31) // 32)) / N) * 2.0 * K * N * (L * T - L * (L - 1) / 2)
         out = {
-            "metric": "MU iterations/sec (convolutive NMF multiplicative update)",
+            "metric": ("MU iterations/sec (convolutive NMF multiplicative update)" if alg == "mult"
+                       else "HALS iterations/sec (convolutive NMF, src/algs/hals.jl)"),
             "value": iters_per_s, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[{args.config - 1}]: N={N} T={T} K={K} L={L} fp32 alg=:mult"
+            "config": {"workload": f"configs[{args.config - 1}]: N={N} T={T} K={K} L={L} fp32 alg=:{alg}"
                                    + (" regularised " + json.dumps(reg) if reg else "")
                                    + (f", T sharded over {world} GPUs, RCCL all-reduce on W" if world > 1 else " on 1xMI355X"),
                        "N": N, "T": T, "K": K, "L": L, "parallelism": f"t-shard{world}",
                        "gen_synthetic_seed": 1234, "init_rand_seed": 0,
                        "loss_first": loss0, "loss_last": losses[-1] if losses else loss0},
             "flops_per_iter": F_iter,
-            "executed_flops_per_iter": F_iter * 6.0 / 7.0,
+            "executed_flops_per_iter": F_iter * 6.0 / 7.0 if alg == "mult" else F_iter,
             "est_reuse": "the est of mult.jl:55 is kept for the next mult.jl:28 (same W, H): 6 of the 7 contractions "
                          "are executed, results bitwise identical; ms_per_step_no_reuse runs all 7",
             "ms_per_step_no_reuse": (1e3 * dt_noreuse) if dt_noreuse else None,
@@ -229,7 +258,7 @@ def main():
     if rank == 0:
         if args.cpu_seconds > 0 and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(data, W0, H0, args.cpu_seconds)
+                out["cpu_baseline"] = (cpu_baseline_hals if alg == "hals" else cpu_baseline)(data, W0, H0, args.cpu_seconds)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line for it
                 out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}

@@ -73,6 +73,34 @@ function update_feature_maps!(rule::HIPMultUpdate, data, W, H; l1H=0, l2H=0, kwa
     return loss[]
 end
 
+"""
+    HIPHALSUpdate(data, W, H; device=0)
+
+Drop-in for `HALSUpdate(data, W, H)` (src/algs/hals.jl:18-28) on the same handle type: the K*L column
+updates of W and the K*T entry updates of H run on the GPU in the reference's Gauss-Seidel order.
+"""
+mutable struct HIPHALSUpdate <: AbstractCFUpdate
+    inner::HIPMultUpdate
+end
+HIPHALSUpdate(data, W, H; kwargs...) = HIPHALSUpdate(HIPMultUpdate(data, W, H; kwargs...))
+
+# update_motifs!(rule::HALSUpdate, ...; l1W=0, l2W=0)  -- src/algs/hals.jl:31-34
+function update_motifs!(rule::HIPHALSUpdate, data, W, H; l1W=0, l2W=0, kwargs...)
+    check(ccall((:cmf_hals_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64), rule.inner.handle, l1W, l2W))
+    return W
+end
+
+# update_feature_maps!(rule::HALSUpdate, ...; l1H=0, l2H=0) -> loss  -- src/algs/hals.jl:37-42
+function update_feature_maps!(rule::HIPHALSUpdate, data, W, H; l1H=0, l2H=0, kwargs...)
+    loss = Ref{Float64}(0.0)
+    check(ccall((:cmf_hals_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
+                rule.inner.handle, l1H, l2H, loss))
+    if rule.inner.sync_every_call
+        check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.inner.handle, W, H))
+    end
+    return loss[]
+end
+
 "Write the device-resident factors into W and H (needed only with `sync_every_call=false`)."
 function download!(rule::HIPMultUpdate, W::Tensor{Float64}, H::Matrix{Float64})
     check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.handle, W, H))
