@@ -6,7 +6,8 @@ repo root:  ``import cmf_jl_amd as cmf``.
 from ._lib import CMFError, LIB_PATH, SYMBOLS, load as load_library  # noqa: F401
 from .host import (  # noqa: F401
     EPSILON, AbstractCFUpdate, AlternatingOptimizer, CNMF_results, HALSUpdate, HIPHALSUpdate, HIPMultUpdate, MultUpdate,
-    compute_loss, converged, fit, fit_cnmf, gen_synthetic, init_rand, tensor_conv, tensor_transconv,
+    compute_loss, converged, evaluate_convergence, evaluate_mse, evaluate_test, fit, fit_cnmf, gen_synthetic,
+    init_rand, load_model, parameter_sweep, save_model, tensor_conv, tensor_transconv,
 )
 
 __version__ = "0.1.0"

@@ -83,6 +83,8 @@ struct cmf_handle_s {
     // launch plans
     int hxt_LP = 1, hxt_groups = 1, hxt_nchunks = 1, hxt_chunk_len = 2;
     int tc_LT = 4, tc_S = 1, tc_nr = 8;
+    int tc_S1 = 1, tc_nr1 = 8;           // n ranges when only one source is contracted
+    int hxt_nchunks1 = 1, hxt_chunk_len1 = 6; // time chunks when only one source is contracted
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
 
     // HALS scratch (allocated on first use)
@@ -96,10 +98,11 @@ struct cmf_handle_s {
     bool factors_set = false;
     bool have_data = false;
     bool reuse_est = true;  // option "reuse_est"
-    bool est_valid = false; // est[t][n] == tensor_conv(W, H) for the resident W, H
+    int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data
 };
 
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
+static int resid_and_loss(cmf_handle_s *h, double *sumsq);
 static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H);
 
 static size_t n_partial(const cmf_handle_s *h) { return (size_t)h->conv_gx * (size_t)std::max(h->conv_gy, h->conv_gy_ext); }
@@ -143,6 +146,13 @@ static void plan(cmf_handle_s *h, int n_cu)
     int64_t clen = rup((d.Tl + nch - 1) / nch, 6 * best);
     h->hxt_chunk_len = (int)clen;
     h->hxt_nchunks = (int)((d.Tl + clen - 1) / clen);
+    {
+        int64_t wpc1 = (int64_t)(d.Np / 32) * d.KB * h->hxt_groups;
+        int nch1 = (int)std::max<int64_t>(1, (wave_slots + wpc1 / 2) / wpc1);
+        int64_t clen1 = rup((d.Tl + nch1 - 1) / nch1, 6 * best);
+        h->hxt_chunk_len1 = (int)clen1;
+        h->hxt_nchunks1 = (int)((d.Tl + clen1 - 1) / clen1);
+    }
     // C3 (transconv): S n-ranges so that (t tiles) x 2 x KB x S ~ 2 workgroups per CU x 2 rounds
     h->tc_LT = d.L <= 32 ? (int)rup(d.L, 4) : 32;
     int64_t base = (int64_t)((d.Tl + 511) / 512) * 2 * d.KB;
@@ -151,6 +161,12 @@ static void plan(cmf_handle_s *h, int n_cu)
     S = (int)std::min<int64_t>(S, n8 / 8);
     h->tc_nr = (int)rup((n8 + S - 1) / S, 8);
     h->tc_S = (int)((n8 + h->tc_nr - 1) / h->tc_nr);
+    {
+        int S1 = (int)std::max<int64_t>(1, (8 * n_cu) / base);
+        S1 = (int)std::min<int64_t>(S1, n8 / 8);
+        h->tc_nr1 = (int)rup((n8 + S1 - 1) / S1, 8);
+        h->tc_S1 = (int)((n8 + h->tc_nr1 - 1) / h->tc_nr1);
+    }
     // C1 (conv)
     h->conv_gx = d.Np / 128;
     h->conv_gy = (d.Tl + 127) / 128;
@@ -254,10 +270,10 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     TRYB(dalloc_zero(&h->XT, TPNp));
     TRYB(dalloc_zero(&h->est, TPNp));
     TRYB(dalloc_zero(&h->estT, TPNp));
-    TRYB(dalloc_zero(&h->wslabs, (size_t)h->hxt_nchunks * 2 * d.L * d.K32 * d.Np));
+    TRYB(dalloc_zero(&h->wslabs, (size_t)std::max(2 * h->hxt_nchunks, h->hxt_nchunks1) * d.L * d.K32 * d.Np));
     TRYB(dalloc_zero(&h->numden_own, (size_t)2 * d.L * d.K32 * d.Np));
     h->numden = h->numden_own;
-    TRYB(dalloc_zero(&h->hslabs, (size_t)h->tc_S * 2 * d.Tl * d.K32));
+    TRYB(dalloc_zero(&h->hslabs, (size_t)std::max(2 * h->tc_S, h->tc_S1) * d.Tl * d.K32));
     for (int w = 0; w < 4; ++w) {
         TRYB(dalloc_zero(&h->halo_own[w], (size_t)std::max(1, d.L - 1) * d.K32));
         h->halo[w] = h->halo_own[w];
@@ -282,11 +298,11 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
 // kernel launchers
 // ------------------------------------------------------------------------------------------
 template <int MODE>
-static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy)
+static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const float *data = nullptr)
 {
     const CmfDims &d = h->d;
     ConvParams p;
-    p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = h->X; p.partial = h->partial;
+    p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = data ? data : h->X; p.partial = h->partial;
     p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = T_store;
     dim3 grid(h->conv_gx, gy), block(256);
     if (d.K % 32 == 0) hipLaunchKernelGGL((conv2_kernel<MODE>), grid, block, 0, h->stream, p);
@@ -318,16 +334,16 @@ static int launch_hxt(cmf_handle_s *h)
     return launch_hxt_on(h, h->X, h->est, h->d.Np, 2, h->wslabs, h->hxt_nchunks, h->hxt_chunk_len);
 }
 
-static int launch_transconv(cmf_handle_s *h, int nsrc)
+static int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullptr)
 {
     const CmfDims &d = h->d;
     TcParams p;
-    p.Wn = h->Wn; p.XT0 = h->XT; p.XT1 = h->estT; p.slabs = h->hslabs;
+    p.Wn = h->Wn; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.slabs = h->hslabs;
     p.NpW = d.Np;
     p.Nlim = (int)rup(d.N, 8); // rows >= N are zero: stop at the last 8-row chunk that holds data
     p.TP = d.TP; p.PADL = d.PADL; p.K32 = d.K32; p.KB = d.KB; p.L = d.L; p.Tl = d.Tl;
-    p.nr = h->tc_nr; p.nsrc = nsrc;
-    dim3 grid((d.Tl + 511) / 512, h->tc_S, nsrc * d.KB), block(256);
+    p.nr = nsrc == 2 ? h->tc_nr : h->tc_nr1; p.nsrc = nsrc;
+    dim3 grid((d.Tl + 511) / 512, nsrc == 2 ? h->tc_S : h->tc_S1, nsrc * d.KB), block(256);
     switch (h->tc_LT) {
 #define CASE(LT_) case LT_: hipLaunchKernelGGL((transconv_kernel<LT_>), grid, block, 0, h->stream, p); break;
         CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
@@ -370,9 +386,9 @@ static int check_ready(cmf_handle_s *h, bool need_data)
 static int w_partial_impl(cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
-    if (!(h->reuse_est && h->est_valid))
+    if (!(h->reuse_est && h->est_kind == 1))
         CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
-    h->est_valid = true;
+    h->est_kind = 1;
     CMFTRY(launch_hxt(h));                                  // mult.jl:31-34
     return launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks, (size_t)2 * d.L * d.K32 * d.Np);
 }
@@ -384,7 +400,7 @@ static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W)
     hipLaunchKernelGGL(w_update_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden, 1,
                        d.N, d.K, d.L, d.Np, d.K32, (float)l1W, (float)(2.0 * l2W)); // mult.jl:37-38
     KCHK("w_update_kernel");
-    h->est_valid = false;
+    h->est_kind = 0;
     return CMF_OK;
 }
 
@@ -397,7 +413,7 @@ static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
     hipLaunchKernelGGL(h_update_kernel, grid, dim3(256), 0, h->stream, h->H, h->Ht, h->hslabs, h->tc_S,
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
     KCHK("h_update_kernel");
-    h->est_valid = false;
+    h->est_kind = 0;
     return CMF_OK;
 }
 
@@ -406,7 +422,7 @@ static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = tru
     const CmfDims &d = h->d;
     if (h->reuse_est) {
         CMFTRY(launch_conv<3>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:55-57, est kept for the next update_motifs!
-        h->est_valid = true;
+        h->est_kind = 1;
     } else {
         CMFTRY(launch_conv<2>(h, nullptr, d.Tl, h->conv_gy)); // mult.jl:55-57
     }
@@ -463,7 +479,7 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
     if (!h || !name) return fail(CMF_ERR_ARG, "NULL argument");
     if (std::strcmp(name, "reuse_est") == 0) {
         h->reuse_est = value != 0;
-        h->est_valid = false;
+        h->est_kind = 0;
         return CMF_OK;
     }
     return fail(CMF_ERR_ARG, "unknown option '%s'", name);
@@ -505,7 +521,7 @@ int cmf_set_factors(cmf_handle h, const double *W, const double *H)
     KCHK("pack_H_kernel");
     HIPCHK(hipStreamSynchronize(h->stream));
     h->factors_set = true;
-    h->est_valid = false;
+    h->est_kind = 0;
     return CMF_OK;
 }
 
@@ -618,7 +634,7 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
     CMFTRY(check_ready(h, true));
     CMFTRY(hals_h_impl(h, l1H, l2H));
     double ss = 0.0;
-    CMFTRY(loss_partial_impl(h, &ss)); // hals.jl:41: norm(resids)/data_norm with resids = est - data
+    CMFTRY(resid_and_loss(h, &ss)); // hals.jl:41: norm(resids)/data_norm; the residual is kept for the next W phase
     *loss = std::sqrt(ss) / h->data_norm;
     return CMF_OK;
 }
@@ -728,6 +744,22 @@ int cmf_halo_unpack(cmf_handle h, int has_left, int has_right)
     return CMF_OK;
 }
 
+// est := tensor_conv(W,H) - data (the residual hals.jl / pgd.jl carry), with the loss sum in d_scalar[0]
+static int resid_and_loss(cmf_handle_s *h, double *sumsq)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(launch_conv<4>(h, h->est, d.Tl, h->conv_gy));
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_gx * h->conv_gy, h->d_scalar);
+    KCHK("loss_reduce_kernel");
+    h->est_kind = 2;
+    return sumsq ? read_scalar(h, 0, sumsq) : CMF_OK;
+}
+
+static int ensure_resid(cmf_handle_s *h)
+{
+    return h->est_kind == 2 ? CMF_OK : resid_and_loss(h, nullptr);
+}
+
 // ---- HALS (src/algs/hals.jl) -------------------------------------------------------------------
 static int hals_ensure(cmf_handle_s *h)
 {
@@ -776,10 +808,10 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
 {
     const CmfDims &d = h->d;
     CMFTRY(hals_ensure(h));
-    // G = resid * H_unfold' = denomW - numW: the MU partial sums (hals.jl:104-110 needs resid * h)
-    if (!(h->reuse_est && h->est_valid)) CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy));
-    CMFTRY(launch_hxt(h));
-    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks, (size_t)2 * d.L * d.K32 * d.Np));
+    // G = resid * H_unfold' (hals.jl:104-110 needs resid * h): ONE C2 contraction on the stored residual
+    CMFTRY(ensure_resid(h));
+    CMFTRY(launch_hxt_on(h, h->est, h->est, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
+    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks1, (size_t)d.L * d.K32 * d.Np));
     // HH = H_unfold * H_unfold' (hals.jl:56-60: row norms are its diagonal) with the same C2 kernel
     hipLaunchKernelGGL(hals_build_hut_kernel, dim3(2048), dim3(256), 0, h->stream, h->H, h->hals_HuT, d.Tl, d.L, d.K32, h->hals_NpH, d.PADL);
     KCHK("hals_build_hut_kernel");
@@ -794,7 +826,7 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     hipLaunchKernelGGL(hals_w_sweep_kernel, grid, block, per_wave * wpb, h->stream, h->Wt, h->Wn, h->numden, h->hals_HH,
                        d.N, d.K, d.L, d.Np, d.K32, h->hals_NpH, (float)l1W, (float)l2W);
     KCHK("hals_w_sweep_kernel");
-    h->est_valid = false;
+    h->est_kind = 0;
     return CMF_OK;
 }
 
@@ -802,10 +834,10 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
 {
     const CmfDims &d = h->d;
     CMFTRY(hals_ensure(h));
-    // P = transconv(W, resid) = denomH - numH (hals.jl:152 needs <W_k window, resid window>)
-    CMFTRY(launch_conv<1>(h, h->estT, d.Tl, h->conv_gy));
-    CMFTRY(launch_transconv(h, 2));
-    hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, h->tc_S, d.Tl, d.K32, h->hals_TPp);
+    // P = transconv(W, resid) (hals.jl:152 needs <W_k window, resid window>): ONE C3 contraction on resid^T
+    CMFTRY(launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT));
+    CMFTRY(launch_transconv(h, 1, h->estT));
+    hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, h->tc_S1, d.Tl, d.K32, h->hals_TPp);
     KCHK("hals_p_init_kernel");
     hipLaunchKernelGGL(hals_pw_kernel, dim3(d.L * d.L, d.KB * d.KB), dim3(32, 32), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
     KCHK("hals_pw_kernel");
@@ -829,7 +861,7 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
         hipLaunchKernelGGL(hals_h_stage_kernel, grid, dim3(256), 0, h->stream, sp);
         KCHK("hals_h_stage_kernel");
     }
-    h->est_valid = false;
+    h->est_kind = 0;
     return CMF_OK;
 }
 
@@ -872,7 +904,7 @@ int cmf_tensor_transconv(int device, int64_t N, int64_t T, int64_t K, int64_t L,
     float *sum = nullptr;
     if (rc == CMF_OK && hipMalloc(&sum, (size_t)h->d.Tl * h->d.K32 * sizeof(float)) != hipSuccess)
         rc = fail(CMF_ERR_HIP, "hipMalloc failed in cmf_tensor_transconv");
-    if (rc == CMF_OK) rc = launch_slab_sum(h, sum, h->hslabs, h->tc_S, (size_t)h->d.Tl * h->d.K32);
+    if (rc == CMF_OK) rc = launch_slab_sum(h, sum, h->hslabs, h->tc_S1, (size_t)h->d.Tl * h->d.K32);
     if (rc == CMF_OK) rc = download_rows(h, out, sum, 0, T, (int)K, h->d.K32);
     if (sum) (void)hipFree(sum);
     destroy_impl(h);

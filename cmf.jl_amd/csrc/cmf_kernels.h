@@ -60,6 +60,8 @@ __device__ __forceinline__ float cmf_bload(__amdgpu_buffer_rsrc_t r, int voff_by
 //   MODE 1: store estT[n][t]     (A operand = W, B = H; same registers, swapped MFMA roles)
 //   MODE 2: no store; per-workgroup sum of (est - data)^2 -> partial[]  (mult.jl:55-57 fused)
 //   MODE 3: MODE 0 + MODE 2
+//   MODE 4: store est - data (the residual of hals.jl / pgd.jl) in the [t][n] layout + the loss sum
+//   MODE 5: store (est - data)^T in the [n][t] layout (p.data = dataT)
 // ---------------------------------------------------------------------------------------------
 struct ConvParams {
     const float *Ht;
@@ -83,7 +85,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
     // Tiles that lie entirely below T_store (all but the last row of tiles) take a branch-free path:
     // per-element exec-mask branches serialise the epilogue (one L2 round trip per data load).
     const bool full = (t0 + 128 <= p.T_store); // workgroup-uniform
-    if (MODE == 0 || MODE == 3 || MODE == 2) {
+    if (MODE == 0 || MODE == 3 || MODE == 2 || MODE == 4) {
         // acc[ti][ni][r]: t = t0 + wt*64 + ti*32 + crow(r,h), n = n0 + wn*64 + ni*32 + i
         float lsum = 0.f;
 #pragma unroll
@@ -92,7 +94,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
             for (int ni = 0; ni < 2; ++ni) {
                 const size_t o0 = (size_t)(p.PADL + t0 + wt * 64 + ti * 32 + 4 * h) * Np + n0 + wn * 64 + ni * 32 + i;
                 float dv[16];
-                if (MODE == 2 || MODE == 3) {
+                if (MODE == 2 || MODE == 3 || MODE == 4) {
                     // the rows of a partial tile beyond T_store are padding rows of X: in bounds
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dv[r] = p.data[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np];
@@ -102,21 +104,22 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[ti][ni][r];
                         if (MODE == 0 || MODE == 3) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = v;
-                        if (MODE == 2 || MODE == 3) { const float d = v - dv[r]; lsum = fmaf(d, d, lsum); }
+                        if (MODE == 4) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = v - dv[r];
+                        if (MODE == 2 || MODE == 3 || MODE == 4) { const float d = v - dv[r]; lsum = fmaf(d, d, lsum); }
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int t = t0 + wt * 64 + ti * 32 + cmf_crow(r, h);
                         const float v = acc[ti][ni][r];
-                        if (MODE == 0 || MODE == 3) {
-                            if (t < p.T_store) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = v;
+                        if (MODE == 0 || MODE == 3 || MODE == 4) {
+                            if (t < p.T_store) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = (MODE == 4) ? v - dv[r] : v;
                         }
-                        if (MODE == 2 || MODE == 3) { const float d = (t < p.T_store) ? v - dv[r] : 0.f; lsum = fmaf(d, d, lsum); }
+                        if (MODE == 2 || MODE == 3 || MODE == 4) { const float d = (t < p.T_store) ? v - dv[r] : 0.f; lsum = fmaf(d, d, lsum); }
                     }
                 }
             }
-        if (MODE == 2 || MODE == 3) {
+        if (MODE == 2 || MODE == 3 || MODE == 4) {
             double ds = (double)lsum;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) ds += __shfl_down(ds, off, 64);
@@ -126,19 +129,20 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
             if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
         }
     } else {
-        // MODE 1: acc[ni][ti][r]: n = n0 + wn*64 + ni*32 + crow(r,h), t = t0 + wt*64 + ti*32 + i
+        // MODE 1 / 5: acc[ni][ti][r]: n = n0 + wn*64 + ni*32 + crow(r,h), t = t0 + wt*64 + ti*32 + i
+        // (MODE 5 stores est - data in the transposed layout; p.data is then dataT [Np][TP])
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti) {
                 const int t = t0 + wt * 64 + ti * 32 + i;
                 const size_t o0 = (size_t)(n0 + wn * 64 + ni * 32 + 4 * h) * TP + p.PADL + t;
-                if (full) {
+                if (full || t < p.T_store) {
+                    float dv[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] = acc[ni][ti][r];
-                } else if (t < p.T_store) {
+                    for (int r = 0; r < 16; ++r) dv[r] = (MODE == 5) ? p.data[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] = acc[ni][ti][r];
+                    for (int r = 0; r < 16; ++r) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] = acc[ni][ti][r] - dv[r];
                 }
             }
     }
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p)
                 const float *hsb = Hs + h * CONV_HS_STRIDE + 32 + wt * 64 + i - (l - lbeg);
                 const float *wsb = Ws + buf * CONV_WS_FLOATS + h * 128 + wn * 64 + i;
 #define CONV_MFMA4(A0, A1, B0, B1)                                                                  \
-    if (MODE == 1) {                                                                                \
+    if (MODE == 1 || MODE == 5) {                                                                   \
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(B0, A0, acc[0][0], 0, 0, 0);               \
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(B0, A1, acc[0][1], 0, 0, 0);               \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(B1, A0, acc[1][0], 0, 0, 0);               \
@@ -297,7 +301,7 @@ __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb,
             na1 = hsb[(kp + 1) * 2 * CONV_HS_STRIDE + 32];
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        if (MODE == 1) {
+        if (MODE == 1 || MODE == 5) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a0, acc[1][0], 0, 0, 0);
@@ -784,9 +788,9 @@ __global__ void hals_build_hut_kernel(const float *H, float *HuT, int Tl, int L,
     }
 }
 
-// W sweep: one wave = NG units n; state g[NG][LK] in LDS (wave-private).  numden = [num | den] in Wt layout.
+// W sweep: one wave = NG units n; state g[NG][LK] in LDS (wave-private).  G = resid * H_unfold' in Wt layout.
 #define HALS_NG 4
-__global__ void hals_w_sweep_kernel(float *Wt, float *Wn, const float *numden, const float *HH,
+__global__ void hals_w_sweep_kernel(float *Wt, float *Wn, const float *G, const float *HH,
                                                             int N, int K, int L, int Np, int K32, int NpH, float l1, float l2)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
@@ -796,13 +800,12 @@ __global__ void hals_w_sweep_kernel(float *Wt, float *Wn, const float *numden, c
     float *dl = g + HALS_NG * LK; // deltas of this step
     const int n0 = (blockIdx.x * (blockDim.x >> 6) + wave) * HALS_NG;
     if (n0 >= N) return;
-    const size_t LKN = (size_t)L * K32 * Np;
-    // G = den - num for the wave's units (zero for padded units)
+    // G[j][n] = <resid[n,:], h_j> for the wave's units (zero for padded units)
     for (int j = lane; j < LK; j += 64)
 #pragma unroll
         for (int u = 0; u < HALS_NG; ++u) {
             int n = n0 + u;
-            g[u * LK + j] = (n < N) ? (numden[LKN + (size_t)j * Np + n] - numden[(size_t)j * Np + n]) : 0.f;
+            g[u * LK + j] = (n < N) ? G[(size_t)j * Np + n] : 0.f;
         }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -841,7 +844,7 @@ __global__ void hals_w_sweep_kernel(float *Wt, float *Wn, const float *numden, c
         }
 }
 
-// PT[k][t] = sum_s (den - num) of the transconv slabs [S][2][Tl][K32]; grid (ceil(Tl/64), KB), block 256
+// PT[k][t] = sum_s of the transconv(W, resid) slabs [S][1][Tl][K32]; grid (ceil(Tl/64), KB), block 256
 __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float *slabs, int S, int Tl, int K32, int TPp)
 {
     __shared__ float tile[32][65];
@@ -856,12 +859,7 @@ __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float
             float v = 0.f;
             if (t < Tl) {
                 size_t idx = (size_t)t * K32 + kb * 32 + kk;
-                float num = 0.f, den = 0.f;
-                for (int s = 0; s < S; ++s) {
-                    num += slabs[(size_t)(2 * s) * TK + idx];
-                    den += slabs[(size_t)(2 * s + 1) * TK + idx];
-                }
-                v = den - num;
+                for (int s = 0; s < S; ++s) v += slabs[(size_t)s * TK + idx];
             }
             tile[kk][tt] = v;
         }

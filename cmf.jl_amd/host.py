@@ -411,3 +411,70 @@ def gen_synthetic(N=100, T=500, K=3, L=20, alpha=0.1, p_h=0.5, sigma=0.2, noise_
     check(lib.cmf_gen_synthetic(_dev(device), N, T, K, L, float(alpha), float(p_h), float(sigma), float(noise_scale),
                                 int(seed) & (2**64 - 1), ptr(data), ptr(W), ptr(H)))
     return (data, W, H) if return_factors else data
+
+
+# --------------------------------------------------------------------------------------
+# callers either side of the path: evaluation, sweeps, results on disk
+# --------------------------------------------------------------------------------------
+def evaluate_mse(r, device=None):
+    """evaluate_mse(r::CNMF_results): src/evaluate.jl:1-5."""
+    return compute_loss(r.data, r.W, r.H, device=device)
+
+
+def evaluate_test(r, test, num_iter=30, device=None):
+    """evaluate_test(r, test; num_iter=30): src/evaluate.jl:8-25 -- refit H on held-out data with the
+    motifs fixed (HALS H sweeps from H = 0, no regularisation), then the normalised loss.  (The
+    reference's version calls a `HALS` module that no longer exists at HEAD; this is its intent.)"""
+    test = farr(test)
+    K = r.W.shape[0]
+    rule = HALSUpdate(test, r.W, np.zeros((K, test.shape[1])), device=device)
+    try:
+        for _ in range(int(num_iter)):
+            rule.update_feature_maps()
+        return rule.compute_loss()
+    finally:
+        rule.close()
+
+
+def evaluate_convergence(r, thresh=0.01):
+    """evaluate_convergence(r; thresh=0.01): src/evaluate.jl:29-44 -- first iteration whose loss is within
+    `thresh` (relative) of the final loss."""
+    min_loss = r.loss_hist[-1]
+    for i, loss in enumerate(r.loss_hist):
+        if loss / min_loss < 1 + thresh:
+            return i
+    return len(r.loss_hist)
+
+
+def parameter_sweep(data, L_vals=(7,), K_vals=(3,), alg_vals=(":mult",), max_itr=100, max_time=math.inf, **kwargs):
+    """parameter_sweep(data; L_vals, K_vals, alg_vals, max_itr, max_time): src/model.jl:132-145.
+    Returns {(L, K, alg): CNMF_results}; other keywords go to every fit_cnmf call (HEAD passes stale
+    `lambda1/initW` names that fit_cnmf ignores; here they would be reported as unknown)."""
+    results = {}
+    for L in L_vals:
+        for K in K_vals:
+            for alg in alg_vals:
+                results[(L, K, alg)] = fit_cnmf(data, L=L, K=K, alg=alg, max_itr=max_itr, max_time=max_time, **kwargs)
+    return results
+
+
+_MODEL_KEYS = ("W", "H", "data", "loss_hist", "time_hist")
+
+
+def save_model(results, path, **meta):
+    """save_model(results, path): src/model.jl:149-163.  Same dataset names as the reference's HDF5 schema
+    (W, H, data, loss_hist, time_hist, plus whatever of l1_H, l2_H, l1_W, l2_W, alg is passed as keywords --
+    CNMF_results itself does not carry them, which is why the reference's own save_model is broken at HEAD),
+    written as a NumPy .npz container: there is no HDF5 library in this environment."""
+    arrays = {k: np.asarray(getattr(results, k)) for k in _MODEL_KEYS}
+    for k, v in meta.items():
+        arrays[k] = np.asarray(v)
+    np.savez_compressed(path, **arrays)
+
+
+def load_model(path):
+    """load_model(path): src/model.jl:167-181 -> (CNMF_results, meta dict)."""
+    with np.load(path, allow_pickle=False) as f:
+        r = CNMF_results(f["data"], f["W"], f["H"], f["time_hist"], f["loss_hist"])
+        meta = {k: f[k][()] for k in f.files if k not in _MODEL_KEYS}
+    return r, meta

@@ -366,3 +366,20 @@ def test_hals_config5_full_size(cmf, config2):
     np.testing.assert_allclose(a.loss_hist, b.loss_hist, rtol=1e-6)
     assert frob_rel(a.H, b.H) < 1e-4
     assert a.W.min() == 0.0 and a.H.min() == 0.0               # clamp at 0 (hals.jl:110,153)
+
+
+def test_evaluate_test_and_sweep(cmf, oracle):
+    """SURVEY.md section 8f callers: held-out evaluation (evaluate.jl:8-25) and parameter_sweep (model.jl:132-145)."""
+    data, _, _ = oracle.c_gen_synthetic(N=60, T=800, K=3, L=10, seed=11)
+    train, test = data[:, :500], data[:, 500:]
+    sweep = cmf.parameter_sweep(train, L_vals=[10], K_vals=[2, 4], alg_vals=[":mult", ":hals"], max_itr=15,
+                                seed=0, check_convergence=False)
+    assert set(sweep) == {(10, 2, ":mult"), (10, 2, ":hals"), (10, 4, ":mult"), (10, 4, ":hals")}
+    r = sweep[(10, 4, ":hals")]
+    assert abs(cmf.evaluate_mse(r) - r.loss_hist[-1]) < 1e-5
+    te = cmf.evaluate_test(r, test)
+    # oracle: 30 HALS H-sweeps from H = 0 with W fixed
+    Wf = np.asarray(r.W, dtype=np.float64)
+    _, Ho, lo, _ = oracle.c_fit_hals(test, Wf, np.zeros((4, test.shape[1])), max_itr=30, eval_mode=True, check_convergence=False)
+    assert abs(te - lo[-1]) <= 1e-4 * lo[-1]
+    assert te > r.loss_hist[-1] * 0.5  # sanity: held-out loss is of the same order

@@ -58,3 +58,18 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".jl")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in txt.lower(), f"{f} mentions the oracle"
+
+
+def test_results_on_disk_and_convergence_helper(cmf, tmp_path):
+    """save_model / load_model (model.jl:149-181 schema names) and evaluate_convergence (evaluate.jl:29-44)
+    are host-only."""
+    r = cmf.CNMF_results(np.ones((3, 5)), np.ones((2, 3, 4)), np.ones((2, 5)), np.arange(4.0), np.array([1.0, 0.5, 0.402, 0.4]))
+    path = str(tmp_path / "m.npz")
+    cmf.save_model(r, path, l1_H=0.1, alg="mult")
+    r2, meta = cmf.load_model(path)
+    for k in ("W", "H", "data", "loss_hist", "time_hist"):
+        np.testing.assert_array_equal(getattr(r, k), getattr(r2, k))
+    assert float(meta["l1_H"]) == 0.1 and str(meta["alg"]) == "mult"
+    assert cmf.evaluate_convergence(r) == 2        # 0.402/0.4 < 1.01
+    assert cmf.evaluate_convergence(r, thresh=0.3) == 1
+    assert (r.num_lags(), r.num_units(), r.num_components(), r.num_iter()) == (4, 3, 2, 4)
