@@ -94,6 +94,10 @@ struct cmf_handle_s {
     float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr;
     int hals_seg = 256, hals_nseg = 1;      // column segments of the pipelined H sweep
 
+    // PGD rule state (pgd.jl:139-154)
+    double pgd_stepW = 5.0, pgd_stepH = 5.0, pgd_cur_loss = -1.0;
+    float *pgd_gradH = nullptr;
+
     double data_sumsq = 0.0, data_norm = 0.0;
     bool factors_set = false;
     bool have_data = false;
@@ -103,9 +107,18 @@ struct cmf_handle_s {
 
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
 static int resid_and_loss(cmf_handle_s *h, double *sumsq);
+static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg);
+static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg, double *loss);
 static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H);
 
-static size_t n_partial(const cmf_handle_s *h) { return (size_t)h->conv_gx * (size_t)std::max(h->conv_gy, h->conv_gy_ext); }
+static size_t n_partial(const cmf_handle_s *h)
+{
+    const CmfDims &d = h->d;
+    size_t n = (size_t)h->conv_gx * (size_t)std::max(h->conv_gy, h->conv_gy_ext);       // conv loss partials
+    n = std::max(n, (size_t)(d.Np / 64) * d.KB * d.L);                                 // PGD gradW norm partials
+    n = std::max(n, (size_t)((d.Tl + 63) / 64) * d.KB);                                // PGD gradH norm partials
+    return n;
+}
 
 static int ensure_stage(cmf_handle_s *h, size_t elems)
 {
@@ -179,7 +192,7 @@ static void destroy_impl(cmf_handle_s *h)
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
                       h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3],
-                      h->hals_HuT, h->hals_hhslabs, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE};
+                      h->pgd_gradH, h->hals_HuT, h->hals_hhslabs, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE};
     for (float *p : fbufs)
         if (p) (void)hipFree(p);
     if (h->partial) (void)hipFree(h->partial);
@@ -639,6 +652,35 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
     return CMF_OK;
 }
 
+int cmf_pgd_reset(cmf_handle h)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    h->pgd_stepW = h->pgd_stepH = 5.0;
+    h->pgd_cur_loss = -1.0;
+    return CMF_OK;
+}
+
+int cmf_pgd_update_motifs(cmf_handle h, double pen_sq, double pen_abs, int nonneg)
+{
+    CMFTRY(check_ready(h, true));
+    return pgd_w_impl(h, pen_sq, pen_abs, nonneg);
+}
+
+int cmf_pgd_update_feature_maps(cmf_handle h, double pen_sq, double pen_abs, int nonneg, double *loss)
+{
+    if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
+    CMFTRY(check_ready(h, true));
+    return pgd_h_impl(h, pen_sq, pen_abs, nonneg, loss);
+}
+
+int cmf_pgd_get_steps(cmf_handle h, double *stepW, double *stepH)
+{
+    if (!h || !stepW || !stepH) return fail(CMF_ERR_ARG, "NULL argument");
+    *stepW = h->pgd_stepW;
+    *stepH = h->pgd_stepH;
+    return CMF_OK;
+}
+
 int cmf_converged(const double *loss_hist, int64_t len, int64_t patience, double tol)
 {
     // src/model.jl:91-107
@@ -862,6 +904,71 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
         KCHK("hals_h_stage_kernel");
     }
     h->est_kind = 0;
+    return CMF_OK;
+}
+
+// ---- PGD (src/algs/pgd.jl) ---------------------------------------------------------------------
+static int pgd_check(cmf_handle_s *h)
+{
+    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "PGD needs an unsharded handle");
+    if (h->pgd_cur_loss < 0.0) h->pgd_cur_loss = h->data_norm; // pgd.jl:151 (the norm, not its square)
+    return CMF_OK;
+}
+
+// pgd.jl:245-253: est (here the residual) with the new factors, loss = norm(data - est)^2, step adaptation
+static int pgd_finish(cmf_handle_s *h, double *step)
+{
+    double loss = 0.0;
+    CMFTRY(resid_and_loss(h, &loss));
+    *step *= (loss < h->pgd_cur_loss) ? 1.05 : 0.70;
+    h->pgd_cur_loss = loss;
+    return CMF_OK;
+}
+
+static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(pgd_check(h));
+    const size_t LKN = (size_t)d.L * d.K32 * d.Np;
+    CMFTRY(ensure_resid(h));                                                                             // pgd.jl:230
+    CMFTRY(launch_hxt_on(h, h->est, h->est, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1)); // pgd.jl:206-214
+    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks1, LKN));
+    dim3 grid(d.Np / 64, d.KB, d.L);
+    const int nblk = (d.Np / 64) * d.KB * d.L;
+    if ((size_t)nblk > n_partial(h)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
+    hipLaunchKernelGGL(pgd_w_grad_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->numden, h->numden + LKN, h->partial,
+                       d.N, d.K, d.Np, d.K32, (float)pen_sq, (float)pen_abs);                            // pgd.jl:231-234
+    KCHK("pgd_w_grad_kernel");
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nblk, h->d_scalar + 1);
+    KCHK("loss_reduce_kernel");
+    hipLaunchKernelGGL(pgd_w_apply_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden + LKN, h->d_scalar + 1,
+                       d.N, d.K, d.Np, d.K32, (float)h->pgd_stepW, nonneg);                              // pgd.jl:237-241
+    KCHK("pgd_w_apply_kernel");
+    h->est_kind = 0;
+    return pgd_finish(h, &h->pgd_stepW);
+}
+
+static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg, double *loss)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(pgd_check(h));
+    if (!h->pgd_gradH) CMFTRY(dalloc_zero(&h->pgd_gradH, (size_t)d.Tl * d.K32));
+    CMFTRY(launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT)); // resid^T (pgd.jl:230)
+    CMFTRY(launch_transconv(h, 1, h->estT));                     // pgd.jl:218-221
+    dim3 grid((d.Tl + 63) / 64, d.KB);
+    const int nblk = ((d.Tl + 63) / 64) * d.KB;
+    if ((size_t)nblk > n_partial(h)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
+    hipLaunchKernelGGL(pgd_h_grad_kernel, grid, dim3(256), 0, h->stream, h->H, h->hslabs, h->tc_S1, h->pgd_gradH, h->partial,
+                       d.Tl, d.K, d.K32, d.PADL, (float)pen_sq, (float)pen_abs);
+    KCHK("pgd_h_grad_kernel");
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nblk, h->d_scalar + 1);
+    KCHK("loss_reduce_kernel");
+    hipLaunchKernelGGL(pgd_h_apply_kernel, grid, dim3(256), 0, h->stream, h->H, h->Ht, h->pgd_gradH, h->d_scalar + 1,
+                       d.Tl, d.K, d.K32, d.PADL, d.TP, (float)h->pgd_stepH, nonneg);
+    KCHK("pgd_h_apply_kernel");
+    h->est_kind = 0;
+    CMFTRY(pgd_finish(h, &h->pgd_stepH));
+    *loss = std::sqrt(h->pgd_cur_loss / (h->data_norm * h->data_norm)); // pgd.jl:201
     return CMF_OK;
 }
 

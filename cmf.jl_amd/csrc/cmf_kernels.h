@@ -1119,6 +1119,147 @@ __global__ __launch_bounds__(256) void hals_h_stage_kernel(HalsStageParams sp)
     }
 }
 
+
+// =============================================================================================
+// PGD rule (src/algs/pgd.jl) on the same contractions:
+//   gradW = 2 * H_shift * resid' (+ penalties)   -> hxt on the stored residual      (pgd.jl:206-214)
+//   gradH = 2 * transconv(W, resid) (+ penalties) -> transconv on resid^T             (pgd.jl:218-221)
+//   x <- proj(x - step / (||grad|| + eps) * grad)                                      (pgd.jl:237-241)
+// Pass 1 forms the gradient and its sum of squares, pass 2 applies the step.
+// =============================================================================================
+__device__ __forceinline__ float cmf_sign(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+// grad[idx] = 2*G + 2*pen_sq*w + pen_abs*sign(w) over the valid entries of the Wt layout; block partials of sum(g^2)
+// grid (Np/64, KB, L), block 256
+__global__ __launch_bounds__(256) void pgd_w_grad_kernel(const float *Wt, const float *G, float *grad, double *partial,
+                                                          int N, int K, int Np, int K32, float pen_sq, float pen_abs)
+{
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x * 64 + (tid & 63), kb = blockIdx.y, l = blockIdx.z;
+    double ss = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = kb * 32 + q * 4 + (tid >> 6);
+        const size_t idx = ((size_t)l * K32 + k) * Np + n;
+        float g = 0.f;
+        if (k < K && n < N) {
+            const float w = Wt[idx];
+            g = 2.f * G[idx] + 2.f * pen_sq * w + pen_abs * cmf_sign(w);
+        }
+        grad[idx] = g;
+        ss += (double)g * (double)g;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    __shared__ double red[4];
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    if (tid == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// W <- proj(W - alpha*grad), alpha = step / (sqrt(*sumsq) + eps); refreshes Wn.  grid (Np/64, KB, L), block 256
+__global__ __launch_bounds__(256) void pgd_w_apply_kernel(float *Wt, float *Wn, const float *grad, const double *sumsq,
+                                                           int N, int K, int Np, int K32, float step, int nonneg)
+{
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * 64, kb = blockIdx.y, l = blockIdx.z;
+    const float alpha = (float)((double)step / (sqrt(*sumsq) + 2.220446049250313e-16));
+    {
+        const int nn = tid & 63;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int kk = q * 4 + (tid >> 6), k = kb * 32 + kk, n = n0 + nn;
+            const size_t idx = ((size_t)l * K32 + k) * Np + n;
+            float w = 0.f;
+            if (k < K && n < N) {
+                w = Wt[idx] - alpha * grad[idx];
+                if (nonneg) w = fmaxf(CMF_EPS_F, w);
+            }
+            Wt[idx] = w;
+            tile[kk][nn] = w;
+        }
+    }
+    __syncthreads();
+    {
+        const int kk = tid & 31;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int nn = q * 8 + (tid >> 5);
+            Wn[((size_t)l * Np + n0 + nn) * K32 + kb * 32 + kk] = tile[kk][nn];
+        }
+    }
+}
+
+// grad[t][k] = 2*sum_s slabs[s][t][k] + 2*pen_sq*h + pen_abs*sign(h); grid (ceil(Tl/64), KB), block 256
+__global__ __launch_bounds__(256) void pgd_h_grad_kernel(const float *H, const float *slabs, int S, float *grad, double *partial,
+                                                          int Tl, int K, int K32, int PADL, float pen_sq, float pen_abs)
+{
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * 64, kb = blockIdx.y;
+    const size_t TK = (size_t)Tl * K32;
+    const int kk = tid & 31, k = kb * 32 + kk;
+    double ss = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int t = t0 + q * 8 + (tid >> 5);
+        if (t < Tl) {
+            const size_t idx = (size_t)t * K32 + k;
+            float g = 0.f;
+            if (k < K) {
+                float v = 0.f;
+                for (int s = 0; s < S; ++s) v += slabs[(size_t)s * TK + idx];
+                const float hv = H[(size_t)(PADL + t) * K32 + k];
+                g = 2.f * v + 2.f * pen_sq * hv + pen_abs * cmf_sign(hv);
+            }
+            grad[idx] = g;
+            ss += (double)g * (double)g;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    __shared__ double red[4];
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// H <- proj(H - alpha*grad); refreshes Ht.  grid (ceil(Tl/64), KB), block 256
+__global__ __launch_bounds__(256) void pgd_h_apply_kernel(float *H, float *Ht, const float *grad, const double *sumsq,
+                                                           int Tl, int K, int K32, int PADL, int TP, float step, int nonneg)
+{
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * 64, kb = blockIdx.y;
+    const float alpha = (float)((double)step / (sqrt(*sumsq) + 2.220446049250313e-16));
+    {
+        const int kk = tid & 31, k = kb * 32 + kk;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int tt = q * 8 + (tid >> 5), t = t0 + tt;
+            float hv = 0.f;
+            if (t < Tl) {
+                const size_t hidx = (size_t)(PADL + t) * K32 + k;
+                if (k < K) {
+                    hv = H[hidx] - alpha * grad[(size_t)t * K32 + k];
+                    if (nonneg) hv = fmaxf(CMF_EPS_F, hv);
+                }
+                H[hidx] = hv;
+            }
+            tile[kk][tt] = hv;
+        }
+    }
+    __syncthreads();
+    {
+        const int tt = tid & 63;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int kk = q * 4 + (tid >> 6), t = t0 + tt;
+            if (t < Tl) Ht[(size_t)(kb * 32 + kk) * TP + PADL + t] = tile[kk][tt];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Layout conversion (fp64 Julia order on the host side <-> padded fp32 device layouts)
 // ---------------------------------------------------------------------------------------------

@@ -263,6 +263,87 @@ class HALSUpdate(MultUpdate):
 HIPHALSUpdate = HALSUpdate
 
 
+# pgd.jl's loss / penalty / constraint types, as far as the GPU rule supports them
+class SquareLoss:
+    """D(b, est) = ||b - est||^2 (src/algs/pgd.jl:29-36)."""
+
+
+class SquarePenalty:
+    """R(x) = weight * ||x||_2^2 (src/algs/pgd.jl:73-80)."""
+
+    def __init__(self, weight):
+        self.weight = float(weight)
+
+
+class AbsolutePenalty:
+    """R(x) = weight * ||x||_1 (src/algs/pgd.jl:83-89)."""
+
+    def __init__(self, weight):
+        self.weight = float(weight)
+
+
+class NonnegConstraint:
+    """x_i >= 0, projected as max(eps(), x) (src/algs/pgd.jl:92-96)."""
+
+
+def _penalty_weights(penalties):
+    sq = sum(p.weight for p in penalties if isinstance(p, SquarePenalty))
+    ab = sum(p.weight for p in penalties if isinstance(p, AbsolutePenalty))
+    if any(not isinstance(p, (SquarePenalty, AbsolutePenalty)) for p in penalties):
+        raise NotImplementedError("PGDUpdate on the GPU supports SquarePenalty and AbsolutePenalty")
+    return sq, ab
+
+
+def _nonneg_flag(constr):
+    if constr is None:
+        return 0
+    if isinstance(constr, NonnegConstraint) or constr is NonnegConstraint:
+        return 1
+    raise NotImplementedError("PGDUpdate on the GPU supports NonnegConstraint or no constraint")
+
+
+class PGDUpdate(MultUpdate):
+    """PGDUpdate on MI355X: drop-in for src/algs/pgd.jl:112-202 with SquareLoss.
+
+    The gradients are the same contractions as the MU numerators (compute_gradW! is the H_shift * X'
+    product of mult.jl:31-34, compute_gradH! is tensor_transconv!), taken on the stored residual.
+    The rule state (stepW, stepH, cur_loss) lives in the library handle."""
+
+    def __init__(self, data, W, H, device=None):
+        super().__init__(data, W, H, device=device)
+        check(self._lib.cmf_pgd_reset(self._h))
+
+    def update_motifs(self, data=None, W=None, H=None, loss_func=None, constrW=NonnegConstraint, penaltiesW=None, **kwargs):
+        """update_motifs!(rule::PGDUpdate, ...; loss_func=SquareLoss(), constrW=NonnegConstraint(),
+        penaltiesW=[SquarePenalty(1)]): src/algs/pgd.jl:158-177."""
+        if loss_func is not None and not isinstance(loss_func, SquareLoss):
+            raise NotImplementedError("PGDUpdate on the GPU supports SquareLoss")
+        sq, ab = _penalty_weights([SquarePenalty(1)] if penaltiesW is None else penaltiesW)
+        check(self._lib.cmf_pgd_update_motifs(self._h, sq, ab, _nonneg_flag(constrW)))
+
+    def update_feature_maps(self, data=None, W=None, H=None, loss_func=None, constrH=NonnegConstraint, penaltiesH=None, **kwargs):
+        """update_feature_maps!(rule::PGDUpdate, ...; constrH=NonnegConstraint(), penaltiesH=[]) -> loss:
+        src/algs/pgd.jl:180-202."""
+        if loss_func is not None and not isinstance(loss_func, SquareLoss):
+            raise NotImplementedError("PGDUpdate on the GPU supports SquareLoss")
+        sq, ab = _penalty_weights([] if penaltiesH is None else penaltiesH)
+        loss = ctypes.c_double()
+        check(self._lib.cmf_pgd_update_feature_maps(self._h, sq, ab, _nonneg_flag(constrH), ctypes.byref(loss)))
+        return loss.value
+
+    @property
+    def steps(self):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        check(self._lib.cmf_pgd_get_steps(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def fit_native(self, *a, **kw):
+        raise NotImplementedError("cmf_fit runs the multiplicative-update rule; drive PGDUpdate with fit()")
+
+
+HIPPGDUpdate = PGDUpdate
+
+
 def _resolve_alg(alg):
     """alg may be a rule type (HEAD, model.jl:60) or a README-style symbol (README.md:30-33)."""
     if isinstance(alg, str):
@@ -271,8 +352,10 @@ def _resolve_alg(alg):
             return MultUpdate
         if name == "hals":
             return HALSUpdate
-        if name in ("anls", "admm", "pgd", "sep"):
-            raise NotImplementedError(f"alg=:{name} is outside the MI355X hot path built here (:mult and :hals)")
+        if name == "pgd":
+            return PGDUpdate
+        if name in ("anls", "admm", "sep"):
+            raise NotImplementedError(f"alg=:{name} is outside the MI355X hot path built here (:mult, :hals, :pgd)")
         raise ValueError(f"unknown algorithm {alg!r}")
     if isinstance(alg, type) and issubclass(alg, AbstractCFUpdate):
         return alg
@@ -342,7 +425,8 @@ def fit(alg, data, L, K, W_init, H_init, verbose=False, **kwargs):
 # --------------------------------------------------------------------------------------
 _REG_ALIASES = {"l1_W": "l1W", "l2_W": "l2W", "l1_H": "l1H", "l2_H": "l2H"}  # README.md:44-52 -> mult.jl:23,42
 _KNOWN_KW = {"seed", "W_init", "H_init", "check_convergence", "patience", "eval_mode", "tol", "verbose",
-             "l1W", "l2W", "l1H", "l2H", "device"}
+             "l1W", "l2W", "l1H", "l2H", "device",
+             "loss_func", "constrW", "constrH", "penaltiesW", "penaltiesH"}  # PGDUpdate (pgd.jl:158-202)
 
 
 def init_rand(data, L, K, seed=None, device=None):

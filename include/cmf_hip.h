@@ -127,6 +127,18 @@ int cmf_fit(cmf_handle h, int64_t max_itr, double max_time,
 int cmf_hals_update_motifs(cmf_handle h, double l1W, double l2W);
 int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss);
 
+/* ---- PGD rule ------------------------------------------
+ * update_motifs!(rule::PGDUpdate, data, W, H; loss_func=SquareLoss(), constrW, penaltiesW)      src/algs/pgd.jl:158-177
+ * update_feature_maps!(rule::PGDUpdate, data, W, H; loss_func, constrH, penaltiesH) -> loss    src/algs/pgd.jl:180-202
+ * with SquareLoss; pen_sq / pen_abs are the summed weights of the SquarePenalty / AbsolutePenalty entries of
+ * the penalty list (pgd.jl:74-89); nonneg selects NonnegConstraint (max(eps, x), pgd.jl:92-96) or none.
+ * The rule's state (stepW = stepH = 5, cur_loss = norm(data), step_incr 1.05, step_decr 0.70; pgd.jl:139-154)
+ * lives in the handle and is (re)initialised by cmf_create and cmf_pgd_reset.  Unsharded handles only. */
+int cmf_pgd_reset(cmf_handle h);
+int cmf_pgd_update_motifs(cmf_handle h, double pen_sq, double pen_abs, int nonneg);
+int cmf_pgd_update_feature_maps(cmf_handle h, double pen_sq, double pen_abs, int nonneg, double *loss);
+int cmf_pgd_get_steps(cmf_handle h, double *stepW, double *stepH);
+
 /* converged(loss_hist, patience, tol): src/model.jl:91-107 (host arithmetic). */
 int cmf_converged(const double *loss_hist, int64_t len, int64_t patience, double tol);
 

@@ -225,6 +225,86 @@ def fit_hals(data, W_init, H_init, max_itr=100, max_time=np.inf, check_convergen
 
 
 # --------------------------------------------------------------------------
+# PGD rule: src/algs/pgd.jl.  numpy restatement only.
+# Supported pieces: SquareLoss (:30-36), SquarePenalty / AbsolutePenalty (:74-89),
+# NonnegConstraint (:92-96) or no constraint.
+# --------------------------------------------------------------------------
+class PGDUpdate:
+    """PGDUpdate state + ctor: src/algs/pgd.jl:112-155."""
+
+    def __init__(self, data, W, H):
+        self.datanorm = np.linalg.norm(data)
+        self.est = tensor_conv(W, H)
+        self.gradW = np.zeros(W.shape)
+        self.gradH = np.zeros(H.shape)
+        self.stepW = 5.0
+        self.stepH = 5.0
+        self.cur_loss = self.datanorm  # :151 (sic: the norm, not its square)
+        self.step_incr = 1.05
+        self.step_decr = 0.70
+
+
+def _pgd(rule, x, gradx, compute_grad, step, data, W, H, pen_sq, pen_abs, nonneg):
+    """pgd!: src/algs/pgd.jl:224-255 (x is W or H, updated in place)."""
+    T = H.shape[1]
+    rule.est[...] = 2.0 * (rule.est - data)  # :230  grad!(SquareLoss): 2*(est - data), in place in r.est
+    compute_grad(gradx, rule.est)  # :231
+    for w in pen_sq:
+        gradx += 2.0 * w * x  # :78-80
+    for w in pen_abs:
+        gradx += w * np.sign(x)  # :87-89
+    alpha = step / (np.linalg.norm(gradx) + EPS)  # :237
+    x -= alpha * gradx  # :240
+    if nonneg:
+        np.maximum(x, EPS, out=x)  # :94-96 max(eps(), x)
+    tensor_conv(W, H, out=rule.est)  # :245
+    loss = np.linalg.norm(data - rule.est) ** 2  # :246, :34-36
+    step = step * (rule.step_incr if loss < rule.cur_loss else rule.step_decr)  # :248-252
+    rule.cur_loss = loss  # :253
+    return step
+
+
+def pgd_update_motifs(rule, data, W, H, penaltiesW_sq=(1.0,), penaltiesW_abs=(), nonneg=True):
+    """update_motifs!(::PGDUpdate): pgd.jl:158-177 (defaults: SquarePenalty(1), NonnegConstraint)."""
+    K, N, L = W.shape
+    T = H.shape[1]
+
+    def grad(gradw, est):  # compute_gradW!: :206-214
+        for lag in range(L):
+            gradw[:, :, lag] = (H[:, : T - lag] @ est[:, lag:].T) if lag < T else 0.0
+
+    rule.stepW = _pgd(rule, W, rule.gradW, grad, rule.stepW, data, W, H, penaltiesW_sq, penaltiesW_abs, nonneg)
+
+
+def pgd_update_feature_maps(rule, data, W, H, penaltiesH_sq=(), penaltiesH_abs=(), nonneg=True):
+    """update_feature_maps!(::PGDUpdate): pgd.jl:180-202 -> sqrt(cur_loss / datanorm^2)."""
+
+    def grad(gradh, est):  # compute_gradH!: :218-221
+        tensor_transconv(W, est, out=gradh)
+
+    rule.stepH = _pgd(rule, H, rule.gradH, grad, rule.stepH, data, W, H, penaltiesH_sq, penaltiesH_abs, nonneg)
+    return np.sqrt(rule.cur_loss / rule.datanorm ** 2)
+
+
+def fit_pgd(data, W_init, H_init, max_itr=100, check_convergence=False, patience=3, tol=1e-4, eval_mode=False, **kw):
+    """fit(::AlternatingOptimizer{PGDUpdate}): src/algs/alternating.jl:16-71."""
+    W = np.array(W_init, dtype=np.float64, copy=True)
+    H = np.array(H_init, dtype=np.float64, copy=True)
+    rule = PGDUpdate(data, W, H)
+    loss_hist = [compute_loss(data, W, H)]
+    kW = {k: v for k, v in kw.items() if k.startswith("penaltiesW")}
+    kH = {k: v for k, v in kw.items() if k.startswith("penaltiesH")}
+    nonneg = kw.get("nonneg", True)
+    for _ in range(max_itr):
+        if not eval_mode:
+            pgd_update_motifs(rule, data, W, H, nonneg=nonneg, **kW)
+        loss_hist.append(pgd_update_feature_maps(rule, data, W, H, nonneg=nonneg, **kH))
+        if check_convergence and converged(loss_hist, patience, tol):
+            break
+    return W, H, np.asarray(loss_hist), (rule.stepW, rule.stepH)
+
+
+# --------------------------------------------------------------------------
 # index-level brute force (tiny sizes only; third, independent statement)
 # --------------------------------------------------------------------------
 def brute_conv(W, H):

@@ -383,3 +383,40 @@ def test_evaluate_test_and_sweep(cmf, oracle):
     _, Ho, lo, _ = oracle.c_fit_hals(test, Wf, np.zeros((4, test.shape[1])), max_itr=30, eval_mode=True, check_convergence=False)
     assert abs(te - lo[-1]) <= 1e-4 * lo[-1]
     assert te > r.loss_hist[-1] * 0.5  # sanity: held-out loss is of the same order
+
+
+# ---- PGD (src/algs/pgd.jl) ---------------------------------------
+@pytest.mark.parametrize("N,T,K,L", [(48, 300, 4, 8), (130, 700, 32, 20), (37, 150, 33, 7), (9, 5, 2, 8)])
+def test_pgd_iterations(cmf, oracle, N, T, K, L):
+    """Default PGDUpdate (SquareLoss, NonnegConstraint, penaltiesW=[SquarePenalty(1)], penaltiesH=[])."""
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    iters = 8
+    res = cmf.fit_cnmf(data, L=L, K=K, alg=cmf.PGDUpdate, max_itr=iters, check_convergence=False, W_init=W0, H_init=H0)
+    Wr, Hr, lr, steps = oracle.fit_pgd(data, W0, H0, max_itr=iters)
+    np.testing.assert_allclose(res.loss_hist, lr, rtol=REL_LOSS)
+    assert frob_rel(res.W, Wr) < REL_FACTORS and frob_rel(res.H, Hr) < REL_FACTORS
+
+
+def test_pgd_penalties_and_unconstrained(cmf, oracle):
+    data, _, _ = oracle.c_gen_synthetic(N=60, T=500, K=3, L=10, seed=5)
+    W0, H0 = oracle.c_init_rand(data, L=10, K=5, seed=1)
+    rule = cmf.PGDUpdate(data, W0, H0)
+    kwW = dict(penaltiesW=[cmf.SquarePenalty(0.5), cmf.AbsolutePenalty(0.2)], constrW=None)
+    kwH = dict(penaltiesH=[cmf.AbsolutePenalty(0.1)], constrH=cmf.NonnegConstraint())
+    lg = []
+    for _ in range(6):
+        rule.update_motifs(**kwW)
+        lg.append(rule.update_feature_maps(**kwH))
+    Wg, Hg = rule.download()
+    sg = rule.steps
+    rule.close()
+    W, H = W0.copy(), H0.copy()
+    orule = oracle.PGDUpdate(data, W, H)
+    lo = []
+    for _ in range(6):
+        oracle.pgd_update_motifs(orule, data, W, H, penaltiesW_sq=(0.5,), penaltiesW_abs=(0.2,), nonneg=False)
+        lo.append(oracle.pgd_update_feature_maps(orule, data, W, H, penaltiesH_abs=(0.1,), nonneg=True))
+    np.testing.assert_allclose(lg, lo, rtol=REL_LOSS)
+    assert frob_rel(Wg, W) < REL_FACTORS and frob_rel(Hg, H) < REL_FACTORS
+    np.testing.assert_allclose(sg, (orule.stepW, orule.stepH), rtol=1e-12)  # same accept/reject decisions
