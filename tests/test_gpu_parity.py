@@ -420,3 +420,31 @@ def test_pgd_penalties_and_unconstrained(cmf, oracle):
     np.testing.assert_allclose(lg, lo, rtol=REL_LOSS)
     assert frob_rel(Wg, W) < REL_FACTORS and frob_rel(Hg, H) < REL_FACTORS
     np.testing.assert_allclose(sg, (orule.stepW, orule.stepH), rtol=1e-12)  # same accept/reject decisions
+
+
+def test_config1_full_fit(cmf, oracle):
+    """BASELINE.json configs[0]: gen_synthetic N=500 T=2000, fit_cnmf alg=:mult K=5 L=10, the reference's own
+    CPU-runnable case, 100 iterations (README.md:34-37 defaults) against the fp64 oracle."""
+    data, _, _ = oracle.c_gen_synthetic(N=500, T=2000, K=3, L=20, seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=10, K=5, seed=0)
+    res = cmf.fit_cnmf(data, L=10, K=5, alg=":mult", max_itr=100, check_convergence=False, W_init=W0, H_init=H0)
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=100, check_convergence=False)
+    assert len(res.loss_hist) == 101
+    np.testing.assert_allclose(res.loss_hist, lr, rtol=REL_LOSS)
+    assert frob_rel(res.W, Wr) < REL_FACTORS and frob_rel(res.H, Hr) < REL_FACTORS
+    # and with the default early stop the iteration count agrees too (alternating.jl:63-66)
+    res2 = cmf.fit_cnmf(data, L=10, K=5, alg=":mult", max_itr=100, W_init=W0, H_init=H0)
+    _, _, lr2, _ = oracle.fit_mult(data, W0, H0, max_itr=100)
+    assert len(res2.loss_hist) == len(lr2)
+
+
+def test_config4_regularised_full_size(cmf, config2):
+    """BASELINE.json configs[3] (README.md:52 regularisers) at full size: runs, stays positive, and differs from
+    the unregularised path in the expected direction (smaller factors)."""
+    data, W0, H0 = config2
+    reg = cmf.fit_cnmf(data, L=20, K=32, max_itr=3, check_convergence=False, W_init=W0, H_init=H0,
+                       l1_H=0.1, l2_H=0.2, l1_W=0.1, l2_W=0.5)
+    plain = cmf.fit_cnmf(data, L=20, K=32, max_itr=3, check_convergence=False, W_init=W0, H_init=H0)
+    assert np.all(np.isfinite(reg.loss_hist)) and reg.W.min() >= cmf.EPSILON and reg.H.min() >= cmf.EPSILON
+    assert np.linalg.norm(reg.W) < np.linalg.norm(plain.W) and np.linalg.norm(reg.H) < np.linalg.norm(plain.H)
+    assert reg.loss_hist[-1] > plain.loss_hist[-1]
