@@ -199,6 +199,19 @@ def main():
         dt_noreuse, _ = timed(1, max(3, args.steps // 2))
         dt_noreuse /= max(3, args.steps // 2)
         rule.set_option("reuse_est", 1)
+    # Optional Gram form of the denominators (executes 2.3 + 1 contractions): reported as
+    # extra fields only, the headline value is the reference formulation above.
+    dt_gram = dt_gram2 = None
+    if world == 1 and alg == "mult":
+        nrep = max(3, args.steps // 2)
+        rule.upload(W0, H0)
+        rule.set_option("gram", 1)
+        dt_gram, lg = timed(1, nrep)
+        dt_gram /= nrep
+        rule.set_option("gram", 2)
+        dt_gram2, _ = timed(1, nrep)
+        dt_gram2 /= nrep
+        rule.set_option("gram", 0)
 
     out = None
     if rank == 0:
@@ -226,6 +239,10 @@ def main():
             "est_reuse": "the est of mult.jl:55 is kept for the next mult.jl:28 (same W, H): 6 of the 7 contractions "
                          "are executed, results bitwise identical; ms_per_step_no_reuse runs all 7",
             "ms_per_step_no_reuse": (1e3 * dt_noreuse) if dt_noreuse else None,
+            "ms_per_step_gram": (1e3 * dt_gram) if dt_gram else None,
+            "ms_per_step_gram_loss": (1e3 * dt_gram2) if dt_gram2 else None,
+            "gram_note": "option gram=1: denomW/denomH through Gram matrices (exact rewriting, rounding-level differences), "
+                         "loss still by conv; gram=2: loss from Gram sums too.  Not part of `value`.",
             "whole_iteration_tflops": F_iter * iters_per_s / 1e12,
             "whole_iteration_mfma_frac": F_iter * iters_per_s / (world * PEAK_FP32_MFMA_TFLOPS * 1e12),
         }

@@ -102,11 +102,15 @@ struct cmf_handle_s {
     bool factors_set = false;
     bool have_data = false;
     bool reuse_est = true;  // option "reuse_est"
+    int gram = 0;           // option "gram": 0 off, 1 Gram-form denominators, 2 also the loss from Gram sums
+    float *gram_numden_h = nullptr; // [1][2][Tl][K32]: numH | denomH in the h_update slab layout
     int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data
 };
 
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
 static int resid_and_loss(cmf_handle_s *h, double *sumsq);
+static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W);
+static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss);
 static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg);
 static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg, double *loss);
 static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H);
@@ -117,6 +121,7 @@ static size_t n_partial(const cmf_handle_s *h)
     size_t n = (size_t)h->conv_gx * (size_t)std::max(h->conv_gy, h->conv_gy_ext);       // conv loss partials
     n = std::max(n, (size_t)(d.Np / 64) * d.KB * d.L);                                 // PGD gradW norm partials
     n = std::max(n, (size_t)((d.Tl + 63) / 64) * d.KB);                                // PGD gradH norm partials
+    n = std::max(n, 2 * (((size_t)d.Tl * d.K32 + 1023) / 1024));                       // Gram-form loss partials
     return n;
 }
 
@@ -192,7 +197,7 @@ static void destroy_impl(cmf_handle_s *h)
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
                       h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3],
-                      h->pgd_gradH, h->hals_HuT, h->hals_hhslabs, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE};
+                      h->gram_numden_h, h->pgd_gradH, h->hals_HuT, h->hals_hhslabs, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE};
     for (float *p : fbufs)
         if (p) (void)hipFree(p);
     if (h->partial) (void)hipFree(h->partial);
@@ -490,6 +495,13 @@ int cmf_set_stream(cmf_handle h, void *hip_stream)
 int cmf_set_option(cmf_handle h, const char *name, int value)
 {
     if (!h || !name) return fail(CMF_ERR_ARG, "NULL argument");
+    if (std::strcmp(name, "gram") == 0) {
+        if (value < 0 || value > 2) return fail(CMF_ERR_ARG, "gram must be 0, 1 or 2");
+        if (value && h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "the Gram form is not available on sharded handles");
+        h->gram = value;
+        h->est_kind = 0;
+        return CMF_OK;
+    }
     if (std::strcmp(name, "reuse_est") == 0) {
         h->reuse_est = value != 0;
         h->est_kind = 0;
@@ -609,6 +621,7 @@ int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
 {
     CMFTRY(check_ready(h, true));
     if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: use the phase-split entries");
+    if (h->gram) return gram_w_impl(h, l1W, l2W);
     CMFTRY(w_partial_impl(h));
     return w_apply_impl(h, l1W, l2W);
 }
@@ -618,6 +631,7 @@ int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
     CMFTRY(check_ready(h, true));
     if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: use the phase-split entries");
+    if (h->gram) return gram_h_impl(h, l1H, l2H, loss);
     CMFTRY(h_update_impl(h, l1H, l2H));
     double ss = 0.0;
     CMFTRY(loss_partial_impl(h, &ss));
@@ -904,6 +918,88 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
         KCHK("hals_h_stage_kernel");
     }
     h->est_kind = 0;
+    return CMF_OK;
+}
+
+// ---- optional Gram form of the MU iteration ----------------------------------
+static int gram_tables(cmf_handle_s *h) // PW -> GW, GE (the lag-Gram taps of W; shared with HALS)
+{
+    const CmfDims &d = h->d;
+    hipLaunchKernelGGL(hals_pw_kernel, dim3(d.L * d.L, d.KB * d.KB), dim3(32, 32), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
+    KCHK("hals_pw_kernel");
+    hipLaunchKernelGGL(hals_gw_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_PW, h->hals_GW, h->hals_GE, d.L, d.K32, h->hals_ne, d.Tl, h->hals_t_edge0);
+    KCHK("hals_gw_kernel");
+    return CMF_OK;
+}
+
+static int gram_denom_h(cmf_handle_s *h, float *out)
+{
+    const CmfDims &d = h->d;
+    const size_t lds = (size_t)d.K32 * (64 + 2 * (d.L - 1)) * sizeof(float);
+    if (lds > 96 * 1024) return fail(CMF_ERR_UNSUPPORTED, "Gram form: K*L too large for the LDS window");
+    hipLaunchKernelGGL(gram_h_kernel, dim3((d.Tl + 63) / 64, d.K32 / 4), dim3(256), lds, h->stream, h->Ht, h->hals_GW, h->hals_GE, out,
+                       d.Tl, d.K, d.L, d.K32, d.TP, d.PADL, h->hals_ne, h->hals_t_edge0);
+    KCHK("gram_h_kernel");
+    return CMF_OK;
+}
+
+static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(hals_ensure(h));
+    const size_t LKN = (size_t)d.L * d.K32 * d.Np;
+    // numW = H_shift * data' (mult.jl:32): one C2 contraction
+    CMFTRY(launch_hxt_on(h, h->X, h->X, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
+    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks1, LKN));
+    // denomW = H_shift * est' (mult.jl:33) = HH * W with HH = H_unfold * H_unfold'
+    hipLaunchKernelGGL(hals_build_hut_kernel, dim3(2048), dim3(256), 0, h->stream, h->H, h->hals_HuT, d.Tl, d.L, d.K32, h->hals_NpH, d.PADL);
+    KCHK("hals_build_hut_kernel");
+    CMFTRY(launch_hxt_on(h, h->hals_HuT, h->hals_HuT, h->hals_NpH, 1, h->hals_hhslabs, h->hals_nch, h->hals_clen));
+    CMFTRY(launch_slab_sum(h, h->hals_HH, h->hals_hhslabs, h->hals_nch, (size_t)d.L * d.K32 * h->hals_NpH));
+    hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 128, d.L * d.KB), dim3(256), 0, h->stream, h->hals_HH, h->Wt, h->numden + LKN,
+                       d.L * d.K32, h->hals_NpH, d.Np);
+    KCHK("gram_w_kernel");
+    return w_apply_impl(h, l1W, l2W); // mult.jl:37-38
+}
+
+static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(hals_ensure(h));
+    const size_t TK = (size_t)d.Tl * d.K32;
+    if (!h->gram_numden_h) CMFTRY(dalloc_zero(&h->gram_numden_h, 2 * TK));
+    // numH = tensor_transconv(W, data) (mult.jl:47): one C3 contraction
+    CMFTRY(launch_transconv(h, 1, h->XT));
+    CMFTRY(launch_slab_sum(h, h->gram_numden_h, h->hslabs, h->tc_S1, TK));
+    // denomH = tensor_transconv(W, tensor_conv(W, H)) (mult.jl:44,48) through the lag-Gram taps of W
+    CMFTRY(gram_tables(h));
+    CMFTRY(gram_denom_h(h, h->gram_numden_h + TK));
+    hipLaunchKernelGGL(h_update_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->H, h->Ht, h->gram_numden_h, 1,
+                       d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
+    KCHK("h_update_kernel");
+    h->est_kind = 0;
+    double ss = 0.0;
+    if (h->gram == 2) {
+        // ||est - data||^2 = <H, denomH(H)> - 2 <H, numH> + ||data||^2 with the NEW H (adjointness of conv/transconv)
+        CMFTRY(gram_denom_h(h, h->gram_numden_h + TK));
+        const int nb = (int)((TK + 1023) / 1024);
+        if ((size_t)2 * nb > n_partial(h)) return fail(CMF_ERR_UNSUPPORTED, "Gram loss: partial buffer too small");
+        hipLaunchKernelGGL(gram_dot_kernel, dim3(nb), dim3(256), 0, h->stream, h->H, h->gram_numden_h, h->gram_numden_h + TK, h->partial,
+                           d.Tl, d.K, d.K32, d.PADL, nb);
+        KCHK("gram_dot_kernel");
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->d_scalar + 2);
+        KCHK("loss_reduce_kernel");
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial + nb, nb, h->d_scalar + 3);
+        KCHK("loss_reduce_kernel");
+        double a = 0.0, b = 0.0;
+        CMFTRY(read_scalar(h, 2, &a));
+        CMFTRY(read_scalar(h, 3, &b));
+        ss = a - 2.0 * b + h->data_sumsq;
+        if (ss < 0.0) ss = 0.0;
+    } else {
+        CMFTRY(loss_partial_impl(h, &ss)); // exact: conv with the fused loss (mult.jl:55-57)
+    }
+    *loss = std::sqrt(ss) / h->data_norm;
     return CMF_OK;
 }
 

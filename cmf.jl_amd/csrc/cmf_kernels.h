@@ -1260,6 +1260,108 @@ __global__ __launch_bounds__(256) void pgd_h_apply_kernel(float *H, float *Ht, c
     }
 }
 
+
+// =============================================================================================
+// Optional Gram form of the MU denominators ("optional algebraic shortcut").
+//   denomW[(l,k)][n] = sum_{(l',k')} HH[(l,k)][(l',k')] * W[(l',k')][n],  HH = H_unfold H_unfold'
+//   denomH[t][k]     = sum_{k',e} taps(t)[k][k'][e] * H[t+e][k'],          taps = lag-Gram of W (as in HALS)
+// Both are exact rewritings of H_shift * est' and tensor_transconv(W, est) with est = tensor_conv(W, H)
+// (including the edge truncations); only the association of the sums differs.  Off by default.
+// =============================================================================================
+
+// out[p][n] = sum_{p'} HH[p'][p] * Wt[p'][n]  (HH is symmetric: row p' is read, columns p0+i -> coalesced)
+// grid (Np/128, LK/32), block 256: wave w -> n block blockIdx.x*4 + w
+__global__ __launch_bounds__(256) void gram_w_kernel(const float *HH, const float *Wt, float *out, int LK, int NpH, int Np)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int p0 = blockIdx.y * 32, n0 = (blockIdx.x * 4 + wave) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float *ap = HH + (size_t)h * NpH + p0 + i;
+    const float *bp = Wt + (size_t)h * Np + n0 + i;
+#pragma unroll 8
+    for (int pp = 0; pp < LK; pp += 2) {
+        const float a = ap[(size_t)pp * NpH];
+        const float b = bp[(size_t)pp * Np];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(size_t)(p0 + cmf_crow(r, h)) * Np + n0 + i] = acc[r];
+}
+
+// out[t][k] = sum_{k',e} taps(t)[k][k'][e] * Ht[k'][PADL + t + e];  taps = GW (full window) or GE (edge columns)
+// grid (ceil(Tl/64), K32/4), block 256: wave w -> k = blockIdx.y*4 + w, lane -> t = t0 + lane
+// dynamic LDS: K32 * (64 + 2*(L-1)) floats
+__global__ __launch_bounds__(256) void gram_h_kernel(const float *Ht, const float *GW, const float *GE, float *out,
+                                                      int Tl, int K, int L, int K32, int TP, int PADL, int ne, int t_edge0)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * 64;
+    const int k = blockIdx.y * 4 + wave;
+    const int E = 2 * L - 1, WN = 64 + 2 * (L - 1);
+    for (int idx = tid; idx < K32 * WN; idx += 256) {
+        const int kp = idx / WN, c = idx - kp * WN;
+        smem_dyn[idx] = Ht[(size_t)kp * TP + PADL + t0 - (L - 1) + c];
+    }
+    __syncthreads();
+    const int t = t0 + lane;
+    float acc = 0.f;
+    if (k < K) {
+        const bool full = (t0 + 64 <= t_edge0); // block-uniform: every column has the full lag window
+        if (full) {
+            const float *gw = GW + (size_t)k * K32 * E; // wave-uniform -> scalar loads
+            for (int kp = 0; kp < K; ++kp) {
+                const float *hw = smem_dyn + kp * WN + lane;
+#pragma unroll 4
+                for (int ei = 0; ei < E; ++ei) acc = fmaf(gw[kp * E + ei], hw[ei], acc);
+            }
+        } else if (t < Tl) {
+            const float *taps = (t < t_edge0) ? GW + (size_t)k * K32 * E
+                                               : GE + ((size_t)k * ne + (t - t_edge0)) * K32 * E;
+            for (int kp = 0; kp < K; ++kp) {
+                const float *hw = smem_dyn + kp * WN + lane;
+                for (int ei = 0; ei < E; ++ei) acc = fmaf(taps[kp * E + ei], hw[ei], acc);
+            }
+        }
+    }
+    if (t < Tl && k < K32) out[(size_t)t * K32 + k] = acc;
+}
+
+// partial[b] = sum H*den, partial[nb + b] = sum H*num over the block's (t, k); grid ceil(Tl*K32/1024), block 256
+__global__ __launch_bounds__(256) void gram_dot_kernel(const float *H, const float *num, const float *den, double *partial,
+                                                        int Tl, int K, int K32, int PADL, int nb)
+{
+    const size_t total = (size_t)Tl * K32;
+    double sd = 0.0, sn = 0.0;
+    for (size_t idx = (size_t)blockIdx.x * 1024 + threadIdx.x; idx < (size_t)(blockIdx.x + 1) * 1024 && idx < total; idx += 256) {
+        const int k = (int)(idx % K32);
+        const size_t t = idx / K32;
+        if (k < K) {
+            const double hv = H[(PADL + t) * K32 + k];
+            sd += hv * (double)den[idx];
+            sn += hv * (double)num[idx];
+        }
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = sd;
+    red[1][threadIdx.x] = sn;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = red[0][0];
+        partial[nb + blockIdx.x] = red[1][0];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Layout conversion (fp64 Julia order on the host side <-> padded fp32 device layouts)
 // ---------------------------------------------------------------------------------------------

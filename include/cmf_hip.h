@@ -77,7 +77,12 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *   "reuse_est" (default 1): the est = tensor_conv(W, H) that closes update_feature_maps!
  *       (mult.jl:55) is kept, and the next update_motifs! (mult.jl:28), which would recompute the
  *       same est from the same W and H, reuses it (6 instead of 7 contractions per iteration,
- *       identical results).  0 = recompute it like the reference does. */
+ *       identical results).  0 = recompute it like the reference does.
+ *   "gram" (default 0): 1 = form denomW and denomH through Gram matrices (denomW = (H_unfold H_unfold') W,
+ *       denomH = lag-Gram taps of W applied to H) instead of through est: exact rewritings of mult.jl:33,48 that
+ *       execute 2.3 instead of 6 contractions plus the loss conv; results differ at rounding level only.
+ *       2 = additionally take the loss from <H, denomH> - 2<H, numH> + ||data||^2 (no conv at all; the fp32
+ *       cancellation limits its relative accuracy to about 1e-6 / loss^2).  Unsharded handles only. */
 int cmf_set_option(cmf_handle h, const char *name, int value);
 
 /* sum(data.^2) over the columns this handle owns (fp64); and the setter used

@@ -449,3 +449,23 @@ def test_config4_regularised_full_size(cmf, config2):
     # the W penalties shrink W (H may compensate); the two paths must actually differ
     assert np.linalg.norm(reg.W) < np.linalg.norm(plain.W)
     assert reg.loss_hist[-1] != plain.loss_hist[-1] and frob_rel(reg.H, plain.H) > 1e-7
+
+
+# ---- optional Gram form of the MU denominators ---------------------------
+@pytest.mark.parametrize("N,T,K,L", [(48, 300, 4, 8), (130, 700, 32, 20), (37, 150, 33, 7), (6, 3, 2, 5), (20, 200, 6, 40)])
+@pytest.mark.parametrize("gram", [1, 2])
+def test_gram_form_matches_oracle(cmf, oracle, N, T, K, L, gram):
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    reg = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2)
+    rule = cmf.MultUpdate(data, W0, H0)
+    rule.set_option("gram", gram)
+    lg = []
+    for _ in range(10):
+        rule.update_motifs(l1W=reg["l1W"], l2W=reg["l2W"])
+        lg.append(rule.update_feature_maps(l1H=reg["l1H"], l2H=reg["l2H"]))
+    Wg, Hg = rule.download()
+    rule.close()
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=10, check_convergence=False, **reg)
+    np.testing.assert_allclose(lg, lr[1:], rtol=REL_LOSS if gram == 1 else 5e-4)
+    assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
