@@ -876,7 +876,8 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     // the K*L sequential column updates, k outer / lag inner (hals.jl:90-97)
     const size_t per_wave = ((size_t)HALS_NG * d.L * d.K32 + 64) * sizeof(float);
     int wpb = (int)std::min<size_t>(4, (size_t)(96 * 1024) / per_wave);
-    if (wpb < 1) return fail(CMF_ERR_UNSUPPORTED, "HALS W sweep: L*K too large for the LDS-resident state (%zu bytes per wave)", per_wave);
+    if (wpb < 1 || d.L * d.K32 > 1024)
+        return fail(CMF_ERR_UNSUPPORTED, "HALS W sweep: L*K = %d exceeds the 1024 state entries per unit it keeps on chip", d.L * d.K32);
     const int units_per_block = wpb * HALS_NG;
     dim3 grid((d.N + units_per_block - 1) / units_per_block), block(64 * wpb);
     hipLaunchKernelGGL(hals_w_sweep_kernel, grid, block, per_wave * wpb, h->stream, h->Wt, h->Wn, h->numden, h->hals_HH,

@@ -789,7 +789,7 @@ __global__ void hals_build_hut_kernel(const float *H, float *HuT, int Tl, int L,
 }
 
 // W sweep: one wave = NG units n; state g[NG][LK] in LDS (wave-private).  G = resid * H_unfold' in Wt layout.
-#define HALS_NG 4
+#define HALS_NG 2
 __global__ void hals_w_sweep_kernel(float *Wt, float *Wn, const float *G, const float *HH,
                                                             int N, int K, int L, int Np, int K32, int NpH, float l1, float l2)
 {
@@ -807,41 +807,75 @@ __global__ void hals_w_sweep_kernel(float *Wt, float *Wn, const float *G, const 
             int n = n0 + u;
             g[u * LK + j] = (n < N) ? G[(size_t)j * Np + n] : 0.f;
         }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int k = 0; k < K; ++k)
-        for (int l = 0; l < L; ++l) {
-            const int pidx = l * K32 + k;
-            const float *hrow = HH + (size_t)pidx * NpH;
-            const float hpp = hrow[pidx];
-            if (lane < HALS_NG) {
-                const int n = n0 + lane;
-                float d = 0.f;
-                if (n < N) {
-                    const size_t wi = (size_t)pidx * Np + n;
-                    const float wo = Wt[wi];
-                    const float v = g[lane * LK + pidx] - wo * hpp;
-                    float wn = (-v - l1) / (hpp + CMF_EPS_F + l2);
-                    wn = fmaxf(wn, 0.f);
-                    Wt[wi] = wn;
-                    Wn[((size_t)l * Np + n) * K32 + k] = wn;
-                    d = wn - wo;
-                }
-                dl[lane] = d;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float du[HALS_NG];
+    // LDS accesses of one wave execute in order; the only thing to prevent is the compiler moving them
+    // across the step boundaries (no s_waitcnt is wanted there: the prefetches below must stay in flight)
+#define HALS_WAVE_SYNC()                 \
+    do {                                 \
+        asm volatile("" ::: "memory");  \
+        __builtin_amdgcn_wave_barrier(); \
+    } while (0)
+    HALS_WAVE_SYNC();
+    // Software pipeline over the K*L steps (k outer, lag inner): the HH row, its diagonal entry and the old
+    // W values of step s+1 are loaded while step s updates the LDS-resident state.
+    constexpr int MAXQ = 16; // LK <= 1024 state entries per unit (host checks)
+    const int nsteps = K * L;
+    const bool owner = lane < HALS_NG && (n0 + lane) < N;
+    const int n_own = n0 + lane;
+    float hcur[MAXQ], hnext[MAXQ], hnext2[MAXQ];
+    float hpp_cur, hpp_next = 0.f, hpp_next2 = 0.f, wo_cur = 0.f, wo_next = 0.f, wo_next2 = 0.f;
+    auto step_index = [&](int sidx, int &kk, int &ll) { // step -> (k, l), clamped to the last step
+        const int c = sidx < nsteps ? sidx : nsteps - 1;
+        kk = c / L;
+        ll = c - kk * L;
+    };
+    auto prefetch = [&](int sidx, float (&hr)[MAXQ], float &hpp, float &wo) {
+        int kk, ll;
+        step_index(sidx, kk, ll);
+        const int pi = ll * K32 + kk;
+        const float *hrow = HH + (size_t)pi * NpH;
 #pragma unroll
-            for (int u = 0; u < HALS_NG; ++u) du[u] = dl[u];
-            for (int j = lane; j < LK; j += 64) {
-                const float hv = hrow[j];
-#pragma unroll
-                for (int u = 0; u < HALS_NG; ++u) g[u * LK + j] = fmaf(du[u], hv, g[u * LK + j]);
+        for (int q = 0; q < MAXQ; ++q) hr[q] = (lane + 64 * q < LK) ? hrow[lane + 64 * q] : 0.f;
+        hpp = hrow[pi];
+        if (owner) wo = Wt[(size_t)pi * Np + n_own];
+    };
+    prefetch(0, hcur, hpp_cur, wo_cur);
+    prefetch(1, hnext, hpp_next, wo_next);
+    for (int sidx = 0; sidx < nsteps; ++sidx) {
+        int k, l;
+        step_index(sidx, k, l);
+        const int pidx = l * K32 + k;
+        prefetch(sidx + 2, hnext2, hpp_next2, wo_next2); // two steps ahead: a step is shorter than an L2 round trip
+        if (lane < HALS_NG) {
+            float d = 0.f;
+            if (owner) {
+                const float v = g[lane * LK + pidx] - wo_cur * hpp_cur;      // hals.jl:104 projected
+                float wn = (-v - l1) / (hpp_cur + CMF_EPS_F + l2);            // hals.jl:110
+                wn = fmaxf(wn, 0.f);
+                Wt[(size_t)pidx * Np + n_own] = wn;
+                Wn[((size_t)l * Np + n_own) * K32 + k] = wn;
+                d = wn - wo_cur;
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            dl[lane] = d;
         }
+        HALS_WAVE_SYNC();
+        float du[HALS_NG];
+#pragma unroll
+        for (int u = 0; u < HALS_NG; ++u) du[u] = dl[u];
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int j = lane + 64 * q;
+            if (j < LK) {
+#pragma unroll
+                for (int u = 0; u < HALS_NG; ++u) g[u * LK + j] = fmaf(du[u], hcur[q], g[u * LK + j]); // hals.jl:106
+            }
+        }
+        HALS_WAVE_SYNC();
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) { hcur[q] = hnext[q]; hnext[q] = hnext2[q]; }
+        hpp_cur = hpp_next; hpp_next = hpp_next2;
+        wo_cur = wo_next; wo_next = wo_next2;
+    }
+#undef HALS_WAVE_SYNC
 }
 
 // PT[k][t] = sum_s of the transconv(W, resid) slabs [S][1][Tl][K32]; grid (ceil(Tl/64), KB), block 256
