@@ -270,7 +270,20 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     d.PADL = (int)rup(L - 1, 32) + 32;
     d.TP = d.PADL + (int)rup(Tl + L, 512) + 256;
     d.Lp = L <= 32 ? (int)rup(L, 4) : (int)rup(L, 32);
+    if ((double)d.Lp * d.Np * d.K32 * 4.0 >= 2147483648.0 || (double)d.TP * d.K32 * 4.0 >= 2147483648.0) {
+        delete h;
+        return fail(CMF_ERR_UNSUPPORTED, "W (L*N*K) or H (T*K) exceeds the 2 GiB the kernels' 32-bit buffer offsets address");
+    }
     plan(h, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    // the C2 kernel addresses a time chunk of X with 32-bit byte offsets: keep chunks below 2 GiB
+    while ((double)(h->hxt_chunk_len + 16 * h->hxt_LP + 8) * d.Np * 4.0 >= 2147483648.0) {
+        h->hxt_chunk_len = (int)rup(h->hxt_chunk_len / 2, 6 * h->hxt_LP);
+        h->hxt_nchunks = (d.Tl + h->hxt_chunk_len - 1) / h->hxt_chunk_len;
+    }
+    while ((double)(h->hxt_chunk_len1 + 16 * h->hxt_LP + 8) * d.Np * 4.0 >= 2147483648.0) {
+        h->hxt_chunk_len1 = (int)rup(h->hxt_chunk_len1 / 2, 6 * h->hxt_LP);
+        h->hxt_nchunks1 = (d.Tl + h->hxt_chunk_len1 - 1) / h->hxt_chunk_len1;
+    }
 
     auto bail = [&](int rc) { destroy_impl(h); return rc; };
 #define TRYB(expr) do { int rc__ = (expr); if (rc__ != CMF_OK) return bail(rc__); } while (0)

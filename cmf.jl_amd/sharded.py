@@ -8,7 +8,7 @@ rule on its block and the ranks meet three times:
                           ONE all-reduce(sum) of that 2*L*Kpad*Npad fp32 buffer    <- the only bulk exchange
                           identical W update on every rank                         (mult.jl:37-38)
     update_feature_maps!  est on own columns + the right lag halo, numH, denomH, H update (mult.jl:44-52)
-                          (L-1)-column H halo exchange with both neighbours        (2 x ~2.4 KB)
+                          (L-1)-column H halo exchange: one all-gather of 2 x 2.4 KB per rank
                           local sum((conv(W,H) - data).^2); all-reduce of one scalar (mult.jl:55-57)
 
 Global edges keep the reference's truncation (no halo = zeros).  The orchestration below only
@@ -70,8 +70,12 @@ class HipShardEngine:
         self.numden = torch.zeros(n.value, dtype=torch.float32, device=dev)
         check(lib.cmf_set_numden_buffer(self._h, ctypes.c_void_p(self.numden.data_ptr())))
         check(lib.cmf_halo_ptr(self._h, 0, ctypes.byref(p), ctypes.byref(n)))
-        self.halo = [torch.zeros(max(n.value, 1), dtype=torch.float32, device=dev) for _ in range(4)]
-        for w in range(4):
+        self.halo_count = max(n.value, 1)
+        # [send-to-left | send-to-right] is one contiguous tensor, so the exchange is ONE all-gather; the
+        # receive sides are pointed straight into the gathered buffer by attach_gathered_halos()
+        self.halo_send = torch.zeros(2 * self.halo_count, dtype=torch.float32, device=dev)
+        self.halo = [self.halo_send[: self.halo_count], self.halo_send[self.halo_count:], None, None]
+        for w in range(2):
             check(lib.cmf_set_halo_buffer(self._h, w, ctypes.c_void_p(self.halo[w].data_ptr())))
         self.scalar = torch.zeros(4, dtype=torch.float64, device=dev)  # [0] = local sum of squared residuals
         check(lib.cmf_set_scalar_buffer(self._h, ctypes.c_void_p(self.scalar.data_ptr())))
@@ -107,6 +111,18 @@ class HipShardEngine:
 
     def halo_pack(self):
         check(self._lib.cmf_halo_pack(self._h))
+
+    def attach_gathered_halos(self, gathered, rank, world):
+        """gathered = all ranks' [send-to-left | send-to-right] blocks: my left halo is the left neighbour's
+        send-to-right block, my right halo the right neighbour's send-to-left block (no copies)."""
+        c = self.halo_count
+        self._gathered = gathered
+        if rank > 0:
+            self.halo[2] = gathered[(2 * (rank - 1) + 1) * c: (2 * (rank - 1) + 2) * c]
+            check(self._lib.cmf_set_halo_buffer(self._h, 2, ctypes.c_void_p(self.halo[2].data_ptr())))
+        if rank < world - 1:
+            self.halo[3] = gathered[(2 * (rank + 1)) * c: (2 * (rank + 1) + 1) * c]
+            check(self._lib.cmf_set_halo_buffer(self._h, 3, ctypes.c_void_p(self.halo[3].data_ptr())))
 
     def halo_unpack(self, has_left, has_right):
         check(self._lib.cmf_halo_unpack(self._h, int(has_left), int(has_right)))
@@ -163,6 +179,7 @@ class ShardedMultUpdate(AbstractCFUpdate):
         self.has_right = self.rank < self.world - 1
         halo_r = min(L - 1, T - t1)
         dev = _lib.default_device() if device is None else device
+        self._gathered = None
         self.engine = engine_cls(data[:, t0:t1 + halo_r], W, H[:, t0:t1], t0, T, dev)
         # data_norm = norm(data) over all shards (mult.jl:13)
         ss = self._allreduce_scalar(self.engine.data_sumsq())
@@ -187,32 +204,23 @@ class ShardedMultUpdate(AbstractCFUpdate):
         return float(t.item())
 
     def _exchange_halos(self):
-        """Own first/last L-1 columns of H -> neighbours' right/left halos."""
+        """Own first/last L-1 columns of H -> neighbours' right/left halos: one small
+        all-gather of every rank's [first | last] block (2*(L-1)*Kpad floats per rank)."""
         if self.L < 2 or self.world == 1:
             return
         eng, dist = self.engine, self.dist
         eng.halo_pack()
-        send_l, send_r, recv_l, recv_r = eng.halo
-        stage = send_l.is_cuda and self.backend != "nccl"
-        if stage:
-            self.torch.cuda.synchronize()
-            send_l, send_r = send_l.cpu(), send_r.cpu()
-            recv_lc, recv_rc = recv_l.cpu(), recv_r.cpu()
+        send = eng.halo_send
+        if self._gathered is None:
+            self._gathered = self.torch.zeros(self.world * send.numel(), dtype=send.dtype, device=send.device)
+            eng.attach_gathered_halos(self._gathered, self.rank, self.world)
+        if send.is_cuda and self.backend != "nccl":
+            tmp_in = send.cpu()
+            tmp_out = self.torch.zeros(self.world * send.numel(), dtype=send.dtype)
+            dist.all_gather_into_tensor(tmp_out, tmp_in, group=self.group)
+            self._gathered.copy_(tmp_out)
         else:
-            recv_lc, recv_rc = recv_l, recv_r
-        ops = []
-        ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.world))
-        if self.has_left:
-            ops.append(dist.P2POp(dist.isend, send_l, ranks[self.rank - 1], self.group))
-            ops.append(dist.P2POp(dist.irecv, recv_lc, ranks[self.rank - 1], self.group))
-        if self.has_right:
-            ops.append(dist.P2POp(dist.isend, send_r, ranks[self.rank + 1], self.group))
-            ops.append(dist.P2POp(dist.irecv, recv_rc, ranks[self.rank + 1], self.group))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        if stage:
-            recv_l.copy_(recv_lc)
-            recv_r.copy_(recv_rc)
+            dist.all_gather_into_tensor(self._gathered, send, group=self.group)
         eng.halo_unpack(self.has_left, self.has_right)
 
     # ---- the rule ---------------------------------------------------------------------------

@@ -25,7 +25,9 @@ class OracleShardEngine:
         self.Hr = np.zeros((K, max(L - 1, 0)))                           # right halo
         self.H = np.array(H_local, dtype=np.float64)
         self.numden = torch.zeros(2 * K * N * L, dtype=torch.float64)
-        self.halo = [torch.zeros(max((L - 1) * K, 1), dtype=torch.float64) for _ in range(4)]
+        self.halo_count = max((L - 1) * K, 1)
+        self.halo_send = torch.zeros(2 * self.halo_count, dtype=torch.float64)
+        self.halo = [self.halo_send[: self.halo_count], self.halo_send[self.halo_count:], None, None]
         self._norm = None
 
     # conv on columns [0, ncols) of the shard, using the halos
@@ -85,6 +87,13 @@ class OracleShardEngine:
             den[:, :w] += self.W[:, :, l] @ est_ext[:, l: l + w]
         self.H *= num / (((den + l1H) + (2.0 * l2H) * self.H) + EPS)
         np.maximum(self.H, EPS, out=self.H)
+
+    def attach_gathered_halos(self, gathered, rank, world):
+        c = self.halo_count
+        if rank > 0:
+            self.halo[2] = gathered[(2 * (rank - 1) + 1) * c: (2 * (rank - 1) + 2) * c]
+        if rank < world - 1:
+            self.halo[3] = gathered[(2 * (rank + 1)) * c: (2 * (rank + 1) + 1) * c]
 
     def halo_pack(self):
         L, K = self.L, self.K
