@@ -909,7 +909,7 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
     CMFTRY(launch_transconv(h, 1, h->estT));
     hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, h->tc_S1, d.Tl, d.K32, h->hals_TPp);
     KCHK("hals_p_init_kernel");
-    hipLaunchKernelGGL(hals_pw_kernel, dim3(d.L * d.L, d.KB * d.KB), dim3(32, 32), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
+    hipLaunchKernelGGL(hals_pw_kernel, dim3((d.L * d.L + 3) / 4, d.KB * d.KB), dim3(256), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
     KCHK("hals_pw_kernel");
     hipLaunchKernelGGL(hals_gw_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_PW, h->hals_GW, h->hals_GE, d.L, d.K32, h->hals_ne, d.Tl, h->hals_t_edge0);
     KCHK("hals_gw_kernel");
@@ -939,7 +939,7 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
 static int gram_tables(cmf_handle_s *h) // PW -> GW, GE (the lag-Gram taps of W; shared with HALS)
 {
     const CmfDims &d = h->d;
-    hipLaunchKernelGGL(hals_pw_kernel, dim3(d.L * d.L, d.KB * d.KB), dim3(32, 32), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
+    hipLaunchKernelGGL(hals_pw_kernel, dim3((d.L * d.L + 3) / 4, d.KB * d.KB), dim3(256), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
     KCHK("hals_pw_kernel");
     hipLaunchKernelGGL(hals_gw_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_PW, h->hals_GW, h->hals_GE, d.L, d.K32, h->hals_ne, d.Tl, h->hals_t_edge0);
     KCHK("hals_gw_kernel");

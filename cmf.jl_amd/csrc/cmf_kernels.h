@@ -909,24 +909,33 @@ __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float
     }
 }
 
-// PW[l][l'][k][k'] = sum_n Wn[l][n][k] * Wn[l'][n][k'];  grid (L*L, KB*KB), block (32, 32)
-__global__ void hals_pw_kernel(const float *Wn, float *PW, int N, int L, int Np, int K32, int KB)
+// PW[l][l'][k][k'] = sum_n Wn[l][n][k] * Wn[l'][n][k'] on the MFMA pipe: one wave per (l, l', k block, k' block),
+// both operands are 128-byte rows of Wn read straight from L2.  grid (ceil(L*L/4), KB*KB), block 256
+__global__ __launch_bounds__(256) void hals_pw_kernel(const float *Wn, float *PW, int N, int L, int Np, int K32, int KB)
 {
-    const int l = blockIdx.x / L, lp = blockIdx.x % L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= L * L) return;
+    const int l = pair / L, lp = pair - l * L;
     const int kb = blockIdx.y / KB, kbp = blockIdx.y % KB;
-    const int k = kb * 32 + threadIdx.y, kp = kbp * 32 + threadIdx.x;
-    const float *a = Wn + (size_t)l * Np * K32 + k;
-    const float *b = Wn + (size_t)lp * Np * K32 + kp;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int n = 0;
-    for (; n + 4 <= N; n += 4) {
-        s0 = fmaf(a[(size_t)n * K32], b[(size_t)n * K32], s0);
-        s1 = fmaf(a[(size_t)(n + 1) * K32], b[(size_t)(n + 1) * K32], s1);
-        s2 = fmaf(a[(size_t)(n + 2) * K32], b[(size_t)(n + 2) * K32], s2);
-        s3 = fmaf(a[(size_t)(n + 3) * K32], b[(size_t)(n + 3) * K32], s3);
+    const float *a = Wn + ((size_t)l * Np + h) * K32 + kb * 32 + i;
+    const float *b = Wn + ((size_t)lp * Np + h) * K32 + kbp * 32 + i;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int N4 = (N + 3) & ~3; // rows >= N of Wn are zero (Np >= N4)
+    for (int n = 0; n < N4; n += 4) {
+        const float a0 = a[(size_t)n * K32], b0 = b[(size_t)n * K32];
+        const float a1 = a[(size_t)(n + 2) * K32], b1 = b[(size_t)(n + 2) * K32];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1, 0, 0, 0);
     }
-    for (; n < N; ++n) s0 = fmaf(a[(size_t)n * K32], b[(size_t)n * K32], s0);
-    PW[(((size_t)l * L + lp) * K32 + k) * K32 + kp] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = kb * 32 + cmf_crow(r, h), kp = kbp * 32 + i;
+        PW[(((size_t)l * L + lp) * K32 + k) * K32 + kp] = acc0[r] + acc1[r];
+    }
 }
 
 // GW[k][k'][e+L-1] = sum_l PW[l][l-e][k][k'], e in (-L, L)        (full-window taps)
