@@ -1030,27 +1030,24 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
     for (; tb + 64 <= nfull && tb + 64 <= t_stop; tb += 64) {
         const float pn2 = Prow[tb + 128 + lane];
         const float hreg2 = Hrow[tb + 64 + lane];
-        float creg = (hreg * nrm - q.l1) * inv_den; // (h_old*nrm - l1)/(nrm+eps+l2) per column
-        float pnr = cmf_wave_rol1(pn);              // lane 63 holds the column that enters next (pn[0] first)
-        float hnew = 0.f, dreg = 0.f;
+        const float creg = (hreg * nrm - q.l1) * inv_den; // (h_old*nrm - l1)/(nrm+eps+l2) per column
+        float pnr = cmf_wave_rol1(pn);                     // lane 63 holds the column that enters next (pn[0] first)
+        float hnew = 0.f;
 #pragma unroll 16
         for (int j = 0; j < 64; ++j) {
             const float s_p = cmf_lane0(p);
-            const float s_c = cmf_lane0(creg);
-            const float s_h = cmf_lane0(hreg);
+            const float s_c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, creg), j));
+            const float s_h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg), j));
             const float x = fmaxf(fmaf(-inv_den, s_p, s_c), 0.f); // hals.jl:152-153
             const float d = x - s_h;
             p = fmaf(d, g, p);                                    // hals.jl:146 on the projected state
             p = cmf_wave_shl1(p, pnr);
             pnr = cmf_wave_rol1(pnr);
             hnew = cmf_wave_shl1(hnew, x);
-            dreg = cmf_wave_shl1(dreg, d);
-            hreg = cmf_wave_shl1(hreg, 0.f);
-            creg = cmf_wave_shl1(creg, 0.f);
         }
         Hrow[tb + lane] = hnew;
         q.H[(size_t)(q.PADL + tb + lane) * q.K32 + k] = hnew;
-        q.D[tb + lane] = dreg;
+        q.D[tb + lane] = hnew - hreg;
         pn = pn2;
         hreg = hreg2;
     }
