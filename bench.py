@@ -223,8 +223,8 @@ def main():
             # of N) + conv_t + transconv (2 sources) + loss conv; the sweeps themselves are latency-bound VALU work
             F_iter = (6.0 + (L * 32.0 * ((K + 31) // 32)) / N) * 2.0 * K * N * (L * T - L * (L - 1) / 2)
         out = {
-            "metric": ("MU iterations/sec (convolutive NMF multiplicative update)" if alg == "mult"
-                       else "HALS iterations/sec (convolutive NMF, src/algs/hals.jl)"),
+            "metric": ("MU iters/sec (convolutive NMF multiplicative update; achieved HBM GB/s in `hbm`)" if alg == "mult"
+                       else "HALS iters/sec (convolutive NMF, src/algs/hals.jl)"),
             "value": iters_per_s, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -272,6 +272,23 @@ def main():
                            "avg_launch_ms": kern["conv"]["avg_ms"]}
         out["kernels"] = kern
 
+    if rank == 0 and alg == "mult":
+        # BASELINE.json's metric also asks for the achieved HBM rate.  Algorithmic bytes per iteration
+        # (est never round-tripped): B_iter = 12*N*T + 48*K*N*L + 40*K*T; measured bytes
+        # per iteration = sum of the PMC-corrected traffic of the four big launches (profiles/r01b_pmc_summary.json).
+        B_iter = 12.0 * N * T + 48.0 * K * N * L + 40.0 * K * T
+        hbm = {"algorithmic_bytes_per_iter": B_iter, "achieved_algorithmic_GBps": B_iter * out["value"] / 1e9,
+               "peak_GBps": 8000.0, "note": "the path is fp32-MFMA-bound (intensity ~700 flop/B), not HBM-bound"}
+        try:
+            if args.config in (2, 4) and world == 1 and not args.T:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_summary.json")))
+                meas = sum(pm[k]["hbm_bytes_corrected"] for k in ("void hxt_kernel<5>", "void conv2_kernel<1>",
+                                                                 "void transconv_kernel<20>", "void conv2_kernel<3>"))
+                hbm["measured_bytes_per_iter"] = meas
+                hbm["achieved_measured_GBps"] = meas * out["value"] / 1e9
+        except Exception:
+            pass
+        out["hbm"] = hbm
     if rank == 0:
         if args.cpu_seconds > 0 and world == 1:
             try:

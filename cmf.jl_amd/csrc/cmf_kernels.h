@@ -1321,7 +1321,6 @@ __global__ __launch_bounds__(256) void gram_w_kernel(const float *HH, const floa
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float *ap = HH + (size_t)h * NpH + p0 + i;
     const float *bp = Wt + (size_t)h * Np + n0 + i;
-#pragma unroll 8
     for (int pp = 0; pp < LK; pp += 2) {
         const float a = ap[(size_t)pp * NpH];
         const float b = bp[(size_t)pp * Np];
