@@ -25,7 +25,7 @@ SYMBOLS = [
     "cmf_set_factors", "cmf_get_factors",
     "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_fit", "cmf_converged",
     "cmf_hals_update_motifs", "cmf_hals_update_feature_maps",
-    "cmf_pgd_reset", "cmf_pgd_update_motifs", "cmf_pgd_update_feature_maps", "cmf_pgd_get_steps",
+    "cmf_pgd_reset", "cmf_set_mask", "cmf_pgd_update_motifs", "cmf_pgd_update_feature_maps", "cmf_pgd_get_steps",
     "cmf_w_partial", "cmf_w_apply", "cmf_h_update", "cmf_loss_partial",
     "cmf_loss_partial_async", "cmf_scalar_ptr", "cmf_set_scalar_buffer",
     "cmf_numden_ptr", "cmf_set_numden_buffer", "cmf_halo_ptr", "cmf_set_halo_buffer", "cmf_halo_pack", "cmf_halo_unpack",
@@ -81,6 +81,7 @@ def load():
     sig("cmf_hals_update_motifs", [vp, dbl, dbl])
     sig("cmf_hals_update_feature_maps", [vp, dbl, dbl, pd])
     sig("cmf_pgd_reset", [vp])
+    sig("cmf_set_mask", [vp, pd])
     sig("cmf_pgd_update_motifs", [vp, dbl, dbl, cint])
     sig("cmf_pgd_update_feature_maps", [vp, dbl, dbl, cint, pd])
     sig("cmf_pgd_get_steps", [vp, pd, pd])

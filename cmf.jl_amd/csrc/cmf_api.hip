@@ -97,6 +97,7 @@ struct cmf_handle_s {
     // PGD rule state (pgd.jl:139-154)
     double pgd_stepW = 5.0, pgd_stepH = 5.0, pgd_cur_loss = -1.0;
     float *pgd_gradH = nullptr;
+    float *M = nullptr, *MT = nullptr; // mask of MaskedLoss (pgd.jl:58-70) in the layouts of X and XT; null = no mask
 
     double data_sumsq = 0.0, data_norm = 0.0;
     bool factors_set = false;
@@ -104,11 +105,11 @@ struct cmf_handle_s {
     bool reuse_est = true;  // option "reuse_est"
     int gram = 0;           // option "gram": 0 off, 1 Gram-form denominators, 2 also the loss from Gram sums
     float *gram_numden_h = nullptr; // [1][2][Tl][K32]: numH | denomH in the h_update slab layout
-    int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data
+    int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data, 3 mask .* (tensor_conv(W,H) - data)
 };
 
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
-static int resid_and_loss(cmf_handle_s *h, double *sumsq);
+static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked = false);
 static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W);
 static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss);
 static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg);
@@ -197,7 +198,7 @@ static void destroy_impl(cmf_handle_s *h)
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
                       h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3],
-                      h->gram_numden_h, h->pgd_gradH, h->hals_HuT, h->hals_hhslabs, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE};
+                      h->gram_numden_h, h->pgd_gradH, h->M, h->MT, h->hals_HuT, h->hals_hhslabs, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE};
     for (float *p : fbufs)
         if (p) (void)hipFree(p);
     if (h->partial) (void)hipFree(h->partial);
@@ -211,8 +212,11 @@ static void destroy_impl(cmf_handle_s *h)
 }
 
 // upload `ncols` columns (fp64, N x ncols column-major) starting at local column tc
-static int upload_cols(cmf_handle_s *h, const double *src, int64_t tc, int64_t ncols, bool rows_layout, bool accumulate_sumsq)
+static int upload_cols(cmf_handle_s *h, const double *src, int64_t tc, int64_t ncols, bool rows_layout, bool accumulate_sumsq,
+                       float *rows_dst = nullptr, float *cols_dst = nullptr)
 {
+    if (!rows_dst) rows_dst = h->X;
+    if (!cols_dst) cols_dst = h->XT;
     const CmfDims &d = h->d;
     const int64_t chunk = std::max<int64_t>(32, (int64_t)(32u << 20) / std::max<int64_t>(1, d.N) / 8 / 32 * 32); // ~32 MiB
     CMFTRY(ensure_stage(h, (size_t)std::min(chunk, rup(ncols, 32)) * d.N + 1024));
@@ -221,7 +225,7 @@ static int upload_cols(cmf_handle_s *h, const double *src, int64_t tc, int64_t n
         HIPCHK(hipMemcpyAsync(h->stage, src + (size_t)c0 * d.N, (size_t)nc * d.N * sizeof(double), hipMemcpyHostToDevice, h->stream));
         dim3 grid((d.N + 31) / 32, (unsigned)((nc + 31) / 32)), block(32, 8);
         hipLaunchKernelGGL(pack_cols_kernel, grid, block, 0, h->stream, h->stage, d.N, (int)(tc + c0), (int)nc,
-                           rows_layout ? h->X : nullptr, h->XT, d.Np, d.TP, d.PADL);
+                           rows_layout ? rows_dst : nullptr, cols_dst, d.Np, d.TP, d.PADL);
         KCHK("pack_cols_kernel");
         if (accumulate_sumsq) {
             double *acc = h->stage + (size_t)nc * d.N; // 256 spare doubles
@@ -334,6 +338,7 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     const CmfDims &d = h->d;
     ConvParams p;
     p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = data ? data : h->X; p.partial = h->partial;
+    p.mask = (MODE == 7) ? h->MT : h->M;
     p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = T_store;
     dim3 grid(h->conv_gx, gy), block(256);
     if (d.K % 32 == 0) hipLaunchKernelGGL((conv2_kernel<MODE>), grid, block, 0, h->stream, p);
@@ -679,6 +684,26 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
     return CMF_OK;
 }
 
+int cmf_set_mask(cmf_handle h, const double *mask)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->sharded) return fail(CMF_ERR_UNSUPPORTED, "MaskedLoss is supported on single-GPU handles only");
+    const CmfDims &d = h->d;
+    h->est_kind = 0;
+    if (!mask) { // back to the plain SquareLoss
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->M) (void)hipFree(h->M);
+        if (h->MT) (void)hipFree(h->MT);
+        h->M = h->MT = nullptr;
+        return CMF_OK;
+    }
+    const size_t TPNp = (size_t)d.TP * d.Np;
+    if (!h->M) CMFTRY(dalloc_zero(&h->M, TPNp));
+    if (!h->MT) CMFTRY(dalloc_zero(&h->MT, TPNp));
+    return upload_cols(h, mask, 0, d.Tl, true, false, h->M, h->MT);
+}
+
 int cmf_pgd_reset(cmf_handle h)
 {
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
@@ -814,19 +839,20 @@ int cmf_halo_unpack(cmf_handle h, int has_left, int has_right)
 }
 
 // est := tensor_conv(W,H) - data (the residual hals.jl / pgd.jl carry), with the loss sum in d_scalar[0]
-static int resid_and_loss(cmf_handle_s *h, double *sumsq)
+static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked)
 {
     const CmfDims &d = h->d;
-    CMFTRY(launch_conv<4>(h, h->est, d.Tl, h->conv_gy));
+    if (masked) CMFTRY(launch_conv<6>(h, h->est, d.Tl, h->conv_gy)); // pgd.jl:64-70
+    else CMFTRY(launch_conv<4>(h, h->est, d.Tl, h->conv_gy));
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_gx * h->conv_gy, h->d_scalar);
     KCHK("loss_reduce_kernel");
-    h->est_kind = 2;
+    h->est_kind = masked ? 3 : 2;
     return sumsq ? read_scalar(h, 0, sumsq) : CMF_OK;
 }
 
-static int ensure_resid(cmf_handle_s *h)
+static int ensure_resid(cmf_handle_s *h, bool masked = false)
 {
-    return h->est_kind == 2 ? CMF_OK : resid_and_loss(h, nullptr);
+    return h->est_kind == (masked ? 3 : 2) ? CMF_OK : resid_and_loss(h, nullptr, masked);
 }
 
 // ---- HALS (src/algs/hals.jl) -------------------------------------------------------------------
@@ -1029,7 +1055,7 @@ static int pgd_check(cmf_handle_s *h)
 static int pgd_finish(cmf_handle_s *h, double *step)
 {
     double loss = 0.0;
-    CMFTRY(resid_and_loss(h, &loss));
+    CMFTRY(resid_and_loss(h, &loss, h->M != nullptr));
     *step *= (loss < h->pgd_cur_loss) ? 1.05 : 0.70;
     h->pgd_cur_loss = loss;
     return CMF_OK;
@@ -1040,7 +1066,7 @@ static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
     const CmfDims &d = h->d;
     CMFTRY(pgd_check(h));
     const size_t LKN = (size_t)d.L * d.K32 * d.Np;
-    CMFTRY(ensure_resid(h));                                                                             // pgd.jl:230
+    CMFTRY(ensure_resid(h, h->M != nullptr));                                                            // pgd.jl:230 (:64-67 with a mask)
     CMFTRY(launch_hxt_on(h, h->est, h->est, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1)); // pgd.jl:206-214
     CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks1, LKN));
     dim3 grid(d.Np / 64, d.KB, d.L);
@@ -1063,7 +1089,8 @@ static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
     const CmfDims &d = h->d;
     CMFTRY(pgd_check(h));
     if (!h->pgd_gradH) CMFTRY(dalloc_zero(&h->pgd_gradH, (size_t)d.Tl * d.K32));
-    CMFTRY(launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT)); // resid^T (pgd.jl:230)
+    if (h->MT) CMFTRY(launch_conv<7>(h, h->estT, d.Tl, h->conv_gy, h->XT)); // (mask .* resid)^T (pgd.jl:64-67)
+    else CMFTRY(launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT));       // resid^T (pgd.jl:230)
     CMFTRY(launch_transconv(h, 1, h->estT));                     // pgd.jl:218-221
     dim3 grid((d.Tl + 63) / 64, d.KB);
     const int nblk = ((d.Tl + 63) / 64) * d.KB;

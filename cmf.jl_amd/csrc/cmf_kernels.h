@@ -62,17 +62,21 @@ __device__ __forceinline__ float cmf_bload(__amdgpu_buffer_rsrc_t r, int voff_by
 //   MODE 3: MODE 0 + MODE 2
 //   MODE 4: store est - data (the residual of hals.jl / pgd.jl) in the [t][n] layout + the loss sum
 //   MODE 5: store (est - data)^T in the [n][t] layout (p.data = dataT)
+//   MODE 6: MODE 4 with the residual multiplied by p.mask [t][n]  (MaskedLoss, pgd.jl:58-70)
+//   MODE 7: MODE 5 with the residual multiplied by p.mask = maskT [n][t]
 // ---------------------------------------------------------------------------------------------
 struct ConvParams {
     const float *Ht;
     const float *Wt;
     float *out;
-    const float *data; // X [TP][Np] (modes 2, 3)
+    const float *data; // X [TP][Np] (modes 2, 3, 4, 6) or XT [Np][TP] (modes 5, 7)
+    const float *mask; // same layout as data (modes 6, 7)
     double *partial;   // [gridDim.x * gridDim.y]
     int Np, TP, PADL, K, KB, L;
     int T_store; // rows t < T_store are stored / counted
 };
 
+#define CONV_TRANSPOSED(MODE) ((MODE) == 1 || (MODE) == 5 || (MODE) == 7)
 #define CONV_HS_STRIDE 160
 #define CONV_HS_FLOATS (32 * CONV_HS_STRIDE)
 #define CONV_WS_FLOATS (32 * 128)
@@ -85,7 +89,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
     // Tiles that lie entirely below T_store (all but the last row of tiles) take a branch-free path:
     // per-element exec-mask branches serialise the epilogue (one L2 round trip per data load).
     const bool full = (t0 + 128 <= p.T_store); // workgroup-uniform
-    if (MODE == 0 || MODE == 3 || MODE == 2 || MODE == 4) {
+    constexpr bool LOSS = (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6);
+    constexpr bool RESID = (MODE == 4 || MODE == 6);
+    constexpr bool MASKED = (MODE == 6 || MODE == 7);
+    if (!CONV_TRANSPOSED(MODE)) {
         // acc[ti][ni][r]: t = t0 + wt*64 + ti*32 + crow(r,h), n = n0 + wn*64 + ni*32 + i
         float lsum = 0.f;
 #pragma unroll
@@ -93,33 +100,35 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const size_t o0 = (size_t)(p.PADL + t0 + wt * 64 + ti * 32 + 4 * h) * Np + n0 + wn * 64 + ni * 32 + i;
-                float dv[16];
-                if (MODE == 2 || MODE == 3 || MODE == 4) {
-                    // the rows of a partial tile beyond T_store are padding rows of X: in bounds
+                float dv[16], mv[16];
+                // the rows of a partial tile beyond T_store are padding rows of X: in bounds
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dv[r] = p.data[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np];
-                }
+                for (int r = 0; r < 16; ++r) dv[r] = LOSS ? p.data[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mv[r] = MASKED ? p.mask[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] : 1.f;
                 if (full) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[ti][ni][r];
+                        const float d = MASKED ? (v - dv[r]) * mv[r] : v - dv[r];
                         if (MODE == 0 || MODE == 3) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = v;
-                        if (MODE == 4) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = v - dv[r];
-                        if (MODE == 2 || MODE == 3 || MODE == 4) { const float d = v - dv[r]; lsum = fmaf(d, d, lsum); }
+                        if (RESID) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = d;
+                        if (LOSS) lsum = fmaf(d, d, lsum);
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int t = t0 + wt * 64 + ti * 32 + cmf_crow(r, h);
                         const float v = acc[ti][ni][r];
-                        if (MODE == 0 || MODE == 3 || MODE == 4) {
-                            if (t < p.T_store) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = (MODE == 4) ? v - dv[r] : v;
+                        const float d0 = MASKED ? (v - dv[r]) * mv[r] : v - dv[r];
+                        if (MODE == 0 || MODE == 3 || RESID) {
+                            if (t < p.T_store) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = RESID ? d0 : v;
                         }
-                        if (MODE == 2 || MODE == 3 || MODE == 4) { const float d = (t < p.T_store) ? v - dv[r] : 0.f; lsum = fmaf(d, d, lsum); }
+                        if (LOSS) { const float d = (t < p.T_store) ? d0 : 0.f; lsum = fmaf(d, d, lsum); }
                     }
                 }
             }
-        if (MODE == 2 || MODE == 3 || MODE == 4) {
+        if (LOSS) {
             double ds = (double)lsum;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) ds += __shfl_down(ds, off, 64);
@@ -129,8 +138,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
             if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
         }
     } else {
-        // MODE 1 / 5: acc[ni][ti][r]: n = n0 + wn*64 + ni*32 + crow(r,h), t = t0 + wt*64 + ti*32 + i
-        // (MODE 5 stores est - data in the transposed layout; p.data is then dataT [Np][TP])
+        // MODE 1 / 5 / 7: acc[ni][ti][r]: n = n0 + wn*64 + ni*32 + crow(r,h), t = t0 + wt*64 + ti*32 + i
+        // (MODE 5 / 7 store est - data in the transposed layout; p.data is then dataT [Np][TP])
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -138,11 +147,14 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
                 const int t = t0 + wt * 64 + ti * 32 + i;
                 const size_t o0 = (size_t)(n0 + wn * 64 + ni * 32 + 4 * h) * TP + p.PADL + t;
                 if (full || t < p.T_store) {
-                    float dv[16];
+                    float dv[16], mv[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dv[r] = (MODE == 5) ? p.data[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] : 0.f;
+                    for (int r = 0; r < 16; ++r) dv[r] = (MODE != 1) ? p.data[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] = acc[ni][ti][r] - dv[r];
+                    for (int r = 0; r < 16; ++r) mv[r] = MASKED ? p.mask[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] : 1.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] = MASKED ? (acc[ni][ti][r] - dv[r]) * mv[r] : acc[ni][ti][r] - dv[r];
                 }
             }
     }
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p)
                 const float *hsb = Hs + h * CONV_HS_STRIDE + 32 + wt * 64 + i - (l - lbeg);
                 const float *wsb = Ws + buf * CONV_WS_FLOATS + h * 128 + wn * 64 + i;
 #define CONV_MFMA4(A0, A1, B0, B1)                                                                  \
-    if (MODE == 1 || MODE == 5) {                                                                   \
+    if (CONV_TRANSPOSED(MODE)) {                                                                   \
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(B0, A0, acc[0][0], 0, 0, 0);               \
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(B0, A1, acc[0][1], 0, 0, 0);               \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(B1, A0, acc[1][0], 0, 0, 0);               \
@@ -301,7 +313,7 @@ __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb,
             na1 = hsb[(kp + 1) * 2 * CONV_HS_STRIDE + 32];
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        if (MODE == 1 || MODE == 5) {
+        if (CONV_TRANSPOSED(MODE)) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a0, acc[1][0], 0, 0, 0);

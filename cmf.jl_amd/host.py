@@ -268,6 +268,17 @@ class SquareLoss:
     """D(b, est) = ||b - est||^2 (src/algs/pgd.jl:29-36)."""
 
 
+class MaskedLoss:
+    """MaskedLoss(loss, mask): gradient and loss of `loss` restricted by an N x T mask (src/algs/pgd.jl:58-70;
+    the loss_func of the reference's test/test.jl:45).  The GPU rule supports MaskedLoss(SquareLoss(), mask)."""
+
+    def __init__(self, loss, mask):
+        if not isinstance(loss, SquareLoss):
+            raise NotImplementedError("MaskedLoss on the GPU wraps SquareLoss")
+        self.loss = loss
+        self.mask = farr(mask)
+
+
 class SquarePenalty:
     """R(x) = weight * ||x||_2^2 (src/algs/pgd.jl:73-80)."""
 
@@ -312,20 +323,37 @@ class PGDUpdate(MultUpdate):
     def __init__(self, data, W, H, device=None):
         super().__init__(data, W, H, device=device)
         check(self._lib.cmf_pgd_reset(self._h))
+        self._mask_key = None
+
+    def _select_loss(self, loss_func):
+        """loss_func=SquareLoss() (default) or MaskedLoss(SquareLoss(), mask): uploads the mask when it changes."""
+        if loss_func is None or isinstance(loss_func, SquareLoss) or loss_func is SquareLoss:
+            key = None
+        elif isinstance(loss_func, MaskedLoss):
+            key = id(loss_func)
+        else:
+            raise NotImplementedError("PGDUpdate on the GPU supports SquareLoss and MaskedLoss(SquareLoss(), mask)")
+        if key == self._mask_key:
+            return
+        if key is None:
+            check(self._lib.cmf_set_mask(self._h, None))
+        else:
+            if loss_func.mask.shape != (self.N, self.T):
+                raise ValueError(f"mask must be {self.N} x {self.T} like data, got {loss_func.mask.shape}")
+            check(self._lib.cmf_set_mask(self._h, ptr(loss_func.mask)))
+        self._mask_key = key
 
     def update_motifs(self, data=None, W=None, H=None, loss_func=None, constrW=NonnegConstraint, penaltiesW=None, **kwargs):
         """update_motifs!(rule::PGDUpdate, ...; loss_func=SquareLoss(), constrW=NonnegConstraint(),
         penaltiesW=[SquarePenalty(1)]): src/algs/pgd.jl:158-177."""
-        if loss_func is not None and not isinstance(loss_func, SquareLoss):
-            raise NotImplementedError("PGDUpdate on the GPU supports SquareLoss")
+        self._select_loss(loss_func)
         sq, ab = _penalty_weights([SquarePenalty(1)] if penaltiesW is None else penaltiesW)
         check(self._lib.cmf_pgd_update_motifs(self._h, sq, ab, _nonneg_flag(constrW)))
 
     def update_feature_maps(self, data=None, W=None, H=None, loss_func=None, constrH=NonnegConstraint, penaltiesH=None, **kwargs):
         """update_feature_maps!(rule::PGDUpdate, ...; constrH=NonnegConstraint(), penaltiesH=[]) -> loss:
         src/algs/pgd.jl:180-202."""
-        if loss_func is not None and not isinstance(loss_func, SquareLoss):
-            raise NotImplementedError("PGDUpdate on the GPU supports SquareLoss")
+        self._select_loss(loss_func)
         sq, ab = _penalty_weights([] if penaltiesH is None else penaltiesH)
         loss = ctypes.c_double()
         check(self._lib.cmf_pgd_update_feature_maps(self._h, sq, ab, _nonneg_flag(constrH), ctypes.byref(loss)))

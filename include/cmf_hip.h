@@ -140,6 +140,10 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
  * The rule's state (stepW = stepH = 5, cur_loss = norm(data), step_incr 1.05, step_decr 0.70; pgd.jl:139-154)
  * lives in the handle and is (re)initialised by cmf_create and cmf_pgd_reset.  Unsharded handles only. */
 int cmf_pgd_reset(cmf_handle h);
+/* MaskedLoss(SquareLoss(), mask)  src/algs/pgd.jl:58-70 (the loss_func of the reference's own test/test.jl:45):
+ * gradient 2*(est - data) .* mask, loss norm(mask.*data - mask.*est)^2.  `mask` is N x T column-major like data
+ * (borrowed for the call); NULL restores the plain SquareLoss.  Only the PGD entries read the mask. */
+int cmf_set_mask(cmf_handle h, const double *mask);
 int cmf_pgd_update_motifs(cmf_handle h, double pen_sq, double pen_abs, int nonneg);
 int cmf_pgd_update_feature_maps(cmf_handle h, double pen_sq, double pen_abs, int nonneg, double *loss);
 int cmf_pgd_get_steps(cmf_handle h, double *stepW, double *stepH);

@@ -226,8 +226,8 @@ def fit_hals(data, W_init, H_init, max_itr=100, max_time=np.inf, check_convergen
 
 # --------------------------------------------------------------------------
 # PGD rule: src/algs/pgd.jl.  numpy restatement only.
-# Supported pieces: SquareLoss (:30-36), SquarePenalty / AbsolutePenalty (:74-89),
-# NonnegConstraint (:92-96) or no constraint.
+# Supported pieces: SquareLoss (:30-36), MaskedLoss(SquareLoss(), mask) (:58-70; `mask=` below),
+# SquarePenalty / AbsolutePenalty (:74-89), NonnegConstraint (:92-96) or no constraint.
 # --------------------------------------------------------------------------
 class PGDUpdate:
     """PGDUpdate state + ctor: src/algs/pgd.jl:112-155."""
@@ -244,10 +244,12 @@ class PGDUpdate:
         self.step_decr = 0.70
 
 
-def _pgd(rule, x, gradx, compute_grad, step, data, W, H, pen_sq, pen_abs, nonneg):
+def _pgd(rule, x, gradx, compute_grad, step, data, W, H, pen_sq, pen_abs, nonneg, mask=None):
     """pgd!: src/algs/pgd.jl:224-255 (x is W or H, updated in place)."""
     T = H.shape[1]
     rule.est[...] = 2.0 * (rule.est - data)  # :230  grad!(SquareLoss): 2*(est - data), in place in r.est
+    if mask is not None:
+        rule.est *= mask  # :64-67  grad!(MaskedLoss): grad .*= mask
     compute_grad(gradx, rule.est)  # :231
     for w in pen_sq:
         gradx += 2.0 * w * x  # :78-80
@@ -258,13 +260,16 @@ def _pgd(rule, x, gradx, compute_grad, step, data, W, H, pen_sq, pen_abs, nonneg
     if nonneg:
         np.maximum(x, EPS, out=x)  # :94-96 max(eps(), x)
     tensor_conv(W, H, out=rule.est)  # :245
-    loss = np.linalg.norm(data - rule.est) ** 2  # :246, :34-36
+    if mask is None:
+        loss = np.linalg.norm(data - rule.est) ** 2  # :246, :34-36
+    else:
+        loss = np.linalg.norm(mask * data - mask * rule.est) ** 2  # :68-70 eval(MaskedLoss)
     step = step * (rule.step_incr if loss < rule.cur_loss else rule.step_decr)  # :248-252
     rule.cur_loss = loss  # :253
     return step
 
 
-def pgd_update_motifs(rule, data, W, H, penaltiesW_sq=(1.0,), penaltiesW_abs=(), nonneg=True):
+def pgd_update_motifs(rule, data, W, H, penaltiesW_sq=(1.0,), penaltiesW_abs=(), nonneg=True, mask=None):
     """update_motifs!(::PGDUpdate): pgd.jl:158-177 (defaults: SquarePenalty(1), NonnegConstraint)."""
     K, N, L = W.shape
     T = H.shape[1]
@@ -273,16 +278,16 @@ def pgd_update_motifs(rule, data, W, H, penaltiesW_sq=(1.0,), penaltiesW_abs=(),
         for lag in range(L):
             gradw[:, :, lag] = (H[:, : T - lag] @ est[:, lag:].T) if lag < T else 0.0
 
-    rule.stepW = _pgd(rule, W, rule.gradW, grad, rule.stepW, data, W, H, penaltiesW_sq, penaltiesW_abs, nonneg)
+    rule.stepW = _pgd(rule, W, rule.gradW, grad, rule.stepW, data, W, H, penaltiesW_sq, penaltiesW_abs, nonneg, mask)
 
 
-def pgd_update_feature_maps(rule, data, W, H, penaltiesH_sq=(), penaltiesH_abs=(), nonneg=True):
+def pgd_update_feature_maps(rule, data, W, H, penaltiesH_sq=(), penaltiesH_abs=(), nonneg=True, mask=None):
     """update_feature_maps!(::PGDUpdate): pgd.jl:180-202 -> sqrt(cur_loss / datanorm^2)."""
 
     def grad(gradh, est):  # compute_gradH!: :218-221
         tensor_transconv(W, est, out=gradh)
 
-    rule.stepH = _pgd(rule, H, rule.gradH, grad, rule.stepH, data, W, H, penaltiesH_sq, penaltiesH_abs, nonneg)
+    rule.stepH = _pgd(rule, H, rule.gradH, grad, rule.stepH, data, W, H, penaltiesH_sq, penaltiesH_abs, nonneg, mask)
     return np.sqrt(rule.cur_loss / rule.datanorm ** 2)
 
 
@@ -295,10 +300,11 @@ def fit_pgd(data, W_init, H_init, max_itr=100, check_convergence=False, patience
     kW = {k: v for k, v in kw.items() if k.startswith("penaltiesW")}
     kH = {k: v for k, v in kw.items() if k.startswith("penaltiesH")}
     nonneg = kw.get("nonneg", True)
+    mask = kw.get("mask", None)
     for _ in range(max_itr):
         if not eval_mode:
-            pgd_update_motifs(rule, data, W, H, nonneg=nonneg, **kW)
-        loss_hist.append(pgd_update_feature_maps(rule, data, W, H, nonneg=nonneg, **kH))
+            pgd_update_motifs(rule, data, W, H, nonneg=nonneg, mask=mask, **kW)
+        loss_hist.append(pgd_update_feature_maps(rule, data, W, H, nonneg=nonneg, mask=mask, **kH))
         if check_convergence and converged(loss_hist, patience, tol):
             break
     return W, H, np.asarray(loss_hist), (rule.stepW, rule.stepH)

@@ -421,6 +421,49 @@ def test_pgd_penalties_and_unconstrained(cmf, oracle):
     assert frob_rel(Wg, W) < REL_FACTORS and frob_rel(Hg, H) < REL_FACTORS
     np.testing.assert_allclose(sg, (orule.stepW, orule.stepH), rtol=1e-12)  # same accept/reject decisions
 
+def test_pgd_masked_loss_reference_test_case(cmf, oracle):
+    """The one runnable entry of the reference's own test/test.jl (:15-21, :41-47): N, T, K, L = 100, 100, 10, 5,
+    data from synthetic_sequences(N, T, K, L) with seed 1234, init_rand, PGDUpdate with
+    loss_func=MaskedLoss(SquareLoss(), mask), mask[1:20, :] = 1 -- run for a fixed iteration count
+    instead of max_time=5 so that both sides do the same work."""
+    N, T, K, L = 100, 100, 10, 5
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=K, L=L, seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    mask = np.zeros(data.shape)
+    mask[:20, :] = 1
+    iters = 25
+    res = cmf.fit_cnmf(data, L=L, K=K, alg=cmf.PGDUpdate, max_itr=iters, check_convergence=False, W_init=W0, H_init=H0,
+                       loss_func=cmf.MaskedLoss(cmf.SquareLoss(), mask))
+    Wr, Hr, lr, _ = oracle.fit_pgd(data, W0, H0, max_itr=iters, mask=mask)
+    assert len(res.loss_hist) == iters + 1
+    np.testing.assert_allclose(res.loss_hist, lr, rtol=REL_LOSS)
+    assert frob_rel(res.W, Wr) < REL_FACTORS and frob_rel(res.H, Hr) < REL_FACTORS
+    # the masked-out rows never enter a gradient: their motifs only shrink under SquarePenalty(1) (pgd.jl:162)
+    assert np.all(res.W[:, 20:, :] <= W0[:, 20:, :] + 1e-12)
+
+
+@pytest.mark.parametrize("N,T,K,L", [(130, 700, 32, 20), (37, 150, 33, 7)])
+def test_pgd_masked_loss_general_mask(cmf, oracle, N, T, K, L):
+    """A real-valued random mask (K % 32 == 0 and the general-K kernel), switching the mask off again in the same rule."""
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=7)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=2)
+    mask = np.random.default_rng(3).uniform(0, 1, size=data.shape) * (np.random.default_rng(4).uniform(size=data.shape) > 0.3)
+    lf = cmf.MaskedLoss(cmf.SquareLoss(), mask)
+    rule = cmf.PGDUpdate(data, W0, H0)
+    W, H = W0.copy(), H0.copy()
+    orule = oracle.PGDUpdate(data, W, H)
+    lg, lo = [], []
+    for it in range(6):
+        m = mask if it < 4 else None  # iterations 5 and 6 run with the plain SquareLoss again
+        rule.update_motifs(loss_func=lf if it < 4 else cmf.SquareLoss())
+        lg.append(rule.update_feature_maps(loss_func=lf if it < 4 else cmf.SquareLoss()))
+        oracle.pgd_update_motifs(orule, data, W, H, mask=m)
+        lo.append(oracle.pgd_update_feature_maps(orule, data, W, H, mask=m))
+    Wg, Hg = rule.download()
+    rule.close()
+    np.testing.assert_allclose(lg, lo, rtol=REL_LOSS)
+    assert frob_rel(Wg, W) < REL_FACTORS and frob_rel(Hg, H) < REL_FACTORS
+
 
 def test_config1_full_fit(cmf, oracle):
     """BASELINE.json configs[0]: gen_synthetic N=500 T=2000, fit_cnmf alg=:mult K=5 L=10, the reference's own

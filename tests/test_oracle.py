@@ -233,3 +233,48 @@ def test_hals_gram_form_equals_residual_form(oracle):
         Hn = H.copy()
         oracle.hals_update_feature_maps(rule, data, W, Hn, l1H=l1, l2H=l2)
         np.testing.assert_allclose(h_sweep(oracle, W, H0, data, l1, l2), Hn, rtol=1e-10, atol=1e-13)
+
+
+def test_pgd_masked_loss_gradient_and_reduction(oracle):
+    """MaskedLoss(SquareLoss(), mask) in the PGD restatement (pgd.jl:58-70): with an all-ones mask it is the plain
+    SquareLoss; the direction pgd! takes is the gradient of eval(MaskedLoss) (finite differences)."""
+    rng = np.random.default_rng(0)
+    N, T, K, L = 7, 40, 3, 4
+    W = rng.uniform(0.1, 1, (K, N, L))
+    H = rng.uniform(0.1, 1, (K, T))
+    data = rng.uniform(0, 2, (N, T))
+    a = oracle.fit_pgd(data, W, H, max_itr=5)
+    b = oracle.fit_pgd(data, W, H, max_itr=5, mask=np.ones((N, T)))
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-13)
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-13)
+    mask = (rng.uniform(size=(N, T)) > 0.4) * rng.uniform(0.5, 1.5, (N, T))
+
+    def J(Wx, Hx):
+        return np.linalg.norm(mask * data - mask * oracle.tensor_conv(Wx, Hx)) ** 2
+
+    # one unpenalised, unconstrained step with a tiny step size moves along -grad J / ||grad J||
+    W1, H1 = W.copy(), H.copy()
+    rule = oracle.PGDUpdate(data, W1, H1)
+    rule.stepW = 1e-6
+    oracle.pgd_update_motifs(rule, data, W1, H1, penaltiesW_sq=(), nonneg=False, mask=mask)
+    e = 1e-6
+    # the reference's mask enters the gradient once (grad .*= mask) but the loss twice (mask.^2): equal for 0/1
+    # masks; for a real-valued mask the step follows sum(mask * 2 * (est - data) ...), so check with mask in {0,1}
+    mask01 = (mask > 0).astype(float)
+
+    def J01(Wx):
+        return np.linalg.norm(mask01 * data - mask01 * oracle.tensor_conv(Wx, H)) ** 2
+
+    g01 = np.zeros_like(W)
+    for idx in np.ndindex(*W.shape):
+        Wp = W.copy(); Wp[idx] += e
+        Wm = W.copy(); Wm[idx] -= e
+        g01[idx] = (J01(Wp) - J01(Wm)) / (2 * e)
+    W2, H2 = W.copy(), H.copy()
+    rule2 = oracle.PGDUpdate(data, W2, H2)
+    rule2.stepW = 1e-6
+    oracle.pgd_update_motifs(rule2, data, W2, H2, penaltiesW_sq=(), nonneg=False, mask=mask01)
+    step = W2 - W
+    np.testing.assert_allclose(step, -1e-6 * g01 / np.linalg.norm(g01), rtol=1e-5, atol=1e-13)
+    assert rule2.cur_loss == pytest.approx(J01(W2), rel=1e-12)
+    assert rule.cur_loss == pytest.approx(J(W1, H1), rel=1e-12)
