@@ -101,6 +101,69 @@ function update_feature_maps!(rule::HIPHALSUpdate, data, W, H; l1H=0, l2H=0, kwa
     return loss[]
 end
 
+"""
+    HIPPGDUpdate(data, W, H; device=0)
+
+Drop-in for `PGDUpdate(data, W, H)` (src/algs/pgd.jl:112-155) with `SquareLoss()` or
+`MaskedLoss(SquareLoss(), mask)`, `SquarePenalty` / `AbsolutePenalty` lists and `NonnegConstraint()` / `nothing`.
+The step-size state (stepW, stepH, cur_loss) lives in the library handle.
+"""
+mutable struct HIPPGDUpdate <: AbstractCFUpdate
+    inner::HIPMultUpdate
+    mask_id::UInt            # objectid of the mask currently resident on the device (0 = none)
+end
+function HIPPGDUpdate(data, W, H; kwargs...)
+    rule = HIPPGDUpdate(HIPMultUpdate(data, W, H; kwargs...), UInt(0))
+    check(ccall((:cmf_pgd_reset, LIBCMF), Cint, (Ptr{Cvoid},), rule.inner.handle))
+    return rule
+end
+
+import ..CMF: SquareLoss, MaskedLoss, SquarePenalty, AbsolutePenalty, NonnegConstraint
+
+penalty_weights(pens) = (sum(Float64[p.weight for p in pens if p isa SquarePenalty]),
+                         sum(Float64[p.weight for p in pens if p isa AbsolutePenalty]))
+nonneg_flag(c) = c === nothing ? Cint(0) : (c isa NonnegConstraint ? Cint(1) : error("unsupported constraint"))
+
+function select_loss!(rule::HIPPGDUpdate, loss_func)
+    if loss_func isa SquareLoss
+        rule.mask_id == 0 || check(ccall((:cmf_set_mask, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}), rule.inner.handle, C_NULL))
+        rule.mask_id = UInt(0)
+    elseif loss_func isa MaskedLoss && loss_func.loss isa SquareLoss      # pgd.jl:58-70
+        id = objectid(loss_func.mask)
+        if id != rule.mask_id
+            m = Matrix{Float64}(loss_func.mask)
+            check(ccall((:cmf_set_mask, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}), rule.inner.handle, m))
+            rule.mask_id = id
+        end
+    else
+        error("HIPPGDUpdate supports SquareLoss() and MaskedLoss(SquareLoss(), mask)")
+    end
+end
+
+# update_motifs!(rule::PGDUpdate, ...; loss_func, constrW, penaltiesW)  -- src/algs/pgd.jl:158-177
+function update_motifs!(rule::HIPPGDUpdate, data, W, H; loss_func=SquareLoss(), constrW=NonnegConstraint(),
+                        penaltiesW=[SquarePenalty(1)], kwargs...)
+    select_loss!(rule, loss_func)
+    sq, ab = penalty_weights(penaltiesW)
+    check(ccall((:cmf_pgd_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Cint),
+                rule.inner.handle, sq, ab, nonneg_flag(constrW)))
+    return W
+end
+
+# update_feature_maps!(rule::PGDUpdate, ...; loss_func, constrH, penaltiesH) -> loss  -- src/algs/pgd.jl:180-202
+function update_feature_maps!(rule::HIPPGDUpdate, data, W, H; loss_func=SquareLoss(), constrH=NonnegConstraint(),
+                              penaltiesH=[], kwargs...)
+    select_loss!(rule, loss_func)
+    sq, ab = penalty_weights(penaltiesH)
+    loss = Ref{Float64}(0.0)
+    check(ccall((:cmf_pgd_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Cint, Ref{Float64}),
+                rule.inner.handle, sq, ab, nonneg_flag(constrH), loss))
+    if rule.inner.sync_every_call
+        check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.inner.handle, W, H))
+    end
+    return loss[]
+end
+
 "Write the device-resident factors into W and H (needed only with `sync_every_call=false`)."
 function download!(rule::HIPMultUpdate, W::Tensor{Float64}, H::Matrix{Float64})
     check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.handle, W, H))
