@@ -445,7 +445,7 @@ static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
     const CmfDims &d = h->d;
     CMFTRY(launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext)); // mult.jl:44 (est with the new W)
     CMFTRY(launch_transconv(h, 2));                                         // mult.jl:47-48
-    dim3 grid((d.Tl + 63) / 64, d.KB);
+    dim3 grid((d.Tl + HUPD_T - 1) / HUPD_T, d.KB);
     hipLaunchKernelGGL(h_update_kernel, grid, dim3(256), 0, h->stream, h->H, h->Ht, h->hslabs, h->tc_S,
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
     KCHK("h_update_kernel");
@@ -1014,7 +1014,7 @@ static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss)
     // denomH = tensor_transconv(W, tensor_conv(W, H)) (mult.jl:44,48) through the lag-Gram taps of W
     CMFTRY(gram_tables(h));
     CMFTRY(gram_denom_h(h, h->gram_numden_h + TK));
-    hipLaunchKernelGGL(h_update_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->H, h->Ht, h->gram_numden_h, 1,
+    hipLaunchKernelGGL(h_update_kernel, dim3((d.Tl + HUPD_T - 1) / HUPD_T, d.KB), dim3(256), 0, h->stream, h->H, h->Ht, h->gram_numden_h, 1,
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
     KCHK("h_update_kernel");
     h->est_kind = 0;

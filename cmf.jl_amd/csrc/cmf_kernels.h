@@ -704,45 +704,57 @@ __global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, con
     }
 }
 
-// grid: (ceil(Tl/64), KB), block 256.  slabs: [S][2][Tl][K32]
+// grid: (ceil(Tl/8), KB), block 256.  slabs: [S][2][Tl][K32]
+// A workgroup owns 8 columns x 32 components = 64 float4 elements; its four 64-thread groups each sum every
+// fourth slab (the slab count grows as the shard gets shorter: 36 at T = 6250), the groups are combined in a
+// fixed order through LDS, so the result does not depend on timing.
+#define HUPD_T 8
 __global__ __launch_bounds__(256) void h_update_kernel(float *H, float *Ht, const float *slabs, int S,
                                                         int Tl, int K, int K32, int PADL, int TP, float l1, float two_l2)
 {
-    __shared__ float tile[32][65];
+    __shared__ f32x4 red[3][64][2];
+    __shared__ float tile[32][HUPD_T + 1];
     const int tid = threadIdx.x;
-    const int t0 = blockIdx.x * 64, kb = blockIdx.y;
-    const size_t TK = (size_t)Tl * K32;
-    {
-        const int kk = tid & 31;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            int tt = q * 8 + (tid >> 5);
-            int t = t0 + tt, k = kb * 32 + kk;
-            float hn = 0.f;
-            if (t < Tl) {
-                size_t idx = (size_t)t * K32 + k;
-                float num = 0.f, den = 0.f;
-                for (int s = 0; s < S; ++s) {
-                    num += slabs[(size_t)(2 * s) * TK + idx];
-                    den += slabs[(size_t)(2 * s + 1) * TK + idx];
-                }
-                size_t hidx = (size_t)(PADL + t) * K32 + k;
-                float x = H[hidx];
-                hn = (k < K) ? cmf_mu(x, num, den, l1, two_l2) : 0.f;
-                H[hidx] = hn;
-            }
-            tile[kk][tt] = hn;
+    const int e = tid & 63, g = tid >> 6;
+    const int tt = e >> 3, k4 = e & 7;
+    const int t0 = blockIdx.x * HUPD_T, kb = blockIdx.y;
+    const int t = t0 + tt, k = kb * 32 + 4 * k4;
+    const size_t TK4 = (size_t)Tl * K32 / 4;
+    const f32x4 *sl = reinterpret_cast<const f32x4 *>(slabs);
+    f32x4 num = {0.f, 0.f, 0.f, 0.f}, den = {0.f, 0.f, 0.f, 0.f};
+    if (t < Tl) {
+        const size_t idx = ((size_t)t * K32 + k) / 4;
+        for (int s = g; s < S; s += 4) {
+            num += sl[(size_t)(2 * s) * TK4 + idx];
+            den += sl[(size_t)(2 * s + 1) * TK4 + idx];
         }
+    }
+    if (g > 0) {
+        red[g - 1][e][0] = num;
+        red[g - 1][e][1] = den;
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            num += red[q][e][0];
+            den += red[q][e][1];
+        }
+        f32x4 hn = {0.f, 0.f, 0.f, 0.f};
+        if (t < Tl) {
+            f32x4 *hp = reinterpret_cast<f32x4 *>(H + (size_t)(PADL + t) * K32 + k);
+            const f32x4 x = *hp;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hn[c] = (k + c < K) ? cmf_mu(x[c], num[c], den[c], l1, two_l2) : 0.f;
+            *hp = hn;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tile[4 * k4 + c][tt] = hn[c];
     }
     __syncthreads();
     {
-        const int tt = tid & 63;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            int kk = q * 4 + (tid >> 6);
-            int t = t0 + tt;
-            if (t < Tl) Ht[(size_t)(kb * 32 + kk) * TP + PADL + t] = tile[kk][tt];
-        }
+        const int kk = tid >> 3, t2 = t0 + (tid & 7);
+        if (t2 < Tl) Ht[(size_t)(kb * 32 + kk) * TP + PADL + t2] = tile[kk][tid & 7];
     }
 }
 

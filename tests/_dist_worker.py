@@ -1,7 +1,7 @@
 """Worker for the multi-process sharding tests (launched by tests/test_sharded.py).
 
 usage: python _dist_worker.py <engine: cpu|hip> <out.npz> <N> <T> <K> <L> <iters> <reg:0|1>
-Env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT (gloo rendezvous on 127.0.0.1).
+Env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT (rendezvous on 127.0.0.1); CMF_TEST_BACKEND=gloo|nccl.
 """
 import os
 import sys
@@ -18,7 +18,12 @@ def main():
     N, T, K, L, iters, reg = (int(x) for x in sys.argv[3:9])
     import torch.distributed as dist
 
-    dist.init_process_group("gloo")
+    backend = os.environ.get("CMF_TEST_BACKEND", "gloo")
+    if backend == "nccl":  # RCCL: one rank per GPU (the single-rank case is what a one-GPU box can run)
+        import torch
+
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     from oracle import cmf_oracle as oracle
     import cmf_jl_amd as cmf

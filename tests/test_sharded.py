@@ -25,12 +25,12 @@ def _free_port():
     return p
 
 
-def run_ranks(world, engine, out, N, T, K, L, iters, reg, timeout=300):
+def run_ranks(world, engine, out, N, T, K, L, iters, reg, timeout=300, backend="gloo"):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", CMF_TEST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), engine, out,
                                        str(N), str(T), str(K), str(L), str(iters), str(int(reg))],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -90,6 +90,21 @@ def test_sharded_hip_engine_gloo(oracle, tmp_path, world, N, T, K, L, reg):
     W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
     kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2) if reg else {}
     Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False, **kw)
+    np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
+    assert frob_rel(got["W"], Wr) < 1e-4
+    assert frob_rel(got["H"], Hr) < 1e-4
+
+
+@pytest.mark.gpu
+def test_sharded_hip_engine_rccl_single_rank(oracle, tmp_path):
+    """The RCCL transport itself (backend "nccl"): a one-GPU box can only form a 1-rank group, which still sends the
+    [numW | denomW] buffer and the loss scalar through RCCL's all-reduce on the library's stream."""
+    N, T, K, L, iters = 130, 900, 32, 20, 6
+    out = str(tmp_path / "res.npz")
+    got = run_ranks(1, "hip", out, N, T, K, L, iters, 0, backend="nccl")
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=L, seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False)
     np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
     assert frob_rel(got["W"], Wr) < 1e-4
     assert frob_rel(got["H"], Hr) < 1e-4
