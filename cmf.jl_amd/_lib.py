@@ -30,7 +30,7 @@ SYMBOLS = [
     "cmf_loss_partial_async", "cmf_scalar_ptr", "cmf_set_scalar_buffer",
     "cmf_numden_ptr", "cmf_set_numden_buffer", "cmf_halo_ptr", "cmf_set_halo_buffer", "cmf_halo_pack", "cmf_halo_unpack",
     "cmf_tensor_conv", "cmf_tensor_transconv", "cmf_init_rand", "cmf_gen_synthetic",
-    "cmf_time_kernel",
+    "cmf_time_kernel", "cmf_kernel_times",
 ]
 
 
@@ -102,6 +102,7 @@ def load():
     sig("cmf_tensor_transconv", [cint, i64, i64, i64, i64, pd, pd, pd])
     sig("cmf_init_rand", [cint, i64, i64, i64, i64, u64, pd, pd, pd])
     sig("cmf_gen_synthetic", [cint, i64, i64, i64, i64, dbl, dbl, dbl, dbl, u64, pd, pd, pd])
+    sig("cmf_kernel_times", [vp, ctypes.c_char_p, pd, pi64])
     sig("cmf_time_kernel", [vp, ctypes.c_char_p, cint, pd, pd])
     _lib = lib
     return lib

@@ -105,6 +105,11 @@ struct cmf_handle_s {
     bool reuse_est = true;  // option "reuse_est"
     int gram = 0;           // option "gram": 0 off, 1 Gram-form denominators, 2 also the loss from Gram sums
     float *gram_numden_h = nullptr; // [1][2][Tl][K32]: numH | denomH in the h_update slab layout
+    // in-loop kernel timing (option "profile"): HIP event pairs around the contraction launches, on the launch stream
+    bool prof = false;
+    struct ProfRec { hipEvent_t a, b; int cls; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
     int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data, 3 mask .* (tensor_conv(W,H) - data)
 };
 
@@ -205,6 +210,8 @@ static void destroy_impl(cmf_handle_s *h)
     if (h->d_scalar_own) (void)hipFree(h->d_scalar_own);
     if (h->h_scalar) (void)hipHostFree(h->h_scalar);
     if (h->stage) (void)hipFree(h->stage);
+    for (auto &r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -332,9 +339,32 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
 // ------------------------------------------------------------------------------------------
 // kernel launchers
 // ------------------------------------------------------------------------------------------
+// kernel classes of the "profile" option
+enum { PROF_CONV = 0, PROF_CONV_T, PROF_CONV_LOSS, PROF_CONV_LOSS_STORE, PROF_HXT, PROF_TRANSCONV, PROF_OTHER, PROF_NCLS };
+static const char *kProfNames[PROF_NCLS] = {"conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv", "other"};
+
+struct ProfScope {
+    cmf_handle_s *h;
+    hipEvent_t b = nullptr;
+    ProfScope(cmf_handle_s *h_, int cls) : h(h_)
+    {
+        if (!h->prof || h->prof_recs.size() >= 8192) return;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        for (int q = 0; q < 2; ++q) {
+            if (!h->prof_pool.empty()) { ev[q] = h->prof_pool.back(); h->prof_pool.pop_back(); }
+            else if (hipEventCreate(&ev[q]) != hipSuccess) { if (q == 1) h->prof_pool.push_back(ev[0]); return; }
+        }
+        (void)hipEventRecord(ev[0], h->stream);
+        h->prof_recs.push_back({ev[0], ev[1], cls});
+        b = ev[1];
+    }
+    ~ProfScope() { if (b) (void)hipEventRecord(b, h->stream); }
+};
+
 template <int MODE>
 static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const float *data = nullptr)
 {
+    ProfScope prof_(h, MODE == 0 ? PROF_CONV : MODE == 1 ? PROF_CONV_T : MODE == 2 ? PROF_CONV_LOSS : MODE == 3 ? PROF_CONV_LOSS_STORE : PROF_OTHER);
     const CmfDims &d = h->d;
     ConvParams p;
     p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = data ? data : h->X; p.partial = h->partial;
@@ -349,6 +379,7 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
 
 static int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int NpX, int nsrc, float *slabs, int nchunks, int chunk_len)
 {
+    ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : PROF_OTHER);
     const CmfDims &d = h->d;
     HxtParams p;
     p.H = h->H; p.X0 = X0; p.X1 = X1; p.slabs = slabs;
@@ -372,6 +403,7 @@ static int launch_hxt(cmf_handle_s *h)
 
 static int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullptr)
 {
+    ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_OTHER);
     const CmfDims &d = h->d;
     TcParams p;
     p.Wn = h->Wn; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.slabs = h->hslabs;
@@ -523,6 +555,14 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
     if (std::strcmp(name, "reuse_est") == 0) {
         h->reuse_est = value != 0;
         h->est_kind = 0;
+        return CMF_OK;
+    }
+    if (std::strcmp(name, "profile") == 0) { // (re)start or stop the in-loop kernel timing; collected times are dropped
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (auto &r : h->prof_recs) { h->prof_pool.push_back(r.a); h->prof_pool.push_back(r.b); }
+        h->prof_recs.clear();
+        h->prof = value != 0;
         return CMF_OK;
     }
     return fail(CMF_ERR_ARG, "unknown option '%s'", name);
@@ -1244,6 +1284,29 @@ int cmf_gen_synthetic(int device, int64_t N, int64_t T, int64_t K, int64_t L, do
 }
 
 // ---- measurement ---------------------------------------------------------------------------------
+int cmf_kernel_times(cmf_handle h, const char *name, double *avg_ms, int64_t *launches)
+{
+    if (!h || !name || !avg_ms || !launches) return fail(CMF_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    int cls = -1;
+    for (int c = 0; c < PROF_NCLS; ++c)
+        if (std::strcmp(name, kProfNames[c]) == 0) cls = c;
+    if (cls < 0) return fail(CMF_ERR_ARG, "unknown kernel class '%s'", name);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double total = 0.0;
+    int64_t n = 0;
+    for (auto &r : h->prof_recs) {
+        if (r.cls != cls) continue;
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        total += ms;
+        ++n;
+    }
+    *avg_ms = n ? total / (double)n : 0.0;
+    *launches = n;
+    return CMF_OK;
+}
+
 int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, double *flops)
 {
     if (!name || !avg_ms || !flops || reps < 1) return fail(CMF_ERR_ARG, "bad argument");

@@ -215,6 +215,12 @@ class MultUpdate(AbstractCFUpdate):
                                 ptr(lh), ptr(th), ctypes.byref(n), ctypes.byref(early)))
         return lh[: n.value].copy(), th[: n.value].copy(), bool(early.value)
 
+    def kernel_times(self, name):
+        """(mean ms, launches) recorded for one kernel class since set_option("profile", 1)."""
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        check(self._lib.cmf_kernel_times(self._h, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
     def time_kernel(self, name, reps=5):
         """(avg ms, algorithmic flops per launch) of one hot kernel, timed with HIP events."""
         ms, fl = ctypes.c_double(), ctypes.c_double()

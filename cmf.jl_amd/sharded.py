@@ -137,6 +137,14 @@ class HipShardEngine:
         check(self._lib.cmf_loss_partial_async(self._h))
         return self.scalar[:1]
 
+    def set_option(self, name, value):
+        check(self._lib.cmf_set_option(self._h, name.encode(), int(value)))
+
+    def kernel_times(self, name):
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        check(self._lib.cmf_kernel_times(self._h, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
     def time_kernel(self, name, reps=5):
         ms, fl = ctypes.c_double(), ctypes.c_double()
         check(self._lib.cmf_time_kernel(self._h, name.encode(), int(reps), ctypes.byref(ms), ctypes.byref(fl)))

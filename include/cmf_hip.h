@@ -217,6 +217,11 @@ int cmf_gen_synthetic(int device, int64_t N, int64_t T, int64_t K, int64_t L,
  * handle's stream and returns the average duration in milliseconds plus the
  * algorithmic flop count of one launch.  name: "conv", "hxt", "transconv". */
 int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, double *flops);
+/* In-loop timing: after cmf_set_option(h, "profile", 1) every contraction launch of the update / loss entries is
+ * bracketed by a HIP event pair on the launch stream; cmf_kernel_times synchronises and returns the mean duration
+ * and the number of launches recorded for one class: "conv" (mult.jl:28), "conv_t" (:44), "conv_loss" /
+ * "conv_loss_store" (:55-57), "hxt" (:31-34), "transconv" (:47-48).  Setting the option again restarts it. */
+int cmf_kernel_times(cmf_handle h, const char *name, double *avg_ms, int64_t *launches);
 
 #ifdef __cplusplus
 }

@@ -512,3 +512,28 @@ def test_gram_form_matches_oracle(cmf, oracle, N, T, K, L, gram):
     Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=10, check_convergence=False, **reg)
     np.testing.assert_allclose(lg, lr[1:], rtol=REL_LOSS if gram == 1 else 5e-4)
     assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
+
+
+def test_in_loop_kernel_timing(cmf, oracle):
+    """Option "profile": HIP event pairs around the contraction launches of the rule entries (bench.py's roofline
+    source).  Counts follow the iteration structure (est reuse: one conv_t, one conv_loss_store, one hxt and one
+    transconv per iteration, plus the first iteration's plain conv); results are unchanged."""
+    W0, H0, data = rand_problem(11, 130, 900, 32, 20)
+    ref = cmf.MultUpdate(data, W0, H0)
+    rule = cmf.MultUpdate(data, W0, H0)
+    rule.set_option("profile", 1)
+    for _ in range(3):
+        ref.update_motifs(); ref.update_feature_maps()
+        rule.update_motifs(); rule.update_feature_maps()
+    counts = {name: rule.kernel_times(name) for name in ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv")}
+    assert [counts[k][1] for k in ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv")] == [1, 3, 0, 3, 3, 3]
+    assert all(ms > 0 for ms, n in counts.values() if n)
+    rule.set_option("profile", 1)  # restart drops the records
+    assert rule.kernel_times("hxt") == (0.0, 0)
+    rule.set_option("profile", 0)
+    Wa, Ha = ref.download()
+    Wb, Hb = rule.download()
+    assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
+    with pytest.raises(cmf.CMFError):
+        rule.kernel_times("nope")
+    ref.close(); rule.close()
