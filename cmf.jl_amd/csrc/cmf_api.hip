@@ -82,8 +82,10 @@ struct cmf_handle_s {
 
     // launch plans
     int hxt_LP = 1, hxt_groups = 1, hxt_nchunks = 1, hxt_chunk_len = 2;
-    int tc_LT = 4, tc_S = 1, tc_nr = 8;
-    int tc_S1 = 1, tc_nr1 = 8;           // n ranges when only one source is contracted
+    int tc_LT = 4, tc_S = 1, tc_W = 4;   // fragment slabs and participating waves of the two-source transconv
+    int tc_S1 = 1, tc_W1 = 4;            // ... when only one source is contracted
+    std::vector<int4> tc_tab_host[2];    // per-wave work tables of the two variants ([0]: two sources, [1]: one)
+    int4 *tc_tab[2] = {nullptr, nullptr};
     int hxt_nchunks1 = 1, hxt_chunk_len1 = 6; // time chunks when only one source is contracted
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
 
@@ -177,20 +179,28 @@ static void plan(cmf_handle_s *h, int n_cu)
         h->hxt_chunk_len1 = (int)clen1;
         h->hxt_nchunks1 = (int)((d.Tl + clen1 - 1) / clen1);
     }
-    // C3 (transconv): S n-ranges so that (t tiles) x 2 x KB x S ~ 2 workgroups per CU x 2 rounds
+    // C3 (transconv): the chunk units of all (t block, k block, source) pairs are dealt out evenly to the resident
+    // waves (2 workgroups of 4 waves per CU); F = the largest number of waves that share one pair
     h->tc_LT = d.L <= 32 ? (int)rup(d.L, 4) : 32;
-    int64_t base = (int64_t)((d.Tl + 511) / 512) * 2 * d.KB;
-    int64_t n8 = rup(d.N, 8);
-    int S = (int)std::max<int64_t>(1, (4 * n_cu) / base);
-    S = (int)std::min<int64_t>(S, n8 / 8);
-    h->tc_nr = (int)rup((n8 + S - 1) / S, 8);
-    h->tc_S = (int)((n8 + h->tc_nr - 1) / h->tc_nr);
-    {
-        int S1 = (int)std::max<int64_t>(1, (8 * n_cu) / base);
-        S1 = (int)std::min<int64_t>(S1, n8 / 8);
-        h->tc_nr1 = (int)rup((n8 + S1 - 1) / S1, 8);
-        h->tc_S1 = (int)((n8 + h->tc_nr1 - 1) / h->tc_nr1);
-    }
+    auto tc_plan = [&](int nsrc, int *Wout, int *Fout, std::vector<int4> &tab) {
+        const long long C = rup(d.N, 8) / 8;
+        const long long pairs = (long long)((d.Tl + 127) / 128) * d.KB * nsrc;
+        const long long U = pairs * C;
+        const long long W = std::min<long long>(8LL * n_cu, U);
+        int F = 1;
+        tab.resize((size_t)W);
+        for (long long w = 0; w < W; ++w) {
+            const long long u0 = w * U / W, u1 = (w + 1) * U / W;
+            const long long pr = u0 / C;
+            const long long first = tc_wave_of(pr * C, U, W); // first wave that touches this pair
+            tab[(size_t)w] = make_int4((int)pr, (int)(u0 - pr * C), (int)(u1 - u0), (int)(w - first));
+            F = std::max<int>(F, (int)(w - first) + 1);
+        }
+        *Wout = (int)W;
+        *Fout = F;
+    };
+    tc_plan(2, &h->tc_W, &h->tc_S, h->tc_tab_host[0]);
+    tc_plan(1, &h->tc_W1, &h->tc_S1, h->tc_tab_host[1]);
     // C1 (conv)
     h->conv_gx = d.Np / 128;
     h->conv_gy = (d.Tl + 127) / 128;
@@ -206,6 +216,8 @@ static void destroy_impl(cmf_handle_s *h)
                       h->gram_numden_h, h->pgd_gradH, h->M, h->MT, h->hals_HuT, h->hals_hhslabs, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE};
     for (float *p : fbufs)
         if (p) (void)hipFree(p);
+    for (int v = 0; v < 2; ++v)
+        if (h->tc_tab[v]) (void)hipFree(h->tc_tab[v]);
     if (h->partial) (void)hipFree(h->partial);
     if (h->d_scalar_own) (void)hipFree(h->d_scalar_own);
     if (h->h_scalar) (void)hipHostFree(h->h_scalar);
@@ -316,6 +328,10 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     TRYB(dalloc_zero(&h->numden_own, (size_t)2 * d.L * d.K32 * d.Np));
     h->numden = h->numden_own;
     TRYB(dalloc_zero(&h->hslabs, (size_t)std::max(2 * h->tc_S, h->tc_S1) * d.Tl * d.K32));
+    for (int v = 0; v < 2; ++v) {
+        HIPB(hipMalloc(&h->tc_tab[v], h->tc_tab_host[v].size() * sizeof(int4)));
+        HIPB(hipMemcpy(h->tc_tab[v], h->tc_tab_host[v].data(), h->tc_tab_host[v].size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
     for (int w = 0; w < 4; ++w) {
         TRYB(dalloc_zero(&h->halo_own[w], (size_t)std::max(1, d.L - 1) * d.K32));
         h->halo[w] = h->halo_own[w];
@@ -408,10 +424,13 @@ static int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullpt
     TcParams p;
     p.Wn = h->Wn; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.slabs = h->hslabs;
     p.NpW = d.Np;
-    p.Nlim = (int)rup(d.N, 8); // rows >= N are zero: stop at the last 8-row chunk that holds data
     p.TP = d.TP; p.PADL = d.PADL; p.K32 = d.K32; p.KB = d.KB; p.L = d.L; p.Tl = d.Tl;
-    p.nr = nsrc == 2 ? h->tc_nr : h->tc_nr1; p.nsrc = nsrc;
-    dim3 grid((d.Tl + 511) / 512, nsrc == 2 ? h->tc_S : h->tc_S1, nsrc * d.KB), block(256);
+    p.nsrc = nsrc;
+    p.C = (int)(rup(d.N, 8) / 8); // rows >= roundup(N, 8) are zero: stop at the last 8-row chunk that holds data
+    p.W = nsrc == 2 ? h->tc_W : h->tc_W1;
+    p.F = nsrc == 2 ? h->tc_S : h->tc_S1;
+    p.wtab = h->tc_tab[nsrc == 2 ? 0 : 1];
+    dim3 grid((p.W + 3) / 4), block(256);
     switch (h->tc_LT) {
 #define CASE(LT_) case LT_: hipLaunchKernelGGL((transconv_kernel<LT_>), grid, block, 0, h->stream, p); break;
         CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)

@@ -515,22 +515,31 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
 
 // ---------------------------------------------------------------------------------------------
 // C3: out[t][k] = sum_{l,n} XT[n][t+l] * Wn[l][n][k]   (numH with X=data, denomH with X=est).
-// One wave = 128 consecutive t (4 MFMA blocks) x one 32-wide k block x one n range.  The wave
-// stages 8 rows (n) x 160 columns (t, incl. the right lag halo) of XT in its own LDS region
-// (wave-private: no workgroup barrier anywhere), reads the 20 lag-shifted windows from LDS as
-// the A operand, and streams the W operand (128-byte rows of Wn) straight from L2 into
-// registers one n pair ahead.  Partial sums over the n ranges go to slabs.
+// A *pair* is 128 consecutive t (4 MFMA blocks) x one 32-wide k block x one source; its work is
+// C = roundup(N,8)/8 chunks of 8 rows (n).  The U = pairs*C chunk units are dealt out evenly and
+// statically to the W resident waves (wave w owns units [w*U/W, (w+1)*U/W)), so every wave does
+// the same amount of MFMA work whatever the shape, in a single round, and the result does not
+// depend on timing.  A wave's range covers one or two pairs; for each it accumulates its chunk
+// range and writes the partial sum to the slab of its *fragment* index (its position among the
+// waves that share the pair); the wave holding a pair's last chunk zero-fills the fragment slabs
+// the pair does not use, so consumers simply sum all F slabs.
+// Per pair segment the wave stages 8 rows (n) x 160 columns (t, incl. the right lag halo) of XT
+// in its own LDS region (wave-private: no workgroup barrier anywhere), reads the 20 lag-shifted
+// windows from LDS as the A operand, and streams the W operand (128-byte rows of Wn) straight
+// from L2 into registers one n pair ahead.
 // ---------------------------------------------------------------------------------------------
 struct TcParams {
     const float *Wn;  // [Lp][Np][K32]
     const float *XT0; // dataT [Np][TP]
     const float *XT1; // estT  [Np][TP]
-    float *slabs;     // [S][2][Tl][K32]
+    float *slabs;     // [F][nsrc][Tl][K32]
     int NpW;          // rows per lag in Wn (= Np)
-    int Nlim;         // roundup(N, 8): XT rows >= Nlim are all zero and are skipped
     int TP, PADL, K32, KB, L, Tl;
-    int nr;           // n rows per range (multiple of 8)
     int nsrc;         // 1: only XT0 (stand-alone transconv), 2: both
+    int C;            // chunks (8 rows of n) per pair = roundup(N, 8) / 8: XT rows beyond are all zero
+    int W;            // waves that share the work (grid = ceil(W/4) workgroups)
+    int F;            // fragment slabs
+    const int4 *wtab; // [W] per wave: {first pair, first chunk in it, number of chunk units, fragment index of the first segment}
 };
 
 #define TC_ROW 160
@@ -565,6 +574,12 @@ __device__ __forceinline__ void tc_pair(f32x16 (&acc)[4], const float *sa, const
     }
 }
 
+// the wave whose range holds chunk unit u (ranges: wave w owns [w*U/W, (w+1)*U/W))
+__host__ __device__ __forceinline__ long long tc_wave_of(long long u, long long U, long long W)
+{
+    return ((u + 1) * W - 1) / U;
+}
+
 template <int LT>
 __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
 {
@@ -572,27 +587,31 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     float *S = smem + wave * (2 * TC_CHUNK);
-
-    const int t0 = (blockIdx.x * 4 + wave) * 128;
-    const int s = blockIdx.y;
-    const int src = blockIdx.z % p.nsrc;
-    const int kb = blockIdx.z / p.nsrc;
     const int Np = p.NpW, TP = p.TP, K32 = p.K32;
-    const float *XT = src ? p.XT1 : p.XT0;
-    const int nlo = s * p.nr;
-    int nhi = nlo + p.nr;
-    if (nhi > p.Nlim) nhi = p.Nlim;
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (gw >= p.W) return;
+    const int4 wt = p.wtab[gw];
+    int pr = wt.x, c0 = wt.y, left = wt.z, frag = wt.w;
+    const int LB = (p.L + 31) >> 5;
+    const size_t lagstride = (size_t)Np * K32;
+    const int lagbytes = (int)(lagstride * 4);
 
-    f32x16 acc[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    while (left > 0) {
+        // pair index -> (t block, k block, source); the source is the fastest index
+        const int c1 = (left < p.C - c0) ? c0 + left : p.C;
+        const int src = pr % p.nsrc;
+        const int kb = (pr / p.nsrc) % p.KB;
+        const int t0 = (pr / (p.nsrc * p.KB)) * 128;
+        const float *XT = src ? p.XT1 : p.XT0;
+        const int nlo = 8 * c0;
+        const int nchunks = c1 - c0;
 
-    if (t0 < p.Tl && nlo < nhi) {
-        const int LB = (p.L + 31) >> 5;
-        const int npairs = (nhi - nlo) >> 1;
-        const size_t lagstride = (size_t)Np * K32;
+        f32x16 acc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
         for (int lb = 0; lb < LB; ++lb) {
             const float *xsrc = XT + (size_t)nlo * TP + (p.PADL + t0 + 32 * lb);
             f32x4 xr[5];
@@ -604,10 +623,8 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
             // W operand for n pair `it`: Wn[lb*32 + l][nlo + 2*it + h][kb*32 + i]  (descriptor base: lag lb*32)
             const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wn + (size_t)(lb * 32) * lagstride, (size_t)LT * lagstride * 4);
             const int woff = (h * K32 + kb * 32 + i) * 4;
-            const int lagbytes = (int)(lagstride * 4);
             float b0[LT], b1[LT]; // ping-pong: no register copies, so a load is first needed one pair later
             tc_load_w<LT>(b0, wr, woff, nlo, K32, lagbytes);
-            const int nchunks = npairs >> 2;
             int buf = 0;
             for (int c = 0; c < nchunks; ++c) {
                 float *Sb = S + buf * TC_CHUNK;
@@ -642,9 +659,9 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
                 buf ^= 1;
             }
         }
-    }
-    if (t0 < p.Tl) {
-        float *slab = p.slabs + (size_t)(s * p.nsrc + src) * p.Tl * K32;
+        // fragment index = position of this wave among the waves sharing the pair (0 for a pair it starts)
+        const size_t slabstride = (size_t)p.nsrc * p.Tl * K32;
+        float *slab = p.slabs + ((size_t)frag * p.nsrc + src) * p.Tl * K32;
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
@@ -652,6 +669,22 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
                 int t = t0 + tb * 32 + cmf_crow(r, h);
                 if (t < p.Tl) slab[(size_t)t * K32 + kb * 32 + i] = acc[tb][r];
             }
+        if (c1 == p.C) { // the pair is complete: clear the fragment slabs it does not use
+            for (int f = frag + 1; f < p.F; ++f) {
+                float *z = slab + (size_t)(f - frag) * slabstride;
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int t = t0 + tb * 32 + cmf_crow(r, h);
+                        if (t < p.Tl) z[(size_t)t * K32 + kb * 32 + i] = 0.f;
+                    }
+            }
+        }
+        left -= nchunks;
+        ++pr;
+        c0 = 0;
+        frag = 0;
     }
 }
 
