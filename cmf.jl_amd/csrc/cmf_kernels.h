@@ -329,9 +329,20 @@ __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb,
     }
 }
 
+#ifdef CMF_CONV_STAMPS
+// debug builds only (tools/conv_stamps.hip): s_memtime stamps + HW_ID / XCC_ID per workgroup, 8 slots each
+__device__ unsigned long long *cmf_stamps;
+#define CMF_STAMP(slot) do { if (threadIdx.x == 0) { unsigned long long *st_ = cmf_stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8; \
+    st_[slot] = __builtin_amdgcn_s_memtime(); \
+    if ((slot) == 0) { st_[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } } } while (0)
+#else
+#define CMF_STAMP(slot) do { } while (0)
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
 {
+    CMF_STAMP(0);
     __shared__ __attribute__((aligned(16))) float Hs[CONV_HS_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -363,8 +374,11 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
             const int npair = (lend - lbeg + 1) >> 1; // lags are processed in pairs; Wt is zero-padded to Lp
             // descriptor base: Wt[lbeg][kb*32][0]
             const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wt + ((size_t)lbeg * K32 + kb * 32) * Np, (size_t)(2 * npair) * lagbytes);
+            CMF_STAMP(5);
             conv2_load_w(wA, wr, woff, 0, lagbytes, rowbytes);
+            CMF_STAMP(6);
             __syncthreads(); // everyone is done with Hs of the previous block
+            CMF_STAMP(7);
             {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,160)
                 const float *src = p.Ht + (size_t)(kb * 32) * TP + (p.PADL + t0 - lbeg - 32);
                 for (int idx = tid; idx < 32 * 40; idx += 256) {
@@ -374,6 +388,7 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
                 }
             }
             __syncthreads();
+            CMF_STAMP(1);
             const float *hsb = Hs + h * CONV_HS_STRIDE + 32 + wt * 64 + i;
             for (int pr = 0; pr < npair; ++pr) {
                 const int l0 = 2 * pr; // lag offsets inside the block
@@ -386,7 +401,9 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
             }
         }
     }
+    CMF_STAMP(2);
     conv_epilogue<MODE>(acc, p, t0, n0, wt, wn, i, h, lane, wave, tid);
+    CMF_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------
