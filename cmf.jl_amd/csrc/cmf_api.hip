@@ -88,6 +88,8 @@ struct cmf_handle_s {
     int4 *tc_tab[2] = {nullptr, nullptr};
     int hxt_nchunks1 = 1, hxt_chunk_len1 = 6; // time chunks when only one source is contracted
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
+    int conv_variant = 0;   // K % 32 == 0: 3 = one-wave workgroups (conv3_kernel), 2 = 128 x 128 tiles (conv2_kernel), 0 = per mode
+    int conv_partials = 1;  // loss partials written by the last conv launch
 
     // HALS scratch (allocated on first use)
     bool hals_ready = false;
@@ -126,7 +128,7 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H);
 static size_t n_partial(const cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
-    size_t n = (size_t)h->conv_gx * (size_t)std::max(h->conv_gy, h->conv_gy_ext);       // conv loss partials
+    size_t n = (size_t)(4 * h->conv_gx) * (size_t)std::max(h->conv_gy, h->conv_gy_ext);  // conv loss partials (64 x 64 tiles)
     n = std::max(n, (size_t)(d.Np / 64) * d.KB * d.L);                                 // PGD gradW norm partials
     n = std::max(n, (size_t)((d.Tl + 63) / 64) * d.KB);                                // PGD gradH norm partials
     n = std::max(n, 2 * (((size_t)d.Tl * d.K32 + 1023) / 1024));                       // Gram-form loss partials
@@ -387,8 +389,15 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     p.mask = (MODE == 7) ? h->MT : h->M;
     p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = T_store;
     dim3 grid(h->conv_gx, gy), block(256);
-    if (d.K % 32 == 0) hipLaunchKernelGGL((conv2_kernel<MODE>), grid, block, 0, h->stream, p);
+    // measured at config 2 (tools/time_kernels.py): the one-wave kernel wins where the epilogue both reads data and
+    // stores est (0.960 vs 0.990 ms), the 128 x 128 tiles win for the store-only epilogues (0.951 vs 0.977 ms)
+    const int variant = h->conv_variant ? h->conv_variant : (MODE == 3 ? 3 : 2);
+    if (d.K % 32 == 0 && variant == 3) {
+        grid = dim3(d.Np / 64, (T_store + 63) / 64);
+        hipLaunchKernelGGL((conv3_kernel<MODE>), grid, dim3(64), 0, h->stream, p);
+    } else if (d.K % 32 == 0) hipLaunchKernelGGL((conv2_kernel<MODE>), grid, block, 0, h->stream, p);
     else hipLaunchKernelGGL((conv_kernel<MODE, 0>), grid, block, 0, h->stream, p);
+    h->conv_partials = (int)(grid.x * grid.y);
     KCHK("conv_kernel");
     return CMF_OK;
 }
@@ -513,7 +522,7 @@ static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = tru
     } else {
         CMFTRY(launch_conv<2>(h, nullptr, d.Tl, h->conv_gy)); // mult.jl:55-57
     }
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_gx * h->conv_gy, h->d_scalar);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar);
     KCHK("loss_reduce_kernel");
     return readback ? read_scalar(h, 0, sumsq) : CMF_OK;
 }
@@ -568,6 +577,12 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         if (value < 0 || value > 2) return fail(CMF_ERR_ARG, "gram must be 0, 1 or 2");
         if (value && h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "the Gram form is not available on sharded handles");
         h->gram = value;
+        h->est_kind = 0;
+        return CMF_OK;
+    }
+    if (std::strcmp(name, "conv_kernel") == 0) { // K % 32 == 0 only: 0 = chosen per mode (default), 3 = one-wave workgroups, 2 = 128 x 128 tiles
+        if (value != 0 && value != 2 && value != 3) return fail(CMF_ERR_ARG, "conv_kernel must be 0 (per mode), 2 or 3");
+        h->conv_variant = value;
         h->est_kind = 0;
         return CMF_OK;
     }
@@ -903,7 +918,7 @@ static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked)
     const CmfDims &d = h->d;
     if (masked) CMFTRY(launch_conv<6>(h, h->est, d.Tl, h->conv_gy)); // pgd.jl:64-70
     else CMFTRY(launch_conv<4>(h, h->est, d.Tl, h->conv_gy));
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_gx * h->conv_gy, h->d_scalar);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar);
     KCHK("loss_reduce_kernel");
     h->est_kind = masked ? 3 : 2;
     return sumsq ? read_scalar(h, 0, sumsq) : CMF_OK;

@@ -81,14 +81,15 @@ struct ConvParams {
 #define CONV_HS_FLOATS (32 * CONV_HS_STRIDE)
 #define CONV_WS_FLOATS (32 * 128)
 
-template <int MODE>
+// WAVES = waves per workgroup: 4 (a 128 x 128 tile as 2 x 2 waves) or 1 (the workgroup IS one 64 x 64 wave tile)
+template <int MODE, int WAVES = 4>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvParams &p, int t0, int n0, int wt, int wn,
                                               int i, int h, int lane, int wave, int tid)
 {
     const int Np = p.Np, TP = p.TP;
     // Tiles that lie entirely below T_store (all but the last row of tiles) take a branch-free path:
     // per-element exec-mask branches serialise the epilogue (one L2 round trip per data load).
-    const bool full = (t0 + 128 <= p.T_store); // workgroup-uniform
+    const bool full = (t0 + (WAVES == 4 ? 128 : 64) <= p.T_store); // workgroup-uniform
     constexpr bool LOSS = (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6);
     constexpr bool RESID = (MODE == 4 || MODE == 6);
     constexpr bool MASKED = (MODE == 6 || MODE == 7);
@@ -132,10 +133,14 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
             double ds = (double)lsum;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) ds += __shfl_down(ds, off, 64);
-            __shared__ double red[4];
-            if (lane == 0) red[wave] = ds;
-            __syncthreads();
-            if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+            if (WAVES == 4) {
+                __shared__ double red[4];
+                if (lane == 0) red[wave] = ds;
+                __syncthreads();
+                if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+            } else {
+                if (lane == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = ds;
+            }
         }
     } else {
         // MODE 1 / 5 / 7: acc[ni][ti][r]: n = n0 + wn*64 + ni*32 + crow(r,h), t = t0 + wt*64 + ti*32 + i
@@ -300,7 +305,7 @@ __device__ __forceinline__ void conv2_load_w(float (&w)[16][2], __amdgpu_buffer_
     }
 }
 
-template <int MODE>
+template <int MODE, int STRIDE = CONV_HS_STRIDE>
 __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb, const float (&w)[16][2])
 {
     float a0 = hsb[0], a1 = hsb[32];
@@ -309,8 +314,8 @@ __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb,
     for (int kp = 0; kp < 16; ++kp) {
         float na0 = 0.f, na1 = 0.f;
         if (kp + 1 < 16) {
-            na0 = hsb[(kp + 1) * 2 * CONV_HS_STRIDE];
-            na1 = hsb[(kp + 1) * 2 * CONV_HS_STRIDE + 32];
+            na0 = hsb[(kp + 1) * 2 * STRIDE];
+            na1 = hsb[(kp + 1) * 2 * STRIDE + 32];
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         if (CONV_TRANSPOSED(MODE)) {
@@ -404,6 +409,78 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
     CMF_STAMP(2);
     conv_epilogue<MODE>(acc, p, t0, n0, wt, wn, i, h, lane, wave, tid);
     CMF_STAMP(3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C1c: tensor_conv with one-wave workgroups (K a multiple of 32).  The workgroup is one wave and one 64 (t) x 64 (n)
+// output tile; its H strip (32 k rows x 96 columns: 64 + the 32-lag halo) lives in a wave-private 12 KB of LDS, so
+// there is no workgroup barrier and the hardware dispatcher balances the chip in units of a quarter of conv2's
+// tile: the per-CU quantisation (25 vs 24.4 big tiles at config 2, 4 vs 3.06 on a T/8 shard) and the drain at the
+// end of the launch shrink fourfold.  Main loop and epilogue are conv2's.
+// ---------------------------------------------------------------------------------------------
+#define CONV3_STRIDE 96
+template <int MODE>
+__global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p)
+{
+    __shared__ __attribute__((aligned(16))) float Hs[32 * CONV3_STRIDE];
+    const int lane = threadIdx.x;
+    const int i = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 64;
+    const int t0 = blockIdx.y * 64;
+    const int Np = p.Np, TP = p.TP;
+    const int K32 = p.KB * 32;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int LB = (p.L + 31) >> 5;
+    const int rowbytes = Np * 4;
+    const int lagbytes = K32 * Np * 4;
+    const int woff = (h * Np + n0 + i) * 4; // per-lane part of the W address
+    float wA[16][2], wB[16][2];
+
+    for (int kb = 0; kb < p.KB; ++kb) {
+        for (int lb = 0; lb < LB; ++lb) {
+            const int lbeg = lb * 32;
+            const int lend = (p.L < lbeg + 32) ? p.L : (lbeg + 32);
+            const int npair = (lend - lbeg + 1) >> 1; // lags are processed in pairs; Wt is zero-padded to Lp
+            const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wt + ((size_t)lbeg * K32 + kb * 32) * Np, (size_t)(2 * npair) * lagbytes);
+            conv2_load_w(wA, wr, woff, 0, lagbytes, rowbytes);
+            {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,96): 8 lanes per row, 8 rows per pass
+                const int r = lane >> 3, c = (lane & 7) * 4;
+                const float *src = p.Ht + (size_t)(kb * 32 + r) * TP + (p.PADL + t0 - lbeg - 32 + c);
+                float *dst = Hs + r * CONV3_STRIDE + c;
+                f32x4 v[12];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) v[q * 3 + j] = *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * j);
+                __builtin_amdgcn_wave_barrier(); // (kb, lb) > 0: every lane is done reading the previous strip
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4 *>(dst + (8 * q) * CONV3_STRIDE + 32 * j) = v[q * 3 + j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float *hsb = Hs + h * CONV3_STRIDE + 32 + i;
+            for (int pr = 0; pr < npair; ++pr) {
+                const int l0 = 2 * pr; // lag offsets inside the block
+                conv2_load_w(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                conv2_lag<MODE, CONV3_STRIDE>(acc, hsb - l0, wA);
+                conv2_load_w(wA, wr, woff, (pr + 1 < npair) ? l0 + 2 : l0, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                conv2_lag<MODE, CONV3_STRIDE>(acc, hsb - l0 - 1, wB);
+            }
+        }
+    }
+    conv_epilogue<MODE, 1>(acc, p, t0, n0, 0, 0, i, h, lane, 0, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

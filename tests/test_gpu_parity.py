@@ -537,3 +537,35 @@ def test_in_loop_kernel_timing(cmf, oracle):
     with pytest.raises(cmf.CMFError):
         rule.kernel_times("nope")
     ref.close(); rule.close()
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("N,T,K,L", [(130, 700, 32, 20), (260, 600, 64, 20), (40, 300, 32, 33), (70, 130, 32, 5)])
+def test_conv_kernel_variants(cmf, oracle, N, T, K, L, variant):
+    """Both K % 32 == 0 conv kernels (128 x 128 workgroup tiles / one-wave 64 x 64 workgroups) in every role of an MU
+    iteration and of the residual-based rules, forced through the "conv_kernel" option."""
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=21)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=3)
+    rule = cmf.MultUpdate(data, W0, H0)
+    rule.set_option("conv_kernel", variant)
+    kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2)
+    lg = []
+    for _ in range(4):
+        rule.update_motifs(**kw)
+        lg.append(rule.update_feature_maps(**kw))
+    Wg, Hg = rule.download()
+    rule.close()
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=4, check_convergence=False, **kw)
+    np.testing.assert_allclose(lg, lr[1:], rtol=REL_LOSS)
+    assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
+    pg = cmf.PGDUpdate(data, W0, H0)
+    pg.set_option("conv_kernel", variant)
+    lp = []
+    for _ in range(3):
+        pg.update_motifs()
+        lp.append(pg.update_feature_maps())
+    Wp, Hp = pg.download()
+    pg.close()
+    Wo, Ho, lo, _ = oracle.fit_pgd(data, W0, H0, max_itr=3)
+    np.testing.assert_allclose(lp, lo[1:], rtol=REL_LOSS)
+    assert frob_rel(Wp, Wo) < REL_FACTORS and frob_rel(Hp, Ho) < REL_FACTORS
