@@ -579,19 +579,45 @@ def parameter_sweep(data, L_vals=(7,), K_vals=(3,), alg_vals=(":mult",), max_itr
 _MODEL_KEYS = ("W", "H", "data", "loss_hist", "time_hist")
 
 
+_META_KEYS = ("l1_H", "l2_H", "l1_W", "l2_W", "alg")
+
+
+def _is_hdf5_path(path):
+    return str(path).lower().endswith((".h5", ".hdf5", ".hdf"))
+
+
 def save_model(results, path, **meta):
-    """save_model(results, path): src/model.jl:149-163.  Same dataset names as the reference's HDF5 schema
-    (W, H, data, loss_hist, time_hist, plus whatever of l1_H, l2_H, l1_W, l2_W, alg is passed as keywords --
-    CNMF_results itself does not carry them, which is why the reference's own save_model is broken at HEAD),
-    written as a NumPy .npz container: there is no HDF5 library in this environment."""
+    """save_model(results, path): src/model.jl:149-163.  The reference's schema: datasets W, H, data, loss_hist,
+    time_hist plus whatever of l1_H, l2_H, l1_W, l2_W, alg is passed as keywords (CNMF_results itself does not carry
+    them, which is why the reference's own save_model is broken at HEAD).  A path ending in .h5 / .hdf5 is written as
+    a real HDF5 file in HDF5.jl's conventions (cmf.jl_amd/_hdf5.py over the system libhdf5), readable by the
+    reference's load_model; any other path is a NumPy .npz container with the same names."""
     arrays = {k: np.asarray(getattr(results, k)) for k in _MODEL_KEYS}
+    if _is_hdf5_path(path):
+        from . import _hdf5
+
+        items = dict(arrays)
+        for k, v in meta.items():
+            items[k] = str(v).lstrip(":") if k == "alg" or isinstance(v, str) else np.asarray(v, dtype=np.float64)
+        _hdf5.write_file(path, items)
+        return
     for k, v in meta.items():
         arrays[k] = np.asarray(v)
     np.savez_compressed(path, **arrays)
 
 
 def load_model(path):
-    """load_model(path): src/model.jl:167-181 -> (CNMF_results, meta dict)."""
+    """load_model(path): src/model.jl:167-181 -> (CNMF_results, meta dict); .h5 / .hdf5 files as written by either
+    side, otherwise the .npz container."""
+    if _is_hdf5_path(path):
+        from . import _hdf5
+
+        d = _hdf5.read_file(path, _MODEL_KEYS + _META_KEYS)
+        missing = [k for k in _MODEL_KEYS if k not in d]
+        if missing:
+            raise KeyError(f"{path}: datasets {missing} are missing")
+        r = CNMF_results(d["data"], d["W"], d["H"], d["time_hist"], d["loss_hist"])
+        return r, {k: d[k] for k in _META_KEYS if k in d}
     with np.load(path, allow_pickle=False) as f:
         r = CNMF_results(f["data"], f["W"], f["H"], f["time_hist"], f["loss_hist"])
         meta = {k: f[k][()] for k in f.files if k not in _MODEL_KEYS}

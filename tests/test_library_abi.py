@@ -73,3 +73,39 @@ def test_results_on_disk_and_convergence_helper(cmf, tmp_path):
     assert cmf.evaluate_convergence(r) == 2        # 0.402/0.4 < 1.01
     assert cmf.evaluate_convergence(r, thresh=0.3) == 1
     assert (r.num_lags(), r.num_units(), r.num_components(), r.num_iter()) == (4, 3, 2, 4)
+
+
+def test_results_as_hdf5_in_the_reference_schema(cmf, tmp_path):
+    """save_model / load_model with a .h5 path: a real HDF5 file in HDF5.jl's conventions (src/model.jl:149-181):
+    Float64 datasets whose dimensions are the Julia dimensions reversed and whose bytes are Julia's column-major
+    buffer; Float64 scalars; `alg` as a string."""
+    from cmf_jl_amd import _hdf5  # noqa: the package shim
+
+    if not _hdf5.available():
+        pytest.skip("no libhdf5 in this environment")
+    rng = np.random.default_rng(0)
+    K, N, L, T = 2, 3, 4, 5
+    r = cmf.CNMF_results(rng.random((N, T)), rng.random((K, N, L)), rng.random((K, T)), np.arange(4.0), np.array([1.0, 0.5, 0.402, 0.4]))
+    path = str(tmp_path / "model.h5")
+    cmf.save_model(r, path, l1_H=0.1, l2_H=0.2, l1_W=0.0, l2_W=0.5, alg=":mult")
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89HDF\r\n\x1a\n"
+    # the W tensor is stored contiguously in Julia order: W[k, n, l] with k fastest
+    assert np.asfortranarray(r.W).tobytes(order="A") in raw or np.asfortranarray(r.W).T.tobytes() in raw
+    r2, meta = cmf.load_model(path)
+    for k in ("W", "H", "data", "loss_hist", "time_hist"):
+        np.testing.assert_array_equal(getattr(r, k), getattr(r2, k))
+    assert meta == {"l1_H": 0.1, "l2_H": 0.2, "l1_W": 0.0, "l2_W": 0.5, "alg": "mult"}
+    # HDF5 sees the reversed dimensions (what h5dump / h5py would print for a file written by HDF5.jl)
+    lib = _hdf5._load()
+    f = lib.H5Fopen(path.encode(), 0, 0)
+    d = lib.H5Dopen2(f, b"W", 0)
+    s = lib.H5Dget_space(d)
+    dims = (_hdf5.hsize_t * 3)()
+    assert lib.H5Sget_simple_extent_ndims(s) == 3
+    lib.H5Sget_simple_extent_dims(s, dims, None)
+    assert tuple(dims) == (L, N, K)
+    lib.H5Sclose(s); lib.H5Dclose(d); lib.H5Fclose(f)
+    with pytest.raises(KeyError):
+        _hdf5.write_file(str(tmp_path / "partial.h5"), {"W": r.W})
+        cmf.load_model(str(tmp_path / "partial.h5"))
