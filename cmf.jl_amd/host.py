@@ -564,15 +564,41 @@ def evaluate_convergence(r, thresh=0.01):
     return len(r.loss_hist)
 
 
-def parameter_sweep(data, L_vals=(7,), K_vals=(3,), alg_vals=(":mult",), max_itr=100, max_time=math.inf, **kwargs):
+def parameter_sweep(data, L_vals=(7,), K_vals=(3,), alg_vals=(":mult",), max_itr=100, max_time=math.inf, group=None, **kwargs):
     """parameter_sweep(data; L_vals, K_vals, alg_vals, max_itr, max_time): src/model.jl:132-145.
     Returns {(L, K, alg): CNMF_results}; other keywords go to every fit_cnmf call (HEAD passes stale
-    `lambda1/initW` names that fit_cnmf ignores; here they would be reported as unknown)."""
+    `lambda1/initW` names that fit_cnmf ignores; here they would be reported as unknown).
+
+    Multi-GPU: the fits are independent, so when a torch.distributed process group is up
+    (one process per GPU) each rank runs every world-th combination on its own device and the results are gathered
+    on all ranks -- replicas, no data-path collective.  A `seed` keyword is used as given by every fit."""
+    combos = [(L, K, alg) for L in L_vals for K in K_vals for alg in alg_vals]
+    dist = None
+    try:
+        import torch.distributed as _dist
+
+        if _dist.is_available() and _dist.is_initialized():
+            dist = _dist
+    except ImportError:
+        pass
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist else (0, 1)
+    mine = {}
+    for idx, (L, K, alg) in enumerate(combos):
+        if idx % world == rank:
+            mine[(L, K, alg)] = fit_cnmf(data, L=L, K=K, alg=alg, max_itr=max_itr, max_time=max_time, **kwargs)
+    if world == 1:
+        return mine
+    # results travel without their copy of `data` (every rank holds it already)
+    packed = {k: (r.W, r.H, r.time_hist, r.loss_hist) for k, r in mine.items()}
+    parts = [None] * world
+    dist.all_gather_object(parts, packed, group=group)
+    data_f = np.asarray(data, dtype=np.float64)
     results = {}
-    for L in L_vals:
-        for K in K_vals:
-            for alg in alg_vals:
-                results[(L, K, alg)] = fit_cnmf(data, L=L, K=K, alg=alg, max_itr=max_itr, max_time=max_time, **kwargs)
+    for key in combos:  # the reference's insertion order
+        for part in parts:
+            if key in part:
+                W, H, th, lh = part[key]
+                results[key] = CNMF_results(data_f, W, H, th, lh)
     return results
 
 

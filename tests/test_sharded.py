@@ -108,3 +108,29 @@ def test_sharded_hip_engine_rccl_single_rank(oracle, tmp_path):
     np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
     assert frob_rel(got["W"], Wr) < 1e-4
     assert frob_rel(got["H"], Hr) < 1e-4
+
+
+@pytest.mark.gpu
+def test_parameter_sweep_over_ranks(tmp_path):
+    """independent fits spread over the ranks of a process group (replicas, one device per
+    rank on a real node; here two gloo ranks share GPU 0) give the single-process sweep's results in its order."""
+    import cmf_jl_amd as cmf
+
+    out = str(tmp_path / "sweep.npz")
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_sweep_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    got = np.load(out)
+    data = cmf.gen_synthetic(N=40, T=300, seed=1234)
+    ref = cmf.parameter_sweep(data, L_vals=(5, 8), K_vals=(2, 3), alg_vals=(":mult",), max_itr=6, seed=0, check_convergence=False)
+    assert [tuple(k) for k in got["keys"]] == [(L, K) for (L, K, _) in ref]
+    for (L, K, _), r in ref.items():
+        np.testing.assert_array_equal(got[f"loss_{L}_{K}"], r.loss_hist)  # same kernels, same seeds: bitwise
+        np.testing.assert_array_equal(got[f"W_{L}_{K}"], r.W)
