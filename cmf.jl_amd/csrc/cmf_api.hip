@@ -188,6 +188,8 @@ static void plan(cmf_handle_s *h, int n_cu)
         const long long C = rup(d.N, 8) / 8;
         const long long pairs = (long long)((d.Tl + 127) / 128) * d.KB * nsrc;
         const long long U = pairs * C;
+        // 2 workgroups of 4 waves per CU; 12 (the register limit with the LDS-DMA staging) measured the same
+        // 1.73 ms at config 2 and costs more fragment slabs
         const long long W = std::min<long long>(8LL * n_cu, U);
         int F = 1;
         tab.resize((size_t)W);

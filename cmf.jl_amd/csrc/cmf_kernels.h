@@ -636,6 +636,9 @@ struct TcParams {
     const int4 *wtab; // [W] per wave: {first pair, first chunk in it, number of chunk units, fragment index of the first segment}
 };
 
+#ifndef CMF_TC_GLDS
+#define CMF_TC_GLDS 1 // X chunks go global -> LDS directly (no register stop-over): 157 VGPRs, 3 waves per SIMD
+#endif
 #define TC_ROW 160
 #define TC_CHUNK (8 * TC_ROW)
 
@@ -668,6 +671,20 @@ __device__ __forceinline__ void tc_pair(f32x16 (&acc)[4], const float *sa, const
     }
 }
 
+// global -> LDS copy of 16 bytes per lane without a register stop-over: LDS destination = lds_base + lane * 16
+// (wave-uniform base in M0), global source = a per-lane 64-bit address.  Written as inline assembly so that the
+// compiler does not see an LDS-DMA in flight: it would otherwise drain vmcnt to 0 at the next use of any ordinary
+// load (cdna_hip_programming.md, "Pipelining across barriers"); completion is awaited by an explicit counted
+// s_waitcnt vmcnt(N) -- an untracked older operation can only make the compiler's own counted waits stricter.
+__device__ __forceinline__ void cmf_glds16(const void *gsrc, unsigned lds_base)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+}
+
 // the wave whose range holds chunk unit u (ranges: wave w owns [w*U/W, (w+1)*U/W))
 __host__ __device__ __forceinline__ long long tc_wave_of(long long u, long long U, long long W)
 {
@@ -689,6 +706,16 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
     const int LB = (p.L + 31) >> 5;
     const size_t lagstride = (size_t)Np * K32;
     const int lagbytes = (int)(lagstride * 4);
+#if CMF_TC_GLDS
+    // LDS byte address of this wave's region (wave-uniform)
+    const unsigned lds_S = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)S);
+    unsigned xoff[5]; // byte offset of this lane's float4 of an 8 x 160 chunk: element idx = lane + 64 q -> (row, column)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        int idx = lane + 64 * q, row = idx / 40, c4 = idx - row * 40;
+        xoff[q] = (unsigned)(row * TP + c4 * 4) * 4u;
+    }
+#endif
 
     while (left > 0) {
         // pair index -> (t block, k block, source); the source is the fastest index
@@ -708,12 +735,20 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
 
         for (int lb = 0; lb < LB; ++lb) {
             const float *xsrc = XT + (size_t)nlo * TP + (p.PADL + t0 + 32 * lb);
+#if CMF_TC_GLDS
+            // chunk 0 straight into LDS buffer 0 (global_load_lds: wave-uniform LDS base + lane * 16 bytes, which is
+            // exactly the strip's layout: element idx = lane + 64 q of the 8 x 160 chunk)
+            __builtin_amdgcn_wave_barrier(); // lag block > 0: the previous block's LDS reads are done
+#pragma unroll
+            for (int q = 0; q < 5; ++q) cmf_glds16(reinterpret_cast<const char *>(xsrc) + xoff[q], lds_S + q * 1024);
+#else
             f32x4 xr[5];
 #pragma unroll
             for (int q = 0; q < 5; ++q) {
                 int idx = lane + 64 * q, row = idx / 40, c4 = idx - row * 40;
                 xr[q] = *reinterpret_cast<const f32x4 *>(xsrc + (size_t)row * TP + c4 * 4);
             }
+#endif
             // W operand for n pair `it`: Wn[lb*32 + l][nlo + 2*it + h][kb*32 + i]  (descriptor base: lag lb*32)
             const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wn + (size_t)(lb * 32) * lagstride, (size_t)LT * lagstride * 4);
             const int woff = (h * K32 + kb * 32 + i) * 4;
@@ -722,6 +757,17 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
             int buf = 0;
             for (int c = 0; c < nchunks; ++c) {
                 float *Sb = S + buf * TC_CHUNK;
+#if CMF_TC_GLDS
+                // chunk c was issued one iteration ago; only the W prefetch (LT loads) is younger
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (LT & 15) | ((LT >> 4) << 14)); // vmcnt(LT), expcnt/lgkmcnt untouched
+                __builtin_amdgcn_wave_barrier();
+                if (c + 1 < nchunks) {
+                    const float *xs2 = xsrc + (size_t)(8 * (c + 1)) * TP;
+                    const unsigned Sn = lds_S + (buf ^ 1) * (TC_CHUNK * 4);
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) cmf_glds16(reinterpret_cast<const char *>(xs2) + xoff[q], Sn + q * 1024);
+                }
+#else
 #pragma unroll
                 for (int q = 0; q < 5; ++q)
                     *reinterpret_cast<f32x4 *>(Sb + (lane + 64 * q) * 4) = xr[q];
@@ -736,6 +782,7 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
                         xr[q] = *reinterpret_cast<const f32x4 *>(xs2 + (size_t)row * TP + c4 * 4);
                     }
                 }
+#endif
                 const int nrow = nlo + 8 * c;
                 const float *sa = Sb + h * TC_ROW + i;
                 tc_load_w<LT>(b1, wr, woff, nrow + 2, K32, lagbytes);
