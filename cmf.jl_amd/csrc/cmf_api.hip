@@ -90,6 +90,7 @@ struct cmf_handle_s {
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
     int conv_variant = 0;   // K % 32 == 0: 3 = one-wave workgroups (conv3_kernel), 2 = 128 x 128 tiles (conv2_kernel), 0 = per mode
     int conv_partials = 1;  // loss partials written by the last conv launch
+    int n_cu = 256;
 
     // HALS scratch (allocated on first use)
     bool hals_ready = false;
@@ -301,7 +302,8 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
         delete h;
         return fail(CMF_ERR_UNSUPPORTED, "W (L*N*K) or H (T*K) exceeds the 2 GiB the kernels' 32-bit buffer offsets address");
     }
-    plan(h, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    plan(h, h->n_cu);
     // the C2 kernel addresses a time chunk of X with 32-bit byte offsets: keep chunks below 2 GiB
     while ((double)(h->hxt_chunk_len + 16 * h->hxt_LP + 8) * d.Np * 4.0 >= 2147483648.0) {
         h->hxt_chunk_len = (int)rup(h->hxt_chunk_len / 2, 6 * h->hxt_LP);

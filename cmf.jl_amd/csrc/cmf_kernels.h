@@ -84,8 +84,9 @@ struct ConvParams {
 // WAVES = waves per workgroup: 4 (a 128 x 128 tile as 2 x 2 waves) or 1 (the workgroup IS one 64 x 64 wave tile)
 template <int MODE, int WAVES = 4>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvParams &p, int t0, int n0, int wt, int wn,
-                                              int i, int h, int lane, int wave, int tid)
+                                              int i, int h, int lane, int wave, int tid, int pidx = -1)
 {
+    if (pidx < 0) pidx = blockIdx.y * gridDim.x + blockIdx.x; // slot of this tile's loss partial
     const int Np = p.Np, TP = p.TP;
     // Tiles that lie entirely below T_store (all but the last row of tiles) take a branch-free path:
     // per-element exec-mask branches serialise the epilogue (one L2 round trip per data load).
@@ -137,9 +138,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
                 __shared__ double red[4];
                 if (lane == 0) red[wave] = ds;
                 __syncthreads();
-                if (tid == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+                if (tid == 0) p.partial[pidx] = red[0] + red[1] + red[2] + red[3];
             } else {
-                if (lane == 0) p.partial[blockIdx.y * gridDim.x + blockIdx.x] = ds;
+                if (lane == 0) p.partial[pidx] = ds;
             }
         }
     } else {
@@ -420,13 +421,9 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
 // ---------------------------------------------------------------------------------------------
 #define CONV3_STRIDE 96
 template <int MODE>
-__global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p)
+__device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t0, int n0, int lane, int pidx)
 {
-    __shared__ __attribute__((aligned(16))) float Hs[32 * CONV3_STRIDE];
-    const int lane = threadIdx.x;
     const int i = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 64;
-    const int t0 = blockIdx.y * 64;
     const int Np = p.Np, TP = p.TP;
     const int K32 = p.KB * 32;
 
@@ -460,7 +457,7 @@ __global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p)
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) v[q * 3 + j] = *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * j);
-                __builtin_amdgcn_wave_barrier(); // (kb, lb) > 0: every lane is done reading the previous strip
+                __builtin_amdgcn_wave_barrier(); // every lane is done reading the previous strip
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -480,7 +477,14 @@ __global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p)
             }
         }
     }
-    conv_epilogue<MODE, 1>(acc, p, t0, n0, 0, 0, i, h, lane, 0, lane);
+    conv_epilogue<MODE, 1>(acc, p, t0, n0, 0, 0, i, h, lane, 0, lane, pidx);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p)
+{
+    __shared__ __attribute__((aligned(16))) float Hs[32 * CONV3_STRIDE];
+    conv3_tile<MODE>(p, Hs, blockIdx.y * 64, blockIdx.x * 64, threadIdx.x, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
