@@ -112,6 +112,8 @@ struct cmf_handle_s {
     float *gram_numden_h = nullptr; // [1][2][Tl][K32]: numH | denomH in the h_update slab layout
     // in-loop kernel timing (option "profile"): HIP event pairs around the contraction launches, on the launch stream
     bool prof = false;
+    int prof_every = 1;          // bracket every n-th launch of a class (option value n)
+    int prof_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     struct ProfRec { hipEvent_t a, b; int cls; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
@@ -371,6 +373,7 @@ struct ProfScope {
     ProfScope(cmf_handle_s *h_, int cls) : h(h_)
     {
         if (!h->prof || h->prof_recs.size() >= 8192) return;
+        if ((h->prof_seen[cls]++ % h->prof_every) != 0) return;
         hipEvent_t ev[2] = {nullptr, nullptr};
         for (int q = 0; q < 2; ++q) {
             if (!h->prof_pool.empty()) { ev[q] = h->prof_pool.back(); h->prof_pool.pop_back(); }
@@ -601,6 +604,8 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         for (auto &r : h->prof_recs) { h->prof_pool.push_back(r.a); h->prof_pool.push_back(r.b); }
         h->prof_recs.clear();
         h->prof = value != 0;
+        h->prof_every = value > 1 ? value : 1;
+        for (int &c : h->prof_seen) c = 0;
         return CMF_OK;
     }
     return fail(CMF_ERR_ARG, "unknown option '%s'", name);

@@ -949,13 +949,20 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *
     }
 }
 
-// *out = sum(partial[0..n))   one block
+// *out = sum(partial[0..n))   one block; eight independent loads per thread and round (the one-wave conv kernel
+// writes 25 024 partials at config 2: a plain strided loop is a chain of dependent HBM round trips)
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial, int n, double *out)
 {
     __shared__ double red[256];
-    double s = 0.0;
-    for (int idx = threadIdx.x; idx < n; idx += 256) s += partial[idx];
-    red[threadIdx.x] = s;
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int base = threadIdx.x; base < n; base += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (base + 256 * u < n) ? partial[base + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += v[u];
+    }
+    red[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];

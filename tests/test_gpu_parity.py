@@ -530,6 +530,11 @@ def test_in_loop_kernel_timing(cmf, oracle):
     assert all(ms > 0 for ms, n in counts.values() if n)
     rule.set_option("profile", 1)  # restart drops the records
     assert rule.kernel_times("hxt") == (0.0, 0)
+    rule.set_option("profile", 2)  # every second launch of each class
+    for _ in range(4):
+        ref.update_motifs(); ref.update_feature_maps()
+        rule.update_motifs(); rule.update_feature_maps()
+    assert rule.kernel_times("hxt")[1] == 2 and rule.kernel_times("transconv")[1] == 2
     rule.set_option("profile", 0)
     Wa, Ha = ref.download()
     Wb, Hb = rule.download()
