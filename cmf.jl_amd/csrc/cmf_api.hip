@@ -203,6 +203,21 @@ static void plan(cmf_handle_s *h, int n_cu)
             tab[(size_t)w] = make_int4((int)pr, (int)(u0 - pr * C), (int)(u1 - u0), (int)(w - first));
             F = std::max<int>(F, (int)(w - first) + 1);
         }
+        // Placement (speed only): workgroup b lands on XCD b % 8 under round-robin dispatch.  Give each XCD the ranges
+        // whose first chunk lies in one eighth of the n axis, so that the W rows it streams (the n range of its
+        // waves, all lags) stay within its 4 MB L2 instead of every XCD cycling through all of W.
+        if (W >= 64 && W % 32 == 0) {
+            std::vector<int> order((size_t)W);
+            for (long long w = 0; w < W; ++w) order[(size_t)w] = (int)w;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tab[(size_t)a].y < tab[(size_t)b].y; });
+            std::vector<int4> placed((size_t)W);
+            const long long per_xcd = W / 8, wgs_per_xcd = per_xcd / 4;
+            for (long long x = 0; x < 8; ++x)
+                for (long long m = 0; m < wgs_per_xcd; ++m)
+                    for (long long j = 0; j < 4; ++j)
+                        placed[(size_t)(4 * (x + 8 * m) + j)] = tab[(size_t)order[(size_t)(x * per_xcd + 4 * m + j)]];
+            tab.swap(placed);
+        }
         *Wout = (int)W;
         *Fout = F;
     };
