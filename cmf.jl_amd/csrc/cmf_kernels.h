@@ -545,11 +545,22 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int nb = (blockIdx.x / p.G) * 4 + wave;
+    // blockIdx.x -> (n block quad, lag group).  Placement (speed only): workgroup b runs on XCD b % 8, so when the
+    // quads come in multiples of 8 the lag groups of one quad are put 8 apart -- the same XCD re-reads their common
+    // X rows from its L2 instead of every lag group fetching them from HBM.
+    int quad, lg;
+    if ((gridDim.x / p.G) % 8 == 0) {
+        lg = (blockIdx.x >> 3) % p.G;
+        quad = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * p.G));
+    } else {
+        quad = blockIdx.x / p.G;
+        lg = blockIdx.x % p.G;
+    }
+    const int nb = quad * 4 + wave;
     const int c = blockIdx.y;
     const int src = blockIdx.z % p.nsrc;
     const int kb = blockIdx.z / p.nsrc;
-    const int lag0 = (blockIdx.x % p.G) * 2 * LP;
+    const int lag0 = lg * 2 * LP;
     const int Np = p.Np, K32 = p.K32;
     const float *X = src ? p.X1 : p.X0;
 
