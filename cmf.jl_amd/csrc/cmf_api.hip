@@ -1011,15 +1011,22 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     CMFTRY(launch_hxt_on(h, h->hals_HuT, h->hals_HuT, h->hals_NpH, 1, h->hals_hhslabs, h->hals_nch, h->hals_clen));
     CMFTRY(launch_slab_sum(h, h->hals_HH, h->hals_hhslabs, h->hals_nch, (size_t)d.L * d.K32 * h->hals_NpH));
     // the K*L sequential column updates, k outer / lag inner (hals.jl:90-97)
-    const size_t per_wave = ((size_t)HALS_NG * d.L * d.K32 + 64) * sizeof(float);
-    int wpb = (int)std::min<size_t>(4, (size_t)(96 * 1024) / per_wave);
-    if (wpb < 1 || d.L * d.K32 > 1024)
+    if (d.L * d.K32 > 1024)
         return fail(CMF_ERR_UNSUPPORTED, "HALS W sweep: L*K = %d exceeds the 1024 state entries per unit it keeps on chip", d.L * d.K32);
-    const int units_per_block = wpb * HALS_NG;
-    dim3 grid((d.N + units_per_block - 1) / units_per_block), block(64 * wpb);
-    hipLaunchKernelGGL(hals_w_sweep_kernel, grid, block, per_wave * wpb, h->stream, h->Wt, h->Wn, h->numden, h->hals_HH,
-                       d.N, d.K, d.L, d.Np, d.K32, h->hals_NpH, (float)l1W, (float)l2W);
-    KCHK("hals_w_sweep_kernel");
+    const int nq = (d.L * d.K32 + 63) / 64;
+    dim3 grid((d.N + 4 * HALS_NG - 1) / (4 * HALS_NG)), block(256);
+#define SWEEP(NQ_)                                                                                                     \
+    hipLaunchKernelGGL((hals_w_sweep_reg_kernel<NQ_>), grid, block, 0, h->stream, h->Wt, h->Wn, h->numden, h->hals_HH, \
+                   d.N, d.K, d.L, d.Np, d.K32, h->hals_NpH, (float)l1W, (float)l2W)
+    if (nq <= 2) SWEEP(2);
+    else if (nq <= 4) SWEEP(4);
+    else if (nq <= 6) SWEEP(6);
+    else if (nq <= 8) SWEEP(8);
+    else if (nq <= 10) SWEEP(10);
+    else if (nq <= 12) SWEEP(12);
+    else SWEEP(16);
+#undef SWEEP
+    KCHK("hals_w_sweep_reg_kernel");
     h->est_kind = 0;
     return CMF_OK;
 }

@@ -1008,94 +1008,94 @@ __global__ void hals_build_hut_kernel(const float *H, float *HuT, int Tl, int L,
     }
 }
 
-// W sweep: one wave = NG units n; state g[NG][LK] in LDS (wave-private).  G = resid * H_unfold' in Wt layout.
 #define HALS_NG 2
-__global__ void hals_w_sweep_kernel(float *Wt, float *Wn, const float *G, const float *HH,
-                                                            int N, int K, int L, int Np, int K32, int NpH, float l1, float l2)
+#define HALS_WD 8 // prefetch depth (steps) of the W sweep
+// W sweep: one wave = HALS_NG units n, the projected state g[u][j] (j over the L*K32 columns
+// of H_unfold) sits in registers, lane (j % 64) slot (j / 64).  A step needs one state entry per unit -- a
+// v_readlane of the slot its column lives in -- and then updates every entry with one FMA; there is no LDS, no
+// wave synchronisation and nothing to wait for except the prefetched HH row, so a step costs a few hundred cycles
+// instead of several LDS and memory round trips.
+// grid: ceil(N / (4 * HALS_NG)), block 256 (4 independent waves).
+template <int NQ>
+__global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float *Wn, const float *G, const float *HH,
+                                                                int N, int K, int L, int Np, int K32, int NpH, float l1, float l2)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int LK = L * K32;
-    float *g = smem_dyn + (size_t)wave * (HALS_NG * LK + 64);
-    float *dl = g + HALS_NG * LK; // deltas of this step
-    const int n0 = (blockIdx.x * (blockDim.x >> 6) + wave) * HALS_NG;
+    const int n0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave) * HALS_NG);
     if (n0 >= N) return;
-    // G[j][n] = <resid[n,:], h_j> for the wave's units (zero for padded units)
-    for (int j = lane; j < LK; j += 64)
+    __shared__ float wnew_all[4][1024 * HALS_NG]; // new W values of the wave's units, step by step (K*L <= 1024)
+    float *wnew = wnew_all[wave];
+    float g[HALS_NG][NQ];
 #pragma unroll
-        for (int u = 0; u < HALS_NG; ++u) {
-            int n = n0 + u;
-            g[u * LK + j] = (n < N) ? G[(size_t)j * Np + n] : 0.f;
-        }
-    // LDS accesses of one wave execute in order; the only thing to prevent is the compiler moving them
-    // across the step boundaries (no s_waitcnt is wanted there: the prefetches below must stay in flight)
-#define HALS_WAVE_SYNC()                 \
-    do {                                 \
-        asm volatile("" ::: "memory");  \
-        __builtin_amdgcn_wave_barrier(); \
-    } while (0)
-    HALS_WAVE_SYNC();
-    // Software pipeline over the K*L steps (k outer, lag inner): the HH row, its diagonal entry and the old
-    // W values of step s+1 are loaded while step s updates the LDS-resident state.
-    constexpr int MAXQ = 16; // LK <= 1024 state entries per unit (host checks)
-    const int nsteps = K * L;
-    const bool owner = lane < HALS_NG && (n0 + lane) < N;
-    const int n_own = n0 + lane;
-    float hcur[MAXQ], hnext[MAXQ], hnext2[MAXQ];
-    float hpp_cur, hpp_next = 0.f, hpp_next2 = 0.f, wo_cur = 0.f, wo_next = 0.f, wo_next2 = 0.f;
-    auto step_index = [&](int sidx, int &kk, int &ll) { // step -> (k, l), clamped to the last step
-        const int c = sidx < nsteps ? sidx : nsteps - 1;
-        kk = c / L;
-        ll = c - kk * L;
-    };
-    auto prefetch = [&](int sidx, float (&hr)[MAXQ], float &hpp, float &wo) {
-        int kk, ll;
-        step_index(sidx, kk, ll);
-        const int pi = ll * K32 + kk;
-        const float *hrow = HH + (size_t)pi * NpH;
+    for (int q = 0; q < NQ; ++q) {
+        const int j = lane + 64 * q;
 #pragma unroll
-        for (int q = 0; q < MAXQ; ++q) hr[q] = (lane + 64 * q < LK) ? hrow[lane + 64 * q] : 0.f;
-        hpp = hrow[pi];
-        if (owner) wo = Wt[(size_t)pi * Np + n_own];
-    };
-    prefetch(0, hcur, hpp_cur, wo_cur);
-    prefetch(1, hnext, hpp_next, wo_next);
-    for (int sidx = 0; sidx < nsteps; ++sidx) {
-        int k, l;
-        step_index(sidx, k, l);
-        const int pidx = l * K32 + k;
-        prefetch(sidx + 2, hnext2, hpp_next2, wo_next2); // two steps ahead: a step is shorter than an L2 round trip
-        if (lane < HALS_NG) {
-            float d = 0.f;
-            if (owner) {
-                const float v = g[lane * LK + pidx] - wo_cur * hpp_cur;      // hals.jl:104 projected
-                float wn = (-v - l1) / (hpp_cur + CMF_EPS_F + l2);            // hals.jl:110
-                wn = fmaxf(wn, 0.f);
-                Wt[(size_t)pidx * Np + n_own] = wn;
-                Wn[((size_t)l * Np + n_own) * K32 + k] = wn;
-                d = wn - wo_cur;
-            }
-            dl[lane] = d;
-        }
-        HALS_WAVE_SYNC();
-        float du[HALS_NG];
-#pragma unroll
-        for (int u = 0; u < HALS_NG; ++u) du[u] = dl[u];
-#pragma unroll
-        for (int q = 0; q < MAXQ; ++q) {
-            const int j = lane + 64 * q;
-            if (j < LK) {
-#pragma unroll
-                for (int u = 0; u < HALS_NG; ++u) g[u * LK + j] = fmaf(du[u], hcur[q], g[u * LK + j]); // hals.jl:106
-            }
-        }
-        HALS_WAVE_SYNC();
-#pragma unroll
-        for (int q = 0; q < MAXQ; ++q) { hcur[q] = hnext[q]; hnext[q] = hnext2[q]; }
-        hpp_cur = hpp_next; hpp_next = hpp_next2;
-        wo_cur = wo_next; wo_next = wo_next2;
+        for (int u = 0; u < HALS_NG; ++u) g[u][q] = (j < LK && n0 + u < N) ? G[(size_t)j * Np + n0 + u] : 0.f;
     }
-#undef HALS_WAVE_SYNC
+    const int nsteps = K * L;
+    // HH rows, diagonal entries and old W values are prefetched HALS_WD steps ahead into a register ring (a step is
+    // ~200 cycles of dependent arithmetic, an L2 round trip several times that); the step loop is unrolled by the
+    // ring depth so that every ring slot is a fixed set of registers.
+    float hr[HALS_WD][NQ], hpp[HALS_WD], wo[HALS_WD][HALS_NG];
+    // all prefetches are buffer loads with wave-uniform (scalar) offsets: no address arithmetic in vector registers,
+    // and the descriptor's bound makes the reads past a row's or the array's end harmless zeros without a branch
+    const __amdgpu_buffer_rsrc_t hrs = cmf_rsrc(HH, (size_t)LK * NpH * 4);
+    const __amdgpu_buffer_rsrc_t wrs = cmf_rsrc(Wt, (size_t)LK * Np * 4);
+    auto prefetch = [&](int sidx, float (&row)[NQ], float &diag, float (&wold)[HALS_NG]) {
+        const int c = sidx < nsteps ? sidx : nsteps - 1; // clamped to the last step
+        const int kk = c / L, ll = c - kk * L;
+        const int pi = ll * K32 + kk;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) row[q] = cmf_bload(hrs, lane * 4, (pi * NpH + 64 * q) * 4);
+        diag = cmf_bload(hrs, 0, (pi * NpH + pi) * 4);
+#pragma unroll
+        for (int u = 0; u < HALS_NG; ++u) wold[u] = cmf_bload(wrs, 0, (pi * Np + n0 + u) * 4); // same address in every lane
+    };
+#pragma unroll
+    for (int i = 0; i < HALS_WD; ++i) prefetch(i, hr[i], hpp[i], wo[i]);
+    for (int s0 = 0; s0 < nsteps; s0 += HALS_WD) {
+#pragma unroll
+        for (int i = 0; i < HALS_WD; ++i) {
+            const int sidx = s0 + i;
+            if (sidx < nsteps) { // wave-uniform
+                const int k = sidx / L, l = sidx - k * L;
+                const int pidx = l * K32 + k;
+                const int tl = pidx & 63, tq = pidx >> 6; // wave-uniform: lane and slot of column pidx
+                float d[HALS_NG];
+#pragma unroll
+                for (int u = 0; u < HALS_NG; ++u) {
+                    float gs = g[u][0];
+#pragma unroll
+                    for (int q = 1; q < NQ; ++q) gs = (tq == q) ? g[u][q] : gs;
+                    const float gv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gs), tl));
+                    const float v = gv - wo[i][u] * hpp[i];                  // hals.jl:104 projected
+                    float wn = (-v - l1) / (hpp[i] + CMF_EPS_F + l2);        // hals.jl:110
+                    wn = fmaxf(wn, 0.f);
+                    wnew[sidx * HALS_NG + u] = wn; // every lane writes the same value; flushed to Wt / Wn after the sweep
+                    d[u] = (n0 + u < N) ? wn - wo[i][u] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int u = 0; u < HALS_NG; ++u) g[u][q] = fmaf(d[u], hr[i][q], g[u][q]); // hals.jl:106
+                prefetch(sidx + HALS_WD, hr[i], hpp[i], wo[i]);
+            }
+        }
+    }
+    // flush: no global store inside the sweep -- loads and stores share the in-order vmcnt on gfx9-class hardware
+    // and the compiler must then wait for *everything* (vmcnt(0)) at each use of a prefetched value
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int idx = lane; idx < nsteps * HALS_NG; idx += 64) {
+        const int sidx = idx / HALS_NG, u = idx - sidx * HALS_NG;
+        const int k = sidx / L, l = sidx - k * L;
+        if (n0 + u < N) {
+            const float wn = wnew[idx];
+            Wt[(size_t)(l * K32 + k) * Np + n0 + u] = wn;
+            Wn[((size_t)l * Np + n0 + u) * K32 + k] = wn;
+        }
+    }
 }
 
 // PT[k][t] = sum_s of the transconv(W, resid) slabs [S][1][Tl][K32]; grid (ceil(Tl/64), KB), block 256
