@@ -134,3 +134,37 @@ def test_parameter_sweep_over_ranks(tmp_path):
     for (L, K, _), r in ref.items():
         np.testing.assert_array_equal(got[f"loss_{L}_{K}"], r.loss_hist)  # same kernels, same seeds: bitwise
         np.testing.assert_array_equal(got[f"W_{L}_{K}"], r.W)
+
+
+@pytest.mark.gpu
+def test_sharded_full_size_matches_single_gpu(tmp_path):
+    """BASELINE config 2 (N=2000, T=50000, K=32, L=20) split over 2 ranks (25000 columns each, the shard of a
+    2-GPU run; both ranks share GPU 0 here and talk over gloo) against the unsharded rule on the same inputs:
+    the halo exchange, the [numW | denomW] all-reduce and the loss reduction at the sizes bench.py --gpus N uses."""
+    import cmf_jl_amd as cmf
+
+    iters = 3
+    out = str(tmp_path / "full.npz")
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_fullsize_worker.py"), out, str(iters)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    got = np.load(out)
+    data = cmf.gen_synthetic(N=2000, T=50000, seed=1234)
+    W0, H0 = cmf.init_rand(data, L=20, K=32, seed=0)
+    rule = cmf.MultUpdate(data, W0, H0)
+    losses = [rule.compute_loss()]
+    for _ in range(iters):
+        rule.update_motifs()
+        losses.append(rule.update_feature_maps())
+    W, H = rule.download()
+    rule.close()
+    # same kernels on different tilings of T: fp32 summation-order differences only
+    np.testing.assert_allclose(got["loss_hist"], losses, rtol=1e-5)
+    assert frob_rel(got["W"], W) < 1e-5 and frob_rel(got["H"], H) < 1e-5
