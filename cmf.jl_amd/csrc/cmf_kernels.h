@@ -82,51 +82,60 @@ struct ConvParams {
 #define CONV_WS_FLOATS (32 * 128)
 
 // WAVES = waves per workgroup: 4 (a 128 x 128 tile as 2 x 2 waves) or 1 (the workgroup IS one 64 x 64 wave tile)
+__device__ __forceinline__ void cmf_bstore(float v, __amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff_bytes, soff_bytes, 0);
+}
+
+// Every access of the epilogue is a buffer load / store: descriptor on the wave's 64 x 64 sub-tile (a wave-uniform
+// base), one per-lane byte offset, and a scalar offset per element -- no vector address arithmetic (VALU slots are
+// what a workgroup at the edge of its life is short of, see conv2_kernel), and nothing wide for the compiler to hoist
+// out of a tile loop.  In the [t][n] layout the descriptor ends at row T_store, so the rows of a partial last tile
+// that do not exist are dropped by the bounds check instead of by per-element branches.
 template <int MODE, int WAVES = 4>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvParams &p, int t0, int n0, int wt, int wn,
                                               int i, int h, int lane, int wave, int tid, int pidx = -1)
 {
     if (pidx < 0) pidx = blockIdx.y * gridDim.x + blockIdx.x; // slot of this tile's loss partial
     const int Np = p.Np, TP = p.TP;
-    // Tiles that lie entirely below T_store (all but the last row of tiles) take a branch-free path:
-    // per-element exec-mask branches serialise the epilogue (one L2 round trip per data load).
-    const bool full = (t0 + (WAVES == 4 ? 128 : 64) <= p.T_store); // workgroup-uniform
     constexpr bool LOSS = (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6);
     constexpr bool RESID = (MODE == 4 || MODE == 6);
     constexpr bool MASKED = (MODE == 6 || MODE == 7);
+    // wave-uniform origin of this wave's 64 x 64 sub-tile
+    const int tw = __builtin_amdgcn_readfirstlane(t0 + wt * 64);
+    const int nw = __builtin_amdgcn_readfirstlane(n0 + wn * 64);
     if (!CONV_TRANSPOSED(MODE)) {
-        // acc[ti][ni][r]: t = t0 + wt*64 + ti*32 + crow(r,h), n = n0 + wn*64 + ni*32 + i
+        // acc[ti][ni][r]: t = tw + ti*32 + crow(r,h), n = nw + ni*32 + i
+        int rows = p.T_store - tw; // rows of the sub-tile that exist
+        rows = rows < 0 ? 0 : (rows > 64 ? 64 : rows);
+        const size_t origin = (size_t)(p.PADL + tw) * Np + nw;
+        const size_t bytes = rows ? ((size_t)(rows - 1) * Np + 64) * 4 : 0;
+        const __amdgpu_buffer_rsrc_t ro = cmf_rsrc(p.out + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rd = cmf_rsrc(p.data + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rm = cmf_rsrc(p.mask + origin, bytes);
+        const int voff = (4 * h * Np + i) * 4;
         float lsum = 0.f;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                const size_t o0 = (size_t)(p.PADL + t0 + wt * 64 + ti * 32 + 4 * h) * Np + n0 + wn * 64 + ni * 32 + i;
                 float dv[16], mv[16];
-                // the rows of a partial tile beyond T_store are padding rows of X: in bounds
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dv[r] = LOSS ? p.data[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] : 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int so = ((ti * 32 + (r & 3) + 8 * (r >> 2)) * Np + ni * 32) * 4;
+                    dv[r] = LOSS ? cmf_bload(rd, voff, so) : 0.f; // rows past T_store read as 0 (and are masked below)
+                    mv[r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
+                }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mv[r] = MASKED ? p.mask[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] : 1.f;
-                if (full) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[ti][ni][r];
-                        const float d = MASKED ? (v - dv[r]) * mv[r] : v - dv[r];
-                        if (MODE == 0 || MODE == 3) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = v;
-                        if (RESID) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = d;
-                        if (LOSS) lsum = fmaf(d, d, lsum);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int t = t0 + wt * 64 + ti * 32 + cmf_crow(r, h);
-                        const float v = acc[ti][ni][r];
-                        const float d0 = MASKED ? (v - dv[r]) * mv[r] : v - dv[r];
-                        if (MODE == 0 || MODE == 3 || RESID) {
-                            if (t < p.T_store) p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * Np] = RESID ? d0 : v;
-                        }
-                        if (LOSS) { const float d = (t < p.T_store) ? d0 : 0.f; lsum = fmaf(d, d, lsum); }
+                for (int r = 0; r < 16; ++r) {
+                    const int so = ((ti * 32 + (r & 3) + 8 * (r >> 2)) * Np + ni * 32) * 4;
+                    const float v = acc[ti][ni][r];
+                    float d = MASKED ? (v - dv[r]) * mv[r] : v - dv[r];
+                    if (MODE == 0 || MODE == 3) cmf_bstore(v, ro, voff, so);
+                    if (RESID) cmf_bstore(d, ro, voff, so);
+                    if (LOSS) {
+                        if (rows < 64) d = (ti * 32 + cmf_crow(r, h) < rows) ? d : 0.f; // last row of tiles only (wave-uniform test)
+                        lsum = fmaf(d, d, lsum);
                     }
                 }
             }
@@ -144,23 +153,32 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
             }
         }
     } else {
-        // MODE 1 / 5 / 7: acc[ni][ti][r]: n = n0 + wn*64 + ni*32 + crow(r,h), t = t0 + wt*64 + ti*32 + i
+        // MODE 1 / 5 / 7: acc[ni][ti][r]: n = nw + ni*32 + crow(r,h), t = tw + ti*32 + i
         // (MODE 5 / 7 store est - data in the transposed layout; p.data is then dataT [Np][TP])
+        const size_t origin = (size_t)nw * TP + p.PADL + tw;
+        const size_t bytes = ((size_t)63 * TP + 64) * 4;
+        const __amdgpu_buffer_rsrc_t ro = cmf_rsrc(p.out + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rd = cmf_rsrc(p.data + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rm = cmf_rsrc(p.mask + origin, bytes);
+        const int voff = (4 * h * TP + i) * 4;
+        const bool full = (tw + 64 <= p.T_store); // wave-uniform
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti) {
-                const int t = t0 + wt * 64 + ti * 32 + i;
-                const size_t o0 = (size_t)(n0 + wn * 64 + ni * 32 + 4 * h) * TP + p.PADL + t;
-                if (full || t < p.T_store) {
+                if (full || tw + ti * 32 + i < p.T_store) {
                     float dv[16], mv[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dv[r] = (MODE != 1) ? p.data[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] : 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        const int so = ((ni * 32 + (r & 3) + 8 * (r >> 2)) * TP + ti * 32) * 4;
+                        dv[r] = (MODE != 1) ? cmf_bload(rd, voff, so) : 0.f;
+                        mv[r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
+                    }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mv[r] = MASKED ? p.mask[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] : 1.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        p.out[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * TP] = MASKED ? (acc[ni][ti][r] - dv[r]) * mv[r] : acc[ni][ti][r] - dv[r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int so = ((ni * 32 + (r & 3) + 8 * (r >> 2)) * TP + ti * 32) * 4;
+                        cmf_bstore(MASKED ? (acc[ni][ti][r] - dv[r]) * mv[r] : acc[ni][ti][r] - dv[r], ro, voff, so);
+                    }
                 }
             }
     }
@@ -306,9 +324,12 @@ __device__ __forceinline__ void conv2_load_w(float (&w)[16][2], __amdgpu_buffer_
     }
 }
 
-template <int MODE, int STRIDE = CONV_HS_STRIDE>
+// FIRST: the accumulators hold nothing yet -- the kp = 0 MFMAs take a zero C operand (an inline constant) instead of
+// 64 register writes of an explicit zero fill
+template <int MODE, int STRIDE = CONV_HS_STRIDE, bool FIRST = false>
 __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb, const float (&w)[16][2])
 {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float a0 = hsb[0], a1 = hsb[32];
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
@@ -319,16 +340,17 @@ __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb,
             na1 = hsb[(kp + 1) * 2 * STRIDE + 32];
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        const bool zc = FIRST && kp == 0;
         if (CONV_TRANSPOSED(MODE)) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a1, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a0, zc ? zero16 : acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a1, zc ? zero16 : acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a0, zc ? zero16 : acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a1, zc ? zero16 : acc[1][1], 0, 0, 0);
         } else {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[kp][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[kp][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[kp][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[kp][1], acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[kp][0], zc ? zero16 : acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[kp][1], zc ? zero16 : acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[kp][0], zc ? zero16 : acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[kp][1], zc ? zero16 : acc[1][1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         a0 = na0; a1 = na1;
