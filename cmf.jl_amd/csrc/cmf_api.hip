@@ -411,10 +411,11 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     p.mask = (MODE == 7) ? h->MT : h->M;
     p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = T_store;
     dim3 grid(h->conv_gx, gy), block(256);
-    // measured at config 2 (tools/time_kernels.py, buffer-addressed epilogue): the one-wave kernel wins for the
-    // [t][n] epilogues (0.901 vs 0.918 ms store only, 0.945 vs 0.995 ms loss + store), the 128 x 128 tiles for the
-    // transposed store (0.915 vs 0.924 ms)
-    const int variant = h->conv_variant ? h->conv_variant : (CONV_TRANSPOSED(MODE) ? 2 : 3);
+    // measured at config 2 (tools/time_kernels.py): the one-wave kernel wins for the epilogues that read data
+    // (0.924 vs 0.931 ms loss only, 0.936 vs 0.943 ms loss + store), the 128 x 128 tiles for the store-only ones
+    // (0.911 vs 0.932 ms est, 0.910 vs 0.924 ms est')
+    constexpr bool reads_data = (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6);
+    const int variant = h->conv_variant ? h->conv_variant : (reads_data ? 3 : 2);
     if (d.K % 32 == 0 && variant == 3) {
         grid = dim3(d.Np / 64, (T_store + 63) / 64);
         hipLaunchKernelGGL((conv3_kernel<MODE>), grid, dim3(64), 0, h->stream, p);

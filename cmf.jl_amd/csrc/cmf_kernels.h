@@ -140,16 +140,22 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
                 }
             }
         if (LOSS) {
-            double ds = (double)lsum;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) ds += __shfl_down(ds, off, 64);
+            // wave sum on the DPP network (row shifts, then the two row broadcasts): the total lands in lane 63.
+            // 4096 squares per wave in fp32, fp64 from the per-tile partials on (fixed order: deterministic)
+            float x = lsum;
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, false)); // row_shr:1
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, false)); // row_shr:2
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, false)); // row_shr:4
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, false)); // row_shr:8
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false)); // row_bcast:15
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false)); // row_bcast:31
             if (WAVES == 4) {
-                __shared__ double red[4];
-                if (lane == 0) red[wave] = ds;
+                __shared__ float red[4];
+                if (lane == 63) red[wave] = x;
                 __syncthreads();
-                if (tid == 0) p.partial[pidx] = red[0] + red[1] + red[2] + red[3];
+                if (tid == 0) p.partial[pidx] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
             } else {
-                if (lane == 0) p.partial[pidx] = ds;
+                if (lane == 63) p.partial[pidx] = (double)x;
             }
         }
     } else {
@@ -222,13 +228,15 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p)
             const int lbeg = lb * 32;
             const int lend = (p.L < lbeg + 32) ? p.L : (lbeg + 32);
             __syncthreads(); // everyone is done with Hs / Ws of the previous block
-            {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,160)
-                const float *src = p.Ht + (size_t)(kb * 32) * TP + (p.PADL + t0 - lbeg - 32);
-                for (int idx = tid; idx < 32 * 40; idx += 256) {
-                    int r = idx / 40, c4 = idx - r * 40;
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)r * TP + c4 * 4);
-                    *reinterpret_cast<f32x4 *>(Hs + r * CONV_HS_STRIDE + c4 * 4) = v;
-                }
+            {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,160): 8 threads per row, 5 float4 each
+                const int r = tid >> 3, c = (tid & 7) * 4;
+                const float *src = p.Ht + (size_t)(kb * 32 + r) * TP + (p.PADL + t0 - lbeg - 32 + c);
+                float *dst = Hs + r * CONV_HS_STRIDE + c;
+                f32x4 v[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) v[j] = *reinterpret_cast<const f32x4 *>(src + 32 * j);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) *reinterpret_cast<f32x4 *>(dst + 32 * j) = v[j];
             }
             f32x4 wreg[4];
             {   // first W chunk of this block straight into Ws[buf]
@@ -381,14 +389,7 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
     const int Np = p.Np, TP = p.TP;
     const int K32 = p.KB * 32;
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
+    f32x16 acc[2][2]; // started by the zero-C MFMAs of the first lag
     const int LB = (p.L + 31) >> 5;
     const int rowbytes = Np * 4;
     const int lagbytes = K32 * Np * 4;
@@ -407,18 +408,30 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
             CMF_STAMP(6);
             __syncthreads(); // everyone is done with Hs of the previous block
             CMF_STAMP(7);
-            {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,160)
-                const float *src = p.Ht + (size_t)(kb * 32) * TP + (p.PADL + t0 - lbeg - 32);
-                for (int idx = tid; idx < 32 * 40; idx += 256) {
-                    int r = idx / 40, c4 = idx - r * 40;
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)r * TP + c4 * 4);
-                    *reinterpret_cast<f32x4 *>(Hs + r * CONV_HS_STRIDE + c4 * 4) = v;
-                }
+            {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,160): 8 threads per row, 5 float4 each
+                const int r = tid >> 3, c = (tid & 7) * 4;
+                const float *src = p.Ht + (size_t)(kb * 32 + r) * TP + (p.PADL + t0 - lbeg - 32 + c);
+                float *dst = Hs + r * CONV_HS_STRIDE + c;
+                f32x4 v[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) v[j] = *reinterpret_cast<const f32x4 *>(src + 32 * j);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) *reinterpret_cast<f32x4 *>(dst + 32 * j) = v[j];
             }
             __syncthreads();
             CMF_STAMP(1);
             const float *hsb = Hs + h * CONV_HS_STRIDE + 32 + wt * 64 + i;
-            for (int pr = 0; pr < npair; ++pr) {
+            int pr = 0;
+            if (kb == 0 && lb == 0) { // peeled first lag pair: its first MFMAs start the accumulators
+                conv2_load_w(wB, wr, woff, 1, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                conv2_lag<MODE, CONV_HS_STRIDE, true>(acc, hsb, wA);
+                conv2_load_w(wA, wr, woff, (1 < npair) ? 2 : 0, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                conv2_lag<MODE>(acc, hsb - 1, wB);
+                pr = 1;
+            }
+            for (; pr < npair; ++pr) {
                 const int l0 = 2 * pr; // lag offsets inside the block
                 conv2_load_w(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
                 __builtin_amdgcn_sched_barrier(0);
@@ -449,14 +462,7 @@ __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t
     const int Np = p.Np, TP = p.TP;
     const int K32 = p.KB * 32;
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
+    f32x16 acc[2][2]; // started by the zero-C MFMAs of the first lag
     const int LB = (p.L + 31) >> 5;
     const int rowbytes = Np * 4;
     const int lagbytes = K32 * Np * 4;
@@ -488,7 +494,17 @@ __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const float *hsb = Hs + h * CONV3_STRIDE + 32 + i;
-            for (int pr = 0; pr < npair; ++pr) {
+            int pr = 0;
+            if (kb == 0 && lb == 0) { // peeled first lag pair: its first MFMAs start the accumulators
+                conv2_load_w(wB, wr, woff, 1, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                conv2_lag<MODE, CONV3_STRIDE, true>(acc, hsb, wA);
+                conv2_load_w(wA, wr, woff, (1 < npair) ? 2 : 0, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                conv2_lag<MODE, CONV3_STRIDE>(acc, hsb - 1, wB);
+                pr = 1;
+            }
+            for (; pr < npair; ++pr) {
                 const int l0 = 2 * pr; // lag offsets inside the block
                 conv2_load_w(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
                 __builtin_amdgcn_sched_barrier(0);
