@@ -20,6 +20,7 @@
 // C/D: col = i, row = (reg&3) + 8*(reg>>2) + 4*h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -115,30 +116,36 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
         const __amdgpu_buffer_rsrc_t rm = cmf_rsrc(p.mask + origin, bytes);
         const int voff = (4 * h * Np + i) * 4;
         float lsum = 0.f;
+        // the body twice, selected by one wave-uniform branch: only the last row of tiles pays for the row test
+        auto body = [&](auto partial_rows) {
+            constexpr bool PARTIAL = decltype(partial_rows)::value;
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+            for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                float dv[16], mv[16];
+                for (int ni = 0; ni < 2; ++ni) {
+                    float dv[16], mv[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int so = ((ti * 32 + (r & 3) + 8 * (r >> 2)) * Np + ni * 32) * 4;
-                    dv[r] = LOSS ? cmf_bload(rd, voff, so) : 0.f; // rows past T_store read as 0 (and are masked below)
-                    mv[r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int so = ((ti * 32 + (r & 3) + 8 * (r >> 2)) * Np + ni * 32) * 4;
+                        dv[r] = LOSS ? cmf_bload(rd, voff, so) : 0.f; // rows past T_store read as 0 (and are masked below)
+                        mv[r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
+                    }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int so = ((ti * 32 + (r & 3) + 8 * (r >> 2)) * Np + ni * 32) * 4;
-                    const float v = acc[ti][ni][r];
-                    float d = MASKED ? (v - dv[r]) * mv[r] : v - dv[r];
-                    if (MODE == 0 || MODE == 3) cmf_bstore(v, ro, voff, so);
-                    if (RESID) cmf_bstore(d, ro, voff, so);
-                    if (LOSS) {
-                        if (rows < 64) d = (ti * 32 + cmf_crow(r, h) < rows) ? d : 0.f; // last row of tiles only (wave-uniform test)
-                        lsum = fmaf(d, d, lsum);
+                    for (int r = 0; r < 16; ++r) {
+                        const int so = ((ti * 32 + (r & 3) + 8 * (r >> 2)) * Np + ni * 32) * 4;
+                        const float v = acc[ti][ni][r];
+                        float d = MASKED ? (v - dv[r]) * mv[r] : v - dv[r];
+                        if (MODE == 0 || MODE == 3) cmf_bstore(v, ro, voff, so);
+                        if (RESID) cmf_bstore(d, ro, voff, so);
+                        if (LOSS) {
+                            if (PARTIAL) d = (ti * 32 + cmf_crow(r, h) < rows) ? d : 0.f;
+                            lsum = fmaf(d, d, lsum);
+                        }
                     }
                 }
-            }
+        };
+        if (rows == 64) body(std::false_type{});
+        else body(std::true_type{});
         if (LOSS) {
             // wave sum on the DPP network (row shifts, then the two row broadcasts): the total lands in lane 63.
             // 4096 squares per wave in fp32, fp64 from the per-tile partials on (fixed order: deterministic)
