@@ -119,29 +119,41 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
         // the body twice, selected by one wave-uniform branch: only the last row of tiles pays for the row test
         auto body = [&](auto partial_rows) {
             constexpr bool PARTIAL = decltype(partial_rows)::value;
+            // all operand loads of a group first (the W registers are dead by now), then arithmetic and stores: a load
+            // queued behind stores would wait for them on the in-order vmcnt.  A group is the whole 64 x 64 sub-tile,
+            // or one 32 x 32 block when the mask doubles the operands (the registers do not stretch further).
+            constexpr int GT = MASKED ? 1 : 2; // blocks per group along t and n
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
+            for (int gt = 0; gt < 2; gt += GT)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    float dv[16], mv[16];
+                for (int gn = 0; gn < 2; gn += GT) {
+                    float dv[GT][GT][16], mv[GT][GT][16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int so = ((ti * 32 + (r & 3) + 8 * (r >> 2)) * Np + ni * 32) * 4;
-                        dv[r] = LOSS ? cmf_bload(rd, voff, so) : 0.f; // rows past T_store read as 0 (and are masked below)
-                        mv[r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
-                    }
+                    for (int ti = 0; ti < GT; ++ti)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int so = ((ti * 32 + (r & 3) + 8 * (r >> 2)) * Np + ni * 32) * 4;
-                        const float v = acc[ti][ni][r];
-                        float d = MASKED ? (v - dv[r]) * mv[r] : v - dv[r];
-                        if (MODE == 0 || MODE == 3) cmf_bstore(v, ro, voff, so);
-                        if (RESID) cmf_bstore(d, ro, voff, so);
-                        if (LOSS) {
-                            if (PARTIAL) d = (ti * 32 + cmf_crow(r, h) < rows) ? d : 0.f;
-                            lsum = fmaf(d, d, lsum);
-                        }
-                    }
+                        for (int ni = 0; ni < GT; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int so = (((gt + ti) * 32 + (r & 3) + 8 * (r >> 2)) * Np + (gn + ni) * 32) * 4;
+                                dv[ti][ni][r] = LOSS ? cmf_bload(rd, voff, so) : 0.f; // rows past T_store read as 0 (masked below)
+                                mv[ti][ni][r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
+                            }
+#pragma unroll
+                    for (int ti = 0; ti < GT; ++ti)
+#pragma unroll
+                        for (int ni = 0; ni < GT; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int so = (((gt + ti) * 32 + (r & 3) + 8 * (r >> 2)) * Np + (gn + ni) * 32) * 4;
+                                const float v = acc[gt + ti][gn + ni][r];
+                                float d = MASKED ? (v - dv[ti][ni][r]) * mv[ti][ni][r] : v - dv[ti][ni][r];
+                                if (MODE == 0 || MODE == 3) cmf_bstore(v, ro, voff, so);
+                                if (RESID) cmf_bstore(d, ro, voff, so);
+                                if (LOSS) {
+                                    if (PARTIAL) d = ((gt + ti) * 32 + cmf_crow(r, h) < rows) ? d : 0.f;
+                                    lsum = fmaf(d, d, lsum);
+                                }
+                            }
                 }
         };
         if (rows == 64) body(std::false_type{});
