@@ -597,6 +597,9 @@ __device__ __forceinline__ void hxt_group(f32x16 (&acc)[2 * LP], const float (&E
     }
 }
 
+#ifndef CMF_HXT_INTERLEAVE
+#define CMF_HXT_INTERLEAVE 1
+#endif
 template <int LP>
 __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
 {
@@ -650,18 +653,39 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
         hxt_load<LP>(E1, O1, B1, hr, xr, hoff, xoff, 2 * LP, K32, Np); // group 0
         // ngroups is a multiple of 3 (chunk_len is a multiple of 6*LP; a ragged last chunk is rounded
         // up and reads zero rows of X), so the body is straight-line code: no exits inside a rotation.
+        // The 3*LP loads of a group alternate with its first 3*LP MFMAs (they are needed a group later, so they must not
+        // trail to the end of this one): the two waves of a SIMD run in lockstep, and a burst of loads at the top of the
+        // group leaves the MFMA pipe idle in both.
+#if CMF_HXT_INTERLEAVE
+#define HXT_SCHED()                                                                   \
+    do {                                                                              \
+        constexpr int per = (2 * LP * LP >= 6 * LP) ? 1 : 0; /* loads in the first part of the group only */ \
+        _Pragma("unroll") for (int q = 0; q < 3 * LP; ++q) {                          \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, per, 0);                      \
+        }                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * LP * LP - per * 3 * LP, 0);   \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+    } while (0)
+#else
+#define HXT_SCHED() do { } while (0)
+#endif
         for (int g = 0; g < ngroups; g += 3) {
             const int g3 = (g + 3 < ngroups) ? g + 3 : g;
             hxt_load<LP>(E2, O2, B2, hr, xr, hoff, xoff, 2 * LP * (g + 2), K32, Np);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!CMF_HXT_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
             hxt_group<LP>(acc, E0, O0, E1, O1, B1);
+            HXT_SCHED();
             hxt_load<LP>(E0, O0, B0, hr, xr, hoff, xoff, 2 * LP * (g + 3), K32, Np);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!CMF_HXT_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
             hxt_group<LP>(acc, E1, O1, E2, O2, B2);
+            HXT_SCHED();
             hxt_load<LP>(E1, O1, B1, hr, xr, hoff, xoff, 2 * LP * (g3 + 1), K32, Np);
-            __builtin_amdgcn_sched_barrier(0);
+            if (!CMF_HXT_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
             hxt_group<LP>(acc, E2, O2, E0, O0, B0);
+            HXT_SCHED();
         }
+#undef HXT_SCHED
     }
 
     // store: acc[a][r] -> lag lag0+a, k = kb*32 + crow(r,h), n = nb*32 + i
