@@ -653,13 +653,13 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
         hxt_load<LP>(E1, O1, B1, hr, xr, hoff, xoff, 2 * LP, K32, Np); // group 0
         // ngroups is a multiple of 3 (chunk_len is a multiple of 6*LP; a ragged last chunk is rounded
         // up and reads zero rows of X), so the body is straight-line code: no exits inside a rotation.
-        // The 3*LP loads of a group alternate with its first 3*LP MFMAs (they are needed a group later, so they must not
+        // The 3*LP loads of a group go one per two MFMAs beside its first 6*LP MFMAs (they are needed a group later, so they must not
         // trail to the end of this one): the two waves of a SIMD run in lockstep, and a burst of loads at the top of the
         // group leaves the MFMA pipe idle in both.
 #if CMF_HXT_INTERLEAVE
 #define HXT_SCHED()                                                                   \
     do {                                                                              \
-        constexpr int per = (2 * LP * LP >= 6 * LP) ? 1 : 0; /* loads in the first part of the group only */ \
+        constexpr int per = (2 * LP * LP >= 9 * LP) ? 2 : ((2 * LP * LP >= 6 * LP) ? 1 : 0); /* the loads stay in the first part of the group */ \
         _Pragma("unroll") for (int q = 0; q < 3 * LP; ++q) {                          \
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                        \
             __builtin_amdgcn_sched_group_barrier(0x008, per, 0);                      \
