@@ -269,10 +269,10 @@ def main():
     # ---- roofline of the dominant kernel = the class with the largest share of the timed region; durations from
     # the HIP event pairs recorded inside the timed loop above (rank 0's shard) ----
     PMC_NAMES = {"transconv": "void transconv_kernel<20>", "hxt": "void hxt_kernel<5>", "conv_t": "void conv2_kernel<1>",
-                 "conv_loss_store": "void conv3_kernel<3>", "conv": "void conv2_kernel<0>", "conv_loss": "void conv2_kernel<2>"}
+                 "conv_loss_store": "void conv3_kernel<3>", "conv": "void conv2_kernel<0>", "conv_loss": "void conv3_kernel<2>"}
     DESCR = {"transconv": "transconv_kernel<LT> (W' x data and W' x est, mult.jl:47-48)", "hxt": "hxt_kernel<LP> (H_shift x data' and H_shift x est', mult.jl:31-34)",
              "conv_t": "conv2_kernel<1> (tensor_conv, est'[n][t], mult.jl:44)", "conv_loss_store": "conv3_kernel<3> (tensor_conv + loss, mult.jl:55-57)",
-             "conv": "conv2_kernel<0> (tensor_conv, mult.jl:28)", "conv_loss": "conv2_kernel<2> (tensor_conv + loss, mult.jl:55-57)"}
+             "conv": "conv2_kernel<0> (tensor_conv, mult.jl:28)", "conv_loss": "conv3_kernel<2> (tensor_conv + loss, mult.jl:55-57)"}
     if rank == 0:
         kern = {}
         timer = rule if world == 1 else rule.engine
@@ -298,9 +298,9 @@ def main():
         traffic, traffic_src = None, None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload, same kernel)
             if args.config in (2, 4) and world == 1 and not args.T:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_summary.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01k_pmc_summary.json")))
                 traffic = pm[PMC_NAMES[dom]]["hbm_bytes_corrected"]
-                traffic_src = "profiles/r01h_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes"
+                traffic_src = "profiles/r01k_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes"
         except Exception:
             pass
         out["roofline"] = {"bound": "mfma", "kernel": DESCR[dom] + ("" if world == 1 else f" on rank 0's shard of {Tl} columns"),
@@ -311,13 +311,13 @@ def main():
     if rank == 0 and alg == "mult":
         # BASELINE.json's metric also asks for the achieved HBM rate.  Algorithmic bytes per iteration
         # (est never round-tripped): B_iter = 12*N*T + 48*K*N*L + 40*K*T; measured bytes
-        # per iteration = sum of the PMC-corrected traffic of the four big launches (profiles/r01h_pmc_summary.json).
+        # per iteration = sum of the PMC-corrected traffic of the four big launches (profiles/r01k_pmc_summary.json).
         B_iter = 12.0 * N * T + 48.0 * K * N * L + 40.0 * K * T
         hbm = {"algorithmic_bytes_per_iter": B_iter, "achieved_algorithmic_GBps": B_iter * out["value"] / 1e9,
                "peak_GBps": 8000.0, "note": "the path is fp32-MFMA-bound (intensity ~700 flop/B), not HBM-bound"}
         try:
             if args.config in (2, 4) and world == 1 and not args.T:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01h_pmc_summary.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01k_pmc_summary.json")))
                 meas = sum(pm[k]["hbm_bytes_corrected"] for k in ("void hxt_kernel<5>", "void conv2_kernel<1>",
                                                                  "void transconv_kernel<20>", "void conv3_kernel<3>"))
                 hbm["measured_bytes_per_iter"] = meas
