@@ -574,3 +574,89 @@ def test_conv_kernel_variants(cmf, oracle, N, T, K, L, variant):
     Wo, Ho, lo, _ = oracle.fit_pgd(data, W0, H0, max_itr=3)
     np.testing.assert_allclose(lp, lo[1:], rtol=REL_LOSS)
     assert frob_rel(Wp, Wo) < REL_FACTORS and frob_rel(Hp, Ho) < REL_FACTORS
+
+
+def _random_shapes(n, seed):
+    """Seeded ragged shapes: every kernel-selection boundary gets hit (K % 32 == 0 or not, one or several k blocks and
+    lag blocks, N and T around the 64 / 128 / 512 tile edges, T shorter than L)."""
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for _ in range(n):
+        K = int(rng.choice([1, 2, 3, 5, 17, 31, 32, 33, 64]))
+        L = int(rng.choice([1, 2, 3, 7, 19, 20, 31, 32, 33, 40]))
+        N = int(rng.choice([1, 2, 31, 63, 64, 65, 127, 128, 129, 200, 257]))
+        T = int(rng.choice([1, 2, L, L + 1, 63, 64, 65, 127, 128, 129, 511, 512, 513, 700, 1100]))
+        shapes.append((N, max(T, 1), K, L))
+    return shapes
+
+
+@pytest.mark.parametrize("N,T,K,L", _random_shapes(28, 2024))
+def test_random_shapes_primitives_and_iteration(cmf, oracle, N, T, K, L):
+    """tensor_conv, tensor_transconv and one regularised MU iteration on seeded ragged shapes (both conv kernels where
+    K % 32 == 0), against the fp64 restatement."""
+    W, H, X = rand_problem(N * 7919 + T * 31 + K * 7 + L, N, T, K, L)
+    ref_c, ref_t = oracle.tensor_conv(W, H), oracle.tensor_transconv(W, X)
+    got_c, got_t = cmf.tensor_conv(W, H), cmf.tensor_transconv(W, X)
+    np.testing.assert_allclose(got_c, ref_c, rtol=2e-5, atol=2e-5 * max(np.abs(ref_c).max(), 1e-30))
+    np.testing.assert_allclose(got_t, ref_t, rtol=2e-5, atol=2e-5 * max(np.abs(ref_t).max(), 1e-30))
+    kw = dict(l1W=0.05, l2W=0.3, l1H=0.1, l2H=0.2)
+    Wr, Hr = W.copy(), H.copy()
+    orule = oracle.MultUpdate(X, Wr, Hr)
+    oracle.update_motifs(orule, X, Wr, Hr, l1W=kw["l1W"], l2W=kw["l2W"])
+    lr = oracle.update_feature_maps(orule, X, Wr, Hr, l1H=kw["l1H"], l2H=kw["l2H"])
+    for variant in ((2, 3) if K % 32 == 0 else (0,)):
+        rule = cmf.MultUpdate(X, W, H)
+        rule.set_option("conv_kernel", variant)
+        rule.update_motifs(l1W=kw["l1W"], l2W=kw["l2W"])
+        loss = rule.update_feature_maps(l1H=kw["l1H"], l2H=kw["l2H"])
+        Wg, Hg = rule.download()
+        rule.close()
+        assert frob_rel(Wg, Wr) < 2e-5 and frob_rel(Hg, Hr) < 2e-5
+        assert abs(loss - lr) <= 2e-5 * max(lr, 1e-30)
+
+
+def _random_rule_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        K = int(rng.choice([1, 3, 5, 16, 32]))
+        L = int(rng.choice([1, 2, 5, 12, 20, 31]))
+        N = int(rng.choice([2, 31, 64, 65, 130]))
+        T = int(rng.choice([L + 2, 63, 64, 129, 300, 513, 777]))
+        out.append((N, T, K, L))
+    return out
+
+
+@pytest.mark.parametrize("N,T,K,L", _random_rule_shapes(12, 77))
+def test_random_shapes_hals_and_pgd(cmf, oracle, N, T, K, L):
+    """One HALS iteration and two PGD iterations (plain and masked loss) on seeded ragged shapes against the oracle."""
+    rng = np.random.default_rng(N + 13 * T + 101 * K + 1009 * L)
+    data = np.asfortranarray(rng.random((N, T)))
+    W0 = np.asfortranarray(rng.random((K, N, L)))
+    H0 = np.asfortranarray(rng.random((K, T)))
+    est = oracle.tensor_conv(W0, H0)
+    s = np.sqrt(abs(np.vdot(data, est) / np.vdot(est, est)))  # the scaling of init_rand (model.jl:118-122): est ~ data,
+    W0 *= s                                                     # otherwise the first residual is two orders above the
+    H0 *= s                                                     # data and fp32 keeps 3 digits of what survives the clamp
+    reg = dict(l1W=0.05, l2W=0.2, l1H=0.1, l2H=0.3)
+    rule = cmf.HALSUpdate(data, W0, H0)
+    rule.update_motifs(l1W=reg["l1W"], l2W=reg["l2W"])
+    loss = rule.update_feature_maps(l1H=reg["l1H"], l2H=reg["l2H"])
+    Wg, Hg = rule.download()
+    rule.close()
+    Wr, Hr, lh, _ = oracle.c_fit_hals(data, W0, H0, max_itr=1, check_convergence=False, **reg)
+    assert frob_rel(Wg, Wr) < 5e-5 and frob_rel(Hg, Hr) < 1e-4
+    assert abs(loss - lh[-1]) <= 5e-5 * lh[-1]
+    mask = (rng.random((N, T)) > 0.3).astype(np.float64)
+    for m in (None, mask):
+        pg = cmf.PGDUpdate(data, W0, H0)
+        lf = cmf.SquareLoss() if m is None else cmf.MaskedLoss(cmf.SquareLoss(), m)
+        lg = []
+        for _ in range(2):
+            pg.update_motifs(loss_func=lf)
+            lg.append(pg.update_feature_maps(loss_func=lf))
+        Wp, Hp = pg.download()
+        pg.close()
+        Wo, Ho, lo, _ = oracle.fit_pgd(data, W0, H0, max_itr=2, mask=m)
+        np.testing.assert_allclose(lg, lo[1:], rtol=REL_LOSS)
+        assert frob_rel(Wp, Wo) < REL_FACTORS and frob_rel(Hp, Ho) < REL_FACTORS
