@@ -80,7 +80,8 @@ def test_sharded_protocol_cpu_gloo(oracle, tmp_path, world, reg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,N,T,K,L,reg", [(2, 130, 900, 32, 20, 0), (3, 40, 333, 5, 10, 1), (1, 48, 300, 4, 8, 0)])
+@pytest.mark.parametrize("world,N,T,K,L,reg", [(2, 130, 900, 32, 20, 0), (3, 40, 333, 5, 10, 1), (1, 48, 300, 4, 8, 0),
+                                                   (4, 70, 517, 32, 20, 1), (2, 65, 256, 64, 33, 0)])
 def test_sharded_hip_engine_gloo(oracle, tmp_path, world, N, T, K, L, reg):
     """Ranks share GPU 0; collectives go through the host (gloo).  fp32 tolerances as in test_gpu_parity."""
     iters = 6
