@@ -315,9 +315,11 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     d.PADL = (int)rup(L - 1, 32) + 32;
     d.TP = d.PADL + (int)rup(Tl + L, 512) + 256;
     d.Lp = L <= 32 ? (int)rup(L, 4) : (int)rup(L, 32);
-    if ((double)d.Lp * d.Np * d.K32 * 4.0 >= 2147483648.0 || (double)d.TP * d.K32 * 4.0 >= 2147483648.0) {
+    if ((double)d.Lp * d.Np * d.K32 * 4.0 >= 2147483648.0 || (double)d.TP * d.K32 * 4.0 >= 2147483648.0 ||
+        64.0 * d.TP * 4.0 >= 2147483648.0 || 64.0 * d.Np * 4.0 >= 2147483648.0) {
         delete h;
-        return fail(CMF_ERR_UNSUPPORTED, "W (L*N*K) or H (T*K) exceeds the 2 GiB the kernels' 32-bit buffer offsets address");
+        return fail(CMF_ERR_UNSUPPORTED, "W (L*N*K), H (T*K) or a 64-row block of est (64*T or 64*N) exceeds the 2 GiB the "
+                                         "kernels' 32-bit buffer offsets address");
     }
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     plan(h, h->n_cu);
