@@ -162,6 +162,7 @@ def main():
         from cmf_jl_amd.sharded import ShardedMultUpdate
 
         rule = ShardedMultUpdate(data, W0, H0, device=local_rank)
+        overlap_env = os.environ.get("CMF_ALLREDUCE_OVERLAP")  # "0" / "1" force it; default: probe both forms
 
         def step():
             rule.update_motifs(l1W=reg_kw["l1W"], l2W=reg_kw["l2W"])
@@ -192,6 +193,21 @@ def main():
         return el, ls
 
     loss0 = rule.compute_loss()
+    probe = None
+    if world > 1:
+        # Two forms of the W phase exist (sharded.py): one all-reduce of [numW | denomW] after both contractions, or
+        # numW contracted and all-reduced right after the H update, underneath the loss conv and the denominator
+        # contraction.  Which one is faster depends on the all-reduce time of this node: time a few steps of each
+        # (max over ranks, so every rank takes the same decision) and keep the faster for the timed region.
+        if overlap_env in ("0", "1"):
+            rule.set_overlap(overlap_env == "1")
+        else:
+            probe = {}
+            for form in (False, True):
+                rule.set_overlap(form)
+                timed(2, 0)
+                probe["overlap" if form else "single"] = timed(0, 5)[0] / 5
+            rule.set_overlap(probe["overlap"] < probe["single"])
     # The timed region carries HIP event pairs around every fourth launch of each contraction kernel (option "profile": events on the
     # launch stream), so the per-kernel durations of the roofline block are measured live over these very steps.
     prof = (rule if world == 1 else rule.engine) if alg == "mult" else None
@@ -201,7 +217,7 @@ def main():
     dt, losses = timed(0, args.steps)
     inloop = {}
     if prof is not None:
-        for name in ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv"):
+        for name in ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "hxt_num", "hxt_den", "transconv"):
             kms, n = prof.kernel_times(name)
             if n:
                 inloop[name] = (kms, n)
@@ -256,6 +272,8 @@ def main():
             "executed_flops_per_iter": F_iter * 6.0 / 7.0 if alg == "mult" else F_iter,
             "est_reuse": "the est of mult.jl:55 is kept for the next mult.jl:28 (same W, H): 6 of the 7 contractions "
                          "are executed, results bitwise identical; ms_per_step_no_reuse runs all 7",
+            "allreduce_overlap": (bool(rule.overlap) if world > 1 else None),
+            "allreduce_overlap_probe_ms": ({k: 1e3 * v for k, v in probe.items()} if probe else None),
             "ms_per_step_without_event_pairs": (1e3 * dt_unprofiled / args.steps) if dt_unprofiled else None,
             "ms_per_step_no_reuse": (1e3 * dt_noreuse) if dt_noreuse else None,
             "ms_per_step_gram": (1e3 * dt_gram) if dt_gram else None,
@@ -268,9 +286,10 @@ def main():
 
     # ---- roofline of the dominant kernel = the class with the largest share of the timed region; durations from
     # the HIP event pairs recorded inside the timed loop above (rank 0's shard) ----
-    PMC_NAMES = {"transconv": "void transconv_kernel<20>", "hxt": "void hxt_kernel<5>", "conv_t": "void conv2_kernel<1>",
+    PMC_NAMES = {"transconv": "void transconv_kernel<20>", "hxt": "void hxt_kernel<5>", "hxt_num": "void hxt_kernel<5>", "hxt_den": "void hxt_kernel<5>", "conv_t": "void conv2_kernel<1>",
                  "conv_loss_store": "void conv3_kernel<3>", "conv": "void conv2_kernel<0>", "conv_loss": "void conv3_kernel<2>"}
-    DESCR = {"transconv": "transconv_kernel<LT> (W' x data and W' x est, mult.jl:47-48)", "hxt": "hxt_kernel<LP> (H_shift x data' and H_shift x est', mult.jl:31-34)",
+    DESCR = {"hxt_num": "hxt_kernel<LP> (H_shift x data', mult.jl:32)", "hxt_den": "hxt_kernel<LP> (H_shift x est', mult.jl:33)",
+             "transconv": "transconv_kernel<LT> (W' x data and W' x est, mult.jl:47-48)", "hxt": "hxt_kernel<LP> (H_shift x data' and H_shift x est', mult.jl:31-34)",
              "conv_t": "conv2_kernel<1> (tensor_conv, est'[n][t], mult.jl:44)", "conv_loss_store": "conv3_kernel<3> (tensor_conv + loss, mult.jl:55-57)",
              "conv": "conv2_kernel<0> (tensor_conv, mult.jl:28)", "conv_loss": "conv3_kernel<2> (tensor_conv + loss, mult.jl:55-57)"}
     if rank == 0:

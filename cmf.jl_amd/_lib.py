@@ -26,7 +26,7 @@ SYMBOLS = [
     "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_fit", "cmf_converged",
     "cmf_hals_update_motifs", "cmf_hals_update_feature_maps",
     "cmf_pgd_reset", "cmf_set_mask", "cmf_pgd_update_motifs", "cmf_pgd_update_feature_maps", "cmf_pgd_get_steps",
-    "cmf_w_partial", "cmf_w_apply", "cmf_h_update", "cmf_loss_partial",
+    "cmf_w_partial", "cmf_w_partial_num", "cmf_w_partial_den", "cmf_w_apply", "cmf_h_update", "cmf_loss_partial",
     "cmf_loss_partial_async", "cmf_scalar_ptr", "cmf_set_scalar_buffer",
     "cmf_numden_ptr", "cmf_set_numden_buffer", "cmf_halo_ptr", "cmf_set_halo_buffer", "cmf_halo_pack", "cmf_halo_unpack",
     "cmf_tensor_conv", "cmf_tensor_transconv", "cmf_init_rand", "cmf_gen_synthetic",
@@ -86,6 +86,8 @@ def load():
     sig("cmf_pgd_update_feature_maps", [vp, dbl, dbl, cint, pd])
     sig("cmf_pgd_get_steps", [vp, pd, pd])
     sig("cmf_w_partial", [vp])
+    sig("cmf_w_partial_num", [vp])
+    sig("cmf_w_partial_den", [vp])
     sig("cmf_w_apply", [vp, dbl, dbl])
     sig("cmf_h_update", [vp, dbl, dbl])
     sig("cmf_loss_partial", [vp, pd])

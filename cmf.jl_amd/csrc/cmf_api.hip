@@ -113,7 +113,7 @@ struct cmf_handle_s {
     // in-loop kernel timing (option "profile"): HIP event pairs around the contraction launches, on the launch stream
     bool prof = false;
     int prof_every = 1;          // bracket every n-th launch of a class (option value n)
-    int prof_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int prof_seen[16] = {0};
     struct ProfRec { hipEvent_t a, b; int cls; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
@@ -381,8 +381,8 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
 // kernel launchers
 // ------------------------------------------------------------------------------------------
 // kernel classes of the "profile" option
-enum { PROF_CONV = 0, PROF_CONV_T, PROF_CONV_LOSS, PROF_CONV_LOSS_STORE, PROF_HXT, PROF_TRANSCONV, PROF_OTHER, PROF_NCLS };
-static const char *kProfNames[PROF_NCLS] = {"conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv", "other"};
+enum { PROF_CONV = 0, PROF_CONV_T, PROF_CONV_LOSS, PROF_CONV_LOSS_STORE, PROF_HXT, PROF_TRANSCONV, PROF_HXT_NUM, PROF_HXT_DEN, PROF_OTHER, PROF_NCLS };
+static const char *kProfNames[PROF_NCLS] = {"conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv", "hxt_num", "hxt_den", "other"};
 
 struct ProfScope {
     cmf_handle_s *h;
@@ -430,7 +430,7 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
 
 static int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int NpX, int nsrc, float *slabs, int nchunks, int chunk_len)
 {
-    ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : PROF_OTHER);
+    ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : (nsrc == 1 && X0 == h->X) ? PROF_HXT_NUM : (nsrc == 1 && X0 == h->est && h->est_kind == 1) ? PROF_HXT_DEN : PROF_OTHER);
     const CmfDims &d = h->d;
     HxtParams p;
     p.H = h->H; p.X0 = X0; p.X1 = X1; p.slabs = slabs;
@@ -513,6 +513,23 @@ static int w_partial_impl(cmf_handle_s *h)
     h->est_kind = 1;
     CMFTRY(launch_hxt(h));                                  // mult.jl:31-34
     return launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks, (size_t)2 * d.L * d.K32 * d.Np);
+}
+
+// The two halves of w_partial_impl as separate steps (same arithmetic, the sources contracted one at a time): the
+// numerator needs H only, so a sharded host can compute and all-reduce it while the loss conv and the denominator
+// contraction are still running.
+static int w_partial_half_impl(cmf_handle_s *h, int den)
+{
+    const CmfDims &d = h->d;
+    const size_t LKN = (size_t)d.L * d.K32 * d.Np;
+    if (den) {
+        if (!(h->reuse_est && h->est_kind == 1))
+            CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
+        h->est_kind = 1;
+    }
+    const float *src = den ? h->est : h->X;
+    CMFTRY(launch_hxt_on(h, src, src, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1)); // mult.jl:31-34, one source
+    return launch_slab_sum(h, h->numden + (den ? LKN : 0), h->wslabs, h->hxt_nchunks1, LKN);
 }
 
 static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W)
@@ -696,6 +713,18 @@ int cmf_w_partial(cmf_handle h)
 {
     CMFTRY(check_ready(h, true));
     return w_partial_impl(h);
+}
+
+int cmf_w_partial_num(cmf_handle h)
+{
+    CMFTRY(check_ready(h, true));
+    return w_partial_half_impl(h, 0);
+}
+
+int cmf_w_partial_den(cmf_handle h)
+{
+    CMFTRY(check_ready(h, true));
+    return w_partial_half_impl(h, 1);
 }
 
 int cmf_w_apply(cmf_handle h, double l1W, double l2W)

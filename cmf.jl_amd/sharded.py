@@ -103,6 +103,12 @@ class HipShardEngine:
     def w_partial(self):
         check(self._lib.cmf_w_partial(self._h))
 
+    def w_partial_num(self):
+        check(self._lib.cmf_w_partial_num(self._h))
+
+    def w_partial_den(self):
+        check(self._lib.cmf_w_partial_den(self._h))
+
     def w_apply(self, l1W, l2W):
         check(self._lib.cmf_w_apply(self._h, float(l1W), float(l2W)))
 
@@ -164,7 +170,7 @@ class ShardedMultUpdate(AbstractCFUpdate):
     its block).  The rule methods have the single-GPU rule's signatures and return the global loss
     on every rank."""
 
-    def __init__(self, data, W, H, device=None, group=None, engine_cls=HipShardEngine):
+    def __init__(self, data, W, H, device=None, group=None, engine_cls=HipShardEngine, overlap=False):
         import torch
         import torch.distributed as dist
 
@@ -188,6 +194,11 @@ class ShardedMultUpdate(AbstractCFUpdate):
         halo_r = min(L - 1, T - t1)
         dev = _lib.default_device() if device is None else device
         self._gathered = None
+        # overlap=True: numW (which needs H only) is contracted and all-reduced right after the H update, underneath
+        # the loss conv and the denominator contraction, so only the denomW half of the all-reduce stays exposed
+        self.overlap = bool(overlap)
+        self._num_work = None     # pending async all-reduce of the numW half
+        self._num_ready = False   # the numW half of the buffer belongs to the current H
         self.engine = engine_cls(data[:, t0:t1 + halo_r], W, H[:, t0:t1], t0, T, dev)
         # data_norm = norm(data) over all shards (mult.jl:13)
         ss = self._allreduce_scalar(self.engine.data_sumsq())
@@ -232,16 +243,51 @@ class ShardedMultUpdate(AbstractCFUpdate):
         eng.halo_unpack(self.has_left, self.has_right)
 
     # ---- the rule ---------------------------------------------------------------------------
+    def _allreduce_async(self, t):
+        """Sum over ranks without blocking the compute stream (RCCL); returns a work handle or None when done."""
+        if t.is_cuda and self.backend == "nccl":
+            return self.dist.all_reduce(t, group=self.group, async_op=True)
+        self._allreduce(t)
+        return None
+
+    def set_overlap(self, flag):
+        """Switch between the two forms of the W phase; a numW all-reduce still in flight is completed first."""
+        if self._num_work is not None:
+            self._num_work.wait()
+            self._num_work = None
+        self._num_ready = False
+        self.overlap = bool(flag)
+
+    def _start_num(self):
+        half = self.engine.numden.numel() // 2
+        self.engine.w_partial_num()
+        self._num_work = self._allreduce_async(self.engine.numden[:half])
+        self._num_ready = True
+
     def update_motifs(self, data=None, W=None, H=None, l1W=0, l2W=0, **kwargs):
-        """update_motifs!: mult.jl:23-39, with the single all-reduce of [numW | denomW]."""
-        self.engine.w_partial()
-        self._allreduce(self.engine.numden)
+        """update_motifs!: mult.jl:23-39, with the single all-reduce of [numW | denomW] (in two halves when
+        overlap is on: the numW half is usually already in flight, started by the previous update_feature_maps!)."""
+        if self.overlap:
+            half = self.engine.numden.numel() // 2
+            if not self._num_ready:
+                self._start_num()
+            self.engine.w_partial_den()
+            self._allreduce(self.engine.numden[half:])
+            if self._num_work is not None:
+                self._num_work.wait()
+                self._num_work = None
+            self._num_ready = False
+        else:
+            self.engine.w_partial()
+            self._allreduce(self.engine.numden)
         self.engine.w_apply(l1W, l2W)
 
     def update_feature_maps(self, data=None, W=None, H=None, l1H=0, l2H=0, **kwargs):
         """update_feature_maps!: mult.jl:42-58 -> global loss."""
         self.engine.h_update(l1H, l2H)
         self._exchange_halos()
+        if self.overlap:
+            self._start_num()  # for the next update_motifs!: H and its halos are final now
         return self.compute_loss()
 
     def compute_loss(self):
@@ -276,4 +322,7 @@ class ShardedMultUpdate(AbstractCFUpdate):
         return Wl, Hg
 
     def close(self):
+        if self._num_work is not None:
+            self._num_work.wait()
+            self._num_work = None
         self.engine.close()

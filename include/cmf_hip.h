@@ -162,6 +162,12 @@ int cmf_converged(const double *loss_hist, int64_t len, int64_t patience, double
  *   <all-reduce the scalar>; loss = sqrt(sum) / data_norm
  * cmf_update_motifs == cmf_w_partial + cmf_w_apply on one rank. */
 int cmf_w_partial(cmf_handle h);
+/* cmf_w_partial in two steps, one source each (mult.jl:31-34): cmf_w_partial_num fills the numW half of the
+ * [numW | denomW] buffer from H and data alone (legal as soon as H and its halos are final, i.e. right after the halo
+ * exchange of the previous H update), cmf_w_partial_den the denomW half (est = conv(W,H) first when it is not
+ * current).  A sharded host can then all-reduce numW while the loss conv and the denominator contraction run. */
+int cmf_w_partial_num(cmf_handle h);
+int cmf_w_partial_den(cmf_handle h);
 int cmf_w_apply(cmf_handle h, double l1W, double l2W);
 int cmf_h_update(cmf_handle h, double l1H, double l2H);
 int cmf_loss_partial(cmf_handle h, double *sumsq);

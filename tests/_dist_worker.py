@@ -36,7 +36,7 @@ def main():
         from shard_engine_cpu import OracleShardEngine as Eng
     else:
         Eng = HipShardEngine
-    rule = ShardedMultUpdate(data, W0, H0, device=0, engine_cls=Eng)
+    rule = ShardedMultUpdate(data, W0, H0, device=0, engine_cls=Eng, overlap=os.environ.get("CMF_TEST_OVERLAP", "0") == "1")
     opt = cmf.AlternatingOptimizer(rule, iters, np.inf)
     res = cmf.fit(opt, data, L, K, W0, H0, check_convergence=False, **kw)
     rule.close()

@@ -65,6 +65,24 @@ class OracleShardEngine:
             den[:, :, l] = Hs @ est.T
         self.numden[:] = torch.from_numpy(np.concatenate([num.ravel(), den.ravel()]))
 
+    def w_partial_num(self):
+        K, N, L = self.W.shape
+        _, Hext = self._est(self.Tl)
+        off = L - 1
+        num = np.zeros((K, N, L))
+        for l in range(L):
+            num[:, :, l] = Hext[:, off - l: off - l + self.Tl] @ self.data.T
+        self.numden[: K * N * L] = torch.from_numpy(num.ravel())
+
+    def w_partial_den(self):
+        K, N, L = self.W.shape
+        est, Hext = self._est(self.Tl)
+        off = L - 1
+        den = np.zeros((K, N, L))
+        for l in range(L):
+            den[:, :, l] = Hext[:, off - l: off - l + self.Tl] @ est.T
+        self.numden[K * N * L:] = torch.from_numpy(den.ravel())
+
     def w_apply(self, l1W, l2W):
         K, N, L = self.W.shape
         nd = self.numden.numpy()

@@ -25,12 +25,13 @@ def _free_port():
     return p
 
 
-def run_ranks(world, engine, out, N, T, K, L, iters, reg, timeout=300, backend="gloo"):
+def run_ranks(world, engine, out, N, T, K, L, iters, reg, timeout=300, backend="gloo", overlap=False):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", CMF_TEST_BACKEND=backend)
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", CMF_TEST_BACKEND=backend,
+                   CMF_TEST_OVERLAP="1" if overlap else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), engine, out,
                                        str(N), str(T), str(K), str(L), str(iters), str(int(reg))],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -64,11 +65,12 @@ def test_partition():
         partition(10, 8, 20)
 
 
-@pytest.mark.parametrize("world,reg", [(2, 0), (3, 1)])
-def test_sharded_protocol_cpu_gloo(oracle, tmp_path, world, reg):
+@pytest.mark.parametrize("world,reg,overlap", [(2, 0, False), (3, 1, False), (2, 1, True)])
+def test_sharded_protocol_cpu_gloo(oracle, tmp_path, world, reg, overlap):
+    """overlap=True is the two-step form of the W partial sums (numW started right after the H update)."""
     N, T, K, L, iters = 17, 101, 3, 6, 8
     out = str(tmp_path / "res.npz")
-    got = run_ranks(world, "cpu", out, N, T, K, L, iters, reg)
+    got = run_ranks(world, "cpu", out, N, T, K, L, iters, reg, overlap=overlap)
     data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=L, seed=1234)
     W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
     kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2) if reg else {}
@@ -97,12 +99,13 @@ def test_sharded_hip_engine_gloo(oracle, tmp_path, world, N, T, K, L, reg):
 
 
 @pytest.mark.gpu
-def test_sharded_hip_engine_rccl_single_rank(oracle, tmp_path):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_sharded_hip_engine_rccl_single_rank(oracle, tmp_path, overlap):
     """The RCCL transport itself (backend "nccl"): a one-GPU box can only form a 1-rank group, which still sends the
     [numW | denomW] buffer and the loss scalar through RCCL's all-reduce on the library's stream."""
     N, T, K, L, iters = 130, 900, 32, 20, 6
     out = str(tmp_path / "res.npz")
-    got = run_ranks(1, "hip", out, N, T, K, L, iters, 0, backend="nccl")
+    got = run_ranks(1, "hip", out, N, T, K, L, iters, 0, backend="nccl", overlap=overlap)
     data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=L, seed=1234)
     W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
     Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False)
@@ -169,3 +172,20 @@ def test_sharded_full_size_matches_single_gpu(tmp_path):
     # same kernels on different tilings of T: fp32 summation-order differences only
     np.testing.assert_allclose(got["loss_hist"], losses, rtol=1e-5)
     assert frob_rel(got["W"], W) < 1e-5 and frob_rel(got["H"], H) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,N,T,K,L,reg", [(2, 130, 900, 32, 20, 1), (3, 40, 333, 5, 10, 0)])
+def test_sharded_hip_engine_overlap_form(oracle, tmp_path, world, N, T, K, L, reg):
+    """The two-step W partial sums (cmf_w_partial_num / cmf_w_partial_den, numW started after the H update) on the
+    real engine against the oracle."""
+    iters = 6
+    out = str(tmp_path / "res.npz")
+    got = run_ranks(world, "hip", out, N, T, K, L, iters, reg, overlap=True)
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2) if reg else {}
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False, **kw)
+    np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
+    assert frob_rel(got["W"], Wr) < 1e-4
+    assert frob_rel(got["H"], Hr) < 1e-4
