@@ -505,15 +505,14 @@ static int check_ready(cmf_handle_s *h, bool need_data)
     return CMF_OK;
 }
 
-static int w_partial_impl(cmf_handle_s *h, bool sum_slabs = true)
+static int w_partial_impl(cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
     if (!(h->reuse_est && h->est_kind == 1))
         CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
     h->est_kind = 1;
     CMFTRY(launch_hxt(h));                                  // mult.jl:31-34
-    // (one rank, no all-reduce in between: the W update sums the time-chunk slabs itself, in the same order)
-    return sum_slabs ? launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks, (size_t)2 * d.L * d.K32 * d.Np) : CMF_OK;
+    return launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks, (size_t)2 * d.L * d.K32 * d.Np);
 }
 
 // The two halves of w_partial_impl as separate steps (same arithmetic, the sources contracted one at a time): the
@@ -533,12 +532,11 @@ static int w_partial_half_impl(cmf_handle_s *h, int den)
     return launch_slab_sum(h, h->numden + (den ? LKN : 0), h->wslabs, h->hxt_nchunks1, LKN);
 }
 
-static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W, bool from_slabs = false)
+static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W)
 {
     const CmfDims &d = h->d;
     dim3 grid(d.Np / 64, d.KB, d.L);
-    hipLaunchKernelGGL(w_update_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, from_slabs ? h->wslabs : h->numden,
-                       from_slabs ? h->hxt_nchunks : 1,
+    hipLaunchKernelGGL(w_update_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden, 1,
                        d.N, d.K, d.L, d.Np, d.K32, (float)l1W, (float)(2.0 * l2W)); // mult.jl:37-38
     KCHK("w_update_kernel");
     h->est_kind = 0;
@@ -773,8 +771,8 @@ int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
     CMFTRY(check_ready(h, true));
     if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: use the phase-split entries");
     if (h->gram) return gram_w_impl(h, l1W, l2W);
-    CMFTRY(w_partial_impl(h, false));
-    return w_apply_impl(h, l1W, l2W, true);
+    CMFTRY(w_partial_impl(h));
+    return w_apply_impl(h, l1W, l2W);
 }
 
 int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
