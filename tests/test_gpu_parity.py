@@ -660,3 +660,17 @@ def test_random_shapes_hals_and_pgd(cmf, oracle, N, T, K, L):
         Wo, Ho, lo, _ = oracle.fit_pgd(data, W0, H0, max_itr=2, mask=m)
         np.testing.assert_allclose(lg, lo[1:], rtol=REL_LOSS)
         assert frob_rel(Wp, Wo) < REL_FACTORS and frob_rel(Hp, Ho) < REL_FACTORS
+
+
+@pytest.mark.parametrize("N,T,K,L", [(777, 5000, 48, 25), (300, 3000, 64, 40), (1001, 2500, 32, 20)])
+def test_medium_sizes_two_iterations(cmf, oracle, N, T, K, L):
+    """Mid-size shapes that exercise several k blocks / lag blocks / many tiles at once (general-K conv kernel, two k
+    blocks with two lag blocks, N just past a tile edge): two regularised MU iterations against the oracle."""
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=20, seed=99)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=5)
+    kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2)
+    res = cmf.fit_cnmf(data, L=L, K=K, alg=":mult", max_itr=2, check_convergence=False, W_init=W0, H_init=H0,
+                       l1_W=kw["l1W"], l2_W=kw["l2W"], l1_H=kw["l1H"], l2_H=kw["l2H"])
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=2, check_convergence=False, **kw)
+    np.testing.assert_allclose(res.loss_hist, lr, rtol=REL_LOSS)
+    assert frob_rel(res.W, Wr) < REL_FACTORS and frob_rel(res.H, Hr) < REL_FACTORS
