@@ -1021,7 +1021,7 @@ static int hals_ensure(cmf_handle_s *h)
     {   // row pipeline: segment length (multiple of 64, >= 256 so that the sweeps and pushes of one stage
         // touch disjoint columns: see hals_h_stage_kernel)
         const char *env = getenv("CMF_HALS_SEG");
-        int seg = env ? atoi(env) : 256;
+        int seg = env ? atoi(env) : 384; // measured at config 5: 8.60 ms (256), 8.13 (320 and 384), 8.56 (512)
         seg = (int)rup(std::max(seg, 256), 64);
         h->hals_seg = seg;
         h->hals_nseg = (d.Tl + seg - 1) / seg;
