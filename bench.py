@@ -135,7 +135,7 @@ def main():
         else:
             dist.init_process_group(backend)
     if rank == 0:
-        __graft_entry__.build()  # no-op when the in-tree .so files are current
+        __graft_entry__.build(quiet=True)  # no-op when the in-tree .so files are current
     if world > 1:
         dist.barrier()
     import cmf_jl_amd as cmf
