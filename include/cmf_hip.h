@@ -226,7 +226,8 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
 /* In-loop timing: after cmf_set_option(h, "profile", 1) every contraction launch of the update / loss entries is
  * bracketed by a HIP event pair on the launch stream; cmf_kernel_times synchronises and returns the mean duration
  * and the number of launches recorded for one class: "conv" (mult.jl:28), "conv_t" (:44), "conv_loss" /
- * "conv_loss_store" (:55-57), "hxt" (:31-34), "transconv" (:47-48).  Setting the option again restarts it; a value
+ * "conv_loss_store" (:55-57), "hxt" (:31-34; "hxt_num" / "hxt_den" for the one-source launches of cmf_w_partial_num /
+ * cmf_w_partial_den), "transconv" (:47-48).  Setting the option again restarts it; a value
  * n > 1 brackets only every n-th launch of each class (an event pair costs a few microseconds on the stream). */
 int cmf_kernel_times(cmf_handle h, const char *name, double *avg_ms, int64_t *launches);
 
