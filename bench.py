@@ -6,11 +6,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one full MU iteration (update_motifs! + update_feature_maps!, including the
-per-iteration loss scalar read-back; for N > 1 also the RCCL all-reduce of [numW|denomW], the
-H halo exchange and the loss all-reduce).  Inputs (data, W, H) are resident in HBM when the
-timed region starts.  For N > 1 the T axis of the SAME problem is sharded over the ranks
-("scaling": "strong").  Rank 0 prints one JSON line.
+A "step" is one full MU iteration (update_motifs! + update_feature_maps!, alternating.jl:51-54, including the
+per-iteration loss scalar read-back; for N > 1 also the RCCL all-reduce of [numW|denomW|loss tail] and the H halo
+all-gather, both issued by libcmf_hip.so itself).  The K timed steps are ONE cmf_iterate call: the same kernels and
+collectives as K x (cmf_update_motifs; cmf_update_feature_maps), with each loss read one iteration late from pinned
+memory so that the host never stalls the device between iterations (every loss is still read by the host inside
+the timed region).  Inputs (data, W, H) are resident in HBM when the timed region starts.  For N > 1 the T axis of
+the SAME problem is sharded over the ranks ("scaling": "strong").  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -21,6 +23,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PMC_PROFILE = "r02_pmc_summary.json"  # rocprofv3 --pmc passes of this round's kernels (profiles/README.md)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 CONFIGS = {
     1: dict(N=500, T=2000, K=5, L=10),
@@ -98,6 +101,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--T", type=int, default=0, help="override T (debugging only; invalidates the metric)")
+    ap.add_argument("--sustain", type=float, default=3.0, help="seconds of back-to-back iterations after the timed steps (0 = skip)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the no-reuse / Gram-form side measurements (profiling runs: keeps one launch shape per kernel)")
     args = ap.parse_args()
@@ -126,7 +130,9 @@ def main():
         import torch
         import torch.distributed as dist
 
-        # CMF_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+        # The process group is only the rendezvous (ncclUniqueId hand-over, barriers, the max over ranks of the
+        # elapsed time): the data path's collectives are the library's own RCCL calls.  CMF_DIST_BACKEND=gloo with
+        # CMF_TRANSPORT=host rehearses the multi-rank path on a box with fewer GPUs than ranks.
         backend = os.environ.get("CMF_DIST_BACKEND", "nccl")
         local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
@@ -152,21 +158,14 @@ def main():
     if world == 1:
         rule = (cmf.HALSUpdate if alg == "hals" else cmf.MultUpdate)(data, W0, H0, device=local_rank)
 
-        def step():
-            rule.update_motifs(l1W=reg_kw["l1W"], l2W=reg_kw["l2W"])
-            return rule.update_feature_maps(l1H=reg_kw["l1H"], l2H=reg_kw["l2H"])
-
         def sync():
-            pass  # update_feature_maps returns the loss: the stream is already drained
+            pass  # every batch ends with its last loss on the host: the stream is drained
     else:
         from cmf_jl_amd.sharded import ShardedMultUpdate
 
-        rule = ShardedMultUpdate(data, W0, H0, device=local_rank)
+        rule = ShardedMultUpdate(data, W0, H0, device=local_rank,
+                                 transport=os.environ.get("CMF_TRANSPORT", "rccl" if backend == "nccl" else "host"))
         overlap_env = os.environ.get("CMF_ALLREDUCE_OVERLAP")  # "0" / "1" force it; default: probe both forms
-
-        def step():
-            rule.update_motifs(l1W=reg_kw["l1W"], l2W=reg_kw["l2W"])
-            return rule.update_feature_maps(l1H=reg_kw["l1H"], l2H=reg_kw["l2H"])
 
         def sync():
             import torch
@@ -174,14 +173,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def run_steps(n):
+        """n steps = n x (update_motifs!; update_feature_maps!): the losses, all read by the host before this returns."""
+        if n <= 0:
+            return []
+        if alg == "mult":
+            return list(rule.iterate(n, **reg_kw))  # cmf_iterate
+        out_ = []
+        for _ in range(n):  # HALS: the rule's two calls per step
+            rule.update_motifs(l1W=reg_kw["l1W"], l2W=reg_kw["l2W"])
+            out_.append(rule.update_feature_maps(l1H=reg_kw["l1H"], l2H=reg_kw["l2H"]))
+        return out_
+
     def timed(nwarm, nsteps):
-        for _ in range(nwarm):
-            step()
+        run_steps(nwarm)
         sync()
         t0 = time.perf_counter()
-        ls = []
-        for _ in range(nsteps):
-            ls.append(step())
+        ls = run_steps(nsteps)
         sync()
         el = time.perf_counter() - t0
         if world > 1:
@@ -210,7 +218,7 @@ def main():
             rule.set_overlap(probe["overlap"] < probe["single"])
     # The timed region carries HIP event pairs around every fourth launch of each contraction kernel (option "profile": events on the
     # launch stream), so the per-kernel durations of the roofline block are measured live over these very steps.
-    prof = (rule if world == 1 else rule.engine) if alg == "mult" else None
+    prof = rule if alg == "mult" else None
     timed(args.warmup, 0)
     if prof is not None:
         prof.set_option("profile", 4)  # every 4th launch of each class
@@ -225,6 +233,14 @@ def main():
     dt_unprofiled = None
     if prof is not None and world == 1:
         dt_unprofiled, _ = timed(0, args.steps)
+    # Steady state: the timed region above is ~0.1 s; run back-to-back iterations for >= 3 s more (same call) so that the
+    # figure also holds at the clock the card settles to (and the driver's GPU-busy sampling has something to see).
+    sustained = None
+    if alg == "mult" and args.sustain > 0:
+        per = max(dt / max(args.steps, 1), 1e-4)
+        n_sus = int(min(max(args.sustain / per, args.steps), 200000))
+        dt_sus, _ = timed(0, n_sus)
+        sustained = {"seconds": dt_sus, "steps": n_sus, "ms_per_step": 1e3 * dt_sus / n_sus, "iters_per_s": n_sus / dt_sus}
     # Same loop with the reference's redundant est recomputation left in (7 executed contractions
     # instead of 6): reported beside the headline so both numbers come from one run.
     dt_noreuse = None
@@ -280,8 +296,13 @@ def main():
             "ms_per_step_gram_loss": (1e3 * dt_gram2) if dt_gram2 else None,
             "gram_note": "option gram=1: denomW/denomH through Gram matrices (exact rewriting, rounding-level differences), "
                          "loss still by conv; gram=2: loss from Gram sums too.  Not part of `value`.",
-            "whole_iteration_tflops": F_iter * iters_per_s / 1e12,
-            "whole_iteration_mfma_frac": F_iter * iters_per_s / (world * PEAK_FP32_MFMA_TFLOPS * 1e12),
+            # whole-iteration MFMA fraction on EXECUTED flops (6 contractions with est reuse); the 7-contraction figure of
+            # SURVEY.md section 8d is kept under an explicit name: it exceeds the executed one by 7/6 by construction
+            "whole_iteration_tflops_executed": (F_iter * (6.0 / 7.0 if alg == "mult" else 1.0)) * iters_per_s / 1e12,
+            "whole_iteration_mfma_frac": (F_iter * (6.0 / 7.0 if alg == "mult" else 1.0)) * iters_per_s / (world * PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "whole_iteration_mfma_frac_reference_formulation_equivalent": F_iter * iters_per_s / (world * PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "sustained": sustained,
+            "comm": (rule.comm_info() if world > 1 else None),
         }
 
     # ---- roofline of the dominant kernel = the class with the largest share of the timed region; durations from
@@ -294,7 +315,7 @@ def main():
              "conv": "conv2_kernel<0> (tensor_conv, mult.jl:28)", "conv_loss": "conv3_kernel<2> (tensor_conv + loss, mult.jl:55-57)"}
     if rank == 0:
         kern = {}
-        timer = rule if world == 1 else rule.engine
+        timer = rule
         Tl = T // world
         f1 = 2.0 * K * N * (L * Tl - L * (L - 1) / 2)  # one contraction on this rank's columns
         for name in ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv"):
@@ -317,9 +338,9 @@ def main():
         traffic, traffic_src = None, None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload, same kernel)
             if args.config in (2, 4) and world == 1 and not args.T:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01k_pmc_summary.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
                 traffic = pm[PMC_NAMES[dom]]["hbm_bytes_corrected"]
-                traffic_src = "profiles/r01k_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes"
+                traffic_src = f"profiled earlier, not in this run: profiles/{PMC_PROFILE} -- (2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes of this workload"
         except Exception:
             pass
         out["roofline"] = {"bound": "mfma", "kernel": DESCR[dom] + ("" if world == 1 else f" on rank 0's shard of {Tl} columns"),
@@ -336,11 +357,12 @@ def main():
                "peak_GBps": 8000.0, "note": "the path is fp32-MFMA-bound (intensity ~700 flop/B), not HBM-bound"}
         try:
             if args.config in (2, 4) and world == 1 and not args.T:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01k_pmc_summary.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
                 meas = sum(pm[k]["hbm_bytes_corrected"] for k in ("void hxt_kernel<5>", "void conv2_kernel<1>",
                                                                  "void transconv_kernel<20>", "void conv3_kernel<3>"))
-                hbm["measured_bytes_per_iter"] = meas
-                hbm["achieved_measured_GBps"] = meas * out["value"] / 1e9
+                hbm["profiled_bytes_per_iter"] = meas
+                hbm["profiled_GBps"] = meas * out["value"] / 1e9
+                hbm["profiled_source"] = f"profiles/{PMC_PROFILE} (PMC passes run separately, not in this run)"
         except Exception:
             pass
         out["hbm"] = hbm

@@ -15,20 +15,23 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcmf_hip.so")
 
-CMF_OK, CMF_ERR_ARG, CMF_ERR_HIP, CMF_ERR_STATE, CMF_ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+CMF_OK, CMF_ERR_ARG, CMF_ERR_HIP, CMF_ERR_STATE, CMF_ERR_UNSUPPORTED, CMF_ERR_COMM = 0, 1, 2, 3, 4, 5
+CMF_COMM_AUTO, CMF_COMM_RCCL, CMF_COMM_LOOPBACK = 0, 1, 2
+
+# host-collective callbacks of cmf_comm_init_callbacks (include/cmf_hip.h)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int64)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.c_int64)
 
 # every symbol include/cmf_hip.h declares (tests check the library exports each one)
 SYMBOLS = [
     "cmf_version", "cmf_last_error", "cmf_device_count",
-    "cmf_create", "cmf_create_shard", "cmf_destroy", "cmf_set_stream",
-    "cmf_set_option", "cmf_get_data_sumsq", "cmf_set_data_norm",
+    "cmf_create", "cmf_create_shard", "cmf_create_multi", "cmf_destroy", "cmf_set_stream",
+    "cmf_comm_unique_id", "cmf_comm_init_rccl", "cmf_comm_init_callbacks", "cmf_comm_info", "cmf_shard_bounds",
+    "cmf_set_option", "cmf_get_data_sumsq",
     "cmf_set_factors", "cmf_get_factors",
-    "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_fit", "cmf_converged",
+    "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_iterate", "cmf_fit", "cmf_converged",
     "cmf_hals_update_motifs", "cmf_hals_update_feature_maps",
     "cmf_pgd_reset", "cmf_set_mask", "cmf_pgd_update_motifs", "cmf_pgd_update_feature_maps", "cmf_pgd_get_steps",
-    "cmf_w_partial", "cmf_w_partial_num", "cmf_w_partial_den", "cmf_w_apply", "cmf_h_update", "cmf_loss_partial",
-    "cmf_loss_partial_async", "cmf_scalar_ptr", "cmf_set_scalar_buffer",
-    "cmf_numden_ptr", "cmf_set_numden_buffer", "cmf_halo_ptr", "cmf_set_halo_buffer", "cmf_halo_pack", "cmf_halo_unpack",
     "cmf_tensor_conv", "cmf_tensor_transconv", "cmf_init_rand", "cmf_gen_synthetic",
     "cmf_time_kernel", "cmf_kernel_times",
 ]
@@ -66,16 +69,22 @@ def load():
     sig("cmf_device_count", [])
     sig("cmf_create", [pvp, cint, i64, i64, i64, i64, pd])
     sig("cmf_create_shard", [pvp, cint, i64, i64, i64, i64, pd, i64, i64])
+    sig("cmf_create_multi", [pvp, cint, ctypes.POINTER(cint), cint, i64, i64, i64, i64, pd])
+    sig("cmf_comm_unique_id", [vp])
+    sig("cmf_comm_init_rccl", [vp, cint, cint, vp])
+    sig("cmf_comm_init_callbacks", [vp, cint, cint, ALLREDUCE_FN, ALLGATHER_FN, vp])
+    sig("cmf_comm_info", [vp, ctypes.c_char_p, i64])
+    sig("cmf_shard_bounds", [vp, cint, pi64, pi64])
     sig("cmf_destroy", [vp])
     sig("cmf_set_stream", [vp, vp])
     sig("cmf_set_option", [vp, ctypes.c_char_p, cint])
     sig("cmf_get_data_sumsq", [vp, pd])
-    sig("cmf_set_data_norm", [vp, dbl])
     sig("cmf_set_factors", [vp, pd, pd])
     sig("cmf_get_factors", [vp, pd, pd])
     sig("cmf_update_motifs", [vp, dbl, dbl])
     sig("cmf_update_feature_maps", [vp, dbl, dbl, pd])
     sig("cmf_compute_loss", [vp, pd])
+    sig("cmf_iterate", [vp, i64, cint, dbl, dbl, dbl, dbl, pd, pd])
     sig("cmf_fit", [vp, i64, dbl, cint, i64, dbl, cint, dbl, dbl, dbl, dbl, pd, pd, pi64, ctypes.POINTER(cint)])
     sig("cmf_converged", [pd, i64, i64, dbl])
     sig("cmf_hals_update_motifs", [vp, dbl, dbl])
@@ -85,21 +94,6 @@ def load():
     sig("cmf_pgd_update_motifs", [vp, dbl, dbl, cint])
     sig("cmf_pgd_update_feature_maps", [vp, dbl, dbl, cint, pd])
     sig("cmf_pgd_get_steps", [vp, pd, pd])
-    sig("cmf_w_partial", [vp])
-    sig("cmf_w_partial_num", [vp])
-    sig("cmf_w_partial_den", [vp])
-    sig("cmf_w_apply", [vp, dbl, dbl])
-    sig("cmf_h_update", [vp, dbl, dbl])
-    sig("cmf_loss_partial", [vp, pd])
-    sig("cmf_loss_partial_async", [vp])
-    sig("cmf_scalar_ptr", [vp, pvp])
-    sig("cmf_set_scalar_buffer", [vp, vp])
-    sig("cmf_numden_ptr", [vp, pvp, pi64])
-    sig("cmf_set_numden_buffer", [vp, vp])
-    sig("cmf_halo_ptr", [vp, cint, pvp, pi64])
-    sig("cmf_set_halo_buffer", [vp, cint, vp])
-    sig("cmf_halo_pack", [vp])
-    sig("cmf_halo_unpack", [vp, cint, cint])
     sig("cmf_tensor_conv", [cint, i64, i64, i64, i64, pd, pd, pd])
     sig("cmf_tensor_transconv", [cint, i64, i64, i64, i64, pd, pd, pd])
     sig("cmf_init_rand", [cint, i64, i64, i64, i64, u64, pd, pd, pd])

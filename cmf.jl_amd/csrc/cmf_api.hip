@@ -118,6 +118,15 @@ struct cmf_handle_s {
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data, 3 mask .* (tensor_conv(W,H) - data)
+
+    // T-sharded groups (cmf_group.h): the handle the caller holds fronts a group when `group` is set
+    struct cmf_group_s *group = nullptr;
+    bool root_only = false;               // cmf_create_multi's front handle: no device state of its own
+    hipStream_t own_comm_stream = nullptr, comm_stream = nullptr; // overlap form: the numW all-reduce runs here
+    hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;
+    // pipelined loss read-back of cmf_iterate (single handle): two pinned slots + events
+    double *h_ring = nullptr;
+    hipEvent_t ring_ev[2] = {nullptr, nullptr};
 };
 
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
@@ -232,6 +241,7 @@ static void plan(cmf_handle_s *h, int n_cu)
 static void destroy_impl(cmf_handle_s *h)
 {
     if (!h) return;
+    if (h->root_only) { delete h; return; }
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
                       h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3],
@@ -248,6 +258,12 @@ static void destroy_impl(cmf_handle_s *h)
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_c0) (void)hipEventDestroy(h->ev_c0);
+    if (h->ev_c1) (void)hipEventDestroy(h->ev_c1);
+    for (int q = 0; q < 2; ++q)
+        if (h->ring_ev[q]) (void)hipEventDestroy(h->ring_ev[q]);
+    if (h->h_ring) (void)hipHostFree(h->h_ring);
+    if (h->own_comm_stream) (void)hipStreamDestroy(h->own_comm_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -499,6 +515,7 @@ static int read_scalar(cmf_handle_s *h, int slot, double *v)
 static int check_ready(cmf_handle_s *h, bool need_data)
 {
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (h->root_only) return fail(CMF_ERR_STATE, "this entry needs a single-GPU handle, not the front handle of a cmf_create_multi group");
     HIPCHK(hipSetDevice(h->device));
     if (!h->factors_set) return fail(CMF_ERR_STATE, "factors not set: call cmf_set_factors first");
     if (need_data && !h->have_data) return fail(CMF_ERR_STATE, "handle was created without data");
@@ -570,6 +587,56 @@ static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = tru
     return readback ? read_scalar(h, 0, sumsq) : CMF_OK;
 }
 
+static int set_factors_impl(cmf_handle_s *h, const double *W, const double *H)
+{
+    if (!h || !W || !H) return fail(CMF_ERR_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    const CmfDims &d = h->d;
+    const size_t nW = (size_t)d.L * d.N * d.K, nH = (size_t)d.Tl * d.K;
+    CMFTRY(ensure_stage(h, std::max(nW, nH)));
+    // padding must be zero: clear, then scatter the valid entries
+    HIPCHK(hipMemsetAsync(h->Wt, 0, (size_t)d.Lp * d.K32 * d.Np * sizeof(float), h->stream));
+    HIPCHK(hipMemsetAsync(h->Wn, 0, (size_t)d.Lp * d.Np * d.K32 * sizeof(float), h->stream));
+    HIPCHK(hipMemsetAsync(h->H, 0, (size_t)d.TP * d.K32 * sizeof(float), h->stream));
+    HIPCHK(hipMemsetAsync(h->Ht, 0, (size_t)d.K32 * d.TP * sizeof(float), h->stream));
+    HIPCHK(hipMemcpyAsync(h->stage, W, nW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(pack_W_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.N, d.K, d.L, h->Wt, h->Wn, d.Np, d.K32);
+    KCHK("pack_W_kernel");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(h->stage, H, nH * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(pack_H_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.Tl, d.K, h->H, h->Ht, d.K32, d.TP, d.PADL);
+    KCHK("pack_H_kernel");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->factors_set = true;
+    h->est_kind = 0;
+    return CMF_OK;
+}
+
+static int get_factors_impl(cmf_handle_s *h, double *W, double *H)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    CMFTRY(check_ready(h, false));
+    const CmfDims &d = h->d;
+    const size_t nW = (size_t)d.L * d.N * d.K, nH = (size_t)d.Tl * d.K;
+    CMFTRY(ensure_stage(h, std::max(nW, nH)));
+    if (W) {
+        hipLaunchKernelGGL(unpack_W_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.N, d.K, d.L, h->Wn, d.Np, d.K32);
+        KCHK("unpack_W_kernel");
+        HIPCHK(hipMemcpyAsync(W, h->stage, nW * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (H) {
+        hipLaunchKernelGGL(unpack_H_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.Tl, d.K, h->H, d.K32, d.PADL);
+        KCHK("unpack_H_kernel");
+        HIPCHK(hipMemcpyAsync(H, h->stage, nH * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return CMF_OK;
+}
+
+
+#include "cmf_group.h"
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -602,6 +669,16 @@ int cmf_create_shard(cmf_handle *h, int device, int64_t N, int64_t T_local, int6
 
 int cmf_destroy(cmf_handle h)
 {
+    if (h && h->group) {
+        cmf_group_s *g = h->group;
+        std::vector<cmf_handle_s *> shards = g->sh;
+        group_destroy(g); // detaches the shards from the group's buffers
+        for (cmf_handle_s *s : shards) {
+            s->group = nullptr;
+            if (s != h) destroy_impl(s);
+        }
+        h->group = nullptr;
+    }
     destroy_impl(h);
     return CMF_OK;
 }
@@ -609,6 +686,7 @@ int cmf_destroy(cmf_handle h)
 int cmf_set_stream(cmf_handle h, void *hip_stream)
 {
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (h->group) return fail(CMF_ERR_STATE, "a group handle runs on its own per-device streams");
     h->stream = (hipStream_t)hip_stream;
     return CMF_OK;
 }
@@ -616,6 +694,26 @@ int cmf_set_stream(cmf_handle h, void *hip_stream)
 int cmf_set_option(cmf_handle h, const char *name, int value)
 {
     if (!h || !name) return fail(CMF_ERR_ARG, "NULL argument");
+    if (h->group) {
+        cmf_group_s *g = h->group;
+        if (std::strcmp(name, "allreduce_overlap") == 0) {
+            CMFTRY(group_sync(g));
+            g->overlap = value != 0;
+            g->num_ready = false;
+            return CMF_OK;
+        }
+        if (std::strcmp(name, "gram") == 0 && value) return fail(CMF_ERR_STATE, "the Gram form is not available on sharded handles");
+        for (cmf_handle_s *s : g->sh) {
+            cmf_group_s *keep = s->group;
+            s->group = nullptr;
+            const int rc = cmf_set_option(s, name, value);
+            s->group = keep;
+            if (rc != CMF_OK) return rc;
+        }
+        g->num_ready = false;
+        return CMF_OK;
+    }
+    if (std::strcmp(name, "allreduce_overlap") == 0) return CMF_OK; // single GPU: nothing to overlap
     if (std::strcmp(name, "gram") == 0) {
         if (value < 0 || value > 2) return fail(CMF_ERR_ARG, "gram must be 0, 1 or 2");
         if (value && h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "the Gram form is not available on sharded handles");
@@ -650,126 +748,33 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
 int cmf_get_data_sumsq(cmf_handle h, double *sumsq)
 {
     if (!h || !sumsq) return fail(CMF_ERR_ARG, "NULL argument");
+    if (h->group) { *sumsq = h->group->data_sumsq; return CMF_OK; }
     *sumsq = h->data_sumsq;
-    return CMF_OK;
-}
-
-int cmf_set_data_norm(cmf_handle h, double data_norm)
-{
-    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
-    if (!(data_norm >= 0.0)) return fail(CMF_ERR_ARG, "data_norm must be >= 0");
-    h->data_norm = data_norm;
     return CMF_OK;
 }
 
 int cmf_set_factors(cmf_handle h, const double *W, const double *H)
 {
     if (!h || !W || !H) return fail(CMF_ERR_ARG, "NULL argument");
-    HIPCHK(hipSetDevice(h->device));
-    const CmfDims &d = h->d;
-    const size_t nW = (size_t)d.L * d.N * d.K, nH = (size_t)d.Tl * d.K;
-    CMFTRY(ensure_stage(h, std::max(nW, nH)));
-    // padding must be zero: clear, then scatter the valid entries
-    HIPCHK(hipMemsetAsync(h->Wt, 0, (size_t)d.Lp * d.K32 * d.Np * sizeof(float), h->stream));
-    HIPCHK(hipMemsetAsync(h->Wn, 0, (size_t)d.Lp * d.Np * d.K32 * sizeof(float), h->stream));
-    HIPCHK(hipMemsetAsync(h->H, 0, (size_t)d.TP * d.K32 * sizeof(float), h->stream));
-    HIPCHK(hipMemsetAsync(h->Ht, 0, (size_t)d.K32 * d.TP * sizeof(float), h->stream));
-    HIPCHK(hipMemcpyAsync(h->stage, W, nW * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(pack_W_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.N, d.K, d.L, h->Wt, h->Wn, d.Np, d.K32);
-    KCHK("pack_W_kernel");
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpyAsync(h->stage, H, nH * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(pack_H_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.Tl, d.K, h->H, h->Ht, d.K32, d.TP, d.PADL);
-    KCHK("pack_H_kernel");
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->factors_set = true;
-    h->est_kind = 0;
-    return CMF_OK;
+    if (h->group) return group_set_factors(h->group, W, H);
+    return set_factors_impl(h, W, H);
 }
 
 int cmf_get_factors(cmf_handle h, double *W, double *H)
 {
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
-    CMFTRY(check_ready(h, false));
-    const CmfDims &d = h->d;
-    const size_t nW = (size_t)d.L * d.N * d.K, nH = (size_t)d.Tl * d.K;
-    CMFTRY(ensure_stage(h, std::max(nW, nH)));
-    if (W) {
-        hipLaunchKernelGGL(unpack_W_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.N, d.K, d.L, h->Wn, d.Np, d.K32);
-        KCHK("unpack_W_kernel");
-        HIPCHK(hipMemcpyAsync(W, h->stage, nW * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    if (H) {
-        hipLaunchKernelGGL(unpack_H_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.Tl, d.K, h->H, d.K32, d.PADL);
-        KCHK("unpack_H_kernel");
-        HIPCHK(hipMemcpyAsync(H, h->stage, nH * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    return CMF_OK;
-}
-
-int cmf_w_partial(cmf_handle h)
-{
-    CMFTRY(check_ready(h, true));
-    return w_partial_impl(h);
-}
-
-int cmf_w_partial_num(cmf_handle h)
-{
-    CMFTRY(check_ready(h, true));
-    return w_partial_half_impl(h, 0);
-}
-
-int cmf_w_partial_den(cmf_handle h)
-{
-    CMFTRY(check_ready(h, true));
-    return w_partial_half_impl(h, 1);
-}
-
-int cmf_w_apply(cmf_handle h, double l1W, double l2W)
-{
-    CMFTRY(check_ready(h, true));
-    return w_apply_impl(h, l1W, l2W);
-}
-
-int cmf_h_update(cmf_handle h, double l1H, double l2H)
-{
-    CMFTRY(check_ready(h, true));
-    return h_update_impl(h, l1H, l2H);
-}
-
-int cmf_loss_partial(cmf_handle h, double *sumsq)
-{
-    if (!sumsq) return fail(CMF_ERR_ARG, "sumsq is NULL");
-    CMFTRY(check_ready(h, true));
-    return loss_partial_impl(h, sumsq);
-}
-
-int cmf_loss_partial_async(cmf_handle h)
-{
-    CMFTRY(check_ready(h, true));
-    return loss_partial_impl(h, nullptr, false);
-}
-
-int cmf_scalar_ptr(cmf_handle h, void **dev_ptr)
-{
-    if (!h || !dev_ptr) return fail(CMF_ERR_ARG, "NULL argument");
-    *dev_ptr = h->d_scalar;
-    return CMF_OK;
-}
-
-int cmf_set_scalar_buffer(cmf_handle h, void *dev_ptr)
-{
-    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
-    h->d_scalar = dev_ptr ? (double *)dev_ptr : h->d_scalar_own;
-    return CMF_OK;
+    if (h->group) return group_get_factors(h->group, W, H);
+    return get_factors_impl(h, W, H);
 }
 
 int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
 {
+    if (h && h->group) {
+        CMFTRY(group_check_ready(h->group));
+        return group_update_motifs(h->group, l1W, l2W);
+    }
     CMFTRY(check_ready(h, true));
-    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: use the phase-split entries");
+    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator (cmf_comm_init_*) or use the phase-split entries");
     if (h->gram) return gram_w_impl(h, l1W, l2W);
     CMFTRY(w_partial_impl(h));
     return w_apply_impl(h, l1W, l2W);
@@ -778,8 +783,15 @@ int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
 int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
 {
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
+    if (h && h->group) {
+        CMFTRY(group_check_ready(h->group));
+        double ss = 0.0;
+        CMFTRY(group_update_feature_maps(h->group, l1H, l2H, &ss));
+        *loss = std::sqrt(ss) / h->group->data_norm;
+        return CMF_OK;
+    }
     CMFTRY(check_ready(h, true));
-    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: use the phase-split entries");
+    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator (cmf_comm_init_*) or use the phase-split entries");
     if (h->gram) return gram_h_impl(h, l1H, l2H, loss);
     CMFTRY(h_update_impl(h, l1H, l2H));
     double ss = 0.0;
@@ -791,6 +803,10 @@ int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
 int cmf_compute_loss(cmf_handle h, double *loss)
 {
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
+    if (h && h->group) {
+        CMFTRY(group_check_ready(h->group));
+        return group_compute_loss(h->group, loss);
+    }
     CMFTRY(check_ready(h, true));
     double ss = 0.0;
     CMFTRY(loss_partial_impl(h, &ss));
@@ -800,12 +816,14 @@ int cmf_compute_loss(cmf_handle h, double *loss)
 
 int cmf_hals_update_motifs(cmf_handle h, double l1W, double l2W)
 {
+    if (h && h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
     CMFTRY(check_ready(h, true));
     return hals_w_impl(h, l1W, l2W);
 }
 
 int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
 {
+    if (h && h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
     CMFTRY(check_ready(h, true));
     CMFTRY(hals_h_impl(h, l1H, l2H));
@@ -818,6 +836,7 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
 int cmf_set_mask(cmf_handle h, const double *mask)
 {
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (h->group) return fail(CMF_ERR_UNSUPPORTED, "MaskedLoss is supported on single-GPU handles only");
     HIPCHK(hipSetDevice(h->device));
     if (h->sharded) return fail(CMF_ERR_UNSUPPORTED, "MaskedLoss is supported on single-GPU handles only");
     const CmfDims &d = h->d;
@@ -845,12 +864,14 @@ int cmf_pgd_reset(cmf_handle h)
 
 int cmf_pgd_update_motifs(cmf_handle h, double pen_sq, double pen_abs, int nonneg)
 {
+    if (h && h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
     CMFTRY(check_ready(h, true));
     return pgd_w_impl(h, pen_sq, pen_abs, nonneg);
 }
 
 int cmf_pgd_update_feature_maps(cmf_handle h, double pen_sq, double pen_abs, int nonneg, double *loss)
 {
+    if (h && h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
     CMFTRY(check_ready(h, true));
     return pgd_h_impl(h, pen_sq, pen_abs, nonneg, loss);
@@ -873,20 +894,86 @@ int cmf_converged(const double *loss_hist, int64_t len, int64_t patience, double
     return 1;
 }
 
+// n MU iterations on a single-GPU handle without stalling the device between iterations: the loss of iteration i is
+// copied to a pinned slot behind its reduction and read after iteration i+1 has been enqueued
+static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W, double l2W, double l1H, double l2H,
+                          double *losses, double *stamps)
+{
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+    if (h->gram) { // the Gram form reads its sums back inside the entry: plain loop
+        for (int64_t it = 0; it < n; ++it) {
+            if (!eval_mode) CMFTRY(cmf_update_motifs(h, l1W, l2W));
+            CMFTRY(cmf_update_feature_maps(h, l1H, l2H, &losses[it]));
+            if (stamps) stamps[it] = now();
+        }
+        return CMF_OK;
+    }
+    if (!h->h_ring) {
+        HIPCHK(hipHostMalloc(&h->h_ring, 2 * sizeof(double)));
+        for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ring_ev[q], hipEventDisableTiming));
+    }
+    auto collect = [&](int64_t it) -> int {
+        const int slot = (int)(it & 1);
+        HIPCHK(hipEventSynchronize(h->ring_ev[slot]));
+        losses[it] = std::sqrt(h->h_ring[slot]) / h->data_norm;
+        if (stamps) stamps[it] = now();
+        return CMF_OK;
+    };
+    for (int64_t it = 0; it < n; ++it) {
+        if (!eval_mode) { // alternating.jl:51-53
+            CMFTRY(w_partial_impl(h));
+            CMFTRY(w_apply_impl(h, l1W, l2W));
+        }
+        CMFTRY(h_update_impl(h, l1H, l2H)); // :54
+        CMFTRY(loss_partial_impl(h, nullptr, false));
+        const int slot = (int)(it & 1);
+        HIPCHK(hipMemcpyAsync(h->h_ring + slot, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->ring_ev[slot], h->stream));
+        if (it > 0) CMFTRY(collect(it - 1));
+    }
+    if (n > 0) CMFTRY(collect(n - 1));
+    return CMF_OK;
+}
+
+int cmf_iterate(cmf_handle h, int64_t n_iter, int eval_mode, double l1W, double l2W, double l1H, double l2H,
+                double *losses, double *stamps)
+{
+    if (!h || !losses) return fail(CMF_ERR_ARG, "NULL argument");
+    if (n_iter < 0) return fail(CMF_ERR_ARG, "n_iter must be >= 0");
+    if (h->group) {
+        CMFTRY(group_check_ready(h->group));
+        return group_iterate(h->group, n_iter, eval_mode, l1W, l2W, l1H, l2H, losses, stamps);
+    }
+    CMFTRY(check_ready(h, true));
+    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator (cmf_comm_init_*) first");
+    return iterate_single(h, n_iter, eval_mode, l1W, l2W, l1H, l2H, losses, stamps);
+}
+
 int cmf_fit(cmf_handle h, int64_t max_itr, double max_time, int check_convergence, int64_t patience, double tol,
             int eval_mode, double l1W, double l2W, double l1H, double l2H,
             double *loss_hist, double *time_hist, int64_t *n_hist, int *converged_early)
 {
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
     if (!loss_hist || !time_hist || !n_hist) return fail(CMF_ERR_ARG, "NULL output argument");
     if (patience < 1) return fail(CMF_ERR_ARG, "patience must be >= 1 (alternating.jl:30)");
     if (max_itr < 0) return fail(CMF_ERR_ARG, "max_itr must be >= 0");
-    CMFTRY(check_ready(h, true));
-    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "cmf_fit needs an unsharded handle");
+    if (!h->group) {
+        CMFTRY(check_ready(h, true));
+        if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator (cmf_comm_init_*) first");
+    }
     if (converged_early) *converged_early = 0;
     int64_t len = 0;
     CMFTRY(cmf_compute_loss(h, &loss_hist[0])); // alternating.jl:37
     time_hist[0] = 0.0;                        // :38
     len = 1;
+    if (!check_convergence && std::isinf(max_time) && max_time > 0) {
+        // neither stop test can fire (:45, :63-66): exactly max_itr iterations, run as one pipelined batch;
+        // time_hist[i] = the moment the loss of iteration i reached the host
+        CMFTRY(cmf_iterate(h, max_itr, eval_mode, l1W, l2W, l1H, l2H, loss_hist + 1, time_hist + 1));
+        *n_hist = max_itr + 1;
+        return CMF_OK;
+    }
     int64_t itr = 1;
     while (itr <= max_itr && time_hist[len - 1] <= max_time) { // :45
         itr += 1;
@@ -895,6 +982,12 @@ int cmf_fit(cmf_handle h, int64_t max_itr, double max_time, int check_convergenc
         double loss = 0.0;
         CMFTRY(cmf_update_feature_maps(h, l1H, l2H, &loss));              // :54
         double dur = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (h->group && !h->group->one_process && std::isfinite(max_time)) {
+            // one process per shard: every rank follows rank 0's clock, so they all leave the loop together
+            std::vector<double> mine(1, dur), all;
+            CMFTRY(group_gather_doubles(h->group, mine, all));
+            dur = all[0];
+        }
         time_hist[len] = time_hist[len - 1] + dur;                        // :58
         loss_hist[len] = loss;                                            // :59
         ++len;
@@ -907,65 +1000,178 @@ int cmf_fit(cmf_handle h, int64_t max_itr, double max_time, int check_convergenc
     return CMF_OK;
 }
 
-int cmf_numden_ptr(cmf_handle h, void **dev_ptr, int64_t *count)
+// ---- groups: construction ---------------------------------------------------------------------------------------
+int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transport,
+                     int64_t N, int64_t T, int64_t K, int64_t L, const double *data)
 {
-    if (!h || !dev_ptr || !count) return fail(CMF_ERR_ARG, "NULL argument");
-    *dev_ptr = h->numden;
-    *count = (int64_t)2 * h->d.L * h->d.K32 * h->d.Np;
+    if (!out) return fail(CMF_ERR_ARG, "handle pointer is NULL");
+    *out = nullptr;
+    if (!devices || !data) return fail(CMF_ERR_ARG, "NULL argument");
+    if (ndev < 1 || ndev > CMF_MAX_LOCAL) return fail(CMF_ERR_ARG, "ndev must be 1..%d (got %d)", CMF_MAX_LOCAL, ndev);
+    if (N < 1 || T < 1 || K < 1 || L < 1) return fail(CMF_ERR_ARG, "N, T, K, L must all be >= 1");
+    bool all_same = true, distinct = true;
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j) {
+            if (devices[i] != devices[j]) all_same = false;
+            else distinct = false;
+        }
+    int tr;
+    if (transport == CMF_COMM_AUTO) tr = (ndev > 1 && distinct) ? CMF_TR_RCCL : CMF_TR_LOOPBACK;
+    else if (transport == CMF_COMM_RCCL) tr = CMF_TR_RCCL;
+    else if (transport == CMF_COMM_LOOPBACK) tr = CMF_TR_LOOPBACK;
+    else return fail(CMF_ERR_ARG, "unknown transport %d", transport);
+    if (tr == CMF_TR_RCCL && !distinct) return fail(CMF_ERR_ARG, "RCCL needs distinct devices (a device is listed twice)");
+    if (tr == CMF_TR_LOOPBACK && !all_same) return fail(CMF_ERR_ARG, "the loopback transport needs all shards on one device; list distinct devices for RCCL");
+    std::vector<int64_t> t0, t1;
+    group_partition(T, ndev, L, t0, t1);
+    for (int r = 0; r < ndev; ++r)
+        if (ndev > 1 && t1[r] - t0[r] < std::max<int64_t>(L - 1, 1))
+            return fail(CMF_ERR_UNSUPPORTED, "T=%lld is too short to shard over %d devices with L=%lld (every shard needs >= L-1 columns)",
+                        (long long)T, ndev, (long long)L);
+
+    cmf_group_s *g = new cmf_group_s();
+    cmf_handle_s *root = new cmf_handle_s();
+    root->root_only = true;
+    root->group = g;
+    root->device = devices[0];
+    g->nranks = ndev;
+    g->transport = tr;
+    g->one_process = true;
+    g->N = N; g->T = T; g->K = K; g->L = L;
+    g->t0 = t0; g->t1 = t1;
+    auto bail = [&](int rc) { cmf_destroy(root); return rc; };
+    for (int r = 0; r < ndev; ++r) {
+        cmf_handle_s *s = nullptr;
+        // column-major N x T: the block [t0, t1 + halo_r) is contiguous
+        int rc = create_impl(&s, devices[r], N, t1[r] - t0[r], K, L, data + (size_t)t0[r] * N, t0[r], T, ndev > 1);
+        if (rc != CMF_OK) return bail(rc);
+        g->sh.push_back(s);
+        g->rank.push_back(r);
+        s->group = g;
+        rc = group_prepare_shard(s);
+        if (rc != CMF_OK) return bail(rc);
+    }
+    if (tr == CMF_TR_LOOPBACK) // one device: every shard works on shard 0's streams, so the kernels of the loopback collectives are ordered
+        for (cmf_handle_s *s : g->sh) { s->stream = g->sh[0]->stream; s->comm_stream = g->sh[0]->comm_stream; }
+    if (tr == CMF_TR_RCCL) {
+        int rc = rccl_load();
+        if (rc != CMF_OK) return bail(rc);
+        g->comm.assign((size_t)ndev, nullptr);
+        ncclResult_t r_ = g_rccl.CommInitAll(g->comm.data(), ndev, devices);
+        if (r_ != ncclSuccess) return bail(fail(CMF_ERR_COMM, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(r_)));
+    }
+    int rc = group_alloc_buffers(g);
+    if (rc == CMF_OK) rc = group_finish_norm(g);
+    if (rc != CMF_OK) return bail(rc);
+    *out = root;
     return CMF_OK;
 }
 
-int cmf_set_numden_buffer(cmf_handle h, void *dev_ptr)
+int cmf_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(CMF_ERR_ARG, "id128 is NULL");
+    CMFTRY(rccl_load());
+    ncclUniqueId id;
+    RCCLCHK(g_rccl.GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    return CMF_OK;
+}
+
+static int comm_attach(cmf_handle_s *h, int nranks, int rank, int transport, const void *id128,
+                       cmf_allreduce_fn ar, cmf_allgather_fn ag, void *user)
 {
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
-    h->numden = dev_ptr ? (float *)dev_ptr : h->numden_own;
-    return CMF_OK;
-}
-
-int cmf_set_halo_buffer(cmf_handle h, int which, void *dev_ptr)
-{
-    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
-    if (which < 0 || which > 3) return fail(CMF_ERR_ARG, "which must be 0..3");
-    h->halo[which] = dev_ptr ? (float *)dev_ptr : h->halo_own[which];
-    return CMF_OK;
-}
-
-int cmf_halo_ptr(cmf_handle h, int which, void **dev_ptr, int64_t *count)
-{
-    if (!h || !dev_ptr || !count) return fail(CMF_ERR_ARG, "NULL argument");
-    if (which < 0 || which > 3) return fail(CMF_ERR_ARG, "which must be 0..3");
-    *dev_ptr = h->halo[which];
-    *count = (int64_t)(h->d.L - 1) * h->d.K32;
-    return CMF_OK;
-}
-
-int cmf_halo_pack(cmf_handle h)
-{
-    CMFTRY(check_ready(h, false));
+    if (h->group) return fail(CMF_ERR_STATE, "the handle already belongs to a group");
+    if (!h->sharded) return fail(CMF_ERR_STATE, "cmf_comm_init_* needs a handle from cmf_create_shard");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(CMF_ERR_ARG, "bad rank %d of %d", rank, nranks);
     const CmfDims &d = h->d;
-    const int rows = d.L - 1;
-    if (rows < 1) return CMF_OK;
-    hipLaunchKernelGGL(halo_copy_kernel, dim3(64), dim3(256), 0, h->stream, h->H, h->Ht, h->halo[0], d.PADL, rows, d.K32, d.TP, 0);
-    KCHK("halo_copy_kernel");
-    hipLaunchKernelGGL(halo_copy_kernel, dim3(64), dim3(256), 0, h->stream, h->H, h->Ht, h->halo[1], d.PADL + d.Tl - rows, rows, d.K32, d.TP, 0);
-    KCHK("halo_copy_kernel");
+    // the shard's place in the global partition must match what the other ranks assume
+    std::vector<int64_t> t0, t1;
+    group_partition(h->T_global, nranks, d.L, t0, t1);
+    if (t0[(size_t)rank] != h->t_offset || t1[(size_t)rank] - t0[(size_t)rank] != d.Tl)
+        return fail(CMF_ERR_ARG, "rank %d of %d must own columns [%lld, %lld) of T=%lld, the handle owns [%lld, %lld)", rank, nranks,
+                    (long long)t0[(size_t)rank], (long long)t1[(size_t)rank], (long long)h->T_global,
+                    (long long)h->t_offset, (long long)(h->t_offset + d.Tl));
+    CMFTRY(group_use(h));
+    cmf_group_s *g = new cmf_group_s();
+    g->nranks = nranks;
+    g->transport = transport;
+    g->one_process = false;
+    g->N = d.N; g->T = h->T_global; g->K = d.K; g->L = d.L;
+    g->t0 = t0; g->t1 = t1;
+    g->sh.push_back(h);
+    g->rank.push_back(rank);
+    g->ar_cb = ar; g->ag_cb = ag; g->cb_user = user;
+    auto bail = [&](int rc) { group_destroy(g); h->group = nullptr; return rc; };
+    int rc = group_prepare_shard(h);
+    if (rc != CMF_OK) return bail(rc);
+    if (transport == CMF_TR_RCCL) {
+        rc = rccl_load();
+        if (rc != CMF_OK) return bail(rc);
+        ncclUniqueId id;
+        std::memcpy(&id, id128, sizeof(id));
+        g->comm.assign(1, nullptr);
+        ncclResult_t r_ = g_rccl.CommInitRank(&g->comm[0], nranks, id, rank);
+        if (r_ != ncclSuccess) return bail(fail(CMF_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r_)));
+    }
+    rc = group_alloc_buffers(g);
+    if (rc == CMF_OK) rc = group_finish_norm(g);
+    if (rc != CMF_OK) return bail(rc);
+    h->group = g;
+    if (h->factors_set) { // factors were set before the communicator existed: the neighbours' halos are still missing
+        g->halos_current = false;
+        h->est_kind = 0;
+    }
     return CMF_OK;
 }
 
-int cmf_halo_unpack(cmf_handle h, int has_left, int has_right)
+int cmf_comm_init_rccl(cmf_handle h, int nranks, int rank, const void *id128)
 {
-    CMFTRY(check_ready(h, false));
-    const CmfDims &d = h->d;
-    const int rows = d.L - 1;
-    if (rows < 1) return CMF_OK;
-    if (has_left) {
-        hipLaunchKernelGGL(halo_copy_kernel, dim3(64), dim3(256), 0, h->stream, h->H, h->Ht, h->halo[2], d.PADL - rows, rows, d.K32, d.TP, 1);
-        KCHK("halo_copy_kernel");
+    if (!id128) return fail(CMF_ERR_ARG, "id128 is NULL");
+    return comm_attach(h, nranks, rank, CMF_TR_RCCL, id128, nullptr, nullptr, nullptr);
+}
+
+int cmf_comm_init_callbacks(cmf_handle h, int nranks, int rank, cmf_allreduce_fn allreduce, cmf_allgather_fn allgather, void *user)
+{
+    if (!allreduce || !allgather) return fail(CMF_ERR_ARG, "NULL callback");
+    return comm_attach(h, nranks, rank, CMF_TR_CALLBACKS, nullptr, allreduce, allgather, user);
+}
+
+int cmf_comm_info(cmf_handle h, char *buf, int64_t len)
+{
+    if (!h || !buf || len < 1) return fail(CMF_ERR_ARG, "bad argument");
+    char tmp[1024];
+    if (!h->group) {
+        snprintf(tmp, sizeof(tmp), "transport=none nranks=1");
+    } else {
+        const cmf_group_s *g = h->group;
+        std::string ranks;
+        for (size_t i = 0; i < g->rank.size(); ++i) ranks += (i ? "," : "") + std::to_string(g->rank[i]) + "@dev" + std::to_string(g->sh[i]->device);
+        if (g->transport == CMF_TR_RCCL) {
+            int v = 0;
+            (void)g_rccl.GetVersion(&v);
+            snprintf(tmp, sizeof(tmp), "transport=rccl version=%d lib=%s nranks=%d local=%zu ranks=%s overlap=%d", v, g_rccl.path.c_str(),
+                     g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap);
+        } else {
+            snprintf(tmp, sizeof(tmp), "transport=%s nranks=%d local=%zu ranks=%s overlap=%d", g->transport == CMF_TR_LOOPBACK ? "loopback" : "callbacks",
+                     g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap);
+        }
     }
-    if (has_right) {
-        hipLaunchKernelGGL(halo_copy_kernel, dim3(64), dim3(256), 0, h->stream, h->H, h->Ht, h->halo[3], d.PADL + d.Tl, rows, d.K32, d.TP, 1);
-        KCHK("halo_copy_kernel");
+    snprintf(buf, (size_t)len, "%s", tmp);
+    return CMF_OK;
+}
+
+int cmf_shard_bounds(cmf_handle h, int rank, int64_t *t0, int64_t *t1)
+{
+    if (!h || !t0 || !t1) return fail(CMF_ERR_ARG, "NULL argument");
+    if (!h->group) {
+        *t0 = h->t_offset;
+        *t1 = h->t_offset + h->d.Tl;
+        return CMF_OK;
     }
+    if (rank < 0 || rank >= h->group->nranks) return fail(CMF_ERR_ARG, "rank %d out of range", rank);
+    *t0 = h->group->t0[(size_t)rank];
+    *t1 = h->group->t1[(size_t)rank];
     return CMF_OK;
 }
 
@@ -1385,6 +1591,7 @@ int cmf_gen_synthetic(int device, int64_t N, int64_t T, int64_t K, int64_t L, do
 int cmf_kernel_times(cmf_handle h, const char *name, double *avg_ms, int64_t *launches)
 {
     if (!h || !name || !avg_ms || !launches) return fail(CMF_ERR_ARG, "NULL argument");
+    if (h->root_only) h = h->group->sh[0]; // shard 0 stands for the group
     HIPCHK(hipSetDevice(h->device));
     int cls = -1;
     for (int c = 0; c < PROF_NCLS; ++c)
@@ -1408,6 +1615,7 @@ int cmf_kernel_times(cmf_handle h, const char *name, double *avg_ms, int64_t *la
 int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, double *flops)
 {
     if (!name || !avg_ms || !flops || reps < 1) return fail(CMF_ERR_ARG, "bad argument");
+    if (h && h->root_only) h = h->group->sh[0]; // shard 0 stands for the group
     CMFTRY(check_ready(h, true));
     const CmfDims &d = h->d;
     const double S = (double)d.L * d.Tl - 0.5 * (double)d.L * (d.L - 1);
@@ -1434,6 +1642,7 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *avg_ms = (double)ms / reps;
+    if (which == 0 || which == 5) h->est_kind = 1; // est now holds plain tensor_conv(W, H), whatever it held before (a residual on HALS / PGD handles)
     *flops = (which == 1 || which == 2) ? 2.0 * f1 : f1;
     return CMF_OK;
 }

@@ -1,0 +1,578 @@
+// cmf_group.h -- T-sharded groups behind the C ABI (included by cmf_api.hip).
+//
+// A *group* is R contiguous column blocks ("shards") of one problem: data / est / H are partitioned along T, W is
+// replicated.  The caller holds ONE handle and makes the reference's two calls per iteration
+// (update_motifs! / update_feature_maps!, alternating.jl:52,54); the library runs the sharded iteration:
+//
+//   update_motifs!        per shard: est = conv(W,H) (reused), [numW | denomW] partial sums        (mult.jl:28-34)
+//                         ONE all-reduce(sum) of [numW | denomW | tail]   <- the only bulk exchange; the tail carries
+//                                                                            the previous loss scalar of every rank
+//                         per shard: the identical W update                                        (mult.jl:37-38)
+//   update_feature_maps!  per shard: est (new W) on own columns + right lag halo, numH, denomH, H  (mult.jl:44-52)
+//                         ONE all-gather of every shard's [first | last] L-1 columns of H (2 x 2.4 KB per shard)
+//                         per shard: loss conv, sum((est - data)^2) -> the tail of the next all-reduce (mult.jl:55-57)
+//
+// Two ways to form a group:
+//   cmf_create_multi       one process drives all shards (ndev devices, per-device streams; RCCL communicators from
+//                          ncclCommInitAll, collectives inside ncclGroupStart/End) -- what a Julia caller of `fit` gets;
+//   cmf_create_shard + cmf_comm_init_rccl / cmf_comm_init_callbacks
+//                          one process per shard (torchrun-style launchers; bench.py --gpus N).
+// Transports: RCCL over xGMI (the product path), "loopback" (all shards of a cmf_create_multi group on ONE device:
+// the collectives are plain kernels -- exercises middle-rank shards on a one-GPU box), and host callbacks (the
+// library stages the buffers through pinned host memory and the host performs the collective, e.g. gloo in the tests).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+// ---- RCCL, bound at run time --------------------------------------------------------------------------------------
+// librccl is opened with dlopen the first time a communicator is needed: the library then loads on hosts without
+// RCCL, and when the process already holds an RCCL (e.g. PyTorch's bundled copy, same SONAME) that copy is reused
+// instead of a second one being mapped.
+struct RcclApi {
+    void *dl = nullptr;
+    std::string path;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_load()
+{
+    if (g_rccl.dl) return CMF_OK;
+    const char *env = getenv("CMF_RCCL_LIB");
+    const char *cands[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *dl = nullptr;
+    for (const char *c : {"librccl.so.1", "librccl.so"}) { // a copy this process already mapped wins
+        dl = dlopen(c, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        if (dl) break;
+    }
+    for (size_t i = 0; !dl && i < sizeof(cands) / sizeof(cands[0]); ++i)
+        if (cands[i] && *cands[i]) dl = dlopen(cands[i], RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return fail(CMF_ERR_COMM, "RCCL not found (librccl.so.1; set CMF_RCCL_LIB): %s", dlerror());
+#define RCCL_SYM(field, name)                                                                 \
+    do {                                                                                      \
+        g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(dl, name));             \
+        if (!g_rccl.field) { dlclose(dl); return fail(CMF_ERR_COMM, "RCCL symbol %s missing", name); } \
+    } while (0)
+    RCCL_SYM(GetVersion, "ncclGetVersion");
+    RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    RCCL_SYM(CommInitAll, "ncclCommInitAll");
+    RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RCCL_SYM(GetErrorString, "ncclGetErrorString");
+    RCCL_SYM(AllReduce, "ncclAllReduce");
+    RCCL_SYM(AllGather, "ncclAllGather");
+    RCCL_SYM(GroupStart, "ncclGroupStart");
+    RCCL_SYM(GroupEnd, "ncclGroupEnd");
+#undef RCCL_SYM
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(g_rccl.AllReduce), &info) && info.dli_fname) g_rccl.path = info.dli_fname;
+    g_rccl.dl = dl;
+    return CMF_OK;
+}
+
+#define RCCLCHK(expr)                                                                                          \
+    do {                                                                                                       \
+        ncclResult_t r_ = (expr);                                                                              \
+        if (r_ != ncclSuccess) return fail(CMF_ERR_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));   \
+    } while (0)
+
+// ---- the group ----------------------------------------------------------------------------------------------------
+enum { CMF_TR_LOOPBACK = 0, CMF_TR_RCCL = 1, CMF_TR_CALLBACKS = 2 };
+
+struct cmf_group_s {
+    int nranks = 1;
+    int transport = CMF_TR_LOOPBACK;
+    bool one_process = false;            // cmf_create_multi: all shards are local, H crosses the ABI as the global K x T matrix
+    std::vector<cmf_handle_s *> sh;      // local shards
+    std::vector<int> rank;               // global rank of each local shard
+    std::vector<ncclComm_t> comm;        // RCCL communicators (one per local shard)
+    cmf_allreduce_fn ar_cb = nullptr;    // host-callback transport
+    cmf_allgather_fn ag_cb = nullptr;
+    void *cb_user = nullptr;
+    float *cb_host = nullptr;            // pinned staging of the callback transport
+    size_t cb_host_elems = 0;
+    // device buffers, one per local shard
+    std::vector<float *> red;            // [LKN2 + tail]: numW | denomW | loss tail  (the shard's numden points here)
+    std::vector<float *> halo_send;      // [2 * HC]: own first | last L-1 columns of H
+    std::vector<float *> halo_all;       // [nranks * 2 * HC]: every rank's send block (the shard's receive halos point inside)
+    std::vector<float *> loss_all;       // [tail]: gathered (hi, lo) loss pairs of the synchronous path
+    float *h_tail = nullptr;             // pinned host: 2 ring slots of `tail` floats (the late loss read-back) + 1 for the synchronous one
+    hipEvent_t ring_ev[2] = {nullptr, nullptr};
+    int64_t LKN2 = 0, tail = 0, HC = 0;
+    int64_t N = 0, T = 0, K = 0, L = 0;
+    std::vector<int64_t> t0, t1;         // column block of every rank
+    double data_sumsq = 0.0, data_norm = 0.0;
+    bool overlap = false;                // option "allreduce_overlap": numW contracted + all-reduced under the loss conv
+    bool num_ready = false;              // overlap form: the numW half belongs to the current H and is reduced (or in flight)
+    bool halos_current = false;
+};
+
+static void group_partition(int64_t T, int R, int64_t L, std::vector<int64_t> &t0, std::vector<int64_t> &t1)
+{
+    const int64_t base = (T + R - 1) / R;
+    t0.resize(R);
+    t1.resize(R);
+    for (int r = 0; r < R; ++r) {
+        t0[r] = std::min<int64_t>((int64_t)r * base, T);
+        t1[r] = std::min<int64_t>(t0[r] + base, T);
+    }
+    (void)L;
+}
+
+static int group_use(cmf_handle_s *s)
+{
+    HIPCHK(hipSetDevice(s->device));
+    return CMF_OK;
+}
+
+static int group_alloc_buffers(cmf_group_s *g)
+{
+    cmf_handle_s *s0 = g->sh[0];
+    const CmfDims &d = s0->d;
+    g->LKN2 = (int64_t)2 * d.L * d.K32 * d.Np;
+    g->tail = rup(2 * g->nranks, 64);
+    g->HC = (int64_t)std::max(1, d.L - 1) * d.K32;
+    const size_t nl = g->sh.size();
+    g->red.assign(nl, nullptr);
+    g->halo_send.assign(nl, nullptr);
+    g->halo_all.assign(nl, nullptr);
+    g->loss_all.assign(nl, nullptr);
+    for (size_t i = 0; i < nl; ++i) {
+        cmf_handle_s *s = g->sh[i];
+        CMFTRY(group_use(s));
+        CMFTRY(dalloc_zero(&g->red[i], (size_t)(g->LKN2 + g->tail)));
+        CMFTRY(dalloc_zero(&g->halo_send[i], (size_t)(2 * g->HC)));
+        CMFTRY(dalloc_zero(&g->halo_all[i], (size_t)(g->nranks * 2 * g->HC)));
+        CMFTRY(dalloc_zero(&g->loss_all[i], (size_t)(2 * g->tail))); // [gathered pairs | send scratch]
+        s->numden = g->red[i];
+        const int r = g->rank[i];
+        s->halo[0] = g->halo_send[i];
+        s->halo[1] = g->halo_send[i] + g->HC;
+        s->halo[2] = r > 0 ? g->halo_all[i] + (size_t)(2 * (r - 1) + 1) * g->HC : nullptr;          // left neighbour's send-to-right block
+        s->halo[3] = r < g->nranks - 1 ? g->halo_all[i] + (size_t)(2 * (r + 1)) * g->HC : nullptr;   // right neighbour's send-to-left block
+    }
+    CMFTRY(group_use(s0));
+    HIPCHK(hipHostMalloc(&g->h_tail, (size_t)(3 * g->tail) * sizeof(float))); // 2 ring slots + the synchronous read-back
+    for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&g->ring_ev[q], hipEventDisableTiming));
+    return CMF_OK;
+}
+
+static int group_cb_stage(cmf_group_s *g, size_t elems)
+{
+    if (g->cb_host_elems >= elems) return CMF_OK;
+    if (g->cb_host) (void)hipHostFree(g->cb_host);
+    g->cb_host = nullptr;
+    g->cb_host_elems = 0;
+    HIPCHK(hipHostMalloc(&g->cb_host, elems * sizeof(float)));
+    g->cb_host_elems = elems;
+    return CMF_OK;
+}
+
+// In-place sum over all ranks of `count` floats at offset `off` of every local shard's buffer `bufs[i]`, ordered on
+// `streams[i]`.
+static int group_allreduce(cmf_group_s *g, const std::vector<float *> &bufs, size_t off, size_t count, bool on_comm_stream = false)
+{
+    const size_t nl = g->sh.size();
+    if (g->nranks == 1 && g->transport != CMF_TR_RCCL) return CMF_OK;
+    auto stream_of = [&](size_t i) { return on_comm_stream ? g->sh[i]->comm_stream : g->sh[i]->stream; };
+    switch (g->transport) {
+    case CMF_TR_RCCL: {
+        if (nl > 1) RCCLCHK(g_rccl.GroupStart());
+        for (size_t i = 0; i < nl; ++i) {
+            CMFTRY(group_use(g->sh[i]));
+            RCCLCHK(g_rccl.AllReduce(bufs[i] + off, bufs[i] + off, count, ncclFloat32, ncclSum, g->comm[i], stream_of(i)));
+        }
+        if (nl > 1) RCCLCHK(g_rccl.GroupEnd());
+        return CMF_OK;
+    }
+    case CMF_TR_LOOPBACK: { // all shards share one device and one stream
+        CmfPtrTable tab;
+        for (size_t i = 0; i < nl; ++i) tab.p[i] = bufs[i] + off;
+        CMFTRY(group_use(g->sh[0]));
+        const int blocks = (int)std::min<size_t>(2048, (count + 255) / 256);
+        hipLaunchKernelGGL(loopback_allreduce_kernel, dim3(blocks), dim3(256), 0, stream_of(0), tab, (int)nl, count);
+        KCHK("loopback_allreduce_kernel");
+        return CMF_OK;
+    }
+    default: { // host callbacks: one local shard
+        cmf_handle_s *s = g->sh[0];
+        CMFTRY(group_use(s));
+        CMFTRY(group_cb_stage(g, count));
+        HIPCHK(hipMemcpyAsync(g->cb_host, bufs[0] + off, count * sizeof(float), hipMemcpyDeviceToHost, stream_of(0)));
+        HIPCHK(hipStreamSynchronize(stream_of(0)));
+        const int rc = g->ar_cb(g->cb_user, g->cb_host, (int64_t)count);
+        if (rc != 0) return fail(CMF_ERR_COMM, "all-reduce callback returned %d", rc);
+        HIPCHK(hipMemcpyAsync(bufs[0] + off, g->cb_host, count * sizeof(float), hipMemcpyHostToDevice, stream_of(0)));
+        HIPCHK(hipStreamSynchronize(stream_of(0)));
+        return CMF_OK;
+    }
+    }
+}
+
+// recv[i] (nranks * count floats) = every rank's send block (count floats), in rank order
+static int group_allgather(cmf_group_s *g, const std::vector<float *> &send, size_t send_off, const std::vector<float *> &recv, size_t count)
+{
+    const size_t nl = g->sh.size();
+    switch (g->transport) {
+    case CMF_TR_RCCL: {
+        if (nl > 1) RCCLCHK(g_rccl.GroupStart());
+        for (size_t i = 0; i < nl; ++i) {
+            CMFTRY(group_use(g->sh[i]));
+            RCCLCHK(g_rccl.AllGather(send[i] + send_off, recv[i], count, ncclFloat32, g->comm[i], g->sh[i]->stream));
+        }
+        if (nl > 1) RCCLCHK(g_rccl.GroupEnd());
+        return CMF_OK;
+    }
+    case CMF_TR_LOOPBACK: {
+        CmfPtrTable ts, tr;
+        for (size_t i = 0; i < nl; ++i) { ts.p[i] = send[i] + send_off; tr.p[i] = recv[i]; }
+        CMFTRY(group_use(g->sh[0]));
+        const int blocks = (int)std::min<size_t>(64, (nl * count + 255) / 256);
+        hipLaunchKernelGGL(loopback_allgather_kernel, dim3(blocks), dim3(256), 0, g->sh[0]->stream, ts, tr, (int)nl, (int)count);
+        KCHK("loopback_allgather_kernel");
+        return CMF_OK;
+    }
+    default: {
+        cmf_handle_s *s = g->sh[0];
+        CMFTRY(group_use(s));
+        CMFTRY(group_cb_stage(g, (size_t)(g->nranks + 1) * count));
+        float *hs = g->cb_host, *hr = g->cb_host + count;
+        HIPCHK(hipMemcpyAsync(hs, send[0] + send_off, count * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        const int rc = g->ag_cb(g->cb_user, hs, hr, (int64_t)count);
+        if (rc != 0) return fail(CMF_ERR_COMM, "all-gather callback returned %d", rc);
+        HIPCHK(hipMemcpyAsync(recv[0], hr, (size_t)g->nranks * count * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        return CMF_OK;
+    }
+    }
+}
+
+// sum over ranks (in rank order) of the doubles posted as (hi, lo) float pairs
+static double group_decode_tail(const cmf_group_s *g, const float *tail)
+{
+    double s = 0.0;
+    for (int r = 0; r < g->nranks; ++r) s += (double)tail[2 * r] + (double)tail[2 * r + 1];
+    return s;
+}
+
+// One double per rank -> all of them on every rank (exact: the bytes travel through the all-gather as float pairs).
+// Every local shard contributes vals[i]; out[r] for all ranks.  Synchronises.
+static int group_gather_doubles(cmf_group_s *g, const std::vector<double> &vals, std::vector<double> &out)
+{
+    const size_t nl = g->sh.size();
+    out.assign((size_t)g->nranks, 0.0);
+    if (g->one_process) { // all ranks are local: no transport needed
+        for (size_t i = 0; i < nl; ++i) out[(size_t)g->rank[i]] = vals[i];
+        return CMF_OK;
+    }
+    // two floats per rank cannot hold an arbitrary double exactly: send the 8 bytes as two 32-bit words instead
+    std::vector<float *> send(nl), recv(nl);
+    for (size_t i = 0; i < nl; ++i) {
+        cmf_handle_s *s = g->sh[i];
+        CMFTRY(group_use(s));
+        float w[2];
+        std::memcpy(w, &vals[i], 8);
+        HIPCHK(hipMemcpyAsync(g->loss_all[i] + g->tail, w, 8, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        send[i] = g->loss_all[i] + g->tail;
+        recv[i] = g->loss_all[i];
+    }
+    CMFTRY(group_allgather(g, send, 0, recv, 2));
+    cmf_handle_s *s = g->sh[0];
+    CMFTRY(group_use(s));
+    std::vector<float> hostw((size_t)2 * g->nranks);
+    HIPCHK(hipMemcpyAsync(hostw.data(), recv[0], hostw.size() * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (int r = 0; r < g->nranks; ++r) std::memcpy(&out[(size_t)r], &hostw[(size_t)2 * r], 8);
+    return CMF_OK;
+}
+
+static int group_check_ready(cmf_group_s *g)
+{
+    for (cmf_handle_s *s : g->sh) {
+        if (!s->factors_set) return fail(CMF_ERR_STATE, "factors not set: call cmf_set_factors first");
+        if (!s->have_data) return fail(CMF_ERR_STATE, "handle was created without data");
+    }
+    return CMF_OK;
+}
+
+static int group_sync(cmf_group_s *g)
+{
+    for (cmf_handle_s *s : g->sh) {
+        CMFTRY(group_use(s));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if (s->comm_stream) HIPCHK(hipStreamSynchronize(s->comm_stream));
+    }
+    return CMF_OK;
+}
+
+// (L-1)-column H halo exchange: pack -> one all-gather -> unpack
+static int group_exchange_halos(cmf_group_s *g)
+{
+    cmf_handle_s *s0 = g->sh[0];
+    const int rows = s0->d.L - 1;
+    g->halos_current = true;
+    if (rows < 1 || g->nranks == 1) return CMF_OK;
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        cmf_handle_s *s = g->sh[i];
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        hipLaunchKernelGGL(halo_pack2_kernel, dim3(8), dim3(256), 0, s->stream, s->H, g->halo_send[i], d.PADL, d.PADL + d.Tl - rows, rows, d.K32);
+        KCHK("halo_pack2_kernel");
+    }
+    CMFTRY(group_allgather(g, g->halo_send, 0, g->halo_all, (size_t)(2 * g->HC)));
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        cmf_handle_s *s = g->sh[i];
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        hipLaunchKernelGGL(halo_unpack2_kernel, dim3(8), dim3(256), 0, s->stream, s->H, s->Ht, s->halo[2], s->halo[3],
+                           d.PADL - rows, d.PADL + d.Tl, rows, d.K32, d.TP);
+        KCHK("halo_unpack2_kernel");
+    }
+    return CMF_OK;
+}
+
+// sum((conv(W,H) - data)^2) of every local shard -> its tail slots of the all-reduce buffer (and d_scalar[0])
+static int group_loss_partials(cmf_group_s *g)
+{
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        cmf_handle_s *s = g->sh[i];
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        if (s->reuse_est) {
+            CMFTRY(launch_conv<3>(s, s->est, d.Tl, s->conv_gy)); // mult.jl:55-57, est kept for the next update_motifs!
+            s->est_kind = 1;
+        } else {
+            CMFTRY(launch_conv<2>(s, nullptr, d.Tl, s->conv_gy));
+        }
+        hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(256), 0, s->stream, s->partial, s->conv_partials, s->d_scalar,
+                           g->red[i] + g->LKN2, (int)g->tail, g->rank[i]);
+        KCHK("loss_tail_kernel");
+    }
+    return CMF_OK;
+}
+
+// the tail of the all-reduce buffer right now (synchronous path): all-gather of the (hi, lo) pairs, read back
+static int group_loss_now(cmf_group_s *g, double *sumsq)
+{
+    const size_t nl = g->sh.size();
+    cmf_handle_s *s = g->sh[0];
+    if (g->nranks == 1 && g->transport != CMF_TR_RCCL) return read_scalar(s, 0, sumsq);
+    std::vector<float *> send(nl);
+    for (size_t i = 0; i < nl; ++i) send[i] = g->red[i] + g->LKN2 + 2 * g->rank[i];
+    CMFTRY(group_allgather(g, send, 0, g->loss_all, 2));
+    CMFTRY(group_use(s));
+    float *stage = g->h_tail + 2 * g->tail; // not a ring slot: a pending one-iteration-late loss may still sit there
+    HIPCHK(hipMemcpyAsync(stage, g->loss_all[0], (size_t)(2 * g->nranks) * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    *sumsq = group_decode_tail(g, stage);
+    return CMF_OK;
+}
+
+// overlap form: numW needs H only -- contract it and start its all-reduce on the communication stream
+static int group_start_num(cmf_group_s *g)
+{
+    const size_t half = (size_t)g->LKN2 / 2;
+    for (cmf_handle_s *s : g->sh) {
+        CMFTRY(group_use(s));
+        CMFTRY(w_partial_half_impl(s, 0));
+        HIPCHK(hipEventRecord(s->ev_c0, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->comm_stream, s->ev_c0, 0));
+    }
+    CMFTRY(group_allreduce(g, g->red, 0, half, true));
+    for (cmf_handle_s *s : g->sh) {
+        CMFTRY(group_use(s));
+        HIPCHK(hipEventRecord(s->ev_c1, s->comm_stream));
+    }
+    g->num_ready = true;
+    return CMF_OK;
+}
+
+// update_motifs! on the group (mult.jl:23-39).  ring_slot >= 0: after the all-reduce the tail (the previous
+// iteration's loss pairs of every rank) is copied to pinned host slot `ring_slot` and ring_ev[ring_slot] is recorded.
+static int group_update_motifs(cmf_group_s *g, double l1W, double l2W, int ring_slot = -1)
+{
+    if (!g->halos_current) CMFTRY(group_exchange_halos(g));
+    const size_t half = (size_t)g->LKN2 / 2;
+    if (g->overlap) {
+        if (!g->num_ready) CMFTRY(group_start_num(g));
+        for (cmf_handle_s *s : g->sh) {
+            CMFTRY(group_use(s));
+            CMFTRY(w_partial_half_impl(s, 1));
+        }
+        CMFTRY(group_allreduce(g, g->red, half, half + (size_t)g->tail));
+        for (cmf_handle_s *s : g->sh) {
+            CMFTRY(group_use(s));
+            HIPCHK(hipStreamWaitEvent(s->stream, s->ev_c1, 0));
+        }
+        g->num_ready = false;
+    } else {
+        for (cmf_handle_s *s : g->sh) {
+            CMFTRY(group_use(s));
+            CMFTRY(w_partial_impl(s));
+        }
+        CMFTRY(group_allreduce(g, g->red, 0, (size_t)(g->LKN2 + g->tail)));
+    }
+    if (ring_slot >= 0) {
+        cmf_handle_s *s = g->sh[0];
+        CMFTRY(group_use(s));
+        HIPCHK(hipMemcpyAsync(g->h_tail + (size_t)ring_slot * g->tail, g->red[0] + g->LKN2, (size_t)(2 * g->nranks) * sizeof(float),
+                              hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipEventRecord(g->ring_ev[ring_slot], s->stream));
+    }
+    for (cmf_handle_s *s : g->sh) {
+        CMFTRY(group_use(s));
+        CMFTRY(w_apply_impl(s, l1W, l2W));
+    }
+    return CMF_OK;
+}
+
+// update_feature_maps! on the group (mult.jl:42-58).  sumsq != NULL: also reduce the loss now (synchronises);
+// NULL: the loss partials stay in the tail of the all-reduce buffer and ride on the next update_motifs!.
+static int group_update_feature_maps(cmf_group_s *g, double l1H, double l2H, double *sumsq)
+{
+    if (!g->halos_current) CMFTRY(group_exchange_halos(g));
+    for (cmf_handle_s *s : g->sh) {
+        CMFTRY(group_use(s));
+        CMFTRY(h_update_impl(s, l1H, l2H));
+    }
+    g->num_ready = false;
+    CMFTRY(group_exchange_halos(g));
+    if (g->overlap) CMFTRY(group_start_num(g)); // for the next update_motifs!: H and its halos are final now
+    CMFTRY(group_loss_partials(g));
+    return sumsq ? group_loss_now(g, sumsq) : CMF_OK;
+}
+
+static int group_compute_loss(cmf_group_s *g, double *loss)
+{
+    if (!g->halos_current) CMFTRY(group_exchange_halos(g));
+    CMFTRY(group_loss_partials(g));
+    double ss = 0.0;
+    CMFTRY(group_loss_now(g, &ss));
+    *loss = std::sqrt(ss) / g->data_norm;
+    return CMF_OK;
+}
+
+// n MU iterations back to back (alternating.jl:51-54 n times).  The loss of iteration i travels in the tail of
+// iteration i+1's all-reduce and is read from pinned memory after iteration i+1 has been enqueued, so the host never
+// stalls the device between iterations; the last loss is flushed with the small all-gather.  stamps (optional):
+// host seconds since entry at which each loss became known.
+static int group_iterate(cmf_group_s *g, int64_t n, int eval_mode, double l1W, double l2W, double l1H, double l2H,
+                         double *losses, double *stamps)
+{
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+    if (eval_mode) { // no W update, so no all-reduce to ride on: synchronous losses
+        for (int64_t it = 0; it < n; ++it) {
+            double ss = 0.0;
+            CMFTRY(group_update_feature_maps(g, l1H, l2H, &ss));
+            losses[it] = std::sqrt(ss) / g->data_norm;
+            if (stamps) stamps[it] = now();
+        }
+        return CMF_OK;
+    }
+    cmf_handle_s *s0 = g->sh[0];
+    for (int64_t it = 0; it < n; ++it) {
+        CMFTRY(group_update_motifs(g, l1W, l2W, it > 0 ? (int)((it - 1) & 1) : -1));
+        const bool last = (it + 1 == n);
+        double ss = 0.0;
+        CMFTRY(group_update_feature_maps(g, l1H, l2H, last ? &ss : nullptr));
+        if (it > 0) {
+            const int slot = (int)((it - 1) & 1);
+            CMFTRY(group_use(s0));
+            HIPCHK(hipEventSynchronize(g->ring_ev[slot]));
+            losses[it - 1] = std::sqrt(group_decode_tail(g, g->h_tail + (size_t)slot * g->tail)) / g->data_norm;
+            if (stamps) stamps[it - 1] = now();
+        }
+        if (last) {
+            losses[it] = std::sqrt(ss) / g->data_norm;
+            if (stamps) stamps[it] = now();
+        }
+    }
+    return CMF_OK;
+}
+
+static int group_set_factors(cmf_group_s *g, const double *W, const double *H)
+{
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        cmf_handle_s *s = g->sh[i];
+        // one process: H is the global K x T matrix (column-major: a shard's columns are contiguous)
+        const double *Hs = g->one_process ? H + (size_t)g->t0[(size_t)g->rank[i]] * g->K : H;
+        CMFTRY(set_factors_impl(s, W, Hs));
+    }
+    g->num_ready = false;
+    g->halos_current = false;
+    return group_exchange_halos(g);
+}
+
+static int group_get_factors(cmf_group_s *g, double *W, double *H)
+{
+    CMFTRY(group_sync(g));
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        cmf_handle_s *s = g->sh[i];
+        double *Hs = (H && g->one_process) ? H + (size_t)g->t0[(size_t)g->rank[i]] * g->K : H;
+        CMFTRY(get_factors_impl(s, i == 0 ? W : nullptr, Hs));
+    }
+    return CMF_OK;
+}
+
+static void group_destroy(cmf_group_s *g)
+{
+    if (!g) return;
+    for (cmf_handle_s *s : g->sh) {
+        (void)hipSetDevice(s->device);
+        (void)hipStreamSynchronize(s->stream);
+        if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
+    }
+    if (g->transport == CMF_TR_RCCL && g_rccl.dl)
+        for (ncclComm_t c : g->comm)
+            if (c) (void)g_rccl.CommDestroy(c);
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        cmf_handle_s *s = g->sh[i];
+        (void)hipSetDevice(s->device);
+        s->numden = s->numden_own;
+        for (int w = 0; w < 4; ++w) s->halo[w] = s->halo_own[w];
+        if (i < g->red.size() && g->red[i]) (void)hipFree(g->red[i]);
+        if (i < g->halo_send.size() && g->halo_send[i]) (void)hipFree(g->halo_send[i]);
+        if (i < g->halo_all.size() && g->halo_all[i]) (void)hipFree(g->halo_all[i]);
+        if (i < g->loss_all.size() && g->loss_all[i]) (void)hipFree(g->loss_all[i]);
+    }
+    if (g->h_tail) (void)hipHostFree(g->h_tail);
+    if (g->cb_host) (void)hipHostFree(g->cb_host);
+    for (int q = 0; q < 2; ++q)
+        if (g->ring_ev[q]) (void)hipEventDestroy(g->ring_ev[q]);
+    delete g;
+}
+
+// streams / events of the overlap form and common post-construction steps of a shard that joins a group
+static int group_prepare_shard(cmf_handle_s *s)
+{
+    CMFTRY(group_use(s));
+    if (!s->own_comm_stream) HIPCHK(hipStreamCreateWithFlags(&s->own_comm_stream, hipStreamNonBlocking));
+    s->comm_stream = s->own_comm_stream;
+    if (!s->ev_c0) HIPCHK(hipEventCreateWithFlags(&s->ev_c0, hipEventDisableTiming));
+    if (!s->ev_c1) HIPCHK(hipEventCreateWithFlags(&s->ev_c1, hipEventDisableTiming));
+    return CMF_OK;
+}
+
+static int group_finish_norm(cmf_group_s *g)
+{
+    std::vector<double> vals(g->sh.size()), all;
+    for (size_t i = 0; i < g->sh.size(); ++i) vals[i] = g->sh[i]->data_sumsq;
+    CMFTRY(group_gather_doubles(g, vals, all));
+    g->data_sumsq = 0.0;
+    for (double v : all) g->data_sumsq += v; // rank order: identical on every rank
+    g->data_norm = std::sqrt(g->data_sumsq);  // mult.jl:13 over all shards
+    for (cmf_handle_s *s : g->sh) s->data_norm = g->data_norm;
+    return CMF_OK;
+}

@@ -1814,3 +1814,82 @@ __global__ __launch_bounds__(256) void sumsq_f64_kernel(const double *in, size_t
     }
     if (threadIdx.x == 0) out_accum[blockIdx.x] = red[0];
 }
+
+// =============================================================================================
+// T-sharded groups: small kernels around the collectives
+// =============================================================================================
+// Both H halo send blocks in one launch: buf = [own first `rows` rows | own last `rows` rows] of H
+__global__ void halo_pack2_kernel(const float *H, float *buf, int r_first, int r_last, int rows, int K32)
+{
+    const int total = rows * K32;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * total; idx += gridDim.x * blockDim.x) {
+        const int w = idx >= total, j = idx - w * total;
+        buf[idx] = H[(size_t)(w ? r_last : r_first) * K32 + j];
+    }
+}
+
+// Both receive halos in one launch: left (rows [r_left, r_left+rows)) from `left`, right from `right`; a NULL
+// source (no neighbour: the global edge) leaves the zeros in place.  Writes H and its transposed copy Ht.
+__global__ void halo_unpack2_kernel(float *H, float *Ht, const float *left, const float *right, int r_left, int r_right,
+                                    int rows, int K32, int TP)
+{
+    const int total = rows * K32;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * total; idx += gridDim.x * blockDim.x) {
+        const int w = idx >= total, j = idx - w * total;
+        const float *src = w ? right : left;
+        if (!src) continue;
+        const int k = j % K32, r = (w ? r_right : r_left) + j / K32;
+        const float v = src[j];
+        H[(size_t)r * K32 + k] = v;
+        Ht[(size_t)k * TP + r] = v;
+    }
+}
+
+// loss_reduce_kernel for a shard of a group: *out = sum(partial[0..n)) as before, and the sum is also posted in the
+// tail of the [numW | denomW] all-reduce buffer as two floats (hi, lo: hi + lo reproduces the double to ~2^-48) in
+// this rank's own slots, zeros in every other rank's slots -- the sum over ranks of the tail is then exact (x + 0 + ...)
+// and every rank can add the per-rank doubles in rank order after the next all-reduce (the loss scalar rides on the
+// single bulk collective).
+__global__ __launch_bounds__(256) void loss_tail_kernel(const double *partial, int n, double *out, float *tail, int tail_len, int rank)
+{
+    __shared__ double red[256];
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int base = threadIdx.x; base < n; base += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (base + 256 * u < n) ? partial[base + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += v[u];
+    }
+    red[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    const double tot = red[0];
+    if (threadIdx.x == 0) *out = tot;
+    const float hi = (float)tot, lo = (float)(tot - (double)hi);
+    for (int j = threadIdx.x; j < tail_len; j += 256) tail[j] = (j == 2 * rank) ? hi : (j == 2 * rank + 1) ? lo : 0.f;
+}
+
+// Loopback transport (several shards of one group living on ONE device, e.g. a middle-rank shard test on a one-GPU
+// box): the collectives are plain kernels over the shards' buffers.  Sums are taken in rank order.
+#define CMF_MAX_LOCAL 16
+struct CmfPtrTable { float *p[CMF_MAX_LOCAL]; };
+__global__ __launch_bounds__(256) void loopback_allreduce_kernel(CmfPtrTable bufs, int R, size_t count)
+{
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < count; idx += (size_t)gridDim.x * blockDim.x) {
+        float s = bufs.p[0][idx];
+        for (int r = 1; r < R; ++r) s += bufs.p[r][idx];
+        for (int r = 0; r < R; ++r) bufs.p[r][idx] = s;
+    }
+}
+__global__ __launch_bounds__(256) void loopback_allgather_kernel(CmfPtrTable send, CmfPtrTable recv, int R, int count)
+{
+    const int total = R * count;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const float v = send.p[idx / count][idx % count];
+        for (int r = 0; r < R; ++r) recv.p[r][idx] = v;
+    }
+}

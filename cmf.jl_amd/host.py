@@ -134,9 +134,14 @@ class MultUpdate(AbstractCFUpdate):
     once at the end, which is observably the same as the reference's in-place
     mutation for every caller that only reads W and H after ``fit`` returns).  If the
     caller changes W or H on the host between calls, it must call :meth:`upload`.
+
+    ``devices=[d0, d1, ...]`` builds the rule as a T-sharded group on several GPUs of this node, driven by this one
+    process (cmf_create_multi): the rule methods keep their meaning and the library runs the sharded iteration --
+    one RCCL all-reduce of [numW | denomW] and one H-halo all-gather per iteration.  Listing
+    one device several times puts that many shards on it (loopback transport; tests).
     """
 
-    def __init__(self, data, W, H, device=None):
+    def __init__(self, data, W, H, device=None, devices=None, transport=_lib.CMF_COMM_AUTO):
         lib = _lib.load()
         self._lib = lib
         self._h = ctypes.c_void_p()
@@ -152,8 +157,16 @@ class MultUpdate(AbstractCFUpdate):
         T = data.shape[1]
         H = farr(H, (K, T))
         self.N, self.T, self.K, self.L = N, T, K, L
-        self.device = _dev(device)
-        check(lib.cmf_create(ctypes.byref(self._h), self.device, N, T, K, L, ptr(data)))
+        if devices is not None:
+            devs = [int(x) for x in devices]
+            if not devs:
+                raise ValueError("devices must not be empty")
+            self.device, self.devices = devs[0], devs
+            arr = (ctypes.c_int * len(devs))(*devs)
+            check(lib.cmf_create_multi(ctypes.byref(self._h), len(devs), arr, int(transport), N, T, K, L, ptr(data)))
+        else:
+            self.device, self.devices = _dev(device), None
+            check(lib.cmf_create(ctypes.byref(self._h), self.device, N, T, K, L, ptr(data)))
         try:
             check(lib.cmf_set_factors(self._h, ptr(W), ptr(H)))
         except Exception:
@@ -180,6 +193,25 @@ class MultUpdate(AbstractCFUpdate):
         loss = ctypes.c_double()
         check(self._lib.cmf_compute_loss(self._h, ctypes.byref(loss)))
         return loss.value
+
+    def iterate(self, n, eval_mode=False, l1W=0, l2W=0, l1H=0, l2H=0, stamps=False):
+        """n x (update_motifs!; update_feature_maps!) back to back (alternating.jl:51-54) in one ccall (cmf_iterate):
+        the losses of the n iterations, read one iteration late so the device never waits for the host."""
+        losses = np.zeros(int(n))
+        st = np.zeros(int(n))
+        check(self._lib.cmf_iterate(self._h, int(n), int(bool(eval_mode)), float(l1W), float(l2W), float(l1H), float(l2H),
+                                    ptr(losses), ptr(st)))
+        return (losses, st) if stamps else losses
+
+    def comm_info(self):
+        buf = ctypes.create_string_buffer(1024)
+        check(self._lib.cmf_comm_info(self._h, buf, 1024))
+        return buf.value.decode()
+
+    def shard_bounds(self, rank):
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        check(self._lib.cmf_shard_bounds(self._h, int(rank), ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def set_option(self, name, value):
         """Library option, e.g. ``set_option("reuse_est", 0)`` to recompute est in update_motifs! like the reference."""
@@ -459,7 +491,7 @@ def fit(alg, data, L, K, W_init, H_init, verbose=False, **kwargs):
 # --------------------------------------------------------------------------------------
 _REG_ALIASES = {"l1_W": "l1W", "l2_W": "l2W", "l1_H": "l1H", "l2_H": "l2H"}  # README.md:44-52 -> mult.jl:23,42
 _KNOWN_KW = {"seed", "W_init", "H_init", "check_convergence", "patience", "eval_mode", "tol", "verbose",
-             "l1W", "l2W", "l1H", "l2H", "device",
+             "l1W", "l2W", "l1H", "l2H", "device", "devices",
              "loss_func", "constrW", "constrH", "penaltiesW", "penaltiesH"}  # PGDUpdate (pgd.jl:158-202)
 
 
@@ -498,6 +530,7 @@ def fit_cnmf(data, L=10, K=5, alg=MultUpdate, max_itr=100, max_time=math.inf, **
         warnings.warn(f"fit_cnmf: ignoring unknown keyword arguments {sorted(unknown)} "
                       "(the reference ignores them silently)", stacklevel=2)
     device = kw.pop("device", None)
+    devices = kw.pop("devices", None)  # several GPUs of this node: the T-sharded group form of the :mult rule
     rule_type = _resolve_alg(alg)
     data = farr(data)
 
@@ -507,8 +540,13 @@ def fit_cnmf(data, L=10, K=5, alg=MultUpdate, max_itr=100, max_time=math.inf, **
     W_init = kw.get("W_init", W_init)  # :72-73
     H_init = kw.get("H_init", H_init)
 
-    rule = (rule_type(data, W_init, H_init, device=device) if issubclass(rule_type, MultUpdate)
-            else rule_type(data, W_init, H_init))
+    if devices is not None and rule_type is not MultUpdate:
+        raise NotImplementedError("devices=[...] (T sharding) is available for alg=:mult; the other rules run on one GPU")
+    if devices is not None:
+        rule = MultUpdate(data, W_init, H_init, devices=devices)
+    else:
+        rule = (rule_type(data, W_init, H_init, device=device) if issubclass(rule_type, MultUpdate)
+                else rule_type(data, W_init, H_init))
     try:
         opt = AlternatingOptimizer(rule, max_itr, max_time)  # :78-82
         loop_kw = {k: v for k, v in kw.items() if k not in ("seed", "W_init", "H_init")}

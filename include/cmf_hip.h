@@ -37,6 +37,7 @@ extern "C" {
 #define CMF_ERR_HIP 2         /* HIP runtime error / no device */
 #define CMF_ERR_STATE 3       /* call sequence error (e.g. factors not set) */
 #define CMF_ERR_UNSUPPORTED 4 /* shape outside what the kernels implement */
+#define CMF_ERR_COMM 5        /* RCCL / collective transport error */
 
 typedef struct cmf_handle_s *cmf_handle;
 
@@ -60,10 +61,51 @@ int cmf_create(cmf_handle *h, int device, int64_t N, int64_t T, int64_t K, int64
  * [t_offset, t_offset + T_local) of a T_global-column problem.
  * `data_local` holds columns [t_offset, t_offset + T_local + halo_r) where
  * halo_r = min(L-1, T_global - t_offset - T_local) (the static right halo of
- * `data` that tensor_transconv needs).  data_norm is the LOCAL sum of squares
- * root until cmf_set_data_norm() installs the global one. */
+ * `data` that tensor_transconv needs).  The shard joins its group with cmf_comm_init_rccl /
+ * cmf_comm_init_callbacks (below), which also all-reduces data_norm. */
 int cmf_create_shard(cmf_handle *h, int device, int64_t N, int64_t T_local, int64_t K, int64_t L,
                      const double *data_local, int64_t t_offset, int64_t T_global);
+
+/* ---- T-sharded groups: the same rule on several GPUs of one node -----------------
+ * The T axis of data / est / H is cut into contiguous column blocks (shard r owns columns
+ * [r*ceil(T/R), min(T, (r+1)*ceil(T/R)))), W is replicated.  Per MU iteration the shards meet twice: ONE RCCL
+ * all-reduce of the [numW | denomW] partial sums (2*L*Kpad*Npad floats + a tail that carries every shard's loss
+ * partial of the previous iteration) and one all-gather of the (L-1)-column H halos (2 x 2.4 KB per shard).
+ * On a group handle cmf_set_factors / cmf_get_factors / cmf_update_motifs / cmf_update_feature_maps /
+ * cmf_compute_loss / cmf_iterate / cmf_fit run the whole sharded iteration including the collectives, so the
+ * reference's `fit` loop (src/algs/alternating.jl:44-67: one update_motifs! and one update_feature_maps! per
+ * iteration) drives all GPUs with the same two calls.
+ *
+ * cmf_create_multi: ONE process drives `ndev` shards (the rule constructor `MultUpdate(data, W, H)`,
+ * src/algs/mult.jl:11-20, for a Julia task).  devices[r] is the HIP device of shard r; `data` is the whole N x T
+ * matrix, H crosses the ABI as the whole K x T matrix.  transport: CMF_COMM_AUTO = RCCL (ncclCommInitAll, one
+ * stream per device, collectives inside ncclGroupStart/End) when the devices are distinct, loopback when they
+ * are all the same device (the shards then share that device and the collectives are plain kernels: middle-rank
+ * shards on a one-GPU box); CMF_COMM_RCCL forces RCCL (a 1-device group then still sends its buffers through
+ * RCCL); CMF_COMM_LOOPBACK forces loopback (devices must all be equal). */
+#define CMF_COMM_AUTO 0
+#define CMF_COMM_RCCL 1
+#define CMF_COMM_LOOPBACK 2
+int cmf_create_multi(cmf_handle *h, int ndev, const int *devices, int transport,
+                     int64_t N, int64_t T, int64_t K, int64_t L, const double *data);
+
+/* One process per shard (torchrun-style launchers): create the shard with cmf_create_shard, then attach the
+ * communicator.  cmf_comm_unique_id writes the 128-byte ncclUniqueId (rank 0 calls it and hands the bytes to the
+ * other ranks by any out-of-band means); cmf_comm_init_rccl is ncclCommInitRank on the handle's device.  Both
+ * all-reduce the data norm; H crosses the ABI as the LOCAL K x T_local block. */
+int cmf_comm_unique_id(void *id128);
+int cmf_comm_init_rccl(cmf_handle h, int nranks, int rank, const void *id128);
+/* Host-collective transport (MPI / gloo style, used by the multi-process tests on one GPU): the library stages
+ * each buffer through pinned host memory and calls back.  allreduce sums `count` floats in place over all ranks;
+ * allgather fills recv (nranks * count floats, rank order) from every rank's `count`-float send block.  A non-zero
+ * return aborts the entry with CMF_ERR_COMM. */
+typedef int (*cmf_allreduce_fn)(void *user, float *host_buf, int64_t count);
+typedef int (*cmf_allgather_fn)(void *user, const float *host_send, float *host_recv, int64_t count);
+int cmf_comm_init_callbacks(cmf_handle h, int nranks, int rank, cmf_allreduce_fn allreduce, cmf_allgather_fn allgather, void *user);
+/* "transport=rccl version=2.x.y lib=/path/librccl.so nranks=8 local=1 ranks=3" (truncated to len). */
+int cmf_comm_info(cmf_handle h, char *buf, int64_t len);
+/* Column block [t0, t1) of shard `rank` of a group handle (of the handle itself when it is not a group). */
+int cmf_shard_bounds(cmf_handle h, int rank, int64_t *t0, int64_t *t1);
 
 int cmf_destroy(cmf_handle h);
 
@@ -82,14 +124,15 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       denomH = lag-Gram taps of W applied to H) instead of through est: exact rewritings of mult.jl:33,48 that
  *       execute 2.3 instead of 6 contractions plus the loss conv; results differ at rounding level only.
  *       2 = additionally take the loss from <H, denomH> - 2<H, numH> + ||data||^2 (no conv at all; the fp32
- *       cancellation limits its relative accuracy to about 1e-6 / loss^2).  Unsharded handles only. */
+ *       cancellation limits its relative accuracy to about 1e-6 / loss^2).  Unsharded handles only.
+ *   "allreduce_overlap" (group handles, default 0): 1 = numW (which needs H only) is contracted and all-reduced on a
+ *       second stream right after the H update, underneath the loss conv and the denominator contraction, so only
+ *       the denomW half of the all-reduce stays exposed; costs a second C2 launch per iteration. */
 int cmf_set_option(cmf_handle h, const char *name, int value);
 
-/* sum(data.^2) over the columns this handle owns (fp64); and the setter used
- * by the sharded host after it all-reduced the per-shard values
+/* sum(data.^2) (fp64) over the columns this handle owns -- over all shards on a group handle
  * (data_norm: src/algs/mult.jl:13). */
 int cmf_get_data_sumsq(cmf_handle h, double *sumsq);
-int cmf_set_data_norm(cmf_handle h, double data_norm);
 
 /* ---- factors -------------------------------------------------------------
  * W (K x N x L) and H (K x T_local) in / out.  `fit` deep-copies the
@@ -116,11 +159,20 @@ int cmf_compute_loss(cmf_handle h, double *loss);
  * doubles; *n_hist receives the number of entries written (iterations + 1);
  * *converged_early is 1 when the loop stopped on `converged` (:63-66; the
  * host wrapper prints "Converged early." like the reference).
- * Only valid on an unsharded handle. */
+ * Valid on single-GPU and group handles (on a group with a finite max_time every rank follows rank 0's clock). */
 int cmf_fit(cmf_handle h, int64_t max_itr, double max_time,
             int check_convergence, int64_t patience, double tol, int eval_mode,
             double l1W, double l2W, double l1H, double l2H,
             double *loss_hist, double *time_hist, int64_t *n_hist, int *converged_early);
+
+/* n_iter MU iterations back to back: exactly `update_motifs!; update_feature_maps!` (alternating.jl:51-54; eval_mode
+ * skips the motif update like :51) n_iter times, losses[i] = the loss update_feature_maps! returned in iteration i.
+ * The host does not stall the device between iterations: the loss of iteration i is read one iteration late from
+ * pinned memory (on a group handle it travels in the tail of iteration i+1's all-reduce, so an iteration costs one
+ * all-reduce, one halo all-gather and one host wait).  stamps (may be NULL): seconds since entry at which each loss
+ * became known to the host.  cmf_fit uses this loop when check_convergence is 0 and max_time is infinite. */
+int cmf_iterate(cmf_handle h, int64_t n_iter, int eval_mode, double l1W, double l2W, double l1H, double l2H,
+                double *losses, double *stamps);
 
 /* ---- HALS rule (BASELINE config 5) ----------------------------------------------
  * update_motifs!(rule::HALSUpdate, data, W, H; l1W=0, l2W=0)            src/algs/hals.jl:31-34, 90-112
@@ -150,52 +202,6 @@ int cmf_pgd_get_steps(cmf_handle h, double *stepW, double *stepH);
 
 /* converged(loss_hist, patience, tol): src/model.jl:91-107 (host arithmetic). */
 int cmf_converged(const double *loss_hist, int64_t len, int64_t patience, double tol);
-
-/* ---- phase-split form of the same iteration, for the T-sharded host ------
- * One MU iteration on R ranks is, per rank:
- *   cmf_w_partial            est = conv(W,H); local [numW|denomW] partial sums
- *   <all-reduce(sum) over cmf_numden_ptr, 2*cmf_numden_count floats>
- *   cmf_w_apply              W update (mult.jl:37-38), identical on every rank
- *   cmf_h_update             est (new W) on own columns + right halo, numH, denomH, H update
- *   <exchange (L-1)-column H halos with both neighbours: cmf_halo_*>
- *   cmf_loss_partial         sum((conv(W,H) - data).^2) over own columns
- *   <all-reduce the scalar>; loss = sqrt(sum) / data_norm
- * cmf_update_motifs == cmf_w_partial + cmf_w_apply on one rank. */
-int cmf_w_partial(cmf_handle h);
-/* cmf_w_partial in two steps, one source each (mult.jl:31-34): cmf_w_partial_num fills the numW half of the
- * [numW | denomW] buffer from H and data alone (legal as soon as H and its halos are final, i.e. right after the halo
- * exchange of the previous H update), cmf_w_partial_den the denomW half (est = conv(W,H) first when it is not
- * current).  A sharded host can then all-reduce numW while the loss conv and the denominator contraction run. */
-int cmf_w_partial_num(cmf_handle h);
-int cmf_w_partial_den(cmf_handle h);
-int cmf_w_apply(cmf_handle h, double l1W, double l2W);
-int cmf_h_update(cmf_handle h, double l1H, double l2H);
-int cmf_loss_partial(cmf_handle h, double *sumsq);
-/* Same, without the host read-back: the fp64 sum is left in the handle's device scalar
- * (cmf_scalar_ptr; replaceable by a caller-owned device double via cmf_set_scalar_buffer) so a
- * device-side all-reduce can consume it and the host synchronises once per iteration. */
-int cmf_loss_partial_async(cmf_handle h);
-int cmf_scalar_ptr(cmf_handle h, void **dev_ptr);
-int cmf_set_scalar_buffer(cmf_handle h, void *dev_ptr);
-/* Device pointer (fp32) of the contiguous [numW | denomW] buffer and its
- * length in floats (same on every rank: 2 * L * Kpad * Npad). */
-int cmf_numden_ptr(cmf_handle h, void **dev_ptr, int64_t *count);
-/* Use a caller-owned device buffer of the same length for [numW | denomW] instead (e.g. the
- * storage of a torch tensor, so torch.distributed can all-reduce it in place); NULL restores
- * the handle's own buffer.  The caller keeps the buffer alive while the handle uses it. */
-int cmf_set_numden_buffer(cmf_handle h, void *dev_ptr);
-/* H halo staging buffers (device, fp32, (L-1) * Kpad floats each):
- *   which = 0: send-to-left  (own first L-1 columns)   -> left rank's right halo
- *   which = 1: send-to-right (own last  L-1 columns)   -> right rank's left halo
- *   which = 2: recv-from-left  (becomes own left halo)
- *   which = 3: recv-from-right (becomes own right halo)
- * cmf_halo_pack fills the send buffers from H; cmf_halo_unpack installs the
- * recv buffers (has_left/has_right say which were actually received). */
-int cmf_halo_ptr(cmf_handle h, int which, void **dev_ptr, int64_t *count);
-/* Caller-owned replacement for staging buffer `which` (same length; NULL restores the handle's own). */
-int cmf_set_halo_buffer(cmf_handle h, int which, void *dev_ptr);
-int cmf_halo_pack(cmf_handle h);
-int cmf_halo_unpack(cmf_handle h, int has_left, int has_right);
 
 /* ---- stand-alone primitives ------------------------------------------------
  * tensor_conv(W, H) -> est (N x T): src/common.jl:17-34. */

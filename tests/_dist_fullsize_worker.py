@@ -1,4 +1,5 @@
-"""Worker: config-2-size MU iterations on the T-sharded path (gloo ranks sharing GPU 0): python _dist_fullsize_worker.py <out.npz> <iters>"""
+"""Worker: config-2-size MU iterations on the T-sharded path, one process per shard (gloo ranks sharing GPU 0, the
+library's host-callback transport): python _dist_fullsize_worker.py <out.npz> <iters>"""
 import os
 import sys
 
@@ -20,10 +21,7 @@ def main():
     data = cmf.gen_synthetic(N=N, T=T, seed=1234, device=0)
     W0, H0 = cmf.init_rand(data, L=L, K=K, seed=0, device=0)
     rule = ShardedMultUpdate(data, W0, H0, device=0)
-    losses = [rule.compute_loss()]
-    for _ in range(iters):
-        rule.update_motifs()
-        losses.append(rule.update_feature_maps())
+    losses = [rule.compute_loss()] + list(rule.iterate(iters))
     W, H = rule.download()
     rule.close()
     if dist.get_rank() == 0:

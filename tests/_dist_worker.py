@@ -1,7 +1,11 @@
 """Worker for the multi-process sharding tests (launched by tests/test_sharded.py).
 
 usage: python _dist_worker.py <engine: cpu|hip> <out.npz> <N> <T> <K> <L> <iters> <reg:0|1>
-Env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT (rendezvous on 127.0.0.1); CMF_TEST_BACKEND=gloo|nccl.
+Env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT (rendezvous on 127.0.0.1); CMF_TEST_BACKEND=gloo|nccl;
+CMF_TEST_OVERLAP=0|1; CMF_TEST_MODE=calls (update_motifs! / update_feature_maps! per iteration) | iterate
+(one cmf_iterate batch) | fit (the host's fit loop / cmf_fit).
+  cpu: the Python mirror of the library's group protocol on the numpy engine (no GPU needed)
+  hip: cmf_jl_amd.sharded.ShardedMultUpdate = the library's own group iteration, one process per shard
 """
 import os
 import sys
@@ -19,29 +23,46 @@ def main():
     import torch.distributed as dist
 
     backend = os.environ.get("CMF_TEST_BACKEND", "gloo")
+    mode = os.environ.get("CMF_TEST_MODE", "calls")
+    overlap = os.environ.get("CMF_TEST_OVERLAP", "0") == "1"
     if backend == "nccl":  # RCCL: one rank per GPU (the single-rank case is what a one-GPU box can run)
         import torch
 
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend)
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rank = dist.get_rank()
     from oracle import cmf_oracle as oracle
-    import cmf_jl_amd as cmf
-    from cmf_jl_amd.sharded import HipShardEngine, ShardedMultUpdate
 
     data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=1234)
     W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
-    kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2) if reg else {}
+    kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2) if reg else dict(l1W=0.0, l2W=0.0, l1H=0.0, l2H=0.0)
+    info = ""
     if engine == "cpu":
-        from shard_engine_cpu import OracleShardEngine as Eng
+        from shard_engine_cpu import OracleShardEngine
+        from shard_protocol_cpu import ProtocolShardedMultUpdate
+
+        rule = ProtocolShardedMultUpdate(data, W0, H0, OracleShardEngine, overlap=overlap)
     else:
-        Eng = HipShardEngine
-    rule = ShardedMultUpdate(data, W0, H0, device=0, engine_cls=Eng, overlap=os.environ.get("CMF_TEST_OVERLAP", "0") == "1")
-    opt = cmf.AlternatingOptimizer(rule, iters, np.inf)
-    res = cmf.fit(opt, data, L, K, W0, H0, check_convergence=False, **kw)
+        from cmf_jl_amd.sharded import ShardedMultUpdate
+
+        rule = ShardedMultUpdate(data, W0, H0, device=0, overlap=overlap,
+                                 transport=os.environ.get("CMF_TEST_TRANSPORT") or None)
+        info = rule.comm_info()
+    losses = [rule.compute_loss()]
+    if mode == "iterate":
+        losses += list(rule.iterate(iters, **kw))
+    elif mode == "fit" and engine == "hip":
+        lh, th, _ = rule.fit_native(iters, np.inf, False, 3, 1e-4, False, **kw)
+        np.testing.assert_allclose(lh[0], losses[0], rtol=1e-12)
+        losses = list(lh)
+    else:
+        for _ in range(iters):
+            rule.update_motifs(l1W=kw["l1W"], l2W=kw["l2W"])
+            losses.append(rule.update_feature_maps(l1H=kw["l1H"], l2H=kw["l2H"]))
+    W, H = rule.download()
     rule.close()
     if rank == 0:
-        np.savez(out, W=res.W, H=res.H, loss_hist=res.loss_hist, bounds=np.asarray(rule.bounds))
+        np.savez(out, W=W, H=H, loss_hist=np.asarray(losses), bounds=np.asarray(rule.bounds), info=np.asarray(info))
     dist.barrier()
     dist.destroy_process_group()
 
