@@ -90,6 +90,7 @@ struct cmf_handle_s {
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
     int conv_variant = 0;   // K % 32 == 0: 3 = one-wave workgroups (conv3_kernel), 2 = 128 x 128 tiles (conv2_kernel), 0 = per mode
     int conv_partials = 1;  // loss partials written by the last conv launch
+    bool conv_split = true; // option "conv_split": quarter tiles for the thin last round of the one-wave conv kernel
     int n_cu = 256;
 
     // HALS scratch (allocated on first use)
@@ -140,7 +141,7 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H);
 static size_t n_partial(const cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
-    size_t n = (size_t)(4 * h->conv_gx) * (size_t)std::max(h->conv_gy, h->conv_gy_ext);  // conv loss partials (64 x 64 tiles)
+    size_t n = (size_t)(16 * h->conv_gx) * (size_t)std::max(h->conv_gy, h->conv_gy_ext); // conv loss partials (64 x 64 tiles, or their quarters)
     n = std::max(n, (size_t)(d.Np / 64) * d.KB * d.L);                                 // PGD gradW norm partials
     n = std::max(n, (size_t)((d.Tl + 63) / 64) * d.KB);                                // PGD gradH norm partials
     n = std::max(n, 2 * (((size_t)d.Tl * d.K32 + 1023) / 1024));                       // Gram-form loss partials
@@ -165,6 +166,16 @@ static int dalloc_zero(T **p, size_t n)
     HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
     return CMF_OK;
 }
+
+// the C2 kernel adds CG consecutive time chunks inside a workgroup: it writes nchunks / CG slabs
+static int hxt_cg(int nchunks)
+{
+    static const int cap = getenv("CMF_HXT_CG") ? atoi(getenv("CMF_HXT_CG")) : 4;
+    int cg = nchunks % 4 == 0 ? 4 : (nchunks % 2 == 0 ? 2 : 1);
+    while (cg > cap && cg > 1) cg /= 2;
+    return cg;
+}
+static int hxt_nslabs(int nchunks) { return nchunks / hxt_cg(nchunks); }
 
 static const int kHxtLP[] = {1, 2, 3, 4, 5, 6, 8}; // 2*LP*16 accumulator registers must fit the 256 AGPRs
 
@@ -365,7 +376,7 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     TRYB(dalloc_zero(&h->XT, TPNp));
     TRYB(dalloc_zero(&h->est, TPNp));
     TRYB(dalloc_zero(&h->estT, TPNp));
-    TRYB(dalloc_zero(&h->wslabs, (size_t)std::max(2 * h->hxt_nchunks, h->hxt_nchunks1) * d.L * d.K32 * d.Np));
+    TRYB(dalloc_zero(&h->wslabs, (size_t)std::max(2 * hxt_nslabs(h->hxt_nchunks), hxt_nslabs(h->hxt_nchunks1)) * d.L * d.K32 * d.Np));
     TRYB(dalloc_zero(&h->numden_own, (size_t)2 * d.L * d.K32 * d.Np));
     h->numden = h->numden_own;
     TRYB(dalloc_zero(&h->hslabs, (size_t)std::max(2 * h->tc_S, h->tc_S1) * d.Tl * d.K32));
@@ -433,10 +444,17 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     // (0.924 vs 0.931 ms loss only, 0.936 vs 0.943 ms loss + store), the 128 x 128 tiles for the store-only ones
     // (0.911 vs 0.932 ms est, 0.910 vs 0.924 ms est')
     constexpr bool reads_data = (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6);
-    const int variant = h->conv_variant ? h->conv_variant : (reads_data ? 3 : 2);
+    // The one-wave kernel can cut the tiles of its thin last round into quarter tiles (conv3_kernel).  That pays when
+    // the remainder is small against the 12 wave slots per CU -- short shards: 3136 tiles on 3072 slots at T/8 -- and
+    // then decides the variant for every mode; a remainder above 3 tiles per CU is left as whole tiles.
+    const int gx3 = d.Np / 64, tiles3 = gx3 * ((T_store + 63) / 64), slots3 = 12 * h->n_cu;
+    const int rem3 = tiles3 % slots3;
+    const bool split = h->conv_split && rem3 > 0 && rem3 <= 3 * h->n_cu && tiles3 / slots3 < 8;
+    const int variant = h->conv_variant ? h->conv_variant : ((reads_data || split) ? 3 : 2);
     if (d.K % 32 == 0 && variant == 3) {
-        grid = dim3(d.Np / 64, (T_store + 63) / 64);
-        hipLaunchKernelGGL((conv3_kernel<MODE>), grid, dim3(64), 0, h->stream, p);
+        const int n_full = split ? tiles3 - rem3 : tiles3;
+        grid = dim3(n_full + 4 * (tiles3 - n_full));
+        hipLaunchKernelGGL((conv3_kernel<MODE>), grid, dim3(64), 0, h->stream, p, gx3, n_full);
     } else if (d.K % 32 == 0) hipLaunchKernelGGL((conv2_kernel<MODE>), grid, block, 0, h->stream, p);
     else hipLaunchKernelGGL((conv_kernel<MODE, 0>), grid, block, 0, h->stream, p);
     h->conv_partials = (int)(grid.x * grid.y);
@@ -452,7 +470,8 @@ static int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int 
     p.H = h->H; p.X0 = X0; p.X1 = X1; p.slabs = slabs;
     p.Np = NpX; p.K32 = d.K32; p.KB = d.KB; p.PADL = d.PADL; p.L = d.L; p.Tl = d.Tl; p.chunk_len = chunk_len;
     p.G = h->hxt_groups; p.nsrc = nsrc;
-    dim3 grid((NpX / 128) * h->hxt_groups, nchunks, nsrc * d.KB), block(256);
+    p.CG = hxt_cg(nchunks);
+    dim3 grid((NpX / 128) * p.CG * h->hxt_groups, nchunks / p.CG, nsrc * d.KB), block(256);
     switch (h->hxt_LP) {
 #define CASE(LP_) case LP_: hipLaunchKernelGGL((hxt_kernel<LP_>), grid, block, 0, h->stream, p); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(8)
@@ -529,7 +548,7 @@ static int w_partial_impl(cmf_handle_s *h)
         CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
     h->est_kind = 1;
     CMFTRY(launch_hxt(h));                                  // mult.jl:31-34
-    return launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks, (size_t)2 * d.L * d.K32 * d.Np);
+    return launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks), (size_t)2 * d.L * d.K32 * d.Np);
 }
 
 // The two halves of w_partial_impl as separate steps (same arithmetic, the sources contracted one at a time): the
@@ -546,15 +565,15 @@ static int w_partial_half_impl(cmf_handle_s *h, int den)
     }
     const float *src = den ? h->est : h->X;
     CMFTRY(launch_hxt_on(h, src, src, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1)); // mult.jl:31-34, one source
-    return launch_slab_sum(h, h->numden + (den ? LKN : 0), h->wslabs, h->hxt_nchunks1, LKN);
+    return launch_slab_sum(h, h->numden + (den ? LKN : 0), h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN);
 }
 
-static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W)
+static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W, const float *tail_src = nullptr, float *tail_dst = nullptr, int tail_n = 0)
 {
     const CmfDims &d = h->d;
     dim3 grid(d.Np / 64, d.KB, d.L);
     hipLaunchKernelGGL(w_update_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden, 1,
-                       d.N, d.K, d.L, d.Np, d.K32, (float)l1W, (float)(2.0 * l2W)); // mult.jl:37-38
+                       d.N, d.K, d.L, d.Np, d.K32, (float)l1W, (float)(2.0 * l2W), tail_src, tail_dst, tail_n); // mult.jl:37-38
     KCHK("w_update_kernel");
     h->est_kind = 0;
     return CMF_OK;
@@ -573,7 +592,7 @@ static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
     return CMF_OK;
 }
 
-static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = true)
+static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = true, double *host_out = nullptr)
 {
     const CmfDims &d = h->d;
     if (h->reuse_est) {
@@ -582,7 +601,7 @@ static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = tru
     } else {
         CMFTRY(launch_conv<2>(h, nullptr, d.Tl, h->conv_gy)); // mult.jl:55-57
     }
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, host_out);
     KCHK("loss_reduce_kernel");
     return readback ? read_scalar(h, 0, sumsq) : CMF_OK;
 }
@@ -724,6 +743,11 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
     if (std::strcmp(name, "conv_kernel") == 0) { // K % 32 == 0 only: 0 = chosen per mode (default), 3 = one-wave workgroups, 2 = 128 x 128 tiles
         if (value != 0 && value != 2 && value != 3) return fail(CMF_ERR_ARG, "conv_kernel must be 0 (per mode), 2 or 3");
         h->conv_variant = value;
+        h->est_kind = 0;
+        return CMF_OK;
+    }
+    if (std::strcmp(name, "conv_split") == 0) { // 0 = never cut the one-wave conv kernel's last round into quarter tiles
+        h->conv_split = value != 0;
         h->est_kind = 0;
         return CMF_OK;
     }
@@ -910,7 +934,7 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
         return CMF_OK;
     }
     if (!h->h_ring) {
-        HIPCHK(hipHostMalloc(&h->h_ring, 2 * sizeof(double)));
+        HIPCHK(hipHostMalloc(&h->h_ring, 2 * sizeof(double), hipHostMallocCoherent)); // written by a kernel, read by the host after an event
         for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ring_ev[q], hipEventDisableTiming));
     }
     auto collect = [&](int64_t it) -> int {
@@ -926,9 +950,8 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
             CMFTRY(w_apply_impl(h, l1W, l2W));
         }
         CMFTRY(h_update_impl(h, l1H, l2H)); // :54
-        CMFTRY(loss_partial_impl(h, nullptr, false));
         const int slot = (int)(it & 1);
-        HIPCHK(hipMemcpyAsync(h->h_ring + slot, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        CMFTRY(loss_partial_impl(h, nullptr, false, h->h_ring + slot)); // the reduction writes the sum to the pinned slot itself
         HIPCHK(hipEventRecord(h->ring_ev[slot], h->stream));
         if (it > 0) CMFTRY(collect(it - 1));
     }
@@ -1057,8 +1080,9 @@ int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transpor
         int rc = rccl_load();
         if (rc != CMF_OK) return bail(rc);
         g->comm.assign((size_t)ndev, nullptr);
+        (void)hipGetLastError(); // RCCL reports a stale (already handled) HIP error of this thread as its own
         ncclResult_t r_ = g_rccl.CommInitAll(g->comm.data(), ndev, devices);
-        if (r_ != ncclSuccess) return bail(fail(CMF_ERR_COMM, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(r_)));
+        if (r_ != ncclSuccess) return bail(fail(CMF_ERR_COMM, "ncclCommInitAll failed: %s (RCCL from %s; if the process holds two HIP runtimes -- e.g. PyTorch imported after this library -- import torch first)", g_rccl.GetErrorString(r_), g_rccl.path.c_str()));
     }
     int rc = group_alloc_buffers(g);
     if (rc == CMF_OK) rc = group_finish_norm(g);
@@ -1111,8 +1135,9 @@ static int comm_attach(cmf_handle_s *h, int nranks, int rank, int transport, con
         ncclUniqueId id;
         std::memcpy(&id, id128, sizeof(id));
         g->comm.assign(1, nullptr);
+        (void)hipGetLastError(); // RCCL reports a stale (already handled) HIP error of this thread as its own
         ncclResult_t r_ = g_rccl.CommInitRank(&g->comm[0], nranks, id, rank);
-        if (r_ != ncclSuccess) return bail(fail(CMF_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r_)));
+        if (r_ != ncclSuccess) return bail(fail(CMF_ERR_COMM, "ncclCommInitRank failed: %s (RCCL from %s; if the process holds two HIP runtimes -- e.g. PyTorch imported after this library -- import torch first)", g_rccl.GetErrorString(r_), g_rccl.path.c_str()));
     }
     rc = group_alloc_buffers(g);
     if (rc == CMF_OK) rc = group_finish_norm(g);
@@ -1181,7 +1206,7 @@ static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked)
     const CmfDims &d = h->d;
     if (masked) CMFTRY(launch_conv<6>(h, h->est, d.Tl, h->conv_gy)); // pgd.jl:64-70
     else CMFTRY(launch_conv<4>(h, h->est, d.Tl, h->conv_gy));
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, (double *)nullptr);
     KCHK("loss_reduce_kernel");
     h->est_kind = masked ? 3 : 2;
     return sumsq ? read_scalar(h, 0, sumsq) : CMF_OK;
@@ -1243,12 +1268,12 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     // G = resid * H_unfold' (hals.jl:104-110 needs resid * h): ONE C2 contraction on the stored residual
     CMFTRY(ensure_resid(h));
     CMFTRY(launch_hxt_on(h, h->est, h->est, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
-    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks1, (size_t)d.L * d.K32 * d.Np));
+    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), (size_t)d.L * d.K32 * d.Np));
     // HH = H_unfold * H_unfold' (hals.jl:56-60: row norms are its diagonal) with the same C2 kernel
     hipLaunchKernelGGL(hals_build_hut_kernel, dim3(2048), dim3(256), 0, h->stream, h->H, h->hals_HuT, d.Tl, d.L, d.K32, h->hals_NpH, d.PADL);
     KCHK("hals_build_hut_kernel");
     CMFTRY(launch_hxt_on(h, h->hals_HuT, h->hals_HuT, h->hals_NpH, 1, h->hals_hhslabs, h->hals_nch, h->hals_clen));
-    CMFTRY(launch_slab_sum(h, h->hals_HH, h->hals_hhslabs, h->hals_nch, (size_t)d.L * d.K32 * h->hals_NpH));
+    CMFTRY(launch_slab_sum(h, h->hals_HH, h->hals_hhslabs, hxt_nslabs(h->hals_nch), (size_t)d.L * d.K32 * h->hals_NpH));
     // the K*L sequential column updates, k outer / lag inner (hals.jl:90-97)
     if (d.L * d.K32 > 1024)
         return fail(CMF_ERR_UNSUPPORTED, "HALS W sweep: L*K = %d exceeds the 1024 state entries per unit it keeps on chip", d.L * d.K32);
@@ -1334,12 +1359,12 @@ static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W)
     const size_t LKN = (size_t)d.L * d.K32 * d.Np;
     // numW = H_shift * data' (mult.jl:32): one C2 contraction
     CMFTRY(launch_hxt_on(h, h->X, h->X, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
-    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks1, LKN));
+    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN));
     // denomW = H_shift * est' (mult.jl:33) = HH * W with HH = H_unfold * H_unfold'
     hipLaunchKernelGGL(hals_build_hut_kernel, dim3(2048), dim3(256), 0, h->stream, h->H, h->hals_HuT, d.Tl, d.L, d.K32, h->hals_NpH, d.PADL);
     KCHK("hals_build_hut_kernel");
     CMFTRY(launch_hxt_on(h, h->hals_HuT, h->hals_HuT, h->hals_NpH, 1, h->hals_hhslabs, h->hals_nch, h->hals_clen));
-    CMFTRY(launch_slab_sum(h, h->hals_HH, h->hals_hhslabs, h->hals_nch, (size_t)d.L * d.K32 * h->hals_NpH));
+    CMFTRY(launch_slab_sum(h, h->hals_HH, h->hals_hhslabs, hxt_nslabs(h->hals_nch), (size_t)d.L * d.K32 * h->hals_NpH));
     hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 128, d.L * d.KB), dim3(256), 0, h->stream, h->hals_HH, h->Wt, h->numden + LKN,
                        d.L * d.K32, h->hals_NpH, d.Np);
     KCHK("gram_w_kernel");
@@ -1371,9 +1396,9 @@ static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss)
         hipLaunchKernelGGL(gram_dot_kernel, dim3(nb), dim3(256), 0, h->stream, h->H, h->gram_numden_h, h->gram_numden_h + TK, h->partial,
                            d.Tl, d.K, d.K32, d.PADL, nb);
         KCHK("gram_dot_kernel");
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->d_scalar + 2);
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->d_scalar + 2, (double *)nullptr);
         KCHK("loss_reduce_kernel");
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial + nb, nb, h->d_scalar + 3);
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial + nb, nb, h->d_scalar + 3, (double *)nullptr);
         KCHK("loss_reduce_kernel");
         double a = 0.0, b = 0.0;
         CMFTRY(read_scalar(h, 2, &a));
@@ -1412,14 +1437,14 @@ static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
     const size_t LKN = (size_t)d.L * d.K32 * d.Np;
     CMFTRY(ensure_resid(h, h->M != nullptr));                                                            // pgd.jl:230 (:64-67 with a mask)
     CMFTRY(launch_hxt_on(h, h->est, h->est, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1)); // pgd.jl:206-214
-    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, h->hxt_nchunks1, LKN));
+    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN));
     dim3 grid(d.Np / 64, d.KB, d.L);
     const int nblk = (d.Np / 64) * d.KB * d.L;
     if ((size_t)nblk > n_partial(h)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
     hipLaunchKernelGGL(pgd_w_grad_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->numden, h->numden + LKN, h->partial,
                        d.N, d.K, d.Np, d.K32, (float)pen_sq, (float)pen_abs);                            // pgd.jl:231-234
     KCHK("pgd_w_grad_kernel");
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nblk, h->d_scalar + 1);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nblk, h->d_scalar + 1, (double *)nullptr);
     KCHK("loss_reduce_kernel");
     hipLaunchKernelGGL(pgd_w_apply_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden + LKN, h->d_scalar + 1,
                        d.N, d.K, d.Np, d.K32, (float)h->pgd_stepW, nonneg);                              // pgd.jl:237-241
@@ -1442,7 +1467,7 @@ static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
     hipLaunchKernelGGL(pgd_h_grad_kernel, grid, dim3(256), 0, h->stream, h->H, h->hslabs, h->tc_S1, h->pgd_gradH, h->partial,
                        d.Tl, d.K, d.K32, d.PADL, (float)pen_sq, (float)pen_abs);
     KCHK("pgd_h_grad_kernel");
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nblk, h->d_scalar + 1);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nblk, h->d_scalar + 1, (double *)nullptr);
     KCHK("loss_reduce_kernel");
     hipLaunchKernelGGL(pgd_h_apply_kernel, grid, dim3(256), 0, h->stream, h->H, h->Ht, h->pgd_gradH, h->d_scalar + 1,
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)h->pgd_stepH, nonneg);

@@ -161,7 +161,7 @@ static int group_alloc_buffers(cmf_group_s *g)
         s->halo[3] = r < g->nranks - 1 ? g->halo_all[i] + (size_t)(2 * (r + 1)) * g->HC : nullptr;   // right neighbour's send-to-left block
     }
     CMFTRY(group_use(s0));
-    HIPCHK(hipHostMalloc(&g->h_tail, (size_t)(3 * g->tail) * sizeof(float))); // 2 ring slots + the synchronous read-back
+    HIPCHK(hipHostMalloc(&g->h_tail, (size_t)(3 * g->tail) * sizeof(float), hipHostMallocCoherent)); // 2 ring slots + the synchronous read-back
     for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&g->ring_ev[q], hipEventDisableTiming));
     return CMF_OK;
 }
@@ -423,16 +423,15 @@ static int group_update_motifs(cmf_group_s *g, double l1W, double l2W, int ring_
         }
         CMFTRY(group_allreduce(g, g->red, 0, (size_t)(g->LKN2 + g->tail)));
     }
-    if (ring_slot >= 0) {
-        cmf_handle_s *s = g->sh[0];
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        cmf_handle_s *s = g->sh[i];
         CMFTRY(group_use(s));
-        HIPCHK(hipMemcpyAsync(g->h_tail + (size_t)ring_slot * g->tail, g->red[0] + g->LKN2, (size_t)(2 * g->nranks) * sizeof(float),
-                              hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipEventRecord(g->ring_ev[ring_slot], s->stream));
-    }
-    for (cmf_handle_s *s : g->sh) {
-        CMFTRY(group_use(s));
-        CMFTRY(w_apply_impl(s, l1W, l2W));
+        if (i == 0 && ring_slot >= 0) { // shard 0's W update also drops the reduced loss pairs into the pinned ring slot
+            CMFTRY(w_apply_impl(s, l1W, l2W, g->red[0] + g->LKN2, g->h_tail + (size_t)ring_slot * g->tail, 2 * g->nranks));
+            HIPCHK(hipEventRecord(g->ring_ev[ring_slot], s->stream));
+        } else {
+            CMFTRY(w_apply_impl(s, l1W, l2W));
+        }
     }
     return CMF_OK;
 }

@@ -537,11 +537,184 @@ __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t
     conv_epilogue<MODE, 1>(acc, p, t0, n0, 0, 0, i, h, lane, 0, lane, pidx);
 }
 
+// One 32 x 32 block of the epilogue (the quarter tiles of conv3_kernel): acc[r] is t = tb + crow(r,h), n = nb + i, or
+// in the transposed modes n = nb + crow(r,h), t = tb + i.  Same buffer-addressed loads / stores as conv_epilogue.
 template <int MODE>
-__global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p)
+__device__ __forceinline__ void conv_epilogue_block(const f32x16 &acc, const ConvParams &p, int tb, int nb, int i, int h, int lane, int pidx)
+{
+    const int Np = p.Np, TP = p.TP;
+    constexpr bool LOSS = (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6);
+    constexpr bool RESID = (MODE == 4 || MODE == 6);
+    constexpr bool MASKED = (MODE == 6 || MODE == 7);
+    if (!CONV_TRANSPOSED(MODE)) {
+        int rows = p.T_store - tb;
+        rows = rows < 0 ? 0 : (rows > 32 ? 32 : rows);
+        const size_t origin = (size_t)(p.PADL + tb) * Np + nb;
+        const size_t bytes = rows ? ((size_t)(rows - 1) * Np + 32) * 4 : 0;
+        const __amdgpu_buffer_rsrc_t ro = cmf_rsrc(p.out + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rd = cmf_rsrc(p.data + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rm = cmf_rsrc(p.mask + origin, bytes);
+        const int voff = (4 * h * Np + i) * 4;
+        float dv[16], mv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int so = (((r & 3) + 8 * (r >> 2)) * Np) * 4;
+            dv[r] = LOSS ? cmf_bload(rd, voff, so) : 0.f; // rows past T_store read as 0 (masked below)
+            mv[r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
+        }
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int so = (((r & 3) + 8 * (r >> 2)) * Np) * 4;
+            const float v = acc[r];
+            float d = MASKED ? (v - dv[r]) * mv[r] : v - dv[r];
+            if (MODE == 0 || MODE == 3) cmf_bstore(v, ro, voff, so);
+            if (RESID) cmf_bstore(d, ro, voff, so);
+            if (LOSS) {
+                d = (cmf_crow(r, h) < rows) ? d : 0.f;
+                lsum = fmaf(d, d, lsum);
+            }
+        }
+        if (LOSS) {
+            float x = lsum;
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, false)); // row_shr:1
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, false)); // row_shr:2
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, false)); // row_shr:4
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, false)); // row_shr:8
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false)); // row_bcast:15
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false)); // row_bcast:31
+            if (lane == 63) p.partial[pidx] = (double)x;
+        }
+    } else {
+        const size_t origin = (size_t)nb * TP + p.PADL + tb;
+        const size_t bytes = ((size_t)31 * TP + 32) * 4;
+        const __amdgpu_buffer_rsrc_t ro = cmf_rsrc(p.out + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rd = cmf_rsrc(p.data + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rm = cmf_rsrc(p.mask + origin, bytes);
+        const int voff = (4 * h * TP + i) * 4;
+        if (tb + i < p.T_store) {
+            float dv[16], mv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = (((r & 3) + 8 * (r >> 2)) * TP) * 4;
+                dv[r] = (MODE != 1) ? cmf_bload(rd, voff, so) : 0.f;
+                mv[r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = (((r & 3) + 8 * (r >> 2)) * TP) * 4;
+                cmf_bstore(MASKED ? (acc[r] - dv[r]) * mv[r] : acc[r] - dv[r], ro, voff, so);
+            }
+        }
+    }
+}
+
+// one lag of a quarter tile: 16 k pairs, one MFMA each, into the single accumulator -- the same k / lag order per
+// output element as conv2_lag, so a quarter tile's results are bitwise those of the 64 x 64 tile path
+template <int MODE, bool FIRST = false>
+__device__ __forceinline__ void convq_lag(f32x16 &acc, const float *hsb, const float (&w)[16])
+{
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float a0 = hsb[0];
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int kp = 0; kp < 16; ++kp) {
+        float na0 = 0.f;
+        if (kp + 1 < 16) {
+            na0 = hsb[(kp + 1) * 2 * CONV3_STRIDE];
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        const bool zc = FIRST && kp == 0;
+        if (CONV_TRANSPOSED(MODE)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp], a0, zc ? zero16 : acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[kp], zc ? zero16 : acc, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        a0 = na0;
+    }
+}
+
+__device__ __forceinline__ void convq_load_w(float (&w)[16], __amdgpu_buffer_rsrc_t wr, int woff, int lag, int lagbytes, int rowbytes)
+{
+#pragma unroll
+    for (int kp = 0; kp < 16; ++kp) w[kp] = cmf_bload(wr, woff, lag * lagbytes + kp * 2 * rowbytes);
+}
+
+// A quarter tile: one wave, one 32 (t) x 32 (n) block at (t0, n0); H strip = 32 k rows x 64 columns (32 + the 32-lag halo)
+template <int MODE>
+__device__ __forceinline__ void conv3_quarter(const ConvParams &p, float *Hs, int t0, int n0, int lane, int pidx)
+{
+    const int i = lane & 31, h = lane >> 5;
+    const int Np = p.Np, TP = p.TP;
+    const int K32 = p.KB * 32;
+    f32x16 acc;
+    const int LB = (p.L + 31) >> 5;
+    const int rowbytes = Np * 4;
+    const int lagbytes = K32 * Np * 4;
+    const int woff = (h * Np + n0 + i) * 4;
+    float wA[16], wB[16];
+    for (int kb = 0; kb < p.KB; ++kb) {
+        for (int lb = 0; lb < LB; ++lb) {
+            const int lbeg = lb * 32;
+            const int lend = (p.L < lbeg + 32) ? p.L : (lbeg + 32);
+            const int npair = (lend - lbeg + 1) >> 1;
+            const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wt + ((size_t)lbeg * K32 + kb * 32) * Np, (size_t)(2 * npair) * lagbytes);
+            convq_load_w(wA, wr, woff, 0, lagbytes, rowbytes);
+            {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,64): 8 lanes per row, 8 rows per pass
+                const int r = lane >> 3, c = (lane & 7) * 4;
+                const float *src = p.Ht + (size_t)(kb * 32 + r) * TP + (p.PADL + t0 - lbeg - 32 + c);
+                float *dst = Hs + r * CONV3_STRIDE + c;
+                f32x4 v[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) v[q * 2 + j] = *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * j);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4 *>(dst + (8 * q) * CONV3_STRIDE + 32 * j) = v[q * 2 + j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float *hsb = Hs + h * CONV3_STRIDE + 32 + i;
+            int pr = 0;
+            if (kb == 0 && lb == 0) {
+                convq_load_w(wB, wr, woff, 1, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                convq_lag<MODE, true>(acc, hsb, wA);
+                convq_load_w(wA, wr, woff, (1 < npair) ? 2 : 0, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                convq_lag<MODE>(acc, hsb - 1, wB);
+                pr = 1;
+            }
+            for (; pr < npair; ++pr) {
+                const int l0 = 2 * pr;
+                convq_load_w(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                convq_lag<MODE>(acc, hsb - l0, wA);
+                convq_load_w(wA, wr, woff, (pr + 1 < npair) ? l0 + 2 : l0, lagbytes, rowbytes);
+                __builtin_amdgcn_sched_barrier(0);
+                convq_lag<MODE>(acc, hsb - l0 - 1, wB);
+            }
+        }
+    }
+    conv_epilogue_block<MODE>(acc, p, t0, n0, i, h, lane, pidx);
+}
+
+// grid: n_full + 4 * (tiles - n_full) one-wave workgroups.  Workgroups [0, n_full) are whole 64 x 64 tiles (tile index
+// = n tile fastest); the remaining tiles -- the part of the grid that would otherwise run as a thin last round on a
+// few SIMDs while the rest of the chip idles (3136 tiles on 3072 wave slots at a T/8 shard) -- are cut into four
+// 32 x 32 quarter tiles each, dispatched last, so that the tail is spread over four times as many SIMDs.
+template <int MODE>
+__global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p, int gx, int n_full)
 {
     __shared__ __attribute__((aligned(16))) float Hs[32 * CONV3_STRIDE];
-    conv3_tile<MODE>(p, Hs, blockIdx.y * 64, blockIdx.x * 64, threadIdx.x, blockIdx.y * gridDim.x + blockIdx.x);
+    const int b = blockIdx.x;
+    if (b < n_full) {
+        conv3_tile<MODE>(p, Hs, (b / gx) * 64, (b % gx) * 64, threadIdx.x, b);
+    } else {
+        const int q = b - n_full, tile = n_full + (q >> 2), sub = q & 3;
+        conv3_quarter<MODE>(p, Hs, (tile / gx) * 64 + (sub >> 1) * 32, (tile % gx) * 64 + (sub & 1) * 32, threadIdx.x, b);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,6 +737,8 @@ struct HxtParams {
     int G;           // lag groups of 2*LP lags (fastest-varying part of blockIdx.x, so the groups
                      // that re-read the same X rows are dispatched together)
     int nsrc;        // 2: X0 and X1 (numW, denomW);  1: X0 only (HALS Gram of H_unfold)
+    int CG;          // time chunks per workgroup (1, 2 or 4): the workgroup's waves are CG chunks x 4/CG adjacent n blocks and
+                     // the CG partial sums of a block are added through LDS before the store (slabs: [ceil(nchunks/CG)]...)
 };
 
 // E[u] = R(2u), O[u] = R(2u-1), B[u] = X rows (2u, 2u+1) of the group that starts `row` rows after the
@@ -603,7 +778,9 @@ __device__ __forceinline__ void hxt_group(f32x16 (&acc)[2 * LP], const float (&E
 template <int LP>
 __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave index as a scalar: the time chunk (and with it the buffer descriptors) depends on it, and a descriptor the
+    // compiler believes to be divergent turns every buffer load into a waterfall loop
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
     // blockIdx.x -> (n block quad, lag group).  Placement (speed only): workgroup b runs on XCD b % 8, so when the
     // quads come in multiples of 8 the lag groups of one quad are put 8 apart -- the same XCD re-reads their common
@@ -616,8 +793,10 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
         quad = blockIdx.x / p.G;
         lg = blockIdx.x % p.G;
     }
-    const int nb = quad * 4 + wave;
-    const int c = blockIdx.y;
+    const int CG = p.CG;
+    const int cw = wave % CG, nw = wave / CG; // wave = nw * CG + cw
+    const int nb = quad * (4 / CG) + nw;
+    const int c = blockIdx.y * CG + cw;
     const int src = blockIdx.z % p.nsrc;
     const int kb = blockIdx.z / p.nsrc;
     const int lag0 = lg * 2 * LP;
@@ -688,17 +867,41 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
 #undef HXT_SCHED
     }
 
-    // store: acc[a][r] -> lag lag0+a, k = kb*32 + crow(r,h), n = nb*32 + i
-    float *slab = p.slabs + (size_t)(c * p.nsrc + src) * p.L * K32 * Np;
+    // store: acc[a][r] -> lag lag0+a, k = kb*32 + crow(r,h), n = nb*32 + i, into the slab of this chunk group
+    float *slab = p.slabs + (size_t)(blockIdx.y * p.nsrc + src) * p.L * K32 * Np;
+    if (CG == 1) {
+#pragma unroll
+        for (int a = 0; a < 2 * LP; ++a) {
+            int l = lag0 + a;
+            if (l < p.L) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int k = kb * 32 + cmf_crow(r, h);
+                    slab[((size_t)l * K32 + k) * Np + nb * 32 + i] = acc[a][r];
+                }
+            }
+        }
+        return;
+    }
+    // The CG waves that hold the same (n block, k block, lag group) for CG consecutive time chunks add their partial
+    // sums through LDS in a fixed order (chunk 0, 1, ...: deterministic) and each stores 16/CG of the registers:
+    // CG times less slab traffic out of this kernel and into the slab sum.  One accumulator block per pass, two LDS
+    // buffers, one barrier per pass.
+    __shared__ float red[2][4][16][64];
 #pragma unroll
     for (int a = 0; a < 2 * LP; ++a) {
-        int l = lag0 + a;
-        if (l < p.L) {
+        const int buf = a & 1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int k = kb * 32 + cmf_crow(r, h);
-                slab[((size_t)l * K32 + k) * Np + nb * 32 + i] = acc[a][r];
-            }
+        for (int r = 0; r < 16; ++r) red[buf][wave][r][lane] = acc[a][r];
+        __syncthreads();
+        const int l = lag0 + a;
+        const int per = 16 / CG;
+        for (int rr = 0; rr < per; ++rr) {
+            const int r = cw * per + rr;
+            float sum = red[buf][nw * CG][r][lane];
+            for (int v = 1; v < CG; ++v) sum += red[buf][nw * CG + v][r][lane];
+            const int k = kb * 32 + cmf_crow(r, h);
+            if (l < p.L) slab[((size_t)l * K32 + k) * Np + nb * 32 + i] = sum;
         }
     }
 }
@@ -938,11 +1141,16 @@ __device__ __forceinline__ float cmf_mu(float x, float num, float den, float l1,
 }
 
 // grid: (Np/64, KB, L), block 256.  numden: [nslabs][2][L][K32][Np]
+// tail_src / tail_dst (may be NULL): block (0,0,0) also copies `tail_n` floats -- the loss pairs behind the
+// [numW | denomW] all-reduce buffer of a sharded group -- to pinned host memory, so the read-back costs no extra launch.
 __global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, const float *numden, int nslabs,
-                                                        int N, int K, int L, int Np, int K32, float l1, float two_l2)
+                                                        int N, int K, int L, int Np, int K32, float l1, float two_l2,
+                                                        const float *tail_src, float *tail_dst, int tail_n)
 {
     __shared__ float tile[32][65];
     const int tid = threadIdx.x;
+    if (tail_dst && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int j = tid; j < tail_n; j += 256) tail_dst[j] = tail_src[j];
     const int n0 = blockIdx.x * 64, kb = blockIdx.y, l = blockIdx.z;
     const size_t LKN = (size_t)L * K32 * Np;
     {
@@ -1043,7 +1251,8 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *
 
 // *out = sum(partial[0..n))   one block; eight independent loads per thread and round (the one-wave conv kernel
 // writes 25 024 partials at config 2: a plain strided loop is a chain of dependent HBM round trips)
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial, int n, double *out)
+// host_out (may be NULL): pinned host memory that receives the sum as well (the pipelined loss read-back of cmf_iterate)
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial, int n, double *out, double *host_out = nullptr)
 {
     __shared__ double red[256];
     double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1060,7 +1269,10 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial,
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = red[0];
+    if (threadIdx.x == 0) {
+        *out = red[0];
+        if (host_out) *host_out = red[0];
+    }
 }
 
 

@@ -612,13 +612,15 @@ def parameter_sweep(data, L_vals=(7,), K_vals=(3,), alg_vals=(":mult",), max_itr
     on all ranks -- replicas, no data-path collective.  A `seed` keyword is used as given by every fit."""
     combos = [(L, K, alg) for L in L_vals for K in K_vals for alg in alg_vals]
     dist = None
-    try:
+    import sys
+
+    if "torch" in sys.modules:  # a process group can only be up if torch is already imported: never import it from here
+        # (importing torch AFTER libcmf_hip.so maps PyTorch's bundled HIP / HSA runtime next to the system one this
+        # library is already bound to, and RCCL then picks the uninitialised copy)
         import torch.distributed as _dist
 
         if _dist.is_available() and _dist.is_initialized():
             dist = _dist
-    except ImportError:
-        pass
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist else (0, 1)
     mine = {}
     for idx, (L, K, alg) in enumerate(combos):
