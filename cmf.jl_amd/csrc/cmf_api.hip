@@ -449,7 +449,8 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     // then decides the variant for every mode; a remainder above 3 tiles per CU is left as whole tiles.
     const int gx3 = d.Np / 64, tiles3 = gx3 * ((T_store + 63) / 64), slots3 = 12 * h->n_cu;
     const int rem3 = tiles3 % slots3;
-    const bool split = h->conv_split && rem3 > 0 && rem3 <= 3 * h->n_cu && tiles3 / slots3 < 8;
+    static const int split_rounds = getenv("CMF_CONV_SPLIT_ROUNDS") ? atoi(getenv("CMF_CONV_SPLIT_ROUNDS")) : 8;
+    const bool split = h->conv_split && rem3 > 0 && rem3 <= 3 * h->n_cu && tiles3 / slots3 < split_rounds;
     const int variant = h->conv_variant ? h->conv_variant : ((reads_data || split) ? 3 : 2);
     if (d.K % 32 == 0 && variant == 3) {
         const int n_full = split ? tiles3 - rem3 : tiles3;

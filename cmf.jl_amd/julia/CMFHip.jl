@@ -7,14 +7,19 @@
 # arrays are already in the layout the C ABI expects (column-major Float64), so every call is a
 # plain pointer hand-off.
 #
-# Usage inside CMF.jl (after `include("CMFHip.jl")` in src/CMF.jl, next to algs/mult.jl):
+# Where to include it: in src/CMF.jl AFTER `include("./algs/pgd.jl")` (src/CMF.jl:35), i.e. after the last algorithm
+# file.  The imports below need names that only exist by then: `update_motifs!` / `update_feature_maps!` become
+# generic functions in algs/mult.jl (:31), and SquareLoss, MaskedLoss, SquarePenalty, AbsolutePenalty and
+# NonnegConstraint are defined in algs/pgd.jl (:35).  (Including it next to algs/mult.jl, as an earlier revision of
+# this file said, fails with UndefVarError at the pgd.jl names.)
 #
 #     results = fit_cnmf(data; L=20, K=32, alg=HIPMultUpdate, max_itr=100)
 #
 module CMFHip
 
 import ..CMF: AbstractCFUpdate, Tensor
-import ..CMF: update_motifs!, update_feature_maps!
+import ..CMF: update_motifs!, update_feature_maps!                                   # generic functions: algs/mult.jl
+import ..CMF: SquareLoss, MaskedLoss, SquarePenalty, AbsolutePenalty, NonnegConstraint  # types: algs/pgd.jl
 
 const LIBCMF = get(ENV, "LIBCMF_HIP", "libcmf_hip.so")
 
@@ -26,11 +31,16 @@ end
 
 """
     HIPMultUpdate(data, W, H; device=0)
+    HIPMultUpdate(data, W, H; devices=0:7)
 
 Drop-in for `MultUpdate(data, W, H)` (src/algs/mult.jl:11-20).  Uploads `data`, `W`, `H`; the
 rule's scratch (est, numW, denomW, numH, denomH) lives on the GPU.  W and H stay device-resident
 between calls and are written back into the caller's arrays after every `update_feature_maps!`
 (the reference mutates W and H in place; mult.jl:37-38, :51-52).
+
+With `devices` the rule is a T-sharded group on several GPUs of the node (`cmf_create_multi`): this one Julia
+task keeps making the same two calls per iteration (alternating.jl:52,54) and the library runs the sharded
+iteration -- one RCCL all-reduce of [numW | denomW] and one H-halo all-gather per iteration.
 """
 mutable struct HIPMultUpdate <: AbstractCFUpdate
     handle::Ptr{Cvoid}
@@ -39,15 +49,23 @@ mutable struct HIPMultUpdate <: AbstractCFUpdate
 end
 
 function HIPMultUpdate(data::Matrix{Float64}, W::Tensor{Float64}, H::Matrix{Float64};
-                       device::Integer=parse(Int, get(ENV, "LOCAL_RANK", "0")), sync_every_call::Bool=true)
+                       device::Integer=parse(Int, get(ENV, "LOCAL_RANK", "0")), devices=nothing,
+                       sync_every_call::Bool=true)
     K, N, L = size(W)
     T = size(data, 2)
     size(data, 1) == N || throw(DimensionMismatch("data has $(size(data,1)) rows, W has N=$N"))
     size(H) == (K, T) || throw(DimensionMismatch("H must be $K x $T"))
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:cmf_create, LIBCMF), Cint,
-                (Ref{Ptr{Cvoid}}, Cint, Int64, Int64, Int64, Int64, Ptr{Float64}),
-                h, device, N, T, K, L, data))
+    if devices === nothing
+        check(ccall((:cmf_create, LIBCMF), Cint,
+                    (Ref{Ptr{Cvoid}}, Cint, Int64, Int64, Int64, Int64, Ptr{Float64}),
+                    h, device, N, T, K, L, data))
+    else
+        devs = Cint[d for d in devices]
+        check(ccall((:cmf_create_multi, LIBCMF), Cint,
+                    (Ref{Ptr{Cvoid}}, Cint, Ptr{Cint}, Cint, Int64, Int64, Int64, Int64, Ptr{Float64}),
+                    h, length(devs), devs, 0, N, T, K, L, data))   # 0 = CMF_COMM_AUTO: RCCL for distinct devices
+    end
     check(ccall((:cmf_set_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], W, H))
     ss = Ref{Float64}(0.0)
     check(ccall((:cmf_get_data_sumsq, LIBCMF), Cint, (Ptr{Cvoid}, Ref{Float64}), h[], ss))
@@ -118,8 +136,6 @@ function HIPPGDUpdate(data, W, H; kwargs...)
     return rule
 end
 
-import ..CMF: SquareLoss, MaskedLoss, SquarePenalty, AbsolutePenalty, NonnegConstraint
-
 penalty_weights(pens) = (sum(Float64[p.weight for p in pens if p isa SquarePenalty]),
                          sum(Float64[p.weight for p in pens if p isa AbsolutePenalty]))
 nonneg_flag(c) = c === nothing ? Cint(0) : (c isa NonnegConstraint ? Cint(1) : error("unsupported constraint"))
@@ -162,6 +178,20 @@ function update_feature_maps!(rule::HIPPGDUpdate, data, W, H; loss_func=SquareLo
         check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.inner.handle, W, H))
     end
     return loss[]
+end
+
+"""
+    iterate!(rule, n; l1W=0, l2W=0, l1H=0, l2H=0, eval_mode=false) -> losses
+
+`n` x (`update_motifs!`; `update_feature_maps!`) back to back (alternating.jl:51-54) in one ccall (`cmf_iterate`): the
+n losses; the host never stalls the device between iterations.  W and H are not copied back (use `download!`).
+"""
+function iterate!(rule::HIPMultUpdate, n::Integer; l1W=0, l2W=0, l1H=0, l2H=0, eval_mode::Bool=false)
+    losses = zeros(n)
+    check(ccall((:cmf_iterate, LIBCMF), Cint,
+                (Ptr{Cvoid}, Int64, Cint, Float64, Float64, Float64, Float64, Ptr{Float64}, Ptr{Float64}),
+                rule.handle, n, eval_mode ? 1 : 0, l1W, l2W, l1H, l2H, losses, C_NULL))
+    return losses
 end
 
 "Write the device-resident factors into W and H (needed only with `sync_every_call=false`)."
