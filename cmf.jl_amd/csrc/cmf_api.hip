@@ -5,6 +5,7 @@
 #include "cmf_rng.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -127,7 +128,7 @@ struct cmf_handle_s {
     hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;
     // pipelined loss read-back of cmf_iterate (single handle): two pinned slots + events
     double *h_ring = nullptr;
-    hipEvent_t ring_ev[2] = {nullptr, nullptr};
+    CmfLossCarry carry{};                 // a loss reduction waiting for the next W phase's slab sum (cmf_iterate only)
 };
 
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
@@ -164,6 +165,9 @@ static int dalloc_zero(T **p, size_t n)
 {
     HIPCHK(hipMalloc(p, n * sizeof(T)));
     HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+    // hipMemset of device memory runs on the null stream and may return before it has finished; the handle's work runs on
+    // non-blocking streams, which the null stream does not order -- a lagging fill would wipe what they wrote meanwhile
+    HIPCHK(hipStreamSynchronize(nullptr));
     return CMF_OK;
 }
 
@@ -271,8 +275,6 @@ static void destroy_impl(cmf_handle_s *h)
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev_c0) (void)hipEventDestroy(h->ev_c0);
     if (h->ev_c1) (void)hipEventDestroy(h->ev_c1);
-    for (int q = 0; q < 2; ++q)
-        if (h->ring_ev[q]) (void)hipEventDestroy(h->ring_ev[q]);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
     if (h->own_comm_stream) (void)hipStreamDestroy(h->own_comm_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -512,11 +514,16 @@ static int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullpt
     return CMF_OK;
 }
 
-static int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nslabs, size_t stride)
+static int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nslabs, size_t stride, bool take_carry = false)
 {
     size_t n4 = stride / 4;
     int blocks = (int)std::min<size_t>(2048, (n4 + 255) / 256);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, h->stream, out, in, nslabs, stride, n4);
+    CmfLossCarry carry{};
+    if (take_carry && h->carry.partial) { // a loss reduction deferred by cmf_iterate rides on this launch
+        carry = h->carry;
+        h->carry = CmfLossCarry{};
+    }
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, h->stream, out, in, nslabs, stride, n4, carry);
     KCHK("slab_sum_kernel");
     return CMF_OK;
 }
@@ -549,7 +556,7 @@ static int w_partial_impl(cmf_handle_s *h)
         CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
     h->est_kind = 1;
     CMFTRY(launch_hxt(h));                                  // mult.jl:31-34
-    return launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks), (size_t)2 * d.L * d.K32 * d.Np);
+    return launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks), (size_t)2 * d.L * d.K32 * d.Np, true);
 }
 
 // The two halves of w_partial_impl as separate steps (same arithmetic, the sources contracted one at a time): the
@@ -566,7 +573,7 @@ static int w_partial_half_impl(cmf_handle_s *h, int den)
     }
     const float *src = den ? h->est : h->X;
     CMFTRY(launch_hxt_on(h, src, src, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1)); // mult.jl:31-34, one source
-    return launch_slab_sum(h, h->numden + (den ? LKN : 0), h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN);
+    return launch_slab_sum(h, h->numden + (den ? LKN : 0), h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN, den != 0);
 }
 
 static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W, const float *tail_src = nullptr, float *tail_dst = nullptr, int tail_n = 0)
@@ -593,15 +600,21 @@ static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
     return CMF_OK;
 }
 
-static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = true, double *host_out = nullptr)
+// the conv of mult.jl:55-57 with the loss fused: per-tile sums of (est - data)^2 -> h->partial
+static int launch_loss_conv(cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
     if (h->reuse_est) {
-        CMFTRY(launch_conv<3>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:55-57, est kept for the next update_motifs!
+        CMFTRY(launch_conv<3>(h, h->est, d.Tl, h->conv_gy)); // est kept for the next update_motifs!
         h->est_kind = 1;
-    } else {
-        CMFTRY(launch_conv<2>(h, nullptr, d.Tl, h->conv_gy)); // mult.jl:55-57
+        return CMF_OK;
     }
+    return launch_conv<2>(h, nullptr, d.Tl, h->conv_gy);
+}
+
+static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = true, double *host_out = nullptr)
+{
+    CMFTRY(launch_loss_conv(h));
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, host_out);
     KCHK("loss_reduce_kernel");
     return readback ? read_scalar(h, 0, sumsq) : CMF_OK;
@@ -654,6 +667,34 @@ static int get_factors_impl(cmf_handle_s *h, double *W, double *H)
     return CMF_OK;
 }
 
+
+// Wait until a kernel has replaced the sentinel pattern in `n` consecutive words of pinned host memory (a loss
+// read-back).  Polling instead of an event keeps barrier packets and cache write-backs out of the stream; the stream is
+// queried now and then so that a failed launch surfaces as an error instead of a hang.
+template <typename U>
+static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel)
+{
+    auto all_there = [&]() {
+        for (int j = 0; j < n; ++j)
+            if (p[j] == sentinel) return false;
+        return true;
+    };
+    for (unsigned spins = 1;; ++spins) {
+        if (all_there()) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return CMF_OK;
+        }
+        if ((spins & 0xFFF) == 0) {
+            const hipError_t e = hipStreamQuery(stream);
+            if (e == hipSuccess) { // everything enqueued has run: the words must be there now
+                if (all_there()) return CMF_OK;
+                return fail(CMF_ERR_HIP, "the stream drained without posting the loss");
+            }
+            if (e != hipErrorNotReady) return fail(CMF_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+        }
+        __builtin_ia32_pause();
+    }
+}
 
 #include "cmf_group.h"
 
@@ -934,14 +975,16 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
         }
         return CMF_OK;
     }
-    if (!h->h_ring) {
-        HIPCHK(hipHostMalloc(&h->h_ring, 2 * sizeof(double), hipHostMallocCoherent)); // written by a kernel, read by the host after an event
-        for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ring_ev[q], hipEventDisableTiming));
-    }
+    if (!h->h_ring) // two slots: written by the loss reduction, polled by the host
+        HIPCHK(hipHostMalloc(&h->h_ring, 2 * sizeof(double), hipHostMallocCoherent));
+    volatile unsigned long long *ring = reinterpret_cast<volatile unsigned long long *>(h->h_ring);
     auto collect = [&](int64_t it) -> int {
         const int slot = (int)(it & 1);
-        HIPCHK(hipEventSynchronize(h->ring_ev[slot]));
-        losses[it] = std::sqrt(h->h_ring[slot]) / h->data_norm;
+        CMFTRY(wait_words<unsigned long long>(h->stream, ring + slot, 1, CMF_SENTINEL64));
+        const unsigned long long bits = ring[slot];
+        double ss;
+        std::memcpy(&ss, &bits, 8);
+        losses[it] = std::sqrt(ss) / h->data_norm;
         if (stamps) stamps[it] = now();
         return CMF_OK;
     };
@@ -952,8 +995,14 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
         }
         CMFTRY(h_update_impl(h, l1H, l2H)); // :54
         const int slot = (int)(it & 1);
-        CMFTRY(loss_partial_impl(h, nullptr, false, h->h_ring + slot)); // the reduction writes the sum to the pinned slot itself
-        HIPCHK(hipEventRecord(h->ring_ev[slot], h->stream));
+        ring[slot] = CMF_SENTINEL64; // the slot's previous loss was collected an iteration ago
+        if (!eval_mode && it + 1 < n) {
+            // the per-tile sums are reduced by the next iteration's slab sum (CmfLossCarry), which stores the total into the pinned slot
+            CMFTRY(launch_loss_conv(h));
+            h->carry = CmfLossCarry{h->partial, h->conv_partials, h->d_scalar, h->h_ring + slot, nullptr, 0, 0};
+        } else {
+            CMFTRY(loss_partial_impl(h, nullptr, false, h->h_ring + slot)); // the reduction stores the sum into the pinned slot itself
+        }
         if (it > 0) CMFTRY(collect(it - 1));
     }
     if (n > 0) CMFTRY(collect(n - 1));

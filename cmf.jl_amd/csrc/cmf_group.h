@@ -105,8 +105,8 @@ struct cmf_group_s {
     std::vector<float *> halo_send;      // [2 * HC]: own first | last L-1 columns of H
     std::vector<float *> halo_all;       // [nranks * 2 * HC]: every rank's send block (the shard's receive halos point inside)
     std::vector<float *> loss_all;       // [tail]: gathered (hi, lo) loss pairs of the synchronous path
-    float *h_tail = nullptr;             // pinned host: 2 ring slots of `tail` floats (the late loss read-back) + 1 for the synchronous one
-    hipEvent_t ring_ev[2] = {nullptr, nullptr};
+    float *h_tail = nullptr;             // pinned host: 2 ring slots (the late loss read-back: pairs + stamp) + 1 for the synchronous one
+    int64_t slot_len = 0;                // floats per slot
     int64_t LKN2 = 0, tail = 0, HC = 0;
     int64_t N = 0, T = 0, K = 0, L = 0;
     std::vector<int64_t> t0, t1;         // column block of every rank
@@ -161,8 +161,10 @@ static int group_alloc_buffers(cmf_group_s *g)
         s->halo[3] = r < g->nranks - 1 ? g->halo_all[i] + (size_t)(2 * (r + 1)) * g->HC : nullptr;   // right neighbour's send-to-left block
     }
     CMFTRY(group_use(s0));
-    HIPCHK(hipHostMalloc(&g->h_tail, (size_t)(3 * g->tail) * sizeof(float), hipHostMallocCoherent)); // 2 ring slots + the synchronous read-back
-    for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&g->ring_ev[q], hipEventDisableTiming));
+    if (2 * g->nranks > 256) return fail(CMF_ERR_UNSUPPORTED, "groups of more than 128 shards are not supported");
+    g->slot_len = g->tail;
+    HIPCHK(hipHostMalloc(&g->h_tail, (size_t)(3 * g->slot_len) * sizeof(float), hipHostMallocCoherent)); // 2 ring slots + the synchronous read-back
+    std::memset(g->h_tail, 0, (size_t)(3 * g->slot_len) * sizeof(float));
     return CMF_OK;
 }
 
@@ -342,18 +344,18 @@ static int group_exchange_halos(cmf_group_s *g)
     return CMF_OK;
 }
 
-// sum((conv(W,H) - data)^2) of every local shard -> its tail slots of the all-reduce buffer (and d_scalar[0])
-static int group_loss_partials(cmf_group_s *g)
+// sum((conv(W,H) - data)^2) of every local shard -> its tail slots of the all-reduce buffer (and d_scalar[0]).
+// defer: the per-tile sums are reduced by the next update_motifs!' slab sum instead (CmfLossCarry), right in front of the
+// all-reduce their total rides on.
+static int group_loss_partials(cmf_group_s *g, bool defer = false)
 {
     for (size_t i = 0; i < g->sh.size(); ++i) {
         cmf_handle_s *s = g->sh[i];
-        const CmfDims &d = s->d;
         CMFTRY(group_use(s));
-        if (s->reuse_est) {
-            CMFTRY(launch_conv<3>(s, s->est, d.Tl, s->conv_gy)); // mult.jl:55-57, est kept for the next update_motifs!
-            s->est_kind = 1;
-        } else {
-            CMFTRY(launch_conv<2>(s, nullptr, d.Tl, s->conv_gy));
+        CMFTRY(launch_loss_conv(s)); // mult.jl:55-57
+        if (defer) {
+            s->carry = CmfLossCarry{s->partial, s->conv_partials, s->d_scalar, nullptr, g->red[i] + g->LKN2, (int)g->tail, g->rank[i]};
+            continue;
         }
         hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(256), 0, s->stream, s->partial, s->conv_partials, s->d_scalar,
                            g->red[i] + g->LKN2, (int)g->tail, g->rank[i]);
@@ -372,7 +374,7 @@ static int group_loss_now(cmf_group_s *g, double *sumsq)
     for (size_t i = 0; i < nl; ++i) send[i] = g->red[i] + g->LKN2 + 2 * g->rank[i];
     CMFTRY(group_allgather(g, send, 0, g->loss_all, 2));
     CMFTRY(group_use(s));
-    float *stage = g->h_tail + 2 * g->tail; // not a ring slot: a pending one-iteration-late loss may still sit there
+    float *stage = g->h_tail + 2 * g->slot_len; // not a ring slot: a pending one-iteration-late loss may still sit there
     HIPCHK(hipMemcpyAsync(stage, g->loss_all[0], (size_t)(2 * g->nranks) * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     *sumsq = group_decode_tail(g, stage);
@@ -399,7 +401,7 @@ static int group_start_num(cmf_group_s *g)
 }
 
 // update_motifs! on the group (mult.jl:23-39).  ring_slot >= 0: after the all-reduce the tail (the previous
-// iteration's loss pairs of every rank) is copied to pinned host slot `ring_slot` and ring_ev[ring_slot] is recorded.
+// iteration's loss pairs of every rank) is copied to pinned host slot `ring_slot`, which the host polls.
 static int group_update_motifs(cmf_group_s *g, double l1W, double l2W, int ring_slot = -1)
 {
     if (!g->halos_current) CMFTRY(group_exchange_halos(g));
@@ -426,9 +428,10 @@ static int group_update_motifs(cmf_group_s *g, double l1W, double l2W, int ring_
     for (size_t i = 0; i < g->sh.size(); ++i) {
         cmf_handle_s *s = g->sh[i];
         CMFTRY(group_use(s));
-        if (i == 0 && ring_slot >= 0) { // shard 0's W update also drops the reduced loss pairs into the pinned ring slot
-            CMFTRY(w_apply_impl(s, l1W, l2W, g->red[0] + g->LKN2, g->h_tail + (size_t)ring_slot * g->tail, 2 * g->nranks));
-            HIPCHK(hipEventRecord(g->ring_ev[ring_slot], s->stream));
+        if (i == 0 && ring_slot >= 0) { // shard 0's W update also drops the reduced loss pairs + a stamp into the pinned ring slot
+            float *ring = g->h_tail + (size_t)ring_slot * g->slot_len;
+            for (int j = 0; j < 2 * g->nranks; ++j) reinterpret_cast<volatile unsigned *>(ring)[j] = CMF_SENTINEL32; // collected an iteration ago
+            CMFTRY(w_apply_impl(s, l1W, l2W, g->red[0] + g->LKN2, ring, 2 * g->nranks));
         } else {
             CMFTRY(w_apply_impl(s, l1W, l2W));
         }
@@ -448,7 +451,7 @@ static int group_update_feature_maps(cmf_group_s *g, double l1H, double l2H, dou
     g->num_ready = false;
     CMFTRY(group_exchange_halos(g));
     if (g->overlap) CMFTRY(group_start_num(g)); // for the next update_motifs!: H and its halos are final now
-    CMFTRY(group_loss_partials(g));
+    CMFTRY(group_loss_partials(g, /*defer=*/sumsq == nullptr));
     return sumsq ? group_loss_now(g, sumsq) : CMF_OK;
 }
 
@@ -489,8 +492,9 @@ static int group_iterate(cmf_group_s *g, int64_t n, int eval_mode, double l1W, d
         if (it > 0) {
             const int slot = (int)((it - 1) & 1);
             CMFTRY(group_use(s0));
-            HIPCHK(hipEventSynchronize(g->ring_ev[slot]));
-            losses[it - 1] = std::sqrt(group_decode_tail(g, g->h_tail + (size_t)slot * g->tail)) / g->data_norm;
+            const float *ring = g->h_tail + (size_t)slot * g->slot_len;
+            CMFTRY(wait_words<unsigned>(s0->stream, reinterpret_cast<const volatile unsigned *>(ring), 2 * g->nranks, CMF_SENTINEL32));
+            losses[it - 1] = std::sqrt(group_decode_tail(g, ring)) / g->data_norm;
             if (stamps) stamps[it - 1] = now();
         }
         if (last) {
@@ -548,8 +552,6 @@ static void group_destroy(cmf_group_s *g)
     }
     if (g->h_tail) (void)hipHostFree(g->h_tail);
     if (g->cb_host) (void)hipHostFree(g->cb_host);
-    for (int q = 0; q < 2; ++q)
-        if (g->ring_ev[q]) (void)hipEventDestroy(g->ring_ev[q]);
     delete g;
 }
 

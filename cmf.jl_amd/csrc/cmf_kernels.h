@@ -1141,16 +1141,17 @@ __device__ __forceinline__ float cmf_mu(float x, float num, float den, float l1,
 }
 
 // grid: (Np/64, KB, L), block 256.  numden: [nslabs][2][L][K32][Np]
-// tail_src / tail_dst (may be NULL): block (0,0,0) also copies `tail_n` floats -- the loss pairs behind the
-// [numW | denomW] all-reduce buffer of a sharded group -- to pinned host memory, so the read-back costs no extra launch.
+// tail_src / tail_dst (may be NULL): block (0,0,0) also copies `tail_n` (<= 256) floats -- the loss pairs behind the
+// [numW | denomW] all-reduce buffer of a sharded group -- to pinned host memory that the host has filled with a
+// sentinel pattern and polls, so the read-back costs neither a launch nor an event (see loss_reduce_kernel).
 __global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, const float *numden, int nslabs,
                                                         int N, int K, int L, int Np, int K32, float l1, float two_l2,
                                                         const float *tail_src, float *tail_dst, int tail_n)
 {
     __shared__ float tile[32][65];
     const int tid = threadIdx.x;
-    if (tail_dst && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
-        for (int j = tid; j < tail_n; j += 256) tail_dst[j] = tail_src[j];
+    if (tail_dst && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < tail_n) // relaxed system-scope word stores:
+        __hip_atomic_store(tail_dst + tid, tail_src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // the host polls every word
     const int n0 = blockIdx.x * 64, kb = blockIdx.y, l = blockIdx.z;
     const size_t LKN = (size_t)L * K32 * Np;
     {
@@ -1236,8 +1237,50 @@ __global__ __launch_bounds__(256) void h_update_kernel(float *H, float *Ht, cons
     }
 }
 
-// out[i] = sum_s in[s*stride + i]  (deterministic slab combine; float4 lanes)
-__global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *in, int nslabs, size_t stride, size_t n4)
+// A loss reduction that rides on another launch (cmf_iterate): the per-tile partials of the loss conv are summed by
+// one block of the NEXT iteration's slab sum instead of by a 4 us launch of their own right behind the conv -- a
+// launch that short in front of the C2 kernel exposes that kernel's dispatch set-up (measured: a 5.6 us hole in an
+// 0.75 ms iteration).  partial == NULL: nothing to carry.
+struct CmfLossCarry {
+    const double *partial; // per-tile sums of (est - data)^2
+    int n;
+    double *out;           // device scalar
+    double *host_out;      // pinned slot the host polls (single GPU) or NULL
+    float *tail;           // tail of the [numW | denomW] all-reduce buffer (groups) or NULL: (hi, lo) in this rank's slots, 0 elsewhere
+    int tail_len, rank;
+};
+
+__device__ __forceinline__ void cmf_block_loss_reduce(const CmfLossCarry &c)
+{
+    __shared__ double red[256];
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int base = threadIdx.x; base < c.n; base += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (base + 256 * u < c.n) ? c.partial[base + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += v[u];
+    }
+    red[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    const double tot = red[0];
+    if (threadIdx.x == 0) {
+        *c.out = tot;
+        if (c.host_out) __hip_atomic_store(c.host_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (c.tail) {
+        const float hi = (float)tot, lo = (float)(tot - (double)hi);
+        for (int j = threadIdx.x; j < c.tail_len; j += 256) c.tail[j] = (j == 2 * c.rank) ? hi : (j == 2 * c.rank + 1) ? lo : 0.f;
+    }
+}
+
+// out[i] = sum_s in[s*stride + i]  (deterministic slab combine; float4 lanes); the last block also performs a carried
+// loss reduction (same summation order as loss_reduce_kernel / loss_tail_kernel)
+__global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *in, int nslabs, size_t stride, size_t n4, CmfLossCarry carry)
 {
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x) {
         float4 a = reinterpret_cast<const float4 *>(in)[idx];
@@ -1247,11 +1290,17 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *
         }
         reinterpret_cast<float4 *>(out)[idx] = a;
     }
+    if (carry.partial && blockIdx.x == gridDim.x - 1) cmf_block_loss_reduce(carry);
 }
 
 // *out = sum(partial[0..n))   one block; eight independent loads per thread and round (the one-wave conv kernel
 // writes 25 024 partials at config 2: a plain strided loop is a chain of dependent HBM round trips)
-// host_out (may be NULL): pinned host memory that receives the sum as well (the pipelined loss read-back of cmf_iterate)
+// host_out (may be NULL): pinned, coherent host memory that receives the sum as well (the pipelined loss read-back of
+// cmf_iterate).  It is ONE relaxed system-scope 8-byte store: the host has filled the slot with a sentinel bit pattern
+// and polls until it changes.  No event and no system-scope fence: either would write the whole dirty L2 back (the est
+// the conv just stored) and idle the device for ~6 us between this kernel and the next.
+#define CMF_SENTINEL64 0xFFFFFFFFFFFFFFFFull
+#define CMF_SENTINEL32 0xFFFFFFFFu
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial, int n, double *out, double *host_out = nullptr)
 {
     __shared__ double red[256];
@@ -1271,7 +1320,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial,
     }
     if (threadIdx.x == 0) {
         *out = red[0];
-        if (host_out) *host_out = red[0];
+        if (host_out) __hip_atomic_store(host_out, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -48,6 +48,8 @@ def main():
         rule = ShardedMultUpdate(data, W0, H0, device=0, overlap=overlap,
                                  transport=os.environ.get("CMF_TEST_TRANSPORT") or None)
         info = rule.comm_info()
+        want = float(np.linalg.norm(data))
+        assert abs(rule.data_norm - want) <= 1e-9 * want, f"rank {rank}: data_norm {rule.data_norm} != {want}"
     losses = [rule.compute_loss()]
     if mode == "iterate":
         losses += list(rule.iterate(iters, **kw))
