@@ -131,6 +131,7 @@ struct cmf_handle_s {
     CmfLossCarry carry{};                 // a loss reduction waiting for the next W phase's slab sum (cmf_iterate only)
 };
 
+static int hals_ensure(cmf_handle_s *h);
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
 static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked = false);
 static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W);
@@ -788,6 +789,10 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         h->est_kind = 0;
         return CMF_OK;
     }
+    if (std::strcmp(name, "hals_prepare") == 0) { // allocate the HALS scratch and check its shape limits now (rule construction)
+        HIPCHK(hipSetDevice(h->device));
+        return hals_ensure(h);
+    }
     if (std::strcmp(name, "conv_split") == 0) { // 0 = never cut the one-wave conv kernel's last round into quarter tiles
         h->conv_split = value != 0;
         h->est_kind = 0;
@@ -1273,7 +1278,14 @@ static int hals_ensure(cmf_handle_s *h)
     if (h->hals_ready) return CMF_OK;
     const CmfDims &d = h->d;
     if (h->sharded && h->T_global != d.Tl) return fail(CMF_ERR_STATE, "HALS needs an unsharded handle (the H sweep is sequential along T)");
+    // limits of the on-chip sweeps (the reference takes any K, L: hals.jl:90-154): the H sweep slides a 64-column window
+    // along a row with the L-1 pending columns in the lanes of one wave; the W sweep keeps the L*Kpad projected state of a
+    // unit in registers (up to 32 slots per lane) and K*L new values per unit in LDS
     if (d.L > 64) return fail(CMF_ERR_UNSUPPORTED, "HALS path supports L <= 64 (got %d)", d.L);
+    if ((int64_t)d.L * d.K32 > 2048)
+        return fail(CMF_ERR_UNSUPPORTED, "HALS path supports L * Kpad <= 2048 (got L=%d, K=%d padded to %d)", d.L, d.K, d.K32);
+    if ((size_t)4 * d.K * d.L * HALS_NG * sizeof(float) > 64 * 1024)
+        return fail(CMF_ERR_UNSUPPORTED, "HALS path supports K * L <= 2048 (got %d)", d.K * d.L);
     const int E = 2 * d.L - 1;
     h->hals_NpH = (int)rup((int64_t)d.L * d.K32, 128);
     h->hals_TPp = (int)rup(d.Tl, 64) + 256;
@@ -1325,20 +1337,22 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     CMFTRY(launch_hxt_on(h, h->hals_HuT, h->hals_HuT, h->hals_NpH, 1, h->hals_hhslabs, h->hals_nch, h->hals_clen));
     CMFTRY(launch_slab_sum(h, h->hals_HH, h->hals_hhslabs, hxt_nslabs(h->hals_nch), (size_t)d.L * d.K32 * h->hals_NpH));
     // the K*L sequential column updates, k outer / lag inner (hals.jl:90-97)
-    if (d.L * d.K32 > 1024)
-        return fail(CMF_ERR_UNSUPPORTED, "HALS W sweep: L*K = %d exceeds the 1024 state entries per unit it keeps on chip", d.L * d.K32);
-    const int nq = (d.L * d.K32 + 63) / 64;
+    const int nq = (d.L * d.K32 + 63) / 64; // <= 32: checked by hals_ensure
     dim3 grid((d.N + 4 * HALS_NG - 1) / (4 * HALS_NG)), block(256);
-#define SWEEP(NQ_)                                                                                                     \
-    hipLaunchKernelGGL((hals_w_sweep_reg_kernel<NQ_>), grid, block, 0, h->stream, h->Wt, h->Wn, h->numden, h->hals_HH, \
+    const size_t lds = (size_t)4 * d.K * d.L * HALS_NG * sizeof(float); // <= 64 KB
+#define SWEEP(NQ_, WD_)                                                                                                     \
+    hipLaunchKernelGGL((hals_w_sweep_reg_kernel<NQ_, WD_>), grid, block, lds, h->stream, h->Wt, h->Wn, h->numden, h->hals_HH, \
                    d.N, d.K, d.L, d.Np, d.K32, h->hals_NpH, (float)l1W, (float)l2W)
-    if (nq <= 2) SWEEP(2);
-    else if (nq <= 4) SWEEP(4);
-    else if (nq <= 6) SWEEP(6);
-    else if (nq <= 8) SWEEP(8);
-    else if (nq <= 10) SWEEP(10);
-    else if (nq <= 12) SWEEP(12);
-    else SWEEP(16);
+    if (nq <= 2) SWEEP(2, 8);
+    else if (nq <= 4) SWEEP(4, 8);
+    else if (nq <= 6) SWEEP(6, 8);
+    else if (nq <= 8) SWEEP(8, 8);
+    else if (nq <= 10) SWEEP(10, 8);
+    else if (nq <= 12) SWEEP(12, 8);
+    else if (nq <= 16) SWEEP(16, 8);
+    else if (nq <= 20) SWEEP(20, 4);
+    else if (nq <= 24) SWEEP(24, 4);
+    else SWEEP(32, 4);
 #undef SWEEP
     KCHK("hals_w_sweep_reg_kernel");
     h->est_kind = 0;

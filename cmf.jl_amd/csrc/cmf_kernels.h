@@ -1351,14 +1351,15 @@ __global__ void hals_build_hut_kernel(const float *H, float *HuT, int Tl, int L,
 }
 
 #define HALS_NG 2
-#define HALS_WD 8 // prefetch depth (steps) of the W sweep
 // W sweep: one wave = HALS_NG units n, the projected state g[u][j] (j over the L*K32 columns
 // of H_unfold) sits in registers, lane (j % 64) slot (j / 64).  A step needs one state entry per unit -- a
 // v_readlane of the slot its column lives in -- and then updates every entry with one FMA; there is no LDS, no
 // wave synchronisation and nothing to wait for except the prefetched HH row, so a step costs a few hundred cycles
 // instead of several LDS and memory round trips.
-// grid: ceil(N / (4 * HALS_NG)), block 256 (4 independent waves).
-template <int NQ>
+// grid: ceil(N / (4 * HALS_NG)), block 256 (4 independent waves); dynamic LDS: 4 * K*L * HALS_NG floats.
+// NQ = state slots per lane (64 * NQ >= L * K32), HALS_WD = prefetch depth in steps: 8 up to 16 slots, 4 for the long
+// states (K32 * L up to 2048, e.g. K = 64, L = 20), whose prefetch ring would otherwise not fit the register file.
+template <int NQ, int HALS_WD>
 __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float *Wn, const float *G, const float *HH,
                                                                 int N, int K, int L, int Np, int K32, int NpH, float l1, float l2)
 {
@@ -1366,8 +1367,8 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
     const int LK = L * K32;
     const int n0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave) * HALS_NG);
     if (n0 >= N) return;
-    __shared__ float wnew_all[4][1024 * HALS_NG]; // new W values of the wave's units, step by step (K*L <= 1024)
-    float *wnew = wnew_all[wave];
+    extern __shared__ float wnew_all[]; // [4][K*L * HALS_NG]: new W values of the wave's units, step by step
+    float *wnew = wnew_all + (size_t)wave * (K * L * HALS_NG);
     float g[HALS_NG][NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {

@@ -284,6 +284,14 @@ class HALSUpdate(MultUpdate):
     ``+ l2`` regularisation and the incremental-residual loss are the reference's.
     """
 
+    def __init__(self, data, W, H, device=None):
+        super().__init__(data, W, H, device=device)
+        try:  # the rule constructor (hals.jl:18-28): scratch + the shape limits of the on-chip sweeps, reported here
+            self.set_option("hals_prepare", 1)
+        except Exception:
+            self.close()
+            raise
+
     def update_motifs(self, data=None, W=None, H=None, l1W=0, l2W=0, **kwargs):
         """update_motifs!(rule::HALSUpdate, data, W, H; l1W=0, l2W=0): src/algs/hals.jl:31-34."""
         check(self._lib.cmf_hals_update_motifs(self._h, float(l1W), float(l2W)))

@@ -180,7 +180,9 @@ int cmf_iterate(cmf_handle h, int64_t n_iter, int eval_mode, double l1W, double 
  * on the same handle (the HALSUpdate constructor, hals.jl:18-28, needs nothing beyond cmf_create +
  * cmf_set_factors: the residual it carries is est - data, kept implicitly).  Same Gauss-Seidel visiting
  * order as the reference; clamp at 0 and "+ l2" regularisation as in hals.jl:110,153.
- * Unsharded handles only (the H sweep is sequential along T); L <= 64. */
+ * Unsharded handles only (the H sweep is sequential along T).  Shape limits of the on-chip sweeps (the reference
+ * has none): L <= 64, L * Kpad <= 2048 and K * L <= 2048 (Kpad = K rounded up to 32); cmf_set_option(h, "hals_prepare", 1)
+ * allocates the rule's scratch and reports a violation at construction time instead of at the first update. */
 int cmf_hals_update_motifs(cmf_handle h, double l1W, double l2W);
 int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss);
 

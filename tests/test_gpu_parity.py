@@ -305,6 +305,8 @@ HALS_SHAPES = [
     (130, 700, 32, 20),  # config-5 K, L
     (37, 200, 33, 7),    # two k blocks
     (200, 1500, 5, 10),
+    (150, 900, 64, 20),  # L * Kpad = 1280: the W sweep's long-state form (20 register slots per lane)
+    (64, 400, 40, 30),   # L * Kpad = 1920 (Kpad = 64): 32 slots
 ]
 
 
@@ -325,6 +327,17 @@ def test_hals_single_iteration(cmf, oracle, N, T, K, L, reg):
     assert frob_rel(Hg, Hr) < 5e-5
     assert abs(loss - lh[-1]) <= 2e-5 * lh[-1]
     assert Wg.min() >= 0.0 and Hg.min() >= 0.0   # clamp at 0, not eps (hals.jl:110,153)
+
+
+def test_hals_shape_limits_reported_at_construction(cmf):
+    """The on-chip sweeps have shape limits the reference does not (L <= 64, L * Kpad <= 2048): the rule constructor
+    reports them (CMF_ERR_UNSUPPORTED), not the first update after the contractions have already run."""
+    rng = np.random.default_rng(0)
+    for K, L, N, T in ((3, 70, 8, 200), (64, 40, 8, 200)):
+        with pytest.raises(cmf.CMFError) as ei:
+            cmf.HALSUpdate(rng.random((N, T)), rng.random((K, N, L)), rng.random((K, T)))
+        assert ei.value.code == 4 and "HALS path supports" in str(ei.value)
+    cmf.HALSUpdate(rng.random((8, 200)), rng.random((64, 8, 32)), rng.random((64, 200))).close()  # exactly 2048: fine
 
 
 def test_hals_fit_against_oracle(cmf, oracle):
