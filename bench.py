@@ -218,20 +218,20 @@ def main():
             rule.set_overlap(probe["overlap"] < probe["single"])
     # The timed region carries HIP event pairs around every fourth launch of each contraction kernel (option "profile": events on the
     # launch stream), so the per-kernel durations of the roofline block are measured live over these very steps.
-    prof = rule if alg == "mult" else None
+    prof = rule
     timed(args.warmup, 0)
-    if prof is not None:
-        prof.set_option("profile", 4)  # every 4th launch of each class
+    prof.set_option("profile", 4 if alg == "mult" else 1)  # every 4th launch of each class (HALS: every span)
     dt, losses = timed(0, args.steps)
     inloop = {}
-    if prof is not None:
-        for name in ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "hxt_num", "hxt_den", "transconv"):
-            kms, n = prof.kernel_times(name)
-            if n:
-                inloop[name] = (kms, n)
-        prof.set_option("profile", 0)
+    for name in ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "hxt_num", "hxt_den", "transconv", "hals_h_pipeline", "hals_w_sweep"):
+        kms, n = prof.kernel_times(name)
+        if n:
+            inloop[name] = (kms, n)
+    prof.set_option("profile", 0)
+    if alg != "mult":
+        hals_spans, inloop = inloop, {}
     dt_unprofiled = None
-    if prof is not None and world == 1:
+    if alg == "mult" and world == 1:
         dt_unprofiled, _ = timed(0, args.steps)
     # Steady state: the timed region above is ~0.1 s; run back-to-back iterations for >= 3 s more (same call) so that the
     # figure also holds at the clock the card settles to (and the driver's GPU-busy sampling has something to see).
@@ -332,7 +332,7 @@ def main():
             dom = max(tab, key=lambda k: tab[k]["avg_ms"])  # every class runs once per step
             ach, avg_ms, kfl = tab[dom]["tflops"], tab[dom]["avg_ms"], f1 * (2.0 if dom in ("hxt", "transconv") else 1.0)
             src = "HIP event pairs around each launch inside the timed region"
-        else:  # HALS: the MFMA kernels are timed stand-alone (its sweeps are latency-bound VALU work)
+        else:  # HALS: see the latency-bound block below; the MFMA kernels are timed stand-alone
             dom, ach, avg_ms, kfl = "conv", kern["conv"]["tflops"], kern["conv"]["avg_ms"], f1
             src = "cmf_time_kernel: HIP events around 5 stand-alone launches"
         traffic, traffic_src = None, None
@@ -347,6 +347,28 @@ def main():
                            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_flops_per_launch": kfl, "avg_launch_ms": avg_ms, "timing": src}
+
+    if rank == 0 and alg == "hals":
+        # The dominant part of a HALS iteration is the K*T strictly ordered H entry updates (hals.jl:121-154), run as a
+        # software pipeline over the rows (hals_h_stage_kernel).  Its bound is dependency latency, not MFMA or HBM: entry
+        # (k, t) needs (k, t-1) and the push of (k-1, t+L-1), so the critical path is T + (K-1)(L-1) dependent steps of
+        # ~88 cycles (2 v_readlane + 5 dependent VALU ops + the DPP shifts: DESIGN.md 4b).  achieved = critical-path steps
+        # per second over the measured pipeline span; peak = one step per 88 cycles at 2.4 GHz.
+        pipe_ms, n_pipe = hals_spans.get("hals_h_pipeline", (0.0, 0))
+        wsw_ms, _ = hals_spans.get("hals_w_sweep", (0.0, 0))
+        STEP_CYCLES, CLK = 88.0, 2.4e9
+        crit_steps = T + (K - 1) * (L - 1)
+        peak_steps = CLK / STEP_CYCLES
+        ach_steps = crit_steps / (pipe_ms * 1e-3) if pipe_ms else 0.0
+        out["roofline_mfma_kernel"] = out["roofline"]
+        out["roofline"] = {"bound": "dependency-latency",
+                           "kernel": "hals_h_stage_kernel row pipeline (K*T ordered entry updates of H, hals.jl:121-154)",
+                           "achieved": ach_steps, "peak": peak_steps, "unit": "critical-path steps/s", "frac": ach_steps / peak_steps,
+                           "traffic": None, "critical_path_steps": crit_steps, "step_cycles_model": STEP_CYCLES,
+                           "pipeline_span_ms": pipe_ms, "pipeline_spans_timed": n_pipe, "pipeline_floor_ms": 1e3 * crit_steps / peak_steps,
+                           "share_of_step": pipe_ms / (1e3 * dt / args.steps) if dt else None,
+                           "w_sweep_ms": wsw_ms,
+                           "timing": "HIP event pair around the whole stage loop inside the timed region (option profile)"}
 
     if rank == 0 and alg == "mult":
         # BASELINE.json's metric also asks for the achieved HBM rate.  Algorithmic bytes per iteration

@@ -115,7 +115,7 @@ struct cmf_handle_s {
     // in-loop kernel timing (option "profile"): HIP event pairs around the contraction launches, on the launch stream
     bool prof = false;
     int prof_every = 1;          // bracket every n-th launch of a class (option value n)
-    int prof_seen[16] = {0};
+    int prof_seen[32] = {0};
     struct ProfRec { hipEvent_t a, b; int cls; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
@@ -411,8 +411,10 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
 // kernel launchers
 // ------------------------------------------------------------------------------------------
 // kernel classes of the "profile" option
-enum { PROF_CONV = 0, PROF_CONV_T, PROF_CONV_LOSS, PROF_CONV_LOSS_STORE, PROF_HXT, PROF_TRANSCONV, PROF_HXT_NUM, PROF_HXT_DEN, PROF_OTHER, PROF_NCLS };
-static const char *kProfNames[PROF_NCLS] = {"conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv", "hxt_num", "hxt_den", "other"};
+enum { PROF_CONV = 0, PROF_CONV_T, PROF_CONV_LOSS, PROF_CONV_LOSS_STORE, PROF_HXT, PROF_TRANSCONV, PROF_HXT_NUM, PROF_HXT_DEN, PROF_OTHER,
+       PROF_HALS_PIPE, PROF_HALS_WSWEEP, PROF_NCLS };
+static const char *kProfNames[PROF_NCLS] = {"conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv", "hxt_num", "hxt_den", "other",
+                                            "hals_h_pipeline", "hals_w_sweep"};
 
 struct ProfScope {
     cmf_handle_s *h;
@@ -1340,6 +1342,7 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     const int nq = (d.L * d.K32 + 63) / 64; // <= 32: checked by hals_ensure
     dim3 grid((d.N + 4 * HALS_NG - 1) / (4 * HALS_NG)), block(256);
     const size_t lds = (size_t)4 * d.K * d.L * HALS_NG * sizeof(float); // <= 64 KB
+    ProfScope prof_(h, PROF_HALS_WSWEEP);
 #define SWEEP(NQ_, WD_)                                                                                                     \
     hipLaunchKernelGGL((hals_w_sweep_reg_kernel<NQ_, WD_>), grid, block, lds, h->stream, h->Wt, h->Wn, h->numden, h->hals_HH, \
                    d.N, d.K, d.L, d.Np, d.K32, h->hals_NpH, (float)l1W, (float)l2W)
@@ -1383,8 +1386,13 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
     sp.Dall = h->hals_D;
     sp.K = d.K; sp.seg = h->hals_seg; sp.nseg = h->hals_nseg;
     sp.CB = (h->hals_seg + 2 * (d.L - 1) + 255) / 256;
-    const int nstages = h->hals_nseg + 3 * (d.K - 1) + 1; // +1: the pushes of the last sweeps (no-ops for the last row)
+    const char *lag_env = getenv("CMF_HALS_LAG"); // 3 = the unshifted round-1 schedule (tests compare the two)
+    sp.lag = (lag_env && atoi(lag_env) == 3) ? 3 : 2;
+    sp.skew = sp.lag == 2 ? 128 : 0; // see hals_h_stage_kernel
+    // the last row's last segment, +1 for the pushes of the last sweeps (no-ops for the last row)
+    const int nstages = (d.Tl + sp.skew * (d.K - 1) + h->hals_seg - 1) / h->hals_seg + sp.lag * (d.K - 1) + 1;
     dim3 grid(d.K + d.K * sp.CB, std::max(1, d.K - 1));
+    ProfScope prof_(h, PROF_HALS_PIPE); // the whole row pipeline (nstages launches) as one timed span
     for (int stage = 0; stage < nstages; ++stage) {
         sp.stage = stage;
         hipLaunchKernelGGL(hals_h_stage_kernel, grid, dim3(256), 0, h->stream, sp);

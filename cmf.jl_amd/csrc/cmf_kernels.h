@@ -1662,61 +1662,91 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
 
 // Cross-row push of row k's changes: PT[k'][t'] += sum_e D[t'-e] * taps(t'-e)[k][k'][e] for k' > k.
 // sources: columns [s_begin, s_end) of row k; targets: [s_begin-(L-1), s_end+L-1) of one later row kp;
-// cb = 256-column block of the target range, tid = thread in the block
+// cb = 256-column block of the target range, tid = thread in the block (all 256 threads call this).
+// The block's window of D (256 + 2(L-1) columns, zero outside the source segment) and the 2L-1 full-window taps are
+// staged in LDS first: read straight from memory, the tap loop is a chain of ~2(2L-1) dependent L2 round trips per
+// thread, and a stage's pushes then take longer than its row sweeps (10-15 us against 12 us at 384-column segments).
+// Source columns in the right edge (t >= t_edge0: truncated windows, hals.jl:136) have per-column taps in GE.
 __device__ __forceinline__ void hals_h_push(float *PT, const float *D, const float *GW, const float *GE,
                                             int k, int kp, int Tl, int L, int K32, int TPp, int ne, int t_edge0,
                                             int s_begin, int s_end, int cb, int tid)
 {
-    const int tp = s_begin - (L - 1) + cb * 256 + tid;
-    if (tp < 0 || tp >= Tl || tp >= s_end + L - 1) return;
+    __shared__ float Ds[256 + 128];
+    __shared__ float taps[128];
     const int E = 2 * L - 1;
-    const float *gw = GW + ((size_t)k * K32 + kp) * E + (L - 1);
+    const int tp0 = s_begin - (L - 1) + cb * 256; // first target column of the block
+    const int w0 = tp0 - (L - 1);                 // first source column the block can see
+    for (int j = tid; j < 256 + 2 * (L - 1); j += 256) {
+        const int t = w0 + j;
+        Ds[j] = (t >= s_begin && t < s_end) ? D[t] : 0.f;
+    }
+    if (tid < E) taps[tid] = GW[((size_t)k * K32 + kp) * E + tid]; // taps[e + L - 1]
+    __syncthreads();
+    const int tp = tp0 + tid;
+    if (tp < 0 || tp >= Tl || tp >= s_end + L - 1) return;
     float s = 0.f;
-    for (int e = -(L - 1); e <= L - 1; ++e) {
-        const int t = tp - e;
-        if (t < s_begin || t >= s_end) continue;
-        float tap;
-        if (t < t_edge0) tap = gw[e];
-        else tap = GE[(((size_t)k * ne + (t - t_edge0)) * K32 + kp) * E + (L - 1) + e];
-        s = fmaf(D[t], tap, s);
+    if (tp0 + 255 + (L - 1) < t_edge0 || s_end <= t_edge0) { // no source column of this block lies in the right edge
+        for (int e = -(L - 1); e <= L - 1; ++e) s = fmaf(Ds[tid + (L - 1) - e], taps[e + L - 1], s); // t = tp - e
+    } else {
+        for (int e = -(L - 1); e <= L - 1; ++e) {
+            const int t = tp - e;
+            if (t < s_begin || t >= s_end) continue;
+            const float tap = (t < t_edge0) ? taps[e + L - 1] : GE[(((size_t)k * ne + (t - t_edge0)) * K32 + kp) * E + (L - 1) + e];
+            s = fmaf(Ds[tid + (L - 1) - e], tap, s);
+        }
     }
     PT[(size_t)kp * TPp + tp] += s;
 }
 
 
-// One pipeline stage of the H sweep (hals.jl:121-154).  Row k sweeps column segment sg = stage - 3k, and
-// the changes of the segments swept in the previous stage are pushed to the later rows.  The lag of 3
-// stages per row guarantees that (a) everything that influences a segment has been pushed before it is
-// swept and (b) the sweeps and pushes of one launch touch disjoint columns (segments are >= 256 columns),
-// so the update order is exactly the reference's while up to ceil(nseg/3) rows are in flight.
+// One pipeline stage of the H sweep (hals.jl:121-154).  Row k sweeps its column segment sg = stage - lag*k, and
+// the changes of the segments swept in the previous stage are pushed to the later rows.  Row k's segments are
+// [sg*seg - skew*k, (sg+1)*seg - skew*k): each row's grid is shifted left by `skew` columns against the row above.
+//   lag 2, skew 128 (default): a segment of row k+1 ends 128 columns before the same-numbered segment of row k, so
+//     it is influenced by row k's segments <= sg only (their pushes reach L-1 <= 63 columns to the left), all pushed
+//     by stage sg + 2k + 1 < sg + 2(k+1); within a launch, a row's sweep -- which also hands the 64-column pending
+//     window behind its segment over to the next stage -- ends at least 128 - 64 - (L-1) >= 1 columns before the first
+//     column any push of that launch touches, and pushes from different rows into one row are >= seg - 2(L-1) apart.
+//   lag 3, skew 0: the round-1 schedule (unshifted grids need one more stage of distance).
+// Either way everything that influences a segment has been pushed before it is swept and the sweeps and pushes of one
+// launch touch disjoint columns (segments are >= 256 columns), so the update order is exactly the reference's while
+// ~nseg/lag rows are in flight.
 // grid: (K + K*CB, max(1, K-1)), block 256.   blockIdx.x < K: sweep of row blockIdx.x (wave 0 only).
 struct HalsStageParams {
     HalsRowParams row;  // k, D, t_begin, t_end filled per block
     float *Dall;        // [K32][TPp]
     int K, seg, nseg, CB, stage;
+    int lag, skew;
 };
+
+// columns [*b, *e) of segment sg of row k (clipped to [0, Tl)); false when the segment is empty
+__device__ __forceinline__ bool hals_segment(const HalsStageParams &sp, int k, int sg, int *b, int *e)
+{
+    if (sg < 0) return false;
+    long long t0 = (long long)sg * sp.seg - (long long)sp.skew * k, t1 = t0 + sp.seg;
+    if (t1 <= 0 || t0 >= sp.row.Tl) return false;
+    *b = t0 < 0 ? 0 : (int)t0;
+    *e = t1 > sp.row.Tl ? sp.row.Tl : (int)t1;
+    return true;
+}
 
 __global__ __launch_bounds__(256) void hals_h_stage_kernel(HalsStageParams sp)
 {
     const int bx = blockIdx.x;
     if (bx < sp.K) {
         if (blockIdx.y != 0 || threadIdx.x >= 64) return;
-        const int k = bx, sg = sp.stage - 3 * k;
-        if (sg < 0 || sg >= sp.nseg) return;
+        const int k = bx;
         HalsRowParams q = sp.row;
+        if (!hals_segment(sp, k, sp.stage - sp.lag * k, &q.t_begin, &q.t_end)) return;
         q.k = k;
         q.D = sp.Dall + (size_t)k * q.TPp;
-        q.t_begin = sg * sp.seg;
-        q.t_end = (sg + 1) * sp.seg < q.Tl ? (sg + 1) * sp.seg : q.Tl;
         hals_h_row_sweep(q, threadIdx.x);
     } else {
         const int k = (bx - sp.K) / sp.CB, cb = (bx - sp.K) % sp.CB;
-        const int sg = sp.stage - 1 - 3 * k; // swept in the previous stage
         const int kp = k + 1 + blockIdx.y;
-        if (sg < 0 || sg >= sp.nseg || kp >= sp.K) return;
+        int s_begin, s_end;
+        if (kp >= sp.K || !hals_segment(sp, k, sp.stage - 1 - sp.lag * k, &s_begin, &s_end)) return; // swept in the previous stage
         const HalsRowParams &r = sp.row;
-        const int s_begin = sg * sp.seg;
-        const int s_end = (sg + 1) * sp.seg < r.Tl ? (sg + 1) * sp.seg : r.Tl;
         hals_h_push(r.PT, sp.Dall + (size_t)k * r.TPp, r.GW, r.GE, k, kp, r.Tl, r.L, r.K32, r.TPp, r.ne, r.t_edge0,
                     s_begin, s_end, cb, threadIdx.x);
     }

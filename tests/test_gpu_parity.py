@@ -361,8 +361,10 @@ def test_hals_config5_full_size(cmf, config2):
 
     data, W0, H0 = config2
     runs = []
-    for seg in ("256", "1024"):
-        os.environ["CMF_HALS_SEG"] = seg
+    for seg in ("256", "1024", "384/lag3"):
+        os.environ["CMF_HALS_SEG"] = seg.split("/")[0]
+        if seg.endswith("lag3"):
+            os.environ["CMF_HALS_LAG"] = "3"  # the unshifted three-stage schedule of round 1
         try:
             r = cmf.fit_cnmf(data, L=20, K=32, alg=":hals", max_itr=3, check_convergence=False, W_init=W0, H_init=H0)
             if seg == "256":  # same configuration twice: bit for bit
@@ -371,8 +373,11 @@ def test_hals_config5_full_size(cmf, config2):
                 np.testing.assert_array_equal(r.H, r2.H)
         finally:
             os.environ.pop("CMF_HALS_SEG", None)
+            os.environ.pop("CMF_HALS_LAG", None)
         runs.append(r)
-    a, b = runs
+    a, b, c = runs
+    np.testing.assert_allclose(a.loss_hist, c.loss_hist, rtol=1e-6)  # both pipeline schedules keep the reference's order
+    assert frob_rel(a.H, c.H) < 1e-4
     assert np.all(np.diff(a.loss_hist) < 0) and a.loss_hist[-1] < 0.25
     # the pipeline never changes the order of the updates; the segment size only changes how the pushed sums
     # are associated at segment boundaries (rounding level)
