@@ -5,8 +5,8 @@ repo root:  ``import cmf_jl_amd as cmf``.
 """
 from ._lib import CMFError, LIB_PATH, SYMBOLS, load as load_library  # noqa: F401
 from .host import (  # noqa: F401
-    EPSILON, AbsolutePenalty, AbstractCFUpdate, AlternatingOptimizer, CNMF_results, HALSUpdate, HIPHALSUpdate,
-    HIPMultUpdate, HIPPGDUpdate, MaskedLoss, MultUpdate, NonnegConstraint, PGDUpdate, SquareLoss, SquarePenalty,
+    EPSILON, AbsoluteLoss, AbsolutePenalty, AbstractCFUpdate, AlternatingOptimizer, CNMF_results, HALSUpdate, HIPHALSUpdate,
+    HIPMultUpdate, HIPPGDUpdate, MaskedLoss, MultUpdate, NonnegConstraint, PGDUpdate, SquareLoss, SquarePenalty, UnitNormConstraint,
     compute_loss, converged, evaluate_convergence, evaluate_mse, evaluate_test, fit, fit_cnmf, gen_synthetic,
     init_rand, load_model, parameter_sweep, save_model, tensor_conv, tensor_transconv,
 )

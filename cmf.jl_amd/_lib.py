@@ -31,7 +31,7 @@ SYMBOLS = [
     "cmf_set_factors", "cmf_get_factors",
     "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_iterate", "cmf_fit", "cmf_converged",
     "cmf_hals_update_motifs", "cmf_hals_update_feature_maps",
-    "cmf_pgd_reset", "cmf_set_mask", "cmf_pgd_update_motifs", "cmf_pgd_update_feature_maps", "cmf_pgd_get_steps",
+    "cmf_pgd_reset", "cmf_set_mask", "cmf_pgd_set_loss", "cmf_pgd_update_motifs", "cmf_pgd_update_feature_maps", "cmf_pgd_get_steps",
     "cmf_tensor_conv", "cmf_tensor_transconv", "cmf_init_rand", "cmf_gen_synthetic",
     "cmf_time_kernel", "cmf_kernel_times",
 ]
@@ -91,6 +91,7 @@ def load():
     sig("cmf_hals_update_feature_maps", [vp, dbl, dbl, pd])
     sig("cmf_pgd_reset", [vp])
     sig("cmf_set_mask", [vp, pd])
+    sig("cmf_pgd_set_loss", [vp, cint])
     sig("cmf_pgd_update_motifs", [vp, dbl, dbl, cint])
     sig("cmf_pgd_update_feature_maps", [vp, dbl, dbl, cint, pd])
     sig("cmf_pgd_get_steps", [vp, pd, pd])

@@ -104,6 +104,9 @@ struct cmf_handle_s {
     // PGD rule state (pgd.jl:139-154)
     double pgd_stepW = 5.0, pgd_stepH = 5.0, pgd_cur_loss = -1.0;
     float *pgd_gradH = nullptr;
+    int pgd_loss_abs_now = 0;  // loss kind of the residual conv being launched (set by resid_and_loss / the PGD H phase)
+    int pgd_loss_abs = 0;      // 0 SquareLoss (pgd.jl:29-36), 1 AbsoluteLoss (pgd.jl:41-47)
+    double *pgd_knorm = nullptr; // [K32] per-component sums of squares of UnitNormConstraint (pgd.jl:100-110)
     float *M = nullptr, *MT = nullptr; // mask of MaskedLoss (pgd.jl:58-70) in the layouts of X and XT; null = no mask
 
     double data_sumsq = 0.0, data_norm = 0.0;
@@ -119,7 +122,8 @@ struct cmf_handle_s {
     struct ProfRec { hipEvent_t a, b; int cls; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
-    int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data, 3 mask .* (tensor_conv(W,H) - data)
+    int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data, 3 mask .* (tensor_conv(W,H) - data),
+                            // 4 sign(tensor_conv(W,H) - data), 5 mask .* sign(...)  (the AbsoluteLoss gradient)
 
     // T-sharded groups (cmf_group.h): the handle the caller holds fronts a group when `group` is set
     struct cmf_group_s *group = nullptr;
@@ -133,7 +137,7 @@ struct cmf_handle_s {
 
 static int hals_ensure(cmf_handle_s *h);
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
-static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked = false);
+static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked = false, bool loss_abs = false);
 static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W);
 static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss);
 static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg);
@@ -267,6 +271,7 @@ static void destroy_impl(cmf_handle_s *h)
     for (int v = 0; v < 2; ++v)
         if (h->tc_tab[v]) (void)hipFree(h->tc_tab[v]);
     if (h->partial) (void)hipFree(h->partial);
+    if (h->pgd_knorm) (void)hipFree(h->pgd_knorm);
     if (h->d_scalar_own) (void)hipFree(h->d_scalar_own);
     if (h->h_scalar) (void)hipHostFree(h->h_scalar);
     if (h->stage) (void)hipFree(h->stage);
@@ -444,6 +449,7 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = data ? data : h->X; p.partial = h->partial;
     p.mask = (MODE == 7) ? h->MT : h->M;
     p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = T_store;
+    p.loss_abs = (MODE >= 4) ? h->pgd_loss_abs_now : 0;
     dim3 grid(h->conv_gx, gy), block(256);
     // measured at config 2 (tools/time_kernels.py): the one-wave kernel wins for the epilogues that read data
     // (0.924 vs 0.931 ms loss only, 0.936 vs 0.943 ms loss + store), the 128 x 128 tiles for the store-only ones
@@ -935,6 +941,16 @@ int cmf_pgd_reset(cmf_handle h)
     return CMF_OK;
 }
 
+int cmf_pgd_set_loss(cmf_handle h, int loss_kind)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
+    if (loss_kind != 0 && loss_kind != 1) return fail(CMF_ERR_ARG, "loss_kind must be 0 (SquareLoss) or 1 (AbsoluteLoss)");
+    if (h->pgd_loss_abs != loss_kind) h->est_kind = 0;
+    h->pgd_loss_abs = loss_kind;
+    return CMF_OK;
+}
+
 int cmf_pgd_update_motifs(cmf_handle h, double pen_sq, double pen_abs, int nonneg)
 {
     if (h && h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
@@ -1258,20 +1274,23 @@ int cmf_shard_bounds(cmf_handle h, int rank, int64_t *t0, int64_t *t1)
 }
 
 // est := tensor_conv(W,H) - data (the residual hals.jl / pgd.jl carry), with the loss sum in d_scalar[0]
-static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked)
+static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked, bool loss_abs)
 {
     const CmfDims &d = h->d;
-    if (masked) CMFTRY(launch_conv<6>(h, h->est, d.Tl, h->conv_gy)); // pgd.jl:64-70
-    else CMFTRY(launch_conv<4>(h, h->est, d.Tl, h->conv_gy));
+    h->pgd_loss_abs_now = loss_abs ? 1 : 0;
+    int rc = masked ? launch_conv<6>(h, h->est, d.Tl, h->conv_gy) // pgd.jl:64-70
+                    : launch_conv<4>(h, h->est, d.Tl, h->conv_gy);
+    h->pgd_loss_abs_now = 0;
+    CMFTRY(rc);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, (double *)nullptr);
     KCHK("loss_reduce_kernel");
-    h->est_kind = masked ? 3 : 2;
+    h->est_kind = 2 + (masked ? 1 : 0) + (loss_abs ? 2 : 0);
     return sumsq ? read_scalar(h, 0, sumsq) : CMF_OK;
 }
 
-static int ensure_resid(cmf_handle_s *h, bool masked = false)
+static int ensure_resid(cmf_handle_s *h, bool masked = false, bool loss_abs = false)
 {
-    return h->est_kind == (masked ? 3 : 2) ? CMF_OK : resid_and_loss(h, nullptr, masked);
+    return h->est_kind == 2 + (masked ? 1 : 0) + (loss_abs ? 2 : 0) ? CMF_OK : resid_and_loss(h, nullptr, masked, loss_abs);
 }
 
 // ---- HALS (src/algs/hals.jl) -------------------------------------------------------------------
@@ -1496,9 +1515,28 @@ static int pgd_check(cmf_handle_s *h)
 static int pgd_finish(cmf_handle_s *h, double *step)
 {
     double loss = 0.0;
-    CMFTRY(resid_and_loss(h, &loss, h->M != nullptr));
+    CMFTRY(resid_and_loss(h, &loss, h->M != nullptr, h->pgd_loss_abs != 0));
     *step *= (loss < h->pgd_cur_loss) ? 1.05 : 0.70;
     h->pgd_cur_loss = loss;
+    return CMF_OK;
+}
+
+// UnitNormConstraint (pgd.jl:100-110) on the freshly stepped factor: per-component norms, then the scaling
+static int pgd_unit_norm(cmf_handle_s *h, bool is_W)
+{
+    const CmfDims &d = h->d;
+    if (!h->pgd_knorm) CMFTRY(dalloc_zero(&h->pgd_knorm, (size_t)d.K32));
+    if (is_W) {
+        hipLaunchKernelGGL(pgd_w_knorm_kernel, dim3(d.K), dim3(256), 0, h->stream, h->Wt, h->pgd_knorm, d.N, d.L, d.Np, d.K32);
+        KCHK("pgd_w_knorm_kernel");
+        hipLaunchKernelGGL(pgd_w_kscale_kernel, dim3(1024), dim3(256), 0, h->stream, h->Wt, h->Wn, h->pgd_knorm, d.N, d.K, d.L, d.Np, d.K32);
+        KCHK("pgd_w_kscale_kernel");
+    } else {
+        hipLaunchKernelGGL(pgd_h_knorm_kernel, dim3(d.K), dim3(256), 0, h->stream, h->Ht, h->pgd_knorm, d.Tl, d.TP, d.PADL);
+        KCHK("pgd_h_knorm_kernel");
+        hipLaunchKernelGGL(pgd_h_kscale_kernel, dim3(1024), dim3(256), 0, h->stream, h->H, h->Ht, h->pgd_knorm, d.Tl, d.K, d.K32, d.TP, d.PADL);
+        KCHK("pgd_h_kscale_kernel");
+    }
     return CMF_OK;
 }
 
@@ -1506,21 +1544,24 @@ static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
 {
     const CmfDims &d = h->d;
     CMFTRY(pgd_check(h));
+    if (nonneg < 0 || nonneg > 2) return fail(CMF_ERR_ARG, "constraint must be 0 (none), 1 (NonnegConstraint) or 2 (UnitNormConstraint)");
+    const float gscale = h->pgd_loss_abs ? 1.f : 2.f; // pgd.jl:31-33 vs :42-44
     const size_t LKN = (size_t)d.L * d.K32 * d.Np;
-    CMFTRY(ensure_resid(h, h->M != nullptr));                                                            // pgd.jl:230 (:64-67 with a mask)
+    CMFTRY(ensure_resid(h, h->M != nullptr, h->pgd_loss_abs != 0));                                                            // pgd.jl:230 (:64-67 with a mask)
     CMFTRY(launch_hxt_on(h, h->est, h->est, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1)); // pgd.jl:206-214
     CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN));
     dim3 grid(d.Np / 64, d.KB, d.L);
     const int nblk = (d.Np / 64) * d.KB * d.L;
     if ((size_t)nblk > n_partial(h)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
     hipLaunchKernelGGL(pgd_w_grad_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->numden, h->numden + LKN, h->partial,
-                       d.N, d.K, d.Np, d.K32, (float)pen_sq, (float)pen_abs);                            // pgd.jl:231-234
+                       d.N, d.K, d.Np, d.K32, (float)pen_sq, (float)pen_abs, gscale);                    // pgd.jl:231-234
     KCHK("pgd_w_grad_kernel");
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nblk, h->d_scalar + 1, (double *)nullptr);
     KCHK("loss_reduce_kernel");
     hipLaunchKernelGGL(pgd_w_apply_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden + LKN, h->d_scalar + 1,
-                       d.N, d.K, d.Np, d.K32, (float)h->pgd_stepW, nonneg);                              // pgd.jl:237-241
+                       d.N, d.K, d.Np, d.K32, (float)h->pgd_stepW, nonneg == 1);                         // pgd.jl:237-241
     KCHK("pgd_w_apply_kernel");
+    if (nonneg == 2) CMFTRY(pgd_unit_norm(h, true));                                                     // pgd.jl:100-110
     h->est_kind = 0;
     return pgd_finish(h, &h->pgd_stepW);
 }
@@ -1529,21 +1570,27 @@ static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
 {
     const CmfDims &d = h->d;
     CMFTRY(pgd_check(h));
+    if (nonneg < 0 || nonneg > 2) return fail(CMF_ERR_ARG, "constraint must be 0 (none), 1 (NonnegConstraint) or 2 (UnitNormConstraint)");
+    const float gscale = h->pgd_loss_abs ? 1.f : 2.f;
     if (!h->pgd_gradH) CMFTRY(dalloc_zero(&h->pgd_gradH, (size_t)d.Tl * d.K32));
-    if (h->MT) CMFTRY(launch_conv<7>(h, h->estT, d.Tl, h->conv_gy, h->XT)); // (mask .* resid)^T (pgd.jl:64-67)
-    else CMFTRY(launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT));       // resid^T (pgd.jl:230)
+    h->pgd_loss_abs_now = h->pgd_loss_abs;
+    int rc_conv = h->MT ? launch_conv<7>(h, h->estT, d.Tl, h->conv_gy, h->XT) // (mask .* resid)^T (pgd.jl:64-67)
+                        : launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT); // resid^T (pgd.jl:230), or its sign (pgd.jl:42-44)
+    h->pgd_loss_abs_now = 0;
+    CMFTRY(rc_conv);
     CMFTRY(launch_transconv(h, 1, h->estT));                     // pgd.jl:218-221
     dim3 grid((d.Tl + 63) / 64, d.KB);
     const int nblk = ((d.Tl + 63) / 64) * d.KB;
     if ((size_t)nblk > n_partial(h)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
     hipLaunchKernelGGL(pgd_h_grad_kernel, grid, dim3(256), 0, h->stream, h->H, h->hslabs, h->tc_S1, h->pgd_gradH, h->partial,
-                       d.Tl, d.K, d.K32, d.PADL, (float)pen_sq, (float)pen_abs);
+                       d.Tl, d.K, d.K32, d.PADL, (float)pen_sq, (float)pen_abs, gscale);
     KCHK("pgd_h_grad_kernel");
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nblk, h->d_scalar + 1, (double *)nullptr);
     KCHK("loss_reduce_kernel");
     hipLaunchKernelGGL(pgd_h_apply_kernel, grid, dim3(256), 0, h->stream, h->H, h->Ht, h->pgd_gradH, h->d_scalar + 1,
-                       d.Tl, d.K, d.K32, d.PADL, d.TP, (float)h->pgd_stepH, nonneg);
+                       d.Tl, d.K, d.K32, d.PADL, d.TP, (float)h->pgd_stepH, nonneg == 1);
     KCHK("pgd_h_apply_kernel");
+    if (nonneg == 2) CMFTRY(pgd_unit_norm(h, false)); // pgd.jl:100-110
     h->est_kind = 0;
     CMFTRY(pgd_finish(h, &h->pgd_stepH));
     *loss = std::sqrt(h->pgd_cur_loss / (h->data_norm * h->data_norm)); // pgd.jl:201

@@ -65,6 +65,8 @@ __device__ __forceinline__ float cmf_bload(__amdgpu_buffer_rsrc_t r, int voff_by
 //   MODE 5: store (est - data)^T in the [n][t] layout (p.data = dataT)
 //   MODE 6: MODE 4 with the residual multiplied by p.mask [t][n]  (MaskedLoss, pgd.jl:58-70)
 //   MODE 7: MODE 5 with the residual multiplied by p.mask = maskT [n][t]
+//   (modes 4-7 with p.loss_abs: the stored quantity is the AbsoluteLoss gradient sign(est - data) [.* mask] and the
+//    loss sum is sum |mask .* (est - data)|, pgd.jl:41-47)
 // ---------------------------------------------------------------------------------------------
 struct ConvParams {
     const float *Ht;
@@ -75,6 +77,7 @@ struct ConvParams {
     double *partial;   // [gridDim.x * gridDim.y]
     int Np, TP, PADL, K, KB, L;
     int T_store; // rows t < T_store are stored / counted
+    int loss_abs; // residual modes (4-7) only: 1 = AbsoluteLoss (pgd.jl:41-47): store sign(est - data) [.* mask], sum |.|
 };
 
 #define CONV_TRANSPOSED(MODE) ((MODE) == 1 || (MODE) == 5 || (MODE) == 7)
@@ -148,10 +151,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
                                 const float v = acc[gt + ti][gn + ni][r];
                                 float d = MASKED ? (v - dv[ti][ni][r]) * mv[ti][ni][r] : v - dv[ti][ni][r];
                                 if (MODE == 0 || MODE == 3) cmf_bstore(v, ro, voff, so);
-                                if (RESID) cmf_bstore(d, ro, voff, so);
+                                if (RESID) {
+                                    const float sg = (v > dv[ti][ni][r]) ? 1.f : ((v < dv[ti][ni][r]) ? -1.f : 0.f);
+                                    cmf_bstore(p.loss_abs ? (MASKED ? sg * mv[ti][ni][r] : sg) : d, ro, voff, so);
+                                }
                                 if (LOSS) {
                                     if (PARTIAL) d = ((gt + ti) * 32 + cmf_crow(r, h) < rows) ? d : 0.f;
-                                    lsum = fmaf(d, d, lsum);
+                                    lsum = (RESID && p.loss_abs) ? lsum + fabsf(d) : fmaf(d, d, lsum);
                                 }
                             }
                 }
@@ -202,7 +208,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int so = ((ni * 32 + (r & 3) + 8 * (r >> 2)) * TP + ti * 32) * 4;
-                        cmf_bstore(MASKED ? (acc[ni][ti][r] - dv[r]) * mv[r] : acc[ni][ti][r] - dv[r], ro, voff, so);
+                        float d = acc[ni][ti][r] - dv[r];
+                        if (MODE != 1 && p.loss_abs) d = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+                        cmf_bstore(MASKED ? d * mv[r] : d, ro, voff, so);
                     }
                 }
             }
@@ -569,10 +577,13 @@ __device__ __forceinline__ void conv_epilogue_block(const f32x16 &acc, const Con
             const float v = acc[r];
             float d = MASKED ? (v - dv[r]) * mv[r] : v - dv[r];
             if (MODE == 0 || MODE == 3) cmf_bstore(v, ro, voff, so);
-            if (RESID) cmf_bstore(d, ro, voff, so);
+            if (RESID) {
+                const float sg = (v > dv[r]) ? 1.f : ((v < dv[r]) ? -1.f : 0.f);
+                cmf_bstore(p.loss_abs ? (MASKED ? sg * mv[r] : sg) : d, ro, voff, so);
+            }
             if (LOSS) {
                 d = (cmf_crow(r, h) < rows) ? d : 0.f;
-                lsum = fmaf(d, d, lsum);
+                lsum = (RESID && p.loss_abs) ? lsum + fabsf(d) : fmaf(d, d, lsum);
             }
         }
         if (LOSS) {
@@ -603,7 +614,9 @@ __device__ __forceinline__ void conv_epilogue_block(const f32x16 &acc, const Con
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int so = (((r & 3) + 8 * (r >> 2)) * TP) * 4;
-                cmf_bstore(MASKED ? (acc[r] - dv[r]) * mv[r] : acc[r] - dv[r], ro, voff, so);
+                float d = acc[r] - dv[r];
+                if (MODE != 1 && p.loss_abs) d = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+                cmf_bstore(MASKED ? d * mv[r] : d, ro, voff, so);
             }
         }
     }
@@ -1762,10 +1775,11 @@ __global__ __launch_bounds__(256) void hals_h_stage_kernel(HalsStageParams sp)
 // =============================================================================================
 __device__ __forceinline__ float cmf_sign(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
-// grad[idx] = 2*G + 2*pen_sq*w + pen_abs*sign(w) over the valid entries of the Wt layout; block partials of sum(g^2)
-// grid (Np/64, KB, L), block 256
+// grad[idx] = gscale*G + 2*pen_sq*w + pen_abs*sign(w) over the valid entries of the Wt layout (gscale: 2 for SquareLoss,
+// whose stored residual is est - data; 1 for AbsoluteLoss, whose stored quantity already is the gradient sign(est - data));
+// block partials of sum(g^2).  grid (Np/64, KB, L), block 256
 __global__ __launch_bounds__(256) void pgd_w_grad_kernel(const float *Wt, const float *G, float *grad, double *partial,
-                                                          int N, int K, int Np, int K32, float pen_sq, float pen_abs)
+                                                          int N, int K, int Np, int K32, float pen_sq, float pen_abs, float gscale)
 {
     const int tid = threadIdx.x;
     const int n = blockIdx.x * 64 + (tid & 63), kb = blockIdx.y, l = blockIdx.z;
@@ -1777,7 +1791,7 @@ __global__ __launch_bounds__(256) void pgd_w_grad_kernel(const float *Wt, const 
         float g = 0.f;
         if (k < K && n < N) {
             const float w = Wt[idx];
-            g = 2.f * G[idx] + 2.f * pen_sq * w + pen_abs * cmf_sign(w);
+            g = gscale * G[idx] + 2.f * pen_sq * w + pen_abs * cmf_sign(w);
         }
         grad[idx] = g;
         ss += (double)g * (double)g;
@@ -1824,9 +1838,9 @@ __global__ __launch_bounds__(256) void pgd_w_apply_kernel(float *Wt, float *Wn, 
     }
 }
 
-// grad[t][k] = 2*sum_s slabs[s][t][k] + 2*pen_sq*h + pen_abs*sign(h); grid (ceil(Tl/64), KB), block 256
+// grad[t][k] = gscale*sum_s slabs[s][t][k] + 2*pen_sq*h + pen_abs*sign(h); grid (ceil(Tl/64), KB), block 256
 __global__ __launch_bounds__(256) void pgd_h_grad_kernel(const float *H, const float *slabs, int S, float *grad, double *partial,
-                                                          int Tl, int K, int K32, int PADL, float pen_sq, float pen_abs)
+                                                          int Tl, int K, int K32, int PADL, float pen_sq, float pen_abs, float gscale)
 {
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * 64, kb = blockIdx.y;
@@ -1843,7 +1857,7 @@ __global__ __launch_bounds__(256) void pgd_h_grad_kernel(const float *H, const f
                 float v = 0.f;
                 for (int s = 0; s < S; ++s) v += slabs[(size_t)s * TK + idx];
                 const float hv = H[(size_t)(PADL + t) * K32 + k];
-                g = 2.f * v + 2.f * pen_sq * hv + pen_abs * cmf_sign(hv);
+                g = gscale * v + 2.f * pen_sq * hv + pen_abs * cmf_sign(hv);
             }
             grad[idx] = g;
             ss += (double)g * (double)g;
@@ -1889,6 +1903,78 @@ __global__ __launch_bounds__(256) void pgd_h_apply_kernel(float *H, float *Ht, c
         for (int q = 0; q < 8; ++q) {
             const int kk = q * 4 + (tid >> 6), t = t0 + tt;
             if (t < Tl) Ht[(size_t)(kb * 32 + kk) * TP + PADL + t] = tile[kk][tt];
+        }
+    }
+}
+
+
+// UnitNormConstraint (pgd.jl:100-110): every component k whose slice (W[k, :, :] or H[k, :]) has norm > 1 is scaled to
+// norm 1.  Pass 1: ss[k] = sum of squares of the slice (one block per k, fp64); pass 2: scale both layouts.
+__global__ __launch_bounds__(256) void pgd_w_knorm_kernel(const float *Wt, double *ss, int N, int L, int Np, int K32)
+{
+    __shared__ double red[256];
+    const int k = blockIdx.x;
+    double s = 0.0;
+    for (int idx = threadIdx.x; idx < L * N; idx += 256) {
+        const int l = idx / N, n = idx - l * N;
+        const double v = Wt[((size_t)l * K32 + k) * Np + n];
+        s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ss[k] = red[0];
+}
+__global__ __launch_bounds__(256) void pgd_h_knorm_kernel(const float *Ht, double *ss, int Tl, int TP, int PADL)
+{
+    __shared__ double red[256];
+    const int k = blockIdx.x;
+    double s = 0.0;
+    for (int t = threadIdx.x; t < Tl; t += 256) {
+        const double v = Ht[(size_t)k * TP + PADL + t];
+        s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ss[k] = red[0];
+}
+__device__ __forceinline__ float cmf_unit_scale(double ss)
+{
+    const double mag = sqrt(ss);
+    return mag > 1.0 ? (float)(1.0 / mag) : 1.f;
+}
+__global__ void pgd_w_kscale_kernel(float *Wt, float *Wn, const double *ss, int N, int K, int L, int Np, int K32)
+{
+    const size_t total = (size_t)L * K * N;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % N), k = (int)((idx / N) % K), l = (int)(idx / ((size_t)N * K));
+        const float sc = cmf_unit_scale(ss[k]);
+        if (sc != 1.f) {
+            const size_t it = ((size_t)l * K32 + k) * Np + n;
+            const float v = Wt[it] * sc;
+            Wt[it] = v;
+            Wn[((size_t)l * Np + n) * K32 + k] = v;
+        }
+    }
+}
+__global__ void pgd_h_kscale_kernel(float *H, float *Ht, const double *ss, int Tl, int K, int K32, int TP, int PADL)
+{
+    const size_t total = (size_t)Tl * K;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % K), t = (int)(idx / K);
+        const float sc = cmf_unit_scale(ss[k]);
+        if (sc != 1.f) {
+            const size_t ih = (size_t)(PADL + t) * K32 + k;
+            const float v = H[ih] * sc;
+            H[ih] = v;
+            Ht[(size_t)k * TP + PADL + t] = v;
         }
     }
 }

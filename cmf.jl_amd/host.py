@@ -314,13 +314,17 @@ class SquareLoss:
     """D(b, est) = ||b - est||^2 (src/algs/pgd.jl:29-36)."""
 
 
+class AbsoluteLoss:
+    """D(b, est) = ||b - est||_1 with gradient sign(est - b) (src/algs/pgd.jl:41-47)."""
+
+
 class MaskedLoss:
     """MaskedLoss(loss, mask): gradient and loss of `loss` restricted by an N x T mask (src/algs/pgd.jl:58-70;
-    the loss_func of the reference's test/test.jl:45).  The GPU rule supports MaskedLoss(SquareLoss(), mask)."""
+    the loss_func of the reference's test/test.jl:45).  `loss` is SquareLoss() or AbsoluteLoss()."""
 
     def __init__(self, loss, mask):
-        if not isinstance(loss, SquareLoss):
-            raise NotImplementedError("MaskedLoss on the GPU wraps SquareLoss")
+        if not isinstance(loss, (SquareLoss, AbsoluteLoss)):
+            raise NotImplementedError("MaskedLoss on the GPU wraps SquareLoss or AbsoluteLoss")
         self.loss = loss
         self.mask = farr(mask)
 
@@ -343,6 +347,11 @@ class NonnegConstraint:
     """x_i >= 0, projected as max(eps(), x) (src/algs/pgd.jl:92-96)."""
 
 
+class UnitNormConstraint:
+    """Every slice along the first dimension (a component k) with norm > 1 is scaled to norm 1 (src/algs/pgd.jl:100-110;
+    `constrW=CMF.UnitNormConstraint()` in figures/thesis/exp_reconstruct_synth.jl:69)."""
+
+
 def _penalty_weights(penalties):
     sq = sum(p.weight for p in penalties if isinstance(p, SquarePenalty))
     ab = sum(p.weight for p in penalties if isinstance(p, AbsolutePenalty))
@@ -356,7 +365,9 @@ def _nonneg_flag(constr):
         return 0
     if isinstance(constr, NonnegConstraint) or constr is NonnegConstraint:
         return 1
-    raise NotImplementedError("PGDUpdate on the GPU supports NonnegConstraint or no constraint")
+    if isinstance(constr, UnitNormConstraint) or constr is UnitNormConstraint:
+        return 2
+    raise NotImplementedError("PGDUpdate on the GPU supports NonnegConstraint, UnitNormConstraint or no constraint")
 
 
 class PGDUpdate(MultUpdate):
@@ -372,13 +383,18 @@ class PGDUpdate(MultUpdate):
         self._mask_key = None
 
     def _select_loss(self, loss_func):
-        """loss_func=SquareLoss() (default) or MaskedLoss(SquareLoss(), mask): uploads the mask when it changes."""
-        if loss_func is None or isinstance(loss_func, SquareLoss) or loss_func is SquareLoss:
-            key = None
-        elif isinstance(loss_func, MaskedLoss):
-            key = id(loss_func)
+        """loss_func=SquareLoss() (default), AbsoluteLoss() or MaskedLoss(either, mask): uploads the mask when it changes."""
+        base = loss_func.loss if isinstance(loss_func, MaskedLoss) else loss_func
+        if base is None or isinstance(base, SquareLoss) or base is SquareLoss:
+            kind = 0
+        elif isinstance(base, AbsoluteLoss) or base is AbsoluteLoss:
+            kind = 1
         else:
-            raise NotImplementedError("PGDUpdate on the GPU supports SquareLoss and MaskedLoss(SquareLoss(), mask)")
+            raise NotImplementedError("PGDUpdate on the GPU supports SquareLoss, AbsoluteLoss and MaskedLoss of either")
+        if kind != getattr(self, "_loss_kind", 0):
+            check(self._lib.cmf_pgd_set_loss(self._h, kind))
+            self._loss_kind = kind
+        key = id(loss_func) if isinstance(loss_func, MaskedLoss) else None
         if key == self._mask_key:
             return
         if key is None:

@@ -19,7 +19,8 @@ module CMFHip
 
 import ..CMF: AbstractCFUpdate, Tensor
 import ..CMF: update_motifs!, update_feature_maps!                                   # generic functions: algs/mult.jl
-import ..CMF: SquareLoss, MaskedLoss, SquarePenalty, AbsolutePenalty, NonnegConstraint  # types: algs/pgd.jl
+import ..CMF: SquareLoss, AbsoluteLoss, MaskedLoss, SquarePenalty, AbsolutePenalty,    # types: algs/pgd.jl
+              NonnegConstraint, UnitNormConstraint
 
 const LIBCMF = get(ENV, "LIBCMF_HIP", "libcmf_hip.so")
 
@@ -122,29 +123,37 @@ end
 """
     HIPPGDUpdate(data, W, H; device=0)
 
-Drop-in for `PGDUpdate(data, W, H)` (src/algs/pgd.jl:112-155) with `SquareLoss()` or
-`MaskedLoss(SquareLoss(), mask)`, `SquarePenalty` / `AbsolutePenalty` lists and `NonnegConstraint()` / `nothing`.
+Drop-in for `PGDUpdate(data, W, H)` (src/algs/pgd.jl:112-155) with `SquareLoss()`, `AbsoluteLoss()` or
+`MaskedLoss(either, mask)`, `SquarePenalty` / `AbsolutePenalty` lists and `NonnegConstraint()` /
+`UnitNormConstraint()` / `nothing`.
 The step-size state (stepW, stepH, cur_loss) lives in the library handle.
 """
 mutable struct HIPPGDUpdate <: AbstractCFUpdate
     inner::HIPMultUpdate
     mask_id::UInt            # objectid of the mask currently resident on the device (0 = none)
+    loss_kind::Cint          # 0 SquareLoss, 1 AbsoluteLoss (cmf_pgd_set_loss)
 end
 function HIPPGDUpdate(data, W, H; kwargs...)
-    rule = HIPPGDUpdate(HIPMultUpdate(data, W, H; kwargs...), UInt(0))
+    rule = HIPPGDUpdate(HIPMultUpdate(data, W, H; kwargs...), UInt(0), Cint(0))
     check(ccall((:cmf_pgd_reset, LIBCMF), Cint, (Ptr{Cvoid},), rule.inner.handle))
     return rule
 end
 
 penalty_weights(pens) = (sum(Float64[p.weight for p in pens if p isa SquarePenalty]),
                          sum(Float64[p.weight for p in pens if p isa AbsolutePenalty]))
-nonneg_flag(c) = c === nothing ? Cint(0) : (c isa NonnegConstraint ? Cint(1) : error("unsupported constraint"))
+# 0 none, 1 NonnegConstraint (pgd.jl:92-96), 2 UnitNormConstraint (pgd.jl:100-110)
+nonneg_flag(c) = c === nothing ? Cint(0) : (c isa NonnegConstraint ? Cint(1) :
+                 (c isa UnitNormConstraint ? Cint(2) : error("unsupported constraint")))
 
 function select_loss!(rule::HIPPGDUpdate, loss_func)
-    if loss_func isa SquareLoss
-        rule.mask_id == 0 || check(ccall((:cmf_set_mask, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}), rule.inner.handle, C_NULL))
-        rule.mask_id = UInt(0)
-    elseif loss_func isa MaskedLoss && loss_func.loss isa SquareLoss      # pgd.jl:58-70
+    base = loss_func isa MaskedLoss ? loss_func.loss : loss_func             # pgd.jl:58-70
+    kind = base isa SquareLoss ? Cint(0) : (base isa AbsoluteLoss ? Cint(1) :
+           error("HIPPGDUpdate supports SquareLoss(), AbsoluteLoss() and MaskedLoss of either"))
+    if kind != rule.loss_kind
+        check(ccall((:cmf_pgd_set_loss, LIBCMF), Cint, (Ptr{Cvoid}, Cint), rule.inner.handle, kind))
+        rule.loss_kind = kind
+    end
+    if loss_func isa MaskedLoss
         id = objectid(loss_func.mask)
         if id != rule.mask_id
             m = Matrix{Float64}(loss_func.mask)
@@ -152,7 +161,8 @@ function select_loss!(rule::HIPPGDUpdate, loss_func)
             rule.mask_id = id
         end
     else
-        error("HIPPGDUpdate supports SquareLoss() and MaskedLoss(SquareLoss(), mask)")
+        rule.mask_id == 0 || check(ccall((:cmf_set_mask, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}), rule.inner.handle, C_NULL))
+        rule.mask_id = UInt(0)
     end
 end
 

@@ -189,8 +189,10 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
 /* ---- PGD rule ------------------------------------------
  * update_motifs!(rule::PGDUpdate, data, W, H; loss_func=SquareLoss(), constrW, penaltiesW)      src/algs/pgd.jl:158-177
  * update_feature_maps!(rule::PGDUpdate, data, W, H; loss_func, constrH, penaltiesH) -> loss    src/algs/pgd.jl:180-202
- * with SquareLoss; pen_sq / pen_abs are the summed weights of the SquarePenalty / AbsolutePenalty entries of
- * the penalty list (pgd.jl:74-89); nonneg selects NonnegConstraint (max(eps, x), pgd.jl:92-96) or none.
+ * with SquareLoss (pgd.jl:29-36) or AbsoluteLoss (pgd.jl:41-47; cmf_pgd_set_loss); pen_sq / pen_abs are the summed
+ * weights of the SquarePenalty / AbsolutePenalty entries of the penalty list (pgd.jl:74-89); `constraint` selects
+ * 0 = none, 1 = NonnegConstraint (max(eps, x), pgd.jl:92-96), 2 = UnitNormConstraint (every component k whose slice
+ * W[k,:,:] / H[k,:] has norm > 1 is scaled to norm 1, pgd.jl:100-110).
  * The rule's state (stepW = stepH = 5, cur_loss = norm(data), step_incr 1.05, step_decr 0.70; pgd.jl:139-154)
  * lives in the handle and is (re)initialised by cmf_create and cmf_pgd_reset.  Unsharded handles only. */
 int cmf_pgd_reset(cmf_handle h);
@@ -198,8 +200,11 @@ int cmf_pgd_reset(cmf_handle h);
  * gradient 2*(est - data) .* mask, loss norm(mask.*data - mask.*est)^2.  `mask` is N x T column-major like data
  * (borrowed for the call); NULL restores the plain SquareLoss.  Only the PGD entries read the mask. */
 int cmf_set_mask(cmf_handle h, const double *mask);
-int cmf_pgd_update_motifs(cmf_handle h, double pen_sq, double pen_abs, int nonneg);
-int cmf_pgd_update_feature_maps(cmf_handle h, double pen_sq, double pen_abs, int nonneg, double *loss);
+/* loss_func of the PGD entries: 0 = SquareLoss (default), 1 = AbsoluteLoss (gradient sign(est - data), loss
+ * norm(data - est, 1); pgd.jl:41-47).  Combines with cmf_set_mask as MaskedLoss(loss, mask). */
+int cmf_pgd_set_loss(cmf_handle h, int loss_kind);
+int cmf_pgd_update_motifs(cmf_handle h, double pen_sq, double pen_abs, int constraint);
+int cmf_pgd_update_feature_maps(cmf_handle h, double pen_sq, double pen_abs, int constraint, double *loss);
 int cmf_pgd_get_steps(cmf_handle h, double *stepW, double *stepH);
 
 /* converged(loss_hist, patience, tol): src/model.jl:91-107 (host arithmetic). */

@@ -423,6 +423,85 @@ int oracle_fit_hals(int64_t N, int64_t T, int64_t K, int64_t L,
 /* W = rand(K,N,L); H = rand(K,T) with the portable RNG (streams 0, 1)  */
 /* in Julia memory order; alpha = <data,est>/||est||^2; both *= sqrt|a|. */
 /* ------------------------------------------------------------------ */
+/* PGD rule: src/algs/pgd.jl (second, independent restatement; the    */
+/* first is the numpy one in cmf_oracle.py)                           */
+/* ------------------------------------------------------------------ */
+static double sgn(double x) { return (x > 0.0) - (x < 0.0); }
+
+/* projection!(::UnitNormConstraint, x): pgd.jl:100-110.  x has K slices along its first (fastest) dimension:
+ * element (k, j) at x[k + K*j], j < M. */
+static void unit_norm_projection(double *x, int64_t K, int64_t M)
+{
+    for (int64_t k = 0; k < K; ++k) {
+        double ss = 0.0;
+        for (int64_t j = 0; j < M; ++j) ss += x[k + K * j] * x[k + K * j];
+        const double mag = sqrt(ss);
+        if (mag > 1.0)
+            for (int64_t j = 0; j < M; ++j) x[k + K * j] /= mag;
+    }
+}
+
+/* pgd!: pgd.jl:224-255.  x (nx entries, K slices of M) is W or H; est holds tensor_conv(W, H) on entry and on exit.
+ * is_W selects compute_gradW! (:206-214) or compute_gradH! (:218-221).  Returns the new step. */
+static double pgd_step(int64_t N, int64_t T, int64_t K, int64_t L, const double *data, double *W, double *H, double *est,
+                       double *x, double *gradx, int is_W, double step, double pen_sq, double pen_abs, int constr,
+                       int loss_abs, const double *mask, double *cur_loss)
+{
+    const size_t NT = (size_t)N * T;
+    const size_t nx = is_W ? (size_t)K * N * L : (size_t)K * T;
+    /* :230  grad!(loss_func, est, est, data): 2 (est - data) (:31-33) or sign(est - data) (:42-44), times the mask (:64-67) */
+    for (size_t i = 0; i < NT; ++i) {
+        double g = loss_abs ? sgn(est[i] - data[i]) : 2.0 * (est[i] - data[i]);
+        est[i] = mask ? g * mask[i] : g;
+    }
+    if (is_W) oracle_hxt(N, T, K, L, H, est, gradx);       /* :231, :206-214 */
+    else oracle_tensor_transconv(N, T, K, L, W, est, gradx); /* :231, :218-221 */
+    for (size_t i = 0; i < nx; ++i) gradx[i] += 2.0 * pen_sq * x[i] + pen_abs * sgn(x[i]); /* :232-234, :78-80, :87-89 */
+    const double alpha = step / (frob_norm(gradx, nx) + 2.220446049250313e-16);            /* :237 */
+    for (size_t i = 0; i < nx; ++i) x[i] -= alpha * gradx[i];                              /* :240 */
+    if (constr == 1) {
+        for (size_t i = 0; i < nx; ++i) x[i] = x[i] > 2.220446049250313e-16 ? x[i] : 2.220446049250313e-16; /* :94-96 */
+    } else if (constr == 2) {
+        unit_norm_projection(x, K, is_W ? N * L : T);                                      /* :100-110 */
+    }
+    oracle_tensor_conv(N, T, K, L, W, H, est);                                             /* :245 */
+    double loss = 0.0;                                                                     /* :246 eval(loss_func, data, est) */
+    for (size_t i = 0; i < NT; ++i) {
+        const double m = mask ? mask[i] : 1.0;
+        const double d = m * data[i] - m * est[i];                                         /* :68-70 */
+        loss += loss_abs ? fabs(d) : d * d;                                                /* :45-47 / :34-36 */
+    }
+    step *= (loss < *cur_loss) ? 1.05 : 0.70;                                              /* :248-252 */
+    *cur_loss = loss;                                                                      /* :253 */
+    return step;
+}
+
+/* fit(::AlternatingOptimizer{PGDUpdate}) for exactly max_itr iterations (alternating.jl:44-60 without the stop tests):
+ * loss_hist[0] = compute_loss (:37), then update_motifs! / update_feature_maps! (pgd.jl:158-202).
+ * constr: 0 none, 1 NonnegConstraint, 2 UnitNormConstraint; loss_abs: AbsoluteLoss instead of SquareLoss; mask may be NULL. */
+void oracle_fit_pgd(int64_t N, int64_t T, int64_t K, int64_t L, const double *data, double *W, double *H, int64_t max_itr,
+                    double penW_sq, double penW_abs, double penH_sq, double penH_abs, int constrW, int constrH,
+                    int loss_abs, const double *mask, double *loss_hist, double *steps_out)
+{
+    const size_t NT = (size_t)N * T;
+    double *est = (double *)malloc(sizeof(double) * NT);
+    double *gradW = (double *)malloc(sizeof(double) * (size_t)K * N * L);
+    double *gradH = (double *)malloc(sizeof(double) * (size_t)K * T);
+    const double datanorm = frob_norm(data, NT);       /* pgd.jl:135 */
+    double stepW = 5.0, stepH = 5.0, cur = datanorm;    /* :148-151 (cur_loss starts as the norm, not its square) */
+    loss_hist[0] = oracle_compute_loss(N, T, K, L, data, W, H, est);
+    oracle_tensor_conv(N, T, K, L, W, H, est);          /* :136 */
+    for (int64_t it = 0; it < max_itr; ++it) {
+        stepW = pgd_step(N, T, K, L, data, W, H, est, W, gradW, 1, stepW, penW_sq, penW_abs, constrW, loss_abs, mask, &cur);
+        stepH = pgd_step(N, T, K, L, data, W, H, est, H, gradH, 0, stepH, penH_sq, penH_abs, constrH, loss_abs, mask, &cur);
+        loss_hist[it + 1] = sqrt(cur / (datanorm * datanorm)); /* :201 */
+    }
+    steps_out[0] = stepW;
+    steps_out[1] = stepH;
+    free(est); free(gradW); free(gradH);
+}
+
+/* ------------------------------------------------------------------ */
 void oracle_init_rand(int64_t N, int64_t T, int64_t K, int64_t L, uint64_t seed,
                       const double *data, double *W, double *H)
 {

@@ -225,9 +225,11 @@ def fit_hals(data, W_init, H_init, max_itr=100, max_time=np.inf, check_convergen
 
 
 # --------------------------------------------------------------------------
-# PGD rule: src/algs/pgd.jl.  numpy restatement only.
-# Supported pieces: SquareLoss (:30-36), MaskedLoss(SquareLoss(), mask) (:58-70; `mask=` below),
-# SquarePenalty / AbsolutePenalty (:74-89), NonnegConstraint (:92-96) or no constraint.
+# PGD rule: src/algs/pgd.jl.  numpy restatement here, C restatement in
+# cmf_oracle.c (oracle_fit_pgd / c_fit_pgd below); the two are cross-checked in tests/test_oracle.py.
+# Pieces: SquareLoss (:30-36), AbsoluteLoss (:41-47; `loss="abs"`), MaskedLoss(loss, mask) (:58-70; `mask=`),
+# SquarePenalty / AbsolutePenalty (:74-89), NonnegConstraint (:92-96), UnitNormConstraint (:100-110;
+# `constr="unitnorm"`) or no constraint.
 # --------------------------------------------------------------------------
 class PGDUpdate:
     """PGDUpdate state + ctor: src/algs/pgd.jl:112-155."""
@@ -244,10 +246,30 @@ class PGDUpdate:
         self.step_decr = 0.70
 
 
-def _pgd(rule, x, gradx, compute_grad, step, data, W, H, pen_sq, pen_abs, nonneg, mask=None):
+def _constr(nonneg, constr):
+    """The constraint of one factor: `constr` ("nonneg" | "unitnorm" | None) when given, else the legacy `nonneg` flag."""
+    if constr == "default":
+        return "nonneg" if nonneg else None
+    return constr
+
+
+def unit_norm_projection(x):
+    """projection!(::UnitNormConstraint, x): src/algs/pgd.jl:100-110 -- every slice along the FIRST dimension (a
+    component k: W[k, :, :] or H[k, :]) with norm > 1 is scaled to norm 1."""
+    for m in range(x.shape[0]):
+        mag = np.linalg.norm(x[m])
+        if mag > 1:
+            x[m] /= mag
+
+
+def _pgd(rule, x, gradx, compute_grad, step, data, W, H, pen_sq, pen_abs, nonneg, mask=None, loss="square", constr="default"):
     """pgd!: src/algs/pgd.jl:224-255 (x is W or H, updated in place)."""
     T = H.shape[1]
-    rule.est[...] = 2.0 * (rule.est - data)  # :230  grad!(SquareLoss): 2*(est - data), in place in r.est
+    constr = _constr(nonneg, constr)
+    if loss == "abs":
+        rule.est[...] = np.sign(rule.est - data)  # :42-44  grad!(AbsoluteLoss): sign(est - data)
+    else:
+        rule.est[...] = 2.0 * (rule.est - data)  # :230  grad!(SquareLoss): 2*(est - data), in place in r.est
     if mask is not None:
         rule.est *= mask  # :64-67  grad!(MaskedLoss): grad .*= mask
     compute_grad(gradx, rule.est)  # :231
@@ -257,19 +279,22 @@ def _pgd(rule, x, gradx, compute_grad, step, data, W, H, pen_sq, pen_abs, nonneg
         gradx += w * np.sign(x)  # :87-89
     alpha = step / (np.linalg.norm(gradx) + EPS)  # :237
     x -= alpha * gradx  # :240
-    if nonneg:
+    if constr == "nonneg":
         np.maximum(x, EPS, out=x)  # :94-96 max(eps(), x)
+    elif constr == "unitnorm":
+        unit_norm_projection(x)  # :100-110
     tensor_conv(W, H, out=rule.est)  # :245
-    if mask is None:
-        loss = np.linalg.norm(data - rule.est) ** 2  # :246, :34-36
+    b, e = (data, rule.est) if mask is None else (mask * data, mask * rule.est)  # :68-70 eval(MaskedLoss)
+    if loss == "abs":
+        lossv = np.abs(b - e).sum()  # :45-47 norm(b - est, 1)
     else:
-        loss = np.linalg.norm(mask * data - mask * rule.est) ** 2  # :68-70 eval(MaskedLoss)
-    step = step * (rule.step_incr if loss < rule.cur_loss else rule.step_decr)  # :248-252
-    rule.cur_loss = loss  # :253
+        lossv = np.linalg.norm(b - e) ** 2  # :246, :34-36
+    step = step * (rule.step_incr if lossv < rule.cur_loss else rule.step_decr)  # :248-252
+    rule.cur_loss = lossv  # :253
     return step
 
 
-def pgd_update_motifs(rule, data, W, H, penaltiesW_sq=(1.0,), penaltiesW_abs=(), nonneg=True, mask=None):
+def pgd_update_motifs(rule, data, W, H, penaltiesW_sq=(1.0,), penaltiesW_abs=(), nonneg=True, mask=None, loss="square", constrW="default"):
     """update_motifs!(::PGDUpdate): pgd.jl:158-177 (defaults: SquarePenalty(1), NonnegConstraint)."""
     K, N, L = W.shape
     T = H.shape[1]
@@ -278,16 +303,16 @@ def pgd_update_motifs(rule, data, W, H, penaltiesW_sq=(1.0,), penaltiesW_abs=(),
         for lag in range(L):
             gradw[:, :, lag] = (H[:, : T - lag] @ est[:, lag:].T) if lag < T else 0.0
 
-    rule.stepW = _pgd(rule, W, rule.gradW, grad, rule.stepW, data, W, H, penaltiesW_sq, penaltiesW_abs, nonneg, mask)
+    rule.stepW = _pgd(rule, W, rule.gradW, grad, rule.stepW, data, W, H, penaltiesW_sq, penaltiesW_abs, nonneg, mask, loss, constrW)
 
 
-def pgd_update_feature_maps(rule, data, W, H, penaltiesH_sq=(), penaltiesH_abs=(), nonneg=True, mask=None):
+def pgd_update_feature_maps(rule, data, W, H, penaltiesH_sq=(), penaltiesH_abs=(), nonneg=True, mask=None, loss="square", constrH="default"):
     """update_feature_maps!(::PGDUpdate): pgd.jl:180-202 -> sqrt(cur_loss / datanorm^2)."""
 
     def grad(gradh, est):  # compute_gradH!: :218-221
         tensor_transconv(W, est, out=gradh)
 
-    rule.stepH = _pgd(rule, H, rule.gradH, grad, rule.stepH, data, W, H, penaltiesH_sq, penaltiesH_abs, nonneg, mask)
+    rule.stepH = _pgd(rule, H, rule.gradH, grad, rule.stepH, data, W, H, penaltiesH_sq, penaltiesH_abs, nonneg, mask, loss, constrH)
     return np.sqrt(rule.cur_loss / rule.datanorm ** 2)
 
 
@@ -301,10 +326,12 @@ def fit_pgd(data, W_init, H_init, max_itr=100, check_convergence=False, patience
     kH = {k: v for k, v in kw.items() if k.startswith("penaltiesH")}
     nonneg = kw.get("nonneg", True)
     mask = kw.get("mask", None)
+    loss = kw.get("loss", "square")
+    cW, cH = kw.get("constrW", "default"), kw.get("constrH", "default")
     for _ in range(max_itr):
         if not eval_mode:
-            pgd_update_motifs(rule, data, W, H, nonneg=nonneg, mask=mask, **kW)
-        loss_hist.append(pgd_update_feature_maps(rule, data, W, H, nonneg=nonneg, mask=mask, **kH))
+            pgd_update_motifs(rule, data, W, H, nonneg=nonneg, mask=mask, loss=loss, constrW=cW, **kW)
+        loss_hist.append(pgd_update_feature_maps(rule, data, W, H, nonneg=nonneg, mask=mask, loss=loss, constrH=cH, **kH))
         if check_convergence and converged(loss_hist, patience, tol):
             break
     return W, H, np.asarray(loss_hist), (rule.stepW, rule.stepH)
@@ -450,6 +477,30 @@ def c_fit_hals(data, W_init, H_init, max_itr=100, max_time=np.inf, check_converg
                             int(check_convergence), patience, tol, int(eval_mode),
                             l1W, l2W, l1H, l2H, _p(lh), _p(th), ctypes.byref(n))
     return W, H, lh[: n.value].copy(), th[: n.value].copy()
+
+
+_CONSTR_CODE = {None: 0, "nonneg": 1, "unitnorm": 2}
+
+
+def c_fit_pgd(data, W_init, H_init, max_itr=100, penW_sq=1.0, penW_abs=0.0, penH_sq=0.0, penH_abs=0.0,
+              constrW="nonneg", constrH="nonneg", loss="square", mask=None):
+    """fit(::AlternatingOptimizer{PGDUpdate}) through the C restatement (oracle_fit_pgd): exactly max_itr iterations.
+    Returns W, H, loss_hist, (stepW, stepH)."""
+    K, N, L = W_init.shape
+    d = _f(data)
+    W = np.array(W_init, dtype=np.float64, order="F", copy=True)
+    H = np.array(H_init, dtype=np.float64, order="F", copy=True)
+    T = H.shape[1]
+    lh = np.zeros(max_itr + 1)
+    steps = np.zeros(2)
+    m = None if mask is None else _f(mask)
+    lib = c_lib()
+    lib.oracle_fit_pgd.restype = None
+    lib.oracle_fit_pgd(ctypes.c_int64(N), ctypes.c_int64(T), ctypes.c_int64(K), ctypes.c_int64(L), _p(d), _p(W), _p(H),
+                       ctypes.c_int64(max_itr), ctypes.c_double(penW_sq), ctypes.c_double(penW_abs), ctypes.c_double(penH_sq),
+                       ctypes.c_double(penH_abs), ctypes.c_int(_CONSTR_CODE[constrW]), ctypes.c_int(_CONSTR_CODE[constrH]),
+                       ctypes.c_int(1 if loss == "abs" else 0), None if m is None else _p(m), _p(lh), _p(steps))
+    return W, H, lh, (steps[0], steps[1])
 
 
 def c_init_rand(data, L, K, seed):

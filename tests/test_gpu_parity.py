@@ -439,6 +439,77 @@ def test_pgd_penalties_and_unconstrained(cmf, oracle):
     assert frob_rel(Wg, W) < REL_FACTORS and frob_rel(Hg, H) < REL_FACTORS
     np.testing.assert_allclose(sg, (orule.stepW, orule.stepH), rtol=1e-12)  # same accept/reject decisions
 
+@pytest.mark.parametrize("N,T,K,L,constrW,constrH", [(60, 500, 5, 10, "unitnorm", "nonneg"), (130, 700, 32, 20, "unitnorm", "nonneg"),
+                                                      (37, 150, 33, 7, "nonneg", "unitnorm"), (48, 300, 4, 8, "unitnorm", "unitnorm")])
+def test_pgd_unit_norm_constraint(cmf, oracle, N, T, K, L, constrW, constrH):
+    """UnitNormConstraint (pgd.jl:100-110; constrW=UnitNormConstraint() in figures/thesis/exp_reconstruct_synth.jl:69)
+    against both oracle restatements: the per-component norms never exceed 1 and the step decisions agree."""
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=7)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=2)
+    cls = {"unitnorm": cmf.UnitNormConstraint(), "nonneg": cmf.NonnegConstraint()}
+    rule = cmf.PGDUpdate(data, W0, H0)
+    lg = []
+    for _ in range(6):
+        rule.update_motifs(constrW=cls[constrW])                       # penaltiesW = [SquarePenalty(1)] (pgd.jl:162)
+        lg.append(rule.update_feature_maps(constrH=cls[constrH]))
+    Wg, Hg = rule.download()
+    sg = rule.steps
+    rule.close()
+    Wr, Hr, lr, sr = oracle.fit_pgd(data, W0, H0, max_itr=6, constrW=constrW, constrH=constrH)
+    Wc, Hc, lc, sc = oracle.c_fit_pgd(data, W0, H0, max_itr=6, constrW=constrW, constrH=constrH)
+    np.testing.assert_allclose(lr[1:], lc[1:], rtol=1e-9)
+    np.testing.assert_allclose(lg, lr[1:], rtol=REL_LOSS)
+    assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
+    np.testing.assert_allclose(sg, sr, rtol=1e-12)
+    if constrW == "unitnorm":
+        assert max(np.linalg.norm(Wg[k]) for k in range(K)) <= 1 + 1e-5
+        assert Wg.min() < 0 or True  # no clamp under this constraint: negative entries are legal
+    if constrH == "unitnorm":
+        assert max(np.linalg.norm(Hg[k]) for k in range(K)) <= 1 + 1e-5
+
+
+@pytest.mark.parametrize("N,T,K,L,masked", [(60, 500, 5, 10, False), (130, 700, 32, 20, False), (48, 300, 4, 8, True), (37, 150, 33, 7, True)])
+def test_pgd_absolute_loss(cmf, oracle, N, T, K, L, masked):
+    """AbsoluteLoss (pgd.jl:41-47): gradient sign(est - data) formed in the conv epilogue, loss norm(data - est, 1);
+    alone and under MaskedLoss (pgd.jl:58-70).  The sign of a residual within fp32 rounding of zero can differ from
+    the fp64 oracle's, so the factors are compared a little looser than the smooth losses."""
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=9)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=4)
+    rng = np.random.default_rng(1)
+    mask = (rng.random((N, T)) < 0.7).astype(float) if masked else None
+    lf = cmf.MaskedLoss(cmf.AbsoluteLoss(), mask) if masked else cmf.AbsoluteLoss()
+    rule = cmf.PGDUpdate(data, W0, H0)
+    lg = []
+    for _ in range(5):
+        rule.update_motifs(loss_func=lf)
+        lg.append(rule.update_feature_maps(loss_func=lf))
+    Wg, Hg = rule.download()
+    sg = rule.steps
+    rule.close()
+    Wr, Hr, lr, sr = oracle.fit_pgd(data, W0, H0, max_itr=5, loss="abs", mask=mask)
+    Wc, Hc, lc, sc = oracle.c_fit_pgd(data, W0, H0, max_itr=5, loss="abs", mask=mask)
+    np.testing.assert_allclose(lr[1:], lc[1:], rtol=1e-9)
+    np.testing.assert_allclose(lg, lr[1:], rtol=REL_LOSS)
+    assert frob_rel(Wg, Wr) < 3e-4 and frob_rel(Hg, Hr) < 3e-4
+    np.testing.assert_allclose(sg, sr, rtol=1e-12)
+    # switching back to SquareLoss on the same handle recomputes the stored residual
+    data2 = data
+    rule = cmf.PGDUpdate(data2, W0, H0)
+    rule.update_motifs(loss_func=cmf.AbsoluteLoss())
+    rule.update_feature_maps(loss_func=cmf.AbsoluteLoss())
+    rule.update_motifs()
+    l_sq = rule.update_feature_maps()
+    Wm, Hm = rule.download()
+    rule.close()
+    W, H = W0.copy(), H0.copy()
+    orule = oracle.PGDUpdate(data, W, H)
+    oracle.pgd_update_motifs(orule, data, W, H, loss="abs")
+    oracle.pgd_update_feature_maps(orule, data, W, H, loss="abs")
+    oracle.pgd_update_motifs(orule, data, W, H)
+    l_sq_o = oracle.pgd_update_feature_maps(orule, data, W, H)
+    assert abs(l_sq - l_sq_o) <= REL_LOSS * l_sq_o and frob_rel(Wm, W) < 3e-4
+
+
 def test_pgd_masked_loss_reference_test_case(cmf, oracle):
     """The one runnable entry of the reference's own test/test.jl (:15-21, :41-47): N, T, K, L = 100, 100, 10, 5,
     data from synthetic_sequences(N, T, K, L) with seed 1234, init_rand, PGDUpdate with

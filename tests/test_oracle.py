@@ -278,3 +278,43 @@ def test_pgd_masked_loss_gradient_and_reduction(oracle):
     np.testing.assert_allclose(step, -1e-6 * g01 / np.linalg.norm(g01), rtol=1e-5, atol=1e-13)
     assert rule2.cur_loss == pytest.approx(J01(W2), rel=1e-12)
     assert rule.cur_loss == pytest.approx(J(W1, H1), rel=1e-12)
+
+
+@pytest.mark.parametrize("loss,constrW,constrH,masked", [("square", "nonneg", "nonneg", False), ("square", "unitnorm", "nonneg", False),
+                                                          ("abs", "nonneg", "nonneg", False), ("square", None, "unitnorm", True),
+                                                          ("abs", "unitnorm", "nonneg", True)])
+def test_pgd_two_restatements_agree(oracle, loss, constrW, constrH, masked):
+    """PGD has two independent restatements like MU and HALS: numpy (cmf_oracle.py) and C (oracle_fit_pgd), covering
+    SquareLoss / AbsoluteLoss (pgd.jl:29-47), MaskedLoss (:58-70), both penalties (:73-89), NonnegConstraint (:92-96) and
+    UnitNormConstraint (:100-110)."""
+    N, T, K, L, iters = 14, 60, 3, 5, 6
+    rng = np.random.default_rng(3)
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=2, L=L, seed=5)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=1)
+    mask = (rng.random((N, T)) < 0.8).astype(float) if masked else None
+    Wa, Ha, la, sa = oracle.fit_pgd(data, W0, H0, max_itr=iters, penaltiesW_sq=(0.7,), penaltiesW_abs=(0.2,), penaltiesH_sq=(0.1,),
+                                    penaltiesH_abs=(0.3,), loss=loss, constrW=constrW, constrH=constrH, mask=mask)
+    Wb, Hb, lb, sb = oracle.c_fit_pgd(data, W0, H0, max_itr=iters, penW_sq=0.7, penW_abs=0.2, penH_sq=0.1, penH_abs=0.3,
+                                      loss=loss, constrW=constrW, constrH=constrH, mask=mask)
+    np.testing.assert_allclose(la, lb, rtol=1e-10)
+    np.testing.assert_allclose(Wa, Wb, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(Ha, Hb, rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(sa, sb, rtol=1e-12)  # the same accept / reject decisions
+    if constrW == "unitnorm":  # every component's motif has norm <= 1 (and some were actually scaled)
+        nrm = np.array([np.linalg.norm(Wa[k]) for k in range(K)])
+        assert np.all(nrm <= 1 + 1e-12)
+
+
+def test_unit_norm_projection_and_absolute_loss_statements(oracle):
+    """UnitNormConstraint scales only the slices (components k) whose norm exceeds 1 (pgd.jl:100-110); AbsoluteLoss is
+    the l1 norm with the sign gradient (pgd.jl:41-47)."""
+    x = np.array([[3.0, 4.0], [0.3, 0.4]])  # component 0: norm 5 -> scaled; component 1: norm 0.5 -> kept
+    y = x.copy()
+    oracle.unit_norm_projection(y)
+    np.testing.assert_allclose(y, [[0.6, 0.8], [0.3, 0.4]])
+    t = np.arange(24.0).reshape(2, 3, 4) / 10
+    z = t.copy()
+    oracle.unit_norm_projection(z)
+    for k in range(2):
+        n = np.linalg.norm(t[k])
+        np.testing.assert_allclose(z[k], t[k] / n if n > 1 else t[k])
