@@ -165,7 +165,10 @@ def main():
 
         rule = ShardedMultUpdate(data, W0, H0, device=local_rank,
                                  transport=os.environ.get("CMF_TRANSPORT", "rccl" if backend == "nccl" else "host"))
-        overlap_env = os.environ.get("CMF_ALLREDUCE_OVERLAP")  # "0" / "1" force it; default: probe both forms
+        # "0" (default): everything on one stream, the plain single all-reduce; "1": the overlap form; "probe": time both
+        # for a few steps and keep the faster.  The overlap form puts a second collective of the same communicator on a
+        # second stream; it is verified on one device only, so it is opt-in until it has run across GPUs.
+        overlap_env = os.environ.get("CMF_ALLREDUCE_OVERLAP", "0")
 
         def sync():
             import torch
