@@ -1574,12 +1574,21 @@ __device__ __forceinline__ float cmf_wave_shl1(float v, float fill)
 // lane i <- lane i+1, lane 63 <- lane 0
 __device__ __forceinline__ float cmf_wave_rol1(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xf, 0xf, false));
+    // bound_ctrl = true: every lane has a source, and with it the `old` operand is dead (no v_mov 0 per rotation)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xf, 0xf, true));
 }
 // lane i <- lane i-1, lane 0 <- lane 63
 __device__ __forceinline__ float cmf_wave_ror1(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, true));
+}
+// a * b + c as one opaque VALU instruction: keeps the SLP vectoriser from packing it with an unrelated FMA
+// (v_pk_fma_f32) whose operands arrive later
+__device__ __forceinline__ float cmf_fma_opaque(float a, float b, float c)
+{
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 __device__ __forceinline__ float cmf_lane0(float v)
 {
@@ -1601,31 +1610,56 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
     float pn = Prow[tb + 64 + lane]; // columns tb + 64 + lane: enter the window one per step
     float hreg = Hrow[tb + lane];    // H_old of columns tb + lane
     const int t_stop = q.t_end < q.Tl ? q.t_end : q.Tl;
-    // ---- fast path: whole 64-column blocks with the full window.  The window slides one lane per step
-    // (DPP wave shift), so the active column is always lane 0 and the taps never move.
-    for (; tb + 64 <= nfull && tb + 64 <= t_stop; tb += 64) {
-        const float pn2 = Prow[tb + 128 + lane];
-        const float hreg2 = Hrow[tb + 64 + lane];
-        const float creg = (hreg * nrm - q.l1) * inv_den; // (h_old*nrm - l1)/(nrm+eps+l2) per column
-        float pnr = cmf_wave_rol1(pn);                     // lane 63 holds the column that enters next (pn[0] first)
-        float hnew = 0.f;
-#pragma unroll 16
-        for (int j = 0; j < 64; ++j) {
-            const float s_p = cmf_lane0(p);
-            const float s_c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, creg), j));
-            const float s_h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg), j));
-            const float x = fmaxf(fmaf(-inv_den, s_p, s_c), 0.f); // hals.jl:152-153
-            const float d = x - s_h;
-            p = fmaf(d, g, p);                                    // hals.jl:146 on the projected state
-            p = cmf_wave_shl1(p, pnr);
-            pnr = cmf_wave_rol1(pnr);
-            hnew = cmf_wave_shl1(hnew, x);
+    // ---- fast path: whole 64-column blocks with the full window.  The window slides one lane per step (DPP wave
+    // shift), so the active column is always lane 0 and the taps never move.  The recurrence is carried in the change
+    // d_t = x_t - h_t, with the lag-1 tap taken out of the wave-wide update and the state kept in "numerator" form
+    //     V_t[i] = (c - h)_{t+i} - inv_den * w_t[i]        w_t = pending P of columns t.., without d_{t-1}'s lag-1 term
+    //     ps     = shl1(V_t)                                 (column t+64 enters at lane 63; ps does not need d_t)
+    //     d_{t+1} = max(kappa * d_t + ps[0], -h_{t+1})       kappa = -inv_den * g[1]          <- the chain: FMA, MAX
+    //     V_{t+1} = ps + d_t * gsn                           gsn[i] = -inv_den * g[i+1] (i >= 1), gsn[0] = 0
+    // so the chain from one column to the next is one FMA and one MAX on lane 0; the v_readfirstlane of d, the wave-wide
+    // update and the shifts trail it by a step.  The direct form (readfirstlane(p), FMA, MAX, SUB, wave-wide FMA, shift:
+    // everything in the chain) cost ~88 cycles per column.
+    if (tb + 64 <= nfull && tb + 64 <= t_stop) {
+        const float g1 = (L > 1) ? gk[1] : 0.f;
+        const float kappa = -inv_den * g1;
+        const float gsn = (lane >= 1 && lane + 1 < L) ? -inv_den * gk[lane + 1] : 0.f;
+        float w = p;         // complete on entry (a hand-over or the initial P): the previous column's change is in it
+        float dprev = 0.f;   // lane 0: change of the previous column whose lag-1 term is still missing from the state
+        float creg = (hreg * nrm - q.l1) * inv_den;      // (h_old*nrm - l1)/(nrm+eps+l2) per column
+        float V = fmaf(-inv_den, w, creg - hreg);
+        for (; tb + 64 <= nfull && tb + 64 <= t_stop; tb += 64) {
+            const float pn2 = Prow[tb + 128 + lane];
+            const float hreg2 = Hrow[tb + 64 + lane];
+            const float creg2 = (hreg2 * nrm - q.l1) * inv_den;
+            float vnr = cmf_wave_rol1(fmaf(-inv_den, pn, creg2 - hreg2)); // lane 63 holds the column that enters next
+            float mhrot = -hreg;                                          // lane 0 = -h of the column being swept
+            float dvec = 0.f;                                             // collects the changes of the block's columns
+            // column 0 of the block: its rh is lane 0 of V itself
+            float d;
+            asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(fmaf(kappa, dprev, V)), "v"(mhrot));
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                const float ps = cmf_wave_shl1(V, vnr);        // shl1(V_j): lane 0 = rh of column j+1
+                const float s_d = cmf_lane0(d);
+                V = fmaf(s_d, gsn, ps);                        // hals.jl:146 on the projected state, lags >= 2
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(dvec) : "s"(s_d), "n"(j)); // lane j <- d_j
+                mhrot = cmf_wave_rol1(mhrot);
+                vnr = cmf_wave_rol1(vnr);
+                dprev = d;
+                if (j + 1 < 64) // hals.jl:152-153 as a change: x - h_old = max(q, 0) - h_old = max(q - h_old, -h_old)
+                    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(fmaf(kappa, dprev, ps)), "v"(mhrot));
+            }
+            const float hnew = hreg + dvec;
+            Hrow[tb + lane] = hnew;
+            q.H[(size_t)(q.PADL + tb + lane) * q.K32 + k] = hnew;
+            q.D[tb + lane] = dvec;
+            pn = pn2;
+            hreg = hreg2;
+            creg = creg2;
         }
-        Hrow[tb + lane] = hnew;
-        q.H[(size_t)(q.PADL + tb + lane) * q.K32 + k] = hnew;
-        q.D[tb + lane] = hnew - hreg;
-        pn = pn2;
-        hreg = hreg2;
+        // back to the complete pending values: w = ((c - h) - V) / inv_den; the last column's lag-1 term goes to lane 0
+        p = ((creg - hreg) - V) * (nrm + CMF_EPS_F + q.l2) + ((lane == 0) ? cmf_lane0(dprev) * g1 : 0.f);
     }
     // ---- generic path (right-edge columns, hals.jl:136, and what is left of the last block): lane j
     // holds the column t' with t' % 64 == j; the taps rotate instead of the window.
