@@ -354,12 +354,14 @@ def main():
     if rank == 0 and alg == "hals":
         # The dominant part of a HALS iteration is the K*T strictly ordered H entry updates (hals.jl:121-154), run as a
         # software pipeline over the rows (hals_h_stage_kernel).  Its bound is dependency latency, not MFMA or HBM: entry
-        # (k, t) needs (k, t-1) and the push of (k-1, t+L-1), so the critical path is T + (K-1)(L-1) dependent steps of
-        # ~88 cycles (2 v_readlane + 5 dependent VALU ops + the DPP shifts: DESIGN.md 4b).  achieved = critical-path steps
-        # per second over the measured pipeline span; peak = one step per 88 cycles at 2.4 GHz.
+        # (k, t) needs (k, t-1) and the push of (k-1, t+L-1), so the critical path is T + (K-1)(L-1) dependent steps.  A
+        # step of the sweep is 9 single-wave instructions whose chain is one FMA and one MAX; in isolation it issues in
+        # 43 cycles (tools/valu_latency.hip, profiles/).  achieved = critical-path steps per second over the measured
+        # pipeline span; peak = one step per 43 cycles at 2.4 GHz.  What separates them is structural: two stages of
+        # pipeline fill per row and ~3 us of launch + prologue per stage.
         pipe_ms, n_pipe = hals_spans.get("hals_h_pipeline", (0.0, 0))
         wsw_ms, _ = hals_spans.get("hals_w_sweep", (0.0, 0))
-        STEP_CYCLES, CLK = 88.0, 2.4e9
+        STEP_CYCLES, CLK = 43.0, 2.4e9
         crit_steps = T + (K - 1) * (L - 1)
         peak_steps = CLK / STEP_CYCLES
         ach_steps = crit_steps / (pipe_ms * 1e-3) if pipe_ms else 0.0

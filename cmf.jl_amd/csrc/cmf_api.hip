@@ -1411,6 +1411,9 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
     // the last row's last segment, +1 for the pushes of the last sweeps (no-ops for the last row)
     const int nstages = (d.Tl + sp.skew * (d.K - 1) + h->hals_seg - 1) / h->hals_seg + sp.lag * (d.K - 1) + 1;
     dim3 grid(d.K + d.K * sp.CB, std::max(1, d.K - 1));
+    if (const char *dbg = getenv("CMF_HALS_DEBUG")) { // timing experiments only (results are wrong): "nopush" launches the sweeps alone
+        if (std::strcmp(dbg, "nopush") == 0) grid = dim3(d.K, 1);
+    }
     ProfScope prof_(h, PROF_HALS_PIPE); // the whole row pipeline (nstages launches) as one timed span
     for (int stage = 0; stage < nstages; ++stage) {
         sp.stage = stage;
