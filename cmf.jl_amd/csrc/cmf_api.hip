@@ -177,13 +177,7 @@ static int dalloc_zero(T **p, size_t n)
 }
 
 // the C2 kernel adds CG consecutive time chunks inside a workgroup: it writes nchunks / CG slabs
-static int hxt_cg(int nchunks)
-{
-    static const int cap = getenv("CMF_HXT_CG") ? atoi(getenv("CMF_HXT_CG")) : 4;
-    int cg = nchunks % 4 == 0 ? 4 : (nchunks % 2 == 0 ? 2 : 1);
-    while (cg > cap && cg > 1) cg /= 2;
-    return cg;
-}
+static int hxt_cg(int nchunks) { return nchunks % 4 == 0 ? 4 : (nchunks % 2 == 0 ? 2 : 1); }
 static int hxt_nslabs(int nchunks) { return nchunks / hxt_cg(nchunks); }
 
 static const int kHxtLP[] = {1, 2, 3, 4, 5, 6, 8}; // 2*LP*16 accumulator registers must fit the 256 AGPRs

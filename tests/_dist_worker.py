@@ -53,6 +53,16 @@ def main():
     losses = [rule.compute_loss()]
     if mode == "iterate":
         losses += list(rule.iterate(iters, **kw))
+    elif mode == "fit_timed" and engine == "hip":
+        # a finite max_time takes cmf_fit's synchronous loop, in which every rank follows rank 0's clock (an all-gather
+        # of the iteration's duration) so that all ranks leave the loop together
+        lh, th, _ = rule.fit_native(iters, 1e6, False, 3, 1e-4, False, **kw)
+        assert len(lh) == iters + 1 and np.all(np.diff(th) > 0)
+        allth = [None] * dist.get_world_size()
+        dist.all_gather_object(allth, [float(x) for x in th])
+        assert all(t == allth[0] for t in allth), "ranks disagree on time_hist"
+        np.testing.assert_allclose(lh[0], losses[0], rtol=1e-12)
+        losses = list(lh)
     elif mode == "fit" and engine == "hip":
         lh, th, _ = rule.fit_native(iters, np.inf, False, 3, 1e-4, False, **kw)
         np.testing.assert_allclose(lh[0], losses[0], rtol=1e-12)

@@ -228,7 +228,8 @@ def test_group_errors():
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,N,T,K,L,reg,overlap,mode", [(2, 130, 900, 32, 20, 0, False, "calls"), (3, 40, 333, 5, 10, 1, False, "iterate"),
-                                                             (3, 70, 517, 32, 20, 1, True, "iterate"), (2, 65, 256, 64, 33, 0, False, "fit")])
+                                                             (3, 70, 517, 32, 20, 1, True, "iterate"), (2, 65, 256, 64, 33, 0, False, "fit"),
+                                                             (2, 48, 300, 4, 8, 1, False, "fit_timed")])
 def test_sharded_processes_host_callbacks(oracle, tmp_path, world, N, T, K, L, reg, overlap, mode):
     """Ranks share GPU 0; the library's collectives go through its host-callback transport (gloo)."""
     iters = 6
