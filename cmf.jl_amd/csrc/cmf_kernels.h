@@ -120,8 +120,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
         const int voff = (4 * h * Np + i) * 4;
         float lsum = 0.f;
         // the body twice, selected by one wave-uniform branch: only the last row of tiles pays for the row test
-        auto body = [&](auto partial_rows) {
+        auto body = [&](auto partial_rows, auto abs_loss) {
             constexpr bool PARTIAL = decltype(partial_rows)::value;
+            constexpr bool ABS = decltype(abs_loss)::value; // AbsoluteLoss (residual modes only): one wave-uniform branch, not a select per element
             // all operand loads of a group first (the W registers are dead by now), then arithmetic and stores: a load
             // queued behind stores would wait for them on the in-order vmcnt.  A group is the whole 64 x 64 sub-tile,
             // or one 32 x 32 block when the mask doubles the operands (the registers do not stretch further).
@@ -152,18 +153,27 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
                                 float d = MASKED ? (v - dv[ti][ni][r]) * mv[ti][ni][r] : v - dv[ti][ni][r];
                                 if (MODE == 0 || MODE == 3) cmf_bstore(v, ro, voff, so);
                                 if (RESID) {
-                                    const float sg = (v > dv[ti][ni][r]) ? 1.f : ((v < dv[ti][ni][r]) ? -1.f : 0.f);
-                                    cmf_bstore(p.loss_abs ? (MASKED ? sg * mv[ti][ni][r] : sg) : d, ro, voff, so);
+                                    if (ABS) {
+                                        const float sg = (v > dv[ti][ni][r]) ? 1.f : ((v < dv[ti][ni][r]) ? -1.f : 0.f);
+                                        cmf_bstore(MASKED ? sg * mv[ti][ni][r] : sg, ro, voff, so);
+                                    } else {
+                                        cmf_bstore(d, ro, voff, so);
+                                    }
                                 }
                                 if (LOSS) {
                                     if (PARTIAL) d = ((gt + ti) * 32 + cmf_crow(r, h) < rows) ? d : 0.f;
-                                    lsum = (RESID && p.loss_abs) ? lsum + fabsf(d) : fmaf(d, d, lsum);
+                                    lsum = ABS ? lsum + fabsf(d) : fmaf(d, d, lsum);
                                 }
                             }
                 }
         };
-        if (rows == 64) body(std::false_type{});
-        else body(std::true_type{});
+        if (RESID && p.loss_abs) {
+            if (rows == 64) body(std::false_type{}, std::true_type{});
+            else body(std::true_type{}, std::true_type{});
+        } else {
+            if (rows == 64) body(std::false_type{}, std::false_type{});
+            else body(std::true_type{}, std::false_type{});
+        }
         if (LOSS) {
             // wave sum on the DPP network (row shifts, then the two row broadcasts): the total lands in lane 63.
             // 4096 squares per wave in fp32, fp64 from the per-tile partials on (fixed order: deterministic)
@@ -193,27 +203,32 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
         const __amdgpu_buffer_rsrc_t rm = cmf_rsrc(p.mask + origin, bytes);
         const int voff = (4 * h * TP + i) * 4;
         const bool full = (tw + 64 <= p.T_store); // wave-uniform
+        auto tbody = [&](auto abs_loss) {
+            constexpr bool ABS = decltype(abs_loss)::value;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                if (full || tw + ti * 32 + i < p.T_store) {
-                    float dv[16], mv[16];
+                for (int ti = 0; ti < 2; ++ti) {
+                    if (full || tw + ti * 32 + i < p.T_store) {
+                        float dv[16], mv[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int so = ((ni * 32 + (r & 3) + 8 * (r >> 2)) * TP + ti * 32) * 4;
-                        dv[r] = (MODE != 1) ? cmf_bload(rd, voff, so) : 0.f;
-                        mv[r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
-                    }
+                        for (int r = 0; r < 16; ++r) {
+                            const int so = ((ni * 32 + (r & 3) + 8 * (r >> 2)) * TP + ti * 32) * 4;
+                            dv[r] = (MODE != 1) ? cmf_bload(rd, voff, so) : 0.f;
+                            mv[r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
+                        }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int so = ((ni * 32 + (r & 3) + 8 * (r >> 2)) * TP + ti * 32) * 4;
-                        float d = acc[ni][ti][r] - dv[r];
-                        if (MODE != 1 && p.loss_abs) d = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-                        cmf_bstore(MASKED ? d * mv[r] : d, ro, voff, so);
+                        for (int r = 0; r < 16; ++r) {
+                            const int so = ((ni * 32 + (r & 3) + 8 * (r >> 2)) * TP + ti * 32) * 4;
+                            float d = acc[ni][ti][r] - dv[r];
+                            if (ABS) d = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+                            cmf_bstore(MASKED ? d * mv[r] : d, ro, voff, so);
+                        }
                     }
                 }
-            }
+        };
+        if (MODE != 1 && p.loss_abs) tbody(std::true_type{});
+        else tbody(std::false_type{});
     }
 }
 
@@ -554,6 +569,7 @@ __device__ __forceinline__ void conv_epilogue_block(const f32x16 &acc, const Con
     constexpr bool LOSS = (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6);
     constexpr bool RESID = (MODE == 4 || MODE == 6);
     constexpr bool MASKED = (MODE == 6 || MODE == 7);
+    const bool abs_loss = (MODE >= 4) && p.loss_abs; // wave-uniform; a quarter tile's 16-element epilogue takes the selects
     if (!CONV_TRANSPOSED(MODE)) {
         int rows = p.T_store - tb;
         rows = rows < 0 ? 0 : (rows > 32 ? 32 : rows);
@@ -579,11 +595,11 @@ __device__ __forceinline__ void conv_epilogue_block(const f32x16 &acc, const Con
             if (MODE == 0 || MODE == 3) cmf_bstore(v, ro, voff, so);
             if (RESID) {
                 const float sg = (v > dv[r]) ? 1.f : ((v < dv[r]) ? -1.f : 0.f);
-                cmf_bstore(p.loss_abs ? (MASKED ? sg * mv[r] : sg) : d, ro, voff, so);
+                cmf_bstore(abs_loss ? (MASKED ? sg * mv[r] : sg) : d, ro, voff, so);
             }
             if (LOSS) {
                 d = (cmf_crow(r, h) < rows) ? d : 0.f;
-                lsum = (RESID && p.loss_abs) ? lsum + fabsf(d) : fmaf(d, d, lsum);
+                lsum = abs_loss ? lsum + fabsf(d) : fmaf(d, d, lsum);
             }
         }
         if (LOSS) {
@@ -615,7 +631,7 @@ __device__ __forceinline__ void conv_epilogue_block(const f32x16 &acc, const Con
             for (int r = 0; r < 16; ++r) {
                 const int so = (((r & 3) + 8 * (r >> 2)) * TP) * 4;
                 float d = acc[r] - dv[r];
-                if (MODE != 1 && p.loss_abs) d = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+                if (abs_loss) d = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
                 cmf_bstore(MASKED ? d * mv[r] : d, ro, voff, so);
             }
         }
