@@ -462,8 +462,7 @@ def test_pgd_unit_norm_constraint(cmf, oracle, N, T, K, L, constrW, constrH):
     assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
     np.testing.assert_allclose(sg, sr, rtol=1e-12)
     if constrW == "unitnorm":
-        assert max(np.linalg.norm(Wg[k]) for k in range(K)) <= 1 + 1e-5
-        assert Wg.min() < 0 or True  # no clamp under this constraint: negative entries are legal
+        assert max(np.linalg.norm(Wg[k]) for k in range(K)) <= 1 + 1e-5  # (no clamp under this constraint: negative entries are legal)
     if constrH == "unitnorm":
         assert max(np.linalg.norm(Hg[k]) for k in range(K)) <= 1 + 1e-5
 
