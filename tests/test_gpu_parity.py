@@ -183,6 +183,39 @@ def test_early_stop_eval_mode_and_native_loop(cmf, oracle):
     assert th[0] == 0.0 and not early and np.all(np.diff(th) > 0)
 
 
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_iterate_is_the_call_by_call_loop(cmf, oracle, devices):
+    """cmf_iterate (losses read one iteration late, loss reduction riding on the next slab sum / all-reduce) is bit for
+    bit n x (update_motifs!; update_feature_maps!) -- with and without eval_mode, for n = 0, 1 and several, on one GPU
+    and on a 3-shard group -- and the options that change the launch sequence keep it so."""
+    data, _, _ = oracle.c_gen_synthetic(N=70, T=517, K=3, L=10, seed=21)
+    W0, H0 = oracle.c_init_rand(data, L=10, K=5, seed=3)
+    kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2)
+    mk = (lambda: cmf.MultUpdate(data, W0, H0, devices=devices)) if devices else (lambda: cmf.MultUpdate(data, W0, H0))
+    for eval_mode in (False, True):
+        for reuse in (1, 0):
+            a, b = mk(), mk()
+            a.set_option("reuse_est", reuse)
+            b.set_option("reuse_est", reuse)
+            assert len(a.iterate(0, eval_mode=eval_mode, **kw)) == 0
+            la = list(a.iterate(1, eval_mode=eval_mode, **kw)) + list(a.iterate(5, eval_mode=eval_mode, **kw))
+            lb = []
+            for _ in range(6):
+                if not eval_mode:
+                    b.update_motifs(l1W=kw["l1W"], l2W=kw["l2W"])
+                lb.append(b.update_feature_maps(l1H=kw["l1H"], l2H=kw["l2H"]))
+            np.testing.assert_array_equal(la, lb)
+            (Wa, Ha), (Wb, Hb) = a.download(), b.download()
+            np.testing.assert_array_equal(Wa, Wb)
+            np.testing.assert_array_equal(Ha, Hb)
+            # a call-by-call step right after a batch sees consistent state (nothing left pending)
+            a.update_motifs()
+            b.update_motifs()
+            assert a.update_feature_maps() == b.update_feature_maps()
+            a.close()
+            b.close()
+
+
 def test_deterministic(cmf, oracle):
     """Slab reductions instead of atomics: two runs agree bit for bit."""
     data, _, _ = oracle.c_gen_synthetic(N=130, T=1500, K=3, L=20, seed=4)
