@@ -203,32 +203,36 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
         const __amdgpu_buffer_rsrc_t rm = cmf_rsrc(p.mask + origin, bytes);
         const int voff = (4 * h * TP + i) * 4;
         const bool full = (tw + 64 <= p.T_store); // wave-uniform
-        auto tbody = [&](auto abs_loss) {
-            constexpr bool ABS = decltype(abs_loss)::value;
+        const bool abs_t = (MODE != 1) && p.loss_abs; // wave-uniform; MODE 1 (the MU path) compiles to the plain store loop
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int ti = 0; ti < 2; ++ti) {
-                    if (full || tw + ti * 32 + i < p.T_store) {
-                        float dv[16], mv[16];
+            for (int ti = 0; ti < 2; ++ti) {
+                if (full || tw + ti * 32 + i < p.T_store) {
+                    float dv[16], mv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int so = ((ni * 32 + (r & 3) + 8 * (r >> 2)) * TP + ti * 32) * 4;
+                        dv[r] = (MODE != 1) ? cmf_bload(rd, voff, so) : 0.f;
+                        mv[r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
+                    }
+                    if (MODE != 1 && abs_t) { // AbsoluteLoss: the stored quantity is the gradient sign(est - data)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int so = ((ni * 32 + (r & 3) + 8 * (r >> 2)) * TP + ti * 32) * 4;
-                            dv[r] = (MODE != 1) ? cmf_bload(rd, voff, so) : 0.f;
-                            mv[r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
-                        }
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int so = ((ni * 32 + (r & 3) + 8 * (r >> 2)) * TP + ti * 32) * 4;
-                            float d = acc[ni][ti][r] - dv[r];
-                            if (ABS) d = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+                            const float e = acc[ni][ti][r] - dv[r];
+                            const float d = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
                             cmf_bstore(MASKED ? d * mv[r] : d, ro, voff, so);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int so = ((ni * 32 + (r & 3) + 8 * (r >> 2)) * TP + ti * 32) * 4;
+                            cmf_bstore(MASKED ? (acc[ni][ti][r] - dv[r]) * mv[r] : acc[ni][ti][r] - dv[r], ro, voff, so);
                         }
                     }
                 }
-        };
-        if (MODE != 1 && p.loss_abs) tbody(std::true_type{});
-        else tbody(std::false_type{});
+            }
     }
 }
 
