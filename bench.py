@@ -163,7 +163,9 @@ def main():
     else:
         from cmf_jl_amd.sharded import ShardedMultUpdate
 
-        rule = ShardedMultUpdate(data, W0, H0, device=local_rank,
+        # in-library RCCL; if its communicator cannot be formed on some rank, all ranks agree to take the host-collective
+        # transport (torch.distributed on staged buffers) so that the run still measures something -- reported in `comm`
+        rule = ShardedMultUpdate(data, W0, H0, device=local_rank, fallback_to_host=True,
                                  transport=os.environ.get("CMF_TRANSPORT", "rccl" if backend == "nccl" else "host"))
         # "0" (default): everything on one stream, the plain single all-reduce; "1": the overlap form; "probe": time both
         # for a few steps and keep the faster.  The overlap form puts a second collective of the same communicator on a
@@ -305,7 +307,8 @@ def main():
             "whole_iteration_mfma_frac": (F_iter * (6.0 / 7.0 if alg == "mult" else 1.0)) * iters_per_s / (world * PEAK_FP32_MFMA_TFLOPS * 1e12),
             "whole_iteration_mfma_frac_reference_formulation_equivalent": F_iter * iters_per_s / (world * PEAK_FP32_MFMA_TFLOPS * 1e12),
             "sustained": sustained,
-            "comm": (rule.comm_info() if world > 1 else None),
+            "comm": (rule.comm_info() + (f" FALLBACK from rccl: {rule.transport_fallback}" if rule.transport_fallback else "")
+                     if world > 1 else None),
         }
 
     # ---- roofline of the dominant kernel = the class with the largest share of the timed region; durations from

@@ -51,7 +51,7 @@ class ShardedMultUpdate(MultUpdate):
     ``data``, ``W``, ``H`` are the GLOBAL arrays (every rank passes the same ones; each keeps only its block).
     The rule methods have the single-GPU rule's signatures and return the global loss on every rank."""
 
-    def __init__(self, data, W, H, device=None, group=None, overlap=False, transport=None):
+    def __init__(self, data, W, H, device=None, group=None, overlap=False, transport=None, fallback_to_host=False):
         import torch
         import torch.distributed as dist
 
@@ -84,8 +84,28 @@ class ShardedMultUpdate(MultUpdate):
         self._h = ctypes.c_void_p()
         data_local = farr(data[:, t0:t1 + halo_r])
         check(lib.cmf_create_shard(ctypes.byref(self._h), self.device, N, t1 - t0, K, L, ptr(data_local), t0, T))
+        self.transport_fallback = None
         try:
-            self._attach()
+            if self.transport == "rccl" and fallback_to_host:
+                # all ranks must end up on the same transport: agree on the outcome of the RCCL attach, and if any rank
+                # failed, every rank rebuilds its shard and takes the host-collective transport instead
+                err = None
+                try:
+                    self._attach()
+                except Exception as e:  # noqa: BLE001 - reported below
+                    err = repr(e)
+                flags = [None] * self.world
+                dist.all_gather_object(flags, err, group=group)
+                bad = [f for f in flags if f]
+                if bad:
+                    self.transport_fallback = bad[0]
+                    lib.cmf_destroy(self._h)
+                    self._h = ctypes.c_void_p()
+                    check(lib.cmf_create_shard(ctypes.byref(self._h), self.device, N, t1 - t0, K, L, ptr(data_local), t0, T))
+                    self.transport = "host"
+                    self._attach()
+            else:
+                self._attach()
             check(lib.cmf_set_factors(self._h, ptr(W), ptr(farr(H[:, t0:t1]))))
             if overlap:
                 self.set_option("allreduce_overlap", 1)
@@ -115,10 +135,18 @@ class ShardedMultUpdate(MultUpdate):
             return
         torch, world, pg = self.torch, self.world, self.pg
 
+        on_device = self.backend == "nccl"  # torch's RCCL backend only takes device tensors: bounce through the GPU
+        dev = torch.device("cuda", self.device) if on_device else None
+
         def allreduce(_user, buf, count):
             try:
                 t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(count,)))
-                dist.all_reduce(t, group=pg)
+                if on_device:
+                    td = t.to(dev)
+                    dist.all_reduce(td, group=pg)
+                    t.copy_(td)
+                else:
+                    dist.all_reduce(t, group=pg)
                 return 0
             except Exception as e:  # an exception must not unwind through the C frames
                 print(f"cmf all-reduce callback failed: {e!r}", flush=True)
@@ -128,7 +156,12 @@ class ShardedMultUpdate(MultUpdate):
             try:
                 s = torch.from_numpy(np.ctypeslib.as_array(send, shape=(count,)))
                 r = torch.from_numpy(np.ctypeslib.as_array(recv, shape=(world * count,)))
-                dist.all_gather_into_tensor(r, s.clone(), group=pg)
+                if on_device:
+                    rd = torch.empty(world * count, dtype=torch.float32, device=dev)
+                    dist.all_gather_into_tensor(rd, s.to(dev), group=pg)
+                    r.copy_(rd)
+                else:
+                    dist.all_gather_into_tensor(r, s.clone(), group=pg)
                 return 0
             except Exception as e:
                 print(f"cmf all-gather callback failed: {e!r}", flush=True)

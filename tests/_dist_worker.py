@@ -46,8 +46,9 @@ def main():
         from cmf_jl_amd.sharded import ShardedMultUpdate
 
         rule = ShardedMultUpdate(data, W0, H0, device=0, overlap=overlap,
-                                 transport=os.environ.get("CMF_TEST_TRANSPORT") or None)
-        info = rule.comm_info()
+                                 transport=os.environ.get("CMF_TEST_TRANSPORT") or None,
+                                 fallback_to_host=os.environ.get("CMF_TEST_FALLBACK", "0") == "1")
+        info = rule.comm_info() + (" FALLBACK" if rule.transport_fallback else "")
         want = float(np.linalg.norm(data))
         assert abs(rule.data_norm - want) <= 1e-9 * want, f"rank {rank}: data_norm {rule.data_norm} != {want}"
     losses = [rule.compute_loss()]

@@ -28,13 +28,15 @@ def _free_port():
     return p
 
 
-def run_ranks(world, engine, out, N, T, K, L, iters, reg, timeout=300, backend="gloo", overlap=False, mode="calls", transport=""):
+def run_ranks(world, engine, out, N, T, K, L, iters, reg, timeout=300, backend="gloo", overlap=False, mode="calls", transport="",
+              fallback=False):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", CMF_TEST_BACKEND=backend,
-                   CMF_TEST_OVERLAP="1" if overlap else "0", CMF_TEST_MODE=mode, CMF_TEST_TRANSPORT=transport)
+                   CMF_TEST_OVERLAP="1" if overlap else "0", CMF_TEST_MODE=mode, CMF_TEST_TRANSPORT=transport,
+                   CMF_TEST_FALLBACK="1" if fallback else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), engine, out,
                                        str(N), str(T), str(K), str(L), str(iters), str(int(reg))],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -255,6 +257,20 @@ def test_sharded_process_rccl_single_rank(oracle, tmp_path, backend, mode):
     np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
     assert frob_rel(got["W"], Wr) < 1e-4
     assert frob_rel(got["H"], Hr) < 1e-4
+
+
+@pytest.mark.gpu
+def test_sharded_processes_fall_back_to_host_transport_together(oracle, tmp_path):
+    """Two ranks on ONE GPU ask for the RCCL transport: RCCL refuses (two ranks of a communicator cannot share a device),
+    every rank learns of it through the process group, and all of them rebuild their shard on the host-collective
+    transport -- the agreement bench.py relies on at N > 1 so that a failed communicator costs speed, not the run."""
+    N, T, K, L, iters = 65, 400, 5, 10, 4
+    out = str(tmp_path / "res.npz")
+    got = run_ranks(2, "hip", out, N, T, K, L, iters, 0, mode="iterate", transport="rccl", fallback=True)
+    assert "transport=callbacks" in str(got["info"]) and "FALLBACK" in str(got["info"])
+    _, _, _, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, 0)
+    np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
+    assert frob_rel(got["W"], Wr) < 1e-4 and frob_rel(got["H"], Hr) < 1e-4
 
 
 @pytest.mark.gpu
