@@ -22,6 +22,7 @@
 // library stages the buffers through pinned host memory and the host performs the collective, e.g. gloo in the tests).
 #pragma once
 #include <dlfcn.h>
+#include <mutex>
 #include <rccl/rccl.h>
 
 // ---- RCCL, bound at run time --------------------------------------------------------------------------------------
@@ -46,6 +47,8 @@ static RcclApi g_rccl;
 
 static int rccl_load()
 {
+    static std::mutex mu; // handles are per-thread, but this table is per process
+    std::lock_guard<std::mutex> lock(mu);
     if (g_rccl.dl) return CMF_OK;
     const char *env = getenv("CMF_RCCL_LIB");
     const char *cands[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
