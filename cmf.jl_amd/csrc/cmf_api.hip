@@ -448,7 +448,7 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     // measured at config 2 (tools/time_kernels.py): the one-wave kernel wins for the epilogues that read data
     // (0.924 vs 0.931 ms loss only, 0.936 vs 0.943 ms loss + store), the 128 x 128 tiles for the store-only ones
     // (0.911 vs 0.932 ms est, 0.910 vs 0.924 ms est')
-    constexpr bool reads_data = (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6);
+    constexpr bool reads_data = (MODE >= 2); // every mode but the two plain stores loads a data (and mask) tile in its epilogue
     // The one-wave kernel can cut the tiles of its thin last round into quarter tiles (conv3_kernel).  That pays when
     // the remainder is small against the 12 wave slots per CU -- short shards: 3136 tiles on 3072 slots at T/8 -- and
     // then decides the variant for every mode; a remainder above 3 tiles per CU is left as whole tiles.
