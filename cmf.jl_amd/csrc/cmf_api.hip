@@ -91,7 +91,8 @@ struct cmf_handle_s {
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
     int conv_variant = 0;   // K % 32 == 0: 3 = one-wave workgroups (conv3_kernel), 2 = 128 x 128 tiles (conv2_kernel), 0 = per mode
     int conv_partials = 1;  // loss partials written by the last conv launch
-    bool conv_split = true; // option "conv_split": quarter tiles for the thin last round of the one-wave conv kernel
+    int conv_split = 1;     // option "conv_split": 0 = whole tiles only, 1 = quarter / sixteenth tiles for the thin last round of the
+                            // one-wave conv kernel, 4 = quarter tiles only
     int n_cu = 256;
 
     // HALS scratch (allocated on first use)
@@ -147,7 +148,7 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H);
 static size_t n_partial(const cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
-    size_t n = (size_t)(16 * h->conv_gx) * (size_t)std::max(h->conv_gy, h->conv_gy_ext); // conv loss partials (64 x 64 tiles, or their quarters)
+    size_t n = (size_t)(64 * h->conv_gx) * (size_t)std::max(h->conv_gy, h->conv_gy_ext); // conv loss partials (64 x 64 tiles, their quarters or sixteenths)
     n = std::max(n, (size_t)(d.Np / 64) * d.KB * d.L);                                 // PGD gradW norm partials
     n = std::max(n, (size_t)((d.Tl + 63) / 64) * d.KB);                                // PGD gradH norm partials
     n = std::max(n, 2 * (((size_t)d.Tl * d.K32 + 1023) / 1024));                       // Gram-form loss partials
@@ -459,8 +460,10 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     const int variant = h->conv_variant ? h->conv_variant : ((reads_data || split) ? 3 : 2);
     if (d.K % 32 == 0 && variant == 3) {
         const int n_full = split ? tiles3 - rem3 : tiles3;
-        grid = dim3(n_full + 4 * (tiles3 - n_full));
-        hipLaunchKernelGGL((conv3_kernel<MODE>), grid, dim3(64), 0, h->stream, p, gx3, n_full);
+        // quarter tiles reach every SIMD only from one remainder tile per CU on; below that, sixteenth tiles
+        const int pieces = (split && rem3 < h->n_cu && h->conv_split != 4) ? 16 : 4;
+        grid = dim3(n_full + pieces * (tiles3 - n_full));
+        hipLaunchKernelGGL((conv3_kernel<MODE>), grid, dim3(64), 0, h->stream, p, gx3, n_full, pieces);
     } else if (d.K % 32 == 0) hipLaunchKernelGGL((conv2_kernel<MODE>), grid, block, 0, h->stream, p);
     else hipLaunchKernelGGL((conv_kernel<MODE, 0>), grid, block, 0, h->stream, p);
     h->conv_partials = (int)(grid.x * grid.y);
@@ -796,7 +799,7 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         return hals_ensure(h);
     }
     if (std::strcmp(name, "conv_split") == 0) { // 0 = never cut the one-wave conv kernel's last round into quarter tiles
-        h->conv_split = value != 0;
+        h->conv_split = value;
         h->est_kind = 0;
         return CMF_OK;
     }

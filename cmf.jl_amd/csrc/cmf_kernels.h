@@ -733,20 +733,167 @@ __device__ __forceinline__ void conv3_quarter(const ConvParams &p, float *Hs, in
     conv_epilogue_block<MODE>(acc, p, t0, n0, i, h, lane, pidx);
 }
 
-// grid: n_full + 4 * (tiles - n_full) one-wave workgroups.  Workgroups [0, n_full) are whole 64 x 64 tiles (tile index
-// = n tile fastest); the remaining tiles -- the part of the grid that would otherwise run as a thin last round on a
-// few SIMDs while the rest of the chip idles (3136 tiles on 3072 wave slots at a T/8 shard) -- are cut into four
-// 32 x 32 quarter tiles each, dispatched last, so that the tail is spread over four times as many SIMDs.
+// ---- sixteenth tiles: one wave, one 16 (t) x 16 (n) block on v_mfma_f32_16x16x4_f32 -----------------------------------
+// When the remainder of a launch is so small that even its quarter tiles would leave most SIMDs idle (64 tiles = 256
+// quarters on 1024 SIMDs at a T/8 shard), it is cut sixteen ways instead: 1024 pieces of a quarter of the work each.
+// Operand maps (16x16x4 f32): lane = 16*kq + j.  A: A[row j][k kq], B: B[k kq][col j], C/D: col = j, row = 4*kq + reg.
+// The k sum runs four at a time here (two at a time in the 32x32x2 kernels), so a sixteenth tile's est differs from the
+// whole-tile path's at rounding level; every launch with the same shape cuts the same tiles, so results stay reproducible.
+#define CONV16_STRIDE 80 // k rows 80 floats apart: the four k rows a ds_read touches land in different bank groups
 template <int MODE>
-__global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p, int gx, int n_full)
+__device__ __forceinline__ void conv16_epilogue(const f32x4 &acc, const ConvParams &p, int tb, int nb, int j, int kq, int lane, int pidx)
+{
+    const int Np = p.Np, TP = p.TP;
+    constexpr bool LOSS = (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6);
+    constexpr bool RESID = (MODE == 4 || MODE == 6);
+    constexpr bool MASKED = (MODE == 6 || MODE == 7);
+    const bool abs_loss = (MODE >= 4) && p.loss_abs;
+    if (!CONV_TRANSPOSED(MODE)) { // acc[r]: t = tb + 4*kq + r, n = nb + j
+        int rows = p.T_store - tb;
+        rows = rows < 0 ? 0 : (rows > 16 ? 16 : rows);
+        const size_t origin = (size_t)(p.PADL + tb) * Np + nb;
+        const size_t bytes = rows ? ((size_t)(rows - 1) * Np + 16) * 4 : 0;
+        const __amdgpu_buffer_rsrc_t ro = cmf_rsrc(p.out + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rd = cmf_rsrc(p.data + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rm = cmf_rsrc(p.mask + origin, bytes);
+        const int voff = (4 * kq * Np + j) * 4;
+        float dv[4], mv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dv[r] = LOSS ? cmf_bload(rd, voff, r * Np * 4) : 0.f;
+            mv[r] = MASKED ? cmf_bload(rm, voff, r * Np * 4) : 1.f;
+        }
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[r];
+            float d = MASKED ? (v - dv[r]) * mv[r] : v - dv[r];
+            if (MODE == 0 || MODE == 3) cmf_bstore(v, ro, voff, r * Np * 4);
+            if (RESID) {
+                const float sg = (v > dv[r]) ? 1.f : ((v < dv[r]) ? -1.f : 0.f);
+                cmf_bstore(abs_loss ? (MASKED ? sg * mv[r] : sg) : d, ro, voff, r * Np * 4);
+            }
+            if (LOSS) {
+                d = (4 * kq + r < rows) ? d : 0.f;
+                lsum = abs_loss ? lsum + fabsf(d) : fmaf(d, d, lsum);
+            }
+        }
+        if (LOSS) {
+            float x = lsum;
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, false)); // row_shr:1
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, false)); // row_shr:2
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, false)); // row_shr:4
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, false)); // row_shr:8
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false)); // row_bcast:15
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false)); // row_bcast:31
+            if (lane == 63) p.partial[pidx] = (double)x;
+        }
+    } else { // acc[r]: n = nb + 4*kq + r, t = tb + j
+        const size_t origin = (size_t)nb * TP + p.PADL + tb;
+        const size_t bytes = ((size_t)15 * TP + 16) * 4;
+        const __amdgpu_buffer_rsrc_t ro = cmf_rsrc(p.out + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rd = cmf_rsrc(p.data + origin, bytes);
+        const __amdgpu_buffer_rsrc_t rm = cmf_rsrc(p.mask + origin, bytes);
+        const int voff = (4 * kq * TP + j) * 4;
+        if (tb + j < p.T_store) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dvr = (MODE != 1) ? cmf_bload(rd, voff, r * TP * 4) : 0.f;
+                const float mvr = MASKED ? cmf_bload(rm, voff, r * TP * 4) : 1.f;
+                float d = acc[r] - dvr;
+                if (abs_loss) d = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+                cmf_bstore(MASKED ? d * mvr : d, ro, voff, r * TP * 4);
+            }
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void conv16_lag(f32x4 &acc, const float *hsb, const float (&w)[8])
+{
+    float a = hsb[0];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const float na = (ks + 1 < 8) ? hsb[(ks + 1) * 4 * CONV16_STRIDE] : 0.f;
+        if (CONV_TRANSPOSED(MODE)) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ks], a, acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[ks], acc, 0, 0, 0);
+        a = na;
+    }
+}
+
+__device__ __forceinline__ void conv16_load_w(float (&w)[8], __amdgpu_buffer_rsrc_t wr, int woff, int lag, int lagbytes, int rowbytes)
+{
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) w[ks] = cmf_bload(wr, woff, lag * lagbytes + ks * 4 * rowbytes);
+}
+
+template <int MODE>
+__device__ __forceinline__ void conv3_sixteenth(const ConvParams &p, float *Hs, int t0, int n0, int lane, int pidx)
+{
+    const int j = lane & 15, kq = lane >> 4;
+    const int Np = p.Np, TP = p.TP;
+    const int K32 = p.KB * 32;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int LB = (p.L + 31) >> 5;
+    const int rowbytes = Np * 4;
+    const int lagbytes = K32 * Np * 4;
+    const int woff = (kq * Np + j) * 4; // the block's n0 goes into the descriptor base
+    float wA[8], wB[8];
+    for (int kb = 0; kb < p.KB; ++kb) {
+        for (int lb = 0; lb < LB; ++lb) {
+            const int lbeg = lb * 32;
+            const int lend = (p.L < lbeg + 32) ? p.L : (lbeg + 32);
+            const int npair = (lend - lbeg + 1) >> 1; // lags in pairs; Wt is zero-padded to Lp
+            const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wt + ((size_t)lbeg * K32 + kb * 32) * Np + n0, (size_t)(2 * npair) * lagbytes - (size_t)n0 * 4);
+            conv16_load_w(wA, wr, woff, 0, lagbytes, rowbytes);
+            {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,64): 8 lanes per row, 8 rows per pass
+                const int r = lane >> 3, c = (lane & 7) * 4;
+                const float *src = p.Ht + (size_t)(kb * 32 + r) * TP + (p.PADL + t0 - lbeg - 32 + c);
+                float *dst = Hs + r * CONV16_STRIDE + c;
+                f32x4 v[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) v[q * 2 + jj] = *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * jj);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) *reinterpret_cast<f32x4 *>(dst + (8 * q) * CONV16_STRIDE + 32 * jj) = v[q * 2 + jj];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float *hsb = Hs + kq * CONV16_STRIDE + 32 + j;
+            for (int pr = 0; pr < npair; ++pr) {
+                const int l0 = 2 * pr;
+                conv16_load_w(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
+                conv16_lag<MODE>(acc, hsb - l0, wA);
+                conv16_load_w(wA, wr, woff, (pr + 1 < npair) ? l0 + 2 : l0, lagbytes, rowbytes);
+                conv16_lag<MODE>(acc, hsb - l0 - 1, wB);
+            }
+        }
+    }
+    conv16_epilogue<MODE>(acc, p, t0, n0, j, kq, lane, pidx);
+}
+
+// grid: n_full + P * (tiles - n_full) one-wave workgroups (P = 4 or 16).  Workgroups [0, n_full) are whole 64 x 64 tiles
+// (tile index = n tile fastest); the remaining tiles -- the part of the grid that would otherwise run as a thin last
+// round on a few SIMDs while the rest of the chip idles (3136 tiles on 3072 wave slots at a T/8 shard) -- are cut into
+// P pieces each (32 x 32 quarter tiles, or 16 x 16 sixteenth tiles when there are too few remainder tiles for the
+// quarters to reach every SIMD), dispatched last, so that the tail is spread over P times as many SIMDs.
+template <int MODE>
+__global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p, int gx, int n_full, int pieces)
 {
     __shared__ __attribute__((aligned(16))) float Hs[32 * CONV3_STRIDE];
     const int b = blockIdx.x;
     if (b < n_full) {
         conv3_tile<MODE>(p, Hs, (b / gx) * 64, (b % gx) * 64, threadIdx.x, b);
-    } else {
+    } else if (pieces == 4) {
         const int q = b - n_full, tile = n_full + (q >> 2), sub = q & 3;
         conv3_quarter<MODE>(p, Hs, (tile / gx) * 64 + (sub >> 1) * 32, (tile % gx) * 64 + (sub & 1) * 32, threadIdx.x, b);
+    } else {
+        const int q = b - n_full, tile = n_full + (q >> 4), sub = q & 15;
+        conv3_sixteenth<MODE>(p, Hs, (tile / gx) * 64 + (sub >> 2) * 16, (tile % gx) * 64 + (sub & 3) * 16, threadIdx.x, b);
     }
 }
 
