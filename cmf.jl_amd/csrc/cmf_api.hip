@@ -1663,25 +1663,35 @@ int cmf_init_rand(int device, int64_t N, int64_t T, int64_t K, int64_t L, uint64
     // src/model.jl:113-125
     if (!data || !W || !H) return fail(CMF_ERR_ARG, "NULL argument");
     if (N < 1 || T < 1 || K < 1 || L < 1) return fail(CMF_ERR_ARG, "N, T, K, L must all be >= 1");
-    const size_t nW = (size_t)K * N * L, nH = (size_t)K * T, NT = (size_t)N * T;
+    const size_t nW = (size_t)K * N * L, nH = (size_t)K * T;
     const uint64_t bW = cmfrng::base(seed, 0), bH = cmfrng::base(seed, 1);
     for (size_t i = 0; i < nW; ++i) W[i] = cmfrng::u01(bW, i); // :116 rand(K, N, L)
     for (size_t i = 0; i < nH; ++i) H[i] = cmfrng::u01(bH, i); // :117 rand(K, T)
-    std::vector<double> est(NT);
-    CMFTRY(cmf_tensor_conv(device, N, T, K, L, W, H, est.data())); // :119
-    std::vector<double> pd(64, 0.0), pn(64, 0.0);
-    {   // :120 alpha = <data, est> / norm(est)^2
-        const size_t per = (NT + 63) / 64;
-        parallel_for(64, [&](size_t a, size_t b) {
-            for (size_t c = a; c < b; ++c) {
-                double sd = 0.0, sn = 0.0;
-                for (size_t i = c * per; i < std::min(NT, (c + 1) * per); ++i) { sd += data[i] * est[i]; sn += est[i] * est[i]; }
-                pd[c] = sd; pn[c] = sn;
-            }
-        });
-    }
+    // :119-120 on the device: est = tensor_conv(W, H) next to the uploaded data, then <data, est> and norm(est)^2 in one
+    // pass over the two (padded, zero-filled) layouts -- no N x T array crosses PCIe back, none is allocated on the host
     double dot = 0.0, nn = 0.0;
-    for (int c = 0; c < 64; ++c) { dot += pd[c]; nn += pn[c]; }
+    {
+        cmf_handle hh = nullptr;
+        CMFTRY(create_impl(&hh, device, N, T, K, L, data, 0, T, false));
+        const CmfDims &d = hh->d;
+        const int nb = 1024;
+        double *part = nullptr;
+        int rc = set_factors_impl(hh, W, H);
+        if (rc == CMF_OK) rc = launch_conv<0>(hh, hh->est, d.Tl, hh->conv_gy);
+        if (rc == CMF_OK && hipMalloc(&part, (size_t)2 * nb * sizeof(double)) != hipSuccess) rc = fail(CMF_ERR_HIP, "hipMalloc failed in cmf_init_rand");
+        if (rc == CMF_OK) {
+            const size_t off = (size_t)d.PADL * d.Np, n4 = (size_t)d.Tl * d.Np / 4; // rows [PADL, PADL + Tl), all columns
+            hipLaunchKernelGGL(init_dot_kernel, dim3(nb), dim3(256), 0, hh->stream, hh->est + off, hh->X + off, n4, part);
+            hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, hh->stream, part, nb, hh->d_scalar + 2, (double *)nullptr);
+            hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, hh->stream, part + nb, nb, hh->d_scalar + 3, (double *)nullptr);
+            if (hipGetLastError() != hipSuccess) rc = fail(CMF_ERR_HIP, "launch failed in cmf_init_rand");
+        }
+        if (rc == CMF_OK) rc = read_scalar(hh, 2, &dot);
+        if (rc == CMF_OK) rc = read_scalar(hh, 3, &nn);
+        if (part) (void)hipFree(part);
+        destroy_impl(hh);
+        CMFTRY(rc);
+    }
     const double s = std::sqrt(std::fabs(dot / nn)); // :121-122
     for (size_t i = 0; i < nW; ++i) W[i] *= s;
     for (size_t i = 0; i < nH; ++i) H[i] *= s;

@@ -2379,6 +2379,34 @@ __global__ void halo_copy_kernel(float *H, float *Ht, float *buf, int r0, int ro
     }
 }
 
+// init_rand's scale factor (model.jl:120): per-block partial sums of <data, est> and <est, est> over the padded layouts
+// (padding is zero in both).  partial[b] = dot, partial[gridDim.x + b] = norm^2; fp64 accumulation of fp32 products.
+__global__ __launch_bounds__(256) void init_dot_kernel(const float *est, const float *X, size_t n4, double *partial)
+{
+    __shared__ double red[2][256];
+    double sd = 0.0, sn = 0.0;
+    for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * 256) {
+        const float4 e = reinterpret_cast<const float4 *>(est)[idx];
+        const float4 x = reinterpret_cast<const float4 *>(X)[idx];
+        sd += (double)e.x * x.x + (double)e.y * x.y + (double)e.z * x.z + (double)e.w * x.w;
+        sn += (double)e.x * e.x + (double)e.y * e.y + (double)e.z * e.z + (double)e.w * e.w;
+    }
+    red[0][threadIdx.x] = sd;
+    red[1][threadIdx.x] = sn;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = red[0][0];
+        partial[gridDim.x + blockIdx.x] = red[1][0];
+    }
+}
+
 // sum of squares of a fp64 array -> *out (one block; used for data_norm on a staged chunk)
 __global__ __launch_bounds__(256) void sumsq_f64_kernel(const double *in, size_t n, double *out_accum)
 {
