@@ -305,6 +305,9 @@ class HALSUpdate(MultUpdate):
     def fit_native(self, *a, **kw):
         raise NotImplementedError("cmf_fit runs the multiplicative-update rule; drive HALSUpdate with fit()")
 
+    def iterate(self, *a, **kw):
+        raise NotImplementedError("cmf_iterate runs the multiplicative-update rule; call update_motifs / update_feature_maps")
+
 
 HIPHALSUpdate = HALSUpdate
 
@@ -429,6 +432,9 @@ class PGDUpdate(MultUpdate):
 
     def fit_native(self, *a, **kw):
         raise NotImplementedError("cmf_fit runs the multiplicative-update rule; drive PGDUpdate with fit()")
+
+    def iterate(self, *a, **kw):
+        raise NotImplementedError("cmf_iterate runs the multiplicative-update rule; call update_motifs / update_feature_maps")
 
 
 HIPPGDUpdate = PGDUpdate
