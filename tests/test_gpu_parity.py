@@ -602,6 +602,32 @@ def test_config1_full_fit(cmf, oracle):
     assert len(res2.loss_hist) == len(lr2)
 
 
+def test_config2_full_size_against_oracle(cmf, oracle, config2):
+    """BASELINE.json configs[1] itself (N=2000, T=50000, K=32, L=20, gen_synthetic seed 1234, init_rand seed 0) against
+    the fp64 oracle: the north star's 1e-4 bar on W, H and loss_hist at the size the metric is quoted on, for as many
+    iterations as the CPU restatement can afford in a test (about 10 s per iteration on the box's host cores)."""
+    data, W0, H0 = config2
+    iters = 3
+    try:
+        from threadpoolctl import threadpool_limits
+
+        ctx = threadpool_limits(limits=16, user_api="blas")
+    except Exception:  # pragma: no cover - threadpoolctl is in the image
+        import contextlib
+
+        ctx = contextlib.nullcontext()
+    with ctx:
+        Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False)
+    rule = cmf.MultUpdate(data, W0, H0)
+    lg = [rule.compute_loss()] + list(rule.iterate(iters))
+    Wg, Hg = rule.download()
+    rule.close()
+    np.testing.assert_allclose(lg, lr, rtol=REL_LOSS)
+    assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
+    print("config 2 vs oracle after", iters, "iterations: relW", frob_rel(Wg, Wr), "relH", frob_rel(Hg, Hr),
+          "max rel loss", float(np.max(np.abs(np.asarray(lg) - lr) / lr)))
+
+
 def test_config4_regularised_full_size(cmf, config2):
     """BASELINE.json configs[3] (README.md:52 regularisers) at full size: runs, stays positive, and differs from
     the unregularised path in the expected direction (smaller W)."""
