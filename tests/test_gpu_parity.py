@@ -602,12 +602,13 @@ def test_config1_full_fit(cmf, oracle):
     assert len(res2.loss_hist) == len(lr2)
 
 
-def test_config2_full_size_against_oracle(cmf, oracle, config2):
-    """BASELINE.json configs[1] itself (N=2000, T=50000, K=32, L=20, gen_synthetic seed 1234, init_rand seed 0) against
-    the fp64 oracle: the north star's 1e-4 bar on W, H and loss_hist at the size the metric is quoted on, for as many
-    iterations as the CPU restatement can afford in a test (about 10 s per iteration on the box's host cores)."""
+@pytest.mark.parametrize("reg,iters", [(dict(), 3), (dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2), 2)])
+def test_config2_full_size_against_oracle(cmf, oracle, config2, reg, iters):
+    """BASELINE.json configs[1] itself (N=2000, T=50000, K=32, L=20, gen_synthetic seed 1234, init_rand seed 0) and
+    configs[3] (the same with README.md:52's regularisers) against the fp64 oracle: the north star's 1e-4 bar on W, H and
+    loss_hist at the size the metric is quoted on, for as many iterations as the CPU restatement can afford in a test
+    (about 10 s per iteration on the box's host cores)."""
     data, W0, H0 = config2
-    iters = 3
     try:
         from threadpoolctl import threadpool_limits
 
@@ -617,9 +618,9 @@ def test_config2_full_size_against_oracle(cmf, oracle, config2):
 
         ctx = contextlib.nullcontext()
     with ctx:
-        Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False)
+        Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False, **reg)
     rule = cmf.MultUpdate(data, W0, H0)
-    lg = [rule.compute_loss()] + list(rule.iterate(iters))
+    lg = [rule.compute_loss()] + list(rule.iterate(iters, **reg))
     Wg, Hg = rule.download()
     rule.close()
     np.testing.assert_allclose(lg, lr, rtol=REL_LOSS)
