@@ -340,6 +340,7 @@ HALS_SHAPES = [
     (200, 1500, 5, 10),
     (150, 900, 64, 20),  # L * Kpad = 1280: the W sweep's long-state form (20 register slots per lane)
     (64, 400, 40, 30),   # L * Kpad = 1920 (Kpad = 64): 32 slots
+    (2000, 1200, 32, 20),  # config 5's N, K, L on as many columns as the CPU restatement sweeps in a few seconds
 ]
 
 
