@@ -628,6 +628,14 @@ def test_config2_full_size_against_oracle(cmf, oracle, config2, reg, iters):
     assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
     print("config 2 vs oracle after", iters, "iterations: relW", frob_rel(Wg, Wr), "relH", frob_rel(Hg, Hr),
           "max rel loss", float(np.max(np.abs(np.asarray(lg) - lr) / lr)))
+    # the same problem as the 8 shards of 6250 columns bench.py --gpus 8 runs (all on this one GPU, loopback transport):
+    # the T-sharded iteration at the metric's size against the same oracle fit
+    rule = cmf.MultUpdate(data, W0, H0, devices=[0] * 8)
+    l8 = [rule.compute_loss()] + list(rule.iterate(iters, **reg))
+    W8, H8 = rule.download()
+    rule.close()
+    np.testing.assert_allclose(l8, lr, rtol=REL_LOSS)
+    assert frob_rel(W8, Wr) < REL_FACTORS and frob_rel(H8, Hr) < REL_FACTORS
 
 
 def test_config4_regularised_full_size(cmf, config2):
