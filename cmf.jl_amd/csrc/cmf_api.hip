@@ -444,6 +444,8 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = data ? data : h->X; p.partial = h->partial;
     p.mask = (MODE == 7) ? h->MT : h->M;
     p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = T_store;
+    static const bool dead_skip = !(getenv("CMF_CONV_DEADSKIP") && atoi(getenv("CMF_CONV_DEADSKIP")) == 0); // measurement knob
+    p.N = dead_skip ? d.N : d.Np;
     p.loss_abs = (MODE >= 4) ? h->pgd_loss_abs_now : 0;
     dim3 grid(h->conv_gx, gy), block(256);
     // measured at config 2 (tools/time_kernels.py): the one-wave kernel wins for the epilogues that read data
@@ -455,13 +457,26 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     // then decides the variant for every mode; a remainder above 3 tiles per CU is left as whole tiles.
     const int gx3 = d.Np / 64, tiles3 = gx3 * ((T_store + 63) / 64), slots3 = 12 * h->n_cu;
     const int rem3 = tiles3 % slots3;
-    static const int split_rounds = getenv("CMF_CONV_SPLIT_ROUNDS") ? atoi(getenv("CMF_CONV_SPLIT_ROUNDS")) : 8;
-    const bool split = h->conv_split && rem3 > 0 && rem3 <= 3 * h->n_cu && tiles3 / slots3 < split_rounds;
+    // The tiles at the end of the grid are cut into one-wave pieces: the remainder of the last round when it is thin
+    // (at most 3 tiles per CU), and, from `split_min_rounds` rounds on, `split_extra` more -- after several rounds of
+    // dynamic dispatch the waves of a SIMD are out of step and the launch ends in a ragged drain one tile long; small
+    // pieces at the end of the queue fill it (measured at config 2, 8.1 rounds: -1.5 % in every mode).
+    // Below 4 rounds the extra cut costs more than it fills (T/4 and T/8 shards: +1-4 %).
+    static const int split_extra_env = getenv("CMF_CONV_SPLIT_EXTRA") ? atoi(getenv("CMF_CONV_SPLIT_EXTRA")) : -1;
+    static const int split_min_rounds = getenv("CMF_CONV_SPLIT_MINR") ? atoi(getenv("CMF_CONV_SPLIT_MINR")) : 4;
+    const int split_extra = split_extra_env >= 0 ? split_extra_env : 3 * h->n_cu;
+    int cut = 0;
+    if (h->conv_split) {
+        if (rem3 > 0 && rem3 <= 3 * h->n_cu) cut = rem3;
+        if (tiles3 / slots3 >= split_min_rounds) cut += split_extra;
+        cut = std::min(cut, tiles3);
+    }
+    const bool split = cut > 0;
     const int variant = h->conv_variant ? h->conv_variant : ((reads_data || split) ? 3 : 2);
     if (d.K % 32 == 0 && variant == 3) {
-        const int n_full = split ? tiles3 - rem3 : tiles3;
-        // quarter tiles reach every SIMD only from one remainder tile per CU on; below that, sixteenth tiles
-        const int pieces = (split && rem3 < h->n_cu && h->conv_split != 4) ? 16 : 4;
+        const int n_full = tiles3 - cut;
+        // quarter tiles reach every SIMD only from one tile per CU on; below that, sixteenth tiles
+        const int pieces = (split && cut < h->n_cu && h->conv_split != 4) ? 16 : 4;
         grid = dim3(n_full + pieces * (tiles3 - n_full));
         hipLaunchKernelGGL((conv3_kernel<MODE>), grid, dim3(64), 0, h->stream, p, gx3, n_full, pieces);
     } else if (d.K % 32 == 0) hipLaunchKernelGGL((conv2_kernel<MODE>), grid, block, 0, h->stream, p);

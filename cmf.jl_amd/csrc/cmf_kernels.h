@@ -77,6 +77,7 @@ struct ConvParams {
     double *partial;   // [gridDim.x * gridDim.y]
     int Np, TP, PADL, K, KB, L;
     int T_store; // rows t < T_store are stored / counted
+    int N;       // columns n >= N are padding: a 32-column MFMA block that lies wholly behind N is not computed (its sums are 0)
     int loss_abs; // residual modes (4-7) only: 1 = AbsoluteLoss (pgd.jl:41-47): store sign(est - data) [.* mask], sum |.|
 };
 
@@ -369,18 +370,28 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p)
 // registers with buffer loads, one lag ahead (two ping-pong register sets), so the lag loop has NO
 // workgroup barrier; only the H strip is shared through LDS (one barrier per 32-lag block).
 // ---------------------------------------------------------------------------------------------
+// NBL = live 32-column n blocks of the wave's 64 columns (2, or 1 when the second block is all padding: at N = 2000 the
+// last 64-column tile holds 16 real columns, and skipping its dead half is 1.6 % of the launch's MFMAs)
+template <int NBL = 2>
 __device__ __forceinline__ void conv2_load_w(float (&w)[16][2], __amdgpu_buffer_rsrc_t wr, int woff, int lag, int lagbytes, int rowbytes)
 {
+#ifdef CMF_CONV_KNOCKOUT // timing experiments only (tools/conv_knockout.py): 1 = W loaded for lag 0 only
+    if ((CMF_CONV_KNOCKOUT & 1) && lag != 0) {
+#pragma unroll
+        for (int kp = 0; kp < 16; ++kp) { asm volatile("" : "+v"(w[kp][0])); asm volatile("" : "+v"(w[kp][1])); }
+        return;
+    }
+#endif
 #pragma unroll
     for (int kp = 0; kp < 16; ++kp) {
         w[kp][0] = cmf_bload(wr, woff, lag * lagbytes + kp * 2 * rowbytes);
-        w[kp][1] = cmf_bload(wr, woff + 128, lag * lagbytes + kp * 2 * rowbytes);
+        if (NBL == 2) w[kp][1] = cmf_bload(wr, woff + 128, lag * lagbytes + kp * 2 * rowbytes);
     }
 }
 
 // FIRST: the accumulators hold nothing yet -- the kp = 0 MFMAs take a zero C operand (an inline constant) instead of
 // 64 register writes of an explicit zero fill
-template <int MODE, int STRIDE = CONV_HS_STRIDE, bool FIRST = false>
+template <int MODE, int STRIDE = CONV_HS_STRIDE, bool FIRST = false, int NBL = 2>
 __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb, const float (&w)[16][2])
 {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -389,6 +400,9 @@ __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb,
 #pragma unroll
     for (int kp = 0; kp < 16; ++kp) {
         float na0 = 0.f, na1 = 0.f;
+#ifdef CMF_CONV_KNOCKOUT // 2 = one H operand read per lag instead of sixteen
+        if (CMF_CONV_KNOCKOUT & 2) { na0 = a0; na1 = a1; asm volatile("" : "+v"(na0), "+v"(na1)); } else
+#endif
         if (kp + 1 < 16) {
             na0 = hsb[(kp + 1) * 2 * STRIDE];
             na1 = hsb[(kp + 1) * 2 * STRIDE + 32];
@@ -398,16 +412,56 @@ __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb,
         if (CONV_TRANSPOSED(MODE)) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a0, zc ? zero16 : acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][0], a1, zc ? zero16 : acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a0, zc ? zero16 : acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a1, zc ? zero16 : acc[1][1], 0, 0, 0);
+            if (NBL == 2) {
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a0, zc ? zero16 : acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kp][1], a1, zc ? zero16 : acc[1][1], 0, 0, 0);
+            }
         } else {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[kp][0], zc ? zero16 : acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[kp][1], zc ? zero16 : acc[0][1], 0, 0, 0);
+            if (NBL == 2) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w[kp][1], zc ? zero16 : acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[kp][0], zc ? zero16 : acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[kp][1], zc ? zero16 : acc[1][1], 0, 0, 0);
+            if (NBL == 2) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w[kp][1], zc ? zero16 : acc[1][1], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NBL == 2 ? 4 : 2, 0);
         a0 = na0; a1 = na1;
+    }
+}
+
+// The lag pairs of one (kb, lb) block for a wave: wA holds lag 0 on entry.  `first`: the block's first MFMAs start the
+// accumulators (zero C operand).
+template <int MODE, int STRIDE, int NBL>
+__device__ __forceinline__ void conv2_lag_pairs(f32x16 (&acc)[2][2], const float *hsb, float (&wA)[16][2], float (&wB)[16][2],
+                                                __amdgpu_buffer_rsrc_t wr, int woff, int npair, bool first, int lagbytes, int rowbytes)
+{
+    int pr = 0;
+    if (first) { // peeled first lag pair
+        conv2_load_w<NBL>(wB, wr, woff, 1, lagbytes, rowbytes);
+        __builtin_amdgcn_sched_barrier(0);
+        conv2_lag<MODE, STRIDE, true, NBL>(acc, hsb, wA);
+        conv2_load_w<NBL>(wA, wr, woff, (1 < npair) ? 2 : 0, lagbytes, rowbytes);
+        __builtin_amdgcn_sched_barrier(0);
+        conv2_lag<MODE, STRIDE, false, NBL>(acc, hsb - 1, wB);
+        pr = 1;
+    }
+    for (; pr < npair; ++pr) {
+        const int l0 = 2 * pr; // lag offsets inside the block
+        conv2_load_w<NBL>(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
+        __builtin_amdgcn_sched_barrier(0);
+        conv2_lag<MODE, STRIDE, false, NBL>(acc, hsb - l0, wA);
+        conv2_load_w<NBL>(wA, wr, woff, (pr + 1 < npair) ? l0 + 2 : l0, lagbytes, rowbytes);
+        __builtin_amdgcn_sched_barrier(0);
+        conv2_lag<MODE, STRIDE, false, NBL>(acc, hsb - l0 - 1, wB);
+    }
+}
+
+// the accumulators of the n block that was not computed (NBL == 1)
+template <int MODE>
+__device__ __forceinline__ void conv2_clear_dead(f32x16 (&acc)[2][2])
+{
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (CONV_TRANSPOSED(MODE)) { acc[1][0][q] = 0.f; acc[1][1][q] = 0.f; }
+        else { acc[0][1][q] = 0.f; acc[1][1][q] = 0.f; }
     }
 }
 
@@ -440,6 +494,7 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
     const int rowbytes = Np * 4;
     const int lagbytes = K32 * Np * 4;
     const int woff = (h * Np + n0 + wn * 64 + i) * 4; // per-lane part of the W address
+    const bool half = n0 + wn * 64 + 32 >= p.N;       // wave-uniform: the wave's second n block is padding
     float wA[16][2], wB[16][2];
 
     for (int kb = 0; kb < p.KB; ++kb) {
@@ -450,7 +505,7 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
             // descriptor base: Wt[lbeg][kb*32][0]
             const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wt + ((size_t)lbeg * K32 + kb * 32) * Np, (size_t)(2 * npair) * lagbytes);
             CMF_STAMP(5);
-            conv2_load_w(wA, wr, woff, 0, lagbytes, rowbytes);
+            if (!half) conv2_load_w<2>(wA, wr, woff, 0, lagbytes, rowbytes); else conv2_load_w<1>(wA, wr, woff, 0, lagbytes, rowbytes);
             CMF_STAMP(6);
             __syncthreads(); // everyone is done with Hs of the previous block
             CMF_STAMP(7);
@@ -467,27 +522,11 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
             __syncthreads();
             CMF_STAMP(1);
             const float *hsb = Hs + h * CONV_HS_STRIDE + 32 + wt * 64 + i;
-            int pr = 0;
-            if (kb == 0 && lb == 0) { // peeled first lag pair: its first MFMAs start the accumulators
-                conv2_load_w(wB, wr, woff, 1, lagbytes, rowbytes);
-                __builtin_amdgcn_sched_barrier(0);
-                conv2_lag<MODE, CONV_HS_STRIDE, true>(acc, hsb, wA);
-                conv2_load_w(wA, wr, woff, (1 < npair) ? 2 : 0, lagbytes, rowbytes);
-                __builtin_amdgcn_sched_barrier(0);
-                conv2_lag<MODE>(acc, hsb - 1, wB);
-                pr = 1;
-            }
-            for (; pr < npair; ++pr) {
-                const int l0 = 2 * pr; // lag offsets inside the block
-                conv2_load_w(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
-                __builtin_amdgcn_sched_barrier(0);
-                conv2_lag<MODE>(acc, hsb - l0, wA);
-                conv2_load_w(wA, wr, woff, (pr + 1 < npair) ? l0 + 2 : l0, lagbytes, rowbytes);
-                __builtin_amdgcn_sched_barrier(0);
-                conv2_lag<MODE>(acc, hsb - l0 - 1, wB);
-            }
+            if (!half) conv2_lag_pairs<MODE, CONV_HS_STRIDE, 2>(acc, hsb, wA, wB, wr, woff, npair, kb == 0 && lb == 0, lagbytes, rowbytes);
+            else conv2_lag_pairs<MODE, CONV_HS_STRIDE, 1>(acc, hsb, wA, wB, wr, woff, npair, kb == 0 && lb == 0, lagbytes, rowbytes);
         }
     }
+    if (half) conv2_clear_dead<MODE>(acc);
     CMF_STAMP(2);
     conv_epilogue<MODE>(acc, p, t0, n0, wt, wn, i, h, lane, wave, tid);
     CMF_STAMP(3);
@@ -501,7 +540,7 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
 // end of the launch shrink fourfold.  Main loop and epilogue are conv2's.
 // ---------------------------------------------------------------------------------------------
 #define CONV3_STRIDE 96
-template <int MODE>
+template <int MODE, int NBL = 2>
 __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t0, int n0, int lane, int pidx)
 {
     const int i = lane & 31, h = lane >> 5;
@@ -521,7 +560,7 @@ __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t
             const int lend = (p.L < lbeg + 32) ? p.L : (lbeg + 32);
             const int npair = (lend - lbeg + 1) >> 1; // lags are processed in pairs; Wt is zero-padded to Lp
             const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wt + ((size_t)lbeg * K32 + kb * 32) * Np, (size_t)(2 * npair) * lagbytes);
-            conv2_load_w(wA, wr, woff, 0, lagbytes, rowbytes);
+            conv2_load_w<NBL>(wA, wr, woff, 0, lagbytes, rowbytes);
             {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,96): 8 lanes per row, 8 rows per pass
                 const int r = lane >> 3, c = (lane & 7) * 4;
                 const float *src = p.Ht + (size_t)(kb * 32 + r) * TP + (p.PADL + t0 - lbeg - 32 + c);
@@ -540,27 +579,10 @@ __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const float *hsb = Hs + h * CONV3_STRIDE + 32 + i;
-            int pr = 0;
-            if (kb == 0 && lb == 0) { // peeled first lag pair: its first MFMAs start the accumulators
-                conv2_load_w(wB, wr, woff, 1, lagbytes, rowbytes);
-                __builtin_amdgcn_sched_barrier(0);
-                conv2_lag<MODE, CONV3_STRIDE, true>(acc, hsb, wA);
-                conv2_load_w(wA, wr, woff, (1 < npair) ? 2 : 0, lagbytes, rowbytes);
-                __builtin_amdgcn_sched_barrier(0);
-                conv2_lag<MODE, CONV3_STRIDE>(acc, hsb - 1, wB);
-                pr = 1;
-            }
-            for (; pr < npair; ++pr) {
-                const int l0 = 2 * pr; // lag offsets inside the block
-                conv2_load_w(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
-                __builtin_amdgcn_sched_barrier(0);
-                conv2_lag<MODE, CONV3_STRIDE>(acc, hsb - l0, wA);
-                conv2_load_w(wA, wr, woff, (pr + 1 < npair) ? l0 + 2 : l0, lagbytes, rowbytes);
-                __builtin_amdgcn_sched_barrier(0);
-                conv2_lag<MODE, CONV3_STRIDE>(acc, hsb - l0 - 1, wB);
-            }
+            conv2_lag_pairs<MODE, CONV3_STRIDE, NBL>(acc, hsb, wA, wB, wr, woff, npair, kb == 0 && lb == 0, lagbytes, rowbytes);
         }
     }
+    if (NBL == 1) conv2_clear_dead<MODE>(acc);
     conv_epilogue<MODE, 1>(acc, p, t0, n0, 0, 0, i, h, lane, 0, lane, pidx);
 }
 
@@ -887,7 +909,9 @@ __global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p, int gx, int 
     __shared__ __attribute__((aligned(16))) float Hs[32 * CONV3_STRIDE];
     const int b = blockIdx.x;
     if (b < n_full) {
-        conv3_tile<MODE>(p, Hs, (b / gx) * 64, (b % gx) * 64, threadIdx.x, b);
+        const int n0 = (b % gx) * 64;
+        if (n0 + 32 < p.N) conv3_tile<MODE, 2>(p, Hs, (b / gx) * 64, n0, threadIdx.x, b);
+        else conv3_tile<MODE, 1>(p, Hs, (b / gx) * 64, n0, threadIdx.x, b);
     } else if (pieces == 4) {
         const int q = b - n_full, tile = n_full + (q >> 2), sub = q & 3;
         conv3_quarter<MODE>(p, Hs, (tile / gx) * 64 + (sub >> 1) * 32, (tile % gx) * 64 + (sub & 1) * 32, threadIdx.x, b);

@@ -126,8 +126,9 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       2 = additionally take the loss from <H, denomH> - 2<H, numH> + ||data||^2 (no conv at all; the fp32
  *       cancellation limits its relative accuracy to about 1e-6 / loss^2).  Unsharded handles only.
  *   "conv_kernel" (default 0 = chosen per launch; 2 = 128 x 128 workgroup tiles, 3 = one-wave 64 x 64 tiles) and
- *   "conv_split" (default 1: the thin last round of the one-wave kernel is cut into 32 x 32 quarter or 16 x 16 sixteenth
- *       tiles; 4 = quarter tiles only; 0 = whole tiles only): kernel selection of tensor_conv, for measurements.
+ *   "conv_split" (default 1: the tiles at the end of the one-wave kernel's grid -- a thin last round, and from four
+ *       rounds on three more tiles per CU -- are cut into 32 x 32 quarter or 16 x 16 sixteenth tiles; 4 = quarter tiles
+ *       only; 0 = whole tiles only): kernel selection of tensor_conv, for measurements.
  *   "hals_prepare": allocate the HALS rule's scratch and check its shape limits now (see the HALS entries).
  *   "profile" (n): bracket every n-th contraction launch with HIP events (cmf_kernel_times); 0 stops.
  *   "allreduce_overlap" (group handles, default 0): 1 = numW (which needs H only) is contracted and all-reduced on a
