@@ -101,6 +101,9 @@ struct cmf_handle_s {
     float *hals_HuT = nullptr, *hals_hhslabs = nullptr, *hals_HH = nullptr, *hals_PT = nullptr, *hals_D = nullptr;
     float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr;
     int hals_seg = 256, hals_nseg = 1;      // column segments of the pipelined H sweep
+    int hals_pullers = 0;                   // persistent H pipeline: puller workgroups per row (0 = stage pipeline)
+    int *hals_flags = nullptr;              // its progress flags (device)
+    int *hals_status = nullptr;             // pinned host word: 1 = a wait of the persistent pipeline ran out
 
     // PGD rule state (pgd.jl:139-154)
     double pgd_stepW = 5.0, pgd_stepH = 5.0, pgd_cur_loss = -1.0;
@@ -266,6 +269,8 @@ static void destroy_impl(cmf_handle_s *h)
     for (int v = 0; v < 2; ++v)
         if (h->tc_tab[v]) (void)hipFree(h->tc_tab[v]);
     if (h->partial) (void)hipFree(h->partial);
+    if (h->hals_flags) (void)hipFree(h->hals_flags);
+    if (h->hals_status) (void)hipHostFree(h->hals_status);
     if (h->pgd_knorm) (void)hipFree(h->pgd_knorm);
     if (h->d_scalar_own) (void)hipFree(h->d_scalar_own);
     if (h->h_scalar) (void)hipHostFree(h->h_scalar);
@@ -920,6 +925,11 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
     CMFTRY(hals_h_impl(h, l1H, l2H));
     double ss = 0.0;
     CMFTRY(resid_and_loss(h, &ss)); // hals.jl:41: norm(resids)/data_norm; the residual is kept for the next W phase
+    if (h->hals_status && *h->hals_status) { // (the stream has been synchronised by the loss read-back)
+        *h->hals_status = 0;
+        return fail(CMF_ERR_HIP, "HALS H pipeline: a wait between its workgroups ran out (is another kernel occupying the device?); "
+                                 "H is partially updated -- set CMF_HALS_PERSIST=0 for the stage pipeline");
+    }
     *loss = std::sqrt(ss) / h->data_norm;
     return CMF_OK;
 }
@@ -1352,6 +1362,24 @@ static int hals_ensure(cmf_handle_s *h)
         h->hals_seg = seg;
         h->hals_nseg = (d.Tl + seg - 1) / seg;
     }
+    {   // persistent H pipeline (hals_h_persist_kernel): K sweepers + (K-1) * P pullers, one workgroup per CU, all resident
+        const char *env = getenv("CMF_HALS_PERSIST"); // 0 = the stage pipeline (the tests compare the two)
+        int P = 0;
+        if (!(env && atoi(env) == 0)) {
+            P = d.K > 1 ? std::min(4, (h->n_cu - d.K) / (d.K - 1)) : 1;
+            if (env && atoi(env) > 1) P = std::min(P, atoi(env));
+            const size_t lds = ((size_t)(d.K - 1) * (E + 64 + 2 * (d.L - 1)) + 1024) * sizeof(float);
+            if (P < 2 && d.K > 1) P = 0; // too many rows for the chip: stage pipeline
+            if (lds > 120 * 1024) P = 0;
+        }
+        h->hals_pullers = P;
+        if (P > 0) {
+            const size_t nflags = (size_t)(d.K + d.K * P + 1) * HALS_FLAG_STRIDE;
+            HIPCHK(hipMalloc((void **)&h->hals_flags, nflags * sizeof(int)));
+            HIPCHK(hipHostMalloc((void **)&h->hals_status, sizeof(int), hipHostMallocDefault));
+            *h->hals_status = 0;
+        }
+    }
     h->hals_ready = true;
     return CMF_OK;
 }
@@ -1410,6 +1438,49 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
     q.PT = h->hals_PT; q.H = h->H; q.Ht = h->Ht; q.D = h->hals_D; q.GW = h->hals_GW; q.GE = h->hals_GE;
     q.Tl = d.Tl; q.L = d.L; q.K32 = d.K32; q.TP = d.TP; q.TPp = h->hals_TPp; q.PADL = d.PADL; q.ne = h->hals_ne; q.t_edge0 = h->hals_t_edge0;
     q.l1 = (float)l1H; q.l2 = (float)l2H;
+    q.edge_lds = nullptr;
+    if (h->hals_pullers > 0) { // the whole sweep as one persistent launch (hals_h_persist_kernel)
+        HalsPersistParams pp;
+        pp.row = q;
+        pp.Dall = h->hals_D;
+        pp.flags = h->hals_flags;
+        pp.host_status = h->hals_status;
+        pp.K = d.K; pp.P = h->hals_pullers; pp.nblk = (d.Tl + 63) / 64;
+        pp.debug = 0;
+        if (const char *dbg = getenv("CMF_HALS_DEBUG")) { // timing experiments only (results are wrong)
+            if (std::strcmp(dbg, "nogate") == 0) pp.debug = 1;  // sweepers alone: no row waits for anything
+            if (std::strcmp(dbg, "nopull") == 0) pp.debug = 2;  // pullers raise their flags without doing the work
+        }
+        const size_t nflags = (size_t)(d.K + d.K * pp.P + 1) * HALS_FLAG_STRIDE;
+        const size_t lds = std::max((size_t)(d.K - 1) * (2 * d.L - 1 + 64 + 2 * (d.L - 1)) + 1024, (size_t)h->hals_ne * (d.L + 1)) * sizeof(float);
+        pp.stamps = nullptr;
+        const char *stamp_path = getenv("CMF_HALS_STAMPS"); // debug: dump s_memtime stamps of this launch to a file
+        const size_t nstamps = (size_t)d.K * pp.nblk * 5;
+        if (stamp_path) {
+            HIPCHK(hipMalloc((void **)&pp.stamps, nstamps * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(pp.stamps, 0, nstamps * sizeof(unsigned long long), h->stream));
+        }
+        {
+            ProfScope prof_(h, PROF_HALS_PIPE);
+            HIPCHK(hipMemsetAsync(h->hals_flags, 0, nflags * sizeof(int), h->stream));
+            hipLaunchKernelGGL(hals_h_persist_kernel, dim3(d.K + (d.K - 1) * pp.P), dim3(1024), lds, h->stream, pp);
+            KCHK("hals_h_persist_kernel");
+        }
+        if (stamp_path) {
+            std::vector<unsigned long long> st(nstamps);
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipMemcpy(st.data(), pp.stamps, nstamps * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            (void)hipFree(pp.stamps);
+            if (FILE *f = fopen(stamp_path, "wb")) {
+                const long long hdr[2] = {d.K, pp.nblk};
+                fwrite(hdr, sizeof(hdr), 1, f);
+                fwrite(st.data(), sizeof(unsigned long long), nstamps, f);
+                fclose(f);
+            }
+        }
+        h->est_kind = 0;
+        return CMF_OK;
+    }
     // hals.jl:124-125: k outer, t inner, as a software pipeline over the rows: one launch per stage
     // (see hals_h_stage_kernel); the order of every update is the reference's.
     HalsStageParams sp;

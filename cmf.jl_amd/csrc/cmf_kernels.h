@@ -469,7 +469,7 @@ __device__ __forceinline__ void conv2_clear_dead(f32x16 (&acc)[2][2])
 // debug builds only (tools/conv_stamps.hip): s_memtime stamps + HW_ID / XCC_ID per workgroup, 8 slots each
 __device__ unsigned long long *cmf_stamps;
 #define CMF_STAMP(slot) do { if (threadIdx.x == 0) { unsigned long long *st_ = cmf_stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8; \
-    st_[slot] = __builtin_amdgcn_s_memtime(); \
+    st_[slot] = __builtin_amdgcn_s_memrealtime(); \
     if ((slot) == 0) { st_[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } } } while (0)
 #else
 #define CMF_STAMP(slot) do { } while (0)
@@ -1755,6 +1755,7 @@ struct HalsRowParams {
     int k, Tl, L, K32, TP, TPp, PADL, ne, t_edge0;
     int t_begin, t_end; // column segment of this launch (t_begin multiple of 64; t_end multiple of 64 or Tl)
     float l1, l2;
+    const float *edge_lds; // persistent kernel: this row's own edge taps GE[k][i][k][e >= 0] as [ne][L], then 1/(norm+eps+l2) as [ne], in LDS; else NULL
 };
 
 // lane i <- lane i+1; lane 63 keeps `fill`
@@ -1786,7 +1787,78 @@ __device__ __forceinline__ float cmf_lane0(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
-__device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lane)
+// ---- how a row sweep meets the other rows ----------------------------------------------------------------------------
+// HalsNoSync: the stage pipeline (hals_h_stage_kernel) -- everything a segment needs was pushed by earlier launches.
+// HalsFlagSync: the persistent pipeline (hals_h_persist_kernel) -- the cross-row terms of block c (64 columns) of this
+// row's P are added by a puller workgroup, which raises pulled[c % P] to c + 1 when the block is in memory; the sweep
+// publishes its own progress (blocks whose changes D are in memory) for the pullers of the next row.  All hand-offs
+// follow MI355X_MICROARCH.md "inter-workgroup visibility": payload stored sc1 (each 128-byte line whole, by one store
+// instruction), s_waitcnt vmcnt(0), then an sc1 flag store; readers poll the flag with sc1 loads and read the payload with
+// sc1 loads.  Every wait is bounded: a poll loop that runs out sets the abort word (and the host's status word) and every
+// other loop leaves on seeing it, so the grid always drains.
+#define HALS_FLAG_STRIDE 32      // ints: one 128-byte line per flag
+#define HALS_POLL_LIMIT (1 << 19) // ~0.5 s of polling: three orders of magnitude above the longest legitimate wait
+__device__ __forceinline__ int cmf_load_sc1(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float cmf_load_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cmf_store_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cmf_store_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cmf_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// wait until *flag >= need; false when the pipeline was aborted (or this wait ran out and aborted it)
+__device__ __forceinline__ bool hals_wait_flag(const int *flag, int need, int *abort_word, int *host_status)
+{
+#pragma nounroll
+    for (int n = 0; n < HALS_POLL_LIMIT; ++n) {
+        const int v = cmf_load_sc1(flag), a = cmf_load_sc1(abort_word); // both in flight together: one round trip per poll
+        if (v >= need) return true;
+        if (a != 0) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    cmf_store_sc1(abort_word, 1);
+    __hip_atomic_store(host_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return false;
+}
+
+struct HalsNoSync {
+    static constexpr bool PERSIST = false;
+    __device__ __forceinline__ float load_p(const float *p) const { return *p; }
+    __device__ __forceinline__ void store_d(float *p, float v) const { *p = v; }
+    __device__ __forceinline__ bool gate(int) const { return true; }
+    __device__ __forceinline__ int gate_issue(int) const { return 0; }
+    __device__ __forceinline__ bool gate_check(int, int) const { return true; }
+    __device__ __forceinline__ void publish(int) const {}
+    __device__ __forceinline__ void stamp(int) const {}
+};
+
+struct HalsFlagSync {
+    static constexpr bool PERSIST = true;
+    const int *pulled; // this row's P flags, HALS_FLAG_STRIDE apart (NULL for row 0: nothing is pulled into it)
+    int *prog;         // this row's progress flag
+    int *abort_word, *host_status;
+    int P, nblk;
+    unsigned long long *stamps; // debug (CMF_HALS_STAMPS): s_memtime at the end of every block of this row, or NULL
+    __device__ __forceinline__ void stamp(int blk) const { if (stamps && threadIdx.x == 0) stamps[blk] = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ float load_p(const float *p) const { return cmf_load_sc1(p); }
+    __device__ __forceinline__ void store_d(float *p, float v) const { cmf_store_sc1(p, v); }
+    __device__ __forceinline__ bool gate(int c) const // block c of this row's P is complete
+    {
+        if (!pulled || c >= nblk) return true;
+        return hals_wait_flag(pulled + (c % P) * HALS_FLAG_STRIDE, c + 1, abort_word, host_status);
+    }
+    __device__ __forceinline__ int gate_issue(int c) const // start reading the flag of block c; its value goes to gate_check
+    {
+        if (!pulled || c >= nblk) return 0x7fffffff;
+        return cmf_load_sc1(pulled + (c % P) * HALS_FLAG_STRIDE);
+    }
+    __device__ __forceinline__ bool gate_check(int c, int seen) const { return seen >= c + 1 ? true : gate(c); }
+    __device__ __forceinline__ void publish(int done) const // every store of blocks < done has completed (caller drained vmcnt)
+    {
+        if (threadIdx.x == 0) cmf_store_sc1(prog, done);
+    }
+};
+
+template <class Sync>
+__device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lane, const Sync &sy)
 {
     const int L = q.L, E = 2 * L - 1, k = q.k;
     float *Prow = q.PT + (size_t)k * q.TPp;
@@ -1797,10 +1869,13 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
     const float g = (lane >= 1 && lane < L) ? gk[lane] : 0.f; // same-row taps, lane = column offset
     const int nfull = q.t_edge0;                              // columns [0, nfull) have the full lag window
     int tb = q.t_begin;
-    float p = Prow[tb + lane];       // pending P of columns tb + lane (PT is zero-padded beyond Tl)
-    float pn = Prow[tb + 64 + lane]; // columns tb + 64 + lane: enter the window one per step
+    if (!sy.gate(tb >> 6) || !sy.gate((tb >> 6) + 1)) return;
+    float p = sy.load_p(Prow + tb + lane);       // pending P of columns tb + lane (PT is zero-padded beyond Tl)
+    float pn = sy.load_p(Prow + tb + 64 + lane); // columns tb + 64 + lane: enter the window one per step
     float hreg = Hrow[tb + lane];    // H_old of columns tb + lane
     const int t_stop = q.t_end < q.Tl ? q.t_end : q.Tl;
+    int t_first = tb;                        // first column left to the generic path
+    float grot0 = g, hnew0 = 0.f, dreg0 = 0.f; // its initial tap rotation and the results of a partial block's columns
     // ---- fast path: whole 64-column blocks with the full window.  The window slides one lane per step (DPP wave
     // shift), so the active column is always lane 0 and the taps never move.  The recurrence is carried in the change
     // d_t = x_t - h_t, with the lag-1 tap taken out of the wave-wide update and the state kept in "numerator" form
@@ -1817,13 +1892,27 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
         const float gsn = (lane >= 1 && lane + 1 < L) ? -inv_den * gk[lane + 1] : 0.f;
         float w = p;         // complete on entry (a hand-over or the initial P): the previous column's change is in it
         float dprev = 0.f;   // lane 0: change of the previous column whose lag-1 term is still missing from the state
-        float creg = (hreg * nrm - q.l1) * inv_den;      // (h_old*nrm - l1)/(nrm+eps+l2) per column
-        float V = fmaf(-inv_den, w, creg - hreg);
+        // cmh = c - h with c = (h_old*nrm - l1)/(nrm+eps+l2), per column.  It enters V here and leaves it again in the
+        // conversion back to pending values below; both must see the SAME float (one variable, pinned): left as two
+        // expressions the compiler may contract them differently, and a column whose pending value is exactly 0 -- W_k
+        // zero on the lags of a truncated window, where the update divides by eps alone -- comes back as an ulp of c - h.
+        float cmh = (hreg * nrm - q.l1) * inv_den - hreg;
+        asm volatile("" : "+v"(cmh));
+        float V = fmaf(-inv_den, w, cmh);
+        float hahead = Hrow[tb + 64 + lane]; // H_old one block ahead: loaded a whole block before its first use (a load at
+                                             // the top of the block it is needed in puts an L2 round trip into every block's chain)
         for (; tb + 64 <= nfull && tb + 64 <= t_stop; tb += 64) {
-            const float pn2 = Prow[tb + 128 + lane];
-            const float hreg2 = Hrow[tb + 64 + lane];
-            const float creg2 = (hreg2 * nrm - q.l1) * inv_den;
-            float vnr = cmf_wave_rol1(fmaf(-inv_den, pn, creg2 - hreg2)); // lane 63 holds the column that enters next
+            // persistent pipeline: the flag of P block +2 is read now and looked at half a block later, together with the
+            // completion of the previous block's stores -- neither round trip sits in the column chain
+            const int seen = sy.gate_issue((tb >> 6) + 2);
+            bool aborted = false;
+            float pn2 = 0.f;
+            if (!Sync::PERSIST) pn2 = Prow[tb + 128 + lane];
+            const float hreg2 = hahead;
+            hahead = Hrow[tb + 128 + lane];
+            float cmh2 = (hreg2 * nrm - q.l1) * inv_den - hreg2;
+            asm volatile("" : "+v"(cmh2));
+            float vnr = cmf_wave_rol1(fmaf(-inv_den, pn, cmh2)); // lane 63 holds the column that enters next
             float mhrot = -hreg;                                          // lane 0 = -h of the column being swept
             float dvec = 0.f;                                             // collects the changes of the block's columns
             // column 0 of the block: its rh is lane 0 of V itself
@@ -1840,62 +1929,148 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
                 dprev = d;
                 if (j + 1 < 64) // hals.jl:152-153 as a change: x - h_old = max(q, 0) - h_old = max(q - h_old, -h_old)
                     asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(fmaf(kappa, dprev, ps)), "v"(mhrot));
+                if (Sync::PERSIST && j == 31) {
+                    cmf_drain_vmem();        // the previous block's D (and H) stores have completed
+                    sy.publish(tb >> 6);     // blocks < tb / 64 are in memory
+                    aborted = !sy.gate_check((tb >> 6) + 2, seen); // (no exit from inside the unrolled block)
+                    pn2 = sy.load_p(Prow + tb + 128 + lane);
+                }
             }
+            if (Sync::PERSIST && aborted) return;
             const float hnew = hreg + dvec;
             Hrow[tb + lane] = hnew;
             q.H[(size_t)(q.PADL + tb + lane) * q.K32 + k] = hnew;
-            q.D[tb + lane] = dvec;
+            sy.store_d(q.D + tb + lane, dvec);
+            sy.stamp(tb >> 6);
             pn = pn2;
             hreg = hreg2;
-            creg = creg2;
+            cmh = cmh2;
         }
-        // back to the complete pending values: w = ((c - h) - V) / inv_den; the last column's lag-1 term goes to lane 0
-        p = ((creg - hreg) - V) * (nrm + CMF_EPS_F + q.l2) + ((lane == 0) ? cmf_lane0(dprev) * g1 : 0.f);
+        if (Sync::PERSIST) { cmf_drain_vmem(); sy.publish(tb >> 6); } // the next row's last pulls wait for these blocks
+        // ---- what is left in front of the edge (or of the segment's end) is less than a block: the same recurrence as a
+        // rolled loop of m steps.  The generic path below costs ~320 cycles a column against ~50 here, and in the persistent
+        // pipeline the rows' tails run strictly one after the other.  C carries c - h in window form beside V (bit copies:
+        // see cmh above); afterwards the window is turned back so that lane j holds the column with t % 64 == j again.
+        const int t_lim = nfull < t_stop ? nfull : t_stop;
+        const int m = t_lim - tb; // < 64
+        const float den = nrm + CMF_EPS_F + q.l2;
+        if (m > 0) {
+            float cmh2 = (hahead * nrm - q.l1) * inv_den - hahead;
+            asm volatile("" : "+v"(cmh2));
+            float vnr = cmf_wave_rol1(fmaf(-inv_den, pn, cmh2));
+            float c2r = cmf_wave_rol1(cmh2);
+            float C = cmh;
+            float mhrot = -hreg;
+            float dvec = 0.f;
+            float d;
+            asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(fmaf(kappa, dprev, V)), "v"(mhrot));
+#pragma nounroll
+            for (int j = 0; j < m; ++j) {
+                const float ps = cmf_wave_shl1(V, vnr);
+                const float s_d = cmf_lane0(d);
+                V = fmaf(s_d, gsn, ps);
+                dvec = (lane == j) ? s_d : dvec;
+                mhrot = cmf_wave_rol1(mhrot);
+                vnr = cmf_wave_rol1(vnr);
+                C = cmf_wave_shl1(C, c2r);
+                c2r = cmf_wave_rol1(c2r);
+                dprev = d;
+                asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(cmf_fma_opaque(kappa, dprev, ps)), "v"(mhrot)); // (the last one is not used)
+            }
+            const float pw = (C - V) * den + ((lane == 0) ? cmf_lane0(dprev) * g1 : 0.f); // lane i: column tb + m + i
+            const int src = ((lane - m) & 63) * 4;
+            p = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, pw)));
+            grot0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, g)));
+            hnew0 = (lane < m) ? hreg + dvec : 0.f;
+            dreg0 = (lane < m) ? dvec : 0.f;
+            t_first = tb + m;
+        } else {
+            // back to the complete pending values: w = ((c - h) - V) / inv_den; the last column's lag-1 term goes to lane 0
+            p = (cmh - V) * den + ((lane == 0) ? cmf_lane0(dprev) * g1 : 0.f);
+            t_first = tb;
+        }
     }
-    // ---- generic path (right-edge columns, hals.jl:136, and what is left of the last block): lane j
+    // ---- generic path (right-edge columns, hals.jl:136, and rows too short for the fast path): lane j
     // holds the column t' with t' % 64 == j; the taps rotate instead of the window.
-    if (tb >= t_stop) {
+    if (t_first >= t_stop) {
+        if (t_first > tb && tb + lane < t_first) { // (L = 1: no edge) the partial block closed the row
+            Hrow[tb + lane] = hnew0;
+            q.H[(size_t)(q.PADL + tb + lane) * q.K32 + k] = hnew0;
+            sy.store_d(q.D + tb + lane, dreg0);
+        }
         // segment ends on a block boundary: hand the pending window (same-row pushes applied) to the
         // launch that continues this row
         if (t_stop < q.Tl) Prow[tb + lane] = p;
+        if (Sync::PERSIST) { cmf_drain_vmem(); sy.publish((t_stop + 63) >> 6); }
         return;
     }
-    float grot = g;
-    float hnew = 0.f, dreg = 0.f;
-    for (int t = tb; t < t_stop; ++t) {
+    if (Sync::PERSIST) // the rest of the row runs on complete P blocks only
+        for (int c = (tb >> 6) + 2; c <= ((t_stop + 63) >> 6) + 1; ++c)
+            if (!sy.gate(c)) return;
+    float grot = grot0;
+    float hnew = hnew0, dreg = dreg0;
+    // closes column t: lane t % 64 takes the column's results and the pending value of column t + 64; whole blocks are
+    // stored (and, in the persistent pipeline, published)
+    auto close_column = [&](int t, float x, float d) {
         const int idx = t & 63;
-        const float s_p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), idx));
-        const float s_h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg), idx));
-        float x, d;
-        if (t < nfull) {
-            x = fmaxf((s_h * nrm - s_p - q.l1) * inv_den, 0.f);
-            d = x - s_h;
-            p = fmaf(d, grot, p);
-        } else {
-            const float *ge = q.GE + (((size_t)k * q.ne + (t - nfull)) * q.K32 + k) * E + (L - 1);
-            const float nrm_e = ge[0];
-            x = fmaxf((s_h * nrm_e - s_p - q.l1) / (nrm_e + CMF_EPS_F + q.l2), 0.f);
-            d = x - s_h;
-            const int e = (lane - t) & 63;
-            const float ge_l = (e >= 1 && e < L) ? ge[e] : 0.f;
-            p = fmaf(d, ge_l, p);
-        }
         if (lane == idx) { hnew = x; dreg = d; p = pn; }
-        grot = cmf_wave_ror1(grot);
         if (idx == 63 || t == t_stop - 1) {
             const int t0 = t - idx;
             if (t0 + lane < q.Tl) {
                 Hrow[t0 + lane] = hnew;
                 q.H[(size_t)(q.PADL + t0 + lane) * q.K32 + k] = hnew;
-                q.D[t0 + lane] = dreg;
+                sy.store_d(q.D + t0 + lane, dreg);
             }
+            sy.stamp(t0 >> 6);
             if (idx == 63) {
-                pn = Prow[t0 + 128 + lane];
+                if (Sync::PERSIST) { cmf_drain_vmem(); sy.publish((t0 >> 6) + 1); }
+                pn = sy.load_p(Prow + t0 + 128 + lane);
                 hreg = Hrow[t0 + 64 + lane];
             }
         }
+    };
+    int t = t_first;
+    for (; t < t_stop && t < nfull; ++t) { // full-window columns of rows too short for the fast path
+        const int idx = t & 63;
+        const float s_p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), idx));
+        const float s_h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg), idx));
+        const float x = fmaxf((s_h * nrm - s_p - q.l1) * inv_den, 0.f);
+        const float d = x - s_h;
+        p = fmaf(d, grot, p);
+        close_column(t, x, d);
+        grot = cmf_wave_ror1(grot);
+    }
+    // edge columns: truncated windows with their own norm and taps (GE), fetched one column ahead -- from LDS in the
+    // persistent kernel: read from memory at their point of use they put two round trips into every edge column
+    float nrm_n = 0.f, inv_n = 0.f, gel_n = 0.f;
+    auto edge_fetch = [&](int tt) {
+        const int e = (lane - tt) & 63;
+        if (q.edge_lds) {
+            const float *ge = q.edge_lds + (tt - nfull) * L;
+            nrm_n = ge[0];
+            inv_n = q.edge_lds[q.ne * L + (tt - nfull)];
+            gel_n = (e >= 1 && e < L) ? ge[e] : 0.f;
+        } else {
+            const float *ge = q.GE + (((size_t)k * q.ne + (tt - nfull)) * q.K32 + k) * E + (L - 1);
+            nrm_n = ge[0];
+            inv_n = 1.0f / (nrm_n + CMF_EPS_F + q.l2);
+            gel_n = (e >= 1 && e < L) ? ge[e] : 0.f;
+        }
+    };
+    if (t < t_stop) edge_fetch(t);
+    for (; t < t_stop; ++t) {
+        const int idx = t & 63;
+        const float nrm_e = nrm_n, inv_e = inv_n, ge_l = gel_n;
+        if (t + 1 < t_stop) edge_fetch(t + 1);
+        const float s_p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), idx));
+        const float s_h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg), idx));
+        const float x = fmaxf((s_h * nrm_e - s_p - q.l1) * inv_e, 0.f);
+        const float d = x - s_h;
+        p = fmaf(d, ge_l, p);
+        close_column(t, x, d);
     }
     if (t_stop < q.Tl) Prow[t_stop + lane] = p; // (t_stop is a multiple of 64 here) window for the next launch
+    if (Sync::PERSIST) { cmf_drain_vmem(); sy.publish((t_stop + 63) >> 6); }
 }
 
 // Cross-row push of row k's changes: PT[k'][t'] += sum_e D[t'-e] * taps(t'-e)[k][k'][e] for k' > k.
@@ -1978,7 +2153,7 @@ __global__ __launch_bounds__(256) void hals_h_stage_kernel(HalsStageParams sp)
         if (!hals_segment(sp, k, sp.stage - sp.lag * k, &q.t_begin, &q.t_end)) return;
         q.k = k;
         q.D = sp.Dall + (size_t)k * q.TPp;
-        hals_h_row_sweep(q, threadIdx.x);
+        hals_h_row_sweep(q, threadIdx.x, HalsNoSync());
     } else {
         const int k = (bx - sp.K) / sp.CB, cb = (bx - sp.K) % sp.CB;
         const int kp = k + 1 + blockIdx.y;
@@ -1990,6 +2165,147 @@ __global__ __launch_bounds__(256) void hals_h_stage_kernel(HalsStageParams sp)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The H sweep as ONE persistent launch (round 2; replaces the ~200 stage launches when the grid fits the chip).
+//   workgroup k < K          : wave 0 sweeps row k from column 0 to Tl (hals_h_row_sweep with HalsFlagSync);
+//   workgroup K + (k-1)P + j : puller j of row k >= 1: for its blocks b = j, j + P, ... (64 columns each) it waits until
+//       row k-1 has published blocks <= b + 1 (rows above k-1 are further ahead by induction), gathers the changes D of
+//       all rows k'' < k around the block, adds  sum_k'' sum_e D[k''][t' - e] * taps(k'', k)[e]  to P[k][block] -- the
+//       cross-row pushes of hals.jl:146 in pull form, so only one workgroup ever writes a given block of P -- and raises
+//       its flag.  The update order is the reference's: a block is swept only after every change that reaches it
+//       (rows above, columns up to L-1 to its right) has been applied.
+// Row k trails row k-1 by about four blocks plus two hand-offs instead of the 640 columns and two launches of the stage
+// pipeline.  The grid, K + (K-1)P workgroups, must be resident at once (the host checks it against the CU count);
+// every wait is bounded (hals_wait_flag).
+// ---------------------------------------------------------------------------------------------
+struct HalsPersistParams {
+    HalsRowParams row;  // k, D filled per workgroup; t_begin = 0, t_end = Tl
+    float *Dall;        // [K32][TPp]
+    int *flags;         // [K prog | K * P pulled | abort], HALS_FLAG_STRIDE ints apart (zeroed before the launch)
+    int *host_status;   // pinned host word: set to 1 when a wait ran out
+    int K, P, nblk;
+    int debug;          // timing experiments only: 1 = no gating, 2 = pullers skip their work
+    unsigned long long *stamps; // debug: [K][nblk] sweeper block-end times, then [K][nblk][4] puller phase times; or NULL
+};
+
+__global__ __launch_bounds__(1024) void hals_h_persist_kernel(HalsPersistParams pp)
+{
+    extern __shared__ float hp_smem[];
+    const int tid = threadIdx.x;
+    const int K = pp.K, P = pp.P, nblk = pp.nblk;
+    int *prog = pp.flags;
+    int *pulled = pp.flags + (size_t)K * HALS_FLAG_STRIDE;
+    int *abort_word = pp.flags + (size_t)(K + K * P) * HALS_FLAG_STRIDE;
+    const HalsRowParams &r = pp.row;
+    if ((int)blockIdx.x < K) { // ---- sweeper of row k
+        if (tid >= 64) return;
+        const int k = blockIdx.x;
+        HalsRowParams q = r;
+        q.k = k;
+        q.D = pp.Dall + (size_t)k * q.TPp;
+        q.t_begin = 0;
+        q.t_end = q.Tl;
+        {   // this row's edge taps -> LDS (hp_smem is sized for the pullers; ne * L floats fit: L <= 64)
+            const int E = 2 * q.L - 1;
+            for (int idx = tid; idx < q.ne * q.L; idx += 64) {
+                const int i = idx / q.L, e = idx - i * q.L;
+                hp_smem[idx] = q.GE[(((size_t)k * q.ne + i) * q.K32 + k) * E + (q.L - 1) + e];
+            }
+            for (int i = tid; i < q.ne; i += 64) // and 1 / (norm + eps + l2) of every edge column
+                hp_smem[q.ne * q.L + i] = 1.0f / (q.GE[(((size_t)k * q.ne + i) * q.K32 + k) * E + (q.L - 1)] + CMF_EPS_F + q.l2);
+            q.edge_lds = q.ne > 0 ? hp_smem : nullptr;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        HalsFlagSync sy;
+        sy.pulled = (k > 0 && P > 0 && pp.debug != 1) ? pulled + (size_t)k * P * HALS_FLAG_STRIDE : nullptr;
+        sy.prog = prog + (size_t)k * HALS_FLAG_STRIDE;
+        sy.abort_word = abort_word;
+        sy.host_status = pp.host_status;
+        sy.P = P;
+        sy.nblk = nblk;
+        sy.stamps = pp.stamps ? pp.stamps + (size_t)k * nblk : nullptr;
+        hals_h_row_sweep(q, tid, sy);
+        return;
+    }
+    // ---- puller j of row k
+    if (pp.debug == 1) return;
+    const int u = blockIdx.x - K;
+    const int k = 1 + u / P, j = u % P;
+    const int L = r.L, E = 2 * L - 1, W = 64 + 2 * (L - 1), K32 = r.K32, Tl = r.Tl, TPp = r.TPp;
+    float *Gs = hp_smem;               // [k][E]: taps of source row k'' onto row k
+    float *Ds = Gs + (size_t)(K - 1) * E; // [k][W]: D of the source rows around the block
+    float *part = Ds + (size_t)(K - 1) * W; // [16][64]
+    __shared__ int ok_s;
+    for (int idx = tid; idx < k * E; idx += 1024) {
+        const int k2 = idx / E, e = idx - k2 * E;
+        Gs[idx] = r.GW[((size_t)k2 * K32 + k) * E + e];
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const int *prog_up = prog + (size_t)(k - 1) * HALS_FLAG_STRIDE;
+    int *my_flag = pulled + ((size_t)k * P + j) * HALS_FLAG_STRIDE;
+    float *Prow = r.PT + (size_t)k * TPp;
+    for (int b = j; b < nblk; b += P) {
+        const int need = (b + 2 < nblk) ? b + 2 : nblk;
+        if (tid == 0) ok_s = hals_wait_flag(prog_up, need, abort_word, pp.host_status) ? 1 : 0;
+        __syncthreads(); // also: everyone is done with Ds / part of the previous block
+        if (!ok_s) return;
+        unsigned long long *st = pp.stamps ? pp.stamps + (size_t)K * nblk + ((size_t)k * nblk + b) * 4 : nullptr;
+        if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
+        if (pp.debug == 2) { if (tid == 0) cmf_store_sc1(my_flag, b + 1); continue; }
+        const int w0 = b * 64 - (L - 1);
+        for (int base = 0; base < k * W; base += 4 * 1024) { // four loads in flight per thread, then the LDS writes
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 1024 + tid;
+                const int k2 = idx / W, c = idx - k2 * W, t = w0 + c;
+                v[u] = (idx < k * W && t >= 0 && t < Tl) ? cmf_load_sc1(pp.Dall + (size_t)k2 * TPp + t) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 1024 + tid;
+                if (idx < k * W) Ds[idx] = v[u];
+            }
+        }
+        const int tp = b * 64 + lane;
+        const float p0 = (wave == 0) ? Prow[tp] : 0.f; // written by the kernel before this one (PT is padded to whole blocks)
+        __syncthreads();
+        if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
+        float s = 0.f;
+        if (b * 64 + 64 + (L - 1) <= r.t_edge0) { // no source column of this block lies in the right edge
+            for (int k2 = wave; k2 < k; k2 += 16) {
+                const float *dsr = Ds + (size_t)k2 * W + lane + (L - 1);
+                const float *gr = Gs + (size_t)k2 * E + (L - 1);
+                for (int e = -(L - 1); e <= L - 1; ++e) s = fmaf(dsr[-e], gr[e], s); // source column t = tp - e
+            }
+        } else { // truncated windows of the last L-1 source columns (hals.jl:136): per-column taps in GE
+            for (int k2 = wave; k2 < k; k2 += 16) {
+                const float *dsr = Ds + (size_t)k2 * W + lane + (L - 1);
+                const float *gr = Gs + (size_t)k2 * E + (L - 1);
+                for (int e = -(L - 1); e <= L - 1; ++e) {
+                    const int t = tp - e;
+                    if (t < 0 || t >= Tl) continue;
+                    const float tap = (t < r.t_edge0) ? gr[e] : r.GE[(((size_t)k2 * r.ne + (t - r.t_edge0)) * K32 + k) * E + (L - 1) + e];
+                    s = fmaf(dsr[-e], tap, s);
+                }
+            }
+        }
+        part[wave * 64 + lane] = s;
+        __syncthreads();
+        if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
+        if (wave == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) tot += part[w * 64 + lane]; // fixed order: reproducible
+            cmf_store_sc1(Prow + tp, p0 + tot); // 64 lanes, two whole 128-byte lines in one instruction
+            cmf_drain_vmem();
+            if (lane == 0) cmf_store_sc1(my_flag, b + 1);
+            if (st && lane == 0) st[3] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+}
 
 // =============================================================================================
 // PGD rule (src/algs/pgd.jl) on the same contractions:

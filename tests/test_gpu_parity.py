@@ -390,34 +390,34 @@ def test_hals_fit_against_oracle(cmf, oracle):
 
 def test_hals_config5_full_size(cmf, config2):
     """BASELINE config 5 (N=2000, T=50000, K=32, L=20, alg=:hals): monotone loss, exact zeros, bitwise
-    repeatability, and agreement of the pipelined row sweep across segment sizes."""
+    repeatability, and agreement of the H sweep's pipelines: the persistent one (default; 4 and 2 puller workgroups per
+    row) and the stage pipeline across segment sizes and schedules."""
     import os
 
     data, W0, H0 = config2
-    runs = []
-    for seg in ("256", "1024", "384/lag3"):
-        os.environ["CMF_HALS_SEG"] = seg.split("/")[0]
-        if seg.endswith("lag3"):
-            os.environ["CMF_HALS_LAG"] = "3"  # the unshifted three-stage schedule of round 1
+    runs = {}
+    for name, env in (("persist", {}), ("persist2", {"CMF_HALS_PERSIST": "2"}),
+                      ("stage256", {"CMF_HALS_PERSIST": "0", "CMF_HALS_SEG": "256"}),
+                      ("stage1024", {"CMF_HALS_PERSIST": "0", "CMF_HALS_SEG": "1024"}),
+                      ("stage384lag3", {"CMF_HALS_PERSIST": "0", "CMF_HALS_SEG": "384", "CMF_HALS_LAG": "3"})):
+        os.environ.update(env)
         try:
             r = cmf.fit_cnmf(data, L=20, K=32, alg=":hals", max_itr=3, check_convergence=False, W_init=W0, H_init=H0)
-            if seg == "256":  # same configuration twice: bit for bit
+            if name in ("persist", "stage256"):  # same configuration twice: bit for bit
                 r2 = cmf.fit_cnmf(data, L=20, K=32, alg=":hals", max_itr=3, check_convergence=False, W_init=W0, H_init=H0)
                 np.testing.assert_array_equal(r.loss_hist, r2.loss_hist)
                 np.testing.assert_array_equal(r.H, r2.H)
         finally:
-            os.environ.pop("CMF_HALS_SEG", None)
-            os.environ.pop("CMF_HALS_LAG", None)
-        runs.append(r)
-    a, b, c = runs
-    np.testing.assert_allclose(a.loss_hist, c.loss_hist, rtol=1e-6)  # both pipeline schedules keep the reference's order
-    assert frob_rel(a.H, c.H) < 1e-4
+            for key in env:
+                os.environ.pop(key, None)
+        runs[name] = r
+    a = runs["persist"]
     assert np.all(np.diff(a.loss_hist) < 0) and a.loss_hist[-1] < 0.25
-    # the pipeline never changes the order of the updates; the segment size only changes how the pushed sums
-    # are associated at segment boundaries (rounding level)
-    np.testing.assert_allclose(a.loss_hist, b.loss_hist, rtol=1e-6)
-    assert frob_rel(a.H, b.H) < 1e-4
     assert a.W.min() == 0.0 and a.H.min() == 0.0               # clamp at 0 (hals.jl:110,153)
+    # no pipeline changes the order of the updates; they differ in how the cross-row sums are associated (rounding level)
+    for name, r in runs.items():
+        np.testing.assert_allclose(a.loss_hist, r.loss_hist, rtol=1e-6, err_msg=name)
+        assert frob_rel(a.H, r.H) < 1e-4, name
 
 
 def test_evaluate_test_and_sweep(cmf, oracle):
