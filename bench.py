@@ -356,12 +356,15 @@ def main():
 
     if rank == 0 and alg == "hals":
         # The dominant part of a HALS iteration is the K*T strictly ordered H entry updates (hals.jl:121-154), run as a
-        # software pipeline over the rows (hals_h_stage_kernel).  Its bound is dependency latency, not MFMA or HBM: entry
+        # software pipeline over the rows (one persistent launch, hals_h_persist_kernel: a sweeper wave per row, puller
+        # workgroups applying the cross-row terms, flags in memory between them; CMF_HALS_PERSIST=0 selects the older
+        # one-launch-per-stage form).  Its bound is dependency latency, not MFMA or HBM: entry
         # (k, t) needs (k, t-1) and the push of (k-1, t+L-1), so the critical path is T + (K-1)(L-1) dependent steps.  A
         # step of the sweep is 9 single-wave instructions whose chain is one FMA and one MAX; in isolation it issues in
         # 43 cycles (tools/valu_latency.hip, profiles/).  achieved = critical-path steps per second over the measured
-        # pipeline span; peak = one step per 43 cycles at 2.4 GHz.  What separates them is structural: two stages of
-        # pipeline fill per row and ~3 us of launch + prologue per stage.
+        # pipeline span; peak = one step per 43 cycles at 2.4 GHz.  What separates them: a row runs ~11 us
+        # behind the row above (five 64-column blocks plus two flag hand-offs) where 19 columns would do, and the rows'
+        # tails (edge columns) run one after the other.
         pipe_ms, n_pipe = hals_spans.get("hals_h_pipeline", (0.0, 0))
         wsw_ms, _ = hals_spans.get("hals_w_sweep", (0.0, 0))
         STEP_CYCLES, CLK = 43.0, 2.4e9
@@ -370,13 +373,14 @@ def main():
         ach_steps = crit_steps / (pipe_ms * 1e-3) if pipe_ms else 0.0
         out["roofline_mfma_kernel"] = out["roofline"]
         out["roofline"] = {"bound": "dependency-latency",
-                           "kernel": "hals_h_stage_kernel row pipeline (K*T ordered entry updates of H, hals.jl:121-154)",
+                           "kernel": ("hals_h_stage_kernel" if os.environ.get("CMF_HALS_PERSIST") == "0" else "hals_h_persist_kernel")
+                                     + " row pipeline (K*T ordered entry updates of H, hals.jl:121-154)",
                            "achieved": ach_steps, "peak": peak_steps, "unit": "critical-path steps/s", "frac": ach_steps / peak_steps,
                            "traffic": None, "critical_path_steps": crit_steps, "step_cycles_model": STEP_CYCLES,
                            "pipeline_span_ms": pipe_ms, "pipeline_spans_timed": n_pipe, "pipeline_floor_ms": 1e3 * crit_steps / peak_steps,
                            "share_of_step": pipe_ms / (1e3 * dt / args.steps) if dt else None,
                            "w_sweep_ms": wsw_ms,
-                           "timing": "HIP event pair around the whole stage loop inside the timed region (option profile)"}
+                           "timing": "HIP event pair around the whole pipeline inside the timed region (option profile)"}
 
     if rank == 0 and alg == "mult":
         # BASELINE.json's metric also asks for the achieved HBM rate.  Algorithmic bytes per iteration

@@ -1438,7 +1438,6 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
     q.PT = h->hals_PT; q.H = h->H; q.Ht = h->Ht; q.D = h->hals_D; q.GW = h->hals_GW; q.GE = h->hals_GE;
     q.Tl = d.Tl; q.L = d.L; q.K32 = d.K32; q.TP = d.TP; q.TPp = h->hals_TPp; q.PADL = d.PADL; q.ne = h->hals_ne; q.t_edge0 = h->hals_t_edge0;
     q.l1 = (float)l1H; q.l2 = (float)l2H;
-    q.edge_lds = nullptr;
     if (h->hals_pullers > 0) { // the whole sweep as one persistent launch (hals_h_persist_kernel)
         HalsPersistParams pp;
         pp.row = q;

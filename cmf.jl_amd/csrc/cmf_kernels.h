@@ -1755,7 +1755,6 @@ struct HalsRowParams {
     int k, Tl, L, K32, TP, TPp, PADL, ne, t_edge0;
     int t_begin, t_end; // column segment of this launch (t_begin multiple of 64; t_end multiple of 64 or Tl)
     float l1, l2;
-    const float *edge_lds; // persistent kernel: this row's own edge taps GE[k][i][k][e >= 0] as [ne][L], then 1/(norm+eps+l2) as [ne], in LDS; else NULL
 };
 
 // lane i <- lane i+1; lane 63 keeps `fill`
@@ -1810,8 +1809,11 @@ __device__ __forceinline__ bool hals_wait_flag(const int *flag, int need, int *a
 #pragma nounroll
     for (int n = 0; n < HALS_POLL_LIMIT; ++n) {
         const int v = cmf_load_sc1(flag), a = cmf_load_sc1(abort_word); // both in flight together: one round trip per poll
-        if (v >= need) return true;
-        if (a != 0) return false;
+        // both values are looked at before either branch: a return with the second load still pending (in the compiler's
+        // books) makes it wait for EVERYTHING outstanding -- the publish store just issued, a microsecond -- at the next
+        // write of that load's register in the caller's hot loop (measured: 1.36 -> 1.72 us per block, by register luck)
+        const bool done = (v >= need), dead = (a != 0);
+        if ((int)done | (int)dead) return done;
         __builtin_amdgcn_s_sleep(2);
     }
     cmf_store_sc1(abort_word, 1);
@@ -1836,6 +1838,8 @@ struct HalsFlagSync {
     int *prog;         // this row's progress flag
     int *abort_word, *host_status;
     int P, nblk;
+    // this row's own edge taps GE[k][i][k][e >= 0] as [ne][L], then 1 / (norm + eps + l2) as [ne], in LDS
+    const __attribute__((address_space(3))) float *edge;
     unsigned long long *stamps; // debug (CMF_HALS_STAMPS): s_memtime at the end of every block of this row, or NULL
     __device__ __forceinline__ void stamp(int blk) const { if (stamps && threadIdx.x == 0) stamps[blk] = __builtin_amdgcn_s_memrealtime(); }
     __device__ __forceinline__ float load_p(const float *p) const { return cmf_load_sc1(p); }
@@ -1901,6 +1905,17 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
         float V = fmaf(-inv_den, w, cmh);
         float hahead = Hrow[tb + 64 + lane]; // H_old one block ahead: loaded a whole block before its first use (a load at
                                              // the top of the block it is needed in puts an L2 round trip into every block's chain)
+        // A block's results are stored half a block after its end (at the middle of the next block): stored at its end,
+        // they are still in flight when the top of the next block waits for its prefetched operands -- vmcnt counts loads
+        // and stores alike -- and every block pays part of a store round trip.
+        float hnew_prev = 0.f, dvec_prev = 0.f;
+        int tb_prev = -1;
+        auto store_prev = [&]() {
+            if (tb_prev < 0) return;
+            Hrow[tb_prev + lane] = hnew_prev;
+            q.H[(size_t)(q.PADL + tb_prev + lane) * q.K32 + k] = hnew_prev;
+            sy.store_d(q.D + tb_prev + lane, dvec_prev);
+        };
         for (; tb + 64 <= nfull && tb + 64 <= t_stop; tb += 64) {
             // persistent pipeline: the flag of P block +2 is read now and looked at half a block later, together with the
             // completion of the previous block's stores -- neither round trip sits in the column chain
@@ -1929,31 +1944,37 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
                 dprev = d;
                 if (j + 1 < 64) // hals.jl:152-153 as a change: x - h_old = max(q, 0) - h_old = max(q - h_old, -h_old)
                     asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(fmaf(kappa, dprev, ps)), "v"(mhrot));
-                if (Sync::PERSIST && j == 31) {
-                    cmf_drain_vmem();        // the previous block's D (and H) stores have completed
-                    sy.publish(tb >> 6);     // blocks < tb / 64 are in memory
-                    aborted = !sy.gate_check((tb >> 6) + 2, seen); // (no exit from inside the unrolled block)
-                    pn2 = sy.load_p(Prow + tb + 128 + lane);
+                if (j == 31) {
+                    if (Sync::PERSIST) {
+                        cmf_drain_vmem();                           // the stores issued at the middle of the block before have completed
+                        sy.publish(tb_prev >= 0 ? tb_prev >> 6 : 0); // ... and with them every block before that one
+                    }
+                    if (Sync::PERSIST) aborted = !sy.gate_check((tb >> 6) + 2, seen); // (no exit from inside the unrolled block)
+                    store_prev(); // (after the look at the flag: a use of a loaded value behind stores waits for the stores)
+                    if (Sync::PERSIST) pn2 = sy.load_p(Prow + tb + 128 + lane);
                 }
             }
             if (Sync::PERSIST && aborted) return;
-            const float hnew = hreg + dvec;
-            Hrow[tb + lane] = hnew;
-            q.H[(size_t)(q.PADL + tb + lane) * q.K32 + k] = hnew;
-            sy.store_d(q.D + tb + lane, dvec);
+            hnew_prev = hreg + dvec;
+            dvec_prev = dvec;
+            tb_prev = tb;
             sy.stamp(tb >> 6);
             pn = pn2;
             hreg = hreg2;
             cmh = cmh2;
         }
-        if (Sync::PERSIST) { cmf_drain_vmem(); sy.publish(tb >> 6); } // the next row's last pulls wait for these blocks
         // ---- what is left in front of the edge (or of the segment's end) is less than a block: the same recurrence as a
         // rolled loop of m steps.  The generic path below costs ~320 cycles a column against ~50 here, and in the persistent
         // pipeline the rows' tails run strictly one after the other.  C carries c - h in window form beside V (bit copies:
         // see cmh above); afterwards the window is turned back so that lane j holds the column with t % 64 == j again.
+        store_prev(); // the last whole block
         const int t_lim = nfull < t_stop ? nfull : t_stop;
         const int m = t_lim - tb; // < 64
         const float den = nrm + CMF_EPS_F + q.l2;
+        // the whole blocks are published (the next row's last pulls wait for them) once their stores have had time to
+        // complete: 40 columns into the partial block, or here if there is none that long
+        const int pub_at = (m > 40) ? 40 : -1;
+        if (Sync::PERSIST && pub_at < 0) { cmf_drain_vmem(); sy.publish(tb >> 6); }
         if (m > 0) {
             float cmh2 = (hahead * nrm - q.l1) * inv_den - hahead;
             asm volatile("" : "+v"(cmh2));
@@ -1976,6 +1997,7 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
                 c2r = cmf_wave_rol1(c2r);
                 dprev = d;
                 asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(cmf_fma_opaque(kappa, dprev, ps)), "v"(mhrot)); // (the last one is not used)
+                if (Sync::PERSIST && j == pub_at) { cmf_drain_vmem(); sy.publish(tb >> 6); }
             }
             const float pw = (C - V) * den + ((lane == 0) ? cmf_lane0(dprev) * g1 : 0.f); // lane i: column tb + m + i
             const int src = ((lane - m) & 63) * 4;
@@ -2009,6 +2031,10 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
             if (!sy.gate(c)) return;
     float grot = grot0;
     float hnew = hnew0, dreg = dreg0;
+    // one block ahead of their use (a load at the block boundary would sit in the chain): H_old of the next block and the
+    // pending values of the block after it
+    float hnext = Hrow[(t_first & ~63) + 64 + lane];
+    float pnn = sy.load_p(Prow + (t_first & ~63) + 128 + lane);
     // closes column t: lane t % 64 takes the column's results and the pending value of column t + 64; whole blocks are
     // stored (and, in the persistent pipeline, published)
     auto close_column = [&](int t, float x, float d) {
@@ -2022,10 +2048,11 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
                 sy.store_d(q.D + t0 + lane, dreg);
             }
             sy.stamp(t0 >> 6);
-            if (idx == 63) {
-                if (Sync::PERSIST) { cmf_drain_vmem(); sy.publish((t0 >> 6) + 1); }
-                pn = sy.load_p(Prow + t0 + 128 + lane);
-                hreg = Hrow[t0 + 64 + lane];
+            if (idx == 63) { // (no publish here: the row's last one follows within a few microseconds, and a drain costs one)
+                pn = pnn;
+                hreg = hnext;
+                pnn = sy.load_p(Prow + t0 + 192 + lane);
+                hnext = Hrow[t0 + 128 + lane];
             }
         }
     };
@@ -2043,24 +2070,27 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
     // edge columns: truncated windows with their own norm and taps (GE), fetched one column ahead -- from LDS in the
     // persistent kernel: read from memory at their point of use they put two round trips into every edge column
     float nrm_n = 0.f, inv_n = 0.f, gel_n = 0.f;
+    bool gel_ok = false; // (the select is applied where the tap is used, so that the fetch is not waited for at once)
     auto edge_fetch = [&](int tt) {
         const int e = (lane - tt) & 63;
-        if (q.edge_lds) {
-            const float *ge = q.edge_lds + (tt - nfull) * L;
-            nrm_n = ge[0];
-            inv_n = q.edge_lds[q.ne * L + (tt - nfull)];
-            gel_n = (e >= 1 && e < L) ? ge[e] : 0.f;
+        if constexpr (Sync::PERSIST) {
+            const int i = tt - nfull;
+            nrm_n = sy.edge[i * L];
+            inv_n = sy.edge[q.ne * L + i];
+            gel_n = sy.edge[i * L + ((e < L) ? e : 0)]; // (an address inside the table for every lane)
+            gel_ok = (e >= 1 && e < L);
         } else {
             const float *ge = q.GE + (((size_t)k * q.ne + (tt - nfull)) * q.K32 + k) * E + (L - 1);
             nrm_n = ge[0];
             inv_n = 1.0f / (nrm_n + CMF_EPS_F + q.l2);
             gel_n = (e >= 1 && e < L) ? ge[e] : 0.f;
+            gel_ok = true;
         }
     };
     if (t < t_stop) edge_fetch(t);
     for (; t < t_stop; ++t) {
         const int idx = t & 63;
-        const float nrm_e = nrm_n, inv_e = inv_n, ge_l = gel_n;
+        const float nrm_e = nrm_n, inv_e = inv_n, ge_l = gel_ok ? gel_n : 0.f;
         if (t + 1 < t_stop) edge_fetch(t + 1);
         const float s_p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), idx));
         const float s_h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg), idx));
@@ -2214,11 +2244,11 @@ __global__ __launch_bounds__(1024) void hals_h_persist_kernel(HalsPersistParams 
             }
             for (int i = tid; i < q.ne; i += 64) // and 1 / (norm + eps + l2) of every edge column
                 hp_smem[q.ne * q.L + i] = 1.0f / (q.GE[(((size_t)k * q.ne + i) * q.K32 + k) * E + (q.L - 1)] + CMF_EPS_F + q.l2);
-            q.edge_lds = q.ne > 0 ? hp_smem : nullptr;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
         HalsFlagSync sy;
+        sy.edge = (const __attribute__((address_space(3))) float *)hp_smem;
         sy.pulled = (k > 0 && P > 0 && pp.debug != 1) ? pulled + (size_t)k * P * HALS_FLAG_STRIDE : nullptr;
         sy.prog = prog + (size_t)k * HALS_FLAG_STRIDE;
         sy.abort_word = abort_word;
