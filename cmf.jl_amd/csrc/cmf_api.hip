@@ -1449,6 +1449,7 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
         if (const char *dbg = getenv("CMF_HALS_DEBUG")) { // timing experiments only (results are wrong)
             if (std::strcmp(dbg, "nogate") == 0) pp.debug = 1;  // sweepers alone: no row waits for anything
             if (std::strcmp(dbg, "nopull") == 0) pp.debug = 2;  // pullers raise their flags without doing the work
+            if (std::strcmp(dbg, "stall") == 0) pp.debug = 3;   // pullers leave at once: every sweeper's wait must run out (tests)
         }
         const size_t nflags = (size_t)(d.K + d.K * pp.P + 1) * HALS_FLAG_STRIDE;
         const size_t lds = std::max((size_t)(d.K - 1) * (2 * d.L - 1 + 64 + 2 * (d.L - 1)) + 1024, (size_t)h->hals_ne * (d.L + 1)) * sizeof(float);

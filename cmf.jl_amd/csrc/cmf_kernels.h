@@ -2215,7 +2215,7 @@ struct HalsPersistParams {
     int *flags;         // [K prog | K * P pulled | abort], HALS_FLAG_STRIDE ints apart (zeroed before the launch)
     int *host_status;   // pinned host word: set to 1 when a wait ran out
     int K, P, nblk;
-    int debug;          // timing experiments only: 1 = no gating, 2 = pullers skip their work
+    int debug;          // timing experiments only: 1 = no gating, 2 = pullers skip their work; tests: 3 = pullers leave at once
     unsigned long long *stamps; // debug: [K][nblk] sweeper block-end times, then [K][nblk][4] puller phase times; or NULL
 };
 
@@ -2260,7 +2260,7 @@ __global__ __launch_bounds__(1024) void hals_h_persist_kernel(HalsPersistParams 
         return;
     }
     // ---- puller j of row k
-    if (pp.debug == 1) return;
+    if (pp.debug == 1 || pp.debug == 3) return;
     const int u = blockIdx.x - K;
     const int k = 1 + u / P, j = u % P;
     const int L = r.L, E = 2 * L - 1, W = 64 + 2 * (L - 1), K32 = r.K32, Tl = r.Tl, TPp = r.TPp;

@@ -188,7 +188,12 @@ int cmf_iterate(cmf_handle h, int64_t n_iter, int eval_mode, double l1W, double 
  * order as the reference; clamp at 0 and "+ l2" regularisation as in hals.jl:110,153.
  * Unsharded handles only (the H sweep is sequential along T).  Shape limits of the on-chip sweeps (the reference
  * has none): L <= 64, L * Kpad <= 2048 and K * L <= 2048 (Kpad = K rounded up to 32); cmf_set_option(h, "hals_prepare", 1)
- * allocates the rule's scratch and reports a violation at construction time instead of at the first update. */
+ * allocates the rule's scratch and reports a violation at construction time instead of at the first update.
+ * The H sweep normally runs as one persistent launch whose workgroups (a sweeper per row of H, puller workgroups that
+ * apply the cross-row terms) wait for each other through flags in device memory.  It needs the device to itself for
+ * those ~2 ms: every such wait is bounded (about half a second), and if one runs out -- another process or stream holding
+ * the CUs -- cmf_hals_update_feature_maps returns CMF_ERR_HIP with H partially updated (set the factors again).
+ * Environment CMF_HALS_PERSIST=0 selects the one-launch-per-stage pipeline instead, which has no such requirement. */
 int cmf_hals_update_motifs(cmf_handle h, double l1W, double l2W);
 int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss);
 

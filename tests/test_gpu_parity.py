@@ -831,3 +831,27 @@ def test_medium_sizes_two_iterations(cmf, oracle, N, T, K, L):
     Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=2, check_convergence=False, **kw)
     np.testing.assert_allclose(res.loss_hist, lr, rtol=REL_LOSS)
     assert frob_rel(res.W, Wr) < REL_FACTORS and frob_rel(res.H, Hr) < REL_FACTORS
+
+
+def test_hals_persistent_pipeline_waits_are_bounded(cmf, oracle):
+    """The persistent H pipeline's workgroups wait for each other through flags in memory; a wait that is never satisfied
+    (here: the puller workgroups leave without doing their work, CMF_HALS_DEBUG=stall) must run out, drain the grid and
+    come back as an error -- not hang the device -- and the handle must stay usable."""
+    import os
+
+    data, _, _ = oracle.c_gen_synthetic(N=40, T=600, K=3, L=8, seed=5)
+    W0, H0 = oracle.c_init_rand(data, L=8, K=4, seed=2)
+    rule = cmf.HALSUpdate(data, W0, H0)
+    rule.update_motifs()
+    os.environ["CMF_HALS_DEBUG"] = "stall"
+    try:
+        with pytest.raises(cmf.CMFError, match="HALS H pipeline"):
+            rule.update_feature_maps()
+    finally:
+        os.environ.pop("CMF_HALS_DEBUG", None)
+    rule.upload(W0, H0)  # H was left partially updated: start again from the same factors
+    rule.update_motifs()
+    loss = rule.update_feature_maps()
+    _, _, lh, _ = oracle.c_fit_hals(data, W0, H0, max_itr=1, check_convergence=False)
+    assert abs(loss - lh[1]) <= 1e-4 * lh[1]
+    rule.close()
