@@ -62,3 +62,62 @@ def h_sweep(o, W, H, data, l1, l2):
                 if 0 <= t + e < T:
                     P[k + 1:, t + e] += D[t] * g[k + 1:, e + L - 1]
     return H
+
+
+def h_sweep_pull_pipeline(o, W, H, data, l1, l2, block=8, seed=0):
+    """The same H sweep in the form of the persistent pipeline (hals_h_persist_kernel): rows advance in blocks of
+    `block` columns; before row k sweeps block b, the cross-row terms of that block are PULLED from the changes D of all
+    rows above (one writer per block of P), which is allowed as soon as row k-1 has finished block b+1 (L-1 <= block);
+    which eligible (row, block) runs next is drawn at random: any order the flags permit must give the same H."""
+    K, N, L = W.shape
+    T = H.shape[1]
+    assert L - 1 <= block
+    R = o.tensor_conv(W, H) - data
+    P = o.tensor_transconv(W, R)
+    PW = np.einsum("knl,jnm->lmkj", W, W)
+
+    def taps(k, Lt):
+        g = np.zeros((K, 2 * L - 1))
+        for e in range(-(L - 1), L):
+            for l in range(Lt):
+                if 0 <= l - e < L:
+                    g[:, e + L - 1] += PW[l, l - e, k, :]
+        return g
+
+    tap_cache = {}
+
+    def tap(k, t):  # taps of source column t of row k: truncated window at the right edge (hals.jl:136)
+        Lt = min(L, T - t)
+        key = (k, Lt)
+        if key not in tap_cache:
+            tap_cache[key] = taps(k, Lt)
+        return tap_cache[key]
+
+    H = H.copy()
+    D = np.zeros((K, T))
+    nblk = -(-T // block)
+    done = [0] * K      # blocks swept per row (the sweeper's progress flag)
+    rng = np.random.default_rng(seed)
+    while min(done) < nblk:
+        ready = [k for k in range(K) if done[k] < nblk and (k == 0 or done[k - 1] >= min(done[k] + 2, nblk))]
+        k = int(rng.choice(ready))
+        b = done[k]
+        t0, t1 = b * block, min((b + 1) * block, T)
+        for k2 in range(k):  # the pull: sources of rows above within L-1 columns of the block, in row order
+            for tp in range(t0, t1):
+                for e in range(-(L - 1), L):
+                    t = tp - e
+                    if 0 <= t < T:
+                        P[k, tp] += D[k2, t] * tap(k2, t)[k, e + L - 1]
+        for t in range(t0, t1):  # the sweep of the block (same-row terms pushed ahead as before)
+            g = tap(k, t)
+            nrm = g[k, L - 1]
+            ho = H[k, t]
+            hn = max((ho * nrm - P[k, t] - l1) / (nrm + o.EPS + l2), 0.0)
+            D[k, t] = hn - ho
+            H[k, t] = hn
+            for e in range(1, L):
+                if t + e < T:
+                    P[k, t + e] += D[k, t] * g[k, e + L - 1]
+        done[k] += 1
+    return H

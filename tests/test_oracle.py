@@ -221,7 +221,7 @@ def test_hals_c_vs_numpy(oracle, reg):
 def test_hals_gram_form_equals_residual_form(oracle):
     """The algebra behind the GPU HALS kernels: sweeping on G = resid*H_unfold' / P = transconv(W, resid)
     with Gram updates reproduces the reference's residual sweeps exactly (incl. the right-edge truncation)."""
-    from hals_gram_form import h_sweep, w_sweep
+    from hals_gram_form import h_sweep, h_sweep_pull_pipeline, w_sweep
 
     data, _, _ = oracle.c_gen_synthetic(N=12, T=40, K=3, L=6, seed=3)
     W0, H0 = oracle.c_init_rand(data, L=5, K=3, seed=0)
@@ -233,6 +233,9 @@ def test_hals_gram_form_equals_residual_form(oracle):
         Hn = H.copy()
         oracle.hals_update_feature_maps(rule, data, W, Hn, l1H=l1, l2H=l2)
         np.testing.assert_allclose(h_sweep(oracle, W, H0, data, l1, l2), Hn, rtol=1e-10, atol=1e-13)
+        # ... and so does the pull form of the persistent pipeline, in whatever order its flags let the rows advance
+        for seed in (0, 1, 2):
+            np.testing.assert_allclose(h_sweep_pull_pipeline(oracle, W, H0, data, l1, l2, block=8, seed=seed), Hn, rtol=1e-10, atol=1e-13)
 
 
 def test_pgd_masked_loss_gradient_and_reduction(oracle):
