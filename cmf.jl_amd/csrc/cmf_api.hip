@@ -97,8 +97,8 @@ struct cmf_handle_s {
 
     // HALS scratch (allocated on first use)
     bool hals_ready = false;
-    int hals_NpH = 0, hals_TPp = 0, hals_ne = 0, hals_t_edge0 = 0, hals_nch = 1, hals_clen = 6;
-    float *hals_HuT = nullptr, *hals_hhslabs = nullptr, *hals_HH = nullptr, *hals_PT = nullptr, *hals_D = nullptr;
+    int hals_NpH = 0, hals_NpC = 0, hals_TPp = 0, hals_ne = 0, hals_t_edge0 = 0, hals_nch = 1, hals_clen = 6;
+    float *hals_HX = nullptr, *hals_cslabs = nullptr, *hals_C = nullptr, *hals_HH = nullptr, *hals_PT = nullptr, *hals_D = nullptr;
     float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr;
     int hals_seg = 256, hals_nseg = 1;      // column segments of the pipelined H sweep
     int hals_pullers = 0;                   // persistent H pipeline: puller workgroups per row (0 = stage pipeline)
@@ -263,7 +263,7 @@ static void destroy_impl(cmf_handle_s *h)
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
                       h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3],
-                      h->gram_numden_h, h->pgd_gradH, h->M, h->MT, h->hals_HuT, h->hals_hhslabs, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE};
+                      h->gram_numden_h, h->pgd_gradH, h->M, h->MT, h->hals_HX, h->hals_cslabs, h->hals_C, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE};
     for (float *p : fbufs)
         if (p) (void)hipFree(p);
     for (int v = 0; v < 2; ++v)
@@ -1334,20 +1334,23 @@ static int hals_ensure(cmf_handle_s *h)
     h->hals_TPp = (int)rup(d.Tl, 64) + 256;
     h->hals_t_edge0 = std::max(0, d.Tl - d.L + 1);
     h->hals_ne = d.Tl - h->hals_t_edge0;
-    {   // time chunks of the H_unfold Gram launch: fill the resident wave slots
+    h->hals_NpC = (int)rup(d.K32, 128); // pitch of H as the X operand of its own lag correlations (compute_hh)
+    {   // time chunks of that launch: fill the resident wave slots
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, h->device));
         const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const int slots = 4 * n_cu * (h->hxt_LP <= 5 ? 2 : 1);
-        int64_t wpc = (int64_t)(h->hals_NpH / 32) * d.KB * h->hxt_groups;
+        int64_t wpc = (int64_t)(h->hals_NpC / 32) * d.KB * h->hxt_groups;
         int nch = (int)std::max<int64_t>(1, (slots + wpc / 2) / wpc);
         int64_t clen = rup((d.Tl + nch - 1) / nch, 6 * h->hxt_LP);
         h->hals_clen = (int)clen;
         h->hals_nch = (int)((d.Tl + clen - 1) / clen);
     }
     const size_t LKN = (size_t)d.L * d.K32 * h->hals_NpH;
-    CMFTRY(dalloc_zero(&h->hals_HuT, (size_t)d.TP * h->hals_NpH));
-    CMFTRY(dalloc_zero(&h->hals_hhslabs, (size_t)h->hals_nch * LKN));
+    const size_t LKC = (size_t)d.L * d.K32 * h->hals_NpC;
+    CMFTRY(dalloc_zero(&h->hals_HX, (size_t)d.TP * h->hals_NpC));
+    CMFTRY(dalloc_zero(&h->hals_cslabs, (size_t)hxt_nslabs(h->hals_nch) * LKC));
+    CMFTRY(dalloc_zero(&h->hals_C, LKC));
     CMFTRY(dalloc_zero(&h->hals_HH, LKN));
     CMFTRY(dalloc_zero(&h->hals_PT, (size_t)d.K32 * h->hals_TPp));
     CMFTRY(dalloc_zero(&h->hals_D, (size_t)d.K32 * h->hals_TPp)); // per row: rows run concurrently
@@ -1384,6 +1387,21 @@ static int hals_ensure(cmf_handle_s *h)
     return CMF_OK;
 }
 
+// HH = H_unfold * H_unfold' (hals.jl:56-60: the row norms are its diagonal) from the lag correlations of H with itself:
+// one C2 contraction on K32 columns, then an assembly pass with the right-end corrections (hals_hh_kernel)
+static int compute_hh(cmf_handle_s *h)
+{
+    const CmfDims &d = h->d;
+    hipLaunchKernelGGL(hals_hx_kernel, dim3(1024), dim3(256), 0, h->stream, h->H, h->hals_HX, d.TP, d.K32, h->hals_NpC);
+    KCHK("hals_hx_kernel");
+    CMFTRY(launch_hxt_on(h, h->hals_HX, h->hals_HX, h->hals_NpC, 1, h->hals_cslabs, h->hals_nch, h->hals_clen));
+    CMFTRY(launch_slab_sum(h, h->hals_C, h->hals_cslabs, hxt_nslabs(h->hals_nch), (size_t)d.L * d.K32 * h->hals_NpC));
+    hipLaunchKernelGGL(hals_hh_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_C, h->H, h->hals_HH, d.Tl, d.L, d.K, d.K32,
+                       h->hals_NpC, h->hals_NpH, d.PADL);
+    KCHK("hals_hh_kernel");
+    return CMF_OK;
+}
+
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
 {
     const CmfDims &d = h->d;
@@ -1392,11 +1410,7 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     CMFTRY(ensure_resid(h));
     CMFTRY(launch_hxt_on(h, h->est, h->est, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
     CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), (size_t)d.L * d.K32 * d.Np));
-    // HH = H_unfold * H_unfold' (hals.jl:56-60: row norms are its diagonal) with the same C2 kernel
-    hipLaunchKernelGGL(hals_build_hut_kernel, dim3(2048), dim3(256), 0, h->stream, h->H, h->hals_HuT, d.Tl, d.L, d.K32, h->hals_NpH, d.PADL);
-    KCHK("hals_build_hut_kernel");
-    CMFTRY(launch_hxt_on(h, h->hals_HuT, h->hals_HuT, h->hals_NpH, 1, h->hals_hhslabs, h->hals_nch, h->hals_clen));
-    CMFTRY(launch_slab_sum(h, h->hals_HH, h->hals_hhslabs, hxt_nslabs(h->hals_nch), (size_t)d.L * d.K32 * h->hals_NpH));
+    CMFTRY(compute_hh(h));
     // the K*L sequential column updates, k outer / lag inner (hals.jl:90-97)
     const int nq = (d.L * d.K32 + 63) / 64; // <= 32: checked by hals_ensure
     dim3 grid((d.N + 4 * HALS_NG - 1) / (4 * HALS_NG)), block(256);
@@ -1538,10 +1552,7 @@ static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W)
     CMFTRY(launch_hxt_on(h, h->X, h->X, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
     CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN));
     // denomW = H_shift * est' (mult.jl:33) = HH * W with HH = H_unfold * H_unfold'
-    hipLaunchKernelGGL(hals_build_hut_kernel, dim3(2048), dim3(256), 0, h->stream, h->H, h->hals_HuT, d.Tl, d.L, d.K32, h->hals_NpH, d.PADL);
-    KCHK("hals_build_hut_kernel");
-    CMFTRY(launch_hxt_on(h, h->hals_HuT, h->hals_HuT, h->hals_NpH, 1, h->hals_hhslabs, h->hals_nch, h->hals_clen));
-    CMFTRY(launch_slab_sum(h, h->hals_HH, h->hals_hhslabs, hxt_nslabs(h->hals_nch), (size_t)d.L * d.K32 * h->hals_NpH));
+    CMFTRY(compute_hh(h));
     hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 128, d.L * d.KB), dim3(256), 0, h->stream, h->hals_HH, h->Wt, h->numden + LKN,
                        d.L * d.K32, h->hals_NpH, d.Np);
     KCHK("gram_w_kernel");

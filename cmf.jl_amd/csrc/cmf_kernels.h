@@ -1542,15 +1542,51 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial,
 //       with the window truncated at the right edge exactly like hals.jl:136-146.
 // =============================================================================================
 
-// HuT[PADL+t][l*K32+k] = H[PADL+t-l][k]  (shift_and_stack transposed, common.jl:133-142), t < Tl
-__global__ void hals_build_hut_kernel(const float *H, float *HuT, int Tl, int L, int K32, int NpH, int PADL)
+// ---- HH = H_unfold * H_unfold' (hals.jl:56-60) from lag correlations ---------------------------------------------
+// HH[(l,k)][(l',k')] = sum_{t >= max(l,l')}^{T-1} H[k][t-l] * H[k'][t-l'] depends on (k, k', l - l') only, up to the
+// few terms at the right end that the shift cuts off:
+//   l >= l', d = l - l':  HH = C[d][k][k'] - sum_{u = T-l'}^{T-1} H[k][u-d] * H[k'][u]
+//   l <  l', d = l' - l:  HH = C[d][k'][k] - sum_{u = T-l}^{T-1}  H[k'][u-d] * H[k][u]
+// with C[d][a][b] = sum_t H[a][t-d] * H[b][t], which is the C2 contraction (hxt_kernel) of H with ITSELF as the X
+// operand: K32 columns (padded to 128) instead of the L*K32 columns of a materialised H_unfold' -- a fifth of the MFMA
+// work of round 1's form at K = 32, L = 20, and no 128 MB H_unfold' to build.
+// HX[r][c] = c < K32 ? H[r][c] : 0 : H in the row pitch hxt wants for its X operand.   grid-stride over TP * K32
+__global__ void hals_hx_kernel(const float *H, float *HX, int TP, int K32, int NpC)
+{
+    const size_t total = (size_t)TP * K32;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx / K32;
+        const int c = (int)(idx - r * K32);
+        HX[r * NpC + c] = H[idx];
+    }
+}
+// HH[(l*K32+k) * NpH + l'*K32+k'] from C [L][K32][NpC] and the last columns of H ([TP][K32]).  One thread per entry.
+__global__ void hals_hh_kernel(const float *C, const float *H, float *HH, int Tl, int L, int K, int K32, int NpC, int NpH, int PADL)
 {
     const int LK = L * K32;
-    size_t total = (size_t)Tl * LK;
+    const size_t total = (size_t)LK * LK;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        int c = (int)(idx % LK), t = (int)(idx / LK);
-        int l = c / K32, k = c - l * K32;
-        HuT[(size_t)(PADL + t) * NpH + c] = H[(size_t)(PADL + t - l) * K32 + k];
+        const int j = (int)(idx / LK), jp = (int)(idx - (size_t)j * LK);
+        const int l = j / K32, k = j - l * K32, lp = jp / K32, kp = jp - lp * K32;
+        float v = 0.f;
+        if (k < K && kp < K) {
+            // a = the row with the larger lag, b the other; cut = the smaller lag: the terms u >= T - cut are not in HH
+            const int d = l >= lp ? l - lp : lp - l;
+            const int a = l >= lp ? k : kp, b = l >= lp ? kp : k, cut = l >= lp ? lp : l;
+            // kept terms: u in [d, T - cut).  When they are few (T of the order of L) they are summed
+            // directly: C minus nearly all of itself would leave rounding noise where H_unfold has exact zeros (rows with
+            // l >= T), and the sweep divides by HH[j][j] + eps
+            const int kept = Tl - cut - d;
+            if (kept <= 0) {
+                v = 0.f;
+            } else if (kept <= cut || kept <= 64) {
+                for (int u = d; u < Tl - cut; ++u) v = fmaf(H[(size_t)(PADL + u - d) * K32 + a], H[(size_t)(PADL + u) * K32 + b], v);
+            } else {
+                v = C[((size_t)d * K32 + a) * NpC + b];
+                for (int u = Tl - cut; u < Tl; ++u) v -= H[(size_t)(PADL + u - d) * K32 + a] * H[(size_t)(PADL + u) * K32 + b]; // (u - d >= 0 here)
+            }
+        }
+        HH[(size_t)j * NpH + jp] = v;
     }
 }
 
