@@ -1727,12 +1727,34 @@ __global__ __launch_bounds__(256) void hals_pw_kernel(const float *Wn, float *PW
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    const int N4 = (N + 3) & ~3; // rows >= N of Wn are zero (Np >= N4)
-    for (int n = 0; n < N4; n += 4) {
-        const float a0 = a[(size_t)n * K32], b0 = b[(size_t)n * K32];
-        const float a1 = a[(size_t)(n + 2) * K32], b1 = b[(size_t)(n + 2) * K32];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1, 0, 0, 0);
+    // 32 rows of n per batch, the next batch's 32 operand loads in flight under this batch's 16 MFMAs: there is one wave
+    // per SIMD at most (L * L waves in all), so the overlap has to come from inside the wave -- with a load, wait, MFMA
+    // loop the kernel was a chain of N / 4 L2 round trips (155 us at N = 2000; now MFMA-paced).  Rows >= N of Wn are zero
+    // up to Np, a multiple of 128.
+    const int NB = (N + 31) & ~31;
+    float av[2][16], bv[2][16];
+    auto load = [&](float (&x)[16], float (&y)[16], int n0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            x[q] = a[(size_t)(n0 + 2 * q) * K32];
+            y[q] = b[(size_t)(n0 + 2 * q) * K32];
+        }
+    };
+    auto mac = [&](const float (&x)[16], const float (&y)[16]) {
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q], y[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q + 1], y[q + 1], acc1, 0, 0, 0);
+        }
+    };
+    load(av[0], bv[0], 0);
+    for (int n0 = 0; n0 < NB; n0 += 64) {
+        if (n0 + 32 < NB) load(av[1], bv[1], n0 + 32);
+        mac(av[0], bv[0]);
+        if (n0 + 32 < NB) {
+            if (n0 + 64 < NB) load(av[0], bv[0], n0 + 64);
+            mac(av[1], bv[1]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
