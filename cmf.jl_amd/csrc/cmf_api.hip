@@ -101,6 +101,8 @@ struct cmf_handle_s {
     float *hals_HX = nullptr, *hals_cslabs = nullptr, *hals_C = nullptr, *hals_HH = nullptr, *hals_PT = nullptr, *hals_D = nullptr;
     float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr;
     int hals_seg = 256, hals_nseg = 1;      // column segments of the pipelined H sweep
+    int hals_gram = 0;                      // 1 = the sweeps' projections as differences of the MU quantities (no residual, two conv launches
+                                            // fewer, ~20x the rounding error: opt-in); 0 = contracted from the stored residual
     int hals_pullers = 0;                   // persistent H pipeline: puller workgroups per row (0 = stage pipeline)
     int *hals_flags = nullptr;              // its progress flags (device)
     int *hals_status = nullptr;             // pinned host word: 1 = a wait of the persistent pipeline ran out
@@ -147,6 +149,7 @@ static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss);
 static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg);
 static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg, double *loss);
 static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H);
+static int gram_denom_h(cmf_handle_s *h, float *out);
 
 static size_t n_partial(const cmf_handle_s *h)
 {
@@ -814,6 +817,11 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         h->est_kind = 0;
         return CMF_OK;
     }
+    if (std::strcmp(name, "hals_gram") == 0) { // 1: HALS projections as differences of the MU quantities; 0 (default): contracted from the residual
+        h->hals_gram = value ? 1 : 0;
+        h->est_kind = 0;
+        return CMF_OK;
+    }
     if (std::strcmp(name, "hals_prepare") == 0) { // allocate the HALS scratch and check its shape limits now (rule construction)
         HIPCHK(hipSetDevice(h->device));
         return hals_ensure(h);
@@ -924,7 +932,15 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
     CMFTRY(check_ready(h, true));
     CMFTRY(hals_h_impl(h, l1H, l2H));
     double ss = 0.0;
-    CMFTRY(resid_and_loss(h, &ss)); // hals.jl:41: norm(resids)/data_norm; the residual is kept for the next W phase
+    if (h->hals_gram) { // hals.jl:41: norm(resids)/data_norm -- the conv with the loss fused in its epilogue, nothing stored
+        CMFTRY(launch_conv<2>(h, nullptr, h->d.Tl, h->conv_gy));
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, (double *)nullptr);
+        KCHK("loss_reduce_kernel");
+        CMFTRY(read_scalar(h, 0, &ss));
+        h->est_kind = 0;
+    } else {
+        CMFTRY(resid_and_loss(h, &ss)); // ... and the residual kept for the next W phase
+    }
     if (h->hals_status && *h->hals_status) { // (the stream has been synchronised by the loss read-back)
         *h->hals_status = 0;
         return fail(CMF_ERR_HIP, "HALS H pipeline: a wait between its workgroups ran out (is another kernel occupying the device?); "
@@ -1329,6 +1345,7 @@ static int hals_ensure(cmf_handle_s *h)
         return fail(CMF_ERR_UNSUPPORTED, "HALS path supports L * Kpad <= 2048 (got L=%d, K=%d padded to %d)", d.L, d.K, d.K32);
     if ((size_t)4 * d.K * d.L * HALS_NG * sizeof(float) > 64 * 1024)
         return fail(CMF_ERR_UNSUPPORTED, "HALS path supports K * L <= 2048 (got %d)", d.K * d.L);
+    if (const char *env = getenv("CMF_HALS_GRAM")) h->hals_gram = atoi(env) ? 1 : 0; // (tests compare the two forms)
     const int E = 2 * d.L - 1;
     h->hals_NpH = (int)rup((int64_t)d.L * d.K32, 128);
     h->hals_TPp = (int)rup(d.Tl, 64) + 256;
@@ -1406,18 +1423,35 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
 {
     const CmfDims &d = h->d;
     CMFTRY(hals_ensure(h));
-    // G = resid * H_unfold' (hals.jl:104-110 needs resid * h): ONE C2 contraction on the stored residual
-    CMFTRY(ensure_resid(h));
-    CMFTRY(launch_hxt_on(h, h->est, h->est, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
-    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), (size_t)d.L * d.K32 * d.Np));
-    CMFTRY(compute_hh(h));
+    // G = resid * H_unfold' (hals.jl:104-110 needs resid * h).  resid = est - data, so G = denomW - numW of the MU path:
+    // numW = H_shift * data' is ONE C2 contraction on the data, denomW = H_shift * est' = HH * W a small GEMM on the Gram
+    // matrix the sweep needs anyway -- no residual, hence no conv, in this phase; but the difference of two quantities
+    // several times its size carries ~20x the rounding error through the sweep's recurrences (parity tests), so this form
+    // is opt-in (option hals_gram) and the default contracts G from the stored residual.
+    const size_t LKN = (size_t)d.L * d.K32 * d.Np;
+    const float *G = h->numden, *Gsub = nullptr;
+    if (h->hals_gram) {
+        CMFTRY(launch_hxt_on(h, h->X, h->X, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
+        CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN));
+        CMFTRY(compute_hh(h));
+        hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 128, d.L * d.KB), dim3(256), 0, h->stream, h->hals_HH, h->Wt, h->numden + LKN,
+                           d.L * d.K32, h->hals_NpH, d.Np);
+        KCHK("gram_w_kernel");
+        G = h->numden + LKN;
+        Gsub = h->numden;
+    } else {
+        CMFTRY(ensure_resid(h));
+        CMFTRY(launch_hxt_on(h, h->est, h->est, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
+        CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN));
+        CMFTRY(compute_hh(h));
+    }
     // the K*L sequential column updates, k outer / lag inner (hals.jl:90-97)
     const int nq = (d.L * d.K32 + 63) / 64; // <= 32: checked by hals_ensure
     dim3 grid((d.N + 4 * HALS_NG - 1) / (4 * HALS_NG)), block(256);
     const size_t lds = (size_t)4 * d.K * d.L * HALS_NG * sizeof(float); // <= 64 KB
     ProfScope prof_(h, PROF_HALS_WSWEEP);
 #define SWEEP(NQ_, WD_)                                                                                                     \
-    hipLaunchKernelGGL((hals_w_sweep_reg_kernel<NQ_, WD_>), grid, block, lds, h->stream, h->Wt, h->Wn, h->numden, h->hals_HH, \
+    hipLaunchKernelGGL((hals_w_sweep_reg_kernel<NQ_, WD_>), grid, block, lds, h->stream, h->Wt, h->Wn, G, Gsub, h->hals_HH, \
                    d.N, d.K, d.L, d.Np, d.K32, h->hals_NpH, (float)l1W, (float)l2W)
     if (nq <= 2) SWEEP(2, 8);
     else if (nq <= 4) SWEEP(4, 8);
@@ -1439,15 +1473,29 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
 {
     const CmfDims &d = h->d;
     CMFTRY(hals_ensure(h));
-    // P = transconv(W, resid) (hals.jl:152 needs <W_k window, resid window>): ONE C3 contraction on resid^T
-    CMFTRY(launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT));
-    CMFTRY(launch_transconv(h, 1, h->estT));
-    hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, h->tc_S1, d.Tl, d.K32, h->hals_TPp);
-    KCHK("hals_p_init_kernel");
+    // the lag-Gram taps of W (GW, and GE for the truncated windows at the right edge)
     hipLaunchKernelGGL(hals_pw_kernel, dim3((d.L * d.L + 3) / 4, d.KB * d.KB), dim3(256), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
     KCHK("hals_pw_kernel");
     hipLaunchKernelGGL(hals_gw_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_PW, h->hals_GW, h->hals_GE, d.L, d.K32, h->hals_ne, d.Tl, h->hals_t_edge0);
     KCHK("hals_gw_kernel");
+    // P = transconv(W, resid) (hals.jl:152 needs <W_k window, resid window>) = denomH - numH of the MU path:
+    // numH = transconv(W, data) is ONE C3 contraction on the data, denomH = transconv(W, conv(W, H)) comes from the taps
+    // above applied to H (gram_h_kernel) -- again no residual and no conv.  (hals_gram = 0: P as one C3 contraction on
+    // the transposed residual, which costs a conv launch.)
+    if (h->hals_gram) {
+        const size_t TK = (size_t)d.Tl * d.K32;
+        if (!h->gram_numden_h) CMFTRY(dalloc_zero(&h->gram_numden_h, 2 * TK));
+        CMFTRY(launch_transconv(h, 1, h->XT));
+        CMFTRY(gram_denom_h(h, h->gram_numden_h + TK));
+        hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, h->gram_numden_h + TK,
+                           h->tc_S1, d.Tl, d.K32, h->hals_TPp);
+    } else {
+        CMFTRY(launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT));
+        CMFTRY(launch_transconv(h, 1, h->estT));
+        hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, (const float *)nullptr,
+                           h->tc_S1, d.Tl, d.K32, h->hals_TPp);
+    }
+    KCHK("hals_p_init_kernel");
     HalsRowParams q;
     q.PT = h->hals_PT; q.H = h->H; q.Ht = h->Ht; q.D = h->hals_D; q.GW = h->hals_GW; q.GE = h->hals_GE;
     q.Tl = d.Tl; q.L = d.L; q.K32 = d.K32; q.TP = d.TP; q.TPp = h->hals_TPp; q.PADL = d.PADL; q.ne = h->hals_ne; q.t_edge0 = h->hals_t_edge0;

@@ -1600,7 +1600,7 @@ __global__ void hals_hh_kernel(const float *C, const float *H, float *HH, int Tl
 // NQ = state slots per lane (64 * NQ >= L * K32), HALS_WD = prefetch depth in steps: 8 up to 16 slots, 4 for the long
 // states (K32 * L up to 2048, e.g. K = 64, L = 20), whose prefetch ring would otherwise not fit the register file.
 template <int NQ, int HALS_WD>
-__global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float *Wn, const float *G, const float *HH,
+__global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float *Wn, const float *G, const float *Gsub, const float *HH,
                                                                 int N, int K, int L, int Np, int K32, int NpH, float l1, float l2)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1614,7 +1614,10 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
     for (int q = 0; q < NQ; ++q) {
         const int j = lane + 64 * q;
 #pragma unroll
-        for (int u = 0; u < HALS_NG; ++u) g[u][q] = (j < LK && n0 + u < N) ? G[(size_t)j * Np + n0 + u] : 0.f;
+        for (int u = 0; u < HALS_NG; ++u) { // Gsub (may be NULL): the projection as a difference, G - Gsub = denomW - numW
+            const size_t at = (size_t)j * Np + n0 + u;
+            g[u][q] = (j < LK && n0 + u < N) ? (Gsub ? G[at] - Gsub[at] : G[at]) : 0.f;
+        }
     }
     const int nsteps = K * L;
     // HH rows, diagonal entries and old W values are prefetched HALS_WD steps ahead into a register ring (a step is
@@ -1681,8 +1684,9 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
     }
 }
 
-// PT[k][t] = sum_s of the transconv(W, resid) slabs [S][1][Tl][K32]; grid (ceil(Tl/64), KB), block 256
-__global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float *slabs, int S, int Tl, int K32, int TPp)
+// PT[k][t] = sum_s of the transconv slabs [S][1][Tl][K32] (of the residual), or, with `den` ([Tl][K32]) given,
+// den[t][k] - that sum (the projection as denomH - numH: slabs of transconv(W, data));   grid (ceil(Tl/64), KB), block 256
+__global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float *slabs, const float *den, int S, int Tl, int K32, int TPp)
 {
     __shared__ float tile[32][65];
     const int tid = threadIdx.x;
@@ -1697,6 +1701,7 @@ __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float
             if (t < Tl) {
                 size_t idx = (size_t)t * K32 + kb * 32 + kk;
                 for (int s = 0; s < S; ++s) v += slabs[(size_t)s * TK + idx];
+                if (den) v = den[idx] - v;
             }
             tile[kk][tt] = v;
         }
