@@ -101,8 +101,9 @@ struct cmf_handle_s {
     float *hals_HX = nullptr, *hals_cslabs = nullptr, *hals_C = nullptr, *hals_HH = nullptr, *hals_PT = nullptr, *hals_D = nullptr;
     float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr;
     int hals_seg = 256, hals_nseg = 1;      // column segments of the pipelined H sweep
-    int hals_gram = 0;                      // 1 = the sweeps' projections as differences of the MU quantities (no residual, two conv launches
-                                            // fewer, ~20x the rounding error: opt-in); 0 = contracted from the stored residual
+    int hals_gram = 2;                      // the sweeps' projections as differences of the MU quantities: 2 = P of the H phase only (default:
+                                            // one conv launch fewer, H within the residual form's bars), 1 = G of the W phase too (~20x the rounding
+                                            // error in W: opt-in), 0 = both contracted from the stored residual
     int hals_pullers = 0;                   // persistent H pipeline: puller workgroups per row (0 = stage pipeline)
     int *hals_flags = nullptr;              // its progress flags (device)
     int *hals_status = nullptr;             // pinned host word: 1 = a wait of the persistent pipeline ran out
@@ -817,8 +818,8 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         h->est_kind = 0;
         return CMF_OK;
     }
-    if (std::strcmp(name, "hals_gram") == 0) { // 1: HALS projections as differences of the MU quantities; 0 (default): contracted from the residual
-        h->hals_gram = value ? 1 : 0;
+    if (std::strcmp(name, "hals_gram") == 0) { // HALS projections as differences of the MU quantities: 2 (default) = H phase, 1 = both phases, 0 = neither
+        h->hals_gram = (value == 1 || value == 2) ? value : 0; // 2 = the H phase only
         h->est_kind = 0;
         return CMF_OK;
     }
@@ -932,7 +933,7 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
     CMFTRY(check_ready(h, true));
     CMFTRY(hals_h_impl(h, l1H, l2H));
     double ss = 0.0;
-    if (h->hals_gram) { // hals.jl:41: norm(resids)/data_norm -- the conv with the loss fused in its epilogue, nothing stored
+    if (h->hals_gram == 1) { // hals.jl:41: norm(resids)/data_norm -- the conv with the loss fused in its epilogue, nothing stored
         CMFTRY(launch_conv<2>(h, nullptr, h->d.Tl, h->conv_gy));
         hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, (double *)nullptr);
         KCHK("loss_reduce_kernel");
@@ -1345,7 +1346,7 @@ static int hals_ensure(cmf_handle_s *h)
         return fail(CMF_ERR_UNSUPPORTED, "HALS path supports L * Kpad <= 2048 (got L=%d, K=%d padded to %d)", d.L, d.K, d.K32);
     if ((size_t)4 * d.K * d.L * HALS_NG * sizeof(float) > 64 * 1024)
         return fail(CMF_ERR_UNSUPPORTED, "HALS path supports K * L <= 2048 (got %d)", d.K * d.L);
-    if (const char *env = getenv("CMF_HALS_GRAM")) h->hals_gram = atoi(env) ? 1 : 0; // (tests compare the two forms)
+    if (const char *env = getenv("CMF_HALS_GRAM")) h->hals_gram = (atoi(env) == 1 || atoi(env) == 2) ? atoi(env) : 0; // (tests compare the forms)
     const int E = 2 * d.L - 1;
     h->hals_NpH = (int)rup((int64_t)d.L * d.K32, 128);
     h->hals_TPp = (int)rup(d.Tl, 64) + 256;
@@ -1425,12 +1426,12 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     CMFTRY(hals_ensure(h));
     // G = resid * H_unfold' (hals.jl:104-110 needs resid * h).  resid = est - data, so G = denomW - numW of the MU path:
     // numW = H_shift * data' is ONE C2 contraction on the data, denomW = H_shift * est' = HH * W a small GEMM on the Gram
-    // matrix the sweep needs anyway -- no residual, hence no conv, in this phase; but the difference of two quantities
-    // several times its size carries ~20x the rounding error through the sweep's recurrences (parity tests), so this form
-    // is opt-in (option hals_gram) and the default contracts G from the stored residual.
+    // matrix the sweep needs anyway -- no residual in this phase; but the difference of two quantities several times its
+    // size carries ~20x the rounding error through the 640 dependent column updates of the sweep (parity tests), so this
+    // is opt-in (hals_gram = 1) and the default contracts G from the residual the loss conv stores anyway.
     const size_t LKN = (size_t)d.L * d.K32 * d.Np;
     const float *G = h->numden, *Gsub = nullptr;
-    if (h->hals_gram) {
+    if (h->hals_gram == 1) {
         CMFTRY(launch_hxt_on(h, h->X, h->X, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
         CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN));
         CMFTRY(compute_hh(h));
@@ -1480,8 +1481,10 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
     KCHK("hals_gw_kernel");
     // P = transconv(W, resid) (hals.jl:152 needs <W_k window, resid window>) = denomH - numH of the MU path:
     // numH = transconv(W, data) is ONE C3 contraction on the data, denomH = transconv(W, conv(W, H)) comes from the taps
-    // above applied to H (gram_h_kernel) -- again no residual and no conv.  (hals_gram = 0: P as one C3 contraction on
-    // the transposed residual, which costs a conv launch.)
+    // above applied to H (gram_h_kernel) -- no transposed residual, i.e. one conv launch (1 ms) less per iteration, and the
+    // H sweep's short recurrences (L-1 columns) do not amplify the cancellation: H stays within the residual form's test
+    // bars (1.8e-5 against the oracle where the residual form has 1.2e-5).  hals_gram = 0: P as one C3 contraction on the
+    // transposed residual.
     if (h->hals_gram) {
         const size_t TK = (size_t)d.Tl * d.K32;
         if (!h->gram_numden_h) CMFTRY(dalloc_zero(&h->gram_numden_h, 2 * TK));

@@ -130,9 +130,10 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       rounds on three more tiles per CU -- are cut into 32 x 32 quarter or 16 x 16 sixteenth tiles; 4 = quarter tiles
  *       only; 0 = whole tiles only): kernel selection of tensor_conv, for measurements.
  *   "hals_prepare": allocate the HALS rule's scratch and check its shape limits now (see the HALS entries).
- *   "hals_gram" (default 0): 1 = the HALS sweeps' projections as differences of the MU quantities (G = denomW - numW,
- *       P = denomH - numH: two conv launches fewer per iteration, about 20x the rounding error of the default, which
- *       contracts them from the stored residual).
+ *   "hals_gram" (default 2): where the HALS sweeps' projections come from.  2 = P of the H phase as denomH - numH of the MU
+ *       quantities (one conv launch less; H within the residual form's accuracy), G of the W phase contracted from the
+ *       stored residual; 0 = both from the residual; 1 = both as differences (no residual at all, but about 20x the
+ *       rounding error in W).
  *   "profile" (n): bracket every n-th contraction launch with HIP events (cmf_kernel_times); 0 stops.
  *   "allreduce_overlap" (group handles, default 0): 1 = numW (which needs H only) is contracted and all-reduced on a
  *       second stream right after the H update, underneath the loss conv and the denominator contraction, so only

@@ -346,16 +346,16 @@ HALS_SHAPES = [
 
 @pytest.mark.parametrize("N,T,K,L", HALS_SHAPES)
 @pytest.mark.parametrize("reg", [dict(), dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2)])
-@pytest.mark.parametrize("form", ["gram", "resid"])
+@pytest.mark.parametrize("form", ["gram", "gram_h", "resid"])
 def test_hals_single_iteration(cmf, oracle, N, T, K, L, reg, form):
-    """One HALS update_motifs! + update_feature_maps! (hals.jl:31-42) against the oracle, in both forms of the sweeps'
-    projections: contracted from the stored residual (default) and as differences of the MU quantities (option
-    hals_gram = 1: G = denomW - numW, P = denomH - numH -- two conv launches fewer per iteration, but the cancellation
-    carries ~20x the rounding error through the sweeps, hence opt-in and looser bars)."""
+    """One HALS update_motifs! + update_feature_maps! (hals.jl:31-42) against the oracle, in the three forms of the
+    sweeps' projections: P of the H phase as denomH - numH of the MU quantities and G of the W phase contracted from the
+    stored residual (default, hals_gram = 2), both contracted from the residual (0; same bars), both as differences (1:
+    G = denomW - numW carries ~20x the rounding error through the W sweep's 640 dependent updates: opt-in, looser bars)."""
     data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20) if L > 1 else 2, seed=1234)
     W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
     rule = cmf.HALSUpdate(data, W0, H0)
-    rule.set_option("hals_gram", 1 if form == "gram" else 0)
+    rule.set_option("hals_gram", {"gram": 1, "gram_h": 2, "resid": 0}[form])
     rule.update_motifs(l1W=reg.get("l1W", 0), l2W=reg.get("l2W", 0))
     Wg, _ = rule.download()
     loss = rule.update_feature_maps(l1H=reg.get("l1H", 0), l2H=reg.get("l2H", 0))
@@ -407,7 +407,8 @@ def test_hals_config5_full_size(cmf, config2):
                       ("stage256", {"CMF_HALS_PERSIST": "0", "CMF_HALS_SEG": "256"}),
                       ("stage1024", {"CMF_HALS_PERSIST": "0", "CMF_HALS_SEG": "1024"}),
                       ("stage384lag3", {"CMF_HALS_PERSIST": "0", "CMF_HALS_SEG": "384", "CMF_HALS_LAG": "3"}),
-                      ("gram", {"CMF_HALS_GRAM": "1"})):  # projections as differences of the MU quantities (opt-in)
+                      ("resid", {"CMF_HALS_GRAM": "0"}),  # both projections contracted from the stored residual
+                      ("gram", {"CMF_HALS_GRAM": "1"})):  # both as differences of the MU quantities (opt-in)
         os.environ.update(env)
         try:
             r = cmf.fit_cnmf(data, L=20, K=32, alg=":hals", max_itr=3, check_convergence=False, W_init=W0, H_init=H0)
@@ -425,8 +426,8 @@ def test_hals_config5_full_size(cmf, config2):
     # no pipeline changes the order of the updates; they differ in how the cross-row sums are associated (rounding level)
     for name, r in runs.items():
         # (the Gram form differs from the default in how G and P are formed, not only in summation order)
-        np.testing.assert_allclose(a.loss_hist, r.loss_hist, rtol=1e-5 if name == "gram" else 1e-6, err_msg=name)
-        assert frob_rel(a.H, r.H) < (1e-3 if name == "gram" else 1e-4), name
+        np.testing.assert_allclose(a.loss_hist, r.loss_hist, rtol=1e-5 if name in ("gram", "resid") else 1e-6, err_msg=name)
+        assert frob_rel(a.H, r.H) < (1e-3 if name in ("gram", "resid") else 1e-4), name
         print(name, float(np.max(np.abs(a.loss_hist / r.loss_hist - 1))), frob_rel(a.H, r.H))
 
 
