@@ -99,7 +99,7 @@ struct cmf_handle_s {
     bool hals_ready = false;
     int hals_NpH = 0, hals_NpC = 0, hals_TPp = 0, hals_ne = 0, hals_t_edge0 = 0, hals_nch = 1, hals_clen = 6;
     float *hals_HX = nullptr, *hals_cslabs = nullptr, *hals_C = nullptr, *hals_HH = nullptr, *hals_PT = nullptr, *hals_D = nullptr;
-    float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr;
+    float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr, *hals_GWt = nullptr;
     int hals_seg = 256, hals_nseg = 1;      // column segments of the pipelined H sweep
     int hals_gram = 2;                      // the sweeps' projections as differences of the MU quantities: 2 = P of the H phase only (default:
                                             // one conv launch fewer, H within the residual form's bars), 1 = G of the W phase too (~20x the rounding
@@ -267,7 +267,7 @@ static void destroy_impl(cmf_handle_s *h)
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
                       h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3],
-                      h->gram_numden_h, h->pgd_gradH, h->M, h->MT, h->hals_HX, h->hals_cslabs, h->hals_C, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE};
+                      h->gram_numden_h, h->pgd_gradH, h->M, h->MT, h->hals_HX, h->hals_cslabs, h->hals_C, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE, h->hals_GWt};
     for (float *p : fbufs)
         if (p) (void)hipFree(p);
     for (int v = 0; v < 2; ++v)
@@ -1375,6 +1375,7 @@ static int hals_ensure(cmf_handle_s *h)
     CMFTRY(dalloc_zero(&h->hals_PW, (size_t)d.L * d.L * d.K32 * d.K32));
     CMFTRY(dalloc_zero(&h->hals_GW, (size_t)d.K32 * d.K32 * E));
     CMFTRY(dalloc_zero(&h->hals_GE, (size_t)d.K32 * std::max(1, h->hals_ne) * d.K32 * E));
+    CMFTRY(dalloc_zero(&h->hals_GWt, (size_t)d.K32 * (E + 1) * d.K32)); // the full-window taps as [k'][e][k] for gram_h_mfma_kernel
     {   // row pipeline: segment length (multiple of 64, >= 256 so that the sweeps and pushes of one stage
         // touch disjoint columns: see hals_h_stage_kernel)
         const char *env = getenv("CMF_HALS_SEG");
@@ -1588,9 +1589,32 @@ static int gram_denom_h(cmf_handle_s *h, float *out)
     const CmfDims &d = h->d;
     const size_t lds = (size_t)d.K32 * (64 + 2 * (d.L - 1)) * sizeof(float);
     if (lds > 96 * 1024) return fail(CMF_ERR_UNSUPPORTED, "Gram form: K*L too large for the LDS window");
-    hipLaunchKernelGGL(gram_h_kernel, dim3((d.Tl + 63) / 64, d.K32 / 4), dim3(256), lds, h->stream, h->Ht, h->hals_GW, h->hals_GE, out,
-                       d.Tl, d.K, d.L, d.K32, d.TP, d.PADL, h->hals_ne, h->hals_t_edge0);
-    KCHK("gram_h_kernel");
+    // columns with the full lag window, in tiles of 128: the MFMA kernel on the transposed taps; the rest (the right edge with
+    // its per-column taps, and what does not fill a tile): the scalar kernel
+    const size_t lds_m = (size_t)d.K32 * (128 + 2 * (d.L - 1)) * sizeof(float);
+    const int ntile = lds_m <= 120 * 1024 ? h->hals_t_edge0 / 128 : 0;
+    if (ntile > 0) {
+        const int Ep = 2 * d.L; // E = 2L - 1 taps padded to an even count
+        hipLaunchKernelGGL(gram_taps_t_kernel, dim3(256), dim3(256), 0, h->stream, h->hals_GW, h->hals_GWt, d.L, d.K32, Ep);
+        KCHK("gram_taps_t_kernel");
+        hipLaunchKernelGGL(gram_h_mfma_kernel, dim3(ntile, d.KB), dim3(256), lds_m, h->stream, h->Ht, h->hals_GWt, out, d.K, d.L, d.K32, d.TP, d.PADL, Ep);
+        KCHK("gram_h_mfma_kernel");
+    }
+    const int t_first = 128 * ntile;
+    if (ntile > 0 && d.Tl - t_first <= 512) { // the usual case: a wave per leftover output
+        if (d.Tl > t_first) {
+            hipLaunchKernelGGL(gram_h_edge_kernel, dim3(d.Tl - t_first, d.K32 / 4), dim3(256), 0, h->stream, h->Ht, h->hals_GW, h->hals_GE, out,
+                               d.Tl, d.K, d.L, d.K32, d.TP, d.PADL, h->hals_ne, h->hals_t_edge0, t_first);
+            KCHK("gram_h_edge_kernel");
+        }
+        return CMF_OK;
+    }
+    const int block0 = 2 * ntile, nblock = (d.Tl + 63) / 64 - block0;
+    if (nblock > 0) {
+        hipLaunchKernelGGL(gram_h_kernel, dim3(nblock, d.K32 / 4), dim3(256), lds, h->stream, h->Ht, h->hals_GW, h->hals_GE, out,
+                           d.Tl, d.K, d.L, d.K32, d.TP, d.PADL, h->hals_ne, h->hals_t_edge0, block0);
+        KCHK("gram_h_kernel");
+    }
     return CMF_OK;
 }
 

@@ -2647,11 +2647,11 @@ __global__ __launch_bounds__(256) void gram_w_kernel(const float *HH, const floa
 // grid (ceil(Tl/64), K32/4), block 256: wave w -> k = blockIdx.y*4 + w, lane -> t = t0 + lane
 // dynamic LDS: K32 * (64 + 2*(L-1)) floats
 __global__ __launch_bounds__(256) void gram_h_kernel(const float *Ht, const float *GW, const float *GE, float *out,
-                                                      int Tl, int K, int L, int K32, int TP, int PADL, int ne, int t_edge0)
+                                                      int Tl, int K, int L, int K32, int TP, int PADL, int ne, int t_edge0, int block0)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t0 = blockIdx.x * 64;
+    const int t0 = (blockIdx.x + block0) * 64; // block0: the 64-column blocks in front belong to gram_h_mfma_kernel
     const int k = blockIdx.y * 4 + wave;
     const int E = 2 * L - 1, WN = 64 + 2 * (L - 1);
     for (int idx = tid; idx < K32 * WN; idx += 256) {
@@ -2675,11 +2675,108 @@ __global__ __launch_bounds__(256) void gram_h_kernel(const float *Ht, const floa
                                                : GE + ((size_t)k * ne + (t - t_edge0)) * K32 * E;
             for (int kp = 0; kp < K; ++kp) {
                 const float *hw = smem_dyn + kp * WN + lane;
-                for (int ei = 0; ei < E; ++ei) acc = fmaf(taps[kp * E + ei], hw[ei], acc);
+#pragma unroll 8
+                for (int ei = 0; ei < E; ++ei) acc = fmaf(taps[kp * E + ei], hw[ei], acc); // (per-lane tap loads: several in flight)
             }
         }
     }
     if (t < Tl && k < K32) out[(size_t)t * K32 + k] = acc;
+}
+
+// The same product on the MFMA pipe for the columns whose lag window is full (all but the last L-1):
+//   out[t][k] = sum_{(k', e)} A[t][(k', e)] * B[(k', e)][k],   A = H[k'][t - (L-1) + e] (windows of the staged H rows),
+//   B = the full-window taps in the layout GWt[k'][e][k] (k fastest, e padded to an even count with a zero tap).
+// One wave = 32 columns t x 32 outputs k, K32 * Ep / 2 MFMAs; A comes from LDS (lane i: window column i + e), B streams
+// from L2 in 128-byte rows, one k' ahead (two register sets).  The scalar kernel above spends an LDS read and a scalar
+// load per FMA and restages the window for every four outputs: 317 us at config 5 against ~60 here.
+// grid (tiles of 128 columns that end at or before t_edge0, KB), block 256 (4 waves = 4 x 32 columns);
+// dynamic LDS: K32 * (128 + 2*(L-1)) floats.
+__global__ void gram_taps_t_kernel(const float *GW, float *GWt, int L, int K32, int Ep)
+{
+    const int E = 2 * L - 1;
+    const size_t total = (size_t)K32 * Ep * K32;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % K32), ei = (int)((idx / K32) % Ep), kp = (int)(idx / ((size_t)K32 * Ep));
+        GWt[idx] = ei < E ? GW[((size_t)k * K32 + kp) * E + ei] : 0.f;
+    }
+}
+// ... and for the few columns the tiles above leave over (the right edge with its per-column taps GE, and what does not
+// fill a tile of 128): one wave per output (t, k), its lanes over the K * E terms -- the taps of a column are K32 * E
+// contiguous floats -- and a DPP wave sum.  (The scalar kernel's edge path walks those terms one load at a time: 76 us
+// for 80 columns.)   grid (columns from t_first on, K32 / 4), block 256: wave w -> k = blockIdx.y * 4 + w
+__global__ __launch_bounds__(256) void gram_h_edge_kernel(const float *Ht, const float *GW, const float *GE, float *out,
+                                                           int Tl, int K, int L, int K32, int TP, int PADL, int ne, int t_edge0, int t_first)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = t_first + blockIdx.x, k = blockIdx.y * 4 + wave;
+    if (t >= Tl) return;
+    const int E = 2 * L - 1;
+    float x = 0.f;
+    if (k < K) {
+        const float *taps = (t < t_edge0) ? GW + (size_t)k * K32 * E : GE + ((size_t)k * ne + (t - t_edge0)) * K32 * E;
+        const float *hw = Ht + PADL + t - (L - 1);
+        for (int idx = lane; idx < K * E; idx += 64) {
+            const int kp = idx / E, ei = idx - kp * E;
+            x = fmaf(taps[idx], hw[(size_t)kp * TP + ei], x);
+        }
+    }
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, false)); // row_shr:1
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, false)); // row_shr:2
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, false)); // row_shr:4
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, false)); // row_shr:8
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false)); // row_bcast:15
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false)); // row_bcast:31
+    if (lane == 63 && k < K32) out[(size_t)t * K32 + k] = x;
+}
+__global__ __launch_bounds__(256) void gram_h_mfma_kernel(const float *Ht, const float *GWt, float *out, int K, int L, int K32, int TP, int PADL, int Ep)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int t0 = blockIdx.x * 128, kbo = blockIdx.y;
+    const int WN = 128 + 2 * (L - 1);
+    for (int idx = tid; idx < K32 * WN; idx += 256) {
+        const int kp = idx / WN, c = idx - kp * WN;
+        smem_dyn[idx] = Ht[(size_t)kp * TP + PADL + t0 - (L - 1) + c];
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // The K * Ep / 2 MFMAs are numbered f = kp * (Ep / 2) + s; their B rows lie 2 * K32 floats apart in f (Ep is even), so
+    // the B stream is one linear walk: 32 rows per chunk, the next chunk's loads issued before this chunk's MFMAs (one
+    // wave or two per SIMD: an L2 round trip must be covered from inside the wave).
+    const int nstep = Ep >> 1, F = K * nstep;
+    const float *arow = smem_dyn + wave * 32 + i + hh;               // + kp * WN + 2 * s
+    const float *brow = GWt + (size_t)hh * K32 + kbo * 32 + i;       // + 2 * f * K32
+    float bb[2][32];
+    auto loadb = [&](float (&x)[32], int f0) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) x[q] = (f0 + q < F) ? brow[(size_t)2 * (f0 + q) * K32] : 0.f;
+    };
+    auto mac = [&](const float (&x)[32], int f0) {
+        int kp = f0 / nstep, s2 = f0 - kp * nstep;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const float a = (f0 + q < F) ? arow[(size_t)kp * WN + 2 * s2] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[q], acc, 0, 0, 0);
+            if (++s2 == nstep) { s2 = 0; ++kp; }
+        }
+    };
+    loadb(bb[0], 0);
+    for (int f0 = 0; f0 < F; f0 += 64) {
+        if (f0 + 32 < F) loadb(bb[1], f0 + 32);
+        mac(bb[0], f0);
+        if (f0 + 32 < F) {
+            if (f0 + 64 < F) loadb(bb[0], f0 + 64);
+            mac(bb[1], f0 + 32);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = t0 + wave * 32 + cmf_crow(r, hh);
+        out[(size_t)t * K32 + kbo * 32 + i] = acc[r];
+    }
 }
 
 // partial[b] = sum H*den, partial[nb + b] = sum H*num over the block's (t, k); grid ceil(Tl*K32/1024), block 256
