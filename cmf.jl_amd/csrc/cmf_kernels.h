@@ -1859,7 +1859,7 @@ __device__ __forceinline__ float cmf_lane0(float v)
 // sc1 loads.  Every wait is bounded: a poll loop that runs out sets the abort word (and the host's status word) and every
 // other loop leaves on seeing it, so the grid always drains.
 #define HALS_FLAG_STRIDE 32      // ints: one 128-byte line per flag
-#define HALS_POLL_LIMIT (1 << 19) // ~0.5 s of polling: three orders of magnitude above the longest legitimate wait
+#define HALS_POLL_LIMIT (1 << 21) // ~2 s of polling: three orders of magnitude above the longest legitimate wait
 __device__ __forceinline__ int cmf_load_sc1(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float cmf_load_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void cmf_store_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -2371,12 +2371,22 @@ __global__ __launch_bounds__(1024) void hals_h_persist_kernel(HalsPersistParams 
             for (int k2 = wave; k2 < k; k2 += 16) {
                 const float *dsr = Ds + (size_t)k2 * W + lane + (L - 1);
                 const float *gr = Gs + (size_t)k2 * E + (L - 1);
-                for (int e = -(L - 1); e <= L - 1; ++e) s = fmaf(dsr[-e], gr[e], s); // source column t = tp - e
+                // two partial sums and eight reads in flight: taken one at a time the loop is a chain of LDS round trips
+                // (100 cycles a tap: the whole compute phase of a block was 1.6 us for ONE source row)
+                float s1 = 0.f;
+#pragma unroll 8
+                for (int e = -(L - 1); e + 1 <= L - 1; e += 2) { // source column t = tp - e
+                    s = fmaf(dsr[-e], gr[e], s);
+                    s1 = fmaf(dsr[-e - 1], gr[e + 1], s1);
+                }
+                s = fmaf(dsr[-(L - 1)], gr[L - 1], s) + s1; // (2L - 1 taps: the last one is left over)
             }
         } else { // truncated windows of the last L-1 source columns (hals.jl:136): per-column taps in GE
             for (int k2 = wave; k2 < k; k2 += 16) {
                 const float *dsr = Ds + (size_t)k2 * W + lane + (L - 1);
-                const float *gr = Gs + (size_t)k2 * E + (L - 1);
+                // (the LDS taps through an address-space-3 pointer: left generic, the compiler folds the two sources of `tap`
+                // into one selected pointer whose LDS-aperture check does not assemble -- "Illegal instruction detected")
+                const __attribute__((address_space(3))) float *gr = (const __attribute__((address_space(3))) float *)hp_smem + k2 * E + (L - 1);
                 for (int e = -(L - 1); e <= L - 1; ++e) {
                     const int t = tp - e;
                     if (t < 0 || t >= Tl) continue;
