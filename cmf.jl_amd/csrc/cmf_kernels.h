@@ -2381,17 +2381,34 @@ __global__ __launch_bounds__(1024) void hals_h_persist_kernel(HalsPersistParams 
                 }
                 s = fmaf(dsr[-(L - 1)], gr[L - 1], s) + s1; // (2L - 1 taps: the last one is left over)
             }
-        } else { // truncated windows of the last L-1 source columns (hals.jl:136): per-column taps in GE
+        } else { // the last blocks of the row: some source columns lie in the right edge (truncated windows, hals.jl:136)
+            // Sources in front of the edge take the full-window taps from LDS as above (masked), the <= L-1 edge sources
+            // their own taps from GE in a loop of their own: one coalesced row of taps per (source row, edge column), several
+            // in flight.  (With both kinds in one loop -- a bounds test and a dependent global load per term -- these last
+            // pulls took 7-20 us, and every row's end waits for them.)
             for (int k2 = wave; k2 < k; k2 += 16) {
                 const float *dsr = Ds + (size_t)k2 * W + lane + (L - 1);
-                // (the LDS taps through an address-space-3 pointer: left generic, the compiler folds the two sources of `tap`
+                // (the LDS taps through an address-space-3 pointer: left generic, the compiler folds the two sources of taps
                 // into one selected pointer whose LDS-aperture check does not assemble -- "Illegal instruction detected")
                 const __attribute__((address_space(3))) float *gr = (const __attribute__((address_space(3))) float *)hp_smem + k2 * E + (L - 1);
+#pragma unroll 8
                 for (int e = -(L - 1); e <= L - 1; ++e) {
                     const int t = tp - e;
-                    if (t < 0 || t >= Tl) continue;
-                    const float tap = (t < r.t_edge0) ? gr[e] : r.GE[(((size_t)k2 * r.ne + (t - r.t_edge0)) * K32 + k) * E + (L - 1) + e];
-                    s = fmaf(dsr[-e], tap, s);
+                    const float d = (t >= 0 && t < r.t_edge0) ? dsr[-e] : 0.f;
+                    s = fmaf(d, gr[e], s);
+                }
+                const float *ge = r.GE + ((size_t)k2 * r.ne * K32 + k) * E + (L - 1); // + i * K32 * E + e
+                for (int i0 = 0; i0 < r.ne; i0 += 8) { // eight tap rows in flight, then their FMAs (more would spill: the
+                    float gv[8], dv[8];                 // 1024-thread workgroup leaves 128 registers a lane)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i2 = i0 + u, e = tp - (r.t_edge0 + i2);
+                        const bool ok = i2 < r.ne && e >= -(L - 1) && e <= L - 1;
+                        gv[u] = ok ? ge[(size_t)i2 * K32 * E + e] : 0.f;
+                        dv[u] = ok ? dsr[-e] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s = fmaf(dv[u], gv[u], s);
                 }
             }
         }

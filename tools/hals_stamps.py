@@ -61,4 +61,13 @@ for c in np.nonzero(big[r])[0][:3]:
     c = int(c)
     print(f"row {r} block {c+1} ended {per[r, c]:.1f} us after block {c}; it needed the pull of block {c+3} (checked at its middle):")
     for bb in (c + 1, c + 2, c + 3, c + 4):
+        if bb + 1 >= sw.shape[1]:
+            break
         print(f"   pull of block {bb}: src row {r-1} block {bb+1} ended {sw[r-1, bb+1] - sw[r, c]:+.1f}, wait done {pu[r, bb, 0] - sw[r, c]:+.1f}, staged {pu[r, bb, 1] - sw[r, c]:+.1f}, computed {pu[r, bb, 2] - sw[r, c]:+.1f}, flag {pu[r, bb, 3] - sw[r, c]:+.1f}  (us, relative to the end of block {c} of row {r})")
+# the end of a row in detail: relative to the end of the row above (its last stamped block, the edge tail)
+raw_sw = (raw[2:].astype(np.float64) * 0.01)[: Kf * nblk].reshape(Kf, nblk)
+for r in (10, 20):
+    F = raw_sw[r - 1, nblk - 1]
+    print(f"row {r}: ends of its blocks {nblk-6}..{nblk-1} relative to the end of row {r-1} (us):", np.round(raw_sw[r, nblk - 6:] - F, 1).tolist())
+    for bb in range(nblk - 4, nblk):
+        print(f"   pull of block {bb}: wait done {pu[r, bb, 0] - F:+.1f}, staged {pu[r, bb, 1] - F:+.1f}, computed {pu[r, bb, 2] - F:+.1f}, flag {pu[r, bb, 3] - F:+.1f}")
