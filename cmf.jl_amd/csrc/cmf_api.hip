@@ -1484,7 +1484,7 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
     // numH = transconv(W, data) is ONE C3 contraction on the data, denomH = transconv(W, conv(W, H)) comes from the taps
     // above applied to H (gram_h_kernel) -- no transposed residual, i.e. one conv launch (1 ms) less per iteration, and the
     // H sweep's short recurrences (L-1 columns) do not amplify the cancellation: H stays within the residual form's test
-    // bars (1.8e-5 against the oracle where the residual form has 1.2e-5).  hals_gram = 0: P as one C3 contraction on the
+    // bars (1.8e-5 against the fp64 restatement where the residual form has 1.2e-5).  hals_gram = 0: P as one C3 contraction on the
     // transposed residual.
     if (h->hals_gram) {
         const size_t TK = (size_t)d.Tl * d.K32;
