@@ -1658,7 +1658,7 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
                     const float v = gv - wo[i][u] * hpp[i];                  // hals.jl:104 projected
                     float wn = (-v - l1) / (hpp[i] + CMF_EPS_F + l2);        // hals.jl:110
                     wn = fmaxf(wn, 0.f);
-                    wnew[sidx * HALS_NG + u] = wn; // every lane writes the same value; flushed to Wt / Wn after the sweep
+                    if (lane == 0) wnew[sidx * HALS_NG + u] = wn; // (one lane: 64 lanes on one address serialise in the LDS) flushed after the sweep
                     d[u] = (n0 + u < N) ? wn - wo[i][u] : 0.f;
                 }
 #pragma unroll
