@@ -121,3 +121,25 @@ def h_sweep_pull_pipeline(o, W, H, data, l1, l2, block=8, seed=0):
                     P[k, t + e] += D[k, t] * g[k, e + L - 1]
         done[k] += 1
     return H
+
+
+def hh_from_lag_correlations(o, H, L):
+    """HH = H_unfold * H_unfold' (hals.jl:56-60) the way compute_hh / hals_hh_kernel form it: from the lag correlations
+    C[d][a][b] = sum_t H[a][t-d] * H[b][t] of H with itself, minus the terms the shift cuts off at the right end."""
+    K, T = H.shape
+    C = np.zeros((L, K, K))
+    for d in range(L):
+        C[d] = H[:, : T - d] @ H[:, d:].T if d < T else 0.0
+    HH = np.zeros((L * K, L * K))
+    for l in range(L):
+        for lp in range(L):
+            d = abs(l - lp)
+            cut = min(l, lp)
+            for k in range(K):
+                for kp in range(K):
+                    a, b = (k, kp) if l >= lp else (kp, k)  # a: the row with the larger lag
+                    v = C[d][a][b] if d < T else 0.0
+                    for u in range(max(T - cut, d), T):
+                        v -= H[a, u - d] * H[b, u]
+                    HH[l * K + k, lp * K + kp] = v
+    return HH

@@ -238,6 +238,19 @@ def test_hals_gram_form_equals_residual_form(oracle):
             np.testing.assert_allclose(h_sweep_pull_pipeline(oracle, W, H0, data, l1, l2, block=8, seed=seed), Hn, rtol=1e-10, atol=1e-13)
 
 
+def test_hals_hh_from_lag_correlations(oracle):
+    """The Gram matrix of H_unfold assembled from the K x K lag correlations of H (what compute_hh does on the GPU with one
+    C2 contraction on K columns) is H_unfold * H_unfold' (hals.jl:56-60), including the truncation at the right end and
+    lags beyond T."""
+    from hals_gram_form import hh_from_lag_correlations
+
+    rng = np.random.default_rng(1)
+    for K, T, L in ((3, 40, 6), (2, 5, 8), (4, 9, 1)):
+        H = rng.uniform(0, 1, (K, T)) * (rng.uniform(size=(K, T)) > 0.3)
+        Hu = oracle.shift_and_stack(H, L)  # row l*K + k = H[k] shifted right by l
+        np.testing.assert_allclose(hh_from_lag_correlations(oracle, H, L), Hu @ Hu.T, rtol=1e-12, atol=1e-13)
+
+
 def test_pgd_masked_loss_gradient_and_reduction(oracle):
     """MaskedLoss(SquareLoss(), mask) in the PGD restatement (pgd.jl:58-70): with an all-ones mask it is the plain
     SquareLoss; the direction pgd! takes is the gradient of eval(MaskedLoss) (finite differences)."""
