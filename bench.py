@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- MU iterations/sec of the MI355X hot path on BASELINE.json's config 2
-(N=2000, T=50000, K=32, L=20, fp32, alg=:mult), one process per GPU.
+(N=2000, T=50000, K=32, L=20, fp32, alg=:mult).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...                      # launched plainly: ONE process drives the N GPUs (cmf_create_multi)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # one process per GPU (cmf_create_shard + RCCL)
 
 A "step" is one full MU iteration (update_motifs! + update_feature_maps!, alternating.jl:51-54, including the
 per-iteration loss scalar read-back; for N > 1 also the RCCL all-reduce of [numW|denomW|loss tail] and the H halo
@@ -12,7 +13,13 @@ all-gather, both issued by libcmf_hip.so itself).  The K timed steps are ONE cmf
 collectives as K x (cmf_update_motifs; cmf_update_feature_maps), with each loss read one iteration late from pinned
 memory so that the host never stalls the device between iterations (every loss is still read by the host inside
 the timed region).  Inputs (data, W, H) are resident in HBM when the timed region starts.  For N > 1 the T axis of
-the SAME problem is sharded over the ranks ("scaling": "strong").  Rank 0 prints one JSON line.
+the SAME problem is sharded over the GPUs ("scaling": "strong").  Rank 0 prints one JSON line.
+
+Which multi-GPU form runs is decided by `route()`: WORLD_SIZE == --gpus > 1 (a launcher started one process per GPU)
+takes the per-process form; --gpus N > 1 with no launcher takes the one-process form -- no relaunch, no exec.  `comm` in
+the JSON line says which transport carried the collectives, the RCCL version and how many ranks it saw.
+Config 5 (HALS) does not shard over T (its H sweep is sequential along T): with --gpus N it runs N independent
+replicas ("scaling": "weak").
 """
 import argparse
 import json
@@ -23,7 +30,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_PROFILE = "r02e_pmc_summary.json"  # rocprofv3 --pmc passes of this round's kernels (profiles/README.md)
+PMC_PROFILE = "r03_pmc_summary.json"  # rocprofv3 --pmc passes of this round's kernels (profiles/README.md)
+PMC_FALLBACK = "r02e_pmc_summary.json"
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 CONFIGS = {
     1: dict(N=500, T=2000, K=5, L=10),
@@ -34,9 +42,39 @@ CONFIGS = {
 }
 
 
+def route(gpus, world_size):
+    """Which form of the run (gpus, WORLD_SIZE) asks for:
+    "single" -- one GPU, one process; "multi" -- ONE process drives `gpus` GPUs (cmf_create_multi, RCCL ncclCommInitAll):
+    what a plain `python bench.py --gpus N` gets; "ranks" -- a launcher (torch.distributed.run) started one process per
+    GPU (cmf_create_shard + cmf_comm_init_rccl).  Anything else is a launcher / flag mismatch."""
+    gpus, world_size = int(gpus), int(world_size or 1)
+    if gpus < 1:
+        raise ValueError(f"--gpus must be >= 1 (got {gpus})")
+    if world_size == 1:
+        return "single" if gpus == 1 else "multi"
+    if world_size == gpus:
+        return "ranks"
+    raise ValueError(f"--gpus {gpus} but WORLD_SIZE={world_size}: start one process per GPU (torch.distributed.run "
+                     f"--nproc-per-node {gpus}) or none at all (plain `python bench.py --gpus {gpus}`)")
+
+
 def flops_per_iter(N, T, K, L):
     S = L * T - L * (L - 1) / 2
     return 14.0 * K * N * S  # SURVEY.md section 8d: 7 contractions x 2*K*N*S
+
+
+def parse_comm(info, mode, fallback=None):
+    """cmf_comm_info's text as a record: did the collectives go through RCCL, which one, and how many ranks did it see."""
+    rec = {"mode": mode, "info": info}
+    for tok in info.split():
+        if "=" in tok:
+            k, v = tok.split("=", 1)
+            rec[k] = int(v) if v.lstrip("-").isdigit() else v
+    if "ranks" in rec and isinstance(rec["ranks"], str):
+        rec["devices"] = [int(x.split("@dev")[1]) for x in rec["ranks"].split(",") if "@dev" in x]
+    if fallback:
+        rec["fallback_from_rccl"] = fallback
+    return rec
 
 
 def cpu_baseline_hals(data, W0, H0, budget_s):
@@ -91,9 +129,106 @@ def cpu_baseline(data, W0, H0, budget_s):
                        f"(+{t1 - t0:.1f} s rule setup)")
 
 
+def hals_roofline(T, K, L, spans, ms_per_step):
+    """The dominant part of a HALS iteration is the K*T strictly ordered H entry updates (hals.jl:121-154), run as a
+    software pipeline over the rows (one persistent launch, hals_h_persist_kernel: a sweeper wave per row, puller
+    workgroups applying the cross-row terms, flags in memory between them; CMF_HALS_PERSIST=0 selects the older
+    one-launch-per-stage form).  Its bound is dependency latency, not MFMA or HBM: entry (k, t) needs (k, t-1) and the
+    push of (k-1, t+L-1), so the critical path is T + (K-1)(L-1) dependent steps.  A step of the sweep is 9 single-wave
+    instructions whose chain is one FMA and one MAX; in isolation it issues in 43 cycles (tools/valu_latency.hip,
+    profiles/).  achieved = critical-path steps per second over the measured pipeline span; peak = one step per 43
+    cycles at 2.4 GHz."""
+    pipe_ms, n_pipe = spans.get("hals_h_pipeline", (0.0, 0))
+    wsw_ms, _ = spans.get("hals_w_sweep", (0.0, 0))
+    STEP_CYCLES, CLK = 43.0, 2.4e9
+    crit_steps = T + (K - 1) * (L - 1)
+    peak_steps = CLK / STEP_CYCLES
+    ach_steps = crit_steps / (pipe_ms * 1e-3) if pipe_ms else 0.0
+    return {"bound": "dependency-latency",
+            "kernel": ("hals_h_stage_kernel" if os.environ.get("CMF_HALS_PERSIST") == "0" else "hals_h_persist_kernel")
+                      + " row pipeline (K*T ordered entry updates of H, hals.jl:121-154)",
+            "achieved": ach_steps, "peak": peak_steps, "unit": "critical-path steps/s", "frac": ach_steps / peak_steps,
+            "traffic": None, "critical_path_steps": crit_steps, "step_cycles_model": STEP_CYCLES,
+            "pipeline_span_ms": pipe_ms, "pipeline_spans_timed": n_pipe, "pipeline_floor_ms": 1e3 * crit_steps / peak_steps,
+            "share_of_step": pipe_ms / ms_per_step if ms_per_step else None,
+            "w_sweep_ms": wsw_ms,
+            "timing": "HIP event pair around the whole pipeline inside the timed region (option profile)"}
+
+
+def hals_steps(rule, n, reg_kw):
+    out_ = []
+    for _ in range(n):  # HALS: the rule's two calls per step
+        rule.update_motifs(l1W=reg_kw["l1W"], l2W=reg_kw["l2W"])
+        out_.append(rule.update_feature_maps(l1H=reg_kw["l1H"], l2H=reg_kw["l2H"]))
+    return out_
+
+
+def other_configs(cmf, rule, data, W0, H0, N, T, K, L, with_config3, device):
+    """BASELINE.json's other configurations in the same run, same inputs and seeds (short: they are reported next to the
+    headline, never part of `value`): config 4 (regularised MU) on the resident rule, config 5 (HALS) on a second rule
+    over the same data with its latency roofline block, config 3's whole problem (T=400000) on this one GPU."""
+    zero = dict(l1W=0.0, l2W=0.0, l1H=0.0, l2H=0.0)
+    res = {}
+
+    def mu_time(r, nsteps, kw):
+        r.iterate(1, **kw)
+        t0 = time.perf_counter()
+        ls = r.iterate(nsteps, **kw)
+        return (time.perf_counter() - t0) / nsteps, ls
+
+    try:  # config 4: config 2 + l1_H=0.1 l2_H=0.2 l1_W=0.1 l2_W=0.5 (README.md:52)
+        rule.upload(W0, H0)
+        c4 = CONFIGS[4]
+        kw = dict(l1W=c4["l1_W"], l2W=c4["l2_W"], l1H=c4["l1_H"], l2H=c4["l2_H"])
+        dt, ls = mu_time(rule, 5, kw)
+        res["configs[3]"] = {"workload": "N=2000 T=50000 K=32 L=20 alg=:mult l1_H=0.1 l2_H=0.2 l1_W=0.1 l2_W=0.5", "steps": 5, "warmup": 1,
+                             "ms_per_step": 1e3 * dt, "iters_per_s": 1.0 / dt, "loss_last": float(ls[-1])}
+    except Exception as e:  # noqa: BLE001 - side measurements never cost the headline
+        res["configs[3]"] = {"error": repr(e)}
+    try:  # config 5: alg=:hals
+        hr = cmf.HALSUpdate(data, W0, H0, device=device)
+        try:
+            hals_steps(hr, 1, zero)
+            hr.set_option("profile", 1)
+            t0 = time.perf_counter()
+            ls = hals_steps(hr, 5, zero)
+            dt = (time.perf_counter() - t0) / 5
+            spans = {nm: hr.kernel_times(nm) for nm in ("hals_h_pipeline", "hals_w_sweep")}
+            hr.set_option("profile", 0)
+            res["configs[4]"] = {"workload": "N=2000 T=50000 K=32 L=20 alg=:hals", "steps": 5, "warmup": 1, "ms_per_step": 1e3 * dt,
+                                 "iters_per_s": 1.0 / dt, "loss_last": float(ls[-1]), "metric": "HALS iters/sec",
+                                 "pipeline_reruns": hr.counter("hals_pipeline_reruns"),
+                                 "roofline": hals_roofline(T, K, L, spans, 1e3 * dt)}
+        finally:
+            hr.close()
+    except Exception as e:  # noqa: BLE001
+        res["configs[4]"] = {"error": repr(e)}
+    if with_config3:
+        try:  # config 3's problem on ONE GPU (its 8-GPU form gives every GPU exactly the config-2 shard)
+            c3 = CONFIGS[3]
+            t0 = time.perf_counter()
+            d3 = cmf.gen_synthetic(N=c3["N"], T=c3["T"], seed=1234, device=device)
+            W3, H3 = cmf.init_rand(d3, L=c3["L"], K=c3["K"], seed=0, device=device)
+            r3 = cmf.MultUpdate(d3, W3, H3, device=device)
+            setup = time.perf_counter() - t0
+            try:
+                dt, ls = mu_time(r3, 2, zero)
+                F3 = flops_per_iter(c3["N"], c3["T"], c3["K"], c3["L"]) * 6.0 / 7.0
+                res["configs[2]"] = {"workload": "N=2000 T=400000 K=32 L=20 alg=:mult, the whole problem on 1xMI355X (unsharded)", "steps": 2,
+                                     "warmup": 1, "ms_per_step": 1e3 * dt, "iters_per_s": 1.0 / dt, "loss_last": float(ls[-1]),
+                                     "whole_iteration_mfma_frac": F3 / dt / (PEAK_FP32_MFMA_TFLOPS * 1e12), "setup_s": setup}
+            finally:
+                r3.close()
+        except Exception as e:  # noqa: BLE001
+            res["configs[2]"] = {"error": repr(e)}
+    return res
+
+
 def main():
     # the oracle's OpenMP loops (HALS baseline) are short: one thread per visible core only adds spinning
     os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+    # RCCL shares device buffers between processes through dmabuf IPC; the host driver of these boxes supports only that
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -101,17 +236,20 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--T", type=int, default=0, help="override T (debugging only; invalidates the metric)")
-    ap.add_argument("--sustain", type=float, default=3.0, help="seconds of back-to-back iterations after the timed steps (0 = skip)")
+    ap.add_argument("--sustain", type=float, default=8.0, help="seconds of back-to-back iterations after the timed steps (0 = skip)")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the no-reuse / Gram-form side measurements (profiling runs: keeps one launch shape per kernel)")
+                    help="skip the no-reuse / Gram-form / other-config side measurements (profiling runs: keeps one launch shape per kernel)")
+    ap.add_argument("--no-config3", action="store_true", help="skip config 3 (T=400000 on one GPU) in other_configs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    try:
+        form = route(args.gpus, os.environ.get("WORLD_SIZE", "1"))
+    except ValueError as e:
+        raise SystemExit(str(e))
+    world = args.gpus if form == "ranks" else 1   # processes
+    ngpu = args.gpus                              # GPUs of the job
 
     import numpy as np
 
@@ -126,7 +264,8 @@ def main():
     reg_kw = dict(l1W=reg.get("l1_W", 0.0), l2W=reg.get("l2_W", 0.0), l1H=reg.get("l1_H", 0.0), l2H=reg.get("l2_H", 0.0))
 
     dist = None
-    if world > 1:
+    backend = None
+    if form == "ranks":
         import torch
         import torch.distributed as dist
 
@@ -142,24 +281,37 @@ def main():
             dist.init_process_group(backend)
     if rank == 0:
         __graft_entry__.build(quiet=True)  # no-op when the in-tree .so files are current
-    if world > 1:
+    if form == "ranks":
         dist.barrier()
     import cmf_jl_amd as cmf
 
-    cmf.load_library()
+    lib = cmf.load_library()
+    if form == "multi" and lib.cmf_device_count() < ngpu:
+        print(f"bench.py --gpus {ngpu}: only {lib.cmf_device_count()} HIP device(s) visible "
+              f"(cmf_last_error: {lib.cmf_last_error().decode() or 'none'})", file=sys.stderr, flush=True)
+        sys.exit(2)
 
     # ---- synthetic inputs: gen_synthetic(seed 1234) + init_rand(seed 0), SURVEY.md section 8d ----
     # Every rank generates the same arrays (counter-based RNG) and keeps its own T block.
     data = cmf.gen_synthetic(N=N, T=T, seed=1234, device=local_rank)
     W0, H0 = cmf.init_rand(data, L=L, K=K, seed=0, device=local_rank)
 
-    if alg == "hals" and world > 1:
-        raise SystemExit("config 5 (HALS) does not shard: its H sweep is sequential along T (replicas only)")
-    if world == 1:
-        rule = (cmf.HALSUpdate if alg == "hals" else cmf.MultUpdate)(data, W0, H0, device=local_rank)
-
-        def sync():
-            pass  # every batch ends with its last loss on the host: the stream is drained
+    replicas = []
+    overlap_env = os.environ.get("CMF_ALLREDUCE_OVERLAP", "0")
+    if alg == "hals":
+        # replicas only: the H sweep is one dependent chain along T, nothing to exchange
+        devs = list(range(ngpu)) if form == "multi" else [local_rank]
+        replicas = [cmf.HALSUpdate(data, W0, H0, device=d) for d in devs]
+        rule = replicas[0]
+    elif form == "single":
+        rule = cmf.MultUpdate(data, W0, H0, device=local_rank)
+    elif form == "multi":
+        # ONE process, ngpu devices: cmf_create_multi -> RCCL communicators from ncclCommInitAll, a stream per device
+        try:
+            rule = cmf.MultUpdate(data, W0, H0, devices=list(range(ngpu)))
+        except cmf.CMFError as e:
+            print(f"bench.py --gpus {ngpu}: the {ngpu}-device group could not be formed: {e}", file=sys.stderr, flush=True)
+            sys.exit(2)
     else:
         from cmf_jl_amd.sharded import ShardedMultUpdate
 
@@ -167,12 +319,11 @@ def main():
         # transport (torch.distributed on staged buffers) so that the run still measures something -- reported in `comm`
         rule = ShardedMultUpdate(data, W0, H0, device=local_rank, fallback_to_host=True,
                                  transport=os.environ.get("CMF_TRANSPORT", "rccl" if backend == "nccl" else "host"))
-        # "0" (default): everything on one stream, the plain single all-reduce; "1": the overlap form; "probe": time both
-        # for a few steps and keep the faster.  The overlap form puts a second collective of the same communicator on a
-        # second stream; it is verified on one device only, so it is opt-in until it has run across GPUs.
-        overlap_env = os.environ.get("CMF_ALLREDUCE_OVERLAP", "0")
 
-        def sync():
+    def sync():
+        for r in (replicas or [rule]):
+            r.synchronize()  # every stream of every local shard
+        if form == "ranks":
             import torch
 
             dist.barrier()
@@ -184,11 +335,21 @@ def main():
             return []
         if alg == "mult":
             return list(rule.iterate(n, **reg_kw))  # cmf_iterate
-        out_ = []
-        for _ in range(n):  # HALS: the rule's two calls per step
-            rule.update_motifs(l1W=reg_kw["l1W"], l2W=reg_kw["l2W"])
-            out_.append(rule.update_feature_maps(l1H=reg_kw["l1H"], l2H=reg_kw["l2H"]))
-        return out_
+        if len(replicas) > 1:  # independent replicas, one host thread each
+            import threading
+
+            outs = [None] * len(replicas)
+
+            def work(i):
+                outs[i] = hals_steps(replicas[i], n, reg_kw)
+
+            th = [threading.Thread(target=work, args=(i,)) for i in range(len(replicas))]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            return outs[0]
+        return hals_steps(rule, n, reg_kw)
 
     def timed(nwarm, nsteps):
         run_steps(nwarm)
@@ -197,7 +358,7 @@ def main():
         ls = run_steps(nsteps)
         sync()
         el = time.perf_counter() - t0
-        if world > 1:
+        if form == "ranks":
             import torch
 
             tmax = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -207,19 +368,20 @@ def main():
 
     loss0 = rule.compute_loss()
     probe = None
-    if world > 1:
-        # Two forms of the W phase exist (sharded.py): one all-reduce of [numW | denomW] after both contractions, or
+    sharded = alg == "mult" and ngpu > 1
+    if sharded:
+        # Two forms of the W phase exist (cmf_group.h): one all-reduce of [numW | denomW] after both contractions, or
         # numW contracted and all-reduced right after the H update, underneath the loss conv and the denominator
-        # contraction.  Which one is faster depends on the all-reduce time of this node: time a few steps of each
-        # (max over ranks, so every rank takes the same decision) and keep the faster for the timed region.
+        # contraction.  "0" (default): everything on one stream, the plain single all-reduce; "1": the overlap form;
+        # "probe": time a few steps of each (max over ranks, so every rank takes the same decision), keep the faster.
         if overlap_env in ("0", "1"):
             rule.set_overlap(overlap_env == "1")
         else:
             probe = {}
-            for form in (False, True):
-                rule.set_overlap(form)
+            for f_ in (False, True):
+                rule.set_overlap(f_)
                 timed(2, 0)
-                probe["overlap" if form else "single"] = timed(0, 5)[0] / 5
+                probe["overlap" if f_ else "single"] = timed(0, 5)[0] / 5
             rule.set_overlap(probe["overlap"] < probe["single"])
     # The timed region carries HIP event pairs around every fourth launch of each contraction kernel (option "profile": events on the
     # launch stream), so the per-kernel durations of the roofline block are measured live over these very steps.
@@ -233,13 +395,14 @@ def main():
         if n:
             inloop[name] = (kms, n)
     prof.set_option("profile", 0)
+    hals_spans = {}
     if alg != "mult":
         hals_spans, inloop = inloop, {}
     dt_unprofiled = None
-    if alg == "mult" and world == 1:
+    if alg == "mult" and form == "single":
         dt_unprofiled, _ = timed(0, args.steps)
-    # Steady state: the timed region above is ~0.1 s; run back-to-back iterations for >= 3 s more (same call) so that the
-    # figure also holds at the clock the card settles to (and the driver's GPU-busy sampling has something to see).
+    # Steady state: the timed region above is ~0.1 s; run back-to-back iterations for several seconds more (same call) so that
+    # the figure also holds at the clock the card settles to (and the driver's GPU-busy sampling has something to see).
     sustained = None
     if alg == "mult" and args.sustain > 0:
         per = max(dt / max(args.steps, 1), 1e-4)
@@ -249,7 +412,8 @@ def main():
     # Same loop with the reference's redundant est recomputation left in (7 executed contractions
     # instead of 6): reported beside the headline so both numbers come from one run.
     dt_noreuse = None
-    if world == 1 and alg == "mult" and not args.no_extras:
+    extras = form == "single" and alg == "mult" and not args.no_extras
+    if extras:
         rule.set_option("reuse_est", 0)
         dt_noreuse, _ = timed(1, max(3, args.steps // 2))
         dt_noreuse /= max(3, args.steps // 2)
@@ -257,7 +421,7 @@ def main():
     # Optional Gram form of the denominators (executes 2.3 + 1 contractions): reported as
     # extra fields only, the headline value is the reference formulation above.
     dt_gram = dt_gram2 = None
-    if world == 1 and alg == "mult" and not args.no_extras:
+    if extras:
         nrep = max(3, args.steps // 2)
         rule.upload(W0, H0)
         rule.set_option("gram", 1)
@@ -269,31 +433,46 @@ def main():
         rule.set_option("gram", 0)
 
     out = None
+    nrep_hals = len(replicas) if form == "multi" else (world if alg == "hals" else 1)
     if rank == 0:
         ms = 1e3 * dt / args.steps
-        iters_per_s = args.steps / dt
+        iters_per_s = args.steps / dt * (nrep_hals if alg == "hals" else 1)
         F_iter = flops_per_iter(N, T, K, L)
         if alg == "hals":
             # executed MFMA work of one HALS iteration: hxt (2 sources) + Gram of H_unfold (L*K32 columns instead
             # of N) + conv_t + transconv (2 sources) + loss conv; the sweeps themselves are latency-bound VALU work
             F_iter = (6.0 + (L * 32.0 * ((K + 31) // 32)) / N) * 2.0 * K * N * (L * T - L * (L - 1) / 2)
+        if alg == "hals":
+            comm = {"mode": "replicas", "nranks": nrep_hals, "info": "independent replicas, no data-path collective"} if ngpu > 1 else None
+        elif ngpu > 1:
+            comm = parse_comm(rule.comm_info(), "one-process" if form == "multi" else "one-process-per-gpu",
+                              getattr(rule, "transport_fallback", None))
+            try:
+                comm["rccl"] = cmf.rccl_version()
+            except Exception as e:  # noqa: BLE001
+                comm["rccl"] = {"error": repr(e)}
+            comm["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+        else:
+            comm = None
         out = {
             "metric": ("MU iters/sec (convolutive NMF multiplicative update; achieved HBM GB/s in `hbm`)" if alg == "mult"
                        else "HALS iters/sec (convolutive NMF, src/algs/hals.jl)"),
-            "value": iters_per_s, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "value": iters_per_s, "unit": "iter/s", "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if alg == "mult" else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[{args.config - 1}]: N={N} T={T} K={K} L={L} fp32 alg=:{alg}"
                                    + (" regularised " + json.dumps(reg) if reg else "")
-                                   + (f", T sharded over {world} GPUs, RCCL all-reduce on W" if world > 1 else " on 1xMI355X"),
-                       "N": N, "T": T, "K": K, "L": L, "parallelism": f"t-shard{world}",
-                       "gen_synthetic_seed": 1234, "init_rand_seed": 0,
+                                   + (f", T sharded over {ngpu} GPUs, RCCL all-reduce on W" if sharded else
+                                      (f", {nrep_hals} independent replicas" if ngpu > 1 else " on 1xMI355X")),
+                       "N": N, "T": T, "K": K, "L": L, "parallelism": f"t-shard{ngpu}" if alg == "mult" else f"replicas{ngpu}",
+                       "launch": form, "gen_synthetic_seed": 1234, "init_rand_seed": 0,
                        "loss_first": loss0, "loss_last": losses[-1] if losses else loss0},
+            "library": lib.cmf_version().decode(),
             "flops_per_iter": F_iter,
             "executed_flops_per_iter": F_iter * 6.0 / 7.0 if alg == "mult" else F_iter,
             "est_reuse": "the est of mult.jl:55 is kept for the next mult.jl:28 (same W, H): 6 of the 7 contractions "
                          "are executed, results bitwise identical; ms_per_step_no_reuse runs all 7",
-            "allreduce_overlap": (bool(rule.overlap) if world > 1 else None),
+            "allreduce_overlap": (bool(rule.overlap) if sharded else None),
             "allreduce_overlap_probe_ms": ({k: 1e3 * v for k, v in probe.items()} if probe else None),
             "ms_per_step_without_event_pairs": (1e3 * dt_unprofiled / args.steps) if dt_unprofiled else None,
             "ms_per_step_no_reuse": (1e3 * dt_noreuse) if dt_noreuse else None,
@@ -304,11 +483,10 @@ def main():
             # whole-iteration MFMA fraction on EXECUTED flops (6 contractions with est reuse); the 7-contraction figure of
             # SURVEY.md section 8d is kept under an explicit name: it exceeds the executed one by 7/6 by construction
             "whole_iteration_tflops_executed": (F_iter * (6.0 / 7.0 if alg == "mult" else 1.0)) * iters_per_s / 1e12,
-            "whole_iteration_mfma_frac": (F_iter * (6.0 / 7.0 if alg == "mult" else 1.0)) * iters_per_s / (world * PEAK_FP32_MFMA_TFLOPS * 1e12),
-            "whole_iteration_mfma_frac_reference_formulation_equivalent": F_iter * iters_per_s / (world * PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "whole_iteration_mfma_frac": (F_iter * (6.0 / 7.0 if alg == "mult" else 1.0)) * iters_per_s / (ngpu * PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "whole_iteration_mfma_frac_reference_formulation_equivalent": F_iter * iters_per_s / (ngpu * PEAK_FP32_MFMA_TFLOPS * 1e12),
             "sustained": sustained,
-            "comm": (rule.comm_info() + (f" FALLBACK from rccl: {rule.transport_fallback}" if rule.transport_fallback else "")
-                     if world > 1 else None),
+            "comm": comm,
         }
 
     # ---- roofline of the dominant kernel = the class with the largest share of the timed region; durations from
@@ -319,10 +497,18 @@ def main():
              "transconv": "transconv_kernel<LT> (W' x data and W' x est, mult.jl:47-48)", "hxt": "hxt_kernel<LP> (H_shift x data' and H_shift x est', mult.jl:31-34)",
              "conv_t": "conv3_kernel<1> (tensor_conv, est'[n][t], mult.jl:44)", "conv_loss_store": "conv3_kernel<3> (tensor_conv + loss, mult.jl:55-57)",
              "conv": "conv3_kernel<0> (tensor_conv, mult.jl:28)", "conv_loss": "conv3_kernel<2> (tensor_conv + loss, mult.jl:55-57)"}
+
+    def load_pmc():
+        for nm in (PMC_PROFILE, PMC_FALLBACK):
+            pth = os.path.join(ROOT, "profiles", nm)
+            if os.path.exists(pth):
+                return json.load(open(pth)), nm
+        raise FileNotFoundError("no PMC summary under profiles/")
+
     if rank == 0:
         kern = {}
         timer = rule
-        Tl = T // world
+        Tl = T // ngpu if alg == "mult" else T
         f1 = 2.0 * K * N * (L * Tl - L * (L - 1) / 2)  # one contraction on this rank's columns
         for name in ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv"):
             kms, kfl = timer.time_kernel(name, reps=5)
@@ -343,73 +529,53 @@ def main():
             src = "cmf_time_kernel: HIP events around 5 stand-alone launches"
         traffic, traffic_src = None, None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload, same kernel)
-            if args.config in (2, 4) and world == 1 and not args.T:
-                pm = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
+            if args.config in (2, 4) and ngpu == 1 and not args.T:
+                pm, pm_name = load_pmc()
                 traffic = pm[PMC_NAMES[dom]]["hbm_bytes_corrected"]
-                traffic_src = f"profiled earlier, not in this run: profiles/{PMC_PROFILE} -- (2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes of this workload"
+                traffic_src = f"profiled earlier, not in this run: profiles/{pm_name} -- (2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes of this workload"
         except Exception:
             pass
-        out["roofline"] = {"bound": "mfma", "kernel": DESCR[dom] + ("" if world == 1 else f" on rank 0's shard of {Tl} columns"),
+        out["roofline"] = {"bound": "mfma", "kernel": DESCR[dom] + ("" if ngpu == 1 or alg != "mult" else f" on rank 0's shard of {Tl} columns"),
                            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_flops_per_launch": kfl, "avg_launch_ms": avg_ms, "timing": src}
 
     if rank == 0 and alg == "hals":
-        # The dominant part of a HALS iteration is the K*T strictly ordered H entry updates (hals.jl:121-154), run as a
-        # software pipeline over the rows (one persistent launch, hals_h_persist_kernel: a sweeper wave per row, puller
-        # workgroups applying the cross-row terms, flags in memory between them; CMF_HALS_PERSIST=0 selects the older
-        # one-launch-per-stage form).  Its bound is dependency latency, not MFMA or HBM: entry
-        # (k, t) needs (k, t-1) and the push of (k-1, t+L-1), so the critical path is T + (K-1)(L-1) dependent steps.  A
-        # step of the sweep is 9 single-wave instructions whose chain is one FMA and one MAX; in isolation it issues in
-        # 43 cycles (tools/valu_latency.hip, profiles/).  achieved = critical-path steps per second over the measured
-        # pipeline span; peak = one step per 43 cycles at 2.4 GHz.  What separates them: a row runs ~11 us
-        # behind the row above (five 64-column blocks plus two flag hand-offs) where 19 columns would do, and the rows'
-        # tails (edge columns) run one after the other.
-        pipe_ms, n_pipe = hals_spans.get("hals_h_pipeline", (0.0, 0))
-        wsw_ms, _ = hals_spans.get("hals_w_sweep", (0.0, 0))
-        STEP_CYCLES, CLK = 43.0, 2.4e9
-        crit_steps = T + (K - 1) * (L - 1)
-        peak_steps = CLK / STEP_CYCLES
-        ach_steps = crit_steps / (pipe_ms * 1e-3) if pipe_ms else 0.0
         out["roofline_mfma_kernel"] = out["roofline"]
-        out["roofline"] = {"bound": "dependency-latency",
-                           "kernel": ("hals_h_stage_kernel" if os.environ.get("CMF_HALS_PERSIST") == "0" else "hals_h_persist_kernel")
-                                     + " row pipeline (K*T ordered entry updates of H, hals.jl:121-154)",
-                           "achieved": ach_steps, "peak": peak_steps, "unit": "critical-path steps/s", "frac": ach_steps / peak_steps,
-                           "traffic": None, "critical_path_steps": crit_steps, "step_cycles_model": STEP_CYCLES,
-                           "pipeline_span_ms": pipe_ms, "pipeline_spans_timed": n_pipe, "pipeline_floor_ms": 1e3 * crit_steps / peak_steps,
-                           "share_of_step": pipe_ms / (1e3 * dt / args.steps) if dt else None,
-                           "w_sweep_ms": wsw_ms,
-                           "timing": "HIP event pair around the whole pipeline inside the timed region (option profile)"}
+        out["roofline"] = hals_roofline(T, K, L, hals_spans, 1e3 * dt / args.steps if dt else None)
+        out["hals_pipeline_reruns"] = rule.counter("hals_pipeline_reruns")
 
     if rank == 0 and alg == "mult":
         # BASELINE.json's metric also asks for the achieved HBM rate.  Algorithmic bytes per iteration
         # (est never round-tripped): B_iter = 12*N*T + 48*K*N*L + 40*K*T; measured bytes
-        # per iteration = sum of the PMC-corrected traffic of the four big launches (profiles/r01k_pmc_summary.json).
+        # per iteration = sum of the PMC-corrected traffic of the four big launches (profiles/*_pmc_summary.json).
         B_iter = 12.0 * N * T + 48.0 * K * N * L + 40.0 * K * T
         hbm = {"algorithmic_bytes_per_iter": B_iter, "achieved_algorithmic_GBps": B_iter * out["value"] / 1e9,
                "peak_GBps": 8000.0, "note": "the path is fp32-MFMA-bound (intensity ~700 flop/B), not HBM-bound"}
         try:
-            if args.config in (2, 4) and world == 1 and not args.T:
-                pm = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
+            if args.config in (2, 4) and ngpu == 1 and not args.T:
+                pm, pm_name = load_pmc()
                 meas = sum(pm[k]["hbm_bytes_corrected"] for k in ("void hxt_kernel<5>", "void conv3_kernel<1>",
                                                                  "void transconv_kernel<20>", "void conv3_kernel<3>"))
                 hbm["profiled_bytes_per_iter"] = meas
                 hbm["profiled_GBps"] = meas * out["value"] / 1e9
-                hbm["profiled_source"] = f"profiles/{PMC_PROFILE} (PMC passes run separately, not in this run)"
+                hbm["profiled_source"] = f"profiles/{pm_name} (PMC passes run separately, not in this run)"
         except Exception:
             pass
         out["hbm"] = hbm
+    if rank == 0 and extras and args.config == 2 and not args.T:
+        out["other_configs"] = other_configs(cmf, rule, data, W0, H0, N, T, K, L, not args.no_config3, local_rank)
     if rank == 0:
-        if args.cpu_seconds > 0 and world == 1:
+        if args.cpu_seconds > 0 and ngpu == 1:
             try:
                 out["cpu_baseline"] = (cpu_baseline_hals if alg == "hals" else cpu_baseline)(data, W0, H0, args.cpu_seconds)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line for it
                 out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
-    rule.close()
-    if world > 1:
+    for r in (replicas or [rule]):
+        r.close()
+    if form == "ranks":
         dist.barrier()
         dist.destroy_process_group()
 

@@ -8,7 +8,7 @@ from .host import (  # noqa: F401
     EPSILON, AbsoluteLoss, AbsolutePenalty, AbstractCFUpdate, AlternatingOptimizer, CNMF_results, HALSUpdate, HIPHALSUpdate,
     HIPMultUpdate, HIPPGDUpdate, MaskedLoss, MultUpdate, NonnegConstraint, PGDUpdate, SquareLoss, SquarePenalty, UnitNormConstraint,
     compute_loss, converged, evaluate_convergence, evaluate_mse, evaluate_test, fit, fit_cnmf, gen_synthetic,
-    init_rand, load_model, parameter_sweep, save_model, tensor_conv, tensor_transconv,
+    init_rand, load_model, parameter_sweep, rccl_version, save_model, tensor_conv, tensor_transconv,
 )
 
 __version__ = "0.1.0"

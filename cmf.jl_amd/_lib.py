@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libcmf_hip.so")
 
 CMF_OK, CMF_ERR_ARG, CMF_ERR_HIP, CMF_ERR_STATE, CMF_ERR_UNSUPPORTED, CMF_ERR_COMM = 0, 1, 2, 3, 4, 5
 CMF_COMM_AUTO, CMF_COMM_RCCL, CMF_COMM_LOOPBACK = 0, 1, 2
+ABI_VERSION = 3  # CMF_ABI_VERSION of include/cmf_hip.h
 
 # host-collective callbacks of cmf_comm_init_callbacks (include/cmf_hip.h)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int64)
@@ -24,8 +25,9 @@ ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ct
 
 # every symbol include/cmf_hip.h declares (tests check the library exports each one)
 SYMBOLS = [
-    "cmf_version", "cmf_last_error", "cmf_device_count",
-    "cmf_create", "cmf_create_shard", "cmf_create_multi", "cmf_destroy", "cmf_set_stream",
+    "cmf_abi_version", "cmf_version", "cmf_source_digest", "cmf_last_error", "cmf_device_count",
+    "cmf_create", "cmf_create_shard", "cmf_create_multi", "cmf_destroy", "cmf_synchronize", "cmf_set_stream",
+    "cmf_rccl_version", "cmf_get_counter",
     "cmf_comm_unique_id", "cmf_comm_init_rccl", "cmf_comm_init_callbacks", "cmf_comm_info", "cmf_shard_bounds",
     "cmf_set_option", "cmf_get_data_sumsq",
     "cmf_set_factors", "cmf_get_factors",
@@ -51,10 +53,25 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # Build provenance: the library carries a digest of the sources it was compiled from (cmf_source_digest).  With the
+    # tree at hand, a binary that does not match it is rebuilt -- or refused when that is impossible; never loaded silently.
+    from . import build as _build
+
+    want = _build.source_digest() if all(os.path.exists(d) for d in _build.DEPS) else None
+    if want is not None and _build.embedded_digest(LIB_PATH) != want:
+        try:
+            _build.build_lib(force=True)
+        except Exception as e:  # noqa: BLE001
+            raise CMFError(CMF_ERR_HIP, f"{LIB_PATH} is missing or was not built from this tree (source digest {want}) and "
+                                        f"cannot be rebuilt here: {e!r} (the HIP path is the only implementation)") from e
     if not os.path.exists(LIB_PATH):
         raise CMFError(CMF_ERR_HIP, f"{LIB_PATH} not found: build it with `python cmf.jl_amd/build.py` "
                                     "(the HIP path is the only implementation)")
     lib = ctypes.CDLL(LIB_PATH)
+    lib.cmf_source_digest.restype = ctypes.c_char_p
+    have = lib.cmf_source_digest().decode()
+    if want is not None and have != want:
+        raise CMFError(CMF_ERR_HIP, f"{LIB_PATH} carries source digest {have}, the tree has {want}")
     i64, u64, dbl, cint = ctypes.c_int64, ctypes.c_uint64, ctypes.c_double, ctypes.c_int
     pd, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
     pvp, pi64 = ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)
@@ -64,7 +81,12 @@ def load():
         f.argtypes = argtypes
         f.restype = restype
 
+    sig("cmf_abi_version", [])
     sig("cmf_version", [], ctypes.c_char_p)
+    sig("cmf_source_digest", [], ctypes.c_char_p)
+    sig("cmf_synchronize", [vp])
+    sig("cmf_rccl_version", [ctypes.POINTER(cint), ctypes.c_char_p, i64])
+    sig("cmf_get_counter", [vp, ctypes.c_char_p, pi64])
     sig("cmf_last_error", [], ctypes.c_char_p)
     sig("cmf_device_count", [])
     sig("cmf_create", [pvp, cint, i64, i64, i64, i64, pd])
@@ -101,6 +123,8 @@ def load():
     sig("cmf_gen_synthetic", [cint, i64, i64, i64, i64, dbl, dbl, dbl, dbl, u64, pd, pd, pd])
     sig("cmf_kernel_times", [vp, ctypes.c_char_p, pd, pi64])
     sig("cmf_time_kernel", [vp, ctypes.c_char_p, cint, pd, pd])
+    if lib.cmf_abi_version() != ABI_VERSION:
+        raise CMFError(CMF_ERR_STATE, f"{LIB_PATH} implements ABI {lib.cmf_abi_version()}, this binding expects {ABI_VERSION}")
     _lib = lib
     return lib
 

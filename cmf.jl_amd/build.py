@@ -6,6 +6,7 @@
 hipcc cross-compiles for gfx950 without a GPU, so this also runs in the CPU-only
 build container; the resulting .so travels to the GPU box with the repo snapshot.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -27,21 +28,51 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: libcmf_hip.so cannot be built (there is no CPU fallback)")
 
 
+def source_digest():
+    """What cmf_source_digest() (include/cmf_hip.h) must return for a library built from this tree: the first 16 hex
+    characters of SHA-256 over the sources in DEPS order, each preceded by its base name and a newline."""
+    h = hashlib.sha256()
+    for path in DEPS:
+        h.update(os.path.basename(path).encode() + b"\n")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def embedded_digest(lib_path=LIB):
+    """The digest compiled into an existing libcmf_hip.so, read from the file without loading it (None if absent)."""
+    try:
+        with open(lib_path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    tag = b"cmf_hip gfx950 "
+    i = blob.find(tag)
+    while i >= 0:
+        end = blob.find(b"\0", i)
+        text = blob[i:end].decode("ascii", "replace")
+        if " src=" in text:
+            return text.rsplit(" src=", 1)[1]
+        i = blob.find(tag, i + 1)
+    return None
+
+
 def is_stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    """A binary is current when the digest compiled into it is the digest of the tree (mtimes do not survive the copy to
+    the GPU box, and a prebuilt .so that no longer matches csrc/ must never be loaded silently)."""
+    return embedded_digest() != source_digest()
 
 
 def build_lib(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC] + SOURCES + ["-o", LIB]
+           f'-DCMF_SRC_DIGEST="{source_digest()}"',
+           "-I", os.path.join(ROOT, "include"), "-I", CSRC] + SOURCES + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)  # never leave a half-written library where a loader could find it
     return LIB
 
 

@@ -107,6 +107,7 @@ struct cmf_handle_s {
     int hals_pullers = 0;                   // persistent H pipeline: puller workgroups per row (0 = stage pipeline)
     int *hals_flags = nullptr;              // its progress flags (device)
     int *hals_status = nullptr;             // pinned host word: 1 = a wait of the persistent pipeline ran out
+    int64_t hals_reruns = 0;                // H sweeps redone on the stage pipeline after such an expiry (cmf_get_counter)
 
     // PGD rule state (pgd.jl:139-154)
     double pgd_stepW = 5.0, pgd_stepH = 5.0, pgd_cur_loss = -1.0;
@@ -700,15 +701,29 @@ static int get_factors_impl(cmf_handle_s *h, double *W, double *H)
 
 // Wait until a kernel has replaced the sentinel pattern in `n` consecutive words of pinned host memory (a loss
 // read-back).  Polling instead of an event keeps barrier packets and cache write-backs out of the stream; the stream is
-// queried now and then so that a failed launch surfaces as an error instead of a hang.
+// queried now and then so that a failed launch surfaces as an error instead of a hang.  `health` (optional) is called at
+// the same cadence: a group passes a check of its other shards' streams and communicators, because the word is posted
+// by shard 0 only and a peer that faulted would otherwise leave the host spinning here.  The wait is bounded
+// (CMF_WAIT_TIMEOUT_S seconds, default 300): a collective that can never complete ends in CMF_ERR_COMM, not in a hang.
+static double wait_timeout_s()
+{
+    static const double t = [] {
+        const char *e = getenv("CMF_WAIT_TIMEOUT_S");
+        const double v = e ? atof(e) : 0.0;
+        return v > 0.0 ? v : 300.0;
+    }();
+    return t;
+}
+
 template <typename U>
-static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel)
+static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel, const std::function<int()> *health = nullptr)
 {
     auto all_there = [&]() {
         for (int j = 0; j < n; ++j)
             if (p[j] == sentinel) return false;
         return true;
     };
+    const auto t_begin = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
         if (all_there()) {
             std::atomic_thread_fence(std::memory_order_acquire);
@@ -721,6 +736,12 @@ static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel
                 return fail(CMF_ERR_HIP, "the stream drained without posting the loss");
             }
             if (e != hipErrorNotReady) return fail(CMF_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+            if (health) CMFTRY((*health)());
+            if ((spins & 0xFFFFF) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > wait_timeout_s())
+                return fail(health ? CMF_ERR_COMM : CMF_ERR_HIP, "no loss arrived within %.0f s (CMF_WAIT_TIMEOUT_S): %s", wait_timeout_s(),
+                            health ? "a collective of the group did not complete -- is every rank / device of the group still running?"
+                                   : "the device did not finish the iteration");
         }
         __builtin_ia32_pause();
     }
@@ -728,12 +749,42 @@ static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel
 
 #include "cmf_group.h"
 
+// A loss reduction deferred by cmf_iterate (CmfLossCarry) only lives between two phases of that call.  If the call
+// failed in between, the record would be consumed by the next W phase and reduce partial sums that have been
+// overwritten since: every public entry that starts a phase drops whatever an aborted batch left behind.
+static void drop_carry(cmf_handle_s *h)
+{
+    if (!h) return;
+    if (h->group) {
+        for (cmf_handle_s *s : h->group->sh) s->carry = CmfLossCarry{};
+        return;
+    }
+    h->carry = CmfLossCarry{};
+}
+struct CarryGuard { // error exits of cmf_iterate: leave no deferred reduction (and no half-reduced numerator) behind
+    cmf_handle_s *h;
+    bool armed = true;
+    ~CarryGuard()
+    {
+        if (!armed) return;
+        drop_carry(h);
+        if (h && h->group) h->group->num_ready = false;
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-const char *cmf_version(void) { return "cmf_hip gfx950 0.1.0"; }
+#ifndef CMF_SRC_DIGEST
+#define CMF_SRC_DIGEST "unknown" // cmf.jl_amd/build.py passes -DCMF_SRC_DIGEST=... (cmf_source_digest, include/cmf_hip.h)
+#endif
+#define CMF_STR2(x) #x
+#define CMF_STR(x) CMF_STR2(x)
+const char *cmf_version(void) { return "cmf_hip gfx950 0.3.0 abi=" CMF_STR(CMF_ABI_VERSION) " src=" CMF_SRC_DIGEST; }
+const char *cmf_source_digest(void) { return CMF_SRC_DIGEST; }
+int cmf_abi_version(void) { return CMF_ABI_VERSION; }
 const char *cmf_last_error(void) { return g_err.c_str(); }
 
 int cmf_device_count(void)
@@ -772,6 +823,31 @@ int cmf_destroy(cmf_handle h)
     }
     destroy_impl(h);
     return CMF_OK;
+}
+
+int cmf_synchronize(cmf_handle h)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (h->group) return group_sync(h->group);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CMF_OK;
+}
+
+int cmf_rccl_version(int *version, char *path, int64_t path_len)
+{
+    if (!version) return fail(CMF_ERR_ARG, "version is NULL");
+    CMFTRY(rccl_load());
+    RCCLCHK(g_rccl.GetVersion(version));
+    if (path && path_len > 0) snprintf(path, (size_t)path_len, "%s", g_rccl.path.c_str());
+    return CMF_OK;
+}
+
+int cmf_get_counter(cmf_handle h, const char *name, int64_t *value)
+{
+    if (!h || !name || !value) return fail(CMF_ERR_ARG, "NULL argument");
+    if (std::strcmp(name, "hals_pipeline_reruns") == 0) { *value = h->hals_reruns; return CMF_OK; }
+    return fail(CMF_ERR_ARG, "unknown counter '%s'", name);
 }
 
 int cmf_set_stream(cmf_handle h, void *hip_stream)
@@ -861,6 +937,7 @@ int cmf_get_data_sumsq(cmf_handle h, double *sumsq)
 int cmf_set_factors(cmf_handle h, const double *W, const double *H)
 {
     if (!h || !W || !H) return fail(CMF_ERR_ARG, "NULL argument");
+    drop_carry(h);
     if (h->group) return group_set_factors(h->group, W, H);
     return set_factors_impl(h, W, H);
 }
@@ -874,12 +951,13 @@ int cmf_get_factors(cmf_handle h, double *W, double *H)
 
 int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
 {
+    drop_carry(h);
     if (h && h->group) {
         CMFTRY(group_check_ready(h->group));
         return group_update_motifs(h->group, l1W, l2W);
     }
     CMFTRY(check_ready(h, true));
-    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator (cmf_comm_init_*) or use the phase-split entries");
+    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator first (cmf_comm_init_rccl / cmf_comm_init_callbacks), or build the group with cmf_create_multi");
     if (h->gram) return gram_w_impl(h, l1W, l2W);
     CMFTRY(w_partial_impl(h));
     return w_apply_impl(h, l1W, l2W);
@@ -888,6 +966,7 @@ int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
 int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
 {
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
+    drop_carry(h);
     if (h && h->group) {
         CMFTRY(group_check_ready(h->group));
         double ss = 0.0;
@@ -896,7 +975,7 @@ int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
         return CMF_OK;
     }
     CMFTRY(check_ready(h, true));
-    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator (cmf_comm_init_*) or use the phase-split entries");
+    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator first (cmf_comm_init_rccl / cmf_comm_init_callbacks), or build the group with cmf_create_multi");
     if (h->gram) return gram_h_impl(h, l1H, l2H, loss);
     CMFTRY(h_update_impl(h, l1H, l2H));
     double ss = 0.0;
@@ -908,6 +987,7 @@ int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
 int cmf_compute_loss(cmf_handle h, double *loss)
 {
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
+    drop_carry(h);
     if (h && h->group) {
         CMFTRY(group_check_ready(h->group));
         return group_compute_loss(h->group, loss);
@@ -1076,13 +1156,19 @@ int cmf_iterate(cmf_handle h, int64_t n_iter, int eval_mode, double l1W, double 
 {
     if (!h || !losses) return fail(CMF_ERR_ARG, "NULL argument");
     if (n_iter < 0) return fail(CMF_ERR_ARG, "n_iter must be >= 0");
+    drop_carry(h);
+    CarryGuard guard{h};
+    int rc;
     if (h->group) {
         CMFTRY(group_check_ready(h->group));
-        return group_iterate(h->group, n_iter, eval_mode, l1W, l2W, l1H, l2H, losses, stamps);
+        rc = group_iterate(h->group, n_iter, eval_mode, l1W, l2W, l1H, l2H, losses, stamps);
+    } else {
+        CMFTRY(check_ready(h, true));
+        if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator (cmf_comm_init_*) first");
+        rc = iterate_single(h, n_iter, eval_mode, l1W, l2W, l1H, l2H, losses, stamps);
     }
-    CMFTRY(check_ready(h, true));
-    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator (cmf_comm_init_*) first");
-    return iterate_single(h, n_iter, eval_mode, l1W, l2W, l1H, l2H, losses, stamps);
+    guard.armed = rc != CMF_OK;
+    return rc;
 }
 
 int cmf_fit(cmf_handle h, int64_t max_itr, double max_time, int check_convergence, int64_t patience, double tol,

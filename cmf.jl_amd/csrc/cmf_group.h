@@ -23,7 +23,17 @@
 #pragma once
 #include <dlfcn.h>
 #include <mutex>
-#include <rccl/rccl.h>
+
+// The handful of RCCL types this file passes through function pointers, declared here (values as in rccl.h of ROCm 7:
+// the NCCL ABI these have had since NCCL 2.0) so that the library builds -- and loads -- on hosts without the RCCL
+// development package; RCCL itself is bound with dlopen below.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;      // non-zero codes are only ever turned into text by ncclGetErrorString
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
 
 // ---- RCCL, bound at run time --------------------------------------------------------------------------------------
 // librccl is opened with dlopen the first time a communicator is needed: the library then loads on hosts without
@@ -37,6 +47,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr; // optional
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -51,6 +62,8 @@ static int rccl_load()
     std::lock_guard<std::mutex> lock(mu);
     if (g_rccl.dl) return CMF_OK;
     const char *env = getenv("CMF_RCCL_LIB");
+    if (env && std::strcmp(env, "none") == 0) // (tests: a rank without RCCL)
+        return fail(CMF_ERR_COMM, "RCCL disabled by CMF_RCCL_LIB=none");
     const char *cands[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void *dl = nullptr;
     for (const char *c : {"librccl.so.1", "librccl.so"}) { // a copy this process already mapped wins
@@ -76,6 +89,7 @@ static int rccl_load()
     RCCL_SYM(GroupStart, "ncclGroupStart");
     RCCL_SYM(GroupEnd, "ncclGroupEnd");
 #undef RCCL_SYM
+    g_rccl.CommGetAsyncError = reinterpret_cast<decltype(g_rccl.CommGetAsyncError)>(dlsym(dl, "ncclCommGetAsyncError"));
     Dl_info info;
     if (dladdr(reinterpret_cast<void *>(g_rccl.AllReduce), &info) && info.dli_fname) g_rccl.path = info.dli_fname;
     g_rccl.dl = dl;
@@ -321,6 +335,27 @@ static int group_sync(cmf_group_s *g)
     return CMF_OK;
 }
 
+// Called while the host polls for a loss that only shard 0 posts: a fault on another local shard's stream, or an
+// asynchronous RCCL error on any local communicator, must end the wait (CMF_ERR_HIP / CMF_ERR_COMM) instead of hanging it.
+static int group_health(cmf_group_s *g)
+{
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        cmf_handle_s *s = g->sh[i];
+        if (i > 0 && s->stream != g->sh[0]->stream) {
+            CMFTRY(group_use(s));
+            const hipError_t e = hipStreamQuery(s->stream);
+            if (e != hipSuccess && e != hipErrorNotReady)
+                return fail(CMF_ERR_HIP, "shard %d (device %d) failed: %s", g->rank[i], s->device, hipGetErrorString(e));
+        }
+        if (g->transport == CMF_TR_RCCL && g_rccl.CommGetAsyncError && i < g->comm.size() && g->comm[i]) {
+            ncclResult_t ae = ncclSuccess;
+            if (g_rccl.CommGetAsyncError(g->comm[i], &ae) == ncclSuccess && ae != ncclSuccess && (int)ae != 7 /* ncclInProgress */)
+                return fail(CMF_ERR_COMM, "RCCL reported an asynchronous error on rank %d: %s", g->rank[i], g_rccl.GetErrorString(ae));
+        }
+    }
+    return group_use(g->sh[0]);
+}
+
 // (L-1)-column H halo exchange: pack -> one all-gather -> unpack
 static int group_exchange_halos(cmf_group_s *g)
 {
@@ -487,6 +522,7 @@ static int group_iterate(cmf_group_s *g, int64_t n, int eval_mode, double l1W, d
         return CMF_OK;
     }
     cmf_handle_s *s0 = g->sh[0];
+    const std::function<int()> health = [g]() { return group_health(g); };
     for (int64_t it = 0; it < n; ++it) {
         CMFTRY(group_update_motifs(g, l1W, l2W, it > 0 ? (int)((it - 1) & 1) : -1));
         const bool last = (it + 1 == n);
@@ -496,7 +532,7 @@ static int group_iterate(cmf_group_s *g, int64_t n, int eval_mode, double l1W, d
             const int slot = (int)((it - 1) & 1);
             CMFTRY(group_use(s0));
             const float *ring = g->h_tail + (size_t)slot * g->slot_len;
-            CMFTRY(wait_words<unsigned>(s0->stream, reinterpret_cast<const volatile unsigned *>(ring), 2 * g->nranks, CMF_SENTINEL32));
+            CMFTRY(wait_words<unsigned>(s0->stream, reinterpret_cast<const volatile unsigned *>(ring), 2 * g->nranks, CMF_SENTINEL32, &health));
             losses[it - 1] = std::sqrt(group_decode_tail(g, ring)) / g->data_norm;
             if (stamps) stamps[it - 1] = now();
         }

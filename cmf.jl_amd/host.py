@@ -112,6 +112,15 @@ def _dev(device):
     return _lib.default_device() if device is None else int(device)
 
 
+def rccl_version():
+    """{"version": code, "lib": path} of the RCCL this process binds (cmf_rccl_version); raises CMFError without one."""
+    lib = _lib.load()
+    v = ctypes.c_int()
+    buf = ctypes.create_string_buffer(1024)
+    check(lib.cmf_rccl_version(ctypes.byref(v), buf, 1024))
+    return {"version": v.value, "lib": buf.value.decode()}
+
+
 # --------------------------------------------------------------------------------------
 # update rules (the plugin boundary: abstract type AbstractCFUpdate, alternating.jl:1-8)
 # --------------------------------------------------------------------------------------
@@ -202,6 +211,24 @@ class MultUpdate(AbstractCFUpdate):
         check(self._lib.cmf_iterate(self._h, int(n), int(bool(eval_mode)), float(l1W), float(l2W), float(l1H), float(l2H),
                                     ptr(losses), ptr(st)))
         return (losses, st) if stamps else losses
+
+    def synchronize(self):
+        """Wait for everything the rule has enqueued (every stream of every local shard of a group)."""
+        check(self._lib.cmf_synchronize(self._h))
+
+    def counter(self, name):
+        """Event counter of the handle (cmf_get_counter), e.g. "hals_pipeline_reruns"."""
+        v = ctypes.c_int64()
+        check(self._lib.cmf_get_counter(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
+
+    overlap = False
+    transport_fallback = None
+
+    def set_overlap(self, flag):
+        """Group handles: switch between the two forms of the W phase (library option "allreduce_overlap")."""
+        self.set_option("allreduce_overlap", int(bool(flag)))
+        self.overlap = bool(flag)
 
     def comm_info(self):
         buf = ctypes.create_string_buffer(1024)

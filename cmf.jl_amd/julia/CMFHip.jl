@@ -24,6 +24,15 @@ import ..CMF: SquareLoss, AbsoluteLoss, MaskedLoss, SquarePenalty, AbsolutePenal
 
 const LIBCMF = get(ENV, "LIBCMF_HIP", "libcmf_hip.so")
 
+# Regulariser keywords: HEAD's rules read `l1W, l2W, l1H, l2H` (src/algs/mult.jl:23,42; hals.jl:31,37); README.md:44-52
+# and BASELINE's `fit_cnmf(data; ..., l1_H=0.1, l2_W=0.5)` spell them `l1_W, l2_W, l1_H, l2_H`, which HEAD's rules let
+# fall into `kwargs...` and silently ignore.  The GPU rules accept both; giving both spellings of one weight is an error.
+function reg(kwargs, head::Symbol, readme::Symbol, head_value)
+    haskey(kwargs, readme) || return Float64(head_value)
+    head_value == 0 || error("regulariser given twice: $head and $readme")
+    return Float64(kwargs[readme])
+end
+
 function check(rc::Cint)
     rc == 0 && return
     msg = unsafe_string(ccall((:cmf_last_error, LIBCMF), Cstring, ()))
@@ -77,7 +86,8 @@ end
 
 # update_motifs!(rule, data, W, H; l1W=0, l2W=0)  -- src/algs/mult.jl:23-39, called at alternating.jl:52
 function update_motifs!(rule::HIPMultUpdate, data, W, H; l1W=0, l2W=0, kwargs...)
-    check(ccall((:cmf_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64), rule.handle, l1W, l2W))
+    check(ccall((:cmf_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64), rule.handle,
+                reg(kwargs, :l1W, :l1_W, l1W), reg(kwargs, :l2W, :l2_W, l2W)))
     return W
 end
 
@@ -85,7 +95,7 @@ end
 function update_feature_maps!(rule::HIPMultUpdate, data, W, H; l1H=0, l2H=0, kwargs...)
     loss = Ref{Float64}(0.0)
     check(ccall((:cmf_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
-                rule.handle, l1H, l2H, loss))
+                rule.handle, reg(kwargs, :l1H, :l1_H, l1H), reg(kwargs, :l2H, :l2_H, l2H), loss))
     if rule.sync_every_call   # keep the reference's in-place semantics for arbitrary callers
         check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.handle, W, H))
     end
@@ -105,7 +115,8 @@ HIPHALSUpdate(data, W, H; kwargs...) = HIPHALSUpdate(HIPMultUpdate(data, W, H; k
 
 # update_motifs!(rule::HALSUpdate, ...; l1W=0, l2W=0)  -- src/algs/hals.jl:31-34
 function update_motifs!(rule::HIPHALSUpdate, data, W, H; l1W=0, l2W=0, kwargs...)
-    check(ccall((:cmf_hals_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64), rule.inner.handle, l1W, l2W))
+    check(ccall((:cmf_hals_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64), rule.inner.handle,
+                reg(kwargs, :l1W, :l1_W, l1W), reg(kwargs, :l2W, :l2_W, l2W)))
     return W
 end
 
@@ -113,7 +124,7 @@ end
 function update_feature_maps!(rule::HIPHALSUpdate, data, W, H; l1H=0, l2H=0, kwargs...)
     loss = Ref{Float64}(0.0)
     check(ccall((:cmf_hals_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
-                rule.inner.handle, l1H, l2H, loss))
+                rule.inner.handle, reg(kwargs, :l1H, :l1_H, l1H), reg(kwargs, :l2H, :l2_H, l2H), loss))
     if rule.inner.sync_every_call
         check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.inner.handle, W, H))
     end
@@ -141,6 +152,12 @@ end
 
 penalty_weights(pens) = (sum(Float64[p.weight for p in pens if p isa SquarePenalty]),
                          sum(Float64[p.weight for p in pens if p isa AbsolutePenalty]))
+# README-style regularisers on the PGD rule (`fit_cnmf(data; alg=:pgd, l1_W=..., l2_W=...)`): l1_* is an AbsolutePenalty
+# weight, l2_* a SquarePenalty weight (pgd.jl:73-89), added to whatever the penalty list already holds
+function penalty_weights(pens, kwargs, l1::Symbol, l2::Symbol)
+    sq, ab = penalty_weights(pens)
+    return sq + Float64(get(kwargs, l2, 0)), ab + Float64(get(kwargs, l1, 0))
+end
 # 0 none, 1 NonnegConstraint (pgd.jl:92-96), 2 UnitNormConstraint (pgd.jl:100-110)
 nonneg_flag(c) = c === nothing ? Cint(0) : (c isa NonnegConstraint ? Cint(1) :
                  (c isa UnitNormConstraint ? Cint(2) : error("unsupported constraint")))
@@ -170,7 +187,7 @@ end
 function update_motifs!(rule::HIPPGDUpdate, data, W, H; loss_func=SquareLoss(), constrW=NonnegConstraint(),
                         penaltiesW=[SquarePenalty(1)], kwargs...)
     select_loss!(rule, loss_func)
-    sq, ab = penalty_weights(penaltiesW)
+    sq, ab = penalty_weights(penaltiesW, kwargs, :l1_W, :l2_W)
     check(ccall((:cmf_pgd_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Cint),
                 rule.inner.handle, sq, ab, nonneg_flag(constrW)))
     return W
@@ -180,7 +197,7 @@ end
 function update_feature_maps!(rule::HIPPGDUpdate, data, W, H; loss_func=SquareLoss(), constrH=NonnegConstraint(),
                               penaltiesH=[], kwargs...)
     select_loss!(rule, loss_func)
-    sq, ab = penalty_weights(penaltiesH)
+    sq, ab = penalty_weights(penaltiesH, kwargs, :l1_H, :l2_H)
     loss = Ref{Float64}(0.0)
     check(ccall((:cmf_pgd_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Cint, Ref{Float64}),
                 rule.inner.handle, sq, ab, nonneg_flag(constrH), loss))
@@ -189,6 +206,19 @@ function update_feature_maps!(rule::HIPPGDUpdate, data, W, H; loss_func=SquareLo
     end
     return loss[]
 end
+
+"""
+    ALGORITHMS
+
+README.md:16,30-33 selects the algorithm with a symbol (`alg=:mult`, `:hals`); HEAD's table for that is commented out
+(src/model.jl:3-8) and `fit_cnmf` calls `alg(data, W_init, H_init)` (model.jl:78-82), so a symbol fails there with a
+MethodError.  INTEGRATION.md section 2b shows the five-line patch to model.jl that looks `alg` up here first.
+"""
+const ALGORITHMS = Dict{Symbol,Any}(
+    :mult => HIPMultUpdate,
+    :hals => HIPHALSUpdate,
+    :pgd => HIPPGDUpdate,
+)
 
 """
     iterate!(rule, n; l1W=0, l2W=0, l1H=0, l2H=0, eval_mode=false) -> losses
@@ -203,6 +233,12 @@ function iterate!(rule::HIPMultUpdate, n::Integer; l1W=0, l2W=0, l1H=0, l2H=0, e
                 rule.handle, n, eval_mode ? 1 : 0, l1W, l2W, l1H, l2H, losses, C_NULL))
     return losses
 end
+
+"Library identification: \"cmf_hip gfx950 <version> abi=<n> src=<digest of the sources it was built from>\"."
+version() = unsafe_string(ccall((:cmf_version, LIBCMF), Cstring, ()))
+
+"Block until everything the rule has enqueued has finished (all devices of a `devices=` group)."
+synchronize(rule::HIPMultUpdate) = check(ccall((:cmf_synchronize, LIBCMF), Cint, (Ptr{Cvoid},), rule.handle))
 
 "Write the device-resident factors into W and H (needed only with `sync_every_call=false`)."
 function download!(rule::HIPMultUpdate, W::Tensor{Float64}, H::Matrix{Float64})

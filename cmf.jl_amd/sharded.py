@@ -25,7 +25,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import check, farr, ptr
+from ._lib import CMFError, check, farr, ptr
 from .host import MultUpdate
 
 
@@ -86,17 +86,13 @@ class ShardedMultUpdate(MultUpdate):
         check(lib.cmf_create_shard(ctypes.byref(self._h), self.device, N, t1 - t0, K, L, ptr(data_local), t0, T))
         self.transport_fallback = None
         try:
-            if self.transport == "rccl" and fallback_to_host:
-                # all ranks must end up on the same transport: agree on the outcome of the RCCL attach, and if any rank
-                # failed, every rank rebuilds its shard and takes the host-collective transport instead
-                err = None
-                try:
-                    self._attach()
-                except Exception as e:  # noqa: BLE001 - reported below
-                    err = repr(e)
-                flags = [None] * self.world
-                dist.all_gather_object(flags, err, group=group)
-                bad = [f for f in flags if f]
+            if self.transport == "rccl":
+                # All ranks must end up on the same transport, and none may enter the blocking ncclCommInitRank alone:
+                # the ranks agree through the process group before and after it (_attach_rccl).  If any rank failed,
+                # every rank rebuilds its shard and takes the host-collective transport instead -- or raises.
+                bad = self._attach_rccl()
+                if bad and not fallback_to_host:
+                    raise CMFError(_lib.CMF_ERR_COMM, f"the RCCL communicator could not be formed: {bad[0]}")
                 if bad:
                     self.transport_fallback = bad[0]
                     lib.cmf_destroy(self._h)
@@ -121,18 +117,46 @@ class ShardedMultUpdate(MultUpdate):
     def _src_rank(self):
         return self.dist.get_process_group_ranks(self.pg)[0] if self.pg is not None else 0
 
-    def _attach(self):
+    def _agree(self, err):
+        """Every rank's error text (None = fine) on every rank: the list of failures, empty when all succeeded."""
+        flags = [None] * self.world
+        self.dist.all_gather_object(flags, err, group=self.pg)
+        return [f"rank {r}: {f}" for r, f in enumerate(flags) if f]
+
+    def _attach_rccl(self):
+        """Form the library's RCCL communicator in two agreed stages; returns the failures of all ranks ([] = attached).
+
+        Stage 1: every rank checks that it can bind RCCL at all (rank 0 by creating the ncclUniqueId, the others with
+        cmf_rccl_version) and rank 0 ALWAYS broadcasts -- the id or None -- so that no rank waits in a broadcast that
+        never comes; then all ranks exchange a ready flag.  Stage 2: only if every rank is ready do they call
+        cmf_comm_init_rccl (ncclCommInitRank blocks until all ranks have entered it), and exchange the outcome."""
         lib, dist = self._lib, self.dist
-        if self.transport == "rccl":
-            box = [None]
+        err, payload = None, None
+        try:
             if self.rank == 0:
                 buf = ctypes.create_string_buffer(128)
                 check(lib.cmf_comm_unique_id(buf))
-                box[0] = buf.raw
-            dist.broadcast_object_list(box, src=self._src_rank(), group=self.pg)
+                payload = buf.raw
+            else:
+                v = ctypes.c_int()
+                check(lib.cmf_rccl_version(ctypes.byref(v), None, 0))
+        except Exception as e:  # noqa: BLE001 - travels to the other ranks as text
+            err = repr(e)
+        box = [payload]
+        dist.broadcast_object_list(box, src=self._src_rank(), group=self.pg)
+        bad = self._agree(err)
+        if bad:
+            return bad
+        try:
             idbuf = ctypes.create_string_buffer(box[0], 128)
             check(lib.cmf_comm_init_rccl(self._h, self.world, self.rank, idbuf))
-            return
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        return self._agree(err)
+
+    def _attach(self):
+        """The host-collective transport: callbacks that run the two collectives with torch.distributed."""
+        lib, dist = self._lib, self.dist
         torch, world, pg = self.torch, self.world, self.pg
 
         on_device = self.backend == "nccl"  # torch's RCCL backend only takes device tensors: bounce through the GPU
@@ -170,11 +194,6 @@ class ShardedMultUpdate(MultUpdate):
         # the CFUNCTYPE objects must outlive the handle
         self._cb = (_lib.ALLREDUCE_FN(allreduce), _lib.ALLGATHER_FN(allgather))
         check(lib.cmf_comm_init_callbacks(self._h, self.world, self.rank, self._cb[0], self._cb[1], None))
-
-    def set_overlap(self, flag):
-        """Switch between the two forms of the W phase (library option "allreduce_overlap")."""
-        self.set_option("allreduce_overlap", int(bool(flag)))
-        self.overlap = bool(flag)
 
     # ---- host-side helpers ------------------------------------------------------------------------
     def agree_scalar(self, x):

@@ -41,8 +41,20 @@ extern "C" {
 
 typedef struct cmf_handle_s *cmf_handle;
 
-/* Library / build identification ("cmf_hip gfx950 <version>"). */
+/* Version of this interface.  3 (round 3): the phase-split entries of version 1 (cmf_w_partial*, cmf_w_apply,
+ * cmf_h_update, cmf_loss_partial*, cmf_halo_*, cmf_numden_ptr, cmf_set_data_norm) are gone -- a sharded iteration
+ * runs behind the rule entries of a group handle (cmf_create_multi / cmf_comm_init_*); cmf_abi_version,
+ * cmf_source_digest, cmf_synchronize, cmf_rccl_version, cmf_get_counter are new. */
+#define CMF_ABI_VERSION 3
+int cmf_abi_version(void);
+
+/* Library / build identification: "cmf_hip gfx950 <version> abi=<n> src=<digest>". */
 const char *cmf_version(void);
+/* Hex SHA-256 prefix (16 characters) of the sources this library was compiled from (csrc/cmf_api.hip, csrc/cmf_kernels.h,
+ * csrc/cmf_group.h, csrc/cmf_rng.h, include/cmf_hip.h, in that order, each preceded by its base name and a newline).
+ * A loader that has the tree at hand recomputes it and refuses (or rebuilds) a stale binary -- cmf.jl_amd/_lib.py does;
+ * "unknown" when the library was built without the build script. */
+const char *cmf_source_digest(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char *cmf_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime unusable). */
@@ -108,6 +120,15 @@ int cmf_comm_info(cmf_handle h, char *buf, int64_t len);
 int cmf_shard_bounds(cmf_handle h, int rank, int64_t *t0, int64_t *t1);
 
 int cmf_destroy(cmf_handle h);
+
+/* Block until everything this handle has enqueued -- on every stream of every local shard of a group -- has finished. */
+int cmf_synchronize(cmf_handle h);
+/* RCCL as this process would bind it (dlopen at first use, a copy the process has already mapped wins): its version
+ * code (e.g. 22703) and, when path != NULL, the file it was loaded from.  CMF_ERR_COMM when no RCCL can be loaded. */
+int cmf_rccl_version(int *version, char *path, int64_t path_len);
+/* Event counters of a handle.  "hals_pipeline_reruns": H sweeps whose persistent pipeline ran out of a bounded wait and
+ * were redone from the snapshot on the stage pipeline (cmf_hals_update_feature_maps). */
+int cmf_get_counter(cmf_handle h, const char *name, int64_t *value);
 
 /* Run all work of this handle on an existing HIP stream (hipStream_t passed
  * as void*), e.g. torch's current stream.  NULL is the HIP null (legacy
@@ -254,8 +275,8 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
 /* In-loop timing: after cmf_set_option(h, "profile", 1) every contraction launch of the update / loss entries is
  * bracketed by a HIP event pair on the launch stream; cmf_kernel_times synchronises and returns the mean duration
  * and the number of launches recorded for one class: "conv" (mult.jl:28), "conv_t" (:44), "conv_loss" /
- * "conv_loss_store" (:55-57), "hxt" (:31-34; "hxt_num" / "hxt_den" for the one-source launches of cmf_w_partial_num /
- * cmf_w_partial_den), "transconv" (:47-48).  Setting the option again restarts it; a value
+ * "conv_loss_store" (:55-57), "hxt" (:31-34; "hxt_num" / "hxt_den" for the one-source launches of the overlap and
+ * Gram forms), "transconv" (:47-48).  Setting the option again restarts it; a value
  * n > 1 brackets only every n-th launch of each class (an event pair costs a few microseconds on the stream). */
 int cmf_kernel_times(cmf_handle h, const char *name, double *avg_ms, int64_t *launches);
 

@@ -45,7 +45,7 @@ def main():
     else:
         from cmf_jl_amd.sharded import ShardedMultUpdate
 
-        rule = ShardedMultUpdate(data, W0, H0, device=0, overlap=overlap,
+        rule = ShardedMultUpdate(data, W0, H0, device=int(os.environ.get("LOCAL_RANK", "0")), overlap=overlap,
                                  transport=os.environ.get("CMF_TEST_TRANSPORT") or None,
                                  fallback_to_host=os.environ.get("CMF_TEST_FALLBACK", "0") == "1")
         info = rule.comm_info() + (" FALLBACK" if rule.transport_fallback else "")

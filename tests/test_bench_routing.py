@@ -1,0 +1,70 @@
+"""bench.py's launch routing and build provenance (CPU)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def test_route_picks_the_form_for_gpus_and_world_size():
+    import bench
+
+    assert bench.route(1, None) == "single" and bench.route(1, "1") == "single"
+    # a plain `python bench.py --gpus 8` (no launcher, WORLD_SIZE unset): one process drives the 8 GPUs
+    assert bench.route(8, None) == "multi" and bench.route(2, "") == "multi" and bench.route(4, "1") == "multi"
+    # torch.distributed.run --nproc-per-node 8: one process per GPU
+    assert bench.route(8, "8") == "ranks" and bench.route(2, 2) == "ranks"
+    for gpus, world in ((8, 4), (1, 8), (2, 3)):
+        with pytest.raises(ValueError):
+            bench.route(gpus, world)
+    with pytest.raises(ValueError):
+        bench.route(0, None)
+
+
+def test_comm_record_from_comm_info():
+    import bench
+
+    info = "transport=rccl version=22703 lib=/opt/rocm/lib/librccl.so.1 nranks=8 local=8 ranks=0@dev0,1@dev1,2@dev2,3@dev3,4@dev4,5@dev5,6@dev6,7@dev7 overlap=0"
+    rec = bench.parse_comm(info, "one-process")
+    assert rec["transport"] == "rccl" and rec["nranks"] == 8 and rec["local"] == 8 and rec["version"] == 22703
+    assert rec["devices"] == list(range(8)) and rec["mode"] == "one-process" and rec["lib"].endswith("librccl.so.1")
+    rec = bench.parse_comm("transport=callbacks nranks=2 local=1 ranks=1@dev1 overlap=0", "one-process-per-gpu", "rank 0: boom")
+    assert rec["transport"] == "callbacks" and rec["devices"] == [1] and rec["fallback_from_rccl"] == "rank 0: boom"
+
+
+def test_bench_sets_the_ipc_mode_itself():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 is what RCCL's dmabuf IPC needs on these hosts: bench.py must not rely on the caller."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    src = src[src.index("def main():"):]
+    i_set = src.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")')
+    assert i_set < src.index("import numpy as np") and i_set < src.index("import torch")
+
+
+def test_library_carries_the_digest_of_the_tree():
+    """cmf_source_digest() of the built library equals the digest build.py computes from csrc/ + include/: a prebuilt
+    .so that no longer matches the sources would be rebuilt or refused by cmf.jl_amd/_lib.load, never loaded silently."""
+    import ctypes
+
+    import cmf_jl_amd as cmf
+    from cmf_jl_amd import build
+
+    lib = cmf.load_library()
+    want = build.source_digest()
+    assert lib.cmf_source_digest().decode() == want and build.embedded_digest() == want
+    assert f"src={want}" in lib.cmf_version().decode() and f"abi={lib.cmf_abi_version()}" in lib.cmf_version().decode()
+    assert lib.cmf_abi_version() == 3
+    assert not build.is_stale()
+    v = ctypes.c_int64()
+    assert lib.cmf_get_counter(None, b"x", ctypes.byref(v)) == 1  # CMF_ERR_ARG: needs a handle
+
+
+def test_stale_library_is_detected(tmp_path):
+    from cmf_jl_amd import build
+
+    fake = tmp_path / "libcmf_hip.so"
+    fake.write_bytes(b"\x7fELF....cmf_hip gfx950 0.3.0 abi=3 src=0123456789abcdef\0....")
+    assert build.embedded_digest(str(fake)) == "0123456789abcdef" != build.source_digest()
+    assert build.embedded_digest(str(tmp_path / "missing.so")) is None

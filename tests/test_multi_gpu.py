@@ -1,0 +1,148 @@
+"""RCCL across DISTINCT devices: the tests a one-GPU box cannot run.
+
+Every test here is gated on cmf_device_count() >= n and skips otherwise, so on the one-GPU box of the round-end run they
+skip and on an N-GPU node they need nobody's help: the one-process group (cmf_create_multi: ncclCommInitAll, a stream per
+device, collectives inside ncclGroupStart/End) and the one-process-per-GPU group (cmf_create_shard + cmf_comm_init_rccl:
+ncclCommInitRank with LOCAL_RANK = device) against the fp64 oracle and against the same partition on loopback shards of
+GPU 0, call by call and as a cmf_iterate batch, with the all-reduce overlap form off and on.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from test_sharded import REG, frob_rel, oracle_fit, run_ranks
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _need_devices(n):
+    import cmf_jl_amd as cmf
+
+    have = cmf.load_library().cmf_device_count()
+    if have < n:
+        pytest.skip(f"needs {n} HIP devices, this box has {have}")
+
+
+def _run(rule, mode, iters, kw):
+    losses = [rule.compute_loss()]
+    if mode == "calls":
+        for _ in range(iters):
+            rule.update_motifs(l1W=kw["l1W"], l2W=kw["l2W"])
+            losses.append(rule.update_feature_maps(l1H=kw["l1H"], l2H=kw["l2H"]))
+    else:
+        losses += list(rule.iterate(iters, **kw))
+    W, H = rule.download()
+    return np.asarray(losses), W, H
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4, 8])
+@pytest.mark.parametrize("overlap", [False, True])
+def test_one_process_group_over_rccl(oracle, n, overlap):
+    """MultUpdate(devices=range(n)) = cmf_create_multi over RCCL, vs the oracle (1e-4) and vs the same n-shard partition
+    on loopback shards of GPU 0 (1e-5: same kernels, same shard shapes -- only the all-reduce's summation order differs)."""
+    _need_devices(n)
+    import cmf_jl_amd as cmf
+
+    N, T, K, L, iters, reg = 130, 1800, 32, 20, 6, 1
+    data, W0, H0, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, reg)
+    kw = REG
+    ref = {}
+    for mode in ("calls", "iterate"):
+        rule = cmf.MultUpdate(data, W0, H0, devices=[0] * n)
+        ref[mode] = _run(rule, mode, iters, kw)
+        rule.close()
+    for mode in ("calls", "iterate"):
+        rule = cmf.MultUpdate(data, W0, H0, devices=list(range(n)))
+        info = rule.comm_info()
+        assert "transport=rccl" in info and f"nranks={n}" in info and f"local={n}" in info
+        assert all(f"{r}@dev{r}" in info for r in range(n))
+        if overlap:
+            rule.set_overlap(True)
+        losses, W, H = _run(rule, mode, iters, kw)
+        rule.synchronize()
+        rule.close()
+        np.testing.assert_allclose(losses, lr, rtol=1e-4)
+        assert frob_rel(W, Wr) < 1e-4 and frob_rel(H, Hr) < 1e-4
+        np.testing.assert_allclose(losses, ref[mode][0], rtol=1e-5)
+        assert frob_rel(W, ref[mode][1]) < 1e-5 and frob_rel(H, ref[mode][2]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_one_process_group_fit_and_shard_shapes(oracle, n):
+    """cmf_fit (pipelined and with the convergence test) on an RCCL group of distinct devices, a T that does not divide
+    evenly, K not a multiple of 32."""
+    _need_devices(n)
+    import cmf_jl_amd as cmf
+
+    N, T, K, L, iters = 70, 997, 5, 10, 10
+    data, W0, H0, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, 0)
+    rule = cmf.MultUpdate(data, W0, H0, devices=list(range(n)))
+    lh, th, early = rule.fit_native(iters, np.inf, False, 3, 1e-4, False)
+    W, H = rule.download()
+    rule.close()
+    assert not early and len(lh) == iters + 1
+    np.testing.assert_allclose(lh, lr, rtol=1e-4)
+    assert frob_rel(W, Wr) < 1e-4 and frob_rel(H, Hr) < 1e-4
+    _, _, lr2, _ = oracle.fit_mult(data, W0, H0, max_itr=200, check_convergence=True, patience=3, tol=2e-3)
+    res = cmf.fit_cnmf(data, L=L, K=K, alg=":mult", max_itr=200, check_convergence=True, patience=3, tol=2e-3,
+                       W_init=W0, H_init=H0, devices=list(range(n)))
+    assert len(res.loss_hist) == len(lr2)
+    np.testing.assert_allclose(res.loss_hist, lr2, rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,mode,overlap", [(2, "calls", False), (2, "iterate", True), (4, "iterate", False), (8, "iterate", False),
+                                            (2, "fit_timed", False)])
+def test_one_process_per_gpu_over_rccl(oracle, tmp_path, n, mode, overlap):
+    """n processes, rank r on GPU r (LOCAL_RANK=r), torch.distributed `nccl` as the rendezvous, the library's own
+    ncclCommInitRank communicator for the data path: ShardedMultUpdate against the oracle."""
+    _need_devices(n)
+    N, T, K, L, iters = 130, 1800, 32, 20, 6
+    out = str(tmp_path / "res.npz")
+    got = run_ranks(n, "hip", out, N, T, K, L, iters, 1, backend="nccl", overlap=overlap, mode=mode, transport="rccl",
+                    distinct_devices=True, timeout=600)
+    info = str(got["info"])
+    assert "transport=rccl" in info and f"nranks={n}" in info and "FALLBACK" not in info
+    _, _, _, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, 1)
+    np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
+    assert frob_rel(got["W"], Wr) < 1e-4 and frob_rel(got["H"], Hr) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_plain_multi_gpu_launch(n):
+    """`python bench.py --gpus n` with no launcher: the one-process form runs, RCCL reports n ranks in `comm`."""
+    _need_devices(n)
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
+                        "--sustain", "0", "--T", "8000"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == n and line["config"]["launch"] == "multi"
+    assert line["comm"]["transport"] == "rccl" and line["comm"]["nranks"] == n and line["comm"]["devices"] == list(range(n))
+    assert line["value"] > 0 and np.isfinite(line["config"]["loss_last"])
+
+
+@pytest.mark.gpu
+def test_bench_plain_multi_gpu_launch_reports_missing_devices():
+    """More GPUs asked for than the box has: a non-zero exit with the reason on stderr, not a traceback or a hang."""
+    import cmf_jl_amd as cmf
+
+    have = cmf.load_library().cmf_device_count()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 2
+    assert f"only {have} HIP device" in p.stderr.decode()
+    assert p.stdout.decode().strip() == ""

@@ -29,14 +29,17 @@ def _free_port():
 
 
 def run_ranks(world, engine, out, N, T, K, L, iters, reg, timeout=300, backend="gloo", overlap=False, mode="calls", transport="",
-              fallback=False):
+              fallback=False, rank_env=None, distinct_devices=False):
+    """rank_env: {rank: {VAR: value}} extra environment of single ranks; distinct_devices: rank r works on GPU r
+    (LOCAL_RANK=r) instead of all ranks sharing GPU 0."""
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r) if distinct_devices else "0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", CMF_TEST_BACKEND=backend,
                    CMF_TEST_OVERLAP="1" if overlap else "0", CMF_TEST_MODE=mode, CMF_TEST_TRANSPORT=transport,
                    CMF_TEST_FALLBACK="1" if fallback else "0")
+        env.update((rank_env or {}).get(r, {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), engine, out,
                                        str(N), str(T), str(K), str(L), str(iters), str(int(reg))],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -271,6 +274,22 @@ def test_sharded_processes_fall_back_to_host_transport_together(oracle, tmp_path
     _, _, _, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, 0)
     np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
     assert frob_rel(got["W"], Wr) < 1e-4 and frob_rel(got["H"], Hr) < 1e-4
+
+
+@pytest.mark.gpu
+def test_sharded_processes_asymmetric_rccl_failure_does_not_hang(oracle, tmp_path):
+    """ONE rank cannot bind RCCL at all (CMF_RCCL_LIB=none makes its rccl_load fail before any collective): the two-stage
+    agreement of ShardedMultUpdate._attach_rccl keeps every rank out of the blocking ncclCommInitRank -- rank 0 still
+    broadcasts its id, the ready flags are exchanged, and all ranks take the host-collective transport together."""
+    N, T, K, L, iters = 65, 400, 5, 10, 4
+    for failing in (1, 0):  # a non-root rank, then the rank that creates the ncclUniqueId
+        out = str(tmp_path / f"res{failing}.npz")
+        got = run_ranks(2, "hip", out, N, T, K, L, iters, 0, mode="iterate", transport="rccl", fallback=True, timeout=240,
+                        rank_env={failing: {"CMF_RCCL_LIB": "none"}})
+        assert "transport=callbacks" in str(got["info"]) and "FALLBACK" in str(got["info"])
+        _, _, _, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, 0)
+        np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
+        assert frob_rel(got["W"], Wr) < 1e-4 and frob_rel(got["H"], Hr) < 1e-4
 
 
 @pytest.mark.gpu
