@@ -97,6 +97,7 @@ struct cmf_handle_s {
 
     // HALS scratch (allocated on first use)
     bool hals_ready = false;
+    bool gram_ready = false;                // the scratch the Gram form and HALS share (gram_ensure)
     int hals_NpH = 0, hals_NpC = 0, hals_TPp = 0, hals_ne = 0, hals_t_edge0 = 0, hals_nch = 1, hals_clen = 6;
     float *hals_HX = nullptr, *hals_cslabs = nullptr, *hals_C = nullptr, *hals_HH = nullptr, *hals_PT = nullptr, *hals_D = nullptr;
     float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr, *hals_GWt = nullptr;
@@ -104,6 +105,7 @@ struct cmf_handle_s {
     int hals_gram = 2;                      // the sweeps' projections as differences of the MU quantities: 2 = P of the H phase only (default:
                                             // one conv launch fewer, H within the residual form's bars), 1 = G of the W phase too (~20x the rounding
                                             // error in W: opt-in), 0 = both contracted from the stored residual
+    bool hals_w_general = false, hals_h_general = false; // shapes beyond the on-chip sweeps' limits: the general sweep kernels
     int hals_pullers = 0;                   // persistent H pipeline: puller workgroups per row (0 = stage pipeline)
     int *hals_flags = nullptr;              // its progress flags (device)
     int *hals_status = nullptr;             // pinned host word: 1 = a wait of the persistent pipeline ran out
@@ -144,14 +146,22 @@ struct cmf_handle_s {
 };
 
 static int hals_ensure(cmf_handle_s *h);
+static int gram_ensure(cmf_handle_s *h);
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
 static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked = false, bool loss_abs = false);
 static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W);
+static int gram_w_partial(cmf_handle_s *h, float *hh_out);
+static int gram_w_finish(cmf_handle_s *h, const float *HH, double l1W, double l2W, const float *tail_src = nullptr, float *tail_dst = nullptr,
+                         int tail_n = 0);
+static int gram_h_update(cmf_handle_s *h, double l1H, double l2H);
 static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss);
 static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg);
 static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg, double *loss);
 static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H);
 static int gram_denom_h(cmf_handle_s *h, float *out);
+static int group_pgd_w(cmf_handle_s *st, struct cmf_group_s *g, double pen_sq, double pen_abs, int nonneg);
+static int group_pgd_h(cmf_handle_s *st, struct cmf_group_s *g, double pen_sq, double pen_abs, int nonneg, double *loss);
+static int group_set_mask(struct cmf_group_s *g, const double *mask);
 
 static size_t n_partial(const cmf_handle_s *h)
 {
@@ -482,15 +492,19 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
         cut = std::min(cut, tiles3);
     }
     const bool split = cut > 0;
-    const int variant = h->conv_variant ? h->conv_variant : ((reads_data || split) ? 3 : 2);
+    const int variant = (h->conv_variant && MODE <= 2) ? h->conv_variant : ((reads_data || split) ? 3 : 2);
     if (d.K % 32 == 0 && variant == 3) {
         const int n_full = tiles3 - cut;
         // quarter tiles reach every SIMD only from one tile per CU on; below that, sixteenth tiles
         const int pieces = (split && cut < h->n_cu && h->conv_split != 4) ? 16 : 4;
         grid = dim3(n_full + pieces * (tiles3 - n_full));
         hipLaunchKernelGGL((conv3_kernel<MODE>), grid, dim3(64), 0, h->stream, p, gx3, n_full, pieces);
-    } else if (d.K % 32 == 0) hipLaunchKernelGGL((conv2_kernel<MODE>), grid, block, 0, h->stream, p);
-    else hipLaunchKernelGGL((conv_kernel<MODE, 0>), grid, block, 0, h->stream, p);
+    } else if (d.K % 32 == 0) {
+        // the 128 x 128 kernel exists for the epilogues that only store or only sum (est, est', loss): with a data tile
+        // read AND a store in the epilogue (mode 3 and the residual modes) it needs more than the 168 registers three
+        // workgroups per CU leave (it spilled to scratch), and the one-wave kernel won those modes anyway
+        if constexpr (MODE <= 2) hipLaunchKernelGGL((conv2_kernel<MODE>), grid, block, 0, h->stream, p);
+    } else hipLaunchKernelGGL((conv_kernel<MODE, 0>), grid, block, 0, h->stream, p);
     h->conv_partials = (int)(grid.x * grid.y);
     KCHK("conv_kernel");
     return CMF_OK;
@@ -607,11 +621,14 @@ static int w_partial_half_impl(cmf_handle_s *h, int den)
     return launch_slab_sum(h, h->numden + (den ? LKN : 0), h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN, den != 0);
 }
 
-static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W, const float *tail_src = nullptr, float *tail_dst = nullptr, int tail_n = 0)
+// den == NULL: denomW lies behind numW in h->numden (the layout of the [numW | denomW] all-reduce buffer)
+static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W, const float *tail_src = nullptr, float *tail_dst = nullptr, int tail_n = 0,
+                        const float *den = nullptr)
 {
     const CmfDims &d = h->d;
     dim3 grid(d.Np / 64, d.KB, d.L);
-    hipLaunchKernelGGL(w_update_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden, 1,
+    if (!den) den = h->numden + (size_t)d.L * d.K32 * d.Np;
+    hipLaunchKernelGGL(w_update_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden, den,
                        d.N, d.K, d.L, d.Np, d.K32, (float)l1W, (float)(2.0 * l2W), tail_src, tail_dst, tail_n); // mult.jl:37-38
     KCHK("w_update_kernel");
     h->est_kind = 0;
@@ -635,7 +652,7 @@ static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
 static int launch_loss_conv(cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
-    if (h->reuse_est) {
+    if (h->reuse_est && !h->gram) { // (the Gram form never reads est: nothing to keep)
         CMFTRY(launch_conv<3>(h, h->est, d.Tl, h->conv_gy)); // est kept for the next update_motifs!
         h->est_kind = 1;
         return CMF_OK;
@@ -869,7 +886,25 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
             g->num_ready = false;
             return CMF_OK;
         }
-        if (std::strcmp(name, "gram") == 0 && value) return fail(CMF_ERR_STATE, "the Gram form is not available on sharded handles");
+        if (std::strcmp(name, "gram") == 0) {
+            // Gram form on a T-sharded group: every shard contracts numW and its additive share of HH = H_unfold H_unfold'
+            // from its own columns, the all-reduce carries [numW | HH | tail] (numW + (L*Kpad)^2 floats instead of 2 numW),
+            // denomW = HH * W is formed on every shard; denomH = lag-Gram taps of W applied to H with the H halos.
+            if (value != 0 && value != 1) return fail(CMF_ERR_UNSUPPORTED, "sharded handles take gram = 0 or 1 (the loss of gram = 2 is not exact to 1e-4)");
+            if (value && g->nranks > 1 && g->T < 4 * g->L)
+                return fail(CMF_ERR_UNSUPPORTED, "the Gram form on a sharded handle needs T >= 4 L (got T=%lld, L=%lld)", (long long)g->T, (long long)g->L);
+            CMFTRY(group_sync(g));
+            for (cmf_handle_s *s : g->sh) {
+                CMFTRY(group_use(s));
+                if (value) CMFTRY(gram_ensure(s));
+                s->gram = value;
+                s->est_kind = 0;
+                s->carry = CmfLossCarry{};
+            }
+            g->gram = value;
+            g->num_ready = false;
+            return CMF_OK;
+        }
         for (cmf_handle_s *s : g->sh) {
             cmf_group_s *keep = s->group;
             s->group = nullptr;
@@ -1034,9 +1069,9 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
 int cmf_set_mask(cmf_handle h, const double *mask)
 {
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
-    if (h->group) return fail(CMF_ERR_UNSUPPORTED, "MaskedLoss is supported on single-GPU handles only");
+    if (h->group) return group_set_mask(h->group, mask);
     HIPCHK(hipSetDevice(h->device));
-    if (h->sharded) return fail(CMF_ERR_UNSUPPORTED, "MaskedLoss is supported on single-GPU handles only");
+    if (h->sharded) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator first (cmf_comm_init_rccl / cmf_comm_init_callbacks)");
     const CmfDims &d = h->d;
     h->est_kind = 0;
     if (!mask) { // back to the plain SquareLoss
@@ -1063,24 +1098,33 @@ int cmf_pgd_reset(cmf_handle h)
 int cmf_pgd_set_loss(cmf_handle h, int loss_kind)
 {
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
-    if (h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
     if (loss_kind != 0 && loss_kind != 1) return fail(CMF_ERR_ARG, "loss_kind must be 0 (SquareLoss) or 1 (AbsoluteLoss)");
-    if (h->pgd_loss_abs != loss_kind) h->est_kind = 0;
+    if (h->pgd_loss_abs != loss_kind) {
+        h->est_kind = 0;
+        if (h->group)
+            for (cmf_handle_s *s : h->group->sh) s->est_kind = 0;
+    }
     h->pgd_loss_abs = loss_kind;
     return CMF_OK;
 }
 
 int cmf_pgd_update_motifs(cmf_handle h, double pen_sq, double pen_abs, int nonneg)
 {
-    if (h && h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
+    if (h && h->group) {
+        CMFTRY(group_check_ready(h->group));
+        return group_pgd_w(h, h->group, pen_sq, pen_abs, nonneg);
+    }
     CMFTRY(check_ready(h, true));
     return pgd_w_impl(h, pen_sq, pen_abs, nonneg);
 }
 
 int cmf_pgd_update_feature_maps(cmf_handle h, double pen_sq, double pen_abs, int nonneg, double *loss)
 {
-    if (h && h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
+    if (h && h->group) {
+        CMFTRY(group_check_ready(h->group));
+        return group_pgd_h(h, h->group, pen_sq, pen_abs, nonneg, loss);
+    }
     CMFTRY(check_ready(h, true));
     return pgd_h_impl(h, pen_sq, pen_abs, nonneg, loss);
 }
@@ -1109,7 +1153,7 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
 {
     const auto t_begin = std::chrono::steady_clock::now();
     auto now = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
-    if (h->gram) { // the Gram form reads its sums back inside the entry: plain loop
+    if (h->gram == 2) { // the Gram-sum loss is read back inside the entry: plain loop
         for (int64_t it = 0; it < n; ++it) {
             if (!eval_mode) CMFTRY(cmf_update_motifs(h, l1W, l2W));
             CMFTRY(cmf_update_feature_maps(h, l1H, l2H, &losses[it]));
@@ -1132,10 +1176,14 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
     };
     for (int64_t it = 0; it < n; ++it) {
         if (!eval_mode) { // alternating.jl:51-53
-            CMFTRY(w_partial_impl(h));
-            CMFTRY(w_apply_impl(h, l1W, l2W));
+            if (h->gram) {
+                CMFTRY(gram_w_impl(h, l1W, l2W));
+            } else {
+                CMFTRY(w_partial_impl(h));
+                CMFTRY(w_apply_impl(h, l1W, l2W));
+            }
         }
-        CMFTRY(h_update_impl(h, l1H, l2H)); // :54
+        CMFTRY(h->gram ? gram_h_update(h, l1H, l2H) : h_update_impl(h, l1H, l2H)); // :54
         const int slot = (int)(it & 1);
         ring[slot] = CMF_SENTINEL64; // the slot's previous loss was collected an iteration ago
         if (!eval_mode && it + 1 < n) {
@@ -1419,31 +1467,23 @@ static int ensure_resid(cmf_handle_s *h, bool masked = false, bool loss_abs = fa
 }
 
 // ---- HALS (src/algs/hals.jl) -------------------------------------------------------------------
-static int hals_ensure(cmf_handle_s *h)
+// Scratch that the Gram form of the MU rule and the HALS rule share: H as its own X operand and the lag correlations
+// (compute_hh), HH, the lag-Gram taps of W (PW -> GW, GE, GWt).  Shard-aware: only the shard that holds the global right
+// edge has truncated lag windows (edge taps GE, cut terms of HH).
+static int gram_ensure(cmf_handle_s *h)
 {
-    if (h->hals_ready) return CMF_OK;
+    if (h->gram_ready) return CMF_OK;
     const CmfDims &d = h->d;
-    if (h->sharded && h->T_global != d.Tl) return fail(CMF_ERR_STATE, "HALS needs an unsharded handle (the H sweep is sequential along T)");
-    // limits of the on-chip sweeps (the reference takes any K, L: hals.jl:90-154): the H sweep slides a 64-column window
-    // along a row with the L-1 pending columns in the lanes of one wave; the W sweep keeps the L*Kpad projected state of a
-    // unit in registers (up to 32 slots per lane) and K*L new values per unit in LDS
-    if (d.L > 64) return fail(CMF_ERR_UNSUPPORTED, "HALS path supports L <= 64 (got %d)", d.L);
-    if ((int64_t)d.L * d.K32 > 2048)
-        return fail(CMF_ERR_UNSUPPORTED, "HALS path supports L * Kpad <= 2048 (got L=%d, K=%d padded to %d)", d.L, d.K, d.K32);
-    if ((size_t)4 * d.K * d.L * HALS_NG * sizeof(float) > 64 * 1024)
-        return fail(CMF_ERR_UNSUPPORTED, "HALS path supports K * L <= 2048 (got %d)", d.K * d.L);
-    if (const char *env = getenv("CMF_HALS_GRAM")) h->hals_gram = (atoi(env) == 1 || atoi(env) == 2) ? atoi(env) : 0; // (tests compare the forms)
     const int E = 2 * d.L - 1;
+    const bool has_edge = !h->sharded || h->t_offset + d.Tl == h->T_global;
     h->hals_NpH = (int)rup((int64_t)d.L * d.K32, 128);
-    h->hals_TPp = (int)rup(d.Tl, 64) + 256;
-    h->hals_t_edge0 = std::max(0, d.Tl - d.L + 1);
+    h->hals_t_edge0 = has_edge ? std::max(0, d.Tl - d.L + 1) : d.Tl;
     h->hals_ne = d.Tl - h->hals_t_edge0;
     h->hals_NpC = (int)rup(d.K32, 128); // pitch of H as the X operand of its own lag correlations (compute_hh)
+    if ((double)d.L * d.K32 * h->hals_NpH * 4.0 >= 2147483648.0 || (double)d.TP * h->hals_NpC * 4.0 >= 2147483648.0)
+        return fail(CMF_ERR_UNSUPPORTED, "Gram form: (L*K)^2 or T*K exceeds the 2 GiB the kernels' 32-bit buffer offsets address");
     {   // time chunks of that launch: fill the resident wave slots
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, h->device));
-        const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        const int slots = 4 * n_cu * (h->hxt_LP <= 5 ? 2 : 1);
+        const int slots = 4 * h->n_cu * (h->hxt_LP <= 5 ? 2 : 1);
         int64_t wpc = (int64_t)(h->hals_NpC / 32) * d.KB * h->hxt_groups;
         int nch = (int)std::max<int64_t>(1, (slots + wpc / 2) / wpc);
         int64_t clen = rup((d.Tl + nch - 1) / nch, 6 * h->hxt_LP);
@@ -1456,12 +1496,36 @@ static int hals_ensure(cmf_handle_s *h)
     CMFTRY(dalloc_zero(&h->hals_cslabs, (size_t)hxt_nslabs(h->hals_nch) * LKC));
     CMFTRY(dalloc_zero(&h->hals_C, LKC));
     CMFTRY(dalloc_zero(&h->hals_HH, LKN));
-    CMFTRY(dalloc_zero(&h->hals_PT, (size_t)d.K32 * h->hals_TPp));
-    CMFTRY(dalloc_zero(&h->hals_D, (size_t)d.K32 * h->hals_TPp)); // per row: rows run concurrently
     CMFTRY(dalloc_zero(&h->hals_PW, (size_t)d.L * d.L * d.K32 * d.K32));
     CMFTRY(dalloc_zero(&h->hals_GW, (size_t)d.K32 * d.K32 * E));
     CMFTRY(dalloc_zero(&h->hals_GE, (size_t)d.K32 * std::max(1, h->hals_ne) * d.K32 * E));
     CMFTRY(dalloc_zero(&h->hals_GWt, (size_t)d.K32 * (E + 1) * d.K32)); // the full-window taps as [k'][e][k] for gram_h_mfma_kernel
+    h->gram_ready = true;
+    return CMF_OK;
+}
+
+static int hals_ensure(cmf_handle_s *h)
+{
+    if (h->hals_ready) return CMF_OK;
+    const CmfDims &d = h->d;
+    if (h->sharded && h->T_global != d.Tl) return fail(CMF_ERR_STATE, "HALS needs an unsharded handle (the H sweep is sequential along T)");
+    if (const char *env = getenv("CMF_HALS_GRAM")) h->hals_gram = (atoi(env) == 1 || atoi(env) == 2) ? atoi(env) : 0; // (tests compare the forms)
+    const int E = 2 * d.L - 1;
+    CMFTRY(gram_ensure(h));
+    h->hals_TPp = (int)rup(d.Tl, 64) + 256;
+    CMFTRY(dalloc_zero(&h->hals_PT, (size_t)d.K32 * h->hals_TPp));
+    CMFTRY(dalloc_zero(&h->hals_D, (size_t)d.K32 * h->hals_TPp)); // per row: rows run concurrently
+    // Which sweep kernels run (the reference takes any K, L: hals.jl:90-154).  The fast on-chip sweeps have shape limits:
+    // the H sweep slides a 64-column window along a row with the L-1 pending columns in the lanes of one wave (L <= 64);
+    // the W sweep keeps the L*Kpad projected state of a unit in registers (up to 32 slots per lane) and K*L new values per
+    // unit in LDS.  Outside them the general sweeps run (hals_w_sweep_gen_kernel / hals_h_row_gen_kernel): the same
+    // recurrences in the same order with the state in LDS / global memory -- slower, no shape limit.
+    h->hals_w_general = ((int64_t)d.L * d.K32 > 2048) || ((size_t)4 * d.K * d.L * HALS_NG * sizeof(float) > 64 * 1024);
+    h->hals_h_general = d.L > 64;
+    if (const char *env = getenv("CMF_HALS_GENERAL")) { // tests: force the general sweeps at any shape
+        if (atoi(env) & 1) h->hals_w_general = true;
+        if (atoi(env) & 2) h->hals_h_general = true;
+    }
     {   // row pipeline: segment length (multiple of 64, >= 256 so that the sweeps and pushes of one stage
         // touch disjoint columns: see hals_h_stage_kernel)
         const char *env = getenv("CMF_HALS_SEG");
@@ -1494,15 +1558,16 @@ static int hals_ensure(cmf_handle_s *h)
 
 // HH = H_unfold * H_unfold' (hals.jl:56-60: the row norms are its diagonal) from the lag correlations of H with itself:
 // one C2 contraction on K32 columns, then an assembly pass with the right-end corrections (hals_hh_kernel)
-static int compute_hh(cmf_handle_s *h)
+static int compute_hh(cmf_handle_s *h, float *out = nullptr)
 {
     const CmfDims &d = h->d;
+    const bool shard = h->sharded && h->T_global != d.Tl; // out = this shard's additive share of HH (hals_hh_kernel)
     hipLaunchKernelGGL(hals_hx_kernel, dim3(1024), dim3(256), 0, h->stream, h->H, h->hals_HX, d.TP, d.K32, h->hals_NpC);
     KCHK("hals_hx_kernel");
     CMFTRY(launch_hxt_on(h, h->hals_HX, h->hals_HX, h->hals_NpC, 1, h->hals_cslabs, h->hals_nch, h->hals_clen));
     CMFTRY(launch_slab_sum(h, h->hals_C, h->hals_cslabs, hxt_nslabs(h->hals_nch), (size_t)d.L * d.K32 * h->hals_NpC));
-    hipLaunchKernelGGL(hals_hh_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_C, h->H, h->hals_HH, d.Tl, d.L, d.K, d.K32,
-                       h->hals_NpC, h->hals_NpH, d.PADL);
+    hipLaunchKernelGGL(hals_hh_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_C, h->H, out ? out : h->hals_HH, d.Tl, d.L, d.K, d.K32,
+                       h->hals_NpC, h->hals_NpH, d.PADL, shard ? 1 : 0, (h->t_offset + d.Tl == h->T_global) ? 1 : 0);
     KCHK("hals_hh_kernel");
     return CMF_OK;
 }
@@ -1704,26 +1769,40 @@ static int gram_denom_h(cmf_handle_s *h, float *out)
     return CMF_OK;
 }
 
-static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W)
+// W phase of the Gram form in two steps, so that a T-sharded group can put its all-reduce between them:
+//   gram_w_partial  numW = H_shift * data' (mult.jl:32; ONE C2 contraction on this handle's columns) -> h->numden[0, LKN),
+//                   and HH = H_unfold * H_unfold' (on a shard: its additive share, see hals_hh_kernel) -> hh_out
+//   gram_w_finish   denomW = H_shift * est' (mult.jl:33) = HH * W -> h->wslabs (free once the slabs are summed), W update
+static int gram_w_partial(cmf_handle_s *h, float *hh_out)
 {
     const CmfDims &d = h->d;
-    CMFTRY(hals_ensure(h));
+    CMFTRY(gram_ensure(h));
     const size_t LKN = (size_t)d.L * d.K32 * d.Np;
-    // numW = H_shift * data' (mult.jl:32): one C2 contraction
     CMFTRY(launch_hxt_on(h, h->X, h->X, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
-    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN));
-    // denomW = H_shift * est' (mult.jl:33) = HH * W with HH = H_unfold * H_unfold'
-    CMFTRY(compute_hh(h));
-    hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 128, d.L * d.KB), dim3(256), 0, h->stream, h->hals_HH, h->Wt, h->numden + LKN,
-                       d.L * d.K32, h->hals_NpH, d.Np);
-    KCHK("gram_w_kernel");
-    return w_apply_impl(h, l1W, l2W); // mult.jl:37-38
+    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN, true)); // (+ a loss reduction deferred by cmf_iterate)
+    return compute_hh(h, hh_out);
 }
 
-static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss)
+static int gram_w_finish(cmf_handle_s *h, const float *HH, double l1W, double l2W, const float *tail_src, float *tail_dst, int tail_n)
 {
     const CmfDims &d = h->d;
-    CMFTRY(hals_ensure(h));
+    hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 128, d.L * d.KB), dim3(256), 0, h->stream, HH, h->Wt, h->wslabs,
+                       d.L * d.K32, h->hals_NpH, d.Np);
+    KCHK("gram_w_kernel");
+    return w_apply_impl(h, l1W, l2W, tail_src, tail_dst, tail_n, h->wslabs); // mult.jl:37-38
+}
+
+static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W)
+{
+    CMFTRY(gram_w_partial(h, nullptr));
+    return gram_w_finish(h, h->hals_HH, l1W, l2W);
+}
+
+// H phase of the Gram form without the loss (mult.jl:44-52)
+static int gram_h_update(cmf_handle_s *h, double l1H, double l2H)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(gram_ensure(h));
     const size_t TK = (size_t)d.Tl * d.K32;
     if (!h->gram_numden_h) CMFTRY(dalloc_zero(&h->gram_numden_h, 2 * TK));
     // numH = tensor_transconv(W, data) (mult.jl:47): one C3 contraction
@@ -1736,6 +1815,14 @@ static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss)
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
     KCHK("h_update_kernel");
     h->est_kind = 0;
+    return CMF_OK;
+}
+
+static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss)
+{
+    const CmfDims &d = h->d;
+    CMFTRY(gram_h_update(h, l1H, l2H));
+    const size_t TK = (size_t)d.Tl * d.K32;
     double ss = 0.0;
     if (h->gram == 2) {
         // ||est - data||^2 = <H, denomH(H)> - 2 <H, numH> + ||data||^2 with the NEW H (adjointness of conv/transconv)
@@ -1764,7 +1851,7 @@ static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss)
 // ---- PGD (src/algs/pgd.jl) ---------------------------------------------------------------------
 static int pgd_check(cmf_handle_s *h)
 {
-    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "PGD needs an unsharded handle");
+    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator first (cmf_comm_init_rccl / cmf_comm_init_callbacks)");
     if (h->pgd_cur_loss < 0.0) h->pgd_cur_loss = h->data_norm; // pgd.jl:151 (the norm, not its square)
     return CMF_OK;
 }
@@ -1852,6 +1939,198 @@ static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
     h->est_kind = 0;
     CMFTRY(pgd_finish(h, &h->pgd_stepH));
     *loss = std::sqrt(h->pgd_cur_loss / (h->data_norm * h->data_norm)); // pgd.jl:201
+    return CMF_OK;
+}
+
+// ---- PGD on T-sharded groups (pgd.jl:158-255 with data / est / H cut along T, W replicated) ------------------------------
+// compute_gradW! (pgd.jl:206-214) is the C2 contraction: every shard contracts its own residual columns and ONE all-reduce
+// sums the K x N x L partial gradients; the penalty, norm(grad) and the step are then identical replicated arithmetic.
+// compute_gradH! (:218-221) is tensor_transconv! on the shard's columns plus its right residual halo (the conv covers
+// Tl + halo_r columns, as in the MU rule); norm(gradH)^2, the per-component norms of UnitNormConstraint and the loss are
+// sums over shards, combined in rank order on the host (exact: doubles travel as two 32-bit words).  The step-size state
+// machine (stepW, stepH, cur_loss; :139-154, :248-253) is replicated: every rank takes the same decisions from the same sums.
+
+// n doubles at device address ptr[i] of every local shard -> their sum over ALL ranks (rank order), written back to every shard
+static int group_sum_doubles(cmf_group_s *g, const std::vector<double *> &ptr, int n, std::vector<double> *host_out = nullptr)
+{
+    const size_t nl = g->sh.size();
+    std::vector<std::vector<double>> local(nl, std::vector<double>((size_t)n));
+    for (size_t i = 0; i < nl; ++i) {
+        cmf_handle_s *s = g->sh[i];
+        CMFTRY(group_use(s));
+        HIPCHK(hipMemcpyAsync(local[i].data(), ptr[i], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    std::vector<double> total((size_t)n, 0.0);
+    if (g->one_process) {
+        for (int r = 0; r < g->nranks; ++r)
+            for (size_t i = 0; i < nl; ++i)
+                if (g->rank[i] == r)
+                    for (int j = 0; j < n; ++j) total[(size_t)j] += local[i][(size_t)j];
+    } else {
+        for (int j = 0; j < n; ++j) { // (n is 1, or K for UnitNormConstraint: a handful of 8-byte all-gathers)
+            std::vector<double> mine(1, local[0][(size_t)j]), all;
+            CMFTRY(group_gather_doubles(g, mine, all));
+            for (double v : all) total[(size_t)j] += v;
+        }
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        cmf_handle_s *s = g->sh[i];
+        CMFTRY(group_use(s));
+        HIPCHK(hipMemcpyAsync(ptr[i], total.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream)); // `total` is pageable host memory: finish before it goes out of scope
+    }
+    if (host_out) *host_out = total;
+    return CMF_OK;
+}
+
+static bool group_masked(const cmf_group_s *g) { return g->sh[0]->M != nullptr; }
+
+// pgd.jl:245-253 on the group: the residual with the new factors on every shard, loss = sum over shards
+static int group_pgd_finish(cmf_handle_s *st, cmf_group_s *g, double *step)
+{
+    std::vector<double *> ptr;
+    for (cmf_handle_s *s : g->sh) {
+        CMFTRY(group_use(s));
+        CMFTRY(resid_and_loss(s, nullptr, group_masked(g), st->pgd_loss_abs != 0));
+        ptr.push_back(s->d_scalar);
+    }
+    std::vector<double> tot;
+    CMFTRY(group_sum_doubles(g, ptr, 1, &tot));
+    const double loss = tot[0];
+    *step *= (loss < st->pgd_cur_loss) ? 1.05 : 0.70;
+    st->pgd_cur_loss = loss;
+    return CMF_OK;
+}
+
+static int group_pgd_prepare(cmf_handle_s *st, cmf_group_s *g, int nonneg)
+{
+    if (nonneg < 0 || nonneg > 2) return fail(CMF_ERR_ARG, "constraint must be 0 (none), 1 (NonnegConstraint) or 2 (UnitNormConstraint)");
+    if (g->gram || g->overlap) return fail(CMF_ERR_STATE, "the PGD rule runs on a group with the options gram and allreduce_overlap off");
+    if (st->pgd_cur_loss < 0.0) st->pgd_cur_loss = g->data_norm; // pgd.jl:151 (the norm, not its square)
+    for (cmf_handle_s *s : g->sh) {
+        s->pgd_loss_abs = st->pgd_loss_abs;
+        s->carry = CmfLossCarry{};
+    }
+    if (!g->halos_current) CMFTRY(group_exchange_halos(g));
+    return CMF_OK;
+}
+
+static int group_pgd_w(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double pen_abs, int nonneg)
+{
+    CMFTRY(group_pgd_prepare(st, g, nonneg));
+    const CmfDims &d0 = g->sh[0]->d;
+    const float gscale = st->pgd_loss_abs ? 1.f : 2.f; // pgd.jl:31-33 vs :42-44
+    const size_t LKN = (size_t)d0.L * d0.K32 * d0.Np;
+    for (cmf_handle_s *s : g->sh) {
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        CMFTRY(ensure_resid(s, group_masked(g), st->pgd_loss_abs != 0));                                 // pgd.jl:230 on the shard's columns
+        CMFTRY(launch_hxt_on(s, s->est, s->est, d.Np, 1, s->wslabs, s->hxt_nchunks1, s->hxt_chunk_len1)); // pgd.jl:206-214, partial over t
+        CMFTRY(launch_slab_sum(s, s->numden, s->wslabs, hxt_nslabs(s->hxt_nchunks1), LKN));
+    }
+    CMFTRY(group_allreduce(g, g->red, 0, LKN)); // the one bulk exchange: K x N x L partial gradients
+    for (cmf_handle_s *s : g->sh) {
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        dim3 grid(d.Np / 64, d.KB, d.L);
+        const int nblk = (d.Np / 64) * d.KB * d.L;
+        if ((size_t)nblk > n_partial(s)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
+        hipLaunchKernelGGL(pgd_w_grad_kernel, grid, dim3(256), 0, s->stream, s->Wt, s->numden, s->numden + LKN, s->partial,
+                           d.N, d.K, d.Np, d.K32, (float)pen_sq, (float)pen_abs, gscale);                // pgd.jl:231-234 (replicated)
+        KCHK("pgd_w_grad_kernel");
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s->stream, s->partial, nblk, s->d_scalar + 1, (double *)nullptr);
+        KCHK("loss_reduce_kernel");
+        hipLaunchKernelGGL(pgd_w_apply_kernel, grid, dim3(256), 0, s->stream, s->Wt, s->Wn, s->numden + LKN, s->d_scalar + 1,
+                           d.N, d.K, d.Np, d.K32, (float)st->pgd_stepW, nonneg == 1);                    // pgd.jl:237-241
+        KCHK("pgd_w_apply_kernel");
+        if (nonneg == 2) CMFTRY(pgd_unit_norm(s, true));                                                 // pgd.jl:100-110 (W is replicated)
+        s->est_kind = 0;
+    }
+    return group_pgd_finish(st, g, &st->pgd_stepW);
+}
+
+static int group_pgd_h(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double pen_abs, int nonneg, double *loss)
+{
+    CMFTRY(group_pgd_prepare(st, g, nonneg));
+    const float gscale = st->pgd_loss_abs ? 1.f : 2.f;
+    std::vector<double *> nrm;
+    for (cmf_handle_s *s : g->sh) {
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        if (!s->pgd_gradH) CMFTRY(dalloc_zero(&s->pgd_gradH, (size_t)d.Tl * d.K32));
+        s->pgd_loss_abs_now = st->pgd_loss_abs;
+        // the transposed residual on the shard's columns AND its right lag halo (transconv reads est[:, t .. t+L-1])
+        int rc_conv = s->MT ? launch_conv<7>(s, s->estT, d.Tl + s->halo_r, s->conv_gy_ext, s->XT)
+                            : launch_conv<5>(s, s->estT, d.Tl + s->halo_r, s->conv_gy_ext, s->XT);
+        s->pgd_loss_abs_now = 0;
+        CMFTRY(rc_conv);
+        CMFTRY(launch_transconv(s, 1, s->estT));                                                         // pgd.jl:218-221
+        dim3 grid((d.Tl + 63) / 64, d.KB);
+        const int nblk = ((d.Tl + 63) / 64) * d.KB;
+        if ((size_t)nblk > n_partial(s)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
+        hipLaunchKernelGGL(pgd_h_grad_kernel, grid, dim3(256), 0, s->stream, s->H, s->hslabs, s->tc_S1, s->pgd_gradH, s->partial,
+                           d.Tl, d.K, d.K32, d.PADL, (float)pen_sq, (float)pen_abs, gscale);
+        KCHK("pgd_h_grad_kernel");
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s->stream, s->partial, nblk, s->d_scalar + 1, (double *)nullptr);
+        KCHK("loss_reduce_kernel");
+        nrm.push_back(s->d_scalar + 1);
+    }
+    CMFTRY(group_sum_doubles(g, nrm, 1)); // norm(gradH)^2 over all shards (pgd.jl:236)
+    std::vector<double *> kn;
+    for (cmf_handle_s *s : g->sh) {
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        dim3 grid((d.Tl + 63) / 64, d.KB);
+        hipLaunchKernelGGL(pgd_h_apply_kernel, grid, dim3(256), 0, s->stream, s->H, s->Ht, s->pgd_gradH, s->d_scalar + 1,
+                           d.Tl, d.K, d.K32, d.PADL, d.TP, (float)st->pgd_stepH, nonneg == 1);
+        KCHK("pgd_h_apply_kernel");
+        if (nonneg == 2) { // pgd.jl:100-110: the norm of a component runs over all of T
+            if (!s->pgd_knorm) CMFTRY(dalloc_zero(&s->pgd_knorm, (size_t)d.K32));
+            hipLaunchKernelGGL(pgd_h_knorm_kernel, dim3(d.K), dim3(256), 0, s->stream, s->Ht, s->pgd_knorm, d.Tl, d.TP, d.PADL);
+            KCHK("pgd_h_knorm_kernel");
+            kn.push_back(s->pgd_knorm);
+        }
+        s->est_kind = 0;
+    }
+    if (nonneg == 2) {
+        CMFTRY(group_sum_doubles(g, kn, g->sh[0]->d.K));
+        for (cmf_handle_s *s : g->sh) {
+            const CmfDims &d = s->d;
+            CMFTRY(group_use(s));
+            hipLaunchKernelGGL(pgd_h_kscale_kernel, dim3(1024), dim3(256), 0, s->stream, s->H, s->Ht, s->pgd_knorm, d.Tl, d.K, d.K32, d.TP, d.PADL);
+            KCHK("pgd_h_kscale_kernel");
+        }
+    }
+    CMFTRY(group_exchange_halos(g));
+    CMFTRY(group_pgd_finish(st, g, &st->pgd_stepH));
+    *loss = std::sqrt(st->pgd_cur_loss / (g->data_norm * g->data_norm)); // pgd.jl:201
+    return CMF_OK;
+}
+
+// MaskedLoss on a group: the mask is cut like data -- shard r holds its own columns in both layouts and the right lag halo
+// in the transposed one.  One process: `mask` is the whole N x T matrix; one process per shard: the block of data_local.
+static int group_set_mask(cmf_group_s *g, const double *mask)
+{
+    CMFTRY(group_sync(g));
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        cmf_handle_s *s = g->sh[i];
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        s->est_kind = 0;
+        if (!mask) {
+            if (s->M) (void)hipFree(s->M);
+            if (s->MT) (void)hipFree(s->MT);
+            s->M = s->MT = nullptr;
+            continue;
+        }
+        const size_t TPNp = (size_t)d.TP * d.Np;
+        if (!s->M) CMFTRY(dalloc_zero(&s->M, TPNp));
+        if (!s->MT) CMFTRY(dalloc_zero(&s->MT, TPNp));
+        const double *m = g->one_process ? mask + (size_t)g->t0[(size_t)g->rank[i]] * d.N : mask;
+        CMFTRY(upload_cols(s, m, 0, d.Tl, true, false, s->M, s->MT));
+        if (s->halo_r > 0) CMFTRY(upload_cols(s, m + (size_t)d.Tl * d.N, d.Tl, s->halo_r, false, false, s->M, s->MT));
+    }
     return CMF_OK;
 }
 

@@ -125,6 +125,8 @@ struct cmf_group_s {
     float *h_tail = nullptr;             // pinned host: 2 ring slots (the late loss read-back: pairs + stamp) + 1 for the synchronous one
     int64_t slot_len = 0;                // floats per slot
     int64_t LKN2 = 0, tail = 0, HC = 0;
+    int64_t HHsz = 0;                    // floats of HH = H_unfold H_unfold' ((L*Kpad) x its 128-padded pitch): the Gram form's share
+    int gram = 0;                        // option "gram" on a group: the all-reduce carries [numW | HH | tail] instead of [numW | denomW | tail]
     int64_t N = 0, T = 0, K = 0, L = 0;
     std::vector<int64_t> t0, t1;         // column block of every rank
     double data_sumsq = 0.0, data_norm = 0.0;
@@ -145,6 +147,10 @@ static void group_partition(int64_t T, int R, int64_t L, std::vector<int64_t> &t
     (void)L;
 }
 
+// Where the loss tail starts in the all-reduce buffer: behind [numW | denomW], or behind [numW | HH] in the Gram form --
+// either way the buffer that travels is ONE contiguous range that ends with the tail.
+static inline size_t group_tail_off(const cmf_group_s *g) { return (size_t)(g->gram ? g->LKN2 / 2 + g->HHsz : g->LKN2); }
+
 static int group_use(cmf_handle_s *s)
 {
     HIPCHK(hipSetDevice(s->device));
@@ -158,6 +164,8 @@ static int group_alloc_buffers(cmf_group_s *g)
     g->LKN2 = (int64_t)2 * d.L * d.K32 * d.Np;
     g->tail = rup(2 * g->nranks, 64);
     g->HC = (int64_t)std::max(1, d.L - 1) * d.K32;
+    g->HHsz = (int64_t)d.L * d.K32 * rup((int64_t)d.L * d.K32, 128);
+    const size_t red_elems = (size_t)std::max(g->LKN2, g->LKN2 / 2 + g->HHsz) + (size_t)g->tail;
     const size_t nl = g->sh.size();
     g->red.assign(nl, nullptr);
     g->halo_send.assign(nl, nullptr);
@@ -166,7 +174,7 @@ static int group_alloc_buffers(cmf_group_s *g)
     for (size_t i = 0; i < nl; ++i) {
         cmf_handle_s *s = g->sh[i];
         CMFTRY(group_use(s));
-        CMFTRY(dalloc_zero(&g->red[i], (size_t)(g->LKN2 + g->tail)));
+        CMFTRY(dalloc_zero(&g->red[i], red_elems));
         CMFTRY(dalloc_zero(&g->halo_send[i], (size_t)(2 * g->HC)));
         CMFTRY(dalloc_zero(&g->halo_all[i], (size_t)(g->nranks * 2 * g->HC)));
         CMFTRY(dalloc_zero(&g->loss_all[i], (size_t)(2 * g->tail))); // [gathered pairs | send scratch]
@@ -392,11 +400,11 @@ static int group_loss_partials(cmf_group_s *g, bool defer = false)
         CMFTRY(group_use(s));
         CMFTRY(launch_loss_conv(s)); // mult.jl:55-57
         if (defer) {
-            s->carry = CmfLossCarry{s->partial, s->conv_partials, s->d_scalar, nullptr, g->red[i] + g->LKN2, (int)g->tail, g->rank[i]};
+            s->carry = CmfLossCarry{s->partial, s->conv_partials, s->d_scalar, nullptr, g->red[i] + group_tail_off(g), (int)g->tail, g->rank[i]};
             continue;
         }
         hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(256), 0, s->stream, s->partial, s->conv_partials, s->d_scalar,
-                           g->red[i] + g->LKN2, (int)g->tail, g->rank[i]);
+                           g->red[i] + group_tail_off(g), (int)g->tail, g->rank[i]);
         KCHK("loss_tail_kernel");
     }
     return CMF_OK;
@@ -409,7 +417,7 @@ static int group_loss_now(cmf_group_s *g, double *sumsq)
     cmf_handle_s *s = g->sh[0];
     if (g->nranks == 1 && g->transport != CMF_TR_RCCL) return read_scalar(s, 0, sumsq);
     std::vector<float *> send(nl);
-    for (size_t i = 0; i < nl; ++i) send[i] = g->red[i] + g->LKN2 + 2 * g->rank[i];
+    for (size_t i = 0; i < nl; ++i) send[i] = g->red[i] + group_tail_off(g) + 2 * g->rank[i];
     CMFTRY(group_allgather(g, send, 0, g->loss_all, 2));
     CMFTRY(group_use(s));
     float *stage = g->h_tail + 2 * g->slot_len; // not a ring slot: a pending one-iteration-late loss may still sit there
@@ -419,17 +427,19 @@ static int group_loss_now(cmf_group_s *g, double *sumsq)
     return CMF_OK;
 }
 
-// overlap form: numW needs H only -- contract it and start its all-reduce on the communication stream
+// overlap form: numW needs H only -- contract it and start its all-reduce on the communication stream.  In the Gram form
+// the whole payload [numW | HH] needs H only, so ALL of the bulk all-reduce runs underneath the loss conv.
 static int group_start_num(cmf_group_s *g)
 {
     const size_t half = (size_t)g->LKN2 / 2;
     for (cmf_handle_s *s : g->sh) {
         CMFTRY(group_use(s));
-        CMFTRY(w_partial_half_impl(s, 0));
+        if (g->gram) CMFTRY(gram_w_partial(s, s->numden + half));
+        else CMFTRY(w_partial_half_impl(s, 0));
         HIPCHK(hipEventRecord(s->ev_c0, s->stream));
         HIPCHK(hipStreamWaitEvent(s->comm_stream, s->ev_c0, 0));
     }
-    CMFTRY(group_allreduce(g, g->red, 0, half, true));
+    CMFTRY(group_allreduce(g, g->red, 0, g->gram ? half + (size_t)g->HHsz : half, true));
     for (cmf_handle_s *s : g->sh) {
         CMFTRY(group_use(s));
         HIPCHK(hipEventRecord(s->ev_c1, s->comm_stream));
@@ -444,13 +454,18 @@ static int group_update_motifs(cmf_group_s *g, double l1W, double l2W, int ring_
 {
     if (!g->halos_current) CMFTRY(group_exchange_halos(g));
     const size_t half = (size_t)g->LKN2 / 2;
+    const size_t toff = group_tail_off(g);
     if (g->overlap) {
         if (!g->num_ready) CMFTRY(group_start_num(g));
-        for (cmf_handle_s *s : g->sh) {
-            CMFTRY(group_use(s));
-            CMFTRY(w_partial_half_impl(s, 1));
+        if (g->gram) { // the bulk is in flight on the communication stream: only the loss tail is left for this stream
+            CMFTRY(group_allreduce(g, g->red, toff, (size_t)g->tail));
+        } else {
+            for (cmf_handle_s *s : g->sh) {
+                CMFTRY(group_use(s));
+                CMFTRY(w_partial_half_impl(s, 1));
+            }
+            CMFTRY(group_allreduce(g, g->red, half, half + (size_t)g->tail));
         }
-        CMFTRY(group_allreduce(g, g->red, half, half + (size_t)g->tail));
         for (cmf_handle_s *s : g->sh) {
             CMFTRY(group_use(s));
             HIPCHK(hipStreamWaitEvent(s->stream, s->ev_c1, 0));
@@ -459,9 +474,10 @@ static int group_update_motifs(cmf_group_s *g, double l1W, double l2W, int ring_
     } else {
         for (cmf_handle_s *s : g->sh) {
             CMFTRY(group_use(s));
-            CMFTRY(w_partial_impl(s));
+            if (g->gram) CMFTRY(gram_w_partial(s, s->numden + half)); // [numW | this shard's share of HH | tail]
+            else CMFTRY(w_partial_impl(s));
         }
-        CMFTRY(group_allreduce(g, g->red, 0, (size_t)(g->LKN2 + g->tail)));
+        CMFTRY(group_allreduce(g, g->red, 0, toff + (size_t)g->tail));
     }
     for (size_t i = 0; i < g->sh.size(); ++i) {
         cmf_handle_s *s = g->sh[i];
@@ -469,9 +485,11 @@ static int group_update_motifs(cmf_group_s *g, double l1W, double l2W, int ring_
         if (i == 0 && ring_slot >= 0) { // shard 0's W update also drops the reduced loss pairs + a stamp into the pinned ring slot
             float *ring = g->h_tail + (size_t)ring_slot * g->slot_len;
             for (int j = 0; j < 2 * g->nranks; ++j) reinterpret_cast<volatile unsigned *>(ring)[j] = CMF_SENTINEL32; // collected an iteration ago
-            CMFTRY(w_apply_impl(s, l1W, l2W, g->red[0] + g->LKN2, ring, 2 * g->nranks));
+            if (g->gram) CMFTRY(gram_w_finish(s, s->numden + half, l1W, l2W, g->red[0] + toff, ring, 2 * g->nranks));
+            else CMFTRY(w_apply_impl(s, l1W, l2W, g->red[0] + toff, ring, 2 * g->nranks));
         } else {
-            CMFTRY(w_apply_impl(s, l1W, l2W));
+            if (g->gram) CMFTRY(gram_w_finish(s, s->numden + half, l1W, l2W));
+            else CMFTRY(w_apply_impl(s, l1W, l2W));
         }
     }
     return CMF_OK;
@@ -484,12 +502,13 @@ static int group_update_feature_maps(cmf_group_s *g, double l1H, double l2H, dou
     if (!g->halos_current) CMFTRY(group_exchange_halos(g));
     for (cmf_handle_s *s : g->sh) {
         CMFTRY(group_use(s));
-        CMFTRY(h_update_impl(s, l1H, l2H));
+        CMFTRY(g->gram ? gram_h_update(s, l1H, l2H) : h_update_impl(s, l1H, l2H));
     }
     g->num_ready = false;
     CMFTRY(group_exchange_halos(g));
     if (g->overlap) CMFTRY(group_start_num(g)); // for the next update_motifs!: H and its halos are final now
-    CMFTRY(group_loss_partials(g, /*defer=*/sumsq == nullptr));
+    // (Gram + overlap: the next W phase has no slab sum left on this stream for a deferred reduction to ride on)
+    CMFTRY(group_loss_partials(g, /*defer=*/sumsq == nullptr && !(g->gram && g->overlap)));
     return sumsq ? group_loss_now(g, sumsq) : CMF_OK;
 }
 

@@ -1344,11 +1344,11 @@ __device__ __forceinline__ float cmf_mu(float x, float num, float den, float l1,
     return (y != y) ? y : fmaxf(CMF_EPS_F, y);
 }
 
-// grid: (Np/64, KB, L), block 256.  numden: [nslabs][2][L][K32][Np]
+// grid: (Np/64, KB, L), block 256.  num, den: [L][K32][Np] each
 // tail_src / tail_dst (may be NULL): block (0,0,0) also copies `tail_n` (<= 256) floats -- the loss pairs behind the
 // [numW | denomW] all-reduce buffer of a sharded group -- to pinned host memory that the host has filled with a
 // sentinel pattern and polls, so the read-back costs neither a launch nor an event (see loss_reduce_kernel).
-__global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, const float *numden, int nslabs,
+__global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, const float *num_p, const float *den_p,
                                                         int N, int K, int L, int Np, int K32, float l1, float two_l2,
                                                         const float *tail_src, float *tail_dst, int tail_n)
 {
@@ -1357,7 +1357,6 @@ __global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, con
     if (tail_dst && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid < tail_n) // relaxed system-scope word stores:
         __hip_atomic_store(tail_dst + tid, tail_src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // the host polls every word
     const int n0 = blockIdx.x * 64, kb = blockIdx.y, l = blockIdx.z;
-    const size_t LKN = (size_t)L * K32 * Np;
     {
         const int nn = tid & 63;
 #pragma unroll
@@ -1365,11 +1364,7 @@ __global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, con
             int kk = q * 4 + (tid >> 6);
             int k = kb * 32 + kk, n = n0 + nn;
             size_t idx = ((size_t)l * K32 + k) * Np + n;
-            float num = 0.f, den = 0.f;
-            for (int s = 0; s < nslabs; ++s) {
-                num += numden[(size_t)(2 * s) * LKN + idx];
-                den += numden[(size_t)(2 * s + 1) * LKN + idx];
-            }
+            const float num = num_p[idx], den = den_p[idx];
             float w = Wt[idx];
             float wn = (k < K && n < N) ? cmf_mu(w, num, den, l1, two_l2) : 0.f;
             Wt[idx] = wn;
@@ -1561,7 +1556,12 @@ __global__ void hals_hx_kernel(const float *H, float *HX, int TP, int K32, int N
     }
 }
 // HH[(l*K32+k) * NpH + l'*K32+k'] from C [L][K32][NpC] and the last columns of H ([TP][K32]).  One thread per entry.
-__global__ void hals_hh_kernel(const float *C, const float *H, float *HH, int Tl, int L, int K, int K32, int NpC, int NpH, int PADL)
+// sharded != 0: this handle owns one column block of a T-sharded problem and C holds the lag correlations over ITS
+// columns only (with the left H halo); the entry is then this shard's additive share of HH -- C as it is, minus the cut
+// terms on the shard that holds the global right edge (is_last; the columns u - d >= Tl - 2(L-1) they read are the
+// shard's own or its left halo) -- and the shares are summed by the group's all-reduce.
+__global__ void hals_hh_kernel(const float *C, const float *H, float *HH, int Tl, int L, int K, int K32, int NpC, int NpH, int PADL,
+                               int sharded, int is_last)
 {
     const int LK = L * K32;
     const size_t total = (size_t)LK * LK;
@@ -1577,7 +1577,11 @@ __global__ void hals_hh_kernel(const float *C, const float *H, float *HH, int Tl
             // directly: C minus nearly all of itself would leave rounding noise where H_unfold has exact zeros (rows with
             // l >= T), and the sweep divides by HH[j][j] + eps
             const int kept = Tl - cut - d;
-            if (kept <= 0) {
+            if (sharded) {
+                v = C[((size_t)d * K32 + a) * NpC + b];
+                if (is_last)
+                    for (int u = Tl - cut; u < Tl; ++u) v -= H[(size_t)(PADL + u - d) * K32 + a] * H[(size_t)(PADL + u) * K32 + b];
+            } else if (kept <= 0) {
                 v = 0.f;
             } else if (kept <= cut || kept <= 64) {
                 for (int u = d; u < Tl - cut; ++u) v = fmaf(H[(size_t)(PADL + u - d) * K32 + a], H[(size_t)(PADL + u) * K32 + b], v);

@@ -401,14 +401,16 @@ def _nonneg_flag(constr):
 
 
 class PGDUpdate(MultUpdate):
-    """PGDUpdate on MI355X: drop-in for src/algs/pgd.jl:112-202 with SquareLoss.
+    """PGDUpdate on MI355X: drop-in for src/algs/pgd.jl:112-202.
 
     The gradients are the same contractions as the MU numerators (compute_gradW! is the H_shift * X'
     product of mult.jl:31-34, compute_gradH! is tensor_transconv!), taken on the stored residual.
-    The rule state (stepW, stepH, cur_loss) lives in the library handle."""
+    The rule state (stepW, stepH, cur_loss) lives in the library handle.  ``devices=[...]`` shards T over several
+    GPUs like MultUpdate does (one all-reduce of the partial gradW per iteration; the long recordings of
+    notebooks/test_mouse.ipynb are fitted with this rule)."""
 
-    def __init__(self, data, W, H, device=None):
-        super().__init__(data, W, H, device=device)
+    def __init__(self, data, W, H, device=None, devices=None, transport=_lib.CMF_COMM_AUTO):
+        super().__init__(data, W, H, device=device, devices=devices, transport=transport)
         check(self._lib.cmf_pgd_reset(self._h))
         self._mask_key = None
 
@@ -428,12 +430,15 @@ class PGDUpdate(MultUpdate):
         if key == self._mask_key:
             return
         if key is None:
-            check(self._lib.cmf_set_mask(self._h, None))
+            self._upload_mask(None)
         else:
             if loss_func.mask.shape != (self.N, self.T):
                 raise ValueError(f"mask must be {self.N} x {self.T} like data, got {loss_func.mask.shape}")
-            check(self._lib.cmf_set_mask(self._h, ptr(loss_func.mask)))
+            self._upload_mask(loss_func.mask)
         self._mask_key = key
+
+    def _upload_mask(self, mask):
+        check(self._lib.cmf_set_mask(self._h, None if mask is None else ptr(mask)))
 
     def update_motifs(self, data=None, W=None, H=None, loss_func=None, constrW=NonnegConstraint, penaltiesW=None, **kwargs):
         """update_motifs!(rule::PGDUpdate, ...; loss_func=SquareLoss(), constrW=NonnegConstraint(),
@@ -597,10 +602,10 @@ def fit_cnmf(data, L=10, K=5, alg=MultUpdate, max_itr=100, max_time=math.inf, **
     W_init = kw.get("W_init", W_init)  # :72-73
     H_init = kw.get("H_init", H_init)
 
-    if devices is not None and rule_type is not MultUpdate:
-        raise NotImplementedError("devices=[...] (T sharding) is available for alg=:mult; the other rules run on one GPU")
+    if devices is not None and rule_type not in (MultUpdate, PGDUpdate):
+        raise NotImplementedError("devices=[...] (T sharding) is available for alg=:mult and :pgd; HALS sweeps H sequentially along T")
     if devices is not None:
-        rule = MultUpdate(data, W_init, H_init, devices=devices)
+        rule = rule_type(data, W_init, H_init, devices=devices)
     else:
         rule = (rule_type(data, W_init, H_init, device=device) if issubclass(rule_type, MultUpdate)
                 else rule_type(data, W_init, H_init))

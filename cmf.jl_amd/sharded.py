@@ -26,7 +26,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import CMFError, check, farr, ptr
-from .host import MultUpdate
+from .host import MultUpdate, PGDUpdate
 
 
 def partition(T, world, L):
@@ -222,3 +222,29 @@ class ShardedMultUpdate(MultUpdate):
             H[...] = Hg
             Hg = H
         return Wl, Hg
+
+
+class ShardedPGDUpdate(ShardedMultUpdate, PGDUpdate):
+    """PGDUpdate (src/algs/pgd.jl:112-202) with the T axis sharded over the ranks of a torch.distributed process group:
+    the same construction as ShardedMultUpdate, the rule methods of PGDUpdate (cmf_pgd_update_motifs /
+    cmf_pgd_update_feature_maps on a group handle).  ``MaskedLoss(loss, mask)`` takes the GLOBAL N x T mask; each rank
+    uploads its block with the right lag halo, like data."""
+
+    def __init__(self, data, W, H, **kw):
+        ShardedMultUpdate.__init__(self, data, W, H, **kw)
+        check(self._lib.cmf_pgd_reset(self._h))
+        self._mask_key = None
+
+    def _upload_mask(self, mask):
+        if mask is None:
+            check(self._lib.cmf_set_mask(self._h, None))
+            return
+        halo_r = min(self.L - 1, self.T - self.t1)
+        block = farr(np.asarray(mask)[:, self.t0:self.t1 + halo_r])
+        check(self._lib.cmf_set_mask(self._h, ptr(block)))
+
+    def fit_native(self, *a, **kw):
+        return PGDUpdate.fit_native(self, *a, **kw)
+
+    def iterate(self, *a, **kw):
+        return PGDUpdate.iterate(self, *a, **kw)

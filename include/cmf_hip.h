@@ -146,7 +146,8 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       execute 2.3 instead of 6 contractions plus the loss conv; results differ at rounding level only.
  *       2 = additionally take the loss from <H, denomH> - 2<H, numH> + ||data||^2 (no conv at all; the fp32
  *       cancellation limits its relative accuracy to about 1e-6 / loss^2).  Unsharded handles only.
- *   "conv_kernel" (default 0 = chosen per launch; 2 = 128 x 128 workgroup tiles, 3 = one-wave 64 x 64 tiles) and
+ *   "conv_kernel" (default 0 = chosen per launch; 2 = 128 x 128 workgroup tiles for the launches that only store or only
+ *       sum the loss -- the epilogues that read data and store always take the one-wave kernel; 3 = one-wave 64 x 64 tiles) and
  *   "conv_split" (default 1: the tiles at the end of the one-wave kernel's grid -- a thin last round, and from four
  *       rounds on three more tiles per CU -- are cut into 32 x 32 quarter or 16 x 16 sixteenth tiles; 4 = quarter tiles
  *       only; 0 = whole tiles only): kernel selection of tensor_conv, for measurements.

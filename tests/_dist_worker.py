@@ -42,6 +42,27 @@ def main():
         from shard_protocol_cpu import ProtocolShardedMultUpdate
 
         rule = ProtocolShardedMultUpdate(data, W0, H0, OracleShardEngine, overlap=overlap)
+    elif engine.startswith("hip_pgd"):
+        import cmf_jl_amd as cmf
+        from cmf_jl_amd.sharded import ShardedPGDUpdate
+
+        rule = ShardedPGDUpdate(data, W0, H0, device=int(os.environ.get("LOCAL_RANK", "0")),
+                                transport=os.environ.get("CMF_TEST_TRANSPORT") or None)
+        lf = None
+        if engine.endswith("masked"):
+            lf = cmf.MaskedLoss(cmf.SquareLoss(), (np.random.default_rng(5).uniform(size=data.shape) > 0.25).astype(float))
+        losses = [rule.compute_loss()]
+        for _ in range(iters):
+            rule.update_motifs(loss_func=lf)
+            losses.append(rule.update_feature_maps(loss_func=lf))
+        W, H = rule.download()
+        steps = rule.steps
+        rule.close()
+        if rank == 0:
+            np.savez(out, W=W, H=H, loss_hist=np.asarray(losses), steps=np.asarray(steps), bounds=np.asarray(rule.bounds), info=np.asarray(""))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     else:
         from cmf_jl_amd.sharded import ShardedMultUpdate
 

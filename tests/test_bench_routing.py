@@ -68,3 +68,17 @@ def test_stale_library_is_detected(tmp_path):
     fake.write_bytes(b"\x7fELF....cmf_hip gfx950 0.3.0 abi=3 src=0123456789abcdef\0....")
     assert build.embedded_digest(str(fake)) == "0123456789abcdef" != build.source_digest()
     assert build.embedded_digest(str(tmp_path / "missing.so")) is None
+
+
+def test_no_shipped_kernel_uses_scratch():
+    """Every kernel of the gfx950 code object runs without a private segment and without VGPR spills (SGPR spills to VGPR
+    lanes are allowed: transconv_kernel keeps its set-up scalars there, outside the MFMA loop)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+
+    rows = kernel_resources.kernel_table()
+    assert len(rows) > 60
+    bad = [(r["name"], r["scratch"], r["vgpr_spills"]) for r in rows if r["scratch"] or r["vgpr_spills"]]
+    assert not bad, bad
+    big = {r["name"]: r for r in rows}
+    assert big["void transconv_kernel<20>(TcParams)"]["vgpr"] + big["void transconv_kernel<20>(TcParams)"]["agpr"] <= 512

@@ -647,6 +647,18 @@ def test_config2_full_size_against_oracle(cmf, oracle, config2, reg, iters):
     rule.close()
     np.testing.assert_allclose(l8, lr, rtol=REL_LOSS)
     assert frob_rel(W8, Wr) < REL_FACTORS and frob_rel(H8, Hr) < REL_FACTORS
+    # the optional Gram form (option gram = 1: denomW = (H_unfold H_unfold') W, denomH from the lag-Gram taps of W) at the
+    # same size against the same oracle fit -- unsharded and as the 8-shard group whose all-reduce carries [numW | HH]
+    for devices in (None, [0] * 8):
+        rule = cmf.MultUpdate(data, W0, H0, devices=devices)
+        rule.set_option("gram", 1)
+        lgm = [rule.compute_loss()] + list(rule.iterate(iters, **reg))
+        Wm, Hm = rule.download()
+        rule.close()
+        np.testing.assert_allclose(lgm, lr, rtol=REL_LOSS)
+        assert frob_rel(Wm, Wr) < REL_FACTORS and frob_rel(Hm, Hr) < REL_FACTORS
+        print("  gram=1", "8 shards" if devices else "unsharded", "relW", frob_rel(Wm, Wr), "relH", frob_rel(Hm, Hr),
+              "max rel loss", float(np.max(np.abs(np.asarray(lgm) - lr) / lr)))
 
 
 def test_config4_regularised_full_size(cmf, config2):
@@ -680,6 +692,24 @@ def test_gram_form_matches_oracle(cmf, oracle, N, T, K, L, gram):
     Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=10, check_convergence=False, **reg)
     np.testing.assert_allclose(lg, lr[1:], rtol=REL_LOSS if gram == 1 else 5e-4)
     assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
+
+
+def test_gram_form_100_iterations_config1(cmf, oracle):
+    """BASELINE configs[0] (N=500, T=2000, K=5, L=10) for 100 iterations: the Gram form's rounding-level differences do
+    not drift away from the reference formulation -- loss_hist, W and H stay inside the 1e-4 bar to the end."""
+    data, _, _ = oracle.c_gen_synthetic(N=500, T=2000, K=3, L=20, seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=10, K=5, seed=0)
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=100, check_convergence=False)
+    for gram in (0, 1):
+        rule = cmf.MultUpdate(data, W0, H0)
+        rule.set_option("gram", gram)
+        lg = [rule.compute_loss()] + list(rule.iterate(100))
+        Wg, Hg = rule.download()
+        rule.close()
+        np.testing.assert_allclose(lg, lr, rtol=REL_LOSS)
+        assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
+        print("gram", gram, "after 100 iterations: relW", frob_rel(Wg, Wr), "relH", frob_rel(Hg, Hr),
+              "max rel loss", float(np.max(np.abs(np.asarray(lg) - lr) / lr)))
 
 
 def test_in_loop_kernel_timing(cmf, oracle):
