@@ -109,6 +109,8 @@ struct cmf_handle_s {
     int hals_pullers = 0;                   // persistent H pipeline: puller workgroups per row (0 = stage pipeline)
     int *hals_flags = nullptr;              // its progress flags (device)
     int *hals_status = nullptr;             // pinned host word: 1 = a wait of the persistent pipeline ran out
+    float *hals_snap = nullptr;             // [2][TP][K32]: H and Ht as they were when the persistent sweep started
+    double hals_l1 = 0.0, hals_l2 = 0.0;    // regularisers of the sweep in flight (for a rerun)
     int64_t hals_reruns = 0;                // H sweeps redone on the stage pipeline after such an expiry (cmf_get_counter)
 
     // PGD rule state (pgd.jl:139-154)
@@ -158,7 +160,9 @@ static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss);
 static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg);
 static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg, double *loss);
 static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H);
+static int hals_h_rerun(cmf_handle_s *h);
 static int gram_denom_h(cmf_handle_s *h, float *out);
+static int gram_tables(cmf_handle_s *h);
 static int group_pgd_w(cmf_handle_s *st, struct cmf_group_s *g, double pen_sq, double pen_abs, int nonneg);
 static int group_pgd_h(cmf_handle_s *st, struct cmf_group_s *g, double pen_sq, double pen_abs, int nonneg, double *loss);
 static int group_set_mask(struct cmf_group_s *g, const double *mask);
@@ -278,7 +282,7 @@ static void destroy_impl(cmf_handle_s *h)
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
                       h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3],
-                      h->gram_numden_h, h->pgd_gradH, h->M, h->MT, h->hals_HX, h->hals_cslabs, h->hals_C, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE, h->hals_GWt};
+                      h->gram_numden_h, h->pgd_gradH, h->M, h->MT, h->hals_snap, h->hals_HX, h->hals_cslabs, h->hals_C, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE, h->hals_GWt};
     for (float *p : fbufs)
         if (p) (void)hipFree(p);
     for (int v = 0; v < 2; ++v)
@@ -1048,19 +1052,20 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
     CMFTRY(check_ready(h, true));
     CMFTRY(hals_h_impl(h, l1H, l2H));
     double ss = 0.0;
-    if (h->hals_gram == 1) { // hals.jl:41: norm(resids)/data_norm -- the conv with the loss fused in its epilogue, nothing stored
-        CMFTRY(launch_conv<2>(h, nullptr, h->d.Tl, h->conv_gy));
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, (double *)nullptr);
-        KCHK("loss_reduce_kernel");
-        CMFTRY(read_scalar(h, 0, &ss));
-        h->est_kind = 0;
-    } else {
-        CMFTRY(resid_and_loss(h, &ss)); // ... and the residual kept for the next W phase
-    }
-    if (h->hals_status && *h->hals_status) { // (the stream has been synchronised by the loss read-back)
-        *h->hals_status = 0;
-        return fail(CMF_ERR_HIP, "HALS H pipeline: a wait between its workgroups ran out (is another kernel occupying the device?); "
-                                 "H is partially updated -- set CMF_HALS_PERSIST=0 for the stage pipeline");
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (h->hals_gram == 1) { // hals.jl:41: norm(resids)/data_norm -- the conv with the loss fused in its epilogue, nothing stored
+            CMFTRY(launch_conv<2>(h, nullptr, h->d.Tl, h->conv_gy));
+            hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, (double *)nullptr);
+            KCHK("loss_reduce_kernel");
+            CMFTRY(read_scalar(h, 0, &ss));
+            h->est_kind = 0;
+        } else {
+            CMFTRY(resid_and_loss(h, &ss)); // ... and the residual kept for the next W phase
+        }
+        // (the stream has been synchronised by the loss read-back)  A bounded wait of the persistent H pipeline ran out:
+        // redo the sweep from the snapshot on the stage pipeline and take the loss again; counted in "hals_pipeline_reruns"
+        if (attempt == 0 && h->hals_status && *h->hals_status) CMFTRY(hals_h_rerun(h));
+        else break;
     }
     *loss = std::sqrt(ss) / h->data_norm;
     return CMF_OK;
@@ -1512,7 +1517,7 @@ static int hals_ensure(cmf_handle_s *h)
     if (const char *env = getenv("CMF_HALS_GRAM")) h->hals_gram = (atoi(env) == 1 || atoi(env) == 2) ? atoi(env) : 0; // (tests compare the forms)
     const int E = 2 * d.L - 1;
     CMFTRY(gram_ensure(h));
-    h->hals_TPp = (int)rup(d.Tl, 64) + 256;
+    h->hals_TPp = (int)rup(d.Tl, 64) + (int)std::max<int64_t>(256, rup(d.L, 64) + 128); // (the general row sweep reads a ring of roundup(L, 64) + 64 columns ahead)
     CMFTRY(dalloc_zero(&h->hals_PT, (size_t)d.K32 * h->hals_TPp));
     CMFTRY(dalloc_zero(&h->hals_D, (size_t)d.K32 * h->hals_TPp)); // per row: rows run concurrently
     // Which sweep kernels run (the reference takes any K, L: hals.jl:90-154).  The fast on-chip sweeps have shape limits:
@@ -1537,7 +1542,7 @@ static int hals_ensure(cmf_handle_s *h)
     {   // persistent H pipeline (hals_h_persist_kernel): K sweepers + (K-1) * P pullers, one workgroup per CU, all resident
         const char *env = getenv("CMF_HALS_PERSIST"); // 0 = the stage pipeline (the tests compare the two)
         int P = 0;
-        if (!(env && atoi(env) == 0)) {
+        if (!(env && atoi(env) == 0) && !h->hals_h_general) {
             P = d.K > 1 ? std::min(4, (h->n_cu - d.K) / (d.K - 1)) : 1;
             if (env && atoi(env) > 1) P = std::min(P, atoi(env));
             const size_t lds = ((size_t)(d.K - 1) * (E + 64 + 2 * (d.L - 1)) + 1024) * sizeof(float);
@@ -1562,7 +1567,7 @@ static int compute_hh(cmf_handle_s *h, float *out = nullptr)
 {
     const CmfDims &d = h->d;
     const bool shard = h->sharded && h->T_global != d.Tl; // out = this shard's additive share of HH (hals_hh_kernel)
-    hipLaunchKernelGGL(hals_hx_kernel, dim3(1024), dim3(256), 0, h->stream, h->H, h->hals_HX, d.TP, d.K32, h->hals_NpC);
+    hipLaunchKernelGGL(hals_hx_kernel, dim3(1024), dim3(256), 0, h->stream, h->H, h->hals_HX, d.TP, d.K32, h->hals_NpC, d.PADL, d.Tl);
     KCHK("hals_hx_kernel");
     CMFTRY(launch_hxt_on(h, h->hals_HX, h->hals_HX, h->hals_NpC, 1, h->hals_cslabs, h->hals_nch, h->hals_clen));
     CMFTRY(launch_slab_sum(h, h->hals_C, h->hals_cslabs, hxt_nslabs(h->hals_nch), (size_t)d.L * d.K32 * h->hals_NpC));
@@ -1599,7 +1604,17 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
         CMFTRY(compute_hh(h));
     }
     // the K*L sequential column updates, k outer / lag inner (hals.jl:90-97)
-    const int nq = (d.L * d.K32 + 63) / 64; // <= 32: checked by hals_ensure
+    if (h->hals_w_general) { // L * Kpad beyond the register-resident sweep: one workgroup per unit, the state in LDS
+        const size_t lds_g = (size_t)d.L * d.K32 * sizeof(float);
+        if (lds_g > 64 * 1024) return fail(CMF_ERR_UNSUPPORTED, "HALS W sweep: L * Kpad = %d exceeds the 16384 state entries of a workgroup's LDS", d.L * d.K32);
+        ProfScope prof_(h, PROF_HALS_WSWEEP);
+        hipLaunchKernelGGL(hals_w_sweep_gen_kernel, dim3(d.N), dim3(256), lds_g, h->stream, h->Wt, h->Wn, G, Gsub, h->hals_HH,
+                           d.N, d.K, d.L, d.Np, d.K32, h->hals_NpH, (float)l1W, (float)l2W);
+        KCHK("hals_w_sweep_gen_kernel");
+        h->est_kind = 0;
+        return CMF_OK;
+    }
+    const int nq = (d.L * d.K32 + 63) / 64; // <= 32 here (hals_ensure)
     dim3 grid((d.N + 4 * HALS_NG - 1) / (4 * HALS_NG)), block(256);
     const size_t lds = (size_t)4 * d.K * d.L * HALS_NG * sizeof(float); // <= 64 KB
     ProfScope prof_(h, PROF_HALS_WSWEEP);
@@ -1622,40 +1637,120 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     return CMF_OK;
 }
 
+// P = transconv(W, resid) (hals.jl:152 needs <W_k window, resid window>) = denomH - numH of the MU path:
+// numH = transconv(W, data) is ONE C3 contraction on the data, denomH = transconv(W, conv(W, H)) comes from the lag-Gram
+// taps applied to H (gram_h_kernel) -- no transposed residual, i.e. one conv launch (1 ms) less per iteration, and the
+// H sweep's short recurrences (L-1 columns) do not amplify the cancellation: H stays within the residual form's test
+// bars (1.8e-5 against the fp64 restatement where the residual form has 1.2e-5).  hals_gram = 0: P as one C3 contraction
+// on the transposed residual.  `contract` = false repeats only the last step (P from the slabs that are still there).
+static int hals_h_project(cmf_handle_s *h, bool contract)
+{
+    const CmfDims &d = h->d;
+    const size_t TK = (size_t)d.Tl * d.K32;
+    const bool gram = h->hals_gram && (size_t)d.K32 * (64 + 2 * (d.L - 1)) * sizeof(float) <= 96 * 1024; // (gram_denom_h's LDS window)
+    if (gram) {
+        if (!h->gram_numden_h) CMFTRY(dalloc_zero(&h->gram_numden_h, 2 * TK));
+        if (contract) {
+            CMFTRY(launch_transconv(h, 1, h->XT));
+            CMFTRY(gram_denom_h(h, h->gram_numden_h + TK));
+        }
+        hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, h->gram_numden_h + TK,
+                           h->tc_S1, d.Tl, d.K32, h->hals_TPp);
+    } else {
+        if (contract) {
+            CMFTRY(launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT));
+            CMFTRY(launch_transconv(h, 1, h->estT));
+        }
+        hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, (const float *)nullptr,
+                           h->tc_S1, d.Tl, d.K32, h->hals_TPp);
+    }
+    KCHK("hals_p_init_kernel");
+    return CMF_OK;
+}
+
+static HalsRowParams hals_row_params(cmf_handle_s *h, double l1H, double l2H)
+{
+    const CmfDims &d = h->d;
+    HalsRowParams q;
+    q.PT = h->hals_PT; q.H = h->H; q.Ht = h->Ht; q.D = h->hals_D; q.GW = h->hals_GW; q.GE = h->hals_GE;
+    q.k = 0; q.t_begin = 0; q.t_end = d.Tl;
+    q.Tl = d.Tl; q.L = d.L; q.K32 = d.K32; q.TP = d.TP; q.TPp = h->hals_TPp; q.PADL = d.PADL; q.ne = h->hals_ne; q.t_edge0 = h->hals_t_edge0;
+    q.l1 = (float)l1H; q.l2 = (float)l2H;
+    return q;
+}
+
+// hals.jl:124-125 (k outer, t inner) as a software pipeline over the rows, one launch per stage (hals_h_stage_kernel);
+// the order of every update is the reference's.  No co-residency requirement.
+static int hals_h_sweep_stage(cmf_handle_s *h, const HalsRowParams &q)
+{
+    const CmfDims &d = h->d;
+    HalsStageParams sp;
+    sp.row = q;
+    sp.Dall = h->hals_D;
+    sp.K = d.K; sp.seg = h->hals_seg; sp.nseg = h->hals_nseg;
+    sp.CB = (h->hals_seg + 2 * (d.L - 1) + 255) / 256;
+    const char *lag_env = getenv("CMF_HALS_LAG"); // 3 = the unshifted round-1 schedule (tests compare the two)
+    sp.lag = (lag_env && atoi(lag_env) == 3) ? 3 : 2;
+    sp.skew = sp.lag == 2 ? 128 : 0; // see hals_h_stage_kernel
+    // the last row's last segment, +1 for the pushes of the last sweeps (no-ops for the last row)
+    const int nstages = (d.Tl + sp.skew * (d.K - 1) + h->hals_seg - 1) / h->hals_seg + sp.lag * (d.K - 1) + 1;
+    dim3 grid(d.K + d.K * sp.CB, std::max(1, d.K - 1));
+    if (const char *dbg = getenv("CMF_HALS_DEBUG")) { // timing experiments only (results are wrong): "nopush" launches the sweeps alone
+        if (std::strcmp(dbg, "nopush") == 0) grid = dim3(d.K, 1);
+    }
+    for (int stage = 0; stage < nstages; ++stage) {
+        sp.stage = stage;
+        hipLaunchKernelGGL(hals_h_stage_kernel, grid, dim3(256), 0, h->stream, sp);
+        KCHK("hals_h_stage_kernel");
+    }
+    return CMF_OK;
+}
+
+// Any L (the on-chip sweeps stop at L = 64): row after row, each swept by one wave with its pending window in LDS
+// (hals_h_row_gen_kernel), its changes then added to the later rows' projections (hals_h_push_gen_kernel) -- the literal
+// k outer / t inner order of hals.jl:124-125, 2K launches.
+static int hals_h_sweep_general(cmf_handle_s *h, HalsRowParams q)
+{
+    const CmfDims &d = h->d;
+    const int M = (int)rup(d.L, 64) + 64;
+    const size_t lds = (size_t)(M + d.L) * sizeof(float);
+    if (lds > 64 * 1024) return fail(CMF_ERR_UNSUPPORTED, "HALS H sweep: L = %d exceeds the LDS window of the general row sweep", d.L);
+    for (int k = 0; k < d.K; ++k) {
+        q.k = k;
+        q.D = h->hals_D + (size_t)k * q.TPp;
+        hipLaunchKernelGGL(hals_h_row_gen_kernel, dim3(1), dim3(64), lds, h->stream, q);
+        KCHK("hals_h_row_gen_kernel");
+        if (k + 1 < d.K) {
+            hipLaunchKernelGGL(hals_h_push_gen_kernel, dim3((d.Tl + 255) / 256, d.K - 1 - k), dim3(256), 0, h->stream, h->hals_PT, q.D, h->hals_GW,
+                               h->hals_GE, k, d.Tl, d.L, d.K32, q.TPp, q.ne, q.t_edge0);
+            KCHK("hals_h_push_gen_kernel");
+        }
+    }
+    return CMF_OK;
+}
+
 static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
 {
     const CmfDims &d = h->d;
     CMFTRY(hals_ensure(h));
     // the lag-Gram taps of W (GW, and GE for the truncated windows at the right edge)
-    hipLaunchKernelGGL(hals_pw_kernel, dim3((d.L * d.L + 3) / 4, d.KB * d.KB), dim3(256), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
-    KCHK("hals_pw_kernel");
-    hipLaunchKernelGGL(hals_gw_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_PW, h->hals_GW, h->hals_GE, d.L, d.K32, h->hals_ne, d.Tl, h->hals_t_edge0);
-    KCHK("hals_gw_kernel");
-    // P = transconv(W, resid) (hals.jl:152 needs <W_k window, resid window>) = denomH - numH of the MU path:
-    // numH = transconv(W, data) is ONE C3 contraction on the data, denomH = transconv(W, conv(W, H)) comes from the taps
-    // above applied to H (gram_h_kernel) -- no transposed residual, i.e. one conv launch (1 ms) less per iteration, and the
-    // H sweep's short recurrences (L-1 columns) do not amplify the cancellation: H stays within the residual form's test
-    // bars (1.8e-5 against the fp64 restatement where the residual form has 1.2e-5).  hals_gram = 0: P as one C3 contraction on the
-    // transposed residual.
-    if (h->hals_gram) {
-        const size_t TK = (size_t)d.Tl * d.K32;
-        if (!h->gram_numden_h) CMFTRY(dalloc_zero(&h->gram_numden_h, 2 * TK));
-        CMFTRY(launch_transconv(h, 1, h->XT));
-        CMFTRY(gram_denom_h(h, h->gram_numden_h + TK));
-        hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, h->gram_numden_h + TK,
-                           h->tc_S1, d.Tl, d.K32, h->hals_TPp);
-    } else {
-        CMFTRY(launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT));
-        CMFTRY(launch_transconv(h, 1, h->estT));
-        hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, (const float *)nullptr,
-                           h->tc_S1, d.Tl, d.K32, h->hals_TPp);
+    CMFTRY(gram_tables(h));
+    CMFTRY(hals_h_project(h, true));
+    const HalsRowParams q = hals_row_params(h, l1H, l2H);
+    h->hals_l1 = l1H; h->hals_l2 = l2H;
+    h->est_kind = 0;
+    if (h->hals_h_general) {
+        ProfScope prof_(h, PROF_HALS_PIPE);
+        return hals_h_sweep_general(h, q);
     }
-    KCHK("hals_p_init_kernel");
-    HalsRowParams q;
-    q.PT = h->hals_PT; q.H = h->H; q.Ht = h->Ht; q.D = h->hals_D; q.GW = h->hals_GW; q.GE = h->hals_GE;
-    q.Tl = d.Tl; q.L = d.L; q.K32 = d.K32; q.TP = d.TP; q.TPp = h->hals_TPp; q.PADL = d.PADL; q.ne = h->hals_ne; q.t_edge0 = h->hals_t_edge0;
-    q.l1 = (float)l1H; q.l2 = (float)l2H;
     if (h->hals_pullers > 0) { // the whole sweep as one persistent launch (hals_h_persist_kernel)
+        // Its workgroups wait for each other and every wait is bounded; if one runs out (the grid did not become resident:
+        // another process or stream holds CUs) the sweep is redone from this snapshot on the stage pipeline
+        // (cmf_hals_update_feature_maps looks at the status word once the stream has drained).
+        const size_t nH = (size_t)d.TP * d.K32;
+        if (!h->hals_snap) CMFTRY(dalloc_zero(&h->hals_snap, 2 * nH));
+        HIPCHK(hipMemcpyAsync(h->hals_snap, h->H, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->hals_snap + nH, h->Ht, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         HalsPersistParams pp;
         pp.row = q;
         pp.Dall = h->hals_D;
@@ -1695,33 +1790,27 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
                 fclose(f);
             }
         }
-        h->est_kind = 0;
         return CMF_OK;
     }
-    // hals.jl:124-125: k outer, t inner, as a software pipeline over the rows: one launch per stage
-    // (see hals_h_stage_kernel); the order of every update is the reference's.
-    HalsStageParams sp;
-    sp.row = q;
-    sp.Dall = h->hals_D;
-    sp.K = d.K; sp.seg = h->hals_seg; sp.nseg = h->hals_nseg;
-    sp.CB = (h->hals_seg + 2 * (d.L - 1) + 255) / 256;
-    const char *lag_env = getenv("CMF_HALS_LAG"); // 3 = the unshifted round-1 schedule (tests compare the two)
-    sp.lag = (lag_env && atoi(lag_env) == 3) ? 3 : 2;
-    sp.skew = sp.lag == 2 ? 128 : 0; // see hals_h_stage_kernel
-    // the last row's last segment, +1 for the pushes of the last sweeps (no-ops for the last row)
-    const int nstages = (d.Tl + sp.skew * (d.K - 1) + h->hals_seg - 1) / h->hals_seg + sp.lag * (d.K - 1) + 1;
-    dim3 grid(d.K + d.K * sp.CB, std::max(1, d.K - 1));
-    if (const char *dbg = getenv("CMF_HALS_DEBUG")) { // timing experiments only (results are wrong): "nopush" launches the sweeps alone
-        if (std::strcmp(dbg, "nopush") == 0) grid = dim3(d.K, 1);
-    }
     ProfScope prof_(h, PROF_HALS_PIPE); // the whole row pipeline (nstages launches) as one timed span
-    for (int stage = 0; stage < nstages; ++stage) {
-        sp.stage = stage;
-        hipLaunchKernelGGL(hals_h_stage_kernel, grid, dim3(256), 0, h->stream, sp);
-        KCHK("hals_h_stage_kernel");
-    }
+    return hals_h_sweep_stage(h, q);
+}
+
+// The persistent pipeline reported an expired wait (status word; the stream has drained): H and P hold a half-finished
+// sweep.  Restore H from the snapshot, rebuild P from the contractions that are still in place, and run the sweep on the
+// stage pipeline, which needs no co-residency.  The handle keeps to the stage pipeline from here on.
+static int hals_h_rerun(cmf_handle_s *h)
+{
+    const CmfDims &d = h->d;
+    const size_t nH = (size_t)d.TP * d.K32;
+    *h->hals_status = 0;
+    h->hals_pullers = 0;
+    h->hals_reruns += 1;
+    HIPCHK(hipMemcpyAsync(h->H, h->hals_snap, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->Ht, h->hals_snap + nH, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    CMFTRY(hals_h_project(h, false));
     h->est_kind = 0;
-    return CMF_OK;
+    return hals_h_sweep_stage(h, hals_row_params(h, h->hals_l1, h->hals_l2));
 }
 
 // ---- optional Gram form of the MU iteration ----------------------------------

@@ -1546,13 +1546,15 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial,
 // operand: K32 columns (padded to 128) instead of the L*K32 columns of a materialised H_unfold' -- a fifth of the MFMA
 // work of round 1's form at K = 32, L = 20, and no 128 MB H_unfold' to build.
 // HX[r][c] = c < K32 ? H[r][c] : 0 : H in the row pitch hxt wants for its X operand.   grid-stride over TP * K32
-__global__ void hals_hx_kernel(const float *H, float *HX, int TP, int K32, int NpC)
+// Only the handle's own rows [PADL, PADL + Tl) are copied: as the X operand the rows behind them must read as zero (the
+// C2 kernel rounds its time chunks up past Tl), and on a shard those rows of H hold the right neighbour's halo.
+__global__ void hals_hx_kernel(const float *H, float *HX, int TP, int K32, int NpC, int PADL, int Tl)
 {
     const size_t total = (size_t)TP * K32;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const size_t r = idx / K32;
         const int c = (int)(idx - r * K32);
-        HX[r * NpC + c] = H[idx];
+        HX[r * NpC + c] = ((int)r >= PADL && (int)r < PADL + Tl) ? H[idx] : 0.f;
     }
 }
 // HH[(l*K32+k) * NpH + l'*K32+k'] from C [L][K32][NpC] and the last columns of H ([TP][K32]).  One thread per entry.
@@ -2429,6 +2431,120 @@ __global__ __launch_bounds__(1024) void hals_h_persist_kernel(HalsPersistParams 
             if (st && lane == 0) st[3] = __builtin_amdgcn_s_memrealtime();
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// General sweeps: the same recurrences in the same order for shapes beyond the on-chip sweeps' limits (the reference
+// takes any K, L: hals.jl:90-154; its own micro-benchmark runs L = 100, notebooks/benchmarks.ipynb cell 2).  Slower --
+// state in LDS / memory instead of registers and wave lanes -- and without a shape limit of their own.
+// ---------------------------------------------------------------------------------------------
+
+// W sweep for any L * Kpad: ONE workgroup per unit n, the unit's projected state g[j] (j over the L*K32 columns of
+// H_unfold) in LDS.  Step (k, l) -- k outer, lag inner, hals.jl:90-97 -- reads g[j] and the diagonal HH[j][j], forms the
+// new w (hals.jl:104-110) in every thread, and adds (w_new - w_old) * HH[j][j'] to the entries j' that later steps of
+// this sweep still read (the HH row comes from L2: all N workgroups walk the same rows).
+// grid N, block 256, dynamic LDS: L*K32 floats.
+__global__ __launch_bounds__(256) void hals_w_sweep_gen_kernel(float *Wt, float *Wn, const float *G, const float *Gsub, const float *HH,
+                                                                int N, int K, int L, int Np, int K32, int NpH, float l1, float l2)
+{
+    extern __shared__ float gen_g[];
+    const int tid = threadIdx.x, n = blockIdx.x;
+    const int LK = L * K32;
+    for (int j = tid; j < LK; j += 256) {
+        const size_t at = (size_t)j * Np + n;
+        gen_g[j] = Gsub ? G[at] - Gsub[at] : G[at];
+    }
+    __syncthreads();
+    for (int k = 0; k < K; ++k)
+        for (int l = 0; l < L; ++l) {
+            const int j = l * K32 + k;
+            const float hjj = HH[(size_t)j * NpH + j];
+            const float w_old = Wt[(size_t)j * Np + n];
+            const float v = gen_g[j] - w_old * hjj;                       // hals.jl:104 projected
+            const float w_new = fmaxf((-v - l1) / (hjj + CMF_EPS_F + l2), 0.f); // hals.jl:110
+            const float d = w_new - w_old;
+            __syncthreads(); // everyone has read g[j] (and this thread's Wt value) before the row update touches them
+            const float *row = HH + (size_t)j * NpH;
+            for (int jp = tid; jp < LK; jp += 256) gen_g[jp] = fmaf(d, row[jp], gen_g[jp]); // hals.jl:106
+            if (tid == 0) {
+                Wt[(size_t)j * Np + n] = w_new;
+                Wn[((size_t)l * Np + n) * K32 + k] = w_new;
+            }
+            __syncthreads();
+        }
+}
+
+// H sweep of ONE row k for any L: one wave walks the row column by column (hals.jl:121-148); the pending values of the
+// columns [t, t + L) live in an LDS ring of M = roundup(L, 64) + 64 entries that is refilled 64 columns at a time from PT
+// (zero-padded behind Tl), H_old comes in blocks of 64 through a register.  A step: x from the pending value, the same-row
+// pushes P[k][t + e] += (x - h_old) * taps[e], e = 1 .. Lt - 1 (full-window taps GW[k][k], or the edge column's own GE).
+// Writes H (both layouts) and the per-column change D[t]; the cross-row terms follow in hals_h_push_gen_kernel.
+// grid 1, block 64, dynamic LDS: (M + L) floats.
+__global__ __launch_bounds__(64) void hals_h_row_gen_kernel(HalsRowParams q)
+{
+    extern __shared__ float gen_ring[];
+    const int lane = threadIdx.x;
+    const int L = q.L, E = 2 * L - 1, k = q.k;
+    const int M = ((L + 63) / 64) * 64 + 64;
+    float *ring = gen_ring, *taps = gen_ring + M;
+    float *Prow = q.PT + (size_t)k * q.TPp;
+    float *Hrow = q.Ht + (size_t)k * q.TP + q.PADL;
+    const float *gk = q.GW + ((size_t)k * q.K32 + k) * E + (L - 1);
+    for (int e = lane; e < L; e += 64) taps[e] = gk[e];
+    for (int c = lane; c < M; c += 64) ring[c] = Prow[c]; // columns [0, M)
+    __syncthreads(); // (one wave: an LDS fence between its lanes)
+    const float nrm_full = taps[0];
+    for (int tb = 0; tb < q.Tl; tb += 64) {
+        if (tb > 0) { // columns [tb + M - 64, tb + M): not yet reached by any same-row push (they reach t + L - 1 < tb + M - 64)
+            ring[(tb + M - 64 + lane) % M] = Prow[tb + M - 64 + lane];
+            __syncthreads();
+        }
+        const float hreg = (tb + lane < q.Tl) ? Hrow[tb + lane] : 0.f;
+        float hnew = 0.f, dreg = 0.f;
+        const int tend = (tb + 64 < q.Tl) ? tb + 64 : q.Tl;
+        for (int t = tb; t < tend; ++t) {
+            const float s_h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg), t - tb));
+            const float s_p = ring[t % M];
+            float nrm = nrm_full;
+            int Lt = L;
+            const float *ge = nullptr;
+            if (t >= q.t_edge0) { // truncated window (hals.jl:136): the column's own norm and taps
+                ge = q.GE + (((size_t)k * q.ne + (t - q.t_edge0)) * q.K32 + k) * E + (L - 1);
+                nrm = ge[0];
+                Lt = q.Tl - t;
+            }
+            const float x = fmaxf((s_h * nrm - s_p - q.l1) / (nrm + CMF_EPS_F + q.l2), 0.f); // hals.jl:152-153
+            const float d = x - s_h;
+            for (int e = 1 + lane; e < Lt; e += 64) ring[(t + e) % M] = fmaf(d, ge ? ge[e] : taps[e], ring[(t + e) % M]); // hals.jl:146
+            __syncthreads(); // the next column's pending value may have been written by another lane
+            if (lane == t - tb) { hnew = x; dreg = d; }
+        }
+        if (tb + lane < q.Tl) {
+            Hrow[tb + lane] = hnew;
+            q.H[(size_t)(q.PADL + tb + lane) * q.K32 + k] = hnew;
+            q.D[tb + lane] = dreg;
+        }
+    }
+}
+
+// Cross-row terms of row k's changes for any L: PT[kp][tp] += sum_e D[tp - e] * taps(tp - e)[k][kp][e], kp > k
+// (hals.jl:146 for the other components; source columns in the right edge use their own taps GE).
+// grid (ceil(Tl / 256), K - 1 - k), block 256: blockIdx.y -> kp = k + 1 + blockIdx.y
+__global__ __launch_bounds__(256) void hals_h_push_gen_kernel(float *PT, const float *D, const float *GW, const float *GE,
+                                                               int k, int Tl, int L, int K32, int TPp, int ne, int t_edge0)
+{
+    const int tp = blockIdx.x * 256 + threadIdx.x, kp = k + 1 + blockIdx.y;
+    if (tp >= Tl) return;
+    const int E = 2 * L - 1;
+    const float *gw = GW + ((size_t)k * K32 + kp) * E + (L - 1);
+    float s = 0.f;
+    for (int e = -(L - 1); e <= L - 1; ++e) {
+        const int t = tp - e;
+        if (t < 0 || t >= Tl) continue;
+        const float tap = (t < t_edge0) ? gw[e] : GE[(((size_t)k * ne + (t - t_edge0)) * K32 + kp) * E + (L - 1) + e];
+        s = fmaf(D[t], tap, s);
+    }
+    PT[(size_t)kp * TPp + tp] += s;
 }
 
 // =============================================================================================

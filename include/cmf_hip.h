@@ -212,14 +212,17 @@ int cmf_iterate(cmf_handle h, int64_t n_iter, int eval_mode, double l1W, double 
  * on the same handle (the HALSUpdate constructor, hals.jl:18-28, needs nothing beyond cmf_create +
  * cmf_set_factors: the residual it carries is est - data, kept implicitly).  Same Gauss-Seidel visiting
  * order as the reference; clamp at 0 and "+ l2" regularisation as in hals.jl:110,153.
- * Unsharded handles only (the H sweep is sequential along T).  Shape limits of the on-chip sweeps (the reference
- * has none): L <= 64, L * Kpad <= 2048 and K * L <= 2048 (Kpad = K rounded up to 32); cmf_set_option(h, "hals_prepare", 1)
- * allocates the rule's scratch and reports a violation at construction time instead of at the first update.
+ * Unsharded handles only (the H sweep is sequential along T).  Any K, L the reference accepts runs: the fast on-chip
+ * sweeps cover L <= 64 (H) and L * Kpad <= 2048, K * L <= 2048 (W; Kpad = K rounded up to 32); beyond them general sweeps
+ * run the same recurrences in the same order with their state in LDS (slower; up to L * Kpad = 16384).
+ * cmf_set_option(h, "hals_prepare", 1) allocates the rule's scratch at construction time instead of at the first update.
  * The H sweep normally runs as one persistent launch whose workgroups (a sweeper per row of H, puller workgroups that
  * apply the cross-row terms) wait for each other through flags in device memory.  It needs the device to itself for
- * those ~2 ms: every such wait is bounded (about half a second), and if one runs out -- another process or stream holding
- * the CUs -- cmf_hals_update_feature_maps returns CMF_ERR_HIP with H partially updated (set the factors again).
- * Environment CMF_HALS_PERSIST=0 selects the one-launch-per-stage pipeline instead, which has no such requirement. */
+ * those ~2 ms: every such wait is bounded (about two seconds), and if one runs out -- another process or stream holding
+ * the CUs -- cmf_hals_update_feature_maps restores H from the snapshot taken at the start of the sweep, redoes the sweep
+ * with one launch per pipeline stage (no co-residency needed; the handle keeps to that form afterwards) and returns
+ * CMF_OK; cmf_get_counter(h, "hals_pipeline_reruns") counts these events.
+ * Environment CMF_HALS_PERSIST=0 selects the one-launch-per-stage pipeline from the start. */
 int cmf_hals_update_motifs(cmf_handle h, double l1W, double l2W);
 int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss);
 

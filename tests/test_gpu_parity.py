@@ -370,15 +370,59 @@ def test_hals_single_iteration(cmf, oracle, N, T, K, L, reg, form):
     assert Wg.min() >= 0.0 and Hg.min() >= 0.0   # clamp at 0, not eps (hals.jl:110,153)
 
 
-def test_hals_shape_limits_reported_at_construction(cmf):
-    """The on-chip sweeps have shape limits the reference does not (L <= 64, L * Kpad <= 2048): the rule constructor
-    reports them (CMF_ERR_UNSUPPORTED), not the first update after the contractions have already run."""
-    rng = np.random.default_rng(0)
-    for K, L, N, T in ((3, 70, 8, 200), (64, 40, 8, 200)):
-        with pytest.raises(cmf.CMFError) as ei:
-            cmf.HALSUpdate(rng.random((N, T)), rng.random((K, N, L)), rng.random((K, T)))
-        assert ei.value.code == 4 and "HALS path supports" in str(ei.value)
-    cmf.HALSUpdate(rng.random((8, 200)), rng.random((64, 8, 32)), rng.random((64, 200))).close()  # exactly 2048: fine
+@pytest.mark.parametrize("N,T,K,L", [(150, 1000, 15, 100),   # the reference's own micro-benchmark shape (notebooks/benchmarks.ipynb cell 2): L > 64
+                                     (96, 700, 64, 40),      # L * Kpad = 2560 > 2048: general W sweep, on-chip H sweep
+                                     (40, 300, 3, 70),       # L just past the wave-wide window
+                                     (30, 50, 4, 80)])       # T < L: every column of H is an edge column
+@pytest.mark.parametrize("reg", [dict(), dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2)])
+def test_hals_shapes_beyond_the_on_chip_sweeps(cmf, oracle, N, T, K, L, reg):
+    """hals.jl:90-154 has no shape limits; the fast sweeps do (L <= 64 for H, L * Kpad <= 2048 for W).  Beyond them the
+    general sweeps run -- same recurrences, same Gauss-Seidel order, state in LDS: two iterations against the oracle."""
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=20, seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    rule = cmf.HALSUpdate(data, W0, H0)
+    losses = []
+    for _ in range(2):
+        rule.update_motifs(l1W=reg.get("l1W", 0), l2W=reg.get("l2W", 0))
+        losses.append(rule.update_feature_maps(l1H=reg.get("l1H", 0), l2H=reg.get("l2H", 0)))
+    Wg, Hg = rule.download()
+    rule.close()
+    Wr, Hr, lh, _ = oracle.c_fit_hals(data, W0, H0, max_itr=2, check_convergence=False, **reg)
+    print((N, T, K, L), frob_rel(Wg, Wr), frob_rel(Hg, Hr), np.abs(np.asarray(losses) - lh[1:]) / lh[1:])
+    np.testing.assert_allclose(losses, lh[1:], rtol=REL_LOSS)
+    assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
+    assert Wg.min() >= 0.0 and Hg.min() >= 0.0
+
+
+@pytest.mark.parametrize("N,T,K,L", [(96, 700, 5, 10), (130, 900, 32, 20), (37, 150, 33, 7), (64, 100, 4, 33)])
+def test_hals_general_sweeps_agree_with_the_on_chip_sweeps(cmf, oracle, N, T, K, L):
+    """The general sweeps forced (CMF_HALS_GENERAL) at shapes the on-chip sweeps cover: same order of updates, so the two
+    agree to rounding; both against the oracle."""
+    import os
+
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=3)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=1)
+    reg = dict(l1W=0.05, l2W=0.1, l1H=0.05, l2H=0.1)
+    out = {}
+    for general in ("0", "3"):
+        os.environ["CMF_HALS_GENERAL"] = general
+        try:
+            rule = cmf.HALSUpdate(data, W0, H0)
+        finally:
+            os.environ.pop("CMF_HALS_GENERAL", None)
+        ls = []
+        for _ in range(3):
+            rule.update_motifs(l1W=reg["l1W"], l2W=reg["l2W"])
+            ls.append(rule.update_feature_maps(l1H=reg["l1H"], l2H=reg["l2H"]))
+        out[general] = (np.asarray(ls),) + rule.download()
+        rule.close()
+    Wr, Hr, lh, _ = oracle.c_fit_hals(data, W0, H0, max_itr=3, check_convergence=False, **reg)
+    for general in ("0", "3"):
+        ls, W, H = out[general]
+        np.testing.assert_allclose(ls, lh[1:], rtol=REL_LOSS)
+        assert frob_rel(W, Wr) < REL_FACTORS and frob_rel(H, Hr) < REL_FACTORS
+    np.testing.assert_allclose(out["0"][0], out["3"][0], rtol=2e-5)
+    assert frob_rel(out["3"][1], out["0"][1]) < 5e-5 and frob_rel(out["3"][2], out["0"][2]) < 5e-5
 
 
 def test_hals_fit_against_oracle(cmf, oracle):
@@ -876,23 +920,35 @@ def test_medium_sizes_two_iterations(cmf, oracle, N, T, K, L):
 
 def test_hals_persistent_pipeline_waits_are_bounded(cmf, oracle):
     """The persistent H pipeline's workgroups wait for each other through flags in memory; a wait that is never satisfied
-    (here: the puller workgroups leave without doing their work, CMF_HALS_DEBUG=stall) must run out, drain the grid and
-    come back as an error -- not hang the device -- and the handle must stay usable."""
+    (here: the puller workgroups leave without doing their work, CMF_HALS_DEBUG=stall) must run out and drain the grid --
+    not hang the device -- and the call must still deliver the sweep: H is restored from the snapshot taken at its start,
+    the sweep is redone on the stage pipeline, the event is counted, the result is the oracle's."""
     import os
 
     data, _, _ = oracle.c_gen_synthetic(N=40, T=600, K=3, L=8, seed=5)
     W0, H0 = oracle.c_init_rand(data, L=8, K=4, seed=2)
+    ref = cmf.HALSUpdate(data, W0, H0)
+    ref.update_motifs()
+    loss_ref = ref.update_feature_maps()
+    Wref, Href = ref.download()
+    ref.close()
     rule = cmf.HALSUpdate(data, W0, H0)
+    assert rule.counter("hals_pipeline_reruns") == 0
     rule.update_motifs()
     os.environ["CMF_HALS_DEBUG"] = "stall"
     try:
-        with pytest.raises(cmf.CMFError, match="HALS H pipeline"):
-            rule.update_feature_maps()
+        loss = rule.update_feature_maps()
     finally:
         os.environ.pop("CMF_HALS_DEBUG", None)
-    rule.upload(W0, H0)  # H was left partially updated: start again from the same factors
-    rule.update_motifs()
-    loss = rule.update_feature_maps()
-    _, _, lh, _ = oracle.c_fit_hals(data, W0, H0, max_itr=1, check_convergence=False)
+    assert rule.counter("hals_pipeline_reruns") == 1
+    Wg, Hg = rule.download()
+    _, _, lh, _ = oracle.c_fit_hals(data, W0, H0, max_itr=2, check_convergence=False)
     assert abs(loss - lh[1]) <= 1e-4 * lh[1]
+    # the stage pipeline performs the same updates in the same order as the persistent one
+    assert abs(loss - loss_ref) <= 1e-6 * loss_ref and frob_rel(Hg, Href) < 1e-6 and frob_rel(Wg, Wref) == 0.0
+    # the handle stays usable (and keeps to the stage pipeline): a second iteration matches the oracle too
+    rule.update_motifs()
+    loss2 = rule.update_feature_maps()
+    assert rule.counter("hals_pipeline_reruns") == 1
+    assert abs(loss2 - lh[2]) <= 1e-4 * lh[2]
     rule.close()

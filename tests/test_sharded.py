@@ -219,7 +219,7 @@ def test_group_errors():
     assert ei.value.code == _lib.CMF_ERR_UNSUPPORTED
     rule = cmf.MultUpdate(data, W, H, devices=[0, 0])
     with pytest.raises(cmf.CMFError):
-        rule.set_option("gram", 1)  # the Gram form does not shard
+        rule.set_option("gram", 2)  # the Gram-sum loss is not available on groups (gram = 1 is: tests/test_group_rules.py)
     lib = cmf.load_library()
     import ctypes
 
