@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcmf_hip.so")
 
 CMF_OK, CMF_ERR_ARG, CMF_ERR_HIP, CMF_ERR_STATE, CMF_ERR_UNSUPPORTED, CMF_ERR_COMM = 0, 1, 2, 3, 4, 5
-CMF_COMM_AUTO, CMF_COMM_RCCL, CMF_COMM_LOOPBACK = 0, 1, 2
+CMF_COMM_AUTO, CMF_COMM_RCCL, CMF_COMM_LOOPBACK, CMF_COMM_LOOPBACK_STREAMS = 0, 1, 2, 3
 ABI_VERSION = 3  # CMF_ABI_VERSION of include/cmf_hip.h
 
 # host-collective callbacks of cmf_comm_init_callbacks (include/cmf_hip.h)

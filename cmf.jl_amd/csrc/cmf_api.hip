@@ -1292,7 +1292,7 @@ int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transpor
     int tr;
     if (transport == CMF_COMM_AUTO) tr = (ndev > 1 && distinct) ? CMF_TR_RCCL : CMF_TR_LOOPBACK;
     else if (transport == CMF_COMM_RCCL) tr = CMF_TR_RCCL;
-    else if (transport == CMF_COMM_LOOPBACK) tr = CMF_TR_LOOPBACK;
+    else if (transport == CMF_COMM_LOOPBACK || transport == CMF_COMM_LOOPBACK_STREAMS) tr = CMF_TR_LOOPBACK;
     else return fail(CMF_ERR_ARG, "unknown transport %d", transport);
     if (tr == CMF_TR_RCCL && !distinct) return fail(CMF_ERR_ARG, "RCCL needs distinct devices (a device is listed twice)");
     if (tr == CMF_TR_LOOPBACK && !all_same) return fail(CMF_ERR_ARG, "the loopback transport needs all shards on one device; list distinct devices for RCCL");
@@ -1325,7 +1325,9 @@ int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transpor
         rc = group_prepare_shard(s);
         if (rc != CMF_OK) return bail(rc);
     }
-    if (tr == CMF_TR_LOOPBACK) // one device: every shard works on shard 0's streams, so the kernels of the loopback collectives are ordered
+    // CMF_LOOPBACK_STREAMS=1 turns every loopback group of the process into the stream-per-shard form (tests)
+    g->loop_ms = tr == CMF_TR_LOOPBACK && (transport == CMF_COMM_LOOPBACK_STREAMS || (getenv("CMF_LOOPBACK_STREAMS") && atoi(getenv("CMF_LOOPBACK_STREAMS")) == 1));
+    if (tr == CMF_TR_LOOPBACK && !g->loop_ms) // one device: every shard works on shard 0's streams, so the kernels of the loopback collectives are ordered
         for (cmf_handle_s *s : g->sh) { s->stream = g->sh[0]->stream; s->comm_stream = g->sh[0]->comm_stream; }
     if (tr == CMF_TR_RCCL) {
         int rc = rccl_load();
@@ -1429,7 +1431,8 @@ int cmf_comm_info(cmf_handle h, char *buf, int64_t len)
             snprintf(tmp, sizeof(tmp), "transport=rccl version=%d lib=%s nranks=%d local=%zu ranks=%s overlap=%d", v, g_rccl.path.c_str(),
                      g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap);
         } else {
-            snprintf(tmp, sizeof(tmp), "transport=%s nranks=%d local=%zu ranks=%s overlap=%d", g->transport == CMF_TR_LOOPBACK ? "loopback" : "callbacks",
+            snprintf(tmp, sizeof(tmp), "transport=%s nranks=%d local=%zu ranks=%s overlap=%d",
+                     g->transport == CMF_TR_LOOPBACK ? (g->loop_ms ? "loopback-streams" : "loopback") : "callbacks",
                      g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap);
         }
     }

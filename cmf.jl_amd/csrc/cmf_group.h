@@ -133,6 +133,12 @@ struct cmf_group_s {
     bool overlap = false;                // option "allreduce_overlap": numW contracted + all-reduced under the loss conv
     bool num_ready = false;              // overlap form: the numW half belongs to the current H and is reduced (or in flight)
     bool halos_current = false;
+    // loopback with one stream PER SHARD (CMF_COMM_LOOPBACK_STREAMS): the collectives keep RCCL's stream semantics -- the
+    // operation starts when every shard's stream has reached it and every shard's stream continues when it is done --
+    // through events, so a missing dependency between shards cannot hide behind a shared stream (tests on a one-GPU box)
+    bool loop_ms = false;
+    hipEvent_t ev_in[2][CMF_MAX_LOCAL] = {};  // [main | comm stream][shard]
+    hipEvent_t ev_out[2] = {nullptr, nullptr};
 };
 
 static void group_partition(int64_t T, int R, int64_t L, std::vector<int64_t> &t0, std::vector<int64_t> &t1)
@@ -204,6 +210,28 @@ static int group_cb_stage(cmf_group_s *g, size_t elems)
     return CMF_OK;
 }
 
+// loopback with a stream per shard: the collective kernel runs on shard 0's stream once every shard's stream has arrived
+// (c = 0: the main streams, 1: the communication streams of the overlap form) ...
+static int loopback_arrive(cmf_group_s *g, int c)
+{
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        if (!g->ev_in[c][i]) HIPCHK(hipEventCreateWithFlags(&g->ev_in[c][i], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(g->ev_in[c][i], c ? g->sh[i]->comm_stream : g->sh[i]->stream));
+    }
+    hipStream_t s0 = c ? g->sh[0]->comm_stream : g->sh[0]->stream;
+    for (size_t i = 1; i < g->sh.size(); ++i) HIPCHK(hipStreamWaitEvent(s0, g->ev_in[c][i], 0));
+    return CMF_OK;
+}
+// ... and every other shard's stream goes on when it has finished
+static int loopback_depart(cmf_group_s *g, int c)
+{
+    hipStream_t s0 = c ? g->sh[0]->comm_stream : g->sh[0]->stream;
+    if (!g->ev_out[c]) HIPCHK(hipEventCreateWithFlags(&g->ev_out[c], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(g->ev_out[c], s0));
+    for (size_t i = 1; i < g->sh.size(); ++i) HIPCHK(hipStreamWaitEvent(c ? g->sh[i]->comm_stream : g->sh[i]->stream, g->ev_out[c], 0));
+    return CMF_OK;
+}
+
 // In-place sum over all ranks of `count` floats at offset `off` of every local shard's buffer `bufs[i]`, ordered on
 // `streams[i]`.
 static int group_allreduce(cmf_group_s *g, const std::vector<float *> &bufs, size_t off, size_t count, bool on_comm_stream = false)
@@ -221,13 +249,16 @@ static int group_allreduce(cmf_group_s *g, const std::vector<float *> &bufs, siz
         if (nl > 1) RCCLCHK(g_rccl.GroupEnd());
         return CMF_OK;
     }
-    case CMF_TR_LOOPBACK: { // all shards share one device and one stream
+    case CMF_TR_LOOPBACK: { // all shards share one device (and, unless loop_ms, one stream)
         CmfPtrTable tab;
         for (size_t i = 0; i < nl; ++i) tab.p[i] = bufs[i] + off;
         CMFTRY(group_use(g->sh[0]));
+        const int c = on_comm_stream ? 1 : 0;
+        if (g->loop_ms) CMFTRY(loopback_arrive(g, c));
         const int blocks = (int)std::min<size_t>(2048, (count + 255) / 256);
         hipLaunchKernelGGL(loopback_allreduce_kernel, dim3(blocks), dim3(256), 0, stream_of(0), tab, (int)nl, count);
         KCHK("loopback_allreduce_kernel");
+        if (g->loop_ms) CMFTRY(loopback_depart(g, c));
         return CMF_OK;
     }
     default: { // host callbacks: one local shard
@@ -263,9 +294,11 @@ static int group_allgather(cmf_group_s *g, const std::vector<float *> &send, siz
         CmfPtrTable ts, tr;
         for (size_t i = 0; i < nl; ++i) { ts.p[i] = send[i] + send_off; tr.p[i] = recv[i]; }
         CMFTRY(group_use(g->sh[0]));
+        if (g->loop_ms) CMFTRY(loopback_arrive(g, 0));
         const int blocks = (int)std::min<size_t>(64, (nl * count + 255) / 256);
         hipLaunchKernelGGL(loopback_allgather_kernel, dim3(blocks), dim3(256), 0, g->sh[0]->stream, ts, tr, (int)nl, (int)count);
         KCHK("loopback_allgather_kernel");
+        if (g->loop_ms) CMFTRY(loopback_depart(g, 0));
         return CMF_OK;
     }
     default: {
@@ -610,6 +643,11 @@ static void group_destroy(cmf_group_s *g)
     }
     if (g->h_tail) (void)hipHostFree(g->h_tail);
     if (g->cb_host) (void)hipHostFree(g->cb_host);
+    for (int c = 0; c < 2; ++c) {
+        for (hipEvent_t e : g->ev_in[c])
+            if (e) (void)hipEventDestroy(e);
+        if (g->ev_out[c]) (void)hipEventDestroy(g->ev_out[c]);
+    }
     delete g;
 }
 

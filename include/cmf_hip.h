@@ -98,6 +98,9 @@ int cmf_create_shard(cmf_handle *h, int device, int64_t N, int64_t T_local, int6
 #define CMF_COMM_AUTO 0
 #define CMF_COMM_RCCL 1
 #define CMF_COMM_LOOPBACK 2
+#define CMF_COMM_LOOPBACK_STREAMS 3 /* loopback with a stream per shard: the collectives keep RCCL's stream semantics (start when
+                                       every shard's stream has arrived, every shard's stream continues when done) through
+                                       events, so a missing dependency between shards cannot hide behind a shared stream */
 int cmf_create_multi(cmf_handle *h, int ndev, const int *devices, int transport,
                      int64_t N, int64_t T, int64_t K, int64_t L, const double *data);
 

@@ -14,13 +14,19 @@ def main():
     dist.init_process_group("gloo")
     import cmf_jl_amd as cmf
 
-    data = cmf.gen_synthetic(N=40, T=300, seed=1234)
-    res = cmf.parameter_sweep(data, L_vals=(5, 8), K_vals=(2, 3), alg_vals=(":mult",), max_itr=6, seed=0,
-                              check_convergence=False, device=0)
+    # replicas: rank r fits on GPU r when the box has one per rank, else the ranks share GPU 0
+    ndev = cmf.load_library().cmf_device_count()
+    device = dist.get_rank() if ndev >= dist.get_world_size() else 0
+    data = cmf.gen_synthetic(N=40, T=300, seed=1234, device=device)
+    algs = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else (":mult",)
+    res = cmf.parameter_sweep(data, L_vals=(5, 8), K_vals=(2, 3), alg_vals=algs, max_itr=6, seed=0,
+                              check_convergence=False, device=device)
     if dist.get_rank() == 0:
-        np.savez(sys.argv[1], keys=np.array([[L, K] for (L, K, _) in res]),
-                 **{f"loss_{L}_{K}": r.loss_hist for (L, K, _), r in res.items()},
-                 **{f"W_{L}_{K}": r.W for (L, K, _), r in res.items()})
+        tag = lambda L, K, a: f"{L}_{K}_{a.lstrip(':')}"  # noqa: E731
+        np.savez(sys.argv[1], keys=np.array([tag(L, K, a) for (L, K, a) in res]), device=np.asarray(device),
+                 **{f"loss_{tag(L, K, a)}": r.loss_hist for (L, K, a), r in res.items()},
+                 **{f"W_{tag(L, K, a)}": r.W for (L, K, a), r in res.items()},
+                 **{f"H_{tag(L, K, a)}": r.H for (L, K, a), r in res.items()})
     dist.barrier()
     dist.destroy_process_group()
 

@@ -217,3 +217,79 @@ def test_sharded_processes_pgd(oracle, tmp_path, world, masked):
     np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
     assert frob_rel(got["W"], Wr) < 1e-4 and frob_rel(got["H"], Hr) < 1e-4
     np.testing.assert_allclose(got["steps"], sr, rtol=1e-12)
+
+
+# ---- a stream per shard: RCCL's stream semantics on one GPU ----------------------------------------------------------
+@pytest.mark.parametrize("R,N,T,K,L,reg,overlap,gram", [(2, 130, 900, 32, 20, 0, False, 0), (4, 70, 517, 32, 20, 1, True, 0), (3, 40, 333, 5, 10, 1, False, 1),
+                                                         (8, 96, 1100, 32, 20, 0, True, 1), (8, 96, 700, 32, 20, 0, False, 0)])
+def test_group_with_a_stream_per_shard(cmf, oracle, R, N, T, K, L, reg, overlap, gram):
+    """The plain loopback transport puts all shards of a one-GPU group on ONE stream, which would hide a missing
+    dependency between shards.  CMF_COMM_LOOPBACK_STREAMS gives every shard its own stream and keeps RCCL's semantics
+    for the collectives (start when every shard's stream has arrived, every stream continues when done) through events:
+    the group iteration -- call by call and as a pipelined cmf_iterate batch, overlap and Gram forms included -- must give
+    the shared-stream group's results bitwise."""
+    from cmf_jl_amd import _lib
+
+    iters = 6
+    data, W0, H0, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, reg)
+    kw = REG if reg else dict(l1W=0.0, l2W=0.0, l1H=0.0, l2H=0.0)
+    res = {}
+    for tr in (_lib.CMF_COMM_LOOPBACK, _lib.CMF_COMM_LOOPBACK_STREAMS):
+        for mode in ("calls", "iterate"):
+            rule = cmf.MultUpdate(data, W0, H0, devices=[0] * R, transport=tr)
+            assert ("loopback-streams" in rule.comm_info()) == (tr == _lib.CMF_COMM_LOOPBACK_STREAMS)
+            if gram:
+                rule.set_option("gram", 1)
+            if overlap:
+                rule.set_overlap(True)
+            res[(tr, mode)] = _mu(rule, mode, iters, kw)
+            rule.close()
+    for mode in ("calls", "iterate"):
+        a, b = res[(_lib.CMF_COMM_LOOPBACK, mode)], res[(_lib.CMF_COMM_LOOPBACK_STREAMS, mode)]
+        np.testing.assert_allclose(b[0], lr, rtol=1e-4)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])
+
+
+def test_group_pgd_with_a_stream_per_shard(cmf, oracle):
+    from cmf_jl_amd import _lib
+
+    data, W0, H0 = _pgd_problem(oracle, 130, 900, 32, 20)
+    mask = (np.random.default_rng(5).uniform(size=data.shape) > 0.25).astype(float)
+    lf = cmf.MaskedLoss(cmf.SquareLoss(), mask)
+    rule = cmf.PGDUpdate(data, W0, H0, devices=[0] * 4, transport=_lib.CMF_COMM_LOOPBACK_STREAMS)
+    lg = []
+    for _ in range(5):
+        rule.update_motifs(loss_func=lf, constrW=cmf.UnitNormConstraint())
+        lg.append(rule.update_feature_maps(loss_func=lf, constrH=cmf.UnitNormConstraint()))
+    Wg, Hg = rule.download()
+    rule.close()
+    Wr, Hr, lr, _ = oracle.fit_pgd(data, W0, H0, max_itr=5, mask=mask, constrW="unitnorm", constrH="unitnorm")
+    np.testing.assert_allclose(lg, lr[1:], rtol=1e-4)
+    assert frob_rel(Wg, Wr) < 1e-4 and frob_rel(Hg, Hr) < 1e-4
+
+
+def test_config2_eight_shards_with_a_stream_per_shard(cmf):
+    """BASELINE config 2 cut into the 8 shards of `bench.py --gpus 8`, every shard on its own stream of GPU 0, 10 pipelined
+    iterations: bitwise the shared-stream group (whose agreement with the oracle test_gpu_parity.py checks at this size)."""
+    from cmf_jl_amd import _lib
+
+    data = cmf.gen_synthetic(N=2000, T=50000, seed=1234)
+    W0, H0 = cmf.init_rand(data, L=20, K=32, seed=0)
+    out = []
+    for tr in (_lib.CMF_COMM_LOOPBACK, _lib.CMF_COMM_LOOPBACK_STREAMS):
+        for overlap in (False, True):
+            rule = cmf.MultUpdate(data, W0, H0, devices=[0] * 8, transport=tr)
+            rule.set_overlap(overlap)
+            ls = list(rule.iterate(10))
+            rule.synchronize()
+            out.append((tr, overlap, np.asarray(ls)) + rule.download())
+            rule.close()
+    for r in out[1:]:
+        if r[1] == out[0][1]:
+            np.testing.assert_array_equal(r[2], out[0][2])
+            np.testing.assert_array_equal(r[3], out[0][3])
+            np.testing.assert_array_equal(r[4], out[0][4])
+    np.testing.assert_array_equal(out[1][2], out[3][2])  # overlap form: streams vs shared stream
+    np.testing.assert_array_equal(out[1][3], out[3][3])

@@ -293,29 +293,43 @@ def test_sharded_processes_asymmetric_rccl_failure_does_not_hang(oracle, tmp_pat
 
 
 @pytest.mark.gpu
-def test_parameter_sweep_over_ranks(tmp_path):
-    """independent fits spread over the ranks of a process group (replicas, one device per
-    rank on a real node; here two gloo ranks share GPU 0) give the single-process sweep's results in its order."""
+def test_parameter_sweep_over_ranks(oracle, tmp_path):
+    """SURVEY.md section 8f, f4 (src/model.jl:132-145): independent fits spread over the ranks of a process group
+    (replicas: rank r on GPU r when the box has one per rank, otherwise the gloo ranks share GPU 0).  Every entry of the
+    gathered sweep is compared with the fp64 oracle's fit of the same (L, K, alg) from the same seeds -- and with the
+    single-process sweep, whose order and results it must reproduce bitwise."""
     import cmf_jl_amd as cmf
 
     out = str(tmp_path / "sweep.npz")
     port = _free_port()
     procs = []
+    algs = (":mult", ":hals")
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_sweep_worker.py"), out], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_sweep_worker.py"), out, ",".join(algs)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
     got = np.load(out)
     data = cmf.gen_synthetic(N=40, T=300, seed=1234)
-    ref = cmf.parameter_sweep(data, L_vals=(5, 8), K_vals=(2, 3), alg_vals=(":mult",), max_itr=6, seed=0, check_convergence=False)
-    assert [tuple(k) for k in got["keys"]] == [(L, K) for (L, K, _) in ref]
-    for (L, K, _), r in ref.items():
-        np.testing.assert_array_equal(got[f"loss_{L}_{K}"], r.loss_hist)  # same kernels, same seeds: bitwise
-        np.testing.assert_array_equal(got[f"W_{L}_{K}"], r.W)
+    ref = cmf.parameter_sweep(data, L_vals=(5, 8), K_vals=(2, 3), alg_vals=algs, max_itr=6, seed=0, check_convergence=False)
+    tag = lambda L, K, a: f"{L}_{K}_{a.lstrip(':')}"  # noqa: E731
+    assert list(got["keys"]) == [tag(L, K, a) for (L, K, a) in ref]  # the reference's insertion order (model.jl:137-142)
+    for (L, K, a), r in ref.items():
+        np.testing.assert_array_equal(got[f"loss_{tag(L, K, a)}"], r.loss_hist)  # same kernels, same seeds: bitwise
+        np.testing.assert_array_equal(got[f"W_{tag(L, K, a)}"], r.W)
+        # ... and the oracle: init_rand(seed 0) + 6 iterations of the rule, fp64
+        W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+        if a == ":mult":
+            Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=6, check_convergence=False)
+            tol = 1e-4
+        else:
+            Wr, Hr, lr, _ = oracle.c_fit_hals(data, W0, H0, max_itr=6, check_convergence=False)
+            tol = 5e-4  # (entries clamp to exact zeros: a rounding-level sign change moves an entry between 0 and a small value)
+        np.testing.assert_allclose(got[f"loss_{tag(L, K, a)}"], lr, rtol=1e-4)
+        assert frob_rel(got[f"W_{tag(L, K, a)}"], Wr) < tol and frob_rel(got[f"H_{tag(L, K, a)}"], Hr) < tol
 
 
 @pytest.mark.gpu
