@@ -88,6 +88,7 @@ struct cmf_handle_s {
     std::vector<int4> tc_tab_host[2];    // per-wave work tables of the two variants ([0]: two sources, [1]: one)
     int4 *tc_tab[2] = {nullptr, nullptr};
     int hxt_nchunks1 = 1, hxt_chunk_len1 = 6; // time chunks when only one source is contracted
+    int hxt_main = 0, hxt_main1 = 0;          // rows the C2 kernel contracts in the two forms; the < 6*LP rows behind them are added by the slab sum
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
     int conv_variant = 0;   // K % 32 == 0: 3 = one-wave workgroups (conv3_kernel), 2 = 128 x 128 tiles (conv2_kernel), 0 = per mode
     int conv_partials = 1;  // loss partials written by the last conv launch
@@ -218,18 +219,25 @@ static void plan(cmf_handle_s *h, int n_cu)
     h->hxt_LP = best;
     h->hxt_groups = (int)(bestP / (2 * best));
     const int wave_slots = 4 * n_cu * (best <= 5 ? 2 : 1); // resident waves (register-limited)
-    int64_t waves_per_chunk = (int64_t)(d.Np / 32) * 2 * d.KB * h->hxt_groups;
-    int nch = (int)std::max<int64_t>(1, (wave_slots + waves_per_chunk / 2) / waves_per_chunk);
-    int64_t clen = rup((d.Tl + nch - 1) / nch, 6 * best);
-    h->hxt_chunk_len = (int)clen;
-    h->hxt_nchunks = (int)((d.Tl + clen - 1) / clen);
-    {
-        int64_t wpc1 = (int64_t)(d.Np / 32) * d.KB * h->hxt_groups;
-        int nch1 = (int)std::max<int64_t>(1, (wave_slots + wpc1 / 2) / wpc1);
-        int64_t clen1 = rup((d.Tl + nch1 - 1) / nch1, 6 * best);
-        h->hxt_chunk_len1 = (int)clen1;
-        h->hxt_nchunks1 = (int)((d.Tl + clen1 - 1) / clen1);
-    }
+    // Time chunks: as many as fill the resident wave slots, each a whole number of ring rotations (6*LP rows).  When
+    // leaving the < 6*LP rows behind the last whole rotation of Tl to the slab sum (CmfHxtTail) lets the chunks get one
+    // rotation shorter, that is done: T = 6250 (the T/8 shard of config 2) over 8 chunks is 26 rotations + 10 rows, not 27.
+    auto chunks = [&](int64_t waves_per_chunk, int *nchunks, int *chunk_len, int *main_rows) {
+        const int unit = 6 * best;
+        int nch = (int)std::max<int64_t>(1, (wave_slots + waves_per_chunk / 2) / waves_per_chunk);
+        const int64_t units_all = (d.Tl + unit - 1) / unit, units_whole = d.Tl / unit;
+        int64_t per = (units_all + nch - 1) / nch;
+        *main_rows = d.Tl;
+        static const bool exact = !(getenv("CMF_HXT_EXACT") && atoi(getenv("CMF_HXT_EXACT")) == 0); // measurement knob
+        if (exact && units_whole > 0 && (units_whole + nch - 1) / nch < per) {
+            per = (units_whole + nch - 1) / nch;
+            *main_rows = (int)(units_whole * unit);
+        }
+        *chunk_len = (int)(per * unit);
+        *nchunks = (int)((*main_rows + *chunk_len - 1) / *chunk_len);
+    };
+    chunks((int64_t)(d.Np / 32) * 2 * d.KB * h->hxt_groups, &h->hxt_nchunks, &h->hxt_chunk_len, &h->hxt_main);
+    chunks((int64_t)(d.Np / 32) * d.KB * h->hxt_groups, &h->hxt_nchunks1, &h->hxt_chunk_len1, &h->hxt_main1);
     // C3 (transconv): the chunk units of all (t block, k block, source) pairs are dealt out evenly to the resident
     // waves (2 workgroups of 4 waves per CU); F = the largest number of waves that share one pair
     h->tc_LT = d.L <= 32 ? (int)rup(d.L, 4) : 32;
@@ -380,10 +388,12 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     // the C2 kernel addresses a time chunk of X with 32-bit byte offsets: keep chunks below 2 GiB
     while ((double)(h->hxt_chunk_len + 16 * h->hxt_LP + 8) * d.Np * 4.0 >= 2147483648.0) {
         h->hxt_chunk_len = (int)rup(h->hxt_chunk_len / 2, 6 * h->hxt_LP);
+        h->hxt_main = d.Tl;
         h->hxt_nchunks = (d.Tl + h->hxt_chunk_len - 1) / h->hxt_chunk_len;
     }
     while ((double)(h->hxt_chunk_len1 + 16 * h->hxt_LP + 8) * d.Np * 4.0 >= 2147483648.0) {
         h->hxt_chunk_len1 = (int)rup(h->hxt_chunk_len1 / 2, 6 * h->hxt_LP);
+        h->hxt_main1 = d.Tl;
         h->hxt_nchunks1 = (d.Tl + h->hxt_chunk_len1 - 1) / h->hxt_chunk_len1;
     }
 
@@ -514,13 +524,14 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     return CMF_OK;
 }
 
-static int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int NpX, int nsrc, float *slabs, int nchunks, int chunk_len)
+static int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int NpX, int nsrc, float *slabs, int nchunks, int chunk_len,
+                         int main_rows = -1)
 {
     ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : (nsrc == 1 && X0 == h->X) ? PROF_HXT_NUM : (nsrc == 1 && X0 == h->est && h->est_kind == 1) ? PROF_HXT_DEN : PROF_OTHER);
     const CmfDims &d = h->d;
     HxtParams p;
     p.H = h->H; p.X0 = X0; p.X1 = X1; p.slabs = slabs;
-    p.Np = NpX; p.K32 = d.K32; p.KB = d.KB; p.PADL = d.PADL; p.L = d.L; p.Tl = d.Tl; p.chunk_len = chunk_len;
+    p.Np = NpX; p.K32 = d.K32; p.KB = d.KB; p.PADL = d.PADL; p.L = d.L; p.Tl = main_rows >= 0 ? main_rows : d.Tl; p.chunk_len = chunk_len;
     p.G = h->hxt_groups; p.nsrc = nsrc;
     p.CG = hxt_cg(nchunks);
     dim3 grid((NpX / 128) * p.CG * h->hxt_groups, nchunks / p.CG, nsrc * d.KB), block(256);
@@ -536,7 +547,7 @@ static int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int 
 
 static int launch_hxt(cmf_handle_s *h)
 {
-    return launch_hxt_on(h, h->X, h->est, h->d.Np, 2, h->wslabs, h->hxt_nchunks, h->hxt_chunk_len);
+    return launch_hxt_on(h, h->X, h->est, h->d.Np, 2, h->wslabs, h->hxt_nchunks, h->hxt_chunk_len, h->hxt_main);
 }
 
 static int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullptr)
@@ -563,7 +574,8 @@ static int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullpt
     return CMF_OK;
 }
 
-static int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nslabs, size_t stride, bool take_carry = false)
+static int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nslabs, size_t stride, bool take_carry = false,
+                           CmfHxtTail tail = CmfHxtTail{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0})
 {
     size_t n4 = stride / 4;
     int blocks = (int)std::min<size_t>(2048, (n4 + 255) / 256);
@@ -572,9 +584,21 @@ static int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nsl
         carry = h->carry;
         h->carry = CmfLossCarry{};
     }
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, h->stream, out, in, nslabs, stride, n4, carry);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, h->stream, out, in, nslabs, stride, n4, carry, tail);
     KCHK("slab_sum_kernel");
     return CMF_OK;
+}
+
+// The C2 contraction of one (nsrc = 1: X0) or two sources with H_shift, complete: kernel, slab sum, and the rows the kernel
+// leaves to the slab sum.   out: [nsrc][L][K32][Np]
+static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int nsrc, float *out, bool take_carry = false)
+{
+    const CmfDims &d = h->d;
+    const int nch = nsrc == 2 ? h->hxt_nchunks : h->hxt_nchunks1, clen = nsrc == 2 ? h->hxt_chunk_len : h->hxt_chunk_len1;
+    const int main_rows = nsrc == 2 ? h->hxt_main : h->hxt_main1;
+    CMFTRY(launch_hxt_on(h, X0, X1, d.Np, nsrc, h->wslabs, nch, clen, main_rows));
+    const CmfHxtTail tail{h->H, X0, X1, d.Tl - main_rows, d.PADL + main_rows, d.L, d.K32, d.Np};
+    return launch_slab_sum(h, out, h->wslabs, hxt_nslabs(nch), (size_t)nsrc * d.L * d.K32 * d.Np, take_carry, tail);
 }
 
 static int read_scalar(cmf_handle_s *h, int slot, double *v)
@@ -604,8 +628,7 @@ static int w_partial_impl(cmf_handle_s *h)
     if (!(h->reuse_est && h->est_kind == 1))
         CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
     h->est_kind = 1;
-    CMFTRY(launch_hxt(h));                                  // mult.jl:31-34
-    return launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks), (size_t)2 * d.L * d.K32 * d.Np, true);
+    return hxt_contract(h, h->X, h->est, 2, h->numden, true); // mult.jl:31-34
 }
 
 // The two halves of w_partial_impl as separate steps (same arithmetic, the sources contracted one at a time): the
@@ -621,8 +644,7 @@ static int w_partial_half_impl(cmf_handle_s *h, int den)
         h->est_kind = 1;
     }
     const float *src = den ? h->est : h->X;
-    CMFTRY(launch_hxt_on(h, src, src, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1)); // mult.jl:31-34, one source
-    return launch_slab_sum(h, h->numden + (den ? LKN : 0), h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN, den != 0);
+    return hxt_contract(h, src, src, 1, h->numden + (den ? LKN : 0), den != 0); // mult.jl:31-34, one source
 }
 
 // den == NULL: denomW lies behind numW in h->numden (the layout of the [numW | denomW] all-reduce buffer)
@@ -645,7 +667,8 @@ static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
     CMFTRY(launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext)); // mult.jl:44 (est with the new W)
     CMFTRY(launch_transconv(h, 2));                                         // mult.jl:47-48
     dim3 grid((d.Tl + HUPD_T - 1) / HUPD_T, d.KB);
-    hipLaunchKernelGGL(h_update_kernel, grid, dim3(256), 0, h->stream, h->H, h->Ht, h->hslabs, h->tc_S,
+    const size_t TK = (size_t)d.Tl * d.K32;
+    hipLaunchKernelGGL(h_update_kernel, grid, dim3(256), 0, h->stream, h->H, h->Ht, h->hslabs, 2 * TK, h->tc_S, h->hslabs + TK, 2 * TK, h->tc_S,
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
     KCHK("h_update_kernel");
     h->est_kind = 0;
@@ -1490,13 +1513,17 @@ static int gram_ensure(cmf_handle_s *h)
     h->hals_NpC = (int)rup(d.K32, 128); // pitch of H as the X operand of its own lag correlations (compute_hh)
     if ((double)d.L * d.K32 * h->hals_NpH * 4.0 >= 2147483648.0 || (double)d.TP * h->hals_NpC * 4.0 >= 2147483648.0)
         return fail(CMF_ERR_UNSUPPORTED, "Gram form: (L*K)^2 or T*K exceeds the 2 GiB the kernels' 32-bit buffer offsets address");
-    {   // time chunks of that launch: fill the resident wave slots
+    {   // time chunks of that launch: fill the resident wave slots -- but no chunk shorter than two rotations of the C2
+        // kernel's register ring, and the chunk count a multiple of 4 so that four chunks are added inside a workgroup
+        // (trailing chunks that start behind Tl do nothing): at K = 32 the launch has 8 waves per chunk, and one rotation
+        // per chunk meant 209 slabs of one chunk each at T = 6250 for the slab sum to walk through (30 us)
         const int slots = 4 * h->n_cu * (h->hxt_LP <= 5 ? 2 : 1);
         int64_t wpc = (int64_t)(h->hals_NpC / 32) * d.KB * h->hxt_groups;
         int nch = (int)std::max<int64_t>(1, (slots + wpc / 2) / wpc);
-        int64_t clen = rup((d.Tl + nch - 1) / nch, 6 * h->hxt_LP);
+        int64_t clen = std::max<int64_t>(rup((d.Tl + nch - 1) / nch, 6 * h->hxt_LP), 12 * h->hxt_LP);
         h->hals_clen = (int)clen;
-        h->hals_nch = (int)((d.Tl + clen - 1) / clen);
+        nch = (int)((d.Tl + clen - 1) / clen);
+        h->hals_nch = nch >= 4 ? (int)rup(nch, 4) : nch;
     }
     const size_t LKN = (size_t)d.L * d.K32 * h->hals_NpH;
     const size_t LKC = (size_t)d.L * d.K32 * h->hals_NpC;
@@ -1592,18 +1619,16 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     const size_t LKN = (size_t)d.L * d.K32 * d.Np;
     const float *G = h->numden, *Gsub = nullptr;
     if (h->hals_gram == 1) {
-        CMFTRY(launch_hxt_on(h, h->X, h->X, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
-        CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN));
+        CMFTRY(hxt_contract(h, h->X, h->X, 1, h->numden));
         CMFTRY(compute_hh(h));
-        hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 128, d.L * d.KB), dim3(256), 0, h->stream, h->hals_HH, h->Wt, h->numden + LKN,
+        hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 32, d.L * d.KB), dim3(256), 0, h->stream, h->hals_HH, h->Wt, h->numden + LKN,
                            d.L * d.K32, h->hals_NpH, d.Np);
         KCHK("gram_w_kernel");
         G = h->numden + LKN;
         Gsub = h->numden;
     } else {
         CMFTRY(ensure_resid(h));
-        CMFTRY(launch_hxt_on(h, h->est, h->est, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
-        CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN));
+        CMFTRY(hxt_contract(h, h->est, h->est, 1, h->numden));
         CMFTRY(compute_hh(h));
     }
     // the K*L sequential column updates, k outer / lag inner (hals.jl:90-97)
@@ -1820,7 +1845,7 @@ static int hals_h_rerun(cmf_handle_s *h)
 static int gram_tables(cmf_handle_s *h) // PW -> GW, GE (the lag-Gram taps of W; shared with HALS)
 {
     const CmfDims &d = h->d;
-    hipLaunchKernelGGL(hals_pw_kernel, dim3((d.L * d.L + 3) / 4, d.KB * d.KB), dim3(256), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
+    hipLaunchKernelGGL(hals_pw_kernel, dim3(d.L * (d.L + 1) / 2, d.KB * d.KB), dim3(256), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
     KCHK("hals_pw_kernel");
     hipLaunchKernelGGL(hals_gw_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_PW, h->hals_GW, h->hals_GE, d.L, d.K32, h->hals_ne, d.Tl, h->hals_t_edge0);
     KCHK("hals_gw_kernel");
@@ -1832,18 +1857,22 @@ static int gram_denom_h(cmf_handle_s *h, float *out)
     const CmfDims &d = h->d;
     const size_t lds = (size_t)d.K32 * (64 + 2 * (d.L - 1)) * sizeof(float);
     if (lds > 96 * 1024) return fail(CMF_ERR_UNSUPPORTED, "Gram form: K*L too large for the LDS window");
-    // columns with the full lag window, in tiles of 128: the MFMA kernel on the transposed taps; the rest (the right edge with
-    // its per-column taps, and what does not fill a tile): the scalar kernel
-    const size_t lds_m = (size_t)d.K32 * (128 + 2 * (d.L - 1)) * sizeof(float);
-    const int ntile = lds_m <= 120 * 1024 ? h->hals_t_edge0 / 128 : 0;
+    // columns with the full lag window, in tiles of 128 / fw: the MFMA kernel on the transposed taps; the rest (the right edge
+    // with its per-column taps, and what does not fill a tile): the scalar kernel.  fw waves share the MFMA chain of an
+    // output block: short handles (a T/8 shard) need the extra waves to fill the chip.
+    static const int fw_env = getenv("CMF_GRAM_FW") ? atoi(getenv("CMF_GRAM_FW")) : 0; // measurement knob
+    const int fw = (fw_env == 1 || fw_env == 2 || fw_env == 4) ? fw_env : (d.Tl < 16384 ? 4 : (d.Tl < 100000 ? 2 : 1));
+    const int tile = 128 / fw;
+    const size_t lds_m = ((size_t)d.K32 * (tile + 2 * (d.L - 1)) + (fw > 1 ? 4096 : 0)) * sizeof(float);
+    const int ntile = lds_m <= 120 * 1024 ? h->hals_t_edge0 / tile : 0;
     if (ntile > 0) {
         const int Ep = 2 * d.L; // E = 2L - 1 taps padded to an even count
         hipLaunchKernelGGL(gram_taps_t_kernel, dim3(256), dim3(256), 0, h->stream, h->hals_GW, h->hals_GWt, d.L, d.K32, Ep);
         KCHK("gram_taps_t_kernel");
-        hipLaunchKernelGGL(gram_h_mfma_kernel, dim3(ntile, d.KB), dim3(256), lds_m, h->stream, h->Ht, h->hals_GWt, out, d.K, d.L, d.K32, d.TP, d.PADL, Ep);
+        hipLaunchKernelGGL(gram_h_mfma_kernel, dim3(ntile, d.KB), dim3(256), lds_m, h->stream, h->Ht, h->hals_GWt, out, d.K, d.L, d.K32, d.TP, d.PADL, Ep, fw);
         KCHK("gram_h_mfma_kernel");
     }
-    const int t_first = 128 * ntile;
+    const int t_first = tile * ntile;
     if (ntile > 0 && d.Tl - t_first <= 512) { // the usual case: a wave per leftover output
         if (d.Tl > t_first) {
             hipLaunchKernelGGL(gram_h_edge_kernel, dim3(d.Tl - t_first, d.K32 / 4), dim3(256), 0, h->stream, h->Ht, h->hals_GW, h->hals_GE, out,
@@ -1852,7 +1881,7 @@ static int gram_denom_h(cmf_handle_s *h, float *out)
         }
         return CMF_OK;
     }
-    const int block0 = 2 * ntile, nblock = (d.Tl + 63) / 64 - block0;
+    const int block0 = t_first / 64, nblock = (d.Tl + 63) / 64 - block0; // (a half block in front of it is simply formed twice)
     if (nblock > 0) {
         hipLaunchKernelGGL(gram_h_kernel, dim3(nblock, d.K32 / 4), dim3(256), lds, h->stream, h->Ht, h->hals_GW, h->hals_GE, out,
                            d.Tl, d.K, d.L, d.K32, d.TP, d.PADL, h->hals_ne, h->hals_t_edge0, block0);
@@ -1870,15 +1899,14 @@ static int gram_w_partial(cmf_handle_s *h, float *hh_out)
     const CmfDims &d = h->d;
     CMFTRY(gram_ensure(h));
     const size_t LKN = (size_t)d.L * d.K32 * d.Np;
-    CMFTRY(launch_hxt_on(h, h->X, h->X, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1));
-    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN, true)); // (+ a loss reduction deferred by cmf_iterate)
+    CMFTRY(hxt_contract(h, h->X, h->X, 1, h->numden, true)); // (+ a loss reduction deferred by cmf_iterate)
     return compute_hh(h, hh_out);
 }
 
 static int gram_w_finish(cmf_handle_s *h, const float *HH, double l1W, double l2W, const float *tail_src, float *tail_dst, int tail_n)
 {
     const CmfDims &d = h->d;
-    hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 128, d.L * d.KB), dim3(256), 0, h->stream, HH, h->Wt, h->wslabs,
+    hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 32, d.L * d.KB), dim3(256), 0, h->stream, HH, h->Wt, h->wslabs,
                        d.L * d.K32, h->hals_NpH, d.Np);
     KCHK("gram_w_kernel");
     return w_apply_impl(h, l1W, l2W, tail_src, tail_dst, tail_n, h->wslabs); // mult.jl:37-38
@@ -1897,13 +1925,15 @@ static int gram_h_update(cmf_handle_s *h, double l1H, double l2H)
     CMFTRY(gram_ensure(h));
     const size_t TK = (size_t)d.Tl * d.K32;
     if (!h->gram_numden_h) CMFTRY(dalloc_zero(&h->gram_numden_h, 2 * TK));
-    // numH = tensor_transconv(W, data) (mult.jl:47): one C3 contraction
+    // numH = tensor_transconv(W, data) (mult.jl:47): one C3 contraction; its fragment slabs are summed by the H update
+    // (gram = 2 needs the sum itself for <H, numH>)
     CMFTRY(launch_transconv(h, 1, h->XT));
-    CMFTRY(launch_slab_sum(h, h->gram_numden_h, h->hslabs, h->tc_S1, TK));
+    if (h->gram == 2) CMFTRY(launch_slab_sum(h, h->gram_numden_h, h->hslabs, h->tc_S1, TK));
     // denomH = tensor_transconv(W, tensor_conv(W, H)) (mult.jl:44,48) through the lag-Gram taps of W
     CMFTRY(gram_tables(h));
     CMFTRY(gram_denom_h(h, h->gram_numden_h + TK));
-    hipLaunchKernelGGL(h_update_kernel, dim3((d.Tl + HUPD_T - 1) / HUPD_T, d.KB), dim3(256), 0, h->stream, h->H, h->Ht, h->gram_numden_h, 1,
+    hipLaunchKernelGGL(h_update_kernel, dim3((d.Tl + HUPD_T - 1) / HUPD_T, d.KB), dim3(256), 0, h->stream, h->H, h->Ht,
+                       h->hslabs, TK, h->tc_S1, h->gram_numden_h + TK, (size_t)0, 1,
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
     KCHK("h_update_kernel");
     h->est_kind = 0;
@@ -1985,8 +2015,7 @@ static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
     const float gscale = h->pgd_loss_abs ? 1.f : 2.f; // pgd.jl:31-33 vs :42-44
     const size_t LKN = (size_t)d.L * d.K32 * d.Np;
     CMFTRY(ensure_resid(h, h->M != nullptr, h->pgd_loss_abs != 0));                                                            // pgd.jl:230 (:64-67 with a mask)
-    CMFTRY(launch_hxt_on(h, h->est, h->est, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1)); // pgd.jl:206-214
-    CMFTRY(launch_slab_sum(h, h->numden, h->wslabs, hxt_nslabs(h->hxt_nchunks1), LKN));
+    CMFTRY(hxt_contract(h, h->est, h->est, 1, h->numden)); // pgd.jl:206-214
     dim3 grid(d.Np / 64, d.KB, d.L);
     const int nblk = (d.Np / 64) * d.KB * d.L;
     if ((size_t)nblk > n_partial(h)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
@@ -2118,8 +2147,7 @@ static int group_pgd_w(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double p
         const CmfDims &d = s->d;
         CMFTRY(group_use(s));
         CMFTRY(ensure_resid(s, group_masked(g), st->pgd_loss_abs != 0));                                 // pgd.jl:230 on the shard's columns
-        CMFTRY(launch_hxt_on(s, s->est, s->est, d.Np, 1, s->wslabs, s->hxt_nchunks1, s->hxt_chunk_len1)); // pgd.jl:206-214, partial over t
-        CMFTRY(launch_slab_sum(s, s->numden, s->wslabs, hxt_nslabs(s->hxt_nchunks1), LKN));
+        CMFTRY(hxt_contract(s, s->est, s->est, 1, s->numden)); // pgd.jl:206-214, partial over t
     }
     CMFTRY(group_allreduce(g, g->red, 0, LKN)); // the one bulk exchange: K x N x L partial gradients
     for (cmf_handle_s *s : g->sh) {

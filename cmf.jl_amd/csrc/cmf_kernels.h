@@ -1387,7 +1387,11 @@ __global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, con
 // fourth slab (the slab count grows as the shard gets shorter: 36 at T = 6250), the groups are combined in a
 // fixed order through LDS, so the result does not depend on timing.
 #define HUPD_T 8
-__global__ __launch_bounds__(256) void h_update_kernel(float *H, float *Ht, const float *slabs, int S,
+// num / den: Snum / Sden partial-sum slabs of [Tl][K32] floats, `num_stride` / `den_stride` floats apart (the two-source
+// transconv writes [S][2][Tl][K32]: num = slabs, den = slabs + Tl*K32, both strides 2*Tl*K32; the Gram form has the S1
+// slabs of the one-source launch for num and ONE array for den).
+__global__ __launch_bounds__(256) void h_update_kernel(float *H, float *Ht, const float *nump, size_t num_stride, int Snum,
+                                                        const float *denp, size_t den_stride, int Sden,
                                                         int Tl, int K, int K32, int PADL, int TP, float l1, float two_l2)
 {
     __shared__ f32x4 red[3][64][2];
@@ -1397,15 +1401,14 @@ __global__ __launch_bounds__(256) void h_update_kernel(float *H, float *Ht, cons
     const int tt = e >> 3, k4 = e & 7;
     const int t0 = blockIdx.x * HUPD_T, kb = blockIdx.y;
     const int t = t0 + tt, k = kb * 32 + 4 * k4;
-    const size_t TK4 = (size_t)Tl * K32 / 4;
-    const f32x4 *sl = reinterpret_cast<const f32x4 *>(slabs);
+    const f32x4 *sn = reinterpret_cast<const f32x4 *>(nump);
+    const f32x4 *sd = reinterpret_cast<const f32x4 *>(denp);
+    const size_t ns4 = num_stride / 4, ds4 = den_stride / 4;
     f32x4 num = {0.f, 0.f, 0.f, 0.f}, den = {0.f, 0.f, 0.f, 0.f};
     if (t < Tl) {
         const size_t idx = ((size_t)t * K32 + k) / 4;
-        for (int s = g; s < S; s += 4) {
-            num += sl[(size_t)(2 * s) * TK4 + idx];
-            den += sl[(size_t)(2 * s + 1) * TK4 + idx];
-        }
+        for (int s = g; s < Snum; s += 4) num += sn[(size_t)s * ns4 + idx];
+        for (int s = g; s < Sden; s += 4) den += sd[(size_t)s * ds4 + idx];
     }
     if (g > 0) {
         red[g - 1][e][0] = num;
@@ -1477,15 +1480,46 @@ __device__ __forceinline__ void cmf_block_loss_reduce(const CmfLossCarry &c)
     }
 }
 
+// The last rows of a C2 contraction, added by the slab sum: the C2 kernel works in whole rotations of its register ring
+// (6*LP time rows), and leaving the < 6*LP rows behind the last whole rotation to this kernel lets the chunks divide the
+// rest exactly (T = 6250 over 16 chunks: 390 rows each + 10 here, instead of 420 each with 30 of them padding).
+//   out[src][l][k][n] += sum_{t = t0}^{t0 + rows - 1} H[t - l][k] * X_src[t][n]       (t = padded row index)
+struct CmfHxtTail {
+    const float *H, *X0, *X1; // rows == 0: nothing to add
+    int rows, t0, L, K32, Np;
+};
+
 // out[i] = sum_s in[s*stride + i]  (deterministic slab combine; float4 lanes); the last block also performs a carried
 // loss reduction (same summation order as loss_reduce_kernel / loss_tail_kernel)
-__global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *in, int nslabs, size_t stride, size_t n4, CmfLossCarry carry)
+__global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *in, int nslabs, size_t stride, size_t n4, CmfLossCarry carry,
+                                                        CmfHxtTail tail)
 {
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x) {
         float4 a = reinterpret_cast<const float4 *>(in)[idx];
-        for (int s = 1; s < nslabs; ++s) {
-            float4 b = reinterpret_cast<const float4 *>(in + (size_t)s * stride)[idx];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        for (int s = 1; s < nslabs; s += 4) { // four loads in flight, added in slab order (one at a time the loop is a chain of HBM round trips)
+            float4 b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int su = (s + u < nslabs) ? s + u : s; // (a slab that exists; its value is dropped below)
+                b[u] = reinterpret_cast<const float4 *>(in + (size_t)su * stride)[idx];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s + u < nslabs) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+        }
+        if (tail.rows > 0) { // element 4 * idx = ((src * L + l) * K32 + k) * Np + n
+            const size_t e = 4 * idx;
+            const int n = (int)(e % tail.Np);
+            const int k = (int)((e / tail.Np) % tail.K32);
+            const int l = (int)((e / ((size_t)tail.Np * tail.K32)) % tail.L);
+            const int src = (int)(e / ((size_t)tail.Np * tail.K32 * tail.L));
+            const float *X = src ? tail.X1 : tail.X0;
+            for (int r = 0; r < tail.rows; ++r) {
+                const int t = tail.t0 + r;
+                const float hv = tail.H[(size_t)(t - l) * tail.K32 + k];
+                const float4 xv = *reinterpret_cast<const float4 *>(X + (size_t)t * tail.Np + n);
+                a.x = fmaf(hv, xv.x, a.x); a.y = fmaf(hv, xv.y, a.y); a.z = fmaf(hv, xv.z, a.z); a.w = fmaf(hv, xv.w, a.w);
+            }
         }
         reinterpret_cast<float4 *>(out)[idx] = a;
     }
@@ -1723,25 +1757,28 @@ __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float
     }
 }
 
-// PW[l][l'][k][k'] = sum_n Wn[l][n][k] * Wn[l'][n][k'] on the MFMA pipe: one wave per (l, l', k block, k' block),
-// both operands are 128-byte rows of Wn read straight from L2.  grid (ceil(L*L/4), KB*KB), block 256
+// PW[l][l'][k][k'] = sum_n Wn[l][n][k] * Wn[l'][n][k'] on the MFMA pipe: one WORKGROUP per (l <= l', k block, k' block),
+// its four waves take every fourth batch of 32 rows of n and add their partial sums through LDS in wave order
+// (deterministic); the pair (l', l) is the transpose and is written from the same result.  Both operands are 128-byte rows
+// of Wn read straight from L2.  grid (L*(L+1)/2, KB*KB), block 256
+// (Round 2 ran one wave per ordered pair: L*L waves of N/2 dependent MFMAs each -- 27 us of MFMA issue per wave at
+// N = 2000 whatever the chip does, 55 us measured, independent of T.)
 __global__ __launch_bounds__(256) void hals_pw_kernel(const float *Wn, float *PW, int N, int L, int Np, int K32, int KB)
 {
+    __shared__ float part[4][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int pair = blockIdx.x * 4 + wave;
-    if (pair >= L * L) return;
-    const int l = pair / L, lp = pair - l * L;
+    int l = 0, rem = blockIdx.x; // pair index -> (l, lp), l <= lp: row l of the upper triangle holds L - l pairs
+    while (rem >= L - l) { rem -= L - l; ++l; }
+    const int lp = l + rem;
     const int kb = blockIdx.y / KB, kbp = blockIdx.y % KB;
     const float *a = Wn + ((size_t)l * Np + h) * K32 + kb * 32 + i;
     const float *b = Wn + ((size_t)lp * Np + h) * K32 + kbp * 32 + i;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    // 32 rows of n per batch, the next batch's 32 operand loads in flight under this batch's 16 MFMAs: there is one wave
-    // per SIMD at most (L * L waves in all), so the overlap has to come from inside the wave -- with a load, wait, MFMA
-    // loop the kernel was a chain of N / 4 L2 round trips (155 us at N = 2000; now MFMA-paced).  Rows >= N of Wn are zero
-    // up to Np, a multiple of 128.
+    // 32 rows of n per batch, the next batch's 32 operand loads in flight under this batch's 16 MFMAs.  Rows >= N of Wn are
+    // zero up to Np, a multiple of 128.
     const int NB = (N + 31) & ~31;
     float av[2][16], bv[2][16];
     auto load = [&](float (&x)[16], float (&y)[16], int n0) {
@@ -1758,56 +1795,52 @@ __global__ __launch_bounds__(256) void hals_pw_kernel(const float *Wn, float *PW
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q + 1], y[q + 1], acc1, 0, 0, 0);
         }
     };
-    load(av[0], bv[0], 0);
-    for (int n0 = 0; n0 < NB; n0 += 64) {
-        if (n0 + 32 < NB) load(av[1], bv[1], n0 + 32);
+    const int first = 32 * wave, step = 128; // batches wave, wave + 4, ...
+    if (first < NB) load(av[0], bv[0], first);
+    for (int n0 = first; n0 < NB; n0 += 2 * step) {
+        if (n0 + step < NB) load(av[1], bv[1], n0 + step);
         mac(av[0], bv[0]);
-        if (n0 + 32 < NB) {
-            if (n0 + 64 < NB) load(av[0], bv[0], n0 + 64);
+        if (n0 + step < NB) {
+            if (n0 + 2 * step < NB) load(av[0], bv[0], n0 + 2 * step);
             mac(av[1], bv[1]);
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k = kb * 32 + cmf_crow(r, h), kp = kbp * 32 + i;
-        PW[(((size_t)l * L + lp) * K32 + k) * K32 + kp] = acc0[r] + acc1[r];
+    for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc0[r] + acc1[r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 16 * 64; o += 256) {
+        const int r = o >> 6, ln = o & 63;
+        const float v = ((part[0][r][ln] + part[1][r][ln]) + part[2][r][ln]) + part[3][r][ln];
+        const int k = kb * 32 + cmf_crow(r, ln >> 5), kp = kbp * 32 + (ln & 31);
+        PW[(((size_t)l * L + lp) * K32 + k) * K32 + kp] = v;
+        if (l != lp) PW[(((size_t)lp * L + l) * K32 + kp) * K32 + k] = v;
     }
 }
 
 // GW[k][k'][e+L-1] = sum_l PW[l][l-e][k][k'], e in (-L, L)        (full-window taps)
-// GE[k][i][k'][e+L-1]: the same with only lags l < Lt(i) = ne - i ... (truncated window of edge column
-// t = t_edge0 + i, Lt = Tl - t), i in [0, ne).  One thread per output.
+// GE[k][i][k'][e+L-1]: the same with only lags l < Lt(i) = ne - i (truncated window of edge column t = t_edge0 + i,
+// Lt = Tl - t), i in [0, ne).  One thread per (k, e, k'), k' fastest across threads (its L reads are 128-byte rows shared
+// with its neighbours); the edge tables are the running sums of the same walk over l -- Lt = l + 1 after lag l -- so all
+// ne + 1 tables cost L reads per thread.  (One thread per OUTPUT, with the tap index fastest, read every term of every
+// table separately: 23 us at K = 32, L = 20, independent of T.)
 __global__ void hals_gw_kernel(const float *PW, float *GW, float *GE, int L, int K32, int ne, int Tl, int t_edge0)
 {
     const int E = 2 * L - 1;
-    const size_t nfull = (size_t)K32 * K32 * E;
-    const size_t total = nfull + (size_t)K32 * ne * K32 * E;
+    const size_t total = (size_t)K32 * K32 * E;
+    (void)Tl; (void)t_edge0;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        int k, kp, ei, Lt;
-        float *dst;
-        if (idx < nfull) {
-            ei = (int)(idx % E);
-            kp = (int)((idx / E) % K32);
-            k = (int)(idx / ((size_t)E * K32));
-            Lt = L;
-            dst = GW + idx;
-        } else {
-            size_t r = idx - nfull;
-            ei = (int)(r % E);
-            kp = (int)((r / E) % K32);
-            int i = (int)((r / ((size_t)E * K32)) % ne);
-            k = (int)(r / ((size_t)E * K32 * ne));
-            Lt = Tl - (t_edge0 + i);
-            if (Lt > L) Lt = L;
-            dst = GE + r;
-        }
+        const int kp = (int)(idx % K32);
+        const int ei = (int)((idx / K32) % E);
+        const int k = (int)(idx / ((size_t)E * K32));
         const int e = ei - (L - 1);
         float s = 0.f;
-        for (int l = 0; l < Lt; ++l) {
-            int lp = l - e;
+        for (int l = 0; l < L; ++l) {
+            const int lp = l - e;
             if (lp >= 0 && lp < L) s += PW[(((size_t)l * L + lp) * K32 + k) * K32 + kp];
+            const int i = ne - (l + 1); // the edge column whose window holds exactly the lags 0 .. l
+            if (i >= 0 && i < ne) GE[(((size_t)k * ne + i) * K32 + kp) * E + ei] = s;
         }
-        *dst = s;
+        GW[((size_t)k * K32 + kp) * E + ei] = s;
     }
 }
 
@@ -2770,24 +2803,58 @@ __global__ void pgd_h_kscale_kernel(float *H, float *Ht, const double *ss, int T
 // =============================================================================================
 
 // out[p][n] = sum_{p'} HH[p'][p] * Wt[p'][n]  (HH is symmetric: row p' is read, columns p0+i -> coalesced)
-// grid (Np/128, LK/32), block 256: wave w -> n block blockIdx.x*4 + w
+// grid (Np/32, LK/32), block 256: ONE 32 x 32 output block per workgroup, its four waves each take a quarter of the
+// reduction range p' and add their partial sums through LDS in wave order (deterministic).  Both operands are 128-byte rows
+// read straight from L2, 16 row pairs in flight under the 16 MFMAs of the batch before (two register sets, two
+// accumulators).  (One wave per output block with a load, wait, MFMA loop was a chain of LK / 2 L2 round trips: 99 us at
+// LK = 640, Np = 2048, independent of T -- a fifth of a T/8 shard's Gram-form iteration; with the reduction split the chip
+// holds five waves per SIMD and the round trips overlap.)
 __global__ __launch_bounds__(256) void gram_w_kernel(const float *HH, const float *Wt, float *out, int LK, int NpH, int Np)
 {
+    __shared__ float part[4][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int p0 = blockIdx.y * 32, n0 = (blockIdx.x * 4 + wave) * 32;
-    f32x16 acc;
+    const int p0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     const float *ap = HH + (size_t)h * NpH + p0 + i;
     const float *bp = Wt + (size_t)h * Np + n0 + i;
-    for (int pp = 0; pp < LK; pp += 2) {
-        const float a = ap[(size_t)pp * NpH];
-        const float b = bp[(size_t)pp * Np];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    const int q4 = LK / 4;                       // LK is a multiple of 32
+    const int lo = wave * q4, hi = lo + q4;
+    float av[2][16], bv[2][16];
+    auto load = [&](float (&x)[16], float (&y)[16], int pp0) { // rows pp0 + 2q (+ h), zero beyond this wave's range
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int pp = pp0 + 2 * q;
+            x[q] = pp < hi ? ap[(size_t)pp * NpH] : 0.f;
+            y[q] = pp < hi ? bp[(size_t)pp * Np] : 0.f;
+        }
+    };
+    auto mac = [&](const float (&x)[16], const float (&y)[16]) {
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q], y[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q + 1], y[q + 1], acc1, 0, 0, 0);
+        }
+    };
+    load(av[0], bv[0], lo);
+    for (int pp0 = lo; pp0 < hi; pp0 += 64) {
+        if (pp0 + 32 < hi) load(av[1], bv[1], pp0 + 32);
+        mac(av[0], bv[0]);
+        if (pp0 + 32 < hi) {
+            if (pp0 + 64 < hi) load(av[0], bv[0], pp0 + 64);
+            mac(av[1], bv[1]);
+        }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[(size_t)(p0 + cmf_crow(r, h)) * Np + n0 + i] = acc[r];
+    for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc0[r] + acc1[r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 16 * 64; o += 256) {
+        const int r = o >> 6, ln = o & 63;
+        const float v = ((part[0][r][ln] + part[1][r][ln]) + part[2][r][ln]) + part[3][r][ln];
+        out[(size_t)(p0 + cmf_crow(r, ln >> 5)) * Np + n0 + (ln & 31)] = v;
+    }
 }
 
 // out[t][k] = sum_{k',e} taps(t)[k][k'][e] * Ht[k'][PADL + t + e];  taps = GW (full window) or GE (edge columns)
@@ -2875,16 +2942,33 @@ __global__ __launch_bounds__(256) void gram_h_edge_kernel(const float *Ht, const
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false)); // row_bcast:31
     if (lane == 63 && k < K32) out[(size_t)t * K32 + k] = x;
 }
-__global__ __launch_bounds__(256) void gram_h_mfma_kernel(const float *Ht, const float *GWt, float *out, int K, int L, int K32, int TP, int PADL, int Ep)
+// fw (1, 2 or 4): the F = K * Ep / 2 MFMAs of an output block are split over fw waves (partial sums added through LDS in
+// wave order), the workgroup's tile is then 128 / fw columns: a short shard (T/8 = 6250 columns: 48 tiles of 128) gets
+// fw times the waves, each with 1/fw of the dependent MFMA chain and of the tap stream (62 -> ~15 us at T = 6250).
+// dynamic LDS: K32 * (128 / fw + 2*(L-1)) floats for the H window (+ 4096 floats for the partial sums when fw > 1).
+__global__ __launch_bounds__(256) void gram_h_mfma_kernel(const float *Ht, const float *GWt, float *out, int K, int L, int K32, int TP, int PADL, int Ep,
+                                                           int fw)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
-    const int t0 = blockIdx.x * 128, kbo = blockIdx.y;
-    const int WN = 128 + 2 * (L - 1);
-    for (int idx = tid; idx < K32 * WN; idx += 256) {
-        const int kp = idx / WN, c = idx - kp * WN;
-        smem_dyn[idx] = Ht[(size_t)kp * TP + PADL + t0 - (L - 1) + c];
+    const int cw = 4 / fw, tile = 32 * cw;
+    const int cg = wave % cw, fg = wave / cw; // column group and F group of this wave
+    const int t0 = blockIdx.x * tile, kbo = blockIdx.y;
+    const int WN = tile + 2 * (L - 1);
+    for (int base = 0; base < K32 * WN; base += 4 * 256) { // four loads in flight per thread, then the LDS writes
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + tid;
+            const int kp = idx / WN, c = idx - kp * WN;
+            v[u] = idx < K32 * WN ? Ht[(size_t)kp * TP + PADL + t0 - (L - 1) + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + tid;
+            if (idx < K32 * WN) smem_dyn[idx] = v[u];
+        }
     }
     __syncthreads();
     f32x16 acc;
@@ -2894,34 +2978,49 @@ __global__ __launch_bounds__(256) void gram_h_mfma_kernel(const float *Ht, const
     // the B stream is one linear walk: 32 rows per chunk, the next chunk's loads issued before this chunk's MFMAs (one
     // wave or two per SIMD: an L2 round trip must be covered from inside the wave).
     const int nstep = Ep >> 1, F = K * nstep;
-    const float *arow = smem_dyn + wave * 32 + i + hh;               // + kp * WN + 2 * s
+    const int Fq = ((F + fw - 1) / fw + 31) & ~31; // this wave's share, in whole chunks
+    const int f_lo = fg * Fq, f_hi = (f_lo + Fq < F) ? f_lo + Fq : F;
+    const float *arow = smem_dyn + cg * 32 + i + hh;                 // + kp * WN + 2 * s
     const float *brow = GWt + (size_t)hh * K32 + kbo * 32 + i;       // + 2 * f * K32
     float bb[2][32];
     auto loadb = [&](float (&x)[32], int f0) {
 #pragma unroll
-        for (int q = 0; q < 32; ++q) x[q] = (f0 + q < F) ? brow[(size_t)2 * (f0 + q) * K32] : 0.f;
+        for (int q = 0; q < 32; ++q) x[q] = (f0 + q < f_hi) ? brow[(size_t)2 * (f0 + q) * K32] : 0.f;
     };
     auto mac = [&](const float (&x)[32], int f0) {
         int kp = f0 / nstep, s2 = f0 - kp * nstep;
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
-            const float a = (f0 + q < F) ? arow[(size_t)kp * WN + 2 * s2] : 0.f;
+            const float a = (f0 + q < f_hi) ? arow[(size_t)kp * WN + 2 * s2] : 0.f;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[q], acc, 0, 0, 0);
             if (++s2 == nstep) { s2 = 0; ++kp; }
         }
     };
-    loadb(bb[0], 0);
-    for (int f0 = 0; f0 < F; f0 += 64) {
-        if (f0 + 32 < F) loadb(bb[1], f0 + 32);
+    if (f_lo < f_hi) loadb(bb[0], f_lo);
+    for (int f0 = f_lo; f0 < f_hi; f0 += 64) {
+        if (f0 + 32 < f_hi) loadb(bb[1], f0 + 32);
         mac(bb[0], f0);
-        if (f0 + 32 < F) {
-            if (f0 + 64 < F) loadb(bb[0], f0 + 64);
+        if (f0 + 32 < f_hi) {
+            if (f0 + 64 < f_hi) loadb(bb[0], f0 + 64);
             mac(bb[1], f0 + 32);
+        }
+    }
+    if (fw > 1) { // add the F groups' partial sums in group order (deterministic)
+        float *part = smem_dyn + (size_t)K32 * WN; // [fw][cw][16][64]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[((fg * cw + cg) * 16 + r) * 64 + lane] = acc[r];
+        __syncthreads();
+        if (fg != 0) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+            for (int g2 = 1; g2 < fw; ++g2) v += part[((g2 * cw + cg) * 16 + r) * 64 + lane];
+            acc[r] = v;
         }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int t = t0 + wave * 32 + cmf_crow(r, hh);
+        const int t = t0 + cg * 32 + cmf_crow(r, hh);
         out[(size_t)t * K32 + kbo * 32 + i] = acc[r];
     }
 }
