@@ -432,6 +432,27 @@ def main():
         dt_gram2 /= nrep
         rule.set_option("gram", 0)
 
+    # Sharded runs, opt-in (CMF_BENCH_GROUP_EXTRAS=1): the Gram form on the group -- the all-reduce carries [numW | HH | tail]
+    # (6.9 MB instead of 10.5 MB at config 2) and, with the overlap option, runs entirely underneath the loss conv.  Extra
+    # fields only; opt-in because a side measurement must never be able to cost the headline of a multi-GPU run.
+    group_extras = None
+    if sharded and os.environ.get("CMF_BENCH_GROUP_EXTRAS") == "1":
+        group_extras = {}
+        keep_overlap = bool(rule.overlap)
+        nrep = max(5, args.steps // 2)
+        try:
+            for name, ov in (("gram", False), ("gram_overlap", True)):
+                rule.upload(W0, H0)
+                rule.set_option("gram", 1)
+                rule.set_overlap(ov)
+                t_, ls_ = timed(2, nrep)
+                group_extras[f"ms_per_step_{name}"] = 1e3 * t_ / nrep
+                group_extras[f"loss_last_{name}"] = float(ls_[-1])
+        except Exception as e:  # noqa: BLE001
+            group_extras["error"] = repr(e)
+        rule.set_option("gram", 0)
+        rule.set_overlap(keep_overlap)
+
     out = None
     nrep_hals = len(replicas) if form == "multi" else (world if alg == "hals" else 1)
     if rank == 0:
@@ -487,6 +508,7 @@ def main():
             "whole_iteration_mfma_frac_reference_formulation_equivalent": F_iter * iters_per_s / (ngpu * PEAK_FP32_MFMA_TFLOPS * 1e12),
             "sustained": sustained,
             "comm": comm,
+            "group_extras": group_extras,
         }
 
     # ---- roofline of the dominant kernel = the class with the largest share of the timed region; durations from

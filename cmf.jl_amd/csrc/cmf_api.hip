@@ -1621,7 +1621,7 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     if (h->hals_gram == 1) {
         CMFTRY(hxt_contract(h, h->X, h->X, 1, h->numden));
         CMFTRY(compute_hh(h));
-        hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 32, d.L * d.KB), dim3(256), 0, h->stream, h->hals_HH, h->Wt, h->numden + LKN,
+        hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 64, (d.L * d.KB + 1) / 2), dim3(256), 0, h->stream, h->hals_HH, h->Wt, h->numden + LKN,
                            d.L * d.K32, h->hals_NpH, d.Np);
         KCHK("gram_w_kernel");
         G = h->numden + LKN;
@@ -1906,7 +1906,7 @@ static int gram_w_partial(cmf_handle_s *h, float *hh_out)
 static int gram_w_finish(cmf_handle_s *h, const float *HH, double l1W, double l2W, const float *tail_src, float *tail_dst, int tail_n)
 {
     const CmfDims &d = h->d;
-    hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 32, d.L * d.KB), dim3(256), 0, h->stream, HH, h->Wt, h->wslabs,
+    hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 64, (d.L * d.KB + 1) / 2), dim3(256), 0, h->stream, HH, h->Wt, h->wslabs,
                        d.L * d.K32, h->hals_NpH, d.Np);
     KCHK("gram_w_kernel");
     return w_apply_impl(h, l1W, l2W, tail_src, tail_dst, tail_n, h->wslabs); // mult.jl:37-38

@@ -1514,11 +1514,21 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *
             const int l = (int)((e / ((size_t)tail.Np * tail.K32)) % tail.L);
             const int src = (int)(e / ((size_t)tail.Np * tail.K32 * tail.L));
             const float *X = src ? tail.X1 : tail.X0;
-            for (int r = 0; r < tail.rows; ++r) {
-                const int t = tail.t0 + r;
-                const float hv = tail.H[(size_t)(t - l) * tail.K32 + k];
-                const float4 xv = *reinterpret_cast<const float4 *>(X + (size_t)t * tail.Np + n);
-                a.x = fmaf(hv, xv.x, a.x); a.y = fmaf(hv, xv.y, a.y); a.z = fmaf(hv, xv.z, a.z); a.w = fmaf(hv, xv.w, a.w);
+            for (int r0 = 0; r0 < tail.rows; r0 += 6) { // six row pairs in flight (one at a time: a chain of round trips)
+                float hv[6];
+                float4 xv[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int t = tail.t0 + ((r0 + u < tail.rows) ? r0 + u : r0);
+                    hv[u] = tail.H[(size_t)(t - l) * tail.K32 + k];
+                    xv[u] = *reinterpret_cast<const float4 *>(X + (size_t)t * tail.Np + n);
+                }
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+                    if (r0 + u < tail.rows) {
+                        a.x = fmaf(hv[u], xv[u].x, a.x); a.y = fmaf(hv[u], xv[u].y, a.y);
+                        a.z = fmaf(hv[u], xv[u].z, a.z); a.w = fmaf(hv[u], xv[u].w, a.w);
+                    }
             }
         }
         reinterpret_cast<float4 *>(out)[idx] = a;
@@ -1834,11 +1844,22 @@ __global__ void hals_gw_kernel(const float *PW, float *GW, float *GE, int L, int
         const int k = (int)(idx / ((size_t)E * K32));
         const int e = ei - (L - 1);
         float s = 0.f;
-        for (int l = 0; l < L; ++l) {
-            const int lp = l - e;
-            if (lp >= 0 && lp < L) s += PW[(((size_t)l * L + lp) * K32 + k) * K32 + kp];
-            const int i = ne - (l + 1); // the edge column whose window holds exactly the lags 0 .. l
-            if (i >= 0 && i < ne) GE[(((size_t)k * ne + i) * K32 + kp) * E + ei] = s;
+        for (int l0 = 0; l0 < L; l0 += 8) { // eight terms in flight, added in lag order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int l = l0 + u, lp = l - e;
+                v[u] = (l < L && lp >= 0 && lp < L) ? PW[(((size_t)l * L + lp) * K32 + k) * K32 + kp] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int l = l0 + u;
+                if (l < L) {
+                    s += v[u];
+                    const int i = ne - (l + 1); // the edge column whose window holds exactly the lags 0 .. l
+                    if (i >= 0 && i < ne) GE[(((size_t)k * ne + i) * K32 + kp) * E + ei] = s;
+                }
+            }
         }
         GW[((size_t)k * K32 + kp) * E + ei] = s;
     }
@@ -2803,58 +2824,77 @@ __global__ void pgd_h_kscale_kernel(float *H, float *Ht, const double *ss, int T
 // =============================================================================================
 
 // out[p][n] = sum_{p'} HH[p'][p] * Wt[p'][n]  (HH is symmetric: row p' is read, columns p0+i -> coalesced)
-// grid (Np/32, LK/32), block 256: ONE 32 x 32 output block per workgroup, its four waves each take a quarter of the
-// reduction range p' and add their partial sums through LDS in wave order (deterministic).  Both operands are 128-byte rows
-// read straight from L2, 16 row pairs in flight under the 16 MFMAs of the batch before (two register sets, two
-// accumulators).  (One wave per output block with a load, wait, MFMA loop was a chain of LK / 2 L2 round trips: 99 us at
-// LK = 640, Np = 2048, independent of T -- a fifth of a T/8 shard's Gram-form iteration; with the reduction split the chip
-// holds five waves per SIMD and the round trips overlap.)
+// grid (Np/64, LK/64), block 256: ONE 64 x 64 output tile per workgroup; its four waves each take a quarter of the
+// reduction range p' for all 2 x 2 blocks of the tile (two A rows and two B rows feed four MFMAs: one 128-byte operand row
+// from L2 per MFMA) and add their partial sums through LDS in wave order (deterministic).  16 row pairs in flight under the
+// MFMAs of the batch before (two register sets).  History: one wave per 32 x 32 block with a load, wait, MFMA loop was a
+// chain of LK / 2 L2 round trips (99 us at LK = 640, Np = 2048, independent of T -- a fifth of a T/8 shard's Gram-form
+// iteration); a 32 x 32 block per workgroup with the reduction split was L2-bandwidth bound (two operand rows per MFMA,
+// 210 MB per launch: 36 us).
 __global__ __launch_bounds__(256) void gram_w_kernel(const float *HH, const float *Wt, float *out, int LK, int NpH, int Np)
 {
     __shared__ float part[4][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int p0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    f32x16 acc0, acc1;
+    const int p0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const bool p_hi = p0 + 32 < LK; // LK is a multiple of 32, not always of 64: the second p block may not exist
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const float *ap = HH + (size_t)h * NpH + p0 + i;
     const float *bp = Wt + (size_t)h * Np + n0 + i;
-    const int q4 = LK / 4;                       // LK is a multiple of 32
-    const int lo = wave * q4, hi = lo + q4;
-    float av[2][16], bv[2][16];
-    auto load = [&](float (&x)[16], float (&y)[16], int pp0) { // rows pp0 + 2q (+ h), zero beyond this wave's range
+    const int q4 = (LK / 4 + 1) & ~1;            // this wave's share of the reduction rows (even)
+    const int lo = wave * q4, hi = (lo + q4 < LK) ? lo + q4 : LK;
+    constexpr int NB = 8;                        // row pairs per batch
+    float a0[2][NB], a1[2][NB], b0[2][NB], b1[2][NB];
+    auto load = [&](int s, int pp0) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < NB; ++q) {
             const int pp = pp0 + 2 * q;
-            x[q] = pp < hi ? ap[(size_t)pp * NpH] : 0.f;
-            y[q] = pp < hi ? bp[(size_t)pp * Np] : 0.f;
+            const bool ok = pp < hi;
+            a0[s][q] = ok ? ap[(size_t)pp * NpH] : 0.f;
+            a1[s][q] = (ok && p_hi) ? ap[(size_t)pp * NpH + 32] : 0.f;
+            b0[s][q] = ok ? bp[(size_t)pp * Np] : 0.f;
+            b1[s][q] = ok ? bp[(size_t)pp * Np + 32] : 0.f;
         }
     };
-    auto mac = [&](const float (&x)[16], const float (&y)[16]) {
+    auto mac = [&](int s) {
 #pragma unroll
-        for (int q = 0; q < 16; q += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q], y[q], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q + 1], y[q + 1], acc1, 0, 0, 0);
+        for (int q = 0; q < NB; ++q) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s][q], b0[s][q], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s][q], b1[s][q], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][q], b0[s][q], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][q], b1[s][q], acc[1][1], 0, 0, 0);
         }
     };
-    load(av[0], bv[0], lo);
-    for (int pp0 = lo; pp0 < hi; pp0 += 64) {
-        if (pp0 + 32 < hi) load(av[1], bv[1], pp0 + 32);
-        mac(av[0], bv[0]);
-        if (pp0 + 32 < hi) {
-            if (pp0 + 64 < hi) load(av[0], bv[0], pp0 + 64);
-            mac(av[1], bv[1]);
+    if (lo < hi) load(0, lo);
+    for (int pp0 = lo; pp0 < hi; pp0 += 4 * NB) {
+        if (pp0 + 2 * NB < hi) load(1, pp0 + 2 * NB);
+        mac(0);
+        if (pp0 + 2 * NB < hi) {
+            if (pp0 + 4 * NB < hi) load(0, pp0 + 4 * NB);
+            mac(1);
         }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc0[r] + acc1[r];
-    __syncthreads();
-    for (int o = threadIdx.x; o < 16 * 64; o += 256) {
-        const int r = o >> 6, ln = o & 63;
-        const float v = ((part[0][r][ln] + part[1][r][ln]) + part[2][r][ln]) + part[3][r][ln];
-        out[(size_t)(p0 + cmf_crow(r, ln >> 5)) * Np + n0 + (ln & 31)] = v;
-    }
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            __syncthreads(); // (the previous block's partial sums have been consumed)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[a][b][r];
+            __syncthreads();
+            if (a == 0 || p_hi)
+                for (int o = threadIdx.x; o < 16 * 64; o += 256) {
+                    const int r = o >> 6, ln = o & 63;
+                    const float v = ((part[0][r][ln] + part[1][r][ln]) + part[2][r][ln]) + part[3][r][ln];
+                    out[(size_t)(p0 + 32 * a + cmf_crow(r, ln >> 5)) * Np + n0 + 32 * b + (ln & 31)] = v;
+                }
+        }
 }
 
 // out[t][k] = sum_{k',e} taps(t)[k][k'][e] * Ht[k'][PADL + t + e];  taps = GW (full window) or GE (edge columns)

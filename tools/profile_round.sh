@@ -22,5 +22,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_hals_stats -
 echo "hals done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_shard8_stats -o t -- $B --T 6250 --steps 40 --warmup 3 > $out/${tag}_shard8_bench_under_rocprof.json 2> $out/${tag}_shard8_stats.err
 python3 tools/trace_gaps.py $out/${tag}_shard8_stats > $out/${tag}_shard8_timeline.txt
+echo "shard8 done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_gram_shard8_stats -o t -- python3 tools/gram_shard_profile.py 6250 50 1 > $out/${tag}_gram_shard8.txt 2> $out/${tag}_gram_shard8.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_gram_stats -o t -- python3 tools/gram_shard_profile.py 50000 30 1 > $out/${tag}_gram.txt 2> $out/${tag}_gram.err
 if [ -x tools/bin/valu_latency ]; then tools/bin/valu_latency > $out/${tag}_valu_latency.txt; fi
 echo "all done"
