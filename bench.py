@@ -286,7 +286,14 @@ def main():
     import cmf_jl_amd as cmf
 
     lib = cmf.load_library()
-    if form == "multi" and lib.cmf_device_count() < ngpu:
+    # CMF_BENCH_DEVICES="0,0,0,0": rehearse the one-process form on a box with fewer GPUs than shards (the same device may
+    # be listed several times: loopback transport) -- everything of the multi-GPU code path but RCCL itself
+    multi_devices = list(range(ngpu))
+    if form == "multi" and os.environ.get("CMF_BENCH_DEVICES"):
+        multi_devices = [int(x) for x in os.environ["CMF_BENCH_DEVICES"].split(",")]
+        if len(multi_devices) != ngpu:
+            raise SystemExit(f"CMF_BENCH_DEVICES lists {len(multi_devices)} devices, --gpus is {ngpu}")
+    if form == "multi" and lib.cmf_device_count() <= max(multi_devices):
         print(f"bench.py --gpus {ngpu}: only {lib.cmf_device_count()} HIP device(s) visible "
               f"(cmf_last_error: {lib.cmf_last_error().decode() or 'none'})", file=sys.stderr, flush=True)
         sys.exit(2)
@@ -300,7 +307,7 @@ def main():
     overlap_env = os.environ.get("CMF_ALLREDUCE_OVERLAP", "0")
     if alg == "hals":
         # replicas only: the H sweep is one dependent chain along T, nothing to exchange
-        devs = list(range(ngpu)) if form == "multi" else [local_rank]
+        devs = multi_devices if form == "multi" else [local_rank]
         replicas = [cmf.HALSUpdate(data, W0, H0, device=d) for d in devs]
         rule = replicas[0]
     elif form == "single":
@@ -308,7 +315,7 @@ def main():
     elif form == "multi":
         # ONE process, ngpu devices: cmf_create_multi -> RCCL communicators from ncclCommInitAll, a stream per device
         try:
-            rule = cmf.MultUpdate(data, W0, H0, devices=list(range(ngpu)))
+            rule = cmf.MultUpdate(data, W0, H0, devices=multi_devices)
         except cmf.CMFError as e:
             print(f"bench.py --gpus {ngpu}: the {ngpu}-device group could not be formed: {e}", file=sys.stderr, flush=True)
             sys.exit(2)

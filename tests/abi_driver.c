@@ -2,14 +2,19 @@
  * prototypes from the header only, column-major Float64 buffers, status codes + cmf_last_error().
  * TEST INFRASTRUCTURE (built by tests/test_abi_driver.py with `gcc -std=c99 -Wall -Werror -I include`).
  *
- *   abi_driver <in.bin> <out.bin> [ndev]
+ *   abi_driver <in.bin> <out.bin> [ndev] [rule]
+ *   rule: mult (default) | gram (mult with cmf_set_option(h, "gram", 1)) | hals | pgd
  *
  * in.bin  : int64 N, T, K, L, iters; double l1W, l2W, l1H, l2H; data[N*T], W0[K*N*L], H0[K*T]   (Julia memory order)
  * out.bin : double loss[iters + 1] (compute_loss, then update_feature_maps! per iteration), W[K*N*L], H[K*T],
  *           then the same three again from cmf_fit on a fresh handle (loss_hist, W, H)
  * The sequence is the reference's: MultUpdate(data, W, H) (mult.jl:11-20, model.jl:79), compute_loss
  * (alternating.jl:37), then update_motifs! / update_feature_maps! per iteration (alternating.jl:52,54).
- * With ndev > 0 the rule is the T-sharded group on devices 0..ndev-1 (all 0 when only one GPU exists). */
+ * With ndev > 0 the rule is the T-sharded group on devices 0..ndev-1 (all 0 when only one GPU exists).
+ * hals: HALSUpdate (hals.jl:18-42) = cmf_create + cmf_set_factors + "hals_prepare", then cmf_hals_update_motifs /
+ * cmf_hals_update_feature_maps; pgd: PGDUpdate (pgd.jl:112-202) with its defaults -- loss_func = SquareLoss(), constrW =
+ * constrH = NonnegConstraint(), penaltiesW = [SquarePenalty(1)], penaltiesH = [] -- through cmf_pgd_reset /
+ * cmf_pgd_update_motifs / cmf_pgd_update_feature_maps.  Those two rules have no cmf_fit: the second pass repeats the calls. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,6 +40,12 @@ int main(int argc, char **argv)
         return 2;
     }
     const int ndev = argc > 3 ? atoi(argv[3]) : 0;
+    const char *rule = argc > 4 ? argv[4] : "mult";
+    const int is_hals = strcmp(rule, "hals") == 0, is_pgd = strcmp(rule, "pgd") == 0, is_gram = strcmp(rule, "gram") == 0;
+    if (!is_hals && !is_pgd && !is_gram && strcmp(rule, "mult") != 0) {
+        fprintf(stderr, "unknown rule %s\n", rule);
+        return 2;
+    }
     FILE *fi = fopen(argv[1], "rb");
     if (!fi) return 3;
     int64_t dims[5];
@@ -52,6 +63,9 @@ int main(int argc, char **argv)
     if (!fo) return 3;
 
     printf("%s, %d device(s)\n", cmf_version(), cmf_device_count());
+    /* build provenance and interface version, as the header promises them */
+    if (cmf_abi_version() != CMF_ABI_VERSION) return 9;
+    if (strstr(cmf_version(), cmf_source_digest()) == NULL || strlen(cmf_source_digest()) < 7) return 9;
     if (cmf_device_count() < 1) {
         fprintf(stderr, "no HIP device: %s\n", cmf_last_error());
         return 6;
@@ -67,7 +81,30 @@ int main(int argc, char **argv)
         if (ndev > 0) CHECK(cmf_create_multi(&h, ndev, devices, CMF_COMM_AUTO, N, T, K, L, data));
         else CHECK(cmf_create(&h, 0, N, T, K, L, data));
         CHECK(cmf_set_factors(h, W0, H0));
-        if (pass == 0) {
+        if (is_gram) CHECK(cmf_set_option(h, "gram", 1));
+        if (is_hals) CHECK(cmf_set_option(h, "hals_prepare", 1)); /* the rule constructor's scratch, hals.jl:18-28 */
+        if (is_pgd) CHECK(cmf_pgd_reset(h));                      /* stepW = stepH = 5, cur_loss = norm(data): pgd.jl:139-154 */
+        if (is_hals || is_pgd) {
+            CHECK(cmf_compute_loss(h, &loss[0]));
+            for (int64_t it = 0; it < iters; ++it) {
+                if (is_hals) {
+                    CHECK(cmf_hals_update_motifs(h, reg[0], reg[1]));
+                    CHECK(cmf_hals_update_feature_maps(h, reg[2], reg[3], &loss[it + 1]));
+                } else {
+                    CHECK(cmf_pgd_update_motifs(h, 1.0, 0.0, 1));
+                    CHECK(cmf_pgd_update_feature_maps(h, 0.0, 0.0, 1, &loss[it + 1]));
+                }
+            }
+            if (is_hals) {
+                int64_t reruns = -1;
+                CHECK(cmf_get_counter(h, "hals_pipeline_reruns", &reruns));
+                if (reruns != 0) return 9;
+            } else {
+                double sw = 0.0, sh = 0.0;
+                CHECK(cmf_pgd_get_steps(h, &sw, &sh));
+                printf("steps %.17g %.17g\n", sw, sh);
+            }
+        } else if (pass == 0) {
             CHECK(cmf_compute_loss(h, &loss[0]));
             for (int64_t it = 0; it < iters; ++it) {
                 CHECK(cmf_update_motifs(h, reg[0], reg[1]));
@@ -79,6 +116,7 @@ int main(int argc, char **argv)
             CHECK(cmf_fit(h, iters, INFINITY, 0, 3, 1e-4, 0, reg[0], reg[1], reg[2], reg[3], loss, th, &n, &early));
             if (n != iters + 1 || early) return 8;
         }
+        CHECK(cmf_synchronize(h));
         CHECK(cmf_get_factors(h, W, H));
         if (pass == 0) {
             char info[256];

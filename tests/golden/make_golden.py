@@ -35,6 +35,25 @@ def fixture(name, N, T, Ktrue, Ltrue, K, L, max_itr, reg, data_seed=1234, init_s
     print(name, data.shape, "loss", la[0], "->", la[-1])
 
 
+def fixture_rule(name, rule, N, T, Ktrue, Ltrue, K, L, max_itr, data_seed=1234, init_seed=0):
+    """HALS (hals.jl:31-42, 90-154) and PGD (pgd.jl:158-255, default loss / penalties / constraints) fixtures: the C and the
+    numpy restatement must agree before anything is written."""
+    data, _, _ = o.c_gen_synthetic(N=N, T=T, K=Ktrue, L=Ltrue, seed=data_seed)
+    W0, H0 = o.c_init_rand(data, L=L, K=K, seed=init_seed)
+    if rule == "hals":
+        Wa, Ha, la, _ = o.c_fit_hals(data, W0, H0, max_itr=max_itr, check_convergence=False)
+        Wb, Hb, lb, _ = o.fit_hals(data, W0, H0, max_itr=max_itr, check_convergence=False)
+    else:
+        Wa, Ha, la, _ = o.fit_pgd(data, W0, H0, max_itr=max_itr)
+        Wb, Hb, lb, _ = o.c_fit_pgd(data, W0, H0, max_itr=max_itr)
+    np.testing.assert_allclose(la, lb, rtol=1e-9)
+    np.testing.assert_allclose(Wa, Wb, rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(Ha, Hb, rtol=1e-7, atol=1e-11)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), data=data.astype(np.float64), W0=W0, H0=H0, W=Wa, H=Ha, loss_hist=la,
+                        max_itr=max_itr, l1W=0.0, l2W=0.0, l1H=0.0, l2H=0.0, rule=rule)
+    print(name, rule, data.shape, "loss", la[0], "->", la[-1])
+
+
 def main():
     lib = o.c_lib()
     np.savez(
@@ -46,6 +65,8 @@ def main():
     fixture("mu_small_reg", N=48, T=300, Ktrue=3, Ltrue=10, K=4, L=8, max_itr=20,
             reg=dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2))  # README.md:52 values
     fixture("mu_k5", N=70, T=257, Ktrue=3, Ltrue=20, K=5, L=10, max_itr=10, reg={})  # config-1 K,L at reduced N,T
+    fixture_rule("hals_small", "hals", N=48, T=300, Ktrue=3, Ltrue=10, K=4, L=8, max_itr=8)
+    fixture_rule("pgd_small", "pgd", N=48, T=300, Ktrue=3, Ltrue=10, K=4, L=8, max_itr=10)
 
 
 if __name__ == "__main__":

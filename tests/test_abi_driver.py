@@ -37,7 +37,7 @@ def test_header_compiles_as_c99_and_driver_links(tmp_path):
     assert p.returncode == 2 and "usage" in p.stderr  # runs far enough to load the library
 
 
-def _run(exe, tmp_path, fixture, ndev):
+def _run(exe, tmp_path, fixture, ndev, rule="mult"):
     d = np.load(os.path.join(HERE, "golden", fixture))
     data, W0, H0 = (np.asfortranarray(d[k]) for k in ("data", "W0", "H0"))
     K, N, L = W0.shape
@@ -48,7 +48,7 @@ def _run(exe, tmp_path, fixture, ndev):
         f.write(struct.pack("<5q4d", N, T, K, L, iters, float(d["l1W"]), float(d["l2W"]), float(d["l1H"]), float(d["l2H"])))
         for a in (data, W0, H0):
             f.write(a.tobytes(order="F"))  # Julia memory order
-    p = subprocess.run([exe, fin, fout] + ([str(ndev)] if ndev else []), capture_output=True, text=True, timeout=300)
+    p = subprocess.run([exe, fin, fout, str(ndev), rule], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     raw = np.fromfile(fout, dtype=np.float64)
     per = iters + 1 + W0.size + H0.size
@@ -75,3 +75,21 @@ def test_c_driver_reproduces_golden_fixture(tmp_path, fixture, ndev):
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
     if ndev:
         assert f"nranks={ndev}" in log
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,ndev,rule", [("hals_small.npz", 0, "hals"), ("pgd_small.npz", 0, "pgd"), ("pgd_small.npz", 2, "pgd"),
+                                               ("mu_small_reg.npz", 0, "gram"), ("mu_small.npz", 3, "gram")])
+def test_c_driver_other_rules(tmp_path, fixture, ndev, rule):
+    """The HALS and PGD entries and the Gram option through the header from C99, against the committed fixtures (HALS:
+    hals.jl:31-42; PGD: pgd.jl:158-202 with its defaults, also as a 2-shard group; Gram form: the MU fixtures, also sharded)."""
+    exe = build_driver(tmp_path)
+    d, outs, log = _run(exe, tmp_path, fixture, ndev, rule)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    for loss, W, H in outs:
+        np.testing.assert_allclose(loss, d["loss_hist"], rtol=1e-4)
+        assert rel(W, d["W"]) < 1e-4 and rel(H, d["H"]) < 1e-4
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])  # the two passes repeat the same arithmetic
+    if ndev:
+        assert f"nranks={ndev}" in log
+    assert "abi=3" in log and "src=" in log

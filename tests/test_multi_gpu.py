@@ -146,3 +146,31 @@ def test_bench_plain_multi_gpu_launch_reports_missing_devices():
     assert p.returncode == 2
     assert f"only {have} HIP device" in p.stderr.decode()
     assert p.stdout.decode().strip() == ""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,config,extras", [(4, 2, "1"), (2, 5, "0")])
+def test_bench_multi_form_rehearsal_on_one_gpu(n, config, extras):
+    """The one-process form of `bench.py --gpus n` on THIS box: CMF_BENCH_DEVICES lists GPU 0 n times (loopback transport),
+    so every line of the multi-GPU branch of bench.py runs -- routing, group construction, timing over all shards' streams,
+    the comm record, the opt-in Gram side measurement, HALS replicas -- except RCCL itself."""
+    env = dict(os.environ, CMF_BENCH_DEVICES=",".join(["0"] * n), CMF_BENCH_GROUP_EXTRAS=extras)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    args = ["--gpus", str(n), "--steps", "3", "--warmup", "1", "--sustain", "0", "--config", str(config)]
+    if config == 2:
+        args += ["--T", "8000"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == n and line["config"]["launch"] == "multi" and line["value"] > 0
+    if config == 2:
+        assert line["comm"]["transport"] == "loopback" and line["comm"]["nranks"] == n and line["comm"]["devices"] == [0] * n
+        assert line["scaling"] == "strong" and line["roofline"]["frac"] > 0
+        ge = line["group_extras"]
+        assert "error" not in ge and ge["ms_per_step_gram"] > 0 and ge["ms_per_step_gram_overlap"] > 0
+        assert abs(ge["loss_last_gram"] - ge["loss_last_gram_overlap"]) <= 1e-6 * ge["loss_last_gram"]
+    else:
+        assert line["comm"]["mode"] == "replicas" and line["comm"]["nranks"] == n and line["scaling"] == "weak"
+        assert line["roofline"]["bound"] == "dependency-latency"

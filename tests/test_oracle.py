@@ -189,6 +189,25 @@ def test_rng_known_answers(oracle):
     np.testing.assert_allclose(np.asarray(gotn), kat["normal_seed1234_stream16"][:4], rtol=1e-14)
 
 
+@pytest.mark.parametrize("name,rule", [("hals_small", "hals"), ("pgd_small", "pgd")])
+def test_golden_fixtures_hals_pgd(oracle, name, rule):
+    """Both restatements of the HALS and PGD rules reproduce their committed fixtures."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert str(g["rule"]) == rule
+    n = int(g["max_itr"])
+    if rule == "hals":
+        fits = (lambda: oracle.c_fit_hals(g["data"], g["W0"], g["H0"], max_itr=n, check_convergence=False),
+                lambda: oracle.fit_hals(g["data"], g["W0"], g["H0"], max_itr=n, check_convergence=False))
+    else:
+        fits = (lambda: oracle.fit_pgd(g["data"], g["W0"], g["H0"], max_itr=n),
+                lambda: oracle.c_fit_pgd(g["data"], g["W0"], g["H0"], max_itr=n))
+    for fit in fits:
+        W, H, lh, _ = fit()
+        np.testing.assert_allclose(lh, g["loss_hist"], rtol=1e-9)
+        np.testing.assert_allclose(W, g["W"], rtol=1e-7, atol=1e-11)
+        np.testing.assert_allclose(H, g["H"], rtol=1e-7, atol=1e-11)
+
+
 @pytest.mark.parametrize("name", ["mu_small", "mu_small_reg", "mu_k5"])
 def test_golden_fixtures(oracle, name):
     """Both restatements reproduce the committed fixtures (tests/golden/make_golden.py)."""
