@@ -144,6 +144,8 @@ mutable struct HIPPGDUpdate <: AbstractCFUpdate
     mask_id::UInt            # objectid of the mask currently resident on the device (0 = none)
     loss_kind::Cint          # 0 SquareLoss, 1 AbsoluteLoss (cmf_pgd_set_loss)
 end
+# `devices=0:7` shards T over several GPUs like HIPMultUpdate does (one all-reduce of the partial gradW per iteration;
+# MaskedLoss masks are cut along T by the library)
 function HIPPGDUpdate(data, W, H; kwargs...)
     rule = HIPPGDUpdate(HIPMultUpdate(data, W, H; kwargs...), UInt(0), Cint(0))
     check(ccall((:cmf_pgd_reset, LIBCMF), Cint, (Ptr{Cvoid},), rule.inner.handle))

@@ -174,3 +174,32 @@ def test_bench_multi_form_rehearsal_on_one_gpu(n, config, extras):
     else:
         assert line["comm"]["mode"] == "replicas" and line["comm"]["nranks"] == n and line["scaling"] == "weak"
         assert line["roofline"]["bound"] == "dependency-latency"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["host", "rccl"])
+def test_bench_ranks_form_rehearsal_on_one_gpu(transport):
+    """The launcher form (`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`) on THIS box: two gloo ranks share
+    GPU 0.  transport = host: the library's collectives go through the callbacks; transport = rccl: RCCL cannot put two ranks
+    of a communicator on one device, every rank learns of it in the agreed attach and all fall back together -- the run
+    still delivers its line, and `comm` says what happened."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, CMF_DIST_BACKEND="gloo", CMF_TRANSPORT=transport, OMP_NUM_THREADS="4")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--sustain", "0",
+           "--T", "8000"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["launch"] == "ranks" and line["value"] > 0
+    assert line["comm"]["mode"] == "one-process-per-gpu" and line["comm"]["transport"] == "callbacks" and line["comm"]["nranks"] == 2
+    assert ("fallback_from_rccl" in line["comm"]) == (transport == "rccl")
