@@ -194,7 +194,12 @@ int cmf_compute_loss(cmf_handle h, double *loss);
  * doubles; *n_hist receives the number of entries written (iterations + 1);
  * *converged_early is 1 when the loop stopped on `converged` (:63-66; the
  * host wrapper prints "Converged early." like the reference).
- * Valid on single-GPU and group handles (on a group with a finite max_time every rank follows rank 0's clock). */
+ * Valid on single-GPU and group handles (on a group with a finite max_time every rank follows rank 0's clock).
+ * time_hist: with a stop test armed (check_convergence != 0 or a finite max_time) entry i is the reference's cumulative
+ * wall-clock time around the two rule calls of iteration i (alternating.jl:49,57-58).  When neither test can fire the loop runs
+ * as ONE pipelined cmf_iterate batch and entry i is the moment iteration i's loss reached the host -- about half an iteration
+ * after that iteration's kernels finished, because the loss rides on the next W phase; the differences between consecutive
+ * entries are still the per-iteration durations in steady state, and the last entry is the batch's total time. */
 int cmf_fit(cmf_handle h, int64_t max_itr, double max_time,
             int check_convergence, int64_t patience, double tol, int eval_mode,
             double l1W, double l2W, double l1H, double l2H,
