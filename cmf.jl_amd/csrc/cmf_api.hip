@@ -2432,6 +2432,51 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
     const double S = (double)d.L * d.Tl - 0.5 * (double)d.L * (d.L - 1);
     const double f1 = 2.0 * d.K * d.N * S; // one contraction
     std::string nm(name);
+    if (nm == "pair_conv_tc" || nm == "seq_conv_tc" || nm == "pair_loss_hxt" || nm == "seq_loss_hxt") {
+        // Experiment: two INDEPENDENT contractions of an iteration -- conv_t and numH = transconv(W, data),
+        // or the loss conv and numW = hxt(data) -- on two streams at once ("pair_") against one after the other ("seq_"):
+        // does the second kernel fill the first one's drain, or does sharing the chip break their static work splits?
+        const bool pair = nm[0] == 'p', first = nm.find("conv_tc") != std::string::npos;
+        hipStream_t aux = nullptr, keep = h->stream;
+        hipEvent_t fork = nullptr, join = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        auto once = [&]() -> int {
+            if (pair) {
+                HIPCHK(hipEventRecord(fork, keep));
+                HIPCHK(hipStreamWaitEvent(aux, fork, 0));
+            }
+            CMFTRY(first ? launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext) : launch_conv<3>(h, h->est, d.Tl, h->conv_gy));
+            h->stream = pair ? aux : keep;
+            int rc = first ? launch_transconv(h, 1, h->XT)
+                           : launch_hxt_on(h, h->X, h->X, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1, h->hxt_main1);
+            h->stream = keep;
+            CMFTRY(rc);
+            if (pair) {
+                HIPCHK(hipEventRecord(join, aux));
+                HIPCHK(hipStreamWaitEvent(keep, join, 0));
+            }
+            return CMF_OK;
+        };
+        int rc = once();
+        if (rc == CMF_OK) {
+            HIPCHK(hipEventRecord(h->ev0, keep));
+            for (int r = 0; r < reps && rc == CMF_OK; ++r) rc = once();
+            HIPCHK(hipEventRecord(h->ev1, keep));
+            HIPCHK(hipEventSynchronize(h->ev1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+            *avg_ms = (double)ms / reps;
+            *flops = 2.0 * f1;
+        }
+        (void)hipStreamSynchronize(aux);
+        (void)hipStreamDestroy(aux);
+        (void)hipEventDestroy(fork);
+        (void)hipEventDestroy(join);
+        h->est_kind = 0;
+        return rc;
+    }
     int which = nm == "conv" ? 0 : nm == "hxt" ? 1 : nm == "transconv" ? 2 : nm == "conv_t" ? 3 : nm == "conv_loss" ? 4
               : nm == "conv_loss_store" ? 5 : -1;
     if (which < 0) return fail(CMF_ERR_ARG, "unknown kernel '%s'", name);
