@@ -2088,12 +2088,11 @@ static int group_sum_doubles(cmf_group_s *g, const std::vector<double *> &ptr, i
             for (size_t i = 0; i < nl; ++i)
                 if (g->rank[i] == r)
                     for (int j = 0; j < n; ++j) total[(size_t)j] += local[i][(size_t)j];
-    } else {
-        for (int j = 0; j < n; ++j) { // (n is 1, or K for UnitNormConstraint: a handful of 8-byte all-gathers)
-            std::vector<double> mine(1, local[0][(size_t)j]), all;
-            CMFTRY(group_gather_doubles(g, mine, all));
-            for (double v : all) total[(size_t)j] += v;
-        }
+    } else { // one all-gather of n doubles per rank, summed in rank order
+        std::vector<double> all;
+        CMFTRY(group_gather_doubles(g, local[0], all, n));
+        for (int r = 0; r < g->nranks; ++r)
+            for (int j = 0; j < n; ++j) total[(size_t)j] += all[(size_t)r * n + j];
     }
     for (size_t i = 0; i < nl; ++i) {
         cmf_handle_s *s = g->sh[i];

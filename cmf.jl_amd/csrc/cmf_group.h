@@ -136,6 +136,8 @@ struct cmf_group_s {
     // loopback with one stream PER SHARD (CMF_COMM_LOOPBACK_STREAMS): the collectives keep RCCL's stream semantics -- the
     // operation starts when every shard's stream has reached it and every shard's stream continues when it is done --
     // through events, so a missing dependency between shards cannot hide behind a shared stream (tests on a one-GPU box)
+    std::vector<float *> gbuf;           // scratch of group_gather_doubles (one per local shard)
+    size_t gbuf_words = 0;
     bool loop_ms = false;
     hipEvent_t ev_in[2][CMF_MAX_LOCAL] = {};  // [main | comm stream][shard]
     hipEvent_t ev_out[2] = {nullptr, nullptr};
@@ -325,35 +327,43 @@ static double group_decode_tail(const cmf_group_s *g, const float *tail)
     return s;
 }
 
-// One double per rank -> all of them on every rank (exact: the bytes travel through the all-gather as float pairs).
-// Every local shard contributes vals[i]; out[r] for all ranks.  Synchronises.
-static int group_gather_doubles(cmf_group_s *g, const std::vector<double> &vals, std::vector<double> &out)
+// n doubles per rank -> all of them on every rank (exact: the 8 bytes of a double travel through the all-gather as two
+// 32-bit words).  Every local shard contributes vals[i*n .. i*n+n); out[r*n + j] for all ranks r.  Synchronises.
+static int group_gather_doubles(cmf_group_s *g, const std::vector<double> &vals, std::vector<double> &out, int n = 1)
 {
     const size_t nl = g->sh.size();
-    out.assign((size_t)g->nranks, 0.0);
+    out.assign((size_t)g->nranks * n, 0.0);
     if (g->one_process) { // all ranks are local: no transport needed
-        for (size_t i = 0; i < nl; ++i) out[(size_t)g->rank[i]] = vals[i];
+        for (size_t i = 0; i < nl; ++i)
+            for (int j = 0; j < n; ++j) out[(size_t)g->rank[i] * n + j] = vals[i * n + j];
         return CMF_OK;
     }
-    // two floats per rank cannot hold an arbitrary double exactly: send the 8 bytes as two 32-bit words instead
+    const size_t words = (size_t)2 * n; // floats per rank
+    if (g->gbuf.size() != nl || g->gbuf_words < words) { // [gathered (nranks * words) | send (words)] per local shard
+        for (size_t i = 0; i < g->gbuf.size(); ++i)
+            if (g->gbuf[i]) { (void)hipSetDevice(g->sh[i]->device); (void)hipFree(g->gbuf[i]); }
+        g->gbuf.assign(nl, nullptr);
+        g->gbuf_words = 0;
+        for (size_t i = 0; i < nl; ++i) {
+            CMFTRY(group_use(g->sh[i]));
+            CMFTRY(dalloc_zero(&g->gbuf[i], (size_t)(g->nranks + 1) * words));
+        }
+        g->gbuf_words = words;
+    }
     std::vector<float *> send(nl), recv(nl);
     for (size_t i = 0; i < nl; ++i) {
         cmf_handle_s *s = g->sh[i];
         CMFTRY(group_use(s));
-        float w[2];
-        std::memcpy(w, &vals[i], 8);
-        HIPCHK(hipMemcpyAsync(g->loss_all[i] + g->tail, w, 8, hipMemcpyHostToDevice, s->stream));
+        recv[i] = g->gbuf[i];
+        send[i] = g->gbuf[i] + (size_t)g->nranks * g->gbuf_words;
+        HIPCHK(hipMemcpyAsync(send[i], vals.data() + i * n, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
-        send[i] = g->loss_all[i] + g->tail;
-        recv[i] = g->loss_all[i];
     }
-    CMFTRY(group_allgather(g, send, 0, recv, 2));
+    CMFTRY(group_allgather(g, send, 0, recv, words));
     cmf_handle_s *s = g->sh[0];
     CMFTRY(group_use(s));
-    std::vector<float> hostw((size_t)2 * g->nranks);
-    HIPCHK(hipMemcpyAsync(hostw.data(), recv[0], hostw.size() * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(out.data(), recv[0], (size_t)g->nranks * n * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    for (int r = 0; r < g->nranks; ++r) std::memcpy(&out[(size_t)r], &hostw[(size_t)2 * r], 8);
     return CMF_OK;
 }
 
@@ -643,6 +653,8 @@ static void group_destroy(cmf_group_s *g)
     }
     if (g->h_tail) (void)hipHostFree(g->h_tail);
     if (g->cb_host) (void)hipHostFree(g->cb_host);
+    for (size_t i = 0; i < g->gbuf.size() && i < g->sh.size(); ++i)
+        if (g->gbuf[i]) { (void)hipSetDevice(g->sh[i]->device); (void)hipFree(g->gbuf[i]); }
     for (int c = 0; c < 2; ++c) {
         for (hipEvent_t e : g->ev_in[c])
             if (e) (void)hipEventDestroy(e);

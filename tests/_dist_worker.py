@@ -51,10 +51,13 @@ def main():
         lf = None
         if engine.endswith("masked"):
             lf = cmf.MaskedLoss(cmf.SquareLoss(), (np.random.default_rng(5).uniform(size=data.shape) > 0.25).astype(float))
+        kwW, kwH = {}, {}
+        if engine.endswith("unitnorm"):  # the component norms of H run over ALL shards (K doubles gathered per H phase)
+            kwW, kwH = dict(constrW=cmf.UnitNormConstraint()), dict(constrH=cmf.UnitNormConstraint())
         losses = [rule.compute_loss()]
         for _ in range(iters):
-            rule.update_motifs(loss_func=lf)
-            losses.append(rule.update_feature_maps(loss_func=lf))
+            rule.update_motifs(loss_func=lf, **kwW)
+            losses.append(rule.update_feature_maps(loss_func=lf, **kwH))
         W, H = rule.download()
         steps = rule.steps
         rule.close()

@@ -203,17 +203,18 @@ def test_group_pgd_refuses_mu_only_options(cmf):
     rule.close()
 
 
-@pytest.mark.parametrize("world,masked", [(2, False), (3, True)])
-def test_sharded_processes_pgd(oracle, tmp_path, world, masked):
+@pytest.mark.parametrize("world,masked,unitnorm", [(2, False, False), (3, True, False), (2, False, True)])
+def test_sharded_processes_pgd(oracle, tmp_path, world, masked, unitnorm):
     """ShardedPGDUpdate: one process per shard (gloo ranks sharing GPU 0, the library's collectives through the host
     callbacks), optionally with a MaskedLoss whose GLOBAL mask every rank cuts to its block."""
     N, T, K, L, iters = 65, 400, 5, 10, 5
     out = str(tmp_path / "res.npz")
-    got = run_ranks(world, "hip_pgd_masked" if masked else "hip_pgd", out, N, T, K, L, iters, 0)
+    got = run_ranks(world, "hip_pgd_masked" if masked else ("hip_pgd_unitnorm" if unitnorm else "hip_pgd"), out, N, T, K, L, iters, 0)
     data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=1234)
     W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
     mask = (np.random.default_rng(5).uniform(size=data.shape) > 0.25).astype(float) if masked else None
-    Wr, Hr, lr, sr = oracle.fit_pgd(data, W0, H0, max_itr=iters, mask=mask)
+    cons = dict(constrW="unitnorm", constrH="unitnorm") if unitnorm else {}
+    Wr, Hr, lr, sr = oracle.fit_pgd(data, W0, H0, max_itr=iters, mask=mask, **cons)
     np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
     assert frob_rel(got["W"], Wr) < 1e-4 and frob_rel(got["H"], Hr) < 1e-4
     np.testing.assert_allclose(got["steps"], sr, rtol=1e-12)
