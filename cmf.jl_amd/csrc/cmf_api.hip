@@ -2039,11 +2039,19 @@ static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
     if (nonneg < 0 || nonneg > 2) return fail(CMF_ERR_ARG, "constraint must be 0 (none), 1 (NonnegConstraint) or 2 (UnitNormConstraint)");
     const float gscale = h->pgd_loss_abs ? 1.f : 2.f;
     if (!h->pgd_gradH) CMFTRY(dalloc_zero(&h->pgd_gradH, (size_t)d.Tl * d.K32));
-    h->pgd_loss_abs_now = h->pgd_loss_abs;
-    int rc_conv = h->MT ? launch_conv<7>(h, h->estT, d.Tl, h->conv_gy, h->XT) // (mask .* resid)^T (pgd.jl:64-67)
-                        : launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT); // resid^T (pgd.jl:230), or its sign (pgd.jl:42-44)
-    h->pgd_loss_abs_now = 0;
-    CMFTRY(rc_conv);
+    static const bool no_transpose = getenv("CMF_PGD_TRANSPOSE") && atoi(getenv("CMF_PGD_TRANSPOSE")) == 0; // measurement knob
+    if (!no_transpose && h->est_kind == 2 + (h->M ? 1 : 0) + (h->pgd_loss_abs ? 2 : 0)) {
+        // est already holds this residual for the resident W, H (stored by the conv that closed the W phase, pgd.jl:245): the
+        // H phase's est of pgd.jl:230 is the same array, only tensor_transconv wants it transposed
+        hipLaunchKernelGGL(transpose_rows_kernel, dim3(d.Np / 64, (d.Tl + 63) / 64), dim3(256), 0, h->stream, h->est, h->estT, d.Tl, d.Np, d.TP, d.PADL);
+        KCHK("transpose_rows_kernel");
+    } else {
+        h->pgd_loss_abs_now = h->pgd_loss_abs;
+        int rc_conv = h->MT ? launch_conv<7>(h, h->estT, d.Tl, h->conv_gy, h->XT) // (mask .* resid)^T (pgd.jl:64-67)
+                            : launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT); // resid^T (pgd.jl:230), or its sign (pgd.jl:42-44)
+        h->pgd_loss_abs_now = 0;
+        CMFTRY(rc_conv);
+    }
     CMFTRY(launch_transconv(h, 1, h->estT));                     // pgd.jl:218-221
     dim3 grid((d.Tl + 63) / 64, d.KB);
     const int nblk = ((d.Tl + 63) / 64) * d.KB;
@@ -2178,12 +2186,25 @@ static int group_pgd_h(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double p
         const CmfDims &d = s->d;
         CMFTRY(group_use(s));
         if (!s->pgd_gradH) CMFTRY(dalloc_zero(&s->pgd_gradH, (size_t)d.Tl * d.K32));
-        s->pgd_loss_abs_now = st->pgd_loss_abs;
         // the transposed residual on the shard's columns AND its right lag halo (transconv reads est[:, t .. t+L-1])
-        int rc_conv = s->MT ? launch_conv<7>(s, s->estT, d.Tl + s->halo_r, s->conv_gy_ext, s->XT)
-                            : launch_conv<5>(s, s->estT, d.Tl + s->halo_r, s->conv_gy_ext, s->XT);
-        s->pgd_loss_abs_now = 0;
-        CMFTRY(rc_conv);
+        static const bool no_transpose = getenv("CMF_PGD_TRANSPOSE") && atoi(getenv("CMF_PGD_TRANSPOSE")) == 0; // measurement knob
+        if (!no_transpose && s->est_kind == 2 + (s->M ? 1 : 0) + (st->pgd_loss_abs ? 2 : 0)) {
+            // the shard's own columns are in est already (the conv that closed the W phase): transposed, not convolved again;
+            // the <= L-1 halo columns are formed directly (resid_halo_kernel)
+            hipLaunchKernelGGL(transpose_rows_kernel, dim3(d.Np / 64, (d.Tl + 63) / 64), dim3(256), 0, s->stream, s->est, s->estT, d.Tl, d.Np, d.TP, d.PADL);
+            KCHK("transpose_rows_kernel");
+            if (s->halo_r > 0) {
+                hipLaunchKernelGGL(resid_halo_kernel, dim3(d.Np / 128, s->halo_r), dim3(128), 0, s->stream, s->Wt, s->H, s->XT, s->MT, s->estT,
+                                   d.Tl, d.K, d.L, d.K32, d.Np, d.TP, d.PADL, st->pgd_loss_abs);
+                KCHK("resid_halo_kernel");
+            }
+        } else {
+            s->pgd_loss_abs_now = st->pgd_loss_abs;
+            int rc_conv = s->MT ? launch_conv<7>(s, s->estT, d.Tl + s->halo_r, s->conv_gy_ext, s->XT)
+                                : launch_conv<5>(s, s->estT, d.Tl + s->halo_r, s->conv_gy_ext, s->XT);
+            s->pgd_loss_abs_now = 0;
+            CMFTRY(rc_conv);
+        }
         CMFTRY(launch_transconv(s, 1, s->estT));                                                         // pgd.jl:218-221
         dim3 grid((d.Tl + 63) / 64, d.KB);
         const int nblk = ((d.Tl + 63) / 64) * d.KB;

@@ -2610,6 +2610,53 @@ __global__ __launch_bounds__(256) void hals_h_push_gen_kernel(float *PT, const f
 // =============================================================================================
 __device__ __forceinline__ float cmf_sign(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
+// outT[n][PADL + t] = in[PADL + t][n] for t < Tl, all Np columns: the stored residual (est - data, masked, or its sign) in the
+// layout tensor_transconv wants.  The H phase of a PGD iteration needs exactly the residual the W phase's closing conv has
+// just stored (same W, same H; pgd.jl:245 and :230), so it is transposed (0.8 GB of traffic) instead of convolved again.
+// grid (Np / 64, ceil(Tl / 64)), block 256
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const float *in, float *outT, int Tl, int Np, int TP, int PADL)
+{
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * 64, t0 = blockIdx.y * 64;
+    {
+        const int nn = tid & 63;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int tt = q * 4 + (tid >> 6), t = t0 + tt;
+            tile[tt][nn] = (t < Tl) ? in[(size_t)(PADL + t) * Np + n0 + nn] : 0.f;
+        }
+    }
+    __syncthreads();
+    {
+        const int tt = tid & 63, t = t0 + tt;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int nn = q * 4 + (tid >> 6);
+            if (t < Tl) outT[(size_t)(n0 + nn) * TP + PADL + t] = tile[tt][nn];
+        }
+    }
+}
+
+// ... and on a T-shard the right lag halo of that transposed residual (columns Tl .. Tl + halo - 1, which the stored [t][n]
+// residual must not hold: the C2 kernel reads the rows behind Tl as zero padding): est there from W and the H halo directly,
+// minus the data halo, masked / as a sign like the conv epilogue does it.  halo <= L - 1 columns: 2*K*L FMAs per output.
+// grid (Np / 128, halo), block 128
+__global__ __launch_bounds__(128) void resid_halo_kernel(const float *Wt, const float *H, const float *XT, const float *MT, float *outT,
+                                                          int Tl, int K, int L, int K32, int Np, int TP, int PADL, int loss_abs)
+{
+    const int n = blockIdx.x * 128 + threadIdx.x, t = Tl + blockIdx.y;
+    float v = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const float *hrow = H + (size_t)(PADL + t - l) * K32; // (rows in front of the shard are its left halo / zero padding)
+        const float *wrow = Wt + (size_t)l * K32 * Np + n;
+        for (int k = 0; k < K; ++k) v = fmaf(wrow[(size_t)k * Np], hrow[k], v);
+    }
+    const size_t at = (size_t)n * TP + PADL + t;
+    const float dv = XT[at], m = MT ? MT[at] : 1.f;
+    outT[at] = loss_abs ? ((v > dv) ? m : ((v < dv) ? -m : 0.f)) : (v - dv) * m;
+}
+
 // grad[idx] = gscale*G + 2*pen_sq*w + pen_abs*sign(w) over the valid entries of the Wt layout (gscale: 2 for SquareLoss,
 // whose stored residual is est - data; 1 for AbsoluteLoss, whose stored quantity already is the gradient sign(est - data));
 // block partials of sum(g^2).  grid (Np/64, KB, L), block 256
