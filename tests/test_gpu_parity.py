@@ -425,6 +425,31 @@ def test_hals_general_sweeps_agree_with_the_on_chip_sweeps(cmf, oracle, N, T, K,
     assert frob_rel(out["3"][1], out["0"][1]) < 5e-5 and frob_rel(out["3"][2], out["0"][2]) < 5e-5
 
 
+@pytest.mark.parametrize("N,T,K,L", [(1, 64, 1, 1), (2, 3, 2, 5), (31, 65, 5, 2), (65, 129, 17, 19), (129, 200, 33, 33), (64, 40, 2, 40),
+                                     (200, 513, 31, 7), (63, 127, 64, 3)])
+def test_hals_general_sweeps_on_ragged_shapes(cmf, oracle, N, T, K, L):
+    """The general sweeps (forced) on ragged shapes -- single units and components, L = 1, T < L, K and L around the 32-wide
+    blocks -- two iterations against the oracle."""
+    import os
+
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20) if L > 1 else 2, seed=9)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=4)
+    os.environ["CMF_HALS_GENERAL"] = "3"
+    try:
+        rule = cmf.HALSUpdate(data, W0, H0)
+    finally:
+        os.environ.pop("CMF_HALS_GENERAL", None)
+    ls = []
+    for _ in range(2):
+        rule.update_motifs(l1W=0.05, l2W=0.1)
+        ls.append(rule.update_feature_maps(l1H=0.05, l2H=0.1))
+    Wg, Hg = rule.download()
+    rule.close()
+    Wr, Hr, lh, _ = oracle.c_fit_hals(data, W0, H0, max_itr=2, check_convergence=False, l1W=0.05, l2W=0.1, l1H=0.05, l2H=0.1)
+    np.testing.assert_allclose(ls, lh[1:], rtol=REL_LOSS)
+    assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
+
+
 def test_hals_fit_against_oracle(cmf, oracle):
     data, _, _ = oracle.c_gen_synthetic(N=120, T=1200, K=3, L=20, seed=1234)
     W0, H0 = oracle.c_init_rand(data, L=20, K=8, seed=0)

@@ -294,3 +294,54 @@ def test_config2_eight_shards_with_a_stream_per_shard(cmf):
             np.testing.assert_array_equal(r[4], out[0][4])
     np.testing.assert_array_equal(out[1][2], out[3][2])  # overlap form: streams vs shared stream
     np.testing.assert_array_equal(out[1][3], out[3][3])
+
+
+# ---- seeded ragged shapes through every group rule ---------------------------------------------------------------------
+def _ragged_group_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    shapes = []
+    while len(shapes) < n:
+        K = int(rng.choice([1, 2, 5, 17, 31, 32, 33, 64]))
+        L = int(rng.choice([1, 2, 3, 7, 19, 20, 31, 32, 33, 40]))
+        N = int(rng.choice([1, 2, 31, 63, 64, 65, 127, 128, 129, 200]))
+        R = int(rng.choice([2, 3, 4, 5, 8]))
+        T = int(rng.choice([64, 127, 128, 129, 300, 511, 513, 700, 1100]))
+        if -(-T // R) >= max(L - 1, 1) and T - (R - 1) * -(-T // R) >= max(L - 1, 1):  # every shard holds >= L-1 columns
+            shapes.append((R, N, T, K, L))
+    return shapes
+
+
+@pytest.mark.parametrize("R,N,T,K,L", _ragged_group_shapes(14, 2024))
+def test_group_rules_on_ragged_shapes(cmf, oracle, R, N, T, K, L):
+    """Every group rule -- MU in the reference formulation, its Gram form (where T >= 4 L), PGD with a mask -- on seeded
+    ragged shapes (K and L around the 32-wide blocks, N and T around the tile edges, uneven last shards), stream per shard,
+    against the oracle."""
+    from cmf_jl_amd import _lib
+
+    data, W0, H0 = _pgd_problem(oracle, N, T, K, L, seed=77)
+    iters = 3
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False, **REG)
+    for gram in (0, 1):
+        if gram and T < 4 * L:
+            continue
+        rule = cmf.MultUpdate(data, W0, H0, devices=[0] * R, transport=_lib.CMF_COMM_LOOPBACK_STREAMS)
+        if gram:
+            rule.set_option("gram", 1)
+        ls, W, H = _mu(rule, "iterate", iters, REG)
+        rule.close()
+        np.testing.assert_allclose(ls, lr, rtol=1e-4, err_msg=f"gram={gram}")
+        assert frob_rel(W, Wr) < 1e-4 and frob_rel(H, Hr) < 1e-4, (gram, frob_rel(W, Wr), frob_rel(H, Hr))
+    mask = (np.random.default_rng(5).uniform(size=data.shape) > 0.25).astype(float)
+    lf = cmf.MaskedLoss(cmf.SquareLoss(), mask)
+    rule = cmf.PGDUpdate(data, W0, H0, devices=[0] * R, transport=_lib.CMF_COMM_LOOPBACK_STREAMS)
+    lg = []
+    for _ in range(iters):
+        rule.update_motifs(loss_func=lf)
+        lg.append(rule.update_feature_maps(loss_func=lf))
+    Wg, Hg = rule.download()
+    sg = rule.steps
+    rule.close()
+    Wo, Ho, lo, so = oracle.fit_pgd(data, W0, H0, max_itr=iters, mask=mask)
+    np.testing.assert_allclose(lg, lo[1:], rtol=1e-4)
+    assert frob_rel(Wg, Wo) < 1e-4 and frob_rel(Hg, Ho) < 1e-4
+    np.testing.assert_allclose(sg, so, rtol=1e-12)
