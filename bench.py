@@ -460,6 +460,18 @@ def main():
         rule.set_option("gram", 0)
         rule.set_overlap(keep_overlap)
 
+    # the group's bulk exchange alone (every rank takes part: it is a collective), so that the record says how much of a
+    # step is communication
+    allreduce = None
+    if sharded:
+        try:
+            ar_ms, ar_bytes = rule.time_kernel("allreduce", reps=10)
+            allreduce = {"avg_ms": ar_ms, "bytes": ar_bytes, "algbw_GBps": ar_bytes / ar_ms / 1e6 if ar_ms > 0 else None,
+                         "busbw_GBps": (ar_bytes / ar_ms / 1e6) * 2.0 * (ngpu - 1) / ngpu if ar_ms > 0 else None,
+                         "payload": "[numW | denomW | loss tail]: what one iteration all-reduces"}
+        except Exception as e:  # noqa: BLE001
+            allreduce = {"error": repr(e)}
+
     out = None
     nrep_hals = len(replicas) if form == "multi" else (world if alg == "hals" else 1)
     if rank == 0:
@@ -480,6 +492,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 comm["rccl"] = {"error": repr(e)}
             comm["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+            comm["allreduce"] = allreduce
         else:
             comm = None
         out = {

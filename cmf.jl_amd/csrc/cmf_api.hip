@@ -2446,6 +2446,33 @@ int cmf_kernel_times(cmf_handle h, const char *name, double *avg_ms, int64_t *la
 int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, double *flops)
 {
     if (!name || !avg_ms || !flops || reps < 1) return fail(CMF_ERR_ARG, "bad argument");
+    if (h && h->group && std::strcmp(name, "allreduce") == 0) {
+        // The group's bulk exchange alone: `reps` all-reduces of the buffer an iteration sends ([numW | denomW | tail], or
+        // [numW | HH | tail] in the Gram form), timed with events on shard 0's stream.  EVERY rank of the group must make this
+        // call (it is a collective).  *flops receives the payload in bytes.  The buffer's contents are scratch between iterations.
+        cmf_group_s *g = h->group;
+        CMFTRY(group_check_ready(g));
+        CMFTRY(group_sync(g));
+        cmf_handle_s *s0 = g->sh[0];
+        const size_t count = group_tail_off(g) + (size_t)g->tail;
+        for (size_t i = 0; i < g->sh.size(); ++i) { // finite input: the sums of `reps` all-reduces of zeros stay zeros
+            CMFTRY(group_use(g->sh[i]));
+            HIPCHK(hipMemsetAsync(g->red[i], 0, count * sizeof(float), g->sh[i]->stream));
+        }
+        CMFTRY(group_allreduce(g, g->red, 0, count)); // warm-up
+        CMFTRY(group_use(s0));
+        HIPCHK(hipEventRecord(s0->ev0, s0->stream));
+        for (int r = 0; r < reps; ++r) CMFTRY(group_allreduce(g, g->red, 0, count));
+        CMFTRY(group_use(s0));
+        HIPCHK(hipEventRecord(s0->ev1, s0->stream));
+        CMFTRY(group_sync(g));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, s0->ev0, s0->ev1));
+        *avg_ms = (double)ms / reps;
+        *flops = (double)count * sizeof(float);
+        g->num_ready = false;
+        return CMF_OK;
+    }
     if (h && h->root_only) h = h->group->sh[0]; // shard 0 stands for the group
     CMFTRY(check_ready(h, true));
     const CmfDims &d = h->d;

@@ -282,7 +282,9 @@ int cmf_gen_synthetic(int device, int64_t N, int64_t T, int64_t K, int64_t L,
 /* ---- measurement hooks (bench.py) ------------------------------------------
  * Times `reps` launches of one named hot kernel with HIP events on the
  * handle's stream and returns the average duration in milliseconds plus the
- * algorithmic flop count of one launch.  name: "conv", "hxt", "transconv". */
+ * algorithmic flop count of one launch.  name: "conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv".
+ * On a group handle "allreduce" times the group's bulk exchange alone (the buffer an iteration all-reduces); it is a
+ * collective -- every rank of the group makes the call -- and *flops receives the payload in bytes. */
 int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, double *flops);
 /* In-loop timing: after cmf_set_option(h, "profile", 1) every contraction launch of the update / loss entries is
  * bracketed by a HIP event pair on the launch stream; cmf_kernel_times synchronises and returns the mean duration

@@ -168,6 +168,7 @@ def test_bench_multi_form_rehearsal_on_one_gpu(n, config, extras):
     if config == 2:
         assert line["comm"]["transport"] == "loopback" and line["comm"]["nranks"] == n and line["comm"]["devices"] == [0] * n
         assert line["scaling"] == "strong" and line["roofline"]["frac"] > 0
+        assert line["comm"]["allreduce"]["avg_ms"] > 0 and line["comm"]["allreduce"]["bytes"] > 1e6
         ge = line["group_extras"]
         assert "error" not in ge and ge["ms_per_step_gram"] > 0 and ge["ms_per_step_gram_overlap"] > 0
         assert abs(ge["loss_last_gram"] - ge["loss_last_gram_overlap"]) <= 1e-6 * ge["loss_last_gram"]
@@ -202,4 +203,5 @@ def test_bench_ranks_form_rehearsal_on_one_gpu(transport):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["launch"] == "ranks" and line["value"] > 0
     assert line["comm"]["mode"] == "one-process-per-gpu" and line["comm"]["transport"] == "callbacks" and line["comm"]["nranks"] == 2
+    assert line["comm"]["allreduce"]["avg_ms"] > 0
     assert ("fallback_from_rccl" in line["comm"]) == (transport == "rccl")
