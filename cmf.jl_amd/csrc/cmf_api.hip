@@ -1896,9 +1896,7 @@ static int gram_denom_h(cmf_handle_s *h, float *out)
 //   gram_w_finish   denomW = H_shift * est' (mult.jl:33) = HH * W -> h->wslabs (free once the slabs are summed), W update
 static int gram_w_partial(cmf_handle_s *h, float *hh_out)
 {
-    const CmfDims &d = h->d;
     CMFTRY(gram_ensure(h));
-    const size_t LKN = (size_t)d.L * d.K32 * d.Np;
     CMFTRY(hxt_contract(h, h->X, h->X, 1, h->numden, true)); // (+ a loss reduction deferred by cmf_iterate)
     return compute_hh(h, hh_out);
 }
@@ -2151,7 +2149,6 @@ static int group_pgd_w(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double p
     const float gscale = st->pgd_loss_abs ? 1.f : 2.f; // pgd.jl:31-33 vs :42-44
     const size_t LKN = (size_t)d0.L * d0.K32 * d0.Np;
     for (cmf_handle_s *s : g->sh) {
-        const CmfDims &d = s->d;
         CMFTRY(group_use(s));
         CMFTRY(ensure_resid(s, group_masked(g), st->pgd_loss_abs != 0));                                 // pgd.jl:230 on the shard's columns
         CMFTRY(hxt_contract(s, s->est, s->est, 1, s->numden)); // pgd.jl:206-214, partial over t
