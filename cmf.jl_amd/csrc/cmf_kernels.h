@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
     // HH rows, diagonal entries and old W values are prefetched HALS_WD steps ahead into a register ring (a step is
     // ~200 cycles of dependent arithmetic, an L2 round trip several times that); the step loop is unrolled by the
     // ring depth so that every ring slot is a fixed set of registers.
-    float hr[HALS_WD][NQ], hpp[HALS_WD], wo[HALS_WD][HALS_NG];
+    float hr[HALS_WD][NQ], hpp[HALS_WD], hinv[HALS_WD], wo[HALS_WD][HALS_NG];
     // all prefetches are buffer loads with wave-uniform (scalar) offsets: no address arithmetic in vector registers,
     // and the descriptor's bound makes the reads past a row's or the array's end harmless zeros without a branch
     const __amdgpu_buffer_rsrc_t hrs = cmf_rsrc(HH, (size_t)LK * NpH * 4);
@@ -1690,6 +1690,7 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
     };
 #pragma unroll
     for (int i = 0; i < HALS_WD; ++i) prefetch(i, hr[i], hpp[i], wo[i]);
+    hinv[0] = 1.0f / (hpp[0] + CMF_EPS_F + l2);
     for (int s0 = 0; s0 < nsteps; s0 += HALS_WD) {
 #pragma unroll
         for (int i = 0; i < HALS_WD; ++i) {
@@ -1706,7 +1707,8 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
                     for (int q = 1; q < NQ; ++q) gs = (tq == q) ? g[u][q] : gs;
                     const float gv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gs), tl));
                     const float v = gv - wo[i][u] * hpp[i];                  // hals.jl:104 projected
-                    float wn = (-v - l1) / (hpp[i] + CMF_EPS_F + l2);        // hals.jl:110
+                    float wn = (-v - l1) * hinv[i];                          // hals.jl:110 (the reciprocal of the norm is formed when the
+                                                                             // diagonal arrives, steps ahead: no division in the chain)
                     wn = fmaxf(wn, 0.f);
                     if (lane == 0) wnew[sidx * HALS_NG + u] = wn; // (one lane: 64 lanes on one address serialise in the LDS) flushed after the sweep
                     d[u] = (n0 + u < N) ? wn - wo[i][u] : 0.f;
@@ -1715,6 +1717,9 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
                 for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int u = 0; u < HALS_NG; ++u) g[u][q] = fmaf(d[u], hr[i][q], g[u][q]); // hals.jl:106
+                // the next step's reciprocal norm: its diagonal entry arrived several steps ago, and nothing in this step's chain
+                // waits for it
+                hinv[(i + 1) % HALS_WD] = 1.0f / (hpp[(i + 1) % HALS_WD] + CMF_EPS_F + l2);
                 prefetch(sidx + HALS_WD, hr[i], hpp[i], wo[i]);
             }
         }
