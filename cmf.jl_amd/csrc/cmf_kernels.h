@@ -1678,6 +1678,10 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
     // and the descriptor's bound makes the reads past a row's or the array's end harmless zeros without a branch
     const __amdgpu_buffer_rsrc_t hrs = cmf_rsrc(HH, (size_t)LK * NpH * 4);
     const __amdgpu_buffer_rsrc_t wrs = cmf_rsrc(Wt, (size_t)LK * Np * 4);
+    // (Scalar bookkeeping -- the step index divided by L, the offsets multiplied out -- is about a third of a step's ~130
+    // instructions, but both cheaper-looking forms were measured SLOWER than this one (0.28 ms): running counters with a wrap
+    // test, 0.35 ms -- the wrap is a scalar branch in a loop whose wave is alone on its SIMD; and the constant parts of the load
+    // offsets folded into the instructions' immediate field, 0.39 ms.)
     auto prefetch = [&](int sidx, float (&row)[NQ], float &diag, float (&wold)[HALS_NG]) {
         const int c = sidx < nsteps ? sidx : nsteps - 1; // clamped to the last step
         const int kk = c / L, ll = c - kk * L;
@@ -1707,8 +1711,8 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
                     for (int q = 1; q < NQ; ++q) gs = (tq == q) ? g[u][q] : gs;
                     const float gv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gs), tl));
                     const float v = gv - wo[i][u] * hpp[i];                  // hals.jl:104 projected
-                    float wn = (-v - l1) * hinv[i];                          // hals.jl:110 (the reciprocal of the norm is formed when the
-                                                                             // diagonal arrives, steps ahead: no division in the chain)
+                    float wn = (-v - l1) * hinv[i];                          // hals.jl:110 (the reciprocal of the norm is formed a step
+                                                                             // ahead, below: no division in the chain)
                     wn = fmaxf(wn, 0.f);
                     if (lane == 0) wnew[sidx * HALS_NG + u] = wn; // (one lane: 64 lanes on one address serialise in the LDS) flushed after the sweep
                     d[u] = (n0 + u < N) ? wn - wo[i][u] : 0.f;
