@@ -146,10 +146,6 @@ def test_readme_keyword_spellings_and_symbols_are_handled():
     assert "CMFHip.ALGORITHMS" in integ and "src/model.jl" in integ
 
 
-if __name__ == "__main__":
-    raise SystemExit(pytest.main([__file__, "-q"]))
-
-
 def test_every_entry_point_is_documented_for_the_maintainer():
     """INTEGRATION.md section 3 maps every C entry to the reference interface it replaces: no symbol of the header may be
     missing from it, and every entry of the header carries a citation of the reference (file:line) in its comment block."""
@@ -158,8 +154,12 @@ def test_every_entry_point_is_documented_for_the_maintainer():
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert [s for s in SYMBOLS if s not in integ] == []
     header = open(HEADER).read()
-    assert len(re.findall(r"src/[\w/]+\.jl:\d+", header)) >= 25  # reference citations (file:line)
+    assert len(re.findall(r"\w+\.jl:\d+", header)) >= 40  # reference citations (file:line)
     for rule_entry, cite in (("cmf_update_motifs", "mult.jl:23-39"), ("cmf_update_feature_maps", "mult.jl:42-58"),
                              ("cmf_hals_update_motifs", "hals.jl:31-34"), ("cmf_pgd_update_motifs", "pgd.jl:158-177"),
                              ("cmf_fit", "alternating.jl:16-71"), ("cmf_compute_loss", "common.jl:54-59")):
         assert rule_entry in header and cite in header
+
+
+if __name__ == "__main__":
+    raise SystemExit(pytest.main([__file__, "-q"]))
