@@ -37,7 +37,28 @@ def main():
     W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
     kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2) if reg else dict(l1W=0.0, l2W=0.0, l1H=0.0, l2H=0.0)
     info = ""
-    if engine == "cpu":
+    if engine.startswith("cpu_pgd"):  # the CPU mirror of the PGD rule on a T-sharded group (tests/shard_rules_cpu.py)
+        from shard_rules_cpu import ProtocolShardedPGD
+
+        mask = (np.random.default_rng(5).uniform(size=data.shape) > 0.25).astype(float) if "masked" in engine else None
+        rule = ProtocolShardedPGD(data, W0, H0, mask=mask, loss="abs" if "abs" in engine else "square")
+        cW = cH = "unitnorm" if "unitnorm" in engine else "nonneg"
+        losses = [rule.compute_loss()]
+        for _ in range(iters):
+            rule.update_motifs(constr=cW)
+            losses.append(rule.update_feature_maps(constr=cH))
+        W, H = rule.download()
+        if rank == 0:
+            np.savez(out, W=W, H=H, loss_hist=np.asarray(losses), steps=np.asarray([rule.stepW, rule.stepH]), bounds=np.asarray(rule.bounds),
+                     info=np.asarray(""))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if engine == "cpu_gram":
+        from shard_rules_cpu import ProtocolShardedGram
+
+        rule = ProtocolShardedGram(data, W0, H0)
+    elif engine == "cpu":
         from shard_engine_cpu import OracleShardEngine
         from shard_protocol_cpu import ProtocolShardedMultUpdate
 

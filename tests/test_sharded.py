@@ -110,6 +110,45 @@ def test_sharded_protocol_cpu_gloo(oracle, tmp_path, world, reg, overlap, mode):
     np.testing.assert_allclose(got["H"], Hr, rtol=1e-8, atol=1e-13)
 
 
+@pytest.mark.parametrize("world,reg,mode", [(2, 0, "calls"), (3, 1, "iterate"), (4, 1, "calls")])
+def test_sharded_gram_form_cpu_gloo(oracle, tmp_path, world, reg, mode):
+    """The Gram form on a T-sharded group, stated in numpy over gloo (tests/shard_rules_cpu.py): numW and every rank's
+    additive share of HH = H_unfold H_unfold' (from the definition, over the columns the rank owns) in ONE all-reduce of
+    [numW | HH | tail], denomW = HH W on every rank, denomH from the pairwise products of W applied to H with both halos and
+    the truncation on the last rank only -- against the unsharded oracle."""
+    N, T, K, L, iters = 17, 121, 3, 6, 6
+    out = str(tmp_path / "res.npz")
+    got = run_ranks(world, "cpu_gram", out, N, T, K, L, iters, reg, mode=mode)
+    _, _, _, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, reg)
+    np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-9)
+    np.testing.assert_allclose(got["W"], Wr, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(got["H"], Hr, rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("world,variant", [(2, ""), (3, "_masked"), (2, "_unitnorm"), (3, "_abs_masked")])
+def test_sharded_pgd_cpu_gloo(oracle, tmp_path, world, variant):
+    """The PGD rule on a T-sharded group in numpy over gloo: one all-reduce of the partial gradW, gradH from the residual on
+    the own columns and the right lag halo, the squared norm of gradH / the UnitNorm component norms / the loss summed over the
+    ranks in rank order, a replicated step-size state machine -- against the unsharded oracle, decisions included."""
+    N, T, K, L, iters = 17, 121, 3, 6, 6
+    out = str(tmp_path / "res.npz")
+    got = run_ranks(world, "cpu_pgd" + variant, out, N, T, K, L, iters, 0)
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    kw = {}
+    if "masked" in variant:
+        kw["mask"] = (np.random.default_rng(5).uniform(size=data.shape) > 0.25).astype(float)
+    if "abs" in variant:
+        kw["loss"] = "abs"
+    if "unitnorm" in variant:
+        kw.update(constrW="unitnorm", constrH="unitnorm")
+    Wr, Hr, lr, sr = oracle.fit_pgd(data, W0, H0, max_itr=iters, **kw)
+    np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-9)
+    np.testing.assert_allclose(got["W"], Wr, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(got["H"], Hr, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(got["steps"], sr, rtol=1e-12)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # GPU: one process drives the group (cmf_create_multi)
 # ---------------------------------------------------------------------------------------------------------------
