@@ -138,6 +138,17 @@ def test_golden_fit(cmf, name):
     assert frob_rel(cmf.tensor_transconv(W0, data), g["transconv0"]) < REL_PRIM
 
 
+@pytest.mark.parametrize("name,alg", [("hals_small", ":hals"), ("pgd_small", ":pgd")])
+def test_golden_fit_hals_pgd(cmf, name, alg):
+    """fit_cnmf(alg=:hals) / (alg=:pgd) against the committed fixtures of those rules (the GPU box needs no oracle for this)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    data, W0, H0 = g["data"], g["W0"], g["H0"]
+    K, N, L = W0.shape
+    res = cmf.fit_cnmf(data, L=L, K=K, alg=alg, max_itr=int(g["max_itr"]), check_convergence=False, W_init=W0, H_init=H0)
+    np.testing.assert_allclose(res.loss_hist, g["loss_hist"], rtol=REL_LOSS)
+    assert frob_rel(res.W, g["W"]) < REL_FACTORS and frob_rel(res.H, g["H"]) < REL_FACTORS
+
+
 def test_fit_k32_l20_against_oracle(cmf, oracle):
     """Config-2 K and L at a size the oracle finishes in seconds; gen_synthetic inputs, init seed 0."""
     data, _, _ = oracle.c_gen_synthetic(N=200, T=3000, K=3, L=20, seed=1234)
