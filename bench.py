@@ -439,16 +439,20 @@ def main():
         dt_gram2 /= nrep
         rule.set_option("gram", 0)
 
-    # Sharded runs, opt-in (CMF_BENCH_GROUP_EXTRAS=1): the Gram form on the group -- the all-reduce carries [numW | HH | tail]
-    # (6.9 MB instead of 10.5 MB at config 2) and, with the overlap option, runs entirely underneath the loss conv.  Extra
-    # fields only; opt-in because a side measurement must never be able to cost the headline of a multi-GPU run.
+    # Sharded runs: the Gram form on the group -- the all-reduce carries [numW | HH | tail] (6.9 MB instead of 10.5 MB at
+    # config 2) -- as extra fields (never part of `value`).  It issues exactly the collectives of the timed region (one
+    # all-reduce, one halo all-gather, on the main stream), only with another count, so it runs by default
+    # (CMF_BENCH_GROUP_EXTRAS=0 skips it).  The overlap variant, whose bulk all-reduce runs on a second stream underneath
+    # the loss conv, is opt-in (CMF_BENCH_GROUP_EXTRAS=1): a second collective in flight on the same communicator has only
+    # ever run on one device, and a side measurement must never be able to cost the headline of a multi-GPU run.
     group_extras = None
-    if sharded and os.environ.get("CMF_BENCH_GROUP_EXTRAS") == "1":
+    ge_mode = os.environ.get("CMF_BENCH_GROUP_EXTRAS", "gram")
+    if sharded and ge_mode != "0" and not args.no_extras:
         group_extras = {}
         keep_overlap = bool(rule.overlap)
         nrep = max(5, args.steps // 2)
         try:
-            for name, ov in (("gram", False), ("gram_overlap", True)):
+            for name, ov in ((("gram", False), ("gram_overlap", True)) if ge_mode == "1" else (("gram", False),)):
                 rule.upload(W0, H0)
                 rule.set_option("gram", 1)
                 rule.set_overlap(ov)
