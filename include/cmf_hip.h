@@ -148,7 +148,9 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       denomH = lag-Gram taps of W applied to H) instead of through est: exact rewritings of mult.jl:33,48 that
  *       execute 2.3 instead of 6 contractions plus the loss conv; results differ at rounding level only.
  *       2 = additionally take the loss from <H, denomH> - 2<H, numH> + ||data||^2 (no conv at all; the fp32
- *       cancellation limits its relative accuracy to about 1e-6 / loss^2).  Unsharded handles only.
+ *       cancellation limits its relative accuracy to about 1e-6 / loss^2; measured <= 5e-7 on the test shapes).  gram = 1 is
+ *       also available on group handles: the all-reduce then carries [numW | HH | tail] (HH = H_unfold H_unfold', every
+ *       shard's additive share) instead of [numW | denomW | tail]; it needs T >= 4 L.  gram = 2: unsharded handles only.
  *   "conv_kernel" (default 0 = chosen per launch; 2 = 128 x 128 workgroup tiles for the launches that only store or only
  *       sum the loss -- the epilogues that read data and store always take the one-wave kernel; 3 = one-wave 64 x 64 tiles) and
  *   "conv_split" (default 1: the tiles at the end of the one-wave kernel's grid -- a thin last round, and from four
@@ -242,11 +244,16 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
  * 0 = none, 1 = NonnegConstraint (max(eps, x), pgd.jl:92-96), 2 = UnitNormConstraint (every component k whose slice
  * W[k,:,:] / H[k,:] has norm > 1 is scaled to norm 1, pgd.jl:100-110).
  * The rule's state (stepW = stepH = 5, cur_loss = norm(data), step_incr 1.05, step_decr 0.70; pgd.jl:139-154)
- * lives in the handle and is (re)initialised by cmf_create and cmf_pgd_reset.  Unsharded handles only. */
+ * lives in the handle and is (re)initialised by cmf_create and cmf_pgd_reset.  Valid on single-GPU handles and on group
+ * handles (cmf_create_multi / cmf_comm_init_*): one all-reduce of the partial gradW per iteration; the squared norm of gradH,
+ * the component norms of UnitNormConstraint and the loss are summed over the shards in rank order, the step-size state
+ * machine is replicated (every rank takes the same accept / reject decisions). */
 int cmf_pgd_reset(cmf_handle h);
 /* MaskedLoss(SquareLoss(), mask)  src/algs/pgd.jl:58-70 (the loss_func of the reference's own test/test.jl:45):
  * gradient 2*(est - data) .* mask, loss norm(mask.*data - mask.*est)^2.  `mask` is N x T column-major like data
- * (borrowed for the call); NULL restores the plain SquareLoss.  Only the PGD entries read the mask. */
+ * (borrowed for the call); NULL restores the plain SquareLoss.  Only the PGD entries read the mask.  On a group handle the
+ * mask is cut along T like data: cmf_create_multi groups take the whole N x T mask, a cmf_create_shard handle its own
+ * columns followed by the right lag halo (the layout of data_local). */
 int cmf_set_mask(cmf_handle h, const double *mask);
 /* loss_func of the PGD entries: 0 = SquareLoss (default), 1 = AbsoluteLoss (gradient sign(est - data), loss
  * norm(data - est, 1); pgd.jl:41-47).  Combines with cmf_set_mask as MaskedLoss(loss, mask). */
