@@ -345,3 +345,41 @@ def test_group_rules_on_ragged_shapes(cmf, oracle, R, N, T, K, L):
     np.testing.assert_allclose(lg, lo[1:], rtol=1e-4)
     assert frob_rel(Wg, Wo) < 1e-4 and frob_rel(Hg, Ho) < 1e-4
     np.testing.assert_allclose(sg, so, rtol=1e-12)
+
+
+def test_long_recording_needs_a_group_and_runs_on_one(cmf, oracle):
+    """The reference's long-recording use (notebooks/test_mouse.ipynb cell 5: a 3 x 19 980 000 matrix, fitted with PGDUpdate): ONE
+    handle refuses that many columns (a 64-row block of est', 64 * Tpad * 4 bytes, passes the 2 GiB its kernels' 32-bit offsets
+    address: 8.3 M columns per handle), a T-sharded group takes them -- here as three shards on this GPU -- and its PGD and MU
+    iterations match the fp64 oracle."""
+    from cmf_jl_amd import _lib
+
+    N, T, K, L = 3, 19_980_000, 3, 20
+    rng = np.random.default_rng(7)
+    data = np.asfortranarray(rng.random((N, T)))
+    W0 = np.asfortranarray(rng.random((K, N, L)) * 0.2)
+    H0 = np.asfortranarray(rng.random((K, T)) * 0.2)
+    with pytest.raises(cmf.CMFError) as ei:
+        cmf.PGDUpdate(data, W0, H0)
+    assert ei.value.code == _lib.CMF_ERR_UNSUPPORTED
+    rule = cmf.PGDUpdate(data, W0, H0, devices=[0, 0, 0])
+    assert rule.shard_bounds(2) == (2 * (T // 3), T)
+    lg = [rule.compute_loss()]
+    for _ in range(2):
+        rule.update_motifs()
+        lg.append(rule.update_feature_maps())
+    Wg, Hg = rule.download()
+    sg = rule.steps
+    rule.close()
+    Wo, Ho, lo, so = oracle.fit_pgd(data, W0, H0, max_itr=2)
+    np.testing.assert_allclose(lg, lo, rtol=1e-4)
+    assert frob_rel(Wg, Wo) < 1e-4 and frob_rel(Hg, Ho) < 1e-4
+    np.testing.assert_allclose(sg, so, rtol=1e-12)
+    del Wo, Ho
+    rule = cmf.MultUpdate(data, W0, H0, devices=[0, 0, 0])
+    lm = [rule.compute_loss()] + list(rule.iterate(2))
+    Wm, Hm = rule.download()
+    rule.close()
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=2, check_convergence=False)
+    np.testing.assert_allclose(lm, lr, rtol=1e-4)
+    assert frob_rel(Wm, Wr) < 1e-4 and frob_rel(Hm, Hr) < 1e-4
