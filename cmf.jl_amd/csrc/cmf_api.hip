@@ -838,9 +838,30 @@ int cmf_device_count(void)
     return n;
 }
 
+// columns one handle can hold: a 64-row block of est' (64 * Tpad floats) must stay below the 2 GiB a 32-bit buffer offset
+// addresses, and so must H (Tpad * Kpad floats)
+static int64_t max_columns_per_handle(int64_t K)
+{
+    if (const char *e = getenv("CMF_MAX_COLUMNS")) // tests: take the long-recording paths at small sizes
+        if (atoll(e) > 0) return atoll(e);
+    const int64_t K32 = 32 * ((K + 31) / 32);
+    const int64_t by_est = ((int64_t)1 << 31) / (64 * 4), by_h = ((int64_t)1 << 31) / (K32 * 4);
+    return std::min(by_est, by_h) - 4096; // (left lag halo and tile padding)
+}
+
 int cmf_create(cmf_handle *h, int device, int64_t N, int64_t T, int64_t K, int64_t L, const double *data)
 {
     if (!data) return fail(CMF_ERR_ARG, "data is NULL");
+    if (K >= 1 && L >= 1 && T > max_columns_per_handle(K)) {
+        // A recording longer than one handle's 32-bit offsets reach (8.3 M columns at K <= 64; the reference's own long
+        // recordings have 20 M: notebooks/test_mouse.ipynb cell 5) is cut along T into shards on the SAME device: a loopback
+        // group behind the same handle type, so the rule constructor of the reference (mult.jl:11-20, pgd.jl:139-154) just works.
+        const int64_t per = max_columns_per_handle(K) - L;
+        const int R = (int)((T + per - 1) / per);
+        if (R > CMF_MAX_LOCAL) return fail(CMF_ERR_UNSUPPORTED, "T=%lld needs %d shards on one device (at most %d)", (long long)T, R, CMF_MAX_LOCAL);
+        std::vector<int> devs((size_t)R, device);
+        return cmf_create_multi(h, R, devs.data(), CMF_COMM_LOOPBACK, N, T, K, L, data);
+    }
     return create_impl(h, device, N, T, K, L, data, 0, T, false);
 }
 
@@ -2342,29 +2363,38 @@ int cmf_init_rand(int device, int64_t N, int64_t T, int64_t K, int64_t L, uint64
     for (size_t i = 0; i < nW; ++i) W[i] = cmfrng::u01(bW, i); // :116 rand(K, N, L)
     for (size_t i = 0; i < nH; ++i) H[i] = cmfrng::u01(bH, i); // :117 rand(K, T)
     // :119-120 on the device: est = tensor_conv(W, H) next to the uploaded data, then <data, est> and norm(est)^2 in one
-    // pass over the two (padded, zero-filled) layouts -- no N x T array crosses PCIe back, none is allocated on the host
+    // pass over the two (padded, zero-filled) layouts -- no N x T array crosses PCIe back, none is allocated on the host.
+    // A recording longer than one handle reaches (max_columns_per_handle) goes through in column blocks: each block is
+    // uploaded with the L-1 columns in front of it, whose est is formed (they complete the lag windows of the block's first
+    // columns) but left out of the two sums.
     double dot = 0.0, nn = 0.0;
-    {
+    const int64_t per = std::max<int64_t>(max_columns_per_handle(K) - L, 1);
+    for (int64_t t0 = 0; t0 < T; t0 += per) {
+        const int64_t t1 = std::min(T, t0 + per), skip = t0 > 0 ? std::min<int64_t>(L - 1, t0) : 0;
+        const int64_t Tb = t1 - t0 + skip;
         cmf_handle hh = nullptr;
-        CMFTRY(create_impl(&hh, device, N, T, K, L, data, 0, T, false));
+        CMFTRY(create_impl(&hh, device, N, Tb, K, L, data + (size_t)(t0 - skip) * N, 0, Tb, false));
         const CmfDims &d = hh->d;
         const int nb = 1024;
         double *part = nullptr;
-        int rc = set_factors_impl(hh, W, H);
+        double dot_b = 0.0, nn_b = 0.0;
+        int rc = set_factors_impl(hh, W, H + (size_t)(t0 - skip) * K);
         if (rc == CMF_OK) rc = launch_conv<0>(hh, hh->est, d.Tl, hh->conv_gy);
         if (rc == CMF_OK && hipMalloc(&part, (size_t)2 * nb * sizeof(double)) != hipSuccess) rc = fail(CMF_ERR_HIP, "hipMalloc failed in cmf_init_rand");
         if (rc == CMF_OK) {
-            const size_t off = (size_t)d.PADL * d.Np, n4 = (size_t)d.Tl * d.Np / 4; // rows [PADL, PADL + Tl), all columns
+            const size_t off = (size_t)(d.PADL + skip) * d.Np, n4 = (size_t)(d.Tl - skip) * d.Np / 4; // the block's own rows, all columns
             hipLaunchKernelGGL(init_dot_kernel, dim3(nb), dim3(256), 0, hh->stream, hh->est + off, hh->X + off, n4, part);
             hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, hh->stream, part, nb, hh->d_scalar + 2, (double *)nullptr);
             hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, hh->stream, part + nb, nb, hh->d_scalar + 3, (double *)nullptr);
             if (hipGetLastError() != hipSuccess) rc = fail(CMF_ERR_HIP, "launch failed in cmf_init_rand");
         }
-        if (rc == CMF_OK) rc = read_scalar(hh, 2, &dot);
-        if (rc == CMF_OK) rc = read_scalar(hh, 3, &nn);
+        if (rc == CMF_OK) rc = read_scalar(hh, 2, &dot_b);
+        if (rc == CMF_OK) rc = read_scalar(hh, 3, &nn_b);
         if (part) (void)hipFree(part);
         destroy_impl(hh);
         CMFTRY(rc);
+        dot += dot_b;
+        nn += nn_b;
     }
     const double s = std::sqrt(std::fabs(dot / nn)); // :121-122
     for (size_t i = 0; i < nW; ++i) W[i] *= s;

@@ -65,7 +65,10 @@ int cmf_device_count(void);
  * (src/algs/mult.jl:11-20, called at src/model.jl:79): uploads `data`
  * (N x T), allocates the rule's scratch (est, numW, denomW, numH, denomH)
  * on `device`, and computes data_norm = norm(data).
- * cmf_create is the single-GPU form of cmf_create_shard. */
+ * cmf_create is the single-GPU form of cmf_create_shard.  A recording with more columns than one handle's 32-bit buffer
+ * offsets reach (8.3 M at K <= 64) is cut along T into several shards on the SAME device automatically (the handle then fronts
+ * a loopback group, see cmf_create_multi): the MU and PGD rules run on it unchanged, HALS -- whose H sweep is one chain along
+ * T -- reports that it cannot. */
 int cmf_create(cmf_handle *h, int device, int64_t N, int64_t T, int64_t K, int64_t L,
                const double *data);
 

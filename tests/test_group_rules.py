@@ -359,11 +359,18 @@ def test_long_recording_needs_a_group_and_runs_on_one(cmf, oracle):
     data = np.asfortranarray(rng.random((N, T)))
     W0 = np.asfortranarray(rng.random((K, N, L)) * 0.2)
     H0 = np.asfortranarray(rng.random((K, T)) * 0.2)
-    with pytest.raises(cmf.CMFError) as ei:
-        cmf.PGDUpdate(data, W0, H0)
-    assert ei.value.code == _lib.CMF_ERR_UNSUPPORTED
-    rule = cmf.PGDUpdate(data, W0, H0, devices=[0, 0, 0])
+    import ctypes
+
+    lib, hs = cmf.load_library(), ctypes.c_void_p()
+    dl = np.asfortranarray(data[:, :T // 2 + L - 1])  # one shard of HALF the columns is still too long for a handle
+    assert lib.cmf_create_shard(ctypes.byref(hs), 0, N, T // 2, K, L, dl.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 0, T) == _lib.CMF_ERR_UNSUPPORTED
+    del dl
+    # the plain rule constructor (cmf_create) cuts such a recording into shards on the same device by itself
+    rule = cmf.PGDUpdate(data, W0, H0)
+    assert "transport=loopback" in rule.comm_info() and "nranks=3" in rule.comm_info()
     assert rule.shard_bounds(2) == (2 * (T // 3), T)
+    with pytest.raises(cmf.CMFError):
+        cmf.HALSUpdate(data, W0, H0)  # the H sweep of HALS is one chain along T: no sharding, and it says so
     lg = [rule.compute_loss()]
     for _ in range(2):
         rule.update_motifs()
@@ -376,10 +383,38 @@ def test_long_recording_needs_a_group_and_runs_on_one(cmf, oracle):
     assert frob_rel(Wg, Wo) < 1e-4 and frob_rel(Hg, Ho) < 1e-4
     np.testing.assert_allclose(sg, so, rtol=1e-12)
     del Wo, Ho
-    rule = cmf.MultUpdate(data, W0, H0, devices=[0, 0, 0])
-    lm = [rule.compute_loss()] + list(rule.iterate(2))
-    Wm, Hm = rule.download()
-    rule.close()
+    res = cmf.fit_cnmf(data, L=L, K=K, alg=":mult", max_itr=2, check_convergence=False, W_init=W0, H_init=H0)  # the public entry, no devices=
+    lm, Wm, Hm = res.loss_hist, res.W, res.H
     Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=2, check_convergence=False)
     np.testing.assert_allclose(lm, lr, rtol=1e-4)
     assert frob_rel(Wm, Wr) < 1e-4 and frob_rel(Hm, Hr) < 1e-4
+
+
+@pytest.mark.parametrize("N,T,K,L,cap", [(40, 1000, 5, 10, 300), (130, 900, 32, 20, 250), (17, 333, 3, 7, 64)])
+def test_long_recording_paths_at_small_sizes(cmf, oracle, N, T, K, L, cap):
+    """The paths a recording longer than one handle takes -- cmf_create cutting it into shards on the same device, init_rand
+    going through it in column blocks with the L-1 columns in front of each block -- forced at small sizes (CMF_MAX_COLUMNS), so
+    that they can be checked against the oracle quickly: init_rand's least-squares scale, then whole fits by fit_cnmf."""
+    import os
+
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=1234)
+    Wo, Ho = oracle.c_init_rand(data, L=L, K=K, seed=3)
+    os.environ["CMF_MAX_COLUMNS"] = str(cap)
+    try:
+        Wg, Hg = cmf.init_rand(data, L=L, K=K, seed=3)
+        res = cmf.fit_cnmf(data, L=L, K=K, alg=":mult", max_itr=5, check_convergence=False, W_init=Wo, H_init=Ho, l1_H=0.1, l2_W=0.5)
+        rule = cmf.MultUpdate(data, Wo, Ho)
+        info = rule.comm_info()
+        rule.close()
+        resp = cmf.fit_cnmf(data, L=L, K=K, alg=":pgd", max_itr=4, check_convergence=False, W_init=Wo, H_init=Ho)
+    finally:
+        os.environ.pop("CMF_MAX_COLUMNS", None)
+    assert frob_rel(Wg, Wo) < 1e-6 and frob_rel(Hg, Ho) < 1e-6  # same uniforms, the scale from the blockwise sums
+    R = -(-T // (cap - L))
+    assert "transport=loopback" in info and f"nranks={R}" in info
+    Wr, Hr, lr, _ = oracle.fit_mult(data, Wo, Ho, max_itr=5, check_convergence=False, l1H=0.1, l2W=0.5)
+    np.testing.assert_allclose(res.loss_hist, lr, rtol=1e-4)
+    assert frob_rel(res.W, Wr) < 1e-4 and frob_rel(res.H, Hr) < 1e-4
+    Wp, Hp, lp, _ = oracle.fit_pgd(data, Wo, Ho, max_itr=4)
+    np.testing.assert_allclose(resp.loss_hist, lp, rtol=1e-4)
+    assert frob_rel(resp.W, Wp) < 1e-4 and frob_rel(resp.H, Hp) < 1e-4
