@@ -2307,35 +2307,50 @@ static int download_rows(cmf_handle_s *h, double *out, const float *buf, int row
     return CMF_OK;
 }
 
+// (both stand-alone primitives go through a matrix longer than one handle reaches -- max_columns_per_handle -- in column
+// blocks: tensor_conv looks L-1 columns back, so a block is computed with the L-1 columns in front of it and those are dropped;
+// tensor_transconv looks L-1 columns ahead, so a block takes the L-1 columns behind it along)
 int cmf_tensor_conv(int device, int64_t N, int64_t T, int64_t K, int64_t L, const double *W, const double *H, double *est)
 {
     if (!W || !H || !est) return fail(CMF_ERR_ARG, "NULL argument");
-    cmf_handle h = nullptr;
-    CMFTRY(create_impl(&h, device, N, T, K, L, nullptr, 0, T, false));
-    int rc = cmf_set_factors(h, W, H);
-    if (rc == CMF_OK) rc = launch_conv<0>(h, h->est, h->d.Tl, h->conv_gy);
-    if (rc == CMF_OK) rc = download_rows(h, est, h->est, h->d.PADL, T, (int)N, h->d.Np);
-    destroy_impl(h);
-    return rc;
+    if (N < 1 || T < 1 || K < 1 || L < 1) return fail(CMF_ERR_ARG, "N, T, K, L must all be >= 1");
+    const int64_t per = std::max<int64_t>(max_columns_per_handle(K) - L, 1);
+    for (int64_t t0 = 0; t0 < T; t0 += per) {
+        const int64_t t1 = std::min(T, t0 + per), skip = std::min<int64_t>(L - 1, t0), Tb = t1 - t0 + skip;
+        cmf_handle h = nullptr;
+        CMFTRY(create_impl(&h, device, N, Tb, K, L, nullptr, 0, Tb, false));
+        int rc = set_factors_impl(h, W, H + (size_t)(t0 - skip) * K);
+        if (rc == CMF_OK) rc = launch_conv<0>(h, h->est, h->d.Tl, h->conv_gy);
+        if (rc == CMF_OK) rc = download_rows(h, est + (size_t)t0 * N, h->est, h->d.PADL + (int)skip, t1 - t0, (int)N, h->d.Np);
+        destroy_impl(h);
+        CMFTRY(rc);
+    }
+    return CMF_OK;
 }
 
 int cmf_tensor_transconv(int device, int64_t N, int64_t T, int64_t K, int64_t L, const double *W, const double *X, double *out)
 {
     if (!W || !X || !out) return fail(CMF_ERR_ARG, "NULL argument");
-    cmf_handle h = nullptr;
-    CMFTRY(create_impl(&h, device, N, T, K, L, X, 0, T, false));
-    std::vector<double> H0((size_t)K * T, 0.0);
-    int rc = cmf_set_factors(h, W, H0.data());
-    if (rc == CMF_OK) rc = launch_transconv(h, 1);
-    // sum the S n-range slabs ([S][1][Tl][K32])
-    float *sum = nullptr;
-    if (rc == CMF_OK && hipMalloc(&sum, (size_t)h->d.Tl * h->d.K32 * sizeof(float)) != hipSuccess)
-        rc = fail(CMF_ERR_HIP, "hipMalloc failed in cmf_tensor_transconv");
-    if (rc == CMF_OK) rc = launch_slab_sum(h, sum, h->hslabs, h->tc_S1, (size_t)h->d.Tl * h->d.K32);
-    if (rc == CMF_OK) rc = download_rows(h, out, sum, 0, T, (int)K, h->d.K32);
-    if (sum) (void)hipFree(sum);
-    destroy_impl(h);
-    return rc;
+    if (N < 1 || T < 1 || K < 1 || L < 1) return fail(CMF_ERR_ARG, "N, T, K, L must all be >= 1");
+    const int64_t per = std::max<int64_t>(max_columns_per_handle(K) - L, 1);
+    for (int64_t t0 = 0; t0 < T; t0 += per) {
+        const int64_t t1 = std::min(T, t0 + per), ahead = std::min<int64_t>(L - 1, T - t1), Tb = t1 - t0 + ahead;
+        cmf_handle h = nullptr;
+        CMFTRY(create_impl(&h, device, N, Tb, K, L, X + (size_t)t0 * N, 0, Tb, false));
+        std::vector<double> H0((size_t)K * Tb, 0.0);
+        int rc = set_factors_impl(h, W, H0.data());
+        if (rc == CMF_OK) rc = launch_transconv(h, 1);
+        // sum the S n-range slabs ([S][1][Tl][K32])
+        float *sum = nullptr;
+        if (rc == CMF_OK && hipMalloc(&sum, (size_t)h->d.Tl * h->d.K32 * sizeof(float)) != hipSuccess)
+            rc = fail(CMF_ERR_HIP, "hipMalloc failed in cmf_tensor_transconv");
+        if (rc == CMF_OK) rc = launch_slab_sum(h, sum, h->hslabs, h->tc_S1, (size_t)h->d.Tl * h->d.K32);
+        if (rc == CMF_OK) rc = download_rows(h, out + (size_t)t0 * K, sum, 0, t1 - t0, (int)K, h->d.K32);
+        if (sum) (void)hipFree(sum);
+        destroy_impl(h);
+        CMFTRY(rc);
+    }
+    return CMF_OK;
 }
 
 // ---- init_rand / gen_synthetic -----------------------------------------------------------------

@@ -402,6 +402,9 @@ def test_long_recording_paths_at_small_sizes(cmf, oracle, N, T, K, L, cap):
     os.environ["CMF_MAX_COLUMNS"] = str(cap)
     try:
         Wg, Hg = cmf.init_rand(data, L=L, K=K, seed=3)
+        est_b = cmf.tensor_conv(Wo, Ho)              # the stand-alone primitives in column blocks
+        tc_b = cmf.tensor_transconv(Wo, data)
+        syn_b = cmf.gen_synthetic(N=N, T=T, seed=5)  # (its tensor_conv goes through the same blocks)
         res = cmf.fit_cnmf(data, L=L, K=K, alg=":mult", max_itr=5, check_convergence=False, W_init=Wo, H_init=Ho, l1_H=0.1, l2_W=0.5)
         rule = cmf.MultUpdate(data, Wo, Ho)
         info = rule.comm_info()
@@ -410,6 +413,8 @@ def test_long_recording_paths_at_small_sizes(cmf, oracle, N, T, K, L, cap):
     finally:
         os.environ.pop("CMF_MAX_COLUMNS", None)
     assert frob_rel(Wg, Wo) < 1e-6 and frob_rel(Hg, Ho) < 1e-6  # same uniforms, the scale from the blockwise sums
+    assert frob_rel(est_b, oracle.tensor_conv(Wo, Ho)) < 2e-6 and frob_rel(tc_b, oracle.tensor_transconv(Wo, data)) < 2e-6
+    np.testing.assert_array_equal(syn_b, cmf.gen_synthetic(N=N, T=T, seed=5))  # blocks or not: the same kernels on the same windows
     R = -(-T // (cap - L))
     assert "transport=loopback" in info and f"nranks={R}" in info
     Wr, Hr, lr, _ = oracle.fit_mult(data, Wo, Ho, max_itr=5, check_convergence=False, l1H=0.1, l2W=0.5)
