@@ -1599,6 +1599,18 @@ static int hals_ensure(cmf_handle_s *h)
             const size_t lds = ((size_t)(d.K - 1) * (E + 64 + 2 * (d.L - 1)) + 1024) * sizeof(float);
             if (P < 2 && d.K > 1) P = 0; // too many rows for the chip: stage pipeline
             if (lds > 120 * 1024) P = 0;
+            // the grid's workgroups wait for each other: all of them must be resident at once.  Ask the runtime how many
+            // 1024-thread workgroups with this much LDS a CU takes instead of assuming one (a device with fewer usable CUs, or
+            // a kernel whose registers no longer allow 1024 threads, would otherwise only show as an expired wait).
+            while (P >= (d.K > 1 ? 2 : 1)) {
+                int per_cu = 0;
+                const size_t lds_run = std::max((size_t)(d.K - 1) * (2 * d.L - 1 + 64 + 2 * (d.L - 1)) + 1024, (size_t)h->hals_ne * (d.L + 1)) * sizeof(float);
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hals_h_persist_kernel, 1024, lds_run) != hipSuccess) per_cu = 0;
+                if ((long long)per_cu * h->n_cu >= (long long)d.K + (long long)(d.K - 1) * P) break;
+                --P;
+            }
+            if (P < 2 && d.K > 1) P = 0;
+            if (P < 1) P = 0;
         }
         h->hals_pullers = P;
         if (P > 0) {
