@@ -20,6 +20,19 @@ takes the per-process form; --gpus N > 1 with no launcher takes the one-process 
 the JSON line says which transport carried the collectives, the RCCL version and how many ranks it saw.
 Config 5 (HALS) does not shard over T (its H sweep is sequential along T): with --gpus N it runs N independent
 replicas ("scaling": "weak").
+
+First contact with a multi-GPU node (no such node was available to the build): for --gpus N > 1 the process that is
+started does NOT touch the GPU.  It supervises: the measurement runs in a child process (a fresh process per attempt, so
+a wedged collective or a crash inside RCCL costs an attempt, not the run), bounded by --attempt-timeout, down a ladder of
+forms -- `attempts` in the JSON line says which ones were tried and why they ended:
+    plain launch      one process, an enqueue thread per GPU  ->  one process, calling thread enqueues (grouped RCCL calls)
+                      ->  one process per GPU started by bench.py itself (the launcher form below)
+    launcher form     library's own RCCL communicator  ->  collectives through torch.distributed's RCCL backend on staged
+                      buffers  ->  through gloo on host buffers
+Under a launcher the supervising ranks agree through the launcher's TCP store (port, outcome of every rank, early abort).
+When every form has failed, rank 0 still prints ONE JSON line -- "value": null, the failing phase, cmf_last_error, `comm` and
+whatever was measured before the failure -- and the exit code is non-zero.  CMF_BENCH_SUPERVISE=0 runs the measurement in
+the started process as before.
 """
 import argparse
 import json
@@ -224,11 +237,7 @@ def other_configs(cmf, rule, data, W0, H0, N, T, K, L, with_config3, device):
     return res
 
 
-def main():
-    # the oracle's OpenMP loops (HALS baseline) are short: one thread per visible core only adds spinning
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
-    # RCCL shares device buffers between processes through dmabuf IPC; the host driver of these boxes supports only that
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -240,14 +249,276 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the no-reuse / Gram-form / other-config side measurements (profiling runs: keeps one launch shape per kernel)")
     ap.add_argument("--no-config3", action="store_true", help="skip config 3 (T=400000 on one GPU) in other_configs")
-    args = ap.parse_args()
+    ap.add_argument("--attempt-timeout", type=float, default=float(os.environ.get("CMF_BENCH_ATTEMPT_TIMEOUT", "420")),
+                    help="--gpus N > 1: seconds one attempt (one form of the ladder, in its own child process) may take")
+    ap.add_argument("--child", default="", help=argparse.SUPPRESS)  # set by the supervisor: this process IS the measurement
+    return ap.parse_args(argv)
 
+
+# ---- supervisor (multi-GPU runs): the measurement in a child process per attempt --------------------------------------
+LADDER = {
+    # plain `python bench.py --gpus N`: (label, form of the child, extra environment)
+    "multi": [("one process, an enqueue thread per GPU, RCCL", "multi", {}),
+              ("one process, the calling thread enqueues every GPU, grouped RCCL calls", "multi", {"CMF_ENQUEUE_THREADS": "0"}),
+              ("one process per GPU (started by bench.py), the library's RCCL communicator", "ranks", {}),
+              ("one process per GPU (started by bench.py), collectives through torch.distributed's RCCL backend", "ranks", {"CMF_TRANSPORT": "host"})],
+    # under a launcher (WORLD_SIZE == --gpus)
+    "ranks": [("the library's RCCL communicator", "ranks", {}),
+              ("collectives through torch.distributed's RCCL backend on staged buffers", "ranks", {"CMF_TRANSPORT": "host"}),
+              ("collectives through gloo on host buffers", "ranks", {"CMF_TRANSPORT": "host", "CMF_DIST_BACKEND": "gloo"})],
+}
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def child_command(args, tag):
+    # (CMF_BENCH_FAKE_CHILD: the CPU tests of the supervisor put a stub in the measurement's place)
+    cmd = [sys.executable, os.environ.get("CMF_BENCH_FAKE_CHILD") or os.path.abspath(__file__), "--child", tag, "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--config", str(args.config), "--cpu-seconds", str(args.cpu_seconds), "--sustain", str(args.sustain)]
+    if args.T:
+        cmd += ["--T", str(args.T)]
+    if args.no_extras:
+        cmd.append("--no-extras")
+    if args.no_config3:
+        cmd.append("--no-config3")
+    return cmd
+
+
+def child_env(extra, rank=None, world=None, port=None):
+    env = dict(os.environ)
+    for k in list(env):  # the child makes its own rendezvous: nothing of the launcher's elastic agent may leak into it
+        if k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE"):
+            env.pop(k)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("CMF_WAIT_TIMEOUT_S", "90")  # a collective that never completes ends the attempt with a message, well inside its time limit
+    env["CMF_BENCH_SUPERVISE"] = "0"
+    env.update(extra)
+    if rank is None:  # one process drives all GPUs
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+    else:
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank if "LOCAL_RANK" not in os.environ or world is None else os.environ.get("LOCAL_RANK", rank)),
+                   WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    return env
+
+
+def stop_children(procs):
+    """End exactly the processes started here (each its own session: its process group goes with it)."""
+    import signal
+
+    for p_ in procs:
+        if p_.poll() is None:
+            try:
+                os.killpg(p_.pid, signal.SIGTERM)
+            except OSError:
+                pass
+    t_end = time.time() + 10
+    for p_ in procs:
+        while p_.poll() is None and time.time() < t_end:
+            time.sleep(0.1)
+        if p_.poll() is None:
+            try:
+                os.killpg(p_.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            p_.wait()
+
+
+def last_json_line(text):
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def run_attempt(cmds_envs, timeout, should_abort=None):
+    """Start the children of one attempt (each in its own session), wait for all of them -- at most `timeout` seconds, and
+    no longer than `should_abort()` allows -- and return (ok, reason, stdout of child 0, tail of the stderrs)."""
+    import subprocess
+    import tempfile
+
+    procs, outs, errs = [], [], []
+    for cmd, env in cmds_envs:
+        fo, fe = tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")
+        outs.append(fo)
+        errs.append(fe)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, start_new_session=True, cwd=ROOT))
+    t0, reason = time.time(), None
+    while True:
+        codes = [p_.poll() for p_ in procs]
+        if any(c not in (None, 0) for c in codes):
+            bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
+            reason = "child process(es) failed: " + ", ".join(f"#{i} exit code {c}" for i, c in bad)
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > timeout:
+            reason = f"no result within {timeout:.0f} s (--attempt-timeout)"
+            break
+        if should_abort is not None and should_abort():
+            reason = "another rank's attempt failed"
+            break
+        time.sleep(0.2)
+    stop_children(procs)
+
+    def text(f):
+        f.seek(0)
+        return f.read()
+
+    out0 = text(outs[0])
+    err_tail = []
+    for i, fe in enumerate(errs):
+        lines = [ln for ln in text(fe).splitlines() if ln.strip()]
+        if lines and (reason or i == 0):
+            err_tail.append({"child": i, "stderr_tail": lines[-6:]})
+    for f in outs + errs:
+        f.close()
+    return reason is None, reason, out0, err_tail
+
+
+def supervise(args, form):
+    """See the module docstring ("First contact").  This process never initialises the GPU."""
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    store = None
+    if form == "ranks":
+        # the supervising ranks agree through a TCP store: the launcher's own (torch.distributed.run hosts one on MASTER_PORT
+        # and sets TORCHELASTIC_USE_AGENT_STORE), else one hosted by rank 0
+        from datetime import timedelta
+
+        from torch.distributed import PrefixStore, TCPStore
+
+        agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
+        base = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world_size=None if agent else world,
+                        is_master=(rank == 0 and not agent), timeout=timedelta(seconds=300), wait_for_workers=False)
+        store = PrefixStore(f"cmfbench/{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}/{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}/", base)
+    attempts, line = [], None
+    for a, (label, child_form, extra) in enumerate(LADDER[form]):
+        rec = {"form": label, "env": extra}
+        extra = dict(extra, CMF_BENCH_ATTEMPT=str(a))
+        t0 = time.time()
+        if form == "multi" and child_form == "multi":
+            ok, reason, out0, errs = run_attempt([(child_command(args, "multi"), child_env(extra))], args.attempt_timeout)
+        elif form == "multi":  # bench.py is its own launcher: one child per GPU
+            port = free_port()
+            ok, reason, out0, errs = run_attempt([(child_command(args, "ranks"), child_env(extra, r, args.gpus, port)) for r in range(args.gpus)],
+                                                 args.attempt_timeout)
+        else:
+            if rank == 0:
+                store.set(f"port{a}", str(free_port()))
+            port = int(store.get(f"port{a}").decode())
+            env = child_env(extra, rank, world, port)
+            env["LOCAL_RANK"] = os.environ.get("LOCAL_RANK", str(rank))
+
+            def should_abort():
+                try:
+                    return bool(store.check([f"failed{a}"]))
+                except Exception:  # noqa: BLE001 - a store hiccup must not end a healthy attempt
+                    return False
+
+            ok, reason, out0, errs = run_attempt([(child_command(args, "ranks"), env)], args.attempt_timeout, should_abort)
+            if not ok:
+                store.set(f"failed{a}", "1")
+            store.set(f"done{a}/{rank}", "ok" if ok else (reason or "failed"))
+            store.wait([f"done{a}/{r}" for r in range(world)])
+            states = [store.get(f"done{a}/{r}").decode() for r in range(world)]
+            if ok and any(st_ != "ok" for st_ in states):
+                ok, reason = False, "; ".join(f"rank {r}: {st_}" for r, st_ in enumerate(states) if st_ != "ok")
+        rec.update(ok=ok, seconds=round(time.time() - t0, 1))
+        got = last_json_line(out0) if rank == 0 else None
+        if not ok:
+            rec["ended"] = reason
+            rec["children"] = errs
+            if got is not None:  # the child's own failure record: phase, cmf_last_error, comm, what it had measured
+                rec["child_line"] = {k: got.get(k) for k in ("failed_phase", "error", "cmf_last_error", "comm", "ms_per_step", "partial") if k in got}
+        attempts.append(rec)
+        if ok and (rank != 0 or (got is not None and got.get("value") is not None)):
+            line = got
+            break
+        if ok:  # every child exited 0 but rank 0's printed no usable line
+            attempts[-1]["ok"], attempts[-1]["ended"] = False, "no JSON line with a value on the child's stdout"
+    if store is not None:  # the rank that hosts the store leaves last
+        try:
+            store.set(f"bye/{rank}", "1")
+            if rank == 0:
+                store.wait([f"bye/{r}" for r in range(world)])
+        except Exception:  # noqa: BLE001 - the run is over either way
+            pass
+    if rank != 0:
+        sys.exit(0 if line is not None or attempts[-1]["ok"] else 3)
+    if line is not None:
+        line["attempts"] = attempts
+        print(json.dumps(line), flush=True)
+        sys.exit(0)
+    cfg = CONFIGS[args.config]
+    print(json.dumps({"metric": "MU iters/sec (convolutive NMF multiplicative update; achieved HBM GB/s in `hbm`)", "value": None, "unit": "iter/s",
+                      "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                      "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": f"configs[{args.config - 1}]: N={cfg['N']} T={args.T or cfg['T']} K={cfg['K']} L={cfg['L']} fp32", "launch": form},
+                      "failed_phase": "every form of the ladder failed", "attempts": attempts}), flush=True)
+    sys.exit(3)
+
+
+def main():
+    args = parse_args()
     try:
         form = route(args.gpus, os.environ.get("WORLD_SIZE", "1"))
     except ValueError as e:
         raise SystemExit(str(e))
+    if args.child:
+        form = args.child
+    elif args.gpus > 1 and os.environ.get("CMF_BENCH_SUPERVISE", "1") != "0":
+        return supervise(args, form)
+    progress = {"phase": "start", "rank": int(os.environ.get("RANK", "0"))}
+    try:
+        measure(args, form, progress)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 - first contact: whatever went wrong, say where, and what was known by then
+        import traceback
+
+        traceback.print_exc()
+        rec = {"metric": "MU iters/sec (convolutive NMF multiplicative update; achieved HBM GB/s in `hbm`)", "value": None, "unit": "iter/s",
+               "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"configs[{args.config - 1}]", "launch": form},
+               "failed_phase": progress.get("phase"), "error": repr(e), "rank": progress.get("rank")}
+        try:
+            rec["cmf_last_error"] = progress["lib"].cmf_last_error().decode() if progress.get("lib") else None
+        except Exception:  # noqa: BLE001
+            rec["cmf_last_error"] = None
+        for k in ("comm", "partial"):
+            if k in progress:
+                rec[k] = progress[k]
+        if "rule" in progress and "comm" not in rec:
+            try:
+                rec["comm"] = parse_comm(progress["rule"].comm_info(), form)
+            except Exception:  # noqa: BLE001
+                pass
+        # every rank says what it saw (stderr); the JSON line is rank 0's -- or the failing rank's own when rank 0 is not it
+        print(f"bench.py rank {progress.get('rank')}: failed in phase '{progress.get('phase')}': {e!r}", file=sys.stderr, flush=True)
+        print(json.dumps(rec), flush=True)
+        sys.exit(3)
+
+
+def measure(args, form, progress):
+    # the oracle's OpenMP loops (HALS baseline) are short: one thread per visible core only adds spinning
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+    # RCCL shares device buffers between processes through dmabuf IPC; the host driver of these boxes supports only that
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = args.gpus if form == "ranks" else 1   # processes
     ngpu = args.gpus                              # GPUs of the job
 
@@ -286,6 +557,7 @@ def main():
     import cmf_jl_amd as cmf
 
     lib = cmf.load_library()
+    progress.update(lib=lib, phase="inputs (gen_synthetic, init_rand)")
     # CMF_BENCH_DEVICES="0,0,0,0": rehearse the one-process form on a box with fewer GPUs than shards (the same device may
     # be listed several times: loopback transport) -- everything of the multi-GPU code path but RCCL itself
     multi_devices = list(range(ngpu))
@@ -304,7 +576,10 @@ def main():
     W0, H0 = cmf.init_rand(data, L=L, K=K, seed=0, device=local_rank)
 
     replicas = []
-    overlap_env = os.environ.get("CMF_ALLREDUCE_OVERLAP", "0")
+    progress["phase"] = "rule / group construction"
+    # the overlap form (its bulk all-reduce on a second stream with a communicator of its own) is probed against the plain
+    # form from 4 GPUs on, where the all-reduce is a visible share of the step: both times are recorded, the faster is kept
+    overlap_env = os.environ.get("CMF_ALLREDUCE_OVERLAP", "probe" if ngpu >= 4 else "0")
     if alg == "hals":
         # replicas only: the H sweep is one dependent chain along T, nothing to exchange
         devs = multi_devices if form == "multi" else [local_rank]
@@ -314,8 +589,14 @@ def main():
         rule = cmf.MultUpdate(data, W0, H0, device=local_rank)
     elif form == "multi":
         # ONE process, ngpu devices: cmf_create_multi -> RCCL communicators from ncclCommInitAll, a stream per device
+        # CMF_BENCH_TRANSPORT: rccl (default for distinct devices) | peer (direct xGMI reads / writes between event fences,
+        # opt-in) | loopback | loopback-streams (rehearsals with CMF_BENCH_DEVICES listing one device several times)
+        tr_name = os.environ.get("CMF_BENCH_TRANSPORT", "auto")
+        tr_codes = {"auto": 0, "rccl": 1, "loopback": 2, "loopback-streams": 3, "peer": 4}
+        if tr_name not in tr_codes:
+            raise SystemExit(f"CMF_BENCH_TRANSPORT must be one of {sorted(tr_codes)}")
         try:
-            rule = cmf.MultUpdate(data, W0, H0, devices=multi_devices)
+            rule = cmf.MultUpdate(data, W0, H0, devices=multi_devices, transport=tr_codes[tr_name])
         except cmf.CMFError as e:
             print(f"bench.py --gpus {ngpu}: the {ngpu}-device group could not be formed: {e}", file=sys.stderr, flush=True)
             sys.exit(2)
@@ -373,6 +654,7 @@ def main():
             el = float(tmax.item())
         return el, ls
 
+    progress.update(rule=rule, phase="first loss (the group's first collectives)")
     loss0 = rule.compute_loss()
     probe = None
     sharded = alg == "mult" and ngpu > 1
@@ -384,18 +666,31 @@ def main():
         if overlap_env in ("0", "1"):
             rule.set_overlap(overlap_env == "1")
         else:
+            progress["phase"] = "overlap probe"
             probe = {}
             for f_ in (False, True):
-                rule.set_overlap(f_)
-                timed(2, 0)
-                probe["overlap" if f_ else "single"] = timed(0, 5)[0] / 5
-            rule.set_overlap(probe["overlap"] < probe["single"])
+                try:
+                    rule.set_overlap(f_)
+                    if f_ and not rule.overlap:  # refused (the second communicator could not be formed on some rank): stay single
+                        probe["overlap_refused"] = str(getattr(rule, "overlap_refused", None))
+                        break
+                    timed(2, 0)
+                    probe["overlap" if f_ else "single"] = timed(0, 5)[0] / 5
+                except cmf.CMFError as e:  # the probe must never cost the headline
+                    probe["overlap_error"] = repr(e)
+                    break
+            rule.set_overlap("overlap" in probe and probe["overlap"] < probe["single"])
+            progress["partial"] = {"allreduce_overlap_probe_ms": {k: (1e3 * v if isinstance(v, float) else v) for k, v in probe.items()}}
     # The timed region carries HIP event pairs around every fourth launch of each contraction kernel (option "profile": events on the
     # launch stream), so the per-kernel durations of the roofline block are measured live over these very steps.
     prof = rule
+    progress["phase"] = "warm-up steps"
     timed(args.warmup, 0)
+    progress["phase"] = "timed steps"
     prof.set_option("profile", 4 if alg == "mult" else 1)  # every 4th launch of each class (HALS: every span)
     dt, losses = timed(0, args.steps)
+    progress.setdefault("partial", {}).update(ms_per_step=1e3 * dt / args.steps, iters_per_s=args.steps / dt, loss_last=float(losses[-1]) if len(losses) else None)
+    progress["phase"] = "side measurements after the timed steps"
     inloop = {}
     for name in ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "hxt_num", "hxt_den", "transconv", "hals_h_pipeline", "hals_w_sweep"):
         kms, n = prof.kernel_times(name)
@@ -440,13 +735,13 @@ def main():
         rule.set_option("gram", 0)
 
     # Sharded runs: the Gram form on the group -- the all-reduce carries [numW | HH | tail] (6.9 MB instead of 10.5 MB at
-    # config 2) -- as extra fields (never part of `value`).  It issues exactly the collectives of the timed region (one
-    # all-reduce, one halo all-gather, on the main stream), only with another count, so it runs by default
-    # (CMF_BENCH_GROUP_EXTRAS=0 skips it).  The overlap variant, whose bulk all-reduce runs on a second stream underneath
-    # the loss conv, is opt-in (CMF_BENCH_GROUP_EXTRAS=1): a second collective in flight on the same communicator has only
-    # ever run on one device, and a side measurement must never be able to cost the headline of a multi-GPU run.
+    # config 2) -- as extra fields (never part of `value`).  OPT-IN (CMF_BENCH_GROUP_EXTRAS=gram, or =1 for its overlap
+    # variant too): RCCL with more than one rank has never run these group forms (no multi-GPU node was available to the
+    # build), a collective that wedges here is not caught by the try/except below but only by the library's bounded wait,
+    # and a side measurement must never be able to cost the headline of a multi-GPU run.  Switch it on once
+    # tests/test_multi_gpu.py has passed on a node.
     group_extras = None
-    ge_mode = os.environ.get("CMF_BENCH_GROUP_EXTRAS", "gram")
+    ge_mode = os.environ.get("CMF_BENCH_GROUP_EXTRAS", "0")
     if sharded and ge_mode != "0" and not args.no_extras:
         group_extras = {}
         keep_overlap = bool(rule.overlap)
@@ -467,14 +762,27 @@ def main():
     # the group's bulk exchange alone (every rank takes part: it is a collective), so that the record says how much of a
     # step is communication
     allreduce = None
+    collectives = None
     if sharded:
-        try:
-            ar_ms, ar_bytes = rule.time_kernel("allreduce", reps=10)
-            allreduce = {"avg_ms": ar_ms, "bytes": ar_bytes, "algbw_GBps": ar_bytes / ar_ms / 1e6 if ar_ms > 0 else None,
-                         "busbw_GBps": (ar_bytes / ar_ms / 1e6) * 2.0 * (ngpu - 1) / ngpu if ar_ms > 0 else None,
-                         "payload": "[numW | denomW | loss tail]: what one iteration all-reduces"}
-        except Exception as e:  # noqa: BLE001
-            allreduce = {"error": repr(e)}
+        progress["phase"] = "collectives timed alone"
+
+        def coll(name, payload, ring=True):
+            try:
+                ms_, by_ = rule.time_kernel(name, reps=10)
+                rec_ = {"avg_ms": ms_, "bytes": by_, "algbw_GBps": by_ / ms_ / 1e6 if ms_ > 0 else None, "payload": payload}
+                if ring:
+                    rec_["busbw_GBps"] = (by_ / ms_ / 1e6) * 2.0 * (ngpu - 1) / ngpu if ms_ > 0 else None
+                return rec_
+            except Exception as e:  # noqa: BLE001
+                return {"error": repr(e)}
+
+        allreduce = coll("allreduce", "[numW | denomW | loss tail]: what one iteration all-reduces")
+        collectives = {"allreduce_gram_payload": coll("allreduce_gram", "[numW | HH | loss tail]: the Gram form's all-reduce (option gram = 1)"),
+                       "allgather_halo": coll("allgather_halo", "every shard's [first | last] L-1 columns of H", ring=False)}
+        if rule.overlap:
+            collectives["allreduce_lane1"] = coll("allreduce_lane1", "numW on the communication stream and its own communicator (overlap form)")
+        progress.setdefault("partial", {}).update(allreduce=allreduce, collectives=collectives)
+        progress["phase"] = "report"
 
     out = None
     nrep_hals = len(replicas) if form == "multi" else (world if alg == "hals" else 1)
@@ -497,6 +805,7 @@ def main():
                 comm["rccl"] = {"error": repr(e)}
             comm["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
             comm["allreduce"] = allreduce
+            comm["collectives"] = collectives
         else:
             comm = None
         out = {
@@ -518,18 +827,18 @@ def main():
             "est_reuse": "the est of mult.jl:55 is kept for the next mult.jl:28 (same W, H): 6 of the 7 contractions "
                          "are executed, results bitwise identical; ms_per_step_no_reuse runs all 7",
             "allreduce_overlap": (bool(rule.overlap) if sharded else None),
-            "allreduce_overlap_probe_ms": ({k: 1e3 * v for k, v in probe.items()} if probe else None),
+            "allreduce_overlap_probe_ms": ({k: (1e3 * v if isinstance(v, float) else v) for k, v in probe.items()} if probe else None),
             "ms_per_step_without_event_pairs": (1e3 * dt_unprofiled / args.steps) if dt_unprofiled else None,
             "ms_per_step_no_reuse": (1e3 * dt_noreuse) if dt_noreuse else None,
             "ms_per_step_gram": (1e3 * dt_gram) if dt_gram else None,
             "ms_per_step_gram_loss": (1e3 * dt_gram2) if dt_gram2 else None,
             "gram_note": "option gram=1: denomW/denomH through Gram matrices (exact rewriting, rounding-level differences), "
                          "loss still by conv; gram=2: loss from Gram sums too.  Not part of `value`.",
-            # whole-iteration MFMA fraction on EXECUTED flops (6 contractions with est reuse); the 7-contraction figure of
-            # SURVEY.md section 8d is kept under an explicit name: it exceeds the executed one by 7/6 by construction
+            # whole-iteration MFMA fraction on EXECUTED flops (6 contractions with est reuse).  (SURVEY.md section 8d's
+            # 7-contraction figure F_iter is `flops_per_iter`; dividing it by the time counts the reused est as work done,
+            # so no fraction is formed from it.)
             "whole_iteration_tflops_executed": (F_iter * (6.0 / 7.0 if alg == "mult" else 1.0)) * iters_per_s / 1e12,
             "whole_iteration_mfma_frac": (F_iter * (6.0 / 7.0 if alg == "mult" else 1.0)) * iters_per_s / (ngpu * PEAK_FP32_MFMA_TFLOPS * 1e12),
-            "whole_iteration_mfma_frac_reference_formulation_equivalent": F_iter * iters_per_s / (ngpu * PEAK_FP32_MFMA_TFLOPS * 1e12),
             "sustained": sustained,
             "comm": comm,
             "group_extras": group_extras,
@@ -551,6 +860,7 @@ def main():
                 return json.load(open(pth)), nm
         raise FileNotFoundError("no PMC summary under profiles/")
 
+    progress["phase"] = "stand-alone kernel timings"
     if rank == 0:
         kern = {}
         timer = rule

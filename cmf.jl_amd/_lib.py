@@ -16,8 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcmf_hip.so")
 
 CMF_OK, CMF_ERR_ARG, CMF_ERR_HIP, CMF_ERR_STATE, CMF_ERR_UNSUPPORTED, CMF_ERR_COMM = 0, 1, 2, 3, 4, 5
-CMF_COMM_AUTO, CMF_COMM_RCCL, CMF_COMM_LOOPBACK, CMF_COMM_LOOPBACK_STREAMS = 0, 1, 2, 3
-ABI_VERSION = 3  # CMF_ABI_VERSION of include/cmf_hip.h
+CMF_COMM_AUTO, CMF_COMM_RCCL, CMF_COMM_LOOPBACK, CMF_COMM_LOOPBACK_STREAMS, CMF_COMM_PEER = 0, 1, 2, 3, 4
+ABI_VERSION = 4  # CMF_ABI_VERSION of include/cmf_hip.h
 
 # host-collective callbacks of cmf_comm_init_callbacks (include/cmf_hip.h)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int64)
@@ -28,7 +28,7 @@ SYMBOLS = [
     "cmf_abi_version", "cmf_version", "cmf_source_digest", "cmf_last_error", "cmf_device_count",
     "cmf_create", "cmf_create_shard", "cmf_create_multi", "cmf_destroy", "cmf_synchronize", "cmf_set_stream",
     "cmf_rccl_version", "cmf_get_counter",
-    "cmf_comm_unique_id", "cmf_comm_init_rccl", "cmf_comm_init_callbacks", "cmf_comm_info", "cmf_shard_bounds",
+    "cmf_comm_unique_id", "cmf_comm_init_rccl", "cmf_comm_init_overlap", "cmf_comm_init_callbacks", "cmf_comm_info", "cmf_shard_bounds",
     "cmf_set_option", "cmf_get_data_sumsq",
     "cmf_set_factors", "cmf_get_factors",
     "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_iterate", "cmf_fit", "cmf_converged",
@@ -94,6 +94,7 @@ def load():
     sig("cmf_create_multi", [pvp, cint, ctypes.POINTER(cint), cint, i64, i64, i64, i64, pd])
     sig("cmf_comm_unique_id", [vp])
     sig("cmf_comm_init_rccl", [vp, cint, cint, vp])
+    sig("cmf_comm_init_overlap", [vp, vp])
     sig("cmf_comm_init_callbacks", [vp, cint, cint, ALLREDUCE_FN, ALLGATHER_FN, vp])
     sig("cmf_comm_info", [vp, ctypes.c_char_p, i64])
     sig("cmf_shard_bounds", [vp, cint, pi64, pi64])

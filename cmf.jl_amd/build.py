@@ -64,17 +64,38 @@ def is_stale():
 
 
 def build_lib(force=False, verbose=False):
+    """Builds the library unless the one in place already carries the tree's digest.  Safe to call from many processes at
+    once (the ranks of a launcher all import the package): an exclusive lock on `libcmf_hip.so.lock` serialises them, the
+    digest is looked at again under the lock so that only the first one compiles, and every build writes to a name of
+    its own before the atomic rename -- no process can ever map a library another hipcc is still writing.  `force`
+    rebuilds even a current binary (command line), but never twice in a row for callers queued on the lock."""
+    import fcntl
+
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           f'-DCMF_SRC_DIGEST="{source_digest()}"',
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC] + SOURCES + ["-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)  # never leave a half-written library where a loader could find it
+    want = source_digest()
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if embedded_digest() == want and not (force and getattr(build_lib, "_cli", False)):
+                return LIB  # another process built it while this one waited
+            tmp = f"{LIB}.{os.getpid()}.tmp"
+            cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+                   f'-DCMF_SRC_DIGEST="{want}"',
+                   "-I", os.path.join(ROOT, "include"), "-I", CSRC] + SOURCES + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB)  # never leave a half-written library where a loader could find it
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
 if __name__ == "__main__":
+    build_lib._cli = True
     print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -53,6 +53,62 @@ static int fail(int code, const char *fmt, ...)
 static inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------------------
+// roctx ranges (tracing)
+// ------------------------------------------------------------------------------------------
+// The phases of an iteration and every collective are bracketed with roctx ranges on the thread that enqueues them, so that
+// a `rocprofv3 --marker-trace --kernel-trace` timeline of a multi-GPU run reads as "W phase | all-reduce | H phase | halo
+// all-gather | loss conv" per shard.  The marker library is bound at run time and only when it is wanted: a copy the
+// process has already mapped (the profiler preloads it) is used, CMF_ROCTX=1 loads it on request; otherwise a range is
+// two predictable branches.
+#include <dlfcn.h>
+struct RoctxApi {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+};
+static const RoctxApi &roctx_api()
+{
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        const char *env = getenv("CMF_ROCTX");
+        if (env && atoi(env) == 0 && *env) return a; // CMF_ROCTX=0: never
+        void *dl = nullptr;
+        for (const char *nm : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            dl = dlopen(nm, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (dl) break;
+        }
+        if (!dl && env && atoi(env) == 1)
+            for (const char *nm : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/libroctx64.so.4"}) {
+                dl = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+                if (dl) break;
+            }
+        if (!dl) return a;
+        a.push = reinterpret_cast<int (*)(const char *)>(dlsym(dl, "roctxRangePushA"));
+        a.pop = reinterpret_cast<int (*)()>(dlsym(dl, "roctxRangePop"));
+        if (!a.push || !a.pop) a.push = nullptr, a.pop = nullptr;
+        return a;
+    }();
+    return api;
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char *name) : on(roctx_api().push != nullptr)
+    {
+        if (on) roctx_api().push(name);
+    }
+    RoctxRange(const char *fmt, int a) : on(roctx_api().push != nullptr)
+    {
+        if (!on) return;
+        char buf[96];
+        snprintf(buf, sizeof(buf), fmt, a);
+        roctx_api().push(buf);
+    }
+    ~RoctxRange()
+    {
+        if (on) roctx_api().pop();
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // handle
 // ------------------------------------------------------------------------------------------
 struct cmf_handle_s {
@@ -747,7 +803,8 @@ static int get_factors_impl(cmf_handle_s *h, double *W, double *H)
 // read-back).  Polling instead of an event keeps barrier packets and cache write-backs out of the stream; the stream is
 // queried now and then so that a failed launch surfaces as an error instead of a hang.  `health` (optional) is called at
 // the same cadence: a group passes a check of its other shards' streams and communicators, because the word is posted
-// by shard 0 only and a peer that faulted would otherwise leave the host spinning here.  The wait is bounded
+// by shard 0 only and a peer that faulted would otherwise leave the host spinning here.  `enqueued` (optional): false while
+// enqueue workers of the group have not yet handed all posted work to the streams.  The wait is bounded
 // (CMF_WAIT_TIMEOUT_S seconds, default 300): a collective that can never complete ends in CMF_ERR_COMM, not in a hang.
 static double wait_timeout_s()
 {
@@ -760,7 +817,8 @@ static double wait_timeout_s()
 }
 
 template <typename U>
-static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel, const std::function<int()> *health = nullptr)
+static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel, const std::function<int()> *health = nullptr,
+                      const std::function<bool()> *enqueued = nullptr)
 {
     auto all_there = [&]() {
         for (int j = 0; j < n; ++j)
@@ -774,7 +832,9 @@ static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel
             return CMF_OK;
         }
         if ((spins & 0xFFF) == 0) {
-            const hipError_t e = hipStreamQuery(stream);
+            // (enqueue workers that are still posting leave the stream idle: only a stream that has been given all its work
+            // and has drained it proves that the words will never come)
+            const hipError_t e = (enqueued && !(*enqueued)()) ? hipErrorNotReady : hipStreamQuery(stream);
             if (e == hipSuccess) { // everything enqueued has run: the words must be there now
                 if (all_there()) return CMF_OK;
                 return fail(CMF_ERR_HIP, "the stream drained without posting the loss");
@@ -826,7 +886,7 @@ extern "C" {
 #endif
 #define CMF_STR2(x) #x
 #define CMF_STR(x) CMF_STR2(x)
-const char *cmf_version(void) { return "cmf_hip gfx950 0.3.0 abi=" CMF_STR(CMF_ABI_VERSION) " src=" CMF_SRC_DIGEST; }
+const char *cmf_version(void) { return "cmf_hip gfx950 0.4.0 abi=" CMF_STR(CMF_ABI_VERSION) " src=" CMF_SRC_DIGEST; }
 const char *cmf_source_digest(void) { return CMF_SRC_DIGEST; }
 int cmf_abi_version(void) { return CMF_ABI_VERSION; }
 const char *cmf_last_error(void) { return g_err.c_str(); }
@@ -842,8 +902,12 @@ int cmf_device_count(void)
 // addresses, and so must H (Tpad * Kpad floats)
 static int64_t max_columns_per_handle(int64_t K)
 {
-    if (const char *e = getenv("CMF_MAX_COLUMNS")) // tests: take the long-recording paths at small sizes
-        if (atoll(e) > 0) return atoll(e);
+    // tests take the long-recording paths at small sizes; the knob is honoured only together with CMF_TEST_HOOKS=1, so that
+    // a stray variable in a production environment cannot move the cut point
+    if (const char *hooks = getenv("CMF_TEST_HOOKS"))
+        if (atoi(hooks) == 1)
+            if (const char *e = getenv("CMF_MAX_COLUMNS"))
+                if (atoll(e) > 0) return atoll(e);
     const int64_t K32 = 32 * ((K + 31) / 32);
     const int64_t by_est = ((int64_t)1 << 31) / (64 * 4), by_h = ((int64_t)1 << 31) / (K32 * 4);
     return std::min(by_est, by_h) - 4096; // (left lag halo and tile padding)
@@ -912,6 +976,17 @@ int cmf_get_counter(cmf_handle h, const char *name, int64_t *value)
 {
     if (!h || !name || !value) return fail(CMF_ERR_ARG, "NULL argument");
     if (std::strcmp(name, "hals_pipeline_reruns") == 0) { *value = h->hals_reruns; return CMF_OK; }
+    if (h->group) { // host cost of the pipelined iterations of a group (reading a counter resets nothing)
+        cmf_group_s *g = h->group;
+        if (std::strcmp(name, "enqueue_ns") == 0) { *value = g->enqueue_ns; return CMF_OK; }       // calling thread: enqueueing / posting
+        if (std::strcmp(name, "enqueue_iters") == 0) { *value = g->enqueue_iters; return CMF_OK; } // ... over this many iterations
+        if (std::strcmp(name, "worker_ns") == 0) {                                                  // busiest enqueue worker: time inside its jobs
+            int64_t m = 0;
+            for (const auto &w : g->workers) m = std::max<int64_t>(m, w->busy_ns.load());
+            *value = m;
+            return CMF_OK;
+        }
+    }
     return fail(CMF_ERR_ARG, "unknown counter '%s'", name);
 }
 
@@ -928,10 +1003,18 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
     if (!h || !name) return fail(CMF_ERR_ARG, "NULL argument");
     if (h->group) {
         cmf_group_s *g = h->group;
+        CMFTRY(group_join(g));
         if (std::strcmp(name, "allreduce_overlap") == 0) {
             CMFTRY(group_sync(g));
+            if (value) CMFTRY(group_ensure_lane1(g)); // the communication stream gets a communicator of its own
             g->overlap = value != 0;
             g->num_ready = false;
+            return CMF_OK;
+        }
+        if (std::strcmp(name, "enqueue_threads") == 0) { // 1: an enqueue worker per shard (cmf_group.h), 0: the calling thread enqueues every shard
+            CMFTRY(group_sync(g));
+            if (value) return group_start_workers(g);
+            group_stop_workers(g);
             return CMF_OK;
         }
         if (std::strcmp(name, "gram") == 0) {
@@ -942,9 +1025,15 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
             if (value && g->nranks > 1 && g->T < 4 * g->L)
                 return fail(CMF_ERR_UNSUPPORTED, "the Gram form on a sharded handle needs T >= 4 L (got T=%lld, L=%lld)", (long long)g->T, (long long)g->L);
             CMFTRY(group_sync(g));
-            for (cmf_handle_s *s : g->sh) {
+            for (size_t i = 0; i < g->sh.size(); ++i) {
+                cmf_handle_s *s = g->sh[i];
                 CMFTRY(group_use(s));
                 if (value) CMFTRY(gram_ensure(s));
+                // the HH block shares its place with denomW of the default form; hals_hh_kernel writes the first L*K columns
+                // of each 128-padded row only, and the all-reduce sums the whole block in place: whatever the pad columns
+                // held would be multiplied by the rank count every iteration until it overflowed
+                if (value && i < g->red.size() && g->red[i])
+                    HIPCHK(hipMemsetAsync(g->red[i] + g->LKN2 / 2, 0, (size_t)g->HHsz * sizeof(float), s->stream));
                 s->gram = value;
                 s->est_kind = 0;
                 s->carry = CmfLossCarry{};
@@ -1034,10 +1123,12 @@ int cmf_get_factors(cmf_handle h, double *W, double *H)
 
 int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
 {
+    RoctxRange range("cmf_update_motifs");
     drop_carry(h);
     if (h && h->group) {
         CMFTRY(group_check_ready(h->group));
-        return group_update_motifs(h->group, l1W, l2W);
+        CMFTRY(group_update_motifs(h->group, l1W, l2W));
+        return group_join(h->group); // (enqueue workers: the phase has been handed to the streams when this returns)
     }
     CMFTRY(check_ready(h, true));
     if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator first (cmf_comm_init_rccl / cmf_comm_init_callbacks), or build the group with cmf_create_multi");
@@ -1048,6 +1139,7 @@ int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
 
 int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
 {
+    RoctxRange range("cmf_update_feature_maps");
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
     drop_carry(h);
     if (h && h->group) {
@@ -1224,7 +1316,9 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
         return CMF_OK;
     };
     for (int64_t it = 0; it < n; ++it) {
+        RoctxRange it_range("cmf:iteration %d", (int)it);
         if (!eval_mode) { // alternating.jl:51-53
+            RoctxRange w_range("cmf:W phase (update_motifs!)");
             if (h->gram) {
                 CMFTRY(gram_w_impl(h, l1W, l2W));
             } else {
@@ -1232,6 +1326,7 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
                 CMFTRY(w_apply_impl(h, l1W, l2W));
             }
         }
+        RoctxRange h_range("cmf:H phase + loss conv (update_feature_maps!)");
         CMFTRY(h->gram ? gram_h_update(h, l1H, l2H) : h_update_impl(h, l1H, l2H)); // :54
         const int slot = (int)(it & 1);
         ring[slot] = CMF_SENTINEL64; // the slot's previous loss was collected an iteration ago
@@ -1251,6 +1346,7 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
 int cmf_iterate(cmf_handle h, int64_t n_iter, int eval_mode, double l1W, double l2W, double l1H, double l2H,
                 double *losses, double *stamps)
 {
+    RoctxRange range("cmf_iterate");
     if (!h || !losses) return fail(CMF_ERR_ARG, "NULL argument");
     if (n_iter < 0) return fail(CMF_ERR_ARG, "n_iter must be >= 0");
     drop_carry(h);
@@ -1337,9 +1433,27 @@ int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transpor
     if (transport == CMF_COMM_AUTO) tr = (ndev > 1 && distinct) ? CMF_TR_RCCL : CMF_TR_LOOPBACK;
     else if (transport == CMF_COMM_RCCL) tr = CMF_TR_RCCL;
     else if (transport == CMF_COMM_LOOPBACK || transport == CMF_COMM_LOOPBACK_STREAMS) tr = CMF_TR_LOOPBACK;
+    else if (transport == CMF_COMM_PEER) tr = CMF_TR_PEER;
     else return fail(CMF_ERR_ARG, "unknown transport %d", transport);
     if (tr == CMF_TR_RCCL && !distinct) return fail(CMF_ERR_ARG, "RCCL needs distinct devices (a device is listed twice)");
     if (tr == CMF_TR_LOOPBACK && !all_same) return fail(CMF_ERR_ARG, "the loopback transport needs all shards on one device; list distinct devices for RCCL");
+    if (tr == CMF_TR_PEER && !(distinct || all_same)) return fail(CMF_ERR_ARG, "the peer transport takes distinct devices, or one device for every shard (rehearsal)");
+    if (tr == CMF_TR_PEER && ndev > 1 && distinct) {
+        // every device maps every other one's memory (xGMI): the transport's kernels read and write the peers' buffers directly
+        for (int i = 0; i < ndev; ++i) {
+            HIPCHK(hipSetDevice(devices[i]));
+            for (int j = 0; j < ndev; ++j) {
+                if (i == j) continue;
+                int can = 0;
+                HIPCHK(hipDeviceCanAccessPeer(&can, devices[i], devices[j]));
+                if (!can) return fail(CMF_ERR_COMM, "device %d cannot access device %d's memory: the peer transport needs peer access between all devices of the group", devices[i], devices[j]);
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(CMF_ERR_HIP, "hipDeviceEnablePeerAccess(%d) on device %d failed: %s", devices[j], devices[i], hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+        }
+    }
     std::vector<int64_t> t0, t1;
     group_partition(T, ndev, L, t0, t1);
     for (int r = 0; r < ndev; ++r)
@@ -1383,9 +1497,25 @@ int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transpor
     }
     int rc = group_alloc_buffers(g);
     if (rc == CMF_OK) rc = group_finish_norm(g);
+    // an enqueue worker per shard wherever every shard has its own stream (cmf_group.h); CMF_ENQUEUE_THREADS=0: the calling
+    // thread enqueues all shards (option "enqueue_threads" switches later)
+    const char *et = getenv("CMF_ENQUEUE_THREADS");
+    if (rc == CMF_OK && !(et && atoi(et) == 0)) rc = group_start_workers(g);
     if (rc != CMF_OK) return bail(rc);
     *out = root;
     return CMF_OK;
+}
+
+// The overlap form's communication stream gets a communicator of its own (cmf_group.h, lane 1).  One process per shard:
+// every rank calls this with the SAME second id (rank 0's cmf_comm_unique_id, handed over like the first); groups from
+// cmf_create_multi create theirs themselves when the option is switched on and need not call it (id128 may be NULL).
+int cmf_comm_init_overlap(cmf_handle h, const void *id128)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (!h->group) return fail(CMF_ERR_STATE, "the handle belongs to no group");
+    if (h->group->transport != CMF_TR_RCCL) return CMF_OK; // the other transports order their lanes with events
+    if (!h->group->one_process && !id128) return fail(CMF_ERR_ARG, "id128 is NULL");
+    return group_ensure_lane1(h->group, id128);
 }
 
 int cmf_comm_unique_id(void *id128)
@@ -1469,15 +1599,17 @@ int cmf_comm_info(cmf_handle h, char *buf, int64_t len)
         const cmf_group_s *g = h->group;
         std::string ranks;
         for (size_t i = 0; i < g->rank.size(); ++i) ranks += (i ? "," : "") + std::to_string(g->rank[i]) + "@dev" + std::to_string(g->sh[i]->device);
+        const char *enq = g->workers.empty() ? "caller" : "threads"; // who enqueues the shards (cmf_group.h)
+        const int lanes = (g->transport == CMF_TR_RCCL && g->comm2.size() == g->sh.size()) ? 2 : 1; // communicators per shard
         if (g->transport == CMF_TR_RCCL) {
             int v = 0;
             (void)g_rccl.GetVersion(&v);
-            snprintf(tmp, sizeof(tmp), "transport=rccl version=%d lib=%s nranks=%d local=%zu ranks=%s overlap=%d", v, g_rccl.path.c_str(),
-                     g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap);
+            snprintf(tmp, sizeof(tmp), "transport=rccl version=%d lib=%s nranks=%d local=%zu ranks=%s overlap=%d enqueue=%s lanes=%d failed=%d", v,
+                     g_rccl.path.c_str(), g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap, enq, lanes, (int)g->failed);
         } else {
-            snprintf(tmp, sizeof(tmp), "transport=%s nranks=%d local=%zu ranks=%s overlap=%d",
-                     g->transport == CMF_TR_LOOPBACK ? (g->loop_ms ? "loopback-streams" : "loopback") : "callbacks",
-                     g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap);
+            snprintf(tmp, sizeof(tmp), "transport=%s nranks=%d local=%zu ranks=%s overlap=%d enqueue=%s lanes=%d failed=%d",
+                     g->transport == CMF_TR_LOOPBACK ? (g->loop_ms ? "loopback-streams" : "loopback") : (g->transport == CMF_TR_PEER ? "peer" : "callbacks"),
+                     g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap, enq, lanes, (int)g->failed);
         }
     }
     snprintf(buf, (size_t)len, "%s", tmp);
@@ -2177,6 +2309,8 @@ static int group_pgd_prepare(cmf_handle_s *st, cmf_group_s *g, int nonneg)
 
 static int group_pgd_w(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double pen_abs, int nonneg)
 {
+    GroupInline scope(g);
+    CMFTRY(scope.rc);
     CMFTRY(group_pgd_prepare(st, g, nonneg));
     const CmfDims &d0 = g->sh[0]->d;
     const float gscale = st->pgd_loss_abs ? 1.f : 2.f; // pgd.jl:31-33 vs :42-44
@@ -2209,6 +2343,8 @@ static int group_pgd_w(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double p
 
 static int group_pgd_h(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double pen_abs, int nonneg, double *loss)
 {
+    GroupInline scope(g);
+    CMFTRY(scope.rc);
     CMFTRY(group_pgd_prepare(st, g, nonneg));
     const float gscale = st->pgd_loss_abs ? 1.f : 2.f;
     std::vector<double *> nrm;
@@ -2500,25 +2636,40 @@ int cmf_kernel_times(cmf_handle h, const char *name, double *avg_ms, int64_t *la
 int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, double *flops)
 {
     if (!name || !avg_ms || !flops || reps < 1) return fail(CMF_ERR_ARG, "bad argument");
-    if (h && h->group && std::strcmp(name, "allreduce") == 0) {
-        // The group's bulk exchange alone: `reps` all-reduces of the buffer an iteration sends ([numW | denomW | tail], or
-        // [numW | HH | tail] in the Gram form), timed with events on shard 0's stream.  EVERY rank of the group must make this
-        // call (it is a collective).  *flops receives the payload in bytes.  The buffer's contents are scratch between iterations.
+    if (h && h->group && (std::strcmp(name, "allreduce") == 0 || std::strcmp(name, "allreduce_gram") == 0 || std::strcmp(name, "allreduce_lane1") == 0 ||
+                          std::strcmp(name, "allgather_halo") == 0)) {
+        // The group's exchanges alone, timed with events on shard 0's stream: "allreduce" = `reps` all-reduces of the buffer an
+        // iteration sends ([numW | denomW | tail], or [numW | HH | tail] when the Gram form is on), "allreduce_gram" = the Gram
+        // form's payload whatever the option says, "allreduce_lane1" = the overlap form's bulk share on the communication
+        // stream and its own communicator, "allgather_halo" = the (L-1)-column H halo all-gather.  EVERY rank of the group must
+        // make this call (it is a collective).  *flops receives the payload in bytes.  The buffers are scratch between iterations.
         cmf_group_s *g = h->group;
         CMFTRY(group_check_ready(g));
+        GroupInline scope(g);
+        CMFTRY(scope.rc);
         CMFTRY(group_sync(g));
         cmf_handle_s *s0 = g->sh[0];
-        const size_t count = group_tail_off(g) + (size_t)g->tail;
-        for (size_t i = 0; i < g->sh.size(); ++i) { // finite input: the sums of `reps` all-reduces of zeros stay zeros
-            CMFTRY(group_use(g->sh[i]));
-            HIPCHK(hipMemsetAsync(g->red[i], 0, count * sizeof(float), g->sh[i]->stream));
+        const bool halo = std::strcmp(name, "allgather_halo") == 0, lane1 = std::strcmp(name, "allreduce_lane1") == 0;
+        const size_t half = (size_t)g->LKN2 / 2;
+        size_t count = group_tail_off(g) + (size_t)g->tail;
+        if (std::strcmp(name, "allreduce_gram") == 0) count = half + (size_t)g->HHsz + (size_t)g->tail;
+        if (lane1) {
+            count = g->gram ? half + (size_t)g->HHsz : half;
+            CMFTRY(group_ensure_lane1(g));
         }
-        CMFTRY(group_allreduce(g, g->red, 0, count)); // warm-up
+        if (halo) count = (size_t)(2 * g->HC);
+        auto once = [&]() -> int { return halo ? group_allgather(g, g->halo_send, g->halo_all, count) : group_allreduce(g, g->red, 0, count, lane1 ? 1 : 0); };
+        for (size_t i = 0; i < g->sh.size() && !halo; ++i) { // finite input: the sums of `reps` all-reduces of zeros stay zeros
+            CMFTRY(group_use(g->sh[i]));
+            HIPCHK(hipMemsetAsync(g->red[i], 0, count * sizeof(float), lane1 ? g->sh[i]->comm_stream : g->sh[i]->stream));
+        }
+        hipStream_t ts = lane1 ? s0->comm_stream : s0->stream;
+        CMFTRY(once()); // warm-up
         CMFTRY(group_use(s0));
-        HIPCHK(hipEventRecord(s0->ev0, s0->stream));
-        for (int r = 0; r < reps; ++r) CMFTRY(group_allreduce(g, g->red, 0, count));
+        HIPCHK(hipEventRecord(s0->ev0, ts));
+        for (int r = 0; r < reps; ++r) CMFTRY(once());
         CMFTRY(group_use(s0));
-        HIPCHK(hipEventRecord(s0->ev1, s0->stream));
+        HIPCHK(hipEventRecord(s0->ev1, ts));
         CMFTRY(group_sync(g));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, s0->ev0, s0->ev1));

@@ -20,8 +20,21 @@
 // Transports: RCCL over xGMI (the product path), "loopback" (all shards of a cmf_create_multi group on ONE device:
 // the collectives are plain kernels -- exercises middle-rank shards on a one-GPU box), and host callbacks (the
 // library stages the buffers through pinned host memory and the host performs the collective, e.g. gloo in the tests).
+//
+// Who enqueues (one-process groups with a stream per shard -- RCCL, peer, loopback-streams): by default one ENQUEUE WORKER
+// thread per shard, bound to the shard's device, takes the shard's whole share of an iteration -- its kernels and its
+// collective calls -- from a small queue, so the calling thread only posts (and polls the pinned loss words): eight shards
+// are enqueued in parallel instead of one after the other.  Each worker calls ncclAllReduce / ncclAllGather on ITS
+// communicator from ITS thread, without ncclGroupStart/End: that is RCCL's one-thread-per-device mode, in which no thread
+// ever manages two devices -- chosen over "workers meet at a barrier, the caller issues one grouped call" because the
+// barrier would put a host round trip back into every collective (two per iteration), which is exactly what the workers
+// are there to remove.  Option "enqueue_threads" = 0 (or CMF_ENQUEUE_THREADS=0) restores the single-thread form with
+// grouped RCCL calls.  The phases are written once, as lists of per-shard segments and collectives (GroupStep), and run
+// either way.
 #pragma once
+#include <condition_variable>
 #include <dlfcn.h>
+#include <memory>
 #include <mutex>
 
 // The handful of RCCL types this file passes through function pointers, declared here (values as in rccl.h of ROCm 7:
@@ -47,6 +60,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // optional
     ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr; // optional
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -90,6 +104,7 @@ static int rccl_load()
     RCCL_SYM(GroupEnd, "ncclGroupEnd");
 #undef RCCL_SYM
     g_rccl.CommGetAsyncError = reinterpret_cast<decltype(g_rccl.CommGetAsyncError)>(dlsym(dl, "ncclCommGetAsyncError"));
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(dl, "ncclCommAbort"));
     Dl_info info;
     if (dladdr(reinterpret_cast<void *>(g_rccl.AllReduce), &info) && info.dli_fname) g_rccl.path = info.dli_fname;
     g_rccl.dl = dl;
@@ -103,7 +118,26 @@ static int rccl_load()
     } while (0)
 
 // ---- the group ----------------------------------------------------------------------------------------------------
-enum { CMF_TR_LOOPBACK = 0, CMF_TR_RCCL = 1, CMF_TR_CALLBACKS = 2 };
+enum { CMF_TR_LOOPBACK = 0, CMF_TR_RCCL = 1, CMF_TR_CALLBACKS = 2, CMF_TR_PEER = 3 };
+enum { CMF_ERR_ECHO = -1000 }; // internal: a worker that gave up because ANOTHER shard's job failed (never crosses the ABI)
+
+// ---- enqueue workers ----------------------------------------------------------------------------------------------
+// One thread per local shard of a one-process group (see the file comment).  Single producer (the thread that calls the
+// ABI -- a handle is used by one host thread at a time), single consumer.  A worker spins briefly for the next job and
+// then sleeps on a condition variable, so an idle group costs nothing.
+struct GroupWorker {
+    static constexpr uint32_t QN = 64;
+    std::thread th;
+    std::function<int()> q[QN];
+    std::atomic<uint32_t> head{0}, tail{0}; // consumer / producer positions (free running)
+    std::atomic<bool> quit{false}, asleep{false};
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> rc{CMF_OK};            // code of the first failed job since the last join
+    std::string err;                        // its message (written before rc is published)
+    int device = 0;
+    std::atomic<int64_t> busy_ns{0};        // time spent inside jobs (cmf_get_counter "worker_ns": the largest of the group)
+};
 
 struct cmf_group_s {
     int nranks = 1;
@@ -112,6 +146,8 @@ struct cmf_group_s {
     std::vector<cmf_handle_s *> sh;      // local shards
     std::vector<int> rank;               // global rank of each local shard
     std::vector<ncclComm_t> comm;        // RCCL communicators (one per local shard)
+    std::vector<ncclComm_t> comm2;       // ... of the communication stream ("lane 1": the overlap form's bulk all-reduce never shares a
+                                         // communicator with a collective of the main stream); created when the overlap form is switched on
     cmf_allreduce_fn ar_cb = nullptr;    // host-callback transport
     cmf_allgather_fn ag_cb = nullptr;
     void *cb_user = nullptr;
@@ -141,6 +177,16 @@ struct cmf_group_s {
     bool loop_ms = false;
     hipEvent_t ev_in[2][CMF_MAX_LOCAL] = {};  // [main | comm stream][shard]
     hipEvent_t ev_out[2] = {nullptr, nullptr};
+    // peer transport: events of the stream fences around its kernels, [lane][before | after the kernel][shard]
+    hipEvent_t ev_peer[2][2][CMF_MAX_LOCAL] = {};
+    // enqueue workers (empty: the calling thread enqueues every shard itself)
+    std::vector<std::unique_ptr<GroupWorker>> workers;
+    std::atomic<bool> abort{false};      // a job failed: workers waiting at a barrier give up, the poll for the loss ends
+    std::atomic<int> bar_count{0}, bar_gen{0};
+    int64_t enqueue_ns = 0, enqueue_iters = 0; // cmf_iterate: time the calling thread spent enqueueing / posting, and the iterations it covers
+    int force_inline = 0;                // > 0: step lists run on the calling thread although workers exist (GroupInline)
+    bool failed = false;                 // a wait for the group ran out (or a collective reported an error): streams and communicators
+                                         // may never drain -- destruction aborts the communicators and does not wait for the streams
 };
 
 static void group_partition(int64_t T, int R, int64_t L, std::vector<int64_t> &t0, std::vector<int64_t> &t1)
@@ -162,6 +208,156 @@ static inline size_t group_tail_off(const cmf_group_s *g) { return (size_t)(g->g
 static int group_use(cmf_handle_s *s)
 {
     HIPCHK(hipSetDevice(s->device));
+    return CMF_OK;
+}
+
+// ---- worker queue ---------------------------------------------------------------------------------------------------
+static void worker_main(cmf_group_s *g, GroupWorker *w)
+{
+    (void)hipSetDevice(w->device);
+    unsigned idle = 0;
+    for (;;) {
+        const uint32_t h = w->head.load(std::memory_order_relaxed);
+        if (h == w->tail.load(std::memory_order_acquire)) {
+            if (w->quit.load(std::memory_order_acquire)) return;
+            if (++idle < 20000) { __builtin_ia32_pause(); continue; }
+            std::unique_lock<std::mutex> lock(w->mu); // nothing for a while (~0.2 ms): sleep until the producer posts
+            w->asleep.store(true, std::memory_order_seq_cst);
+            w->cv.wait(lock, [&] { return h != w->tail.load(std::memory_order_acquire) || w->quit.load(std::memory_order_acquire); });
+            w->asleep.store(false, std::memory_order_seq_cst);
+            idle = 0;
+            continue;
+        }
+        idle = 0;
+        std::function<int()> &job = w->q[h % GroupWorker::QN];
+        // after a failure the rest of the batch is skipped: its kernels would run on half-made inputs
+        if (w->rc.load(std::memory_order_relaxed) == CMF_OK && !g->abort.load(std::memory_order_acquire)) {
+            const auto tj = std::chrono::steady_clock::now();
+            const int rc = job();
+            w->busy_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tj).count(), std::memory_order_relaxed);
+            if (rc != CMF_OK) {
+                w->err = g_err;
+                w->rc.store(rc, std::memory_order_release);
+                g->abort.store(true, std::memory_order_release);
+            }
+        }
+        job = nullptr;
+        w->head.store(h + 1, std::memory_order_release);
+    }
+}
+
+static void worker_post(GroupWorker *w, std::function<int()> job)
+{
+    const uint32_t t = w->tail.load(std::memory_order_relaxed);
+    while (t - w->head.load(std::memory_order_acquire) >= GroupWorker::QN) __builtin_ia32_pause(); // queue full: the worker is behind
+    w->q[t % GroupWorker::QN] = std::move(job);
+    w->tail.store(t + 1, std::memory_order_seq_cst);
+    if (w->asleep.load(std::memory_order_seq_cst)) {
+        std::lock_guard<std::mutex> lock(w->mu);
+        w->cv.notify_one();
+    }
+}
+
+// have the workers taken everything that was posted?  (the device may still be running it)
+static bool group_enqueued(const cmf_group_s *g)
+{
+    for (const auto &w : g->workers)
+        if (w->head.load(std::memory_order_acquire) != w->tail.load(std::memory_order_acquire)) return false;
+    return true;
+}
+
+// Wait until every worker has run every posted job; the first failure (in shard order) becomes this thread's error.
+// Bounded like every wait of the group (CMF_WAIT_TIMEOUT_S): a worker that does not come back from a collective call ends
+// in CMF_ERR_COMM and a group marked failed, not in a hang.
+static int group_join(cmf_group_s *g)
+{
+    if (g->workers.empty()) return CMF_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
+    for (unsigned spins = 1; !group_enqueued(g); ++spins) {
+        if ((spins & 0xFFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > wait_timeout_s()) {
+            g->failed = true;
+            g->abort.store(true, std::memory_order_release);
+            return fail(CMF_ERR_COMM, "an enqueue worker of the group did not return within %.0f s (CMF_WAIT_TIMEOUT_S): a collective call is blocked on the host", wait_timeout_s());
+        }
+        __builtin_ia32_pause();
+    }
+    int rc = CMF_OK;
+    for (int pass = 0; pass < 2 && rc == CMF_OK; ++pass) // the failure itself, not its echoes from the shards that waited for it
+        for (auto &w : g->workers) {
+            const int r = w->rc.load(std::memory_order_acquire);
+            if (r != CMF_OK && rc == CMF_OK && (pass == 1 || r != CMF_ERR_ECHO)) {
+                rc = r == CMF_ERR_ECHO ? CMF_ERR_STATE : r;
+                g_err = w->err;
+            }
+        }
+    for (auto &w : g->workers) w->rc.store(CMF_OK, std::memory_order_relaxed);
+    g->abort.store(false, std::memory_order_release);
+    g->bar_count.store(0, std::memory_order_relaxed); // (workers that left a barrier on abort did not complete it)
+    if (rc == CMF_ERR_COMM) g->failed = true;
+    return rc;
+}
+
+// The entries that are not on the MU hot path (PGD, masks, stand-alone timings, ...) enqueue from the calling thread as they
+// always did: inside this scope the workers are idle and every step list runs in line.
+struct GroupInline {
+    cmf_group_s *g;
+    int rc;
+    explicit GroupInline(cmf_group_s *g_) : g(g_), rc(group_join(g_)) { ++g->force_inline; }
+    ~GroupInline() { --g->force_inline; }
+};
+
+// Meeting point of the workers inside a collective of the event-ordered transports (an event must have been recorded before
+// another stream is told to wait for it).  Gives up when any job of the group has failed.
+static int group_barrier(cmf_group_s *g)
+{
+    const int n = (int)g->workers.size();
+    const int gen = g->bar_gen.load(std::memory_order_acquire);
+    if (g->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+        g->bar_count.store(0, std::memory_order_relaxed);
+        g->bar_gen.fetch_add(1, std::memory_order_acq_rel);
+        return CMF_OK;
+    }
+    while (g->bar_gen.load(std::memory_order_acquire) == gen) {
+        if (g->abort.load(std::memory_order_acquire)) return fail(CMF_ERR_ECHO, "another shard of the group failed");
+        __builtin_ia32_pause();
+    }
+    return CMF_OK;
+}
+
+static void group_stop_workers(cmf_group_s *g)
+{
+    for (auto &w : g->workers) {
+        w->quit.store(true, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lock(w->mu);
+            w->cv.notify_one();
+        }
+        if (!w->th.joinable()) continue;
+        if (g->failed && w->head.load(std::memory_order_acquire) != w->tail.load(std::memory_order_acquire)) {
+            w->th.detach(); // stuck inside a call that will never return: the thread (and its queue) is abandoned, not joined
+            (void)w.release();
+            continue;
+        }
+        w->th.join();
+    }
+    g->workers.clear();
+}
+
+static bool group_wants_workers(const cmf_group_s *g)
+{
+    if (!g->one_process || g->sh.size() < 2) return false;
+    return g->transport == CMF_TR_RCCL || g->transport == CMF_TR_PEER || (g->transport == CMF_TR_LOOPBACK && g->loop_ms);
+}
+
+static int group_start_workers(cmf_group_s *g)
+{
+    if (!g->workers.empty() || !group_wants_workers(g)) return CMF_OK;
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        g->workers.emplace_back(new GroupWorker());
+        GroupWorker *w = g->workers.back().get();
+        w->device = g->sh[i]->device;
+        w->th = std::thread(worker_main, g, w);
+    }
     return CMF_OK;
 }
 
@@ -212,41 +408,93 @@ static int group_cb_stage(cmf_group_s *g, size_t elems)
     return CMF_OK;
 }
 
+static inline hipStream_t lane_stream(const cmf_group_s *g, size_t i, int lane) { return lane ? g->sh[i]->comm_stream : g->sh[i]->stream; }
+static inline ncclComm_t lane_comm(const cmf_group_s *g, size_t i, int lane) { return lane ? g->comm2[i] : g->comm[i]; }
+
+static int lane_event(hipEvent_t *e)
+{
+    if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return CMF_OK;
+}
+
 // loopback with a stream per shard: the collective kernel runs on shard 0's stream once every shard's stream has arrived
 // (c = 0: the main streams, 1: the communication streams of the overlap form) ...
 static int loopback_arrive(cmf_group_s *g, int c)
 {
     for (size_t i = 0; i < g->sh.size(); ++i) {
-        if (!g->ev_in[c][i]) HIPCHK(hipEventCreateWithFlags(&g->ev_in[c][i], hipEventDisableTiming));
-        HIPCHK(hipEventRecord(g->ev_in[c][i], c ? g->sh[i]->comm_stream : g->sh[i]->stream));
+        CMFTRY(lane_event(&g->ev_in[c][i]));
+        HIPCHK(hipEventRecord(g->ev_in[c][i], lane_stream(g, i, c)));
     }
-    hipStream_t s0 = c ? g->sh[0]->comm_stream : g->sh[0]->stream;
+    hipStream_t s0 = lane_stream(g, 0, c);
     for (size_t i = 1; i < g->sh.size(); ++i) HIPCHK(hipStreamWaitEvent(s0, g->ev_in[c][i], 0));
     return CMF_OK;
 }
 // ... and every other shard's stream goes on when it has finished
 static int loopback_depart(cmf_group_s *g, int c)
 {
-    hipStream_t s0 = c ? g->sh[0]->comm_stream : g->sh[0]->stream;
-    if (!g->ev_out[c]) HIPCHK(hipEventCreateWithFlags(&g->ev_out[c], hipEventDisableTiming));
+    hipStream_t s0 = lane_stream(g, 0, c);
+    CMFTRY(lane_event(&g->ev_out[c]));
     HIPCHK(hipEventRecord(g->ev_out[c], s0));
-    for (size_t i = 1; i < g->sh.size(); ++i) HIPCHK(hipStreamWaitEvent(c ? g->sh[i]->comm_stream : g->sh[i]->stream, g->ev_out[c], 0));
+    for (size_t i = 1; i < g->sh.size(); ++i) HIPCHK(hipStreamWaitEvent(lane_stream(g, i, c), g->ev_out[c], 0));
     return CMF_OK;
 }
 
-// In-place sum over all ranks of `count` floats at offset `off` of every local shard's buffer `bufs[i]`, ordered on
-// `streams[i]`.
-static int group_allreduce(cmf_group_s *g, const std::vector<float *> &bufs, size_t off, size_t count, bool on_comm_stream = false)
+// peer transport: every shard's stream of the lane waits until every other shard's stream has reached this point
+// (site 0: in front of the transport's kernel, 1: behind it).  The calling thread does it for all shards ...
+static int peer_fence_all(cmf_group_s *g, int lane, int site)
+{
+    const size_t nl = g->sh.size();
+    for (size_t i = 0; i < nl; ++i) {
+        CMFTRY(group_use(g->sh[i]));
+        CMFTRY(lane_event(&g->ev_peer[lane][site][i]));
+        HIPCHK(hipEventRecord(g->ev_peer[lane][site][i], lane_stream(g, i, lane)));
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        CMFTRY(group_use(g->sh[i]));
+        for (size_t j = 0; j < nl; ++j)
+            if (j != i) HIPCHK(hipStreamWaitEvent(lane_stream(g, i, lane), g->ev_peer[lane][site][j], 0));
+    }
+    return CMF_OK;
+}
+// ... or every enqueue worker for its own shard: record, meet (a wait must find the record made), wait for the others
+static int peer_fence_shard(cmf_group_s *g, size_t i, int lane, int site)
+{
+    CMFTRY(lane_event(&g->ev_peer[lane][site][i]));
+    HIPCHK(hipEventRecord(g->ev_peer[lane][site][i], lane_stream(g, i, lane)));
+    CMFTRY(group_barrier(g));
+    for (size_t j = 0; j < g->sh.size(); ++j)
+        if (j != i) HIPCHK(hipStreamWaitEvent(lane_stream(g, i, lane), g->ev_peer[lane][site][j], 0));
+    return CMF_OK;
+}
+
+static int peer_allreduce_launch(cmf_group_s *g, size_t i, const CmfPtrTable &tab, size_t count, int lane)
+{
+    const int R = (int)g->sh.size();
+    size_t per = (count + R - 1) / R;
+    per = (per + 3) / 4 * 4;
+    int vec4 = 1;
+    for (int r = 0; r < R; ++r)
+        if (reinterpret_cast<uintptr_t>(tab.p[r]) % 16) vec4 = 0;
+    const int blocks = (int)std::min<size_t>(1024, std::max<size_t>(1, (per / 4 + 255) / 256));
+    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(blocks), dim3(256), 0, lane_stream(g, i, lane), tab, R, (int)i, count, per, vec4);
+    KCHK("peer_allreduce_kernel");
+    return CMF_OK;
+}
+
+// ---- collectives, issued by the calling thread for all local shards -------------------------------------------------
+// In-place sum over all ranks of `count` floats at offset `off` of every local shard's buffer `bufs[i]`, ordered on the
+// shards' main streams (lane 0) or communication streams (lane 1).
+static int group_allreduce(cmf_group_s *g, const std::vector<float *> &bufs, size_t off, size_t count, int lane = 0)
 {
     const size_t nl = g->sh.size();
     if (g->nranks == 1 && g->transport != CMF_TR_RCCL) return CMF_OK;
-    auto stream_of = [&](size_t i) { return on_comm_stream ? g->sh[i]->comm_stream : g->sh[i]->stream; };
     switch (g->transport) {
     case CMF_TR_RCCL: {
+        if (lane && g->comm2.size() != nl) return fail(CMF_ERR_STATE, "the communication stream has no communicator of its own");
         if (nl > 1) RCCLCHK(g_rccl.GroupStart());
         for (size_t i = 0; i < nl; ++i) {
             CMFTRY(group_use(g->sh[i]));
-            RCCLCHK(g_rccl.AllReduce(bufs[i] + off, bufs[i] + off, count, ncclFloat32, ncclSum, g->comm[i], stream_of(i)));
+            RCCLCHK(g_rccl.AllReduce(bufs[i] + off, bufs[i] + off, count, ncclFloat32, ncclSum, lane_comm(g, i, lane), lane_stream(g, i, lane)));
         }
         if (nl > 1) RCCLCHK(g_rccl.GroupEnd());
         return CMF_OK;
@@ -255,31 +503,40 @@ static int group_allreduce(cmf_group_s *g, const std::vector<float *> &bufs, siz
         CmfPtrTable tab;
         for (size_t i = 0; i < nl; ++i) tab.p[i] = bufs[i] + off;
         CMFTRY(group_use(g->sh[0]));
-        const int c = on_comm_stream ? 1 : 0;
-        if (g->loop_ms) CMFTRY(loopback_arrive(g, c));
+        if (g->loop_ms) CMFTRY(loopback_arrive(g, lane));
         const int blocks = (int)std::min<size_t>(2048, (count + 255) / 256);
-        hipLaunchKernelGGL(loopback_allreduce_kernel, dim3(blocks), dim3(256), 0, stream_of(0), tab, (int)nl, count);
+        hipLaunchKernelGGL(loopback_allreduce_kernel, dim3(blocks), dim3(256), 0, lane_stream(g, 0, lane), tab, (int)nl, count);
         KCHK("loopback_allreduce_kernel");
-        if (g->loop_ms) CMFTRY(loopback_depart(g, c));
+        if (g->loop_ms) CMFTRY(loopback_depart(g, lane));
         return CMF_OK;
+    }
+    case CMF_TR_PEER: {
+        CmfPtrTable tab;
+        for (size_t i = 0; i < nl; ++i) tab.p[i] = bufs[i] + off;
+        CMFTRY(peer_fence_all(g, lane, 0));
+        for (size_t i = 0; i < nl; ++i) {
+            CMFTRY(group_use(g->sh[i]));
+            CMFTRY(peer_allreduce_launch(g, i, tab, count, lane));
+        }
+        return peer_fence_all(g, lane, 1);
     }
     default: { // host callbacks: one local shard
         cmf_handle_s *s = g->sh[0];
         CMFTRY(group_use(s));
         CMFTRY(group_cb_stage(g, count));
-        HIPCHK(hipMemcpyAsync(g->cb_host, bufs[0] + off, count * sizeof(float), hipMemcpyDeviceToHost, stream_of(0)));
-        HIPCHK(hipStreamSynchronize(stream_of(0)));
+        HIPCHK(hipMemcpyAsync(g->cb_host, bufs[0] + off, count * sizeof(float), hipMemcpyDeviceToHost, lane_stream(g, 0, lane)));
+        HIPCHK(hipStreamSynchronize(lane_stream(g, 0, lane)));
         const int rc = g->ar_cb(g->cb_user, g->cb_host, (int64_t)count);
         if (rc != 0) return fail(CMF_ERR_COMM, "all-reduce callback returned %d", rc);
-        HIPCHK(hipMemcpyAsync(bufs[0] + off, g->cb_host, count * sizeof(float), hipMemcpyHostToDevice, stream_of(0)));
-        HIPCHK(hipStreamSynchronize(stream_of(0)));
+        HIPCHK(hipMemcpyAsync(bufs[0] + off, g->cb_host, count * sizeof(float), hipMemcpyHostToDevice, lane_stream(g, 0, lane)));
+        HIPCHK(hipStreamSynchronize(lane_stream(g, 0, lane)));
         return CMF_OK;
     }
     }
 }
 
-// recv[i] (nranks * count floats) = every rank's send block (count floats), in rank order
-static int group_allgather(cmf_group_s *g, const std::vector<float *> &send, size_t send_off, const std::vector<float *> &recv, size_t count)
+// recv[i] (nranks * count floats) = every rank's send block (count floats at send[i]), in rank order
+static int group_allgather(cmf_group_s *g, const std::vector<float *> &send, const std::vector<float *> &recv, size_t count)
 {
     const size_t nl = g->sh.size();
     switch (g->transport) {
@@ -287,14 +544,14 @@ static int group_allgather(cmf_group_s *g, const std::vector<float *> &send, siz
         if (nl > 1) RCCLCHK(g_rccl.GroupStart());
         for (size_t i = 0; i < nl; ++i) {
             CMFTRY(group_use(g->sh[i]));
-            RCCLCHK(g_rccl.AllGather(send[i] + send_off, recv[i], count, ncclFloat32, g->comm[i], g->sh[i]->stream));
+            RCCLCHK(g_rccl.AllGather(send[i], recv[i], count, ncclFloat32, g->comm[i], g->sh[i]->stream));
         }
         if (nl > 1) RCCLCHK(g_rccl.GroupEnd());
         return CMF_OK;
     }
     case CMF_TR_LOOPBACK: {
         CmfPtrTable ts, tr;
-        for (size_t i = 0; i < nl; ++i) { ts.p[i] = send[i] + send_off; tr.p[i] = recv[i]; }
+        for (size_t i = 0; i < nl; ++i) { ts.p[i] = send[i]; tr.p[i] = recv[i]; }
         CMFTRY(group_use(g->sh[0]));
         if (g->loop_ms) CMFTRY(loopback_arrive(g, 0));
         const int blocks = (int)std::min<size_t>(64, (nl * count + 255) / 256);
@@ -303,12 +560,24 @@ static int group_allgather(cmf_group_s *g, const std::vector<float *> &send, siz
         if (g->loop_ms) CMFTRY(loopback_depart(g, 0));
         return CMF_OK;
     }
+    case CMF_TR_PEER: {
+        CmfPtrTable ts;
+        for (size_t i = 0; i < nl; ++i) ts.p[i] = send[i];
+        CMFTRY(peer_fence_all(g, 0, 0));
+        for (size_t i = 0; i < nl; ++i) {
+            CMFTRY(group_use(g->sh[i]));
+            const int blocks = (int)std::min<size_t>(64, (nl * count + 255) / 256);
+            hipLaunchKernelGGL(peer_allgather_kernel, dim3(blocks), dim3(256), 0, g->sh[i]->stream, ts, recv[i], (int)nl, (int)count);
+            KCHK("peer_allgather_kernel");
+        }
+        return peer_fence_all(g, 0, 1);
+    }
     default: {
         cmf_handle_s *s = g->sh[0];
         CMFTRY(group_use(s));
         CMFTRY(group_cb_stage(g, (size_t)(g->nranks + 1) * count));
         float *hs = g->cb_host, *hr = g->cb_host + count;
-        HIPCHK(hipMemcpyAsync(hs, send[0] + send_off, count * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(hs, send[0], count * sizeof(float), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         const int rc = g->ag_cb(g->cb_user, hs, hr, (int64_t)count);
         if (rc != 0) return fail(CMF_ERR_COMM, "all-gather callback returned %d", rc);
@@ -317,6 +586,163 @@ static int group_allgather(cmf_group_s *g, const std::vector<float *> &send, siz
         return CMF_OK;
     }
     }
+}
+
+// ---- the same collectives, issued by shard i's enqueue worker for its own shard ---------------------------------------
+// (only the transports that have workers: RCCL -- one thread per device, no group call --, peer, loopback-streams)
+static int shard_allreduce(cmf_group_s *g, size_t i, const std::vector<float *> &bufs, size_t off, size_t count, int lane)
+{
+    const size_t nl = g->sh.size();
+    if (const char *hooks = getenv("CMF_TEST_HOOKS")) // tests: make one shard's collective call fail (honoured only with CMF_TEST_HOOKS=1)
+        if (atoi(hooks) == 1)
+            if (const char *e = getenv("CMF_TEST_FAIL_SHARD"))
+                if ((size_t)atoi(e) == i) return fail(CMF_ERR_STATE, "CMF_TEST_FAIL_SHARD: the all-reduce call of shard %zu was made to fail", i);
+    switch (g->transport) {
+    case CMF_TR_RCCL:
+        if (lane && g->comm2.size() != nl) return fail(CMF_ERR_STATE, "the communication stream has no communicator of its own");
+        RCCLCHK(g_rccl.AllReduce(bufs[i] + off, bufs[i] + off, count, ncclFloat32, ncclSum, lane_comm(g, i, lane), lane_stream(g, i, lane)));
+        return CMF_OK;
+    case CMF_TR_PEER: {
+        CmfPtrTable tab;
+        for (size_t j = 0; j < nl; ++j) tab.p[j] = bufs[j] + off;
+        CMFTRY(peer_fence_shard(g, i, lane, 0));
+        CMFTRY(peer_allreduce_launch(g, i, tab, count, lane));
+        return peer_fence_shard(g, i, lane, 1);
+    }
+    case CMF_TR_LOOPBACK: { // loop_ms: shard 0's worker runs the kernel between two meetings of the workers
+        CMFTRY(lane_event(&g->ev_in[lane][i]));
+        HIPCHK(hipEventRecord(g->ev_in[lane][i], lane_stream(g, i, lane)));
+        CMFTRY(group_barrier(g));
+        if (i == 0) {
+            CmfPtrTable tab;
+            for (size_t j = 0; j < nl; ++j) tab.p[j] = bufs[j] + off;
+            for (size_t j = 1; j < nl; ++j) HIPCHK(hipStreamWaitEvent(lane_stream(g, 0, lane), g->ev_in[lane][j], 0));
+            const int blocks = (int)std::min<size_t>(2048, (count + 255) / 256);
+            hipLaunchKernelGGL(loopback_allreduce_kernel, dim3(blocks), dim3(256), 0, lane_stream(g, 0, lane), tab, (int)nl, count);
+            KCHK("loopback_allreduce_kernel");
+            CMFTRY(lane_event(&g->ev_out[lane]));
+            HIPCHK(hipEventRecord(g->ev_out[lane], lane_stream(g, 0, lane)));
+        }
+        CMFTRY(group_barrier(g));
+        if (i > 0) HIPCHK(hipStreamWaitEvent(lane_stream(g, i, lane), g->ev_out[lane], 0));
+        return CMF_OK;
+    }
+    default:
+        return fail(CMF_ERR_STATE, "this transport has no enqueue workers");
+    }
+}
+
+static int shard_allgather(cmf_group_s *g, size_t i, const std::vector<float *> &send, const std::vector<float *> &recv, size_t count)
+{
+    const size_t nl = g->sh.size();
+    switch (g->transport) {
+    case CMF_TR_RCCL:
+        RCCLCHK(g_rccl.AllGather(send[i], recv[i], count, ncclFloat32, g->comm[i], g->sh[i]->stream));
+        return CMF_OK;
+    case CMF_TR_PEER: {
+        CmfPtrTable ts;
+        for (size_t j = 0; j < nl; ++j) ts.p[j] = send[j];
+        CMFTRY(peer_fence_shard(g, i, 0, 0));
+        const int blocks = (int)std::min<size_t>(64, (nl * count + 255) / 256);
+        hipLaunchKernelGGL(peer_allgather_kernel, dim3(blocks), dim3(256), 0, g->sh[i]->stream, ts, recv[i], (int)nl, (int)count);
+        KCHK("peer_allgather_kernel");
+        return peer_fence_shard(g, i, 0, 1);
+    }
+    case CMF_TR_LOOPBACK: {
+        CMFTRY(lane_event(&g->ev_in[0][i]));
+        HIPCHK(hipEventRecord(g->ev_in[0][i], g->sh[i]->stream));
+        CMFTRY(group_barrier(g));
+        if (i == 0) {
+            CmfPtrTable ts, tr;
+            for (size_t j = 0; j < nl; ++j) { ts.p[j] = send[j]; tr.p[j] = recv[j]; }
+            for (size_t j = 1; j < nl; ++j) HIPCHK(hipStreamWaitEvent(g->sh[0]->stream, g->ev_in[0][j], 0));
+            const int blocks = (int)std::min<size_t>(64, (nl * count + 255) / 256);
+            hipLaunchKernelGGL(loopback_allgather_kernel, dim3(blocks), dim3(256), 0, g->sh[0]->stream, ts, tr, (int)nl, (int)count);
+            KCHK("loopback_allgather_kernel");
+            CMFTRY(lane_event(&g->ev_out[0]));
+            HIPCHK(hipEventRecord(g->ev_out[0], g->sh[0]->stream));
+        }
+        CMFTRY(group_barrier(g));
+        if (i > 0) HIPCHK(hipStreamWaitEvent(g->sh[i]->stream, g->ev_out[0], 0));
+        return CMF_OK;
+    }
+    default:
+        return fail(CMF_ERR_STATE, "this transport has no enqueue workers");
+    }
+}
+
+// ---- phases as step lists ---------------------------------------------------------------------------------------------
+// A phase of the sharded iteration is a list of steps: per-shard segments (kernel launches of ONE shard on its own
+// streams) and collectives.  Without workers the calling thread walks the list -- a segment for every shard in shard
+// order, a collective as one (grouped) call; with workers every shard's worker walks the whole list for its shard.
+// Everything a step needs is held by value: the list outlives the call that posted it.
+struct GroupStep {
+    const char *name = "";            // roctx range of the step (a string literal)
+    std::function<int(size_t)> seg;   // per-shard work, or empty
+    int coll = 0;                     // 0 none, 1 all-reduce (in place in a[i] + off), 2 all-gather (a[i] -> b[i])
+    std::vector<float *> a, b;
+    size_t off = 0, count = 0;
+    int lane = 0;
+};
+using StepList = std::vector<GroupStep>;
+
+static void step_seg(StepList &st, const char *name, std::function<int(size_t)> fn)
+{
+    GroupStep s;
+    s.name = name;
+    s.seg = std::move(fn);
+    st.push_back(std::move(s));
+}
+static void step_allreduce(cmf_group_s *g, StepList &st, const char *name, const std::vector<float *> &bufs, size_t off, size_t count, int lane = 0)
+{
+    if (g->nranks == 1 && g->transport != CMF_TR_RCCL) return;
+    GroupStep s;
+    s.name = name;
+    s.coll = 1; s.a = bufs; s.off = off; s.count = count; s.lane = lane;
+    st.push_back(std::move(s));
+}
+static void step_allgather(StepList &st, const char *name, const std::vector<float *> &send, const std::vector<float *> &recv, size_t count)
+{
+    GroupStep s;
+    s.name = name;
+    s.coll = 2; s.a = send; s.b = recv; s.count = count;
+    st.push_back(std::move(s));
+}
+
+static int group_run_shard(cmf_group_s *g, const StepList &st, size_t i)
+{
+    for (const GroupStep &s : st) {
+        RoctxRange range(s.name);
+        CMFTRY(group_use(g->sh[i]));
+        if (s.seg) CMFTRY(s.seg(i));
+        if (s.coll == 1) CMFTRY(shard_allreduce(g, i, s.a, s.off, s.count, s.lane));
+        else if (s.coll == 2) CMFTRY(shard_allgather(g, i, s.a, s.b, s.count));
+    }
+    return CMF_OK;
+}
+
+// Runs the list: returns when it has been ENQUEUED (no workers) or merely posted (workers: failures then surface at the
+// next group_join, and through group_health while the host polls for a loss).
+static int group_run(cmf_group_s *g, StepList &&st)
+{
+    if (st.empty()) return CMF_OK;
+    if (g->workers.empty() || g->force_inline > 0) {
+        for (const GroupStep &s : st) {
+            RoctxRange range(s.name);
+            if (s.seg)
+                for (size_t i = 0; i < g->sh.size(); ++i) {
+                    CMFTRY(group_use(g->sh[i]));
+                    CMFTRY(s.seg(i));
+                }
+            if (s.coll == 1) CMFTRY(group_allreduce(g, s.a, s.off, s.count, s.lane));
+            else if (s.coll == 2) CMFTRY(group_allgather(g, s.a, s.b, s.count));
+        }
+        return CMF_OK;
+    }
+    auto shared = std::make_shared<StepList>(std::move(st));
+    for (size_t i = 0; i < g->workers.size(); ++i)
+        worker_post(g->workers[i].get(), [g, shared, i]() { return group_run_shard(g, *shared, i); });
+    return CMF_OK;
 }
 
 // sum over ranks (in rank order) of the doubles posted as (hi, lo) float pairs
@@ -338,6 +764,7 @@ static int group_gather_doubles(cmf_group_s *g, const std::vector<double> &vals,
             for (int j = 0; j < n; ++j) out[(size_t)g->rank[i] * n + j] = vals[i * n + j];
         return CMF_OK;
     }
+    CMFTRY(group_join(g));
     const size_t words = (size_t)2 * n; // floats per rank
     if (g->gbuf.size() != nl || g->gbuf_words < words) { // [gathered (nranks * words) | send (words)] per local shard
         for (size_t i = 0; i < g->gbuf.size(); ++i)
@@ -359,7 +786,7 @@ static int group_gather_doubles(cmf_group_s *g, const std::vector<double> &vals,
         HIPCHK(hipMemcpyAsync(send[i], vals.data() + i * n, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
     }
-    CMFTRY(group_allgather(g, send, 0, recv, words));
+    CMFTRY(group_allgather(g, send, recv, words));
     cmf_handle_s *s = g->sh[0];
     CMFTRY(group_use(s));
     HIPCHK(hipMemcpyAsync(out.data(), recv[0], (size_t)g->nranks * n * 8, hipMemcpyDeviceToHost, s->stream));
@@ -369,6 +796,7 @@ static int group_gather_doubles(cmf_group_s *g, const std::vector<double> &vals,
 
 static int group_check_ready(cmf_group_s *g)
 {
+    if (g->failed) return fail(CMF_ERR_COMM, "this group has failed (a collective did not complete, or a communicator reported an error): destroy the handle");
     for (cmf_handle_s *s : g->sh) {
         if (!s->factors_set) return fail(CMF_ERR_STATE, "factors not set: call cmf_set_factors first");
         if (!s->have_data) return fail(CMF_ERR_STATE, "handle was created without data");
@@ -378,6 +806,7 @@ static int group_check_ready(cmf_group_s *g)
 
 static int group_sync(cmf_group_s *g)
 {
+    CMFTRY(group_join(g));
     for (cmf_handle_s *s : g->sh) {
         CMFTRY(group_use(s));
         HIPCHK(hipStreamSynchronize(s->stream));
@@ -386,82 +815,103 @@ static int group_sync(cmf_group_s *g)
     return CMF_OK;
 }
 
-// Called while the host polls for a loss that only shard 0 posts: a fault on another local shard's stream, or an
-// asynchronous RCCL error on any local communicator, must end the wait (CMF_ERR_HIP / CMF_ERR_COMM) instead of hanging it.
+// Called while the host polls for a loss that only shard 0 posts: a failed enqueue job, a fault on another local shard's
+// stream, or an asynchronous RCCL error on any local communicator, must end the wait (CMF_ERR_HIP / CMF_ERR_COMM) instead
+// of hanging it.
 static int group_health(cmf_group_s *g)
 {
+    if (g->abort.load(std::memory_order_acquire)) {
+        const int rc = group_join(g);
+        return rc != CMF_OK ? rc : fail(CMF_ERR_STATE, "an enqueue worker of the group gave up");
+    }
+    const bool posted = group_enqueued(g); // (a worker that has not enqueued yet leaves its stream idle: that is not a fault)
     for (size_t i = 0; i < g->sh.size(); ++i) {
         cmf_handle_s *s = g->sh[i];
-        if (i > 0 && s->stream != g->sh[0]->stream) {
+        if (posted && i > 0 && s->stream != g->sh[0]->stream) {
             CMFTRY(group_use(s));
             const hipError_t e = hipStreamQuery(s->stream);
             if (e != hipSuccess && e != hipErrorNotReady)
                 return fail(CMF_ERR_HIP, "shard %d (device %d) failed: %s", g->rank[i], s->device, hipGetErrorString(e));
         }
-        if (g->transport == CMF_TR_RCCL && g_rccl.CommGetAsyncError && i < g->comm.size() && g->comm[i]) {
-            ncclResult_t ae = ncclSuccess;
-            if (g_rccl.CommGetAsyncError(g->comm[i], &ae) == ncclSuccess && ae != ncclSuccess && (int)ae != 7 /* ncclInProgress */)
-                return fail(CMF_ERR_COMM, "RCCL reported an asynchronous error on rank %d: %s", g->rank[i], g_rccl.GetErrorString(ae));
-        }
+        if (g->transport == CMF_TR_RCCL && g_rccl.CommGetAsyncError)
+            for (const std::vector<ncclComm_t> *cs : {&g->comm, &g->comm2})
+                if (i < cs->size() && (*cs)[i]) {
+                    ncclResult_t ae = ncclSuccess;
+                    if (g_rccl.CommGetAsyncError((*cs)[i], &ae) == ncclSuccess && ae != ncclSuccess && (int)ae != 7 /* ncclInProgress */) {
+                        g->failed = true;
+                        return fail(CMF_ERR_COMM, "RCCL reported an asynchronous error on rank %d: %s", g->rank[i], g_rccl.GetErrorString(ae));
+                    }
+                }
     }
     return group_use(g->sh[0]);
 }
 
 // (L-1)-column H halo exchange: pack -> one all-gather -> unpack
-static int group_exchange_halos(cmf_group_s *g)
+static void build_exchange_halos(cmf_group_s *g, StepList &st)
 {
     cmf_handle_s *s0 = g->sh[0];
     const int rows = s0->d.L - 1;
     g->halos_current = true;
-    if (rows < 1 || g->nranks == 1) return CMF_OK;
-    for (size_t i = 0; i < g->sh.size(); ++i) {
+    if (rows < 1 || g->nranks == 1) return;
+    step_seg(st, "cmf:halo pack", [g, rows](size_t i) {
         cmf_handle_s *s = g->sh[i];
         const CmfDims &d = s->d;
-        CMFTRY(group_use(s));
         hipLaunchKernelGGL(halo_pack2_kernel, dim3(8), dim3(256), 0, s->stream, s->H, g->halo_send[i], d.PADL, d.PADL + d.Tl - rows, rows, d.K32);
         KCHK("halo_pack2_kernel");
-    }
-    CMFTRY(group_allgather(g, g->halo_send, 0, g->halo_all, (size_t)(2 * g->HC)));
-    for (size_t i = 0; i < g->sh.size(); ++i) {
+        return CMF_OK;
+    });
+    step_allgather(st, "cmf:all-gather of the H halos", g->halo_send, g->halo_all, (size_t)(2 * g->HC));
+    step_seg(st, "cmf:halo unpack", [g, rows](size_t i) {
         cmf_handle_s *s = g->sh[i];
         const CmfDims &d = s->d;
-        CMFTRY(group_use(s));
         hipLaunchKernelGGL(halo_unpack2_kernel, dim3(8), dim3(256), 0, s->stream, s->H, s->Ht, s->halo[2], s->halo[3],
                            d.PADL - rows, d.PADL + d.Tl, rows, d.K32, d.TP);
         KCHK("halo_unpack2_kernel");
-    }
-    return CMF_OK;
+        return CMF_OK;
+    });
+}
+static int group_exchange_halos(cmf_group_s *g)
+{
+    StepList st;
+    build_exchange_halos(g, st);
+    return group_run(g, std::move(st));
 }
 
 // sum((conv(W,H) - data)^2) of every local shard -> its tail slots of the all-reduce buffer (and d_scalar[0]).
 // defer: the per-tile sums are reduced by the next update_motifs!' slab sum instead (CmfLossCarry), right in front of the
 // all-reduce their total rides on.
-static int group_loss_partials(cmf_group_s *g, bool defer = false)
+static void build_loss_partials(cmf_group_s *g, StepList &st, bool defer = false)
 {
-    for (size_t i = 0; i < g->sh.size(); ++i) {
+    const size_t toff = group_tail_off(g);
+    step_seg(st, "cmf:loss conv (mult.jl:55-57)", [g, defer, toff](size_t i) {
         cmf_handle_s *s = g->sh[i];
-        CMFTRY(group_use(s));
         CMFTRY(launch_loss_conv(s)); // mult.jl:55-57
         if (defer) {
-            s->carry = CmfLossCarry{s->partial, s->conv_partials, s->d_scalar, nullptr, g->red[i] + group_tail_off(g), (int)g->tail, g->rank[i]};
-            continue;
+            s->carry = CmfLossCarry{s->partial, s->conv_partials, s->d_scalar, nullptr, g->red[i] + toff, (int)g->tail, g->rank[i]};
+            return CMF_OK;
         }
         hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(256), 0, s->stream, s->partial, s->conv_partials, s->d_scalar,
-                           g->red[i] + group_tail_off(g), (int)g->tail, g->rank[i]);
+                           g->red[i] + toff, (int)g->tail, g->rank[i]);
         KCHK("loss_tail_kernel");
-    }
-    return CMF_OK;
+        return CMF_OK;
+    });
 }
 
 // the tail of the all-reduce buffer right now (synchronous path): all-gather of the (hi, lo) pairs, read back
-static int group_loss_now(cmf_group_s *g, double *sumsq)
+static int group_loss_now(cmf_group_s *g, StepList &&st, double *sumsq)
 {
     const size_t nl = g->sh.size();
     cmf_handle_s *s = g->sh[0];
-    if (g->nranks == 1 && g->transport != CMF_TR_RCCL) return read_scalar(s, 0, sumsq);
+    if (g->nranks == 1 && g->transport != CMF_TR_RCCL) {
+        CMFTRY(group_run(g, std::move(st)));
+        CMFTRY(group_join(g));
+        return read_scalar(s, 0, sumsq);
+    }
     std::vector<float *> send(nl);
     for (size_t i = 0; i < nl; ++i) send[i] = g->red[i] + group_tail_off(g) + 2 * g->rank[i];
-    CMFTRY(group_allgather(g, send, 0, g->loss_all, 2));
+    step_allgather(st, "cmf:all-gather of the loss pairs", send, g->loss_all, 2);
+    CMFTRY(group_run(g, std::move(st)));
+    CMFTRY(group_join(g));
     CMFTRY(group_use(s));
     float *stage = g->h_tail + 2 * g->slot_len; // not a ring slot: a pending one-iteration-late loss may still sit there
     HIPCHK(hipMemcpyAsync(stage, g->loss_all[0], (size_t)(2 * g->nranks) * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -470,97 +920,112 @@ static int group_loss_now(cmf_group_s *g, double *sumsq)
     return CMF_OK;
 }
 
-// overlap form: numW needs H only -- contract it and start its all-reduce on the communication stream.  In the Gram form
-// the whole payload [numW | HH] needs H only, so ALL of the bulk all-reduce runs underneath the loss conv.
-static int group_start_num(cmf_group_s *g)
+// overlap form: numW needs H only -- contract it and start its all-reduce on the communication stream (lane 1: its own
+// stream AND its own communicator, so that it never shares one with the main stream's collectives that are issued while
+// it is in flight).  In the Gram form the whole payload [numW | HH] needs H only, so ALL of the bulk all-reduce runs
+// underneath the loss conv.
+static void build_start_num(cmf_group_s *g, StepList &st)
 {
     const size_t half = (size_t)g->LKN2 / 2;
-    for (cmf_handle_s *s : g->sh) {
-        CMFTRY(group_use(s));
-        if (g->gram) CMFTRY(gram_w_partial(s, s->numden + half));
+    const int gram = g->gram;
+    step_seg(st, "cmf:numW contraction (overlap form)", [g, half, gram](size_t i) {
+        cmf_handle_s *s = g->sh[i];
+        if (gram) CMFTRY(gram_w_partial(s, s->numden + half));
         else CMFTRY(w_partial_half_impl(s, 0));
         HIPCHK(hipEventRecord(s->ev_c0, s->stream));
         HIPCHK(hipStreamWaitEvent(s->comm_stream, s->ev_c0, 0));
-    }
-    CMFTRY(group_allreduce(g, g->red, 0, g->gram ? half + (size_t)g->HHsz : half, true));
-    for (cmf_handle_s *s : g->sh) {
-        CMFTRY(group_use(s));
+        return CMF_OK;
+    });
+    step_allreduce(g, st, "cmf:all-reduce of numW on the communication stream", g->red, 0, gram ? half + (size_t)g->HHsz : half, 1);
+    step_seg(st, "cmf:overlap join event", [g](size_t i) {
+        cmf_handle_s *s = g->sh[i];
         HIPCHK(hipEventRecord(s->ev_c1, s->comm_stream));
-    }
+        return CMF_OK;
+    });
     g->num_ready = true;
-    return CMF_OK;
 }
 
 // update_motifs! on the group (mult.jl:23-39).  ring_slot >= 0: after the all-reduce the tail (the previous
 // iteration's loss pairs of every rank) is copied to pinned host slot `ring_slot`, which the host polls.
-static int group_update_motifs(cmf_group_s *g, double l1W, double l2W, int ring_slot = -1)
+static void build_update_motifs(cmf_group_s *g, StepList &st, double l1W, double l2W, int ring_slot = -1)
 {
-    if (!g->halos_current) CMFTRY(group_exchange_halos(g));
+    if (!g->halos_current) build_exchange_halos(g, st);
     const size_t half = (size_t)g->LKN2 / 2;
     const size_t toff = group_tail_off(g);
+    const int gram = g->gram;
     if (g->overlap) {
-        if (!g->num_ready) CMFTRY(group_start_num(g));
-        if (g->gram) { // the bulk is in flight on the communication stream: only the loss tail is left for this stream
-            CMFTRY(group_allreduce(g, g->red, toff, (size_t)g->tail));
+        if (!g->num_ready) build_start_num(g, st);
+        if (gram) { // the bulk is in flight on the communication stream: only the loss tail is left for this stream
+            step_allreduce(g, st, "cmf:all-reduce of the loss tail", g->red, toff, (size_t)g->tail);
         } else {
-            for (cmf_handle_s *s : g->sh) {
-                CMFTRY(group_use(s));
-                CMFTRY(w_partial_half_impl(s, 1));
-            }
-            CMFTRY(group_allreduce(g, g->red, half, half + (size_t)g->tail));
+            step_seg(st, "cmf:denomW contraction", [g](size_t i) { return w_partial_half_impl(g->sh[i], 1); });
+            step_allreduce(g, st, "cmf:all-reduce of [denomW | tail]", g->red, half, half + (size_t)g->tail);
         }
-        for (cmf_handle_s *s : g->sh) {
-            CMFTRY(group_use(s));
+        step_seg(st, "cmf:wait for the communication stream", [g](size_t i) {
+            cmf_handle_s *s = g->sh[i];
             HIPCHK(hipStreamWaitEvent(s->stream, s->ev_c1, 0));
-        }
+            return CMF_OK;
+        });
         g->num_ready = false;
     } else {
-        for (cmf_handle_s *s : g->sh) {
-            CMFTRY(group_use(s));
-            if (g->gram) CMFTRY(gram_w_partial(s, s->numden + half)); // [numW | this shard's share of HH | tail]
-            else CMFTRY(w_partial_impl(s));
-        }
-        CMFTRY(group_allreduce(g, g->red, 0, toff + (size_t)g->tail));
+        step_seg(st, "cmf:W phase contractions (mult.jl:28-34)", [g, half, gram](size_t i) {
+            cmf_handle_s *s = g->sh[i];
+            if (gram) return gram_w_partial(s, s->numden + half); // [numW | this shard's share of HH | tail]
+            return w_partial_impl(s);
+        });
+        step_allreduce(g, st, "cmf:all-reduce of [numW | denomW | tail]", g->red, 0, toff + (size_t)g->tail);
     }
-    for (size_t i = 0; i < g->sh.size(); ++i) {
+    float *ring = nullptr;
+    if (ring_slot >= 0) { // shard 0's W update also drops the reduced loss pairs + a stamp into the pinned ring slot
+        ring = g->h_tail + (size_t)ring_slot * g->slot_len;
+        for (int j = 0; j < 2 * g->nranks; ++j) reinterpret_cast<volatile unsigned *>(ring)[j] = CMF_SENTINEL32; // collected an iteration ago
+    }
+    const int npairs = 2 * g->nranks;
+    step_seg(st, "cmf:W update (mult.jl:37-38)", [g, half, toff, gram, l1W, l2W, ring, npairs](size_t i) {
         cmf_handle_s *s = g->sh[i];
-        CMFTRY(group_use(s));
-        if (i == 0 && ring_slot >= 0) { // shard 0's W update also drops the reduced loss pairs + a stamp into the pinned ring slot
-            float *ring = g->h_tail + (size_t)ring_slot * g->slot_len;
-            for (int j = 0; j < 2 * g->nranks; ++j) reinterpret_cast<volatile unsigned *>(ring)[j] = CMF_SENTINEL32; // collected an iteration ago
-            if (g->gram) CMFTRY(gram_w_finish(s, s->numden + half, l1W, l2W, g->red[0] + toff, ring, 2 * g->nranks));
-            else CMFTRY(w_apply_impl(s, l1W, l2W, g->red[0] + toff, ring, 2 * g->nranks));
-        } else {
-            if (g->gram) CMFTRY(gram_w_finish(s, s->numden + half, l1W, l2W));
-            else CMFTRY(w_apply_impl(s, l1W, l2W));
+        if (i == 0 && ring) {
+            if (gram) return gram_w_finish(s, s->numden + half, l1W, l2W, g->red[0] + toff, ring, npairs);
+            return w_apply_impl(s, l1W, l2W, g->red[0] + toff, ring, npairs);
         }
-    }
-    return CMF_OK;
+        if (gram) return gram_w_finish(s, s->numden + half, l1W, l2W);
+        return w_apply_impl(s, l1W, l2W);
+    });
+}
+static int group_update_motifs(cmf_group_s *g, double l1W, double l2W)
+{
+    StepList st;
+    build_update_motifs(g, st, l1W, l2W);
+    return group_run(g, std::move(st));
 }
 
-// update_feature_maps! on the group (mult.jl:42-58).  sumsq != NULL: also reduce the loss now (synchronises);
-// NULL: the loss partials stay in the tail of the all-reduce buffer and ride on the next update_motifs!.
+// update_feature_maps! on the group (mult.jl:42-58), without the loss read-back: with `defer` the loss partials stay in the
+// tail of the all-reduce buffer and ride on the next update_motifs!.
+static void build_update_feature_maps(cmf_group_s *g, StepList &st, double l1H, double l2H, bool defer)
+{
+    if (!g->halos_current) build_exchange_halos(g, st);
+    const int gram = g->gram;
+    step_seg(st, "cmf:H phase (mult.jl:44-52)", [g, gram, l1H, l2H](size_t i) { return gram ? gram_h_update(g->sh[i], l1H, l2H) : h_update_impl(g->sh[i], l1H, l2H); });
+    g->num_ready = false;
+    build_exchange_halos(g, st);
+    if (g->overlap) build_start_num(g, st); // for the next update_motifs!: H and its halos are final now
+    // (Gram + overlap: the next W phase has no slab sum left on this stream for a deferred reduction to ride on)
+    build_loss_partials(g, st, defer && !(g->gram && g->overlap));
+}
+// sumsq != NULL: also reduce the loss now (synchronises)
 static int group_update_feature_maps(cmf_group_s *g, double l1H, double l2H, double *sumsq)
 {
-    if (!g->halos_current) CMFTRY(group_exchange_halos(g));
-    for (cmf_handle_s *s : g->sh) {
-        CMFTRY(group_use(s));
-        CMFTRY(g->gram ? gram_h_update(s, l1H, l2H) : h_update_impl(s, l1H, l2H));
-    }
-    g->num_ready = false;
-    CMFTRY(group_exchange_halos(g));
-    if (g->overlap) CMFTRY(group_start_num(g)); // for the next update_motifs!: H and its halos are final now
-    // (Gram + overlap: the next W phase has no slab sum left on this stream for a deferred reduction to ride on)
-    CMFTRY(group_loss_partials(g, /*defer=*/sumsq == nullptr && !(g->gram && g->overlap)));
-    return sumsq ? group_loss_now(g, sumsq) : CMF_OK;
+    StepList st;
+    build_update_feature_maps(g, st, l1H, l2H, sumsq == nullptr);
+    return sumsq ? group_loss_now(g, std::move(st), sumsq) : group_run(g, std::move(st));
 }
 
 static int group_compute_loss(cmf_group_s *g, double *loss)
 {
-    if (!g->halos_current) CMFTRY(group_exchange_halos(g));
-    CMFTRY(group_loss_partials(g));
+    StepList st;
+    if (!g->halos_current) build_exchange_halos(g, st);
+    build_loss_partials(g, st);
     double ss = 0.0;
-    CMFTRY(group_loss_now(g, &ss));
+    CMFTRY(group_loss_now(g, std::move(st), &ss));
     *loss = std::sqrt(ss) / g->data_norm;
     return CMF_OK;
 }
@@ -585,16 +1050,29 @@ static int group_iterate(cmf_group_s *g, int64_t n, int eval_mode, double l1W, d
     }
     cmf_handle_s *s0 = g->sh[0];
     const std::function<int()> health = [g]() { return group_health(g); };
+    const std::function<bool()> enqueued = [g]() { return group_enqueued(g); };
     for (int64_t it = 0; it < n; ++it) {
-        CMFTRY(group_update_motifs(g, l1W, l2W, it > 0 ? (int)((it - 1) & 1) : -1));
         const bool last = (it + 1 == n);
+        const auto t_enq = std::chrono::steady_clock::now();
+        StepList st;
+        build_update_motifs(g, st, l1W, l2W, it > 0 ? (int)((it - 1) & 1) : -1);
+        build_update_feature_maps(g, st, l1H, l2H, !last);
         double ss = 0.0;
-        CMFTRY(group_update_feature_maps(g, l1H, l2H, last ? &ss : nullptr));
+        if (last) CMFTRY(group_loss_now(g, std::move(st), &ss));
+        else {
+            CMFTRY(group_run(g, std::move(st)));
+            g->enqueue_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_enq).count();
+            g->enqueue_iters += 1;
+        }
         if (it > 0) {
             const int slot = (int)((it - 1) & 1);
             CMFTRY(group_use(s0));
             const float *ring = g->h_tail + (size_t)slot * g->slot_len;
-            CMFTRY(wait_words<unsigned>(s0->stream, reinterpret_cast<const volatile unsigned *>(ring), 2 * g->nranks, CMF_SENTINEL32, &health));
+            const int rc = wait_words<unsigned>(s0->stream, reinterpret_cast<const volatile unsigned *>(ring), 2 * g->nranks, CMF_SENTINEL32, &health, &enqueued);
+            if (rc != CMF_OK) {
+                if (rc == CMF_ERR_COMM) g->failed = true;
+                return rc;
+            }
             losses[it - 1] = std::sqrt(group_decode_tail(g, ring)) / g->data_norm;
             if (stamps) stamps[it - 1] = now();
         }
@@ -603,11 +1081,12 @@ static int group_iterate(cmf_group_s *g, int64_t n, int eval_mode, double l1W, d
             if (stamps) stamps[it] = now();
         }
     }
-    return CMF_OK;
+    return group_join(g);
 }
 
 static int group_set_factors(cmf_group_s *g, const double *W, const double *H)
 {
+    CMFTRY(group_join(g));
     for (size_t i = 0; i < g->sh.size(); ++i) {
         cmf_handle_s *s = g->sh[i];
         // one process: H is the global K x T matrix (column-major: a shard's columns are contiguous)
@@ -616,7 +1095,8 @@ static int group_set_factors(cmf_group_s *g, const double *W, const double *H)
     }
     g->num_ready = false;
     g->halos_current = false;
-    return group_exchange_halos(g);
+    CMFTRY(group_exchange_halos(g));
+    return group_join(g);
 }
 
 static int group_get_factors(cmf_group_s *g, double *W, double *H)
@@ -630,35 +1110,59 @@ static int group_get_factors(cmf_group_s *g, double *W, double *H)
     return CMF_OK;
 }
 
+// a stream of a failed group may never drain (a collective kernel waiting for a peer that is gone): wait a little, then move on
+static void bounded_stream_sync(hipStream_t st, bool failed)
+{
+    if (!failed) {
+        (void)hipStreamSynchronize(st);
+        return;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipStreamQuery(st) == hipErrorNotReady && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.0)
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+}
+
 static void group_destroy(cmf_group_s *g)
 {
     if (!g) return;
+    (void)group_join(g); // (bounded; marks the group failed when a worker is stuck in a collective call)
+    group_stop_workers(g);
+    if (g->failed && g->transport == CMF_TR_RCCL && g_rccl.dl && g_rccl.CommAbort) { // unblocks collective kernels that wait for a peer
+        for (std::vector<ncclComm_t> *cs : {&g->comm, &g->comm2})
+            for (ncclComm_t &c : *cs)
+                if (c) { (void)g_rccl.CommAbort(c); c = nullptr; }
+    }
     for (cmf_handle_s *s : g->sh) {
         (void)hipSetDevice(s->device);
-        (void)hipStreamSynchronize(s->stream);
-        if (s->comm_stream) (void)hipStreamSynchronize(s->comm_stream);
+        bounded_stream_sync(s->stream, g->failed);
+        if (s->comm_stream) bounded_stream_sync(s->comm_stream, g->failed);
     }
-    if (g->transport == CMF_TR_RCCL && g_rccl.dl)
-        for (ncclComm_t c : g->comm)
-            if (c) (void)g_rccl.CommDestroy(c);
+    if (g->transport == CMF_TR_RCCL && g_rccl.dl && !g->failed)
+        for (std::vector<ncclComm_t> *cs : {&g->comm2, &g->comm})
+            for (ncclComm_t c : *cs)
+                if (c) (void)g_rccl.CommDestroy(c);
     for (size_t i = 0; i < g->sh.size(); ++i) {
         cmf_handle_s *s = g->sh[i];
         (void)hipSetDevice(s->device);
         s->numden = s->numden_own;
         for (int w = 0; w < 4; ++w) s->halo[w] = s->halo_own[w];
+        if (g->failed) continue; // the device may still be reading these: leaked on purpose
         if (i < g->red.size() && g->red[i]) (void)hipFree(g->red[i]);
         if (i < g->halo_send.size() && g->halo_send[i]) (void)hipFree(g->halo_send[i]);
         if (i < g->halo_all.size() && g->halo_all[i]) (void)hipFree(g->halo_all[i]);
         if (i < g->loss_all.size() && g->loss_all[i]) (void)hipFree(g->loss_all[i]);
     }
-    if (g->h_tail) (void)hipHostFree(g->h_tail);
+    if (g->h_tail && !g->failed) (void)hipHostFree(g->h_tail);
     if (g->cb_host) (void)hipHostFree(g->cb_host);
     for (size_t i = 0; i < g->gbuf.size() && i < g->sh.size(); ++i)
-        if (g->gbuf[i]) { (void)hipSetDevice(g->sh[i]->device); (void)hipFree(g->gbuf[i]); }
+        if (g->gbuf[i] && !g->failed) { (void)hipSetDevice(g->sh[i]->device); (void)hipFree(g->gbuf[i]); }
     for (int c = 0; c < 2; ++c) {
         for (hipEvent_t e : g->ev_in[c])
             if (e) (void)hipEventDestroy(e);
         if (g->ev_out[c]) (void)hipEventDestroy(g->ev_out[c]);
+        for (int site = 0; site < 2; ++site)
+            for (hipEvent_t e : g->ev_peer[c][site])
+                if (e) (void)hipEventDestroy(e);
     }
     delete g;
 }
@@ -671,6 +1175,30 @@ static int group_prepare_shard(cmf_handle_s *s)
     s->comm_stream = s->own_comm_stream;
     if (!s->ev_c0) HIPCHK(hipEventCreateWithFlags(&s->ev_c0, hipEventDisableTiming));
     if (!s->ev_c1) HIPCHK(hipEventCreateWithFlags(&s->ev_c1, hipEventDisableTiming));
+    return CMF_OK;
+}
+
+// The communication stream's own communicators (lane 1).  One process: a second ncclCommInitAll over the same devices;
+// one process per shard: cmf_comm_init_overlap hands in a second ncclUniqueId.  Other transports have nothing to create.
+static int group_ensure_lane1(cmf_group_s *g, const void *id128 = nullptr)
+{
+    if (g->transport != CMF_TR_RCCL || g->comm2.size() == g->sh.size()) return CMF_OK;
+    CMFTRY(group_join(g));
+    const size_t nl = g->sh.size();
+    std::vector<ncclComm_t> c2(nl, nullptr);
+    (void)hipGetLastError();
+    if (g->one_process) {
+        std::vector<int> devs(nl);
+        for (size_t i = 0; i < nl; ++i) devs[i] = g->sh[i]->device;
+        RCCLCHK(g_rccl.CommInitAll(c2.data(), (int)nl, devs.data()));
+    } else {
+        if (!id128) return fail(CMF_ERR_STATE, "the overlap form needs a communicator of its own for the communication stream: call cmf_comm_init_overlap (every rank, with a second id from cmf_comm_unique_id) before switching allreduce_overlap on");
+        ncclUniqueId id;
+        std::memcpy(&id, id128, sizeof(id));
+        CMFTRY(group_use(g->sh[0]));
+        RCCLCHK(g_rccl.CommInitRank(&c2[0], g->nranks, id, g->rank[0]));
+    }
+    g->comm2 = c2;
     return CMF_OK;
 }
 

@@ -3372,3 +3372,52 @@ __global__ __launch_bounds__(256) void loopback_allgather_kernel(CmfPtrTable sen
         for (int r = 0; r < R; ++r) recv.p[r][idx] = v;
     }
 }
+
+// "Peer" transport (all shards of a one-process group, each on its own stream, reading and writing each other's buffers
+// directly: over xGMI with peer access between distinct devices, trivially on one device).  Visibility is by kernel
+// boundaries only -- the host fences every stream against every other one with events around these kernels -- never by
+// flags inside a kernel.  All-reduce as ONE kernel per shard: shard `me` owns the `me`-th of R equal slices, sums it over
+// the R buffers in rank order (bitwise the loopback kernel's sum) and stores the result into ALL R buffers: a
+// reduce-scatter by reading the peers and an all-gather by writing them, 1/R of the payload per link and direction
+// (1.3 MB of the 10.5 MB at R = 8) where a ring moves (R-1)/R of it through every link, twice.  No two shards touch the
+// same slice, so the R kernels need no order among themselves.
+__global__ __launch_bounds__(256) void peer_allreduce_kernel(CmfPtrTable bufs, int R, int me, size_t count, size_t per, int vec4)
+{
+    const size_t lo = (size_t)me * per, hi = lo + per < count ? lo + per : count;
+    if (lo >= hi) return;
+    if (vec4) { // every buffer 16-byte aligned, per a multiple of 4: the slice in float4 words + a scalar rest at the end of the payload
+        const size_t n4 = (hi - lo) / 4;
+        for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
+            float4 v[CMF_MAX_LOCAL];
+#pragma unroll
+            for (int r = 0; r < CMF_MAX_LOCAL; ++r)
+                if (r < R) v[r] = reinterpret_cast<const float4 *>(bufs.p[r] + lo)[q];
+            float4 s = v[0];
+#pragma unroll
+            for (int r = 1; r < CMF_MAX_LOCAL; ++r)
+                if (r < R) { s.x += v[r].x; s.y += v[r].y; s.z += v[r].z; s.w += v[r].w; }
+#pragma unroll
+            for (int r = 0; r < CMF_MAX_LOCAL; ++r)
+                if (r < R) reinterpret_cast<float4 *>(bufs.p[r] + lo)[q] = s;
+        }
+        const size_t done = lo + 4 * n4;
+        for (size_t idx = done + blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < hi; idx += (size_t)gridDim.x * blockDim.x) {
+            float s = bufs.p[0][idx];
+            for (int r = 1; r < R; ++r) s += bufs.p[r][idx];
+            for (int r = 0; r < R; ++r) bufs.p[r][idx] = s;
+        }
+        return;
+    }
+    for (size_t idx = lo + blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < hi; idx += (size_t)gridDim.x * blockDim.x) {
+        float s = bufs.p[0][idx];
+        for (int r = 1; r < R; ++r) s += bufs.p[r][idx];
+        for (int r = 0; r < R; ++r) bufs.p[r][idx] = s;
+    }
+}
+// all-gather of the peer transport: shard `me` pulls every rank's send block into its own receive buffer
+__global__ __launch_bounds__(256) void peer_allgather_kernel(CmfPtrTable send, float *recv, int R, int count)
+{
+    const int total = R * count;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
+        recv[idx] = send.p[idx / count][idx % count];
+}

@@ -729,8 +729,8 @@ def save_model(results, path, **meta):
             items[k] = str(v).lstrip(":") if k == "alg" or isinstance(v, str) else np.asarray(v, dtype=np.float64)
         _hdf5.write_file(path, items)
         return
-    for k, v in meta.items():
-        arrays[k] = np.asarray(v)
+    for k, v in meta.items():  # (`alg` without the colon of a Julia symbol, in both containers)
+        arrays[k] = np.asarray(str(v).lstrip(":") if k == "alg" else v)
     np.savez_compressed(path, **arrays)
 
 

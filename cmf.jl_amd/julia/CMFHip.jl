@@ -154,12 +154,10 @@ end
 
 penalty_weights(pens) = (sum(Float64[p.weight for p in pens if p isa SquarePenalty]),
                          sum(Float64[p.weight for p in pens if p isa AbsolutePenalty]))
-# README-style regularisers on the PGD rule (`fit_cnmf(data; alg=:pgd, l1_W=..., l2_W=...)`): l1_* is an AbsolutePenalty
-# weight, l2_* a SquarePenalty weight (pgd.jl:73-89), added to whatever the penalty list already holds
-function penalty_weights(pens, kwargs, l1::Symbol, l2::Symbol)
-    sq, ab = penalty_weights(pens)
-    return sq + Float64(get(kwargs, l2, 0)), ab + Float64(get(kwargs, l1, 0))
-end
+# README-style regularisers (`l1_W`, `l2_W`, `l1_H`, `l2_H`) do NOT reach the PGD rule: the reference's PGD methods take
+# penalties only through `penaltiesW` / `penaltiesH` and swallow every other keyword in `kwargs...` (pgd.jl:158-202), and
+# so do these (and PGDUpdate in cmf.jl_amd/host.py): `fit_cnmf(data; alg=:pgd, l2_W=0.5)` gives the factors of
+# `fit_cnmf(data; alg=:pgd)` here, in the Python mirror and in the reference alike.
 # 0 none, 1 NonnegConstraint (pgd.jl:92-96), 2 UnitNormConstraint (pgd.jl:100-110)
 nonneg_flag(c) = c === nothing ? Cint(0) : (c isa NonnegConstraint ? Cint(1) :
                  (c isa UnitNormConstraint ? Cint(2) : error("unsupported constraint")))
@@ -189,7 +187,7 @@ end
 function update_motifs!(rule::HIPPGDUpdate, data, W, H; loss_func=SquareLoss(), constrW=NonnegConstraint(),
                         penaltiesW=[SquarePenalty(1)], kwargs...)
     select_loss!(rule, loss_func)
-    sq, ab = penalty_weights(penaltiesW, kwargs, :l1_W, :l2_W)
+    sq, ab = penalty_weights(penaltiesW)
     check(ccall((:cmf_pgd_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Cint),
                 rule.inner.handle, sq, ab, nonneg_flag(constrW)))
     return W
@@ -199,7 +197,7 @@ end
 function update_feature_maps!(rule::HIPPGDUpdate, data, W, H; loss_func=SquareLoss(), constrH=NonnegConstraint(),
                               penaltiesH=[], kwargs...)
     select_loss!(rule, loss_func)
-    sq, ab = penalty_weights(penaltiesH, kwargs, :l1_H, :l2_H)
+    sq, ab = penalty_weights(penaltiesH)
     loss = Ref{Float64}(0.0)
     check(ccall((:cmf_pgd_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Cint, Ref{Float64}),
                 rule.inner.handle, sq, ab, nonneg_flag(constrH), loss))

@@ -104,14 +104,13 @@ class ShardedMultUpdate(MultUpdate):
                 self._attach()
             check(lib.cmf_set_factors(self._h, ptr(W), ptr(farr(H[:, t0:t1]))))
             if overlap:
-                self.set_option("allreduce_overlap", 1)
+                self.set_overlap(True)
         except Exception:
             self.close()
             raise
         ss = ctypes.c_double()
         check(lib.cmf_get_data_sumsq(self._h, ctypes.byref(ss)))  # over all shards
         self.data_norm = math.sqrt(ss.value)  # mult.jl:13
-        self.overlap = bool(overlap)
 
     # ---- communicator ---------------------------------------------------------------------------
     def _src_rank(self):
@@ -194,6 +193,39 @@ class ShardedMultUpdate(MultUpdate):
         # the CFUNCTYPE objects must outlive the handle
         self._cb = (_lib.ALLREDUCE_FN(allreduce), _lib.ALLGATHER_FN(allgather))
         check(lib.cmf_comm_init_callbacks(self._h, self.world, self.rank, self._cb[0], self._cb[1], None))
+
+    def set_overlap(self, flag):
+        """The overlap form's bulk all-reduce runs on a second stream while collectives of the main stream are issued: in
+        the RCCL transport that stream gets a communicator of its own (cmf_comm_init_overlap), formed here -- once, on all
+        ranks together, from a second ncclUniqueId of rank 0 -- before the option is switched on.  If it cannot be formed on
+        some rank, every rank stays with the single-stream form (and says so in `overlap_refused`)."""
+        if flag and self.transport == "rccl" and not getattr(self, "_lane1", False):
+            lib, dist = self._lib, self.dist
+            err, payload = None, None
+            if self.rank == 0:
+                try:
+                    buf = ctypes.create_string_buffer(128)
+                    check(lib.cmf_comm_unique_id(buf))
+                    payload = buf.raw
+                except Exception as e:  # noqa: BLE001
+                    err = repr(e)
+            box = [payload]
+            dist.broadcast_object_list(box, src=self._src_rank(), group=self.pg)
+            bad = self._agree(err)
+            if not bad:
+                try:
+                    check(lib.cmf_comm_init_overlap(self._h, ctypes.create_string_buffer(box[0], 128)))
+                except Exception as e:  # noqa: BLE001
+                    err = repr(e)
+                bad = self._agree(err)
+            if bad:
+                self.overlap_refused = bad[0]
+                flag = False
+            else:
+                self._lane1 = True
+        MultUpdate.set_overlap(self, flag)
+
+    overlap_refused = None
 
     # ---- host-side helpers ------------------------------------------------------------------------
     def agree_scalar(self, x):

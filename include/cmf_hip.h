@@ -45,7 +45,7 @@ typedef struct cmf_handle_s *cmf_handle;
  * cmf_h_update, cmf_loss_partial*, cmf_halo_*, cmf_numden_ptr, cmf_set_data_norm) are gone -- a sharded iteration
  * runs behind the rule entries of a group handle (cmf_create_multi / cmf_comm_init_*); cmf_abi_version,
  * cmf_source_digest, cmf_synchronize, cmf_rccl_version, cmf_get_counter are new. */
-#define CMF_ABI_VERSION 3
+#define CMF_ABI_VERSION 4
 int cmf_abi_version(void);
 
 /* Library / build identification: "cmf_hip gfx950 <version> abi=<n> src=<digest>". */
@@ -104,6 +104,19 @@ int cmf_create_shard(cmf_handle *h, int device, int64_t N, int64_t T_local, int6
 #define CMF_COMM_LOOPBACK_STREAMS 3 /* loopback with a stream per shard: the collectives keep RCCL's stream semantics (start when
                                        every shard's stream has arrived, every shard's stream continues when done) through
                                        events, so a missing dependency between shards cannot hide behind a shared stream */
+#define CMF_COMM_PEER 4 /* direct peer access instead of RCCL (opt-in; one-process groups only): hipDeviceEnablePeerAccess between
+                           all devices, the all-reduce is ONE kernel per device that sums its 1/R slice from the R buffers (reads
+                           over xGMI) and stores the result into all of them (writes over xGMI) -- 1/R of the payload per link and
+                           direction where a ring moves (R-1)/R of it twice -- between two event fences of all streams; visibility by
+                           kernel boundaries only.  Sums in rank order: bitwise the loopback transport's results.  `devices` may also
+                           list ONE device ndev times (rehearsal of the protocol on a one-GPU box).  RCCL stays the default: this
+                           transport has never run across distinct devices. */
+/* Who enqueues: groups whose shards have a stream each (RCCL, peer, loopback-streams) start one ENQUEUE WORKER thread per
+ * shard; the calling thread only posts a shard's share of a phase to its worker, which issues the kernels and that shard's
+ * collective calls (RCCL's one-thread-per-device mode: no ncclGroupStart/End).  cmf_set_option(h, "enqueue_threads", 0) or
+ * CMF_ENQUEUE_THREADS=0 in the environment: the calling thread enqueues all shards, collectives in grouped calls.  Either
+ * way a handle is used by one host thread at a time, every call returns with its work handed to the streams, and results
+ * are bitwise the same. */
 int cmf_create_multi(cmf_handle *h, int ndev, const int *devices, int transport,
                      int64_t N, int64_t T, int64_t K, int64_t L, const double *data);
 
@@ -113,6 +126,13 @@ int cmf_create_multi(cmf_handle *h, int ndev, const int *devices, int transport,
  * all-reduce the data norm; H crosses the ABI as the LOCAL K x T_local block. */
 int cmf_comm_unique_id(void *id128);
 int cmf_comm_init_rccl(cmf_handle h, int nranks, int rank, const void *id128);
+/* The overlap form (option "allreduce_overlap") runs its bulk all-reduce on a second stream while collectives of the main
+ * stream are issued: that stream gets a communicator of its OWN, so that no two collectives in flight ever share one.
+ * One process per shard: every rank calls this once with a SECOND id (rank 0's cmf_comm_unique_id, handed over like the
+ * first) before switching the option on -- without it the option is refused (CMF_ERR_STATE).  cmf_create_multi groups
+ * create their second set of communicators themselves (a second ncclCommInitAll) when the option is switched on.
+ * No reference counterpart: the reference has no distributed code. */
+int cmf_comm_init_overlap(cmf_handle h, const void *id128);
 /* Host-collective transport (MPI / gloo style, used by the multi-process tests on one GPU): the library stages
  * each buffer through pinned host memory and calls back.  allreduce sums `count` floats in place over all ranks;
  * allgather fills recv (nranks * count floats, rank order) from every rank's `count`-float send block.  A non-zero
@@ -133,13 +153,19 @@ int cmf_synchronize(cmf_handle h);
  * code (e.g. 22703) and, when path != NULL, the file it was loaded from.  CMF_ERR_COMM when no RCCL can be loaded. */
 int cmf_rccl_version(int *version, char *path, int64_t path_len);
 /* Event counters of a handle.  "hals_pipeline_reruns": H sweeps whose persistent pipeline ran out of a bounded wait and
- * were redone from the snapshot on the stage pipeline (cmf_hals_update_feature_maps). */
+ * were redone from the snapshot on the stage pipeline (cmf_hals_update_feature_maps).  Group handles: "enqueue_ns" /
+ * "enqueue_iters" = nanoseconds the calling thread spent enqueueing (or posting to the enqueue workers) the pipelined
+ * iterations of cmf_iterate, and how many iterations that covers; "worker_ns" = time the busiest enqueue worker spent
+ * inside its jobs (0 without workers). */
 int cmf_get_counter(cmf_handle h, const char *name, int64_t *value);
 
 /* Run all work of this handle on an existing HIP stream (hipStream_t passed
  * as void*), e.g. torch's current stream.  NULL is the HIP null (legacy
  * default) stream -- which is what torch's default "current stream" is.
- * A new handle runs on a private non-blocking stream until this is called. */
+ * A new handle runs on a private non-blocking stream until this is called.
+ * Group handles refuse it (CMF_ERR_STATE): they run on their own per-shard streams, and that includes the handle
+ * cmf_create returns for a recording longer than one handle addresses (T > 8.3 M columns at K <= 64, see cmf_create) --
+ * a caller that orders work through torch's current stream must cmf_synchronize such a handle instead. */
 int cmf_set_stream(cmf_handle h, void *hip_stream);
 
 /* Options (name, value):
@@ -163,7 +189,9 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *   "hals_gram" (default 2): where the HALS sweeps' projections come from.  2 = P of the H phase as denomH - numH of the MU
  *       quantities (one conv launch less; H within the residual form's accuracy), G of the W phase contracted from the
  *       stored residual; 0 = both from the residual; 1 = both as differences (no residual at all, but about 20x the
- *       rounding error in W).
+ *       rounding error in W).  ACCURACY: 0 and 2 meet the north star's 1e-4 (fp32 against the fp64 reference arithmetic)
+ *       on W, H and loss_hist; hals_gram = 1 does NOT -- it is held to 3e-4 in the tests (measured: W 4-8e-5, H up to
+ *       1.4e-4) and exists for measurements only.
  *   "profile" (n): bracket every n-th contraction launch with HIP events (cmf_kernel_times); 0 stops.
  *   "allreduce_overlap" (group handles, default 0): 1 = numW (which needs H only) is contracted and all-reduced on a
  *       second stream right after the H update, underneath the loss conv and the denominator contraction, so only
@@ -259,7 +287,10 @@ int cmf_pgd_reset(cmf_handle h);
  * columns followed by the right lag halo (the layout of data_local). */
 int cmf_set_mask(cmf_handle h, const double *mask);
 /* loss_func of the PGD entries: 0 = SquareLoss (default), 1 = AbsoluteLoss (gradient sign(est - data), loss
- * norm(data - est, 1); pgd.jl:41-47).  Combines with cmf_set_mask as MaskedLoss(loss, mask). */
+ * norm(data - est, 1); pgd.jl:41-47).  Combines with cmf_set_mask as MaskedLoss(loss, mask).
+ * ACCURACY: with AbsoluteLoss the factors are held to 3e-4 (Frobenius-relative against the fp64 reference arithmetic), not
+ * the 1e-4 of every other rule and loss: the gradient is sign(est - data), and an entry of est within fp32 rounding of
+ * data takes the other sign than in fp64 -- a discontinuity no fp32 path can follow.  loss_hist stays within 1e-4. */
 int cmf_pgd_set_loss(cmf_handle h, int loss_kind);
 int cmf_pgd_update_motifs(cmf_handle h, double pen_sq, double pen_abs, int constraint);
 int cmf_pgd_update_feature_maps(cmf_handle h, double pen_sq, double pen_abs, int constraint, double *loss);

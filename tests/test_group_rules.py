@@ -400,6 +400,7 @@ def test_long_recording_paths_at_small_sizes(cmf, oracle, N, T, K, L, cap):
     data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=1234)
     Wo, Ho = oracle.c_init_rand(data, L=L, K=K, seed=3)
     os.environ["CMF_MAX_COLUMNS"] = str(cap)
+    os.environ["CMF_TEST_HOOKS"] = "1"
     try:
         Wg, Hg = cmf.init_rand(data, L=L, K=K, seed=3)
         est_b = cmf.tensor_conv(Wo, Ho)              # the stand-alone primitives in column blocks
@@ -412,6 +413,7 @@ def test_long_recording_paths_at_small_sizes(cmf, oracle, N, T, K, L, cap):
         resp = cmf.fit_cnmf(data, L=L, K=K, alg=":pgd", max_itr=4, check_convergence=False, W_init=Wo, H_init=Ho)
     finally:
         os.environ.pop("CMF_MAX_COLUMNS", None)
+        os.environ.pop("CMF_TEST_HOOKS", None)
     assert frob_rel(Wg, Wo) < 1e-6 and frob_rel(Hg, Ho) < 1e-6  # same uniforms, the scale from the blockwise sums
     assert frob_rel(est_b, oracle.tensor_conv(Wo, Ho)) < 2e-6 and frob_rel(tc_b, oracle.tensor_transconv(Wo, data)) < 2e-6
     np.testing.assert_array_equal(syn_b, cmf.gen_synthetic(N=N, T=T, seed=5))  # blocks or not: the same kernels on the same windows

@@ -133,11 +133,14 @@ def test_rule_entries_are_all_bound():
 
 def test_readme_keyword_spellings_and_symbols_are_handled():
     """README.md:44-52 spells the regularisers l1_W / l2_W / l1_H / l2_H and README.md:16,30-33 selects rules by
-    symbol: the binding accepts the spellings in all three rules and exports the symbol table INTEGRATION.md's model.jl
-    patch looks up."""
+    symbol: the binding accepts the spellings in the MU and HALS rules and exports the symbol table INTEGRATION.md's
+    model.jl patch looks up.  The PGD rule must NOT map them: the reference's PGD methods take penalties through
+    penaltiesW / penaltiesH only and swallow the rest (pgd.jl:158-202), and so does PGDUpdate in host.py."""
     text = open(JULIA).read()
     for readme in (":l1_W", ":l2_W", ":l1_H", ":l2_H"):
-        assert text.count(readme) >= 3, readme  # MU, HALS and PGD
+        assert text.count(readme) == 2, readme  # MU and HALS
+    pgd = text[text.index("function update_motifs!(rule::HIPPGDUpdate"):text.index("    ALGORITHMS")]
+    assert "penalty_weights(penaltiesW)" in pgd and "penalty_weights(penaltiesH)" in pgd and "l1_" not in pgd and "l2_" not in pgd
     m = re.search(r"const ALGORITHMS = Dict\{Symbol,Any\}\((.*?)\n\)", text, flags=re.S)
     assert m
     table = dict(re.findall(r":(\w+)\s*=>\s*(\w+)", m.group(1)))
