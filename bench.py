@@ -383,7 +383,12 @@ def run_attempt(cmds_envs, timeout, should_abort=None):
             err_tail.append({"child": i, "stderr_tail": lines[-6:]})
     for f in outs + errs:
         f.close()
-    return reason is None, reason, out0, err_tail
+    fatal = any(c == 2 for c in codes)  # exit code 2: this box cannot run the job at all (e.g. fewer GPUs than --gpus): no other form can
+    if fatal:
+        for e_ in err_tail:
+            for ln in e_["stderr_tail"]:
+                print(ln, file=sys.stderr, flush=True)
+    return (reason is None, "FATAL: " + (reason or "") if fatal else reason, out0, err_tail)
 
 
 def supervise(args, form):
@@ -429,11 +434,15 @@ def supervise(args, form):
             ok, reason, out0, errs = run_attempt([(child_command(args, "ranks"), env)], args.attempt_timeout, should_abort)
             if not ok:
                 store.set(f"failed{a}", "1")
+            if not ok and (reason or "").startswith("FATAL"):
+                store.set(f"fatal{a}", "1")
             store.set(f"done{a}/{rank}", "ok" if ok else (reason or "failed"))
             store.wait([f"done{a}/{r}" for r in range(world)])
             states = [store.get(f"done{a}/{r}").decode() for r in range(world)]
             if ok and any(st_ != "ok" for st_ in states):
                 ok, reason = False, "; ".join(f"rank {r}: {st_}" for r, st_ in enumerate(states) if st_ != "ok")
+            if any(st_.startswith("FATAL") for st_ in states) and not (reason or "").startswith("FATAL"):
+                reason = "FATAL: " + (reason or "")
         rec.update(ok=ok, seconds=round(time.time() - t0, 1))
         got = last_json_line(out0) if rank == 0 else None
         if not ok:
@@ -442,6 +451,8 @@ def supervise(args, form):
             if got is not None:  # the child's own failure record: phase, cmf_last_error, comm, what it had measured
                 rec["child_line"] = {k: got.get(k) for k in ("failed_phase", "error", "cmf_last_error", "comm", "ms_per_step", "partial") if k in got}
         attempts.append(rec)
+        if not ok and (reason or "").startswith("FATAL"):
+            sys.exit(2)  # (the child's message is on stderr; nothing on stdout, as before the supervisor existed)
         if ok and (rank != 0 or (got is not None and got.get("value") is not None)):
             line = got
             break

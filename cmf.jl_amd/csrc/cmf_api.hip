@@ -145,6 +145,12 @@ struct cmf_handle_s {
     int4 *tc_tab[2] = {nullptr, nullptr};
     int hxt_nchunks1 = 1, hxt_chunk_len1 = 6; // time chunks when only one source is contracted
     int hxt_main = 0, hxt_main1 = 0;          // rows the C2 kernel contracts in the two forms; the < 6*LP rows behind them are added by the slab sum
+    // few components (K <= 16): the contractions on the flattened (lag, component) index (cmf_small_k.h)
+    bool small_k = false;                   // option "small_k" (default on where the shape allows it)
+    bool small_k_ok = false;                // the shape allows it
+    int sk_J = 0, sk_JP = 0, sk_MG = 1, sk_chunk_len = 16, sk_ngroups = 1, sk_TG = 128;
+    float *sk_slabs = nullptr, *sk_Wj = nullptr, *sk_G = nullptr;
+    int tc_S_full = 1, tc_S1_full = 1;      // fragment slabs of the general transconv kernel (tc_S / tc_S1 are 1 while small_k is on)
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
     int conv_variant = 0;   // K % 32 == 0: 3 = one-wave workgroups (conv3_kernel), 2 = 128 x 128 tiles (conv2_kernel), 0 = per mode
     int conv_partials = 1;  // loss partials written by the last conv launch
@@ -333,6 +339,22 @@ static void plan(cmf_handle_s *h, int n_cu)
     };
     tc_plan(2, &h->tc_W, &h->tc_S, h->tc_tab_host[0]);
     tc_plan(1, &h->tc_W1, &h->tc_S1, h->tc_tab_host[1]);
+    h->tc_S_full = h->tc_S;
+    h->tc_S1_full = h->tc_S1;
+    // few components: J = L*K rows on the MFMA axes (cmf_small_k.h)
+    h->small_k_ok = d.K <= 16 && d.L <= SK_MAXL;
+    if (h->small_k_ok) {
+        h->sk_J = d.L * d.K;
+        h->sk_JP = (int)rup(h->sk_J, 128);
+        h->sk_MG = h->sk_JP / 128;
+        h->sk_TG = (int)rup(d.Tl + d.L - 1, 128);
+        // C2: a wave = (n block, m group, source, time chunk); about two waves per SIMD, chunks of whole 16-row rounds, 4 chunks per workgroup
+        const int64_t per_chunk = (int64_t)(d.Np / 32) * h->sk_MG * 2;
+        int64_t nch = std::max<int64_t>(4, (8LL * n_cu + per_chunk - 1) / per_chunk);
+        h->sk_chunk_len = (int)std::max<int64_t>(16, rup((d.Tl + nch - 1) / nch, 16));
+        nch = (d.Tl + h->sk_chunk_len - 1) / h->sk_chunk_len;
+        h->sk_ngroups = (int)((nch + 3) / 4);
+    }
     // C1 (conv)
     h->conv_gx = d.Np / 128;
     h->conv_gy = (d.Tl + 127) / 128;
@@ -343,6 +365,9 @@ static void destroy_impl(cmf_handle_s *h)
 {
     if (!h) return;
     if (h->root_only) { delete h; return; }
+    (void)hipSetDevice(h->device);
+    for (float *q : {h->sk_slabs, h->sk_Wj, h->sk_G})
+        if (q) (void)hipFree(q);
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
                       h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3],
@@ -473,6 +498,14 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     TRYB(dalloc_zero(&h->numden_own, (size_t)2 * d.L * d.K32 * d.Np));
     h->numden = h->numden_own;
     TRYB(dalloc_zero(&h->hslabs, (size_t)std::max(2 * h->tc_S, h->tc_S1) * d.Tl * d.K32));
+    if (h->small_k_ok) {
+        TRYB(dalloc_zero(&h->sk_slabs, (size_t)h->sk_ngroups * 2 * h->sk_JP * d.Np));
+        TRYB(dalloc_zero(&h->sk_Wj, (size_t)d.Np * h->sk_JP));
+        TRYB(dalloc_zero(&h->sk_G, (size_t)2 * h->sk_JP * h->sk_TG));
+        static const bool off = getenv("CMF_SMALL_K") && atoi(getenv("CMF_SMALL_K")) == 0; // measurement knob: the general kernels for every K
+        h->small_k = !off;
+        if (h->small_k) h->tc_S = h->tc_S1 = 1;
+    }
     for (int v = 0; v < 2; ++v) {
         HIPB(hipMalloc(&h->tc_tab[v], h->tc_tab_host[v].size() * sizeof(int4)));
         HIPB(hipMemcpy(h->tc_tab[v], h->tc_tab_host[v].data(), h->tc_tab_host[v].size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -561,6 +594,19 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
         if (tiles3 / slots3 >= split_min_rounds) cut += split_extra;
         cut = std::min(cut, tiles3);
     }
+    if constexpr (MODE <= 3) {
+        if (h->small_k) { // few components: one-wave tiles over the ceil(K/2) live k pairs per lag (conv_small_kernel)
+            const int nkp = (d.K + 1) / 2;
+            grid = dim3(tiles3);
+#define CASE(NKP_) hipLaunchKernelGGL((conv_small_kernel<MODE, NKP_>), grid, dim3(64), 0, h->stream, p, gx3)
+            if (nkp <= 1) CASE(1); else if (nkp == 2) CASE(2); else if (nkp == 3) CASE(3); else if (nkp == 4) CASE(4);
+            else if (nkp <= 6) CASE(6); else CASE(8);
+#undef CASE
+            h->conv_partials = (int)grid.x;
+            KCHK("conv_small_kernel");
+            return CMF_OK;
+        }
+    }
     const bool split = cut > 0;
     const int variant = (h->conv_variant && MODE <= 2) ? h->conv_variant : ((reads_data || split) ? 3 : 2);
     if (d.K % 32 == 0 && variant == 3) {
@@ -606,8 +652,27 @@ static int launch_hxt(cmf_handle_s *h)
     return launch_hxt_on(h, h->X, h->est, h->d.Np, 2, h->wslabs, h->hxt_nchunks, h->hxt_chunk_len, h->hxt_main);
 }
 
+// C3 for few components: Wj pack -> G = Wf x XT (a plain GEMM over n) -> out[t][k] = sum_l G[l*K+k][t+l], into hslabs [1][nsrc][Tl][K32]
+static int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
+{
+    ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_OTHER);
+    const CmfDims &d = h->d;
+    hipLaunchKernelGGL(wj_pack_kernel, dim3((unsigned)std::min<size_t>(1024, ((size_t)d.Np * h->sk_JP + 255) / 256)), dim3(256), 0, h->stream,
+                       h->Wn, h->sk_Wj, d.Np, d.K, d.K32, h->sk_J, h->sk_JP);
+    KCHK("wj_pack_kernel");
+    SkGemmParams p;
+    p.Wj = h->sk_Wj; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.G = h->sk_G;
+    p.TP = d.TP; p.PADL = d.PADL; p.JP = h->sk_JP; p.MG = h->sk_MG; p.TG = h->sk_TG; p.N2 = (int)rup(d.N, 2); p.Np = d.Np; p.nsrc = nsrc;
+    hipLaunchKernelGGL(g_gemm_small_kernel, dim3(h->sk_TG / 128, nsrc * h->sk_MG), dim3(256), 0, h->stream, p);
+    KCHK("g_gemm_small_kernel");
+    hipLaunchKernelGGL(fold_small_kernel, dim3((d.Tl + 63) / 64, nsrc), dim3(256), 0, h->stream, h->sk_G, h->hslabs, d.Tl, d.K, d.L, d.K32, h->sk_JP, h->sk_TG);
+    KCHK("fold_small_kernel");
+    return CMF_OK;
+}
+
 static int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullptr)
 {
+    if (h->small_k) return launch_transconv_small(h, nsrc, xt0);
     ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_OTHER);
     const CmfDims &d = h->d;
     TcParams p;
@@ -650,6 +715,26 @@ static int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nsl
 static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int nsrc, float *out, bool take_carry = false)
 {
     const CmfDims &d = h->d;
+    if (h->small_k) { // few components: the rows j = l*K + k on the MFMA axis (hxt_small_kernel), compact slabs, their sum expanded to [L][K32][Np]
+        ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : (nsrc == 1 && X0 == h->X) ? PROF_HXT_NUM : (nsrc == 1 && X0 == h->est && h->est_kind == 1) ? PROF_HXT_DEN : PROF_OTHER);
+        SkHxtParams p;
+        p.Ht = h->Ht; p.X0 = X0; p.X1 = X1; p.slabs = h->sk_slabs;
+        p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.L = d.L; p.J = h->sk_J; p.JP = h->sk_JP; p.MG = h->sk_MG; p.Tl = d.Tl;
+        p.chunk_len = h->sk_chunk_len; p.nsrc = nsrc;
+        const size_t lds = std::max<size_t>((size_t)4 * (d.K + 1) * SK_HS_STRIDE, 4 * 16 * 64) * sizeof(float);
+        hipLaunchKernelGGL(hxt_small_kernel, dim3(d.Np / 32, h->sk_ngroups, nsrc * h->sk_MG), dim3(256), lds, h->stream, p);
+        KCHK("hxt_small_kernel");
+        CmfLossCarry carry{};
+        if (take_carry && h->carry.partial) { // a loss reduction deferred by cmf_iterate rides on this launch
+            carry = h->carry;
+            h->carry = CmfLossCarry{};
+        }
+        const size_t n4 = (size_t)nsrc * d.L * d.K32 * d.Np / 4;
+        hipLaunchKernelGGL(slab_sum_small_kernel, dim3((unsigned)std::min<size_t>(2048, (n4 + 255) / 256)), dim3(256), 0, h->stream, out, h->sk_slabs,
+                           h->sk_ngroups, nsrc, d.L, d.K, d.K32, d.Np, h->sk_JP, carry);
+        KCHK("slab_sum_small_kernel");
+        return CMF_OK;
+    }
     const int nch = nsrc == 2 ? h->hxt_nchunks : h->hxt_nchunks1, clen = nsrc == 2 ? h->hxt_chunk_len : h->hxt_chunk_len1;
     const int main_rows = nsrc == 2 ? h->hxt_main : h->hxt_main1;
     CMFTRY(launch_hxt_on(h, X0, X1, d.Np, nsrc, h->wslabs, nch, clen, main_rows));
@@ -1077,6 +1162,15 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
     }
     if (std::strcmp(name, "conv_split") == 0) { // 0 = never cut the one-wave conv kernel's last round into quarter tiles
         h->conv_split = value;
+        h->est_kind = 0;
+        return CMF_OK;
+    }
+    if (std::strcmp(name, "small_k") == 0) { // K <= 16: 1 = the few-component kernels (cmf_small_k.h; default), 0 = the general kernels
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->small_k = value != 0 && h->small_k_ok;
+        h->tc_S = h->small_k ? 1 : h->tc_S_full;
+        h->tc_S1 = h->small_k ? 1 : h->tc_S1_full;
         h->est_kind = 0;
         return CMF_OK;
     }
@@ -2735,7 +2829,7 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
     auto run = [&]() -> int {
         switch (which) {
         case 0: return launch_conv<0>(h, h->est, d.Tl, h->conv_gy);
-        case 1: return launch_hxt(h);
+        case 1: return h->small_k ? hxt_contract(h, h->X, h->est, 2, h->numden) : launch_hxt(h); // (few components: kernel + its slab sum)
         case 2: return launch_transconv(h, 2);
         case 3: return launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext);
         case 4: return launch_conv<2>(h, nullptr, d.Tl, h->conv_gy);

@@ -372,18 +372,20 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p)
 // ---------------------------------------------------------------------------------------------
 // NBL = live 32-column n blocks of the wave's 64 columns (2, or 1 when the second block is all padding: at N = 2000 the
 // last 64-column tile holds 16 real columns, and skipping its dead half is 1.6 % of the launch's MFMAs)
-template <int NBL = 2>
-__device__ __forceinline__ void conv2_load_w(float (&w)[16][2], __amdgpu_buffer_rsrc_t wr, int woff, int lag, int lagbytes, int rowbytes)
+// NKP = k pairs per lag: 16 for a whole 32-row k block; the few-component kernel (conv_small_kernel, K <= 16) runs the same
+// lag loop over the ceil(K / 2) pairs that hold data
+template <int NBL = 2, int NKP = 16>
+__device__ __forceinline__ void conv2_load_w(float (&w)[NKP][2], __amdgpu_buffer_rsrc_t wr, int woff, int lag, int lagbytes, int rowbytes)
 {
 #ifdef CMF_CONV_KNOCKOUT // timing experiments only (tools/conv_knockout.py): 1 = W loaded for lag 0 only
     if ((CMF_CONV_KNOCKOUT & 1) && lag != 0) {
 #pragma unroll
-        for (int kp = 0; kp < 16; ++kp) { asm volatile("" : "+v"(w[kp][0])); asm volatile("" : "+v"(w[kp][1])); }
+        for (int kp = 0; kp < NKP; ++kp) { asm volatile("" : "+v"(w[kp][0])); asm volatile("" : "+v"(w[kp][1])); }
         return;
     }
 #endif
 #pragma unroll
-    for (int kp = 0; kp < 16; ++kp) {
+    for (int kp = 0; kp < NKP; ++kp) {
         w[kp][0] = cmf_bload(wr, woff, lag * lagbytes + kp * 2 * rowbytes);
         if (NBL == 2) w[kp][1] = cmf_bload(wr, woff + 128, lag * lagbytes + kp * 2 * rowbytes);
     }
@@ -391,19 +393,19 @@ __device__ __forceinline__ void conv2_load_w(float (&w)[16][2], __amdgpu_buffer_
 
 // FIRST: the accumulators hold nothing yet -- the kp = 0 MFMAs take a zero C operand (an inline constant) instead of
 // 64 register writes of an explicit zero fill
-template <int MODE, int STRIDE = CONV_HS_STRIDE, bool FIRST = false, int NBL = 2>
-__device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb, const float (&w)[16][2])
+template <int MODE, int STRIDE = CONV_HS_STRIDE, bool FIRST = false, int NBL = 2, int NKP = 16>
+__device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb, const float (&w)[NKP][2])
 {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float a0 = hsb[0], a1 = hsb[32];
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
-    for (int kp = 0; kp < 16; ++kp) {
+    for (int kp = 0; kp < NKP; ++kp) {
         float na0 = 0.f, na1 = 0.f;
 #ifdef CMF_CONV_KNOCKOUT // 2 = one H operand read per lag instead of sixteen
         if (CMF_CONV_KNOCKOUT & 2) { na0 = a0; na1 = a1; asm volatile("" : "+v"(na0), "+v"(na1)); } else
 #endif
-        if (kp + 1 < 16) {
+        if (kp + 1 < NKP) {
             na0 = hsb[(kp + 1) * 2 * STRIDE];
             na1 = hsb[(kp + 1) * 2 * STRIDE + 32];
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -429,28 +431,28 @@ __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb,
 
 // The lag pairs of one (kb, lb) block for a wave: wA holds lag 0 on entry.  `first`: the block's first MFMAs start the
 // accumulators (zero C operand).
-template <int MODE, int STRIDE, int NBL>
-__device__ __forceinline__ void conv2_lag_pairs(f32x16 (&acc)[2][2], const float *hsb, float (&wA)[16][2], float (&wB)[16][2],
+template <int MODE, int STRIDE, int NBL, int NKP = 16>
+__device__ __forceinline__ void conv2_lag_pairs(f32x16 (&acc)[2][2], const float *hsb, float (&wA)[NKP][2], float (&wB)[NKP][2],
                                                 __amdgpu_buffer_rsrc_t wr, int woff, int npair, bool first, int lagbytes, int rowbytes)
 {
     int pr = 0;
     if (first) { // peeled first lag pair
-        conv2_load_w<NBL>(wB, wr, woff, 1, lagbytes, rowbytes);
+        conv2_load_w<NBL, NKP>(wB, wr, woff, 1, lagbytes, rowbytes);
         __builtin_amdgcn_sched_barrier(0);
-        conv2_lag<MODE, STRIDE, true, NBL>(acc, hsb, wA);
-        conv2_load_w<NBL>(wA, wr, woff, (1 < npair) ? 2 : 0, lagbytes, rowbytes);
+        conv2_lag<MODE, STRIDE, true, NBL, NKP>(acc, hsb, wA);
+        conv2_load_w<NBL, NKP>(wA, wr, woff, (1 < npair) ? 2 : 0, lagbytes, rowbytes);
         __builtin_amdgcn_sched_barrier(0);
-        conv2_lag<MODE, STRIDE, false, NBL>(acc, hsb - 1, wB);
+        conv2_lag<MODE, STRIDE, false, NBL, NKP>(acc, hsb - 1, wB);
         pr = 1;
     }
     for (; pr < npair; ++pr) {
         const int l0 = 2 * pr; // lag offsets inside the block
-        conv2_load_w<NBL>(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
+        conv2_load_w<NBL, NKP>(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
         __builtin_amdgcn_sched_barrier(0);
-        conv2_lag<MODE, STRIDE, false, NBL>(acc, hsb - l0, wA);
-        conv2_load_w<NBL>(wA, wr, woff, (pr + 1 < npair) ? l0 + 2 : l0, lagbytes, rowbytes);
+        conv2_lag<MODE, STRIDE, false, NBL, NKP>(acc, hsb - l0, wA);
+        conv2_load_w<NBL, NKP>(wA, wr, woff, (pr + 1 < npair) ? l0 + 2 : l0, lagbytes, rowbytes);
         __builtin_amdgcn_sched_barrier(0);
-        conv2_lag<MODE, STRIDE, false, NBL>(acc, hsb - l0 - 1, wB);
+        conv2_lag<MODE, STRIDE, false, NBL, NKP>(acc, hsb - l0 - 1, wB);
     }
 }
 
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
 // end of the launch shrink fourfold.  Main loop and epilogue are conv2's.
 // ---------------------------------------------------------------------------------------------
 #define CONV3_STRIDE 96
-template <int MODE, int NBL = 2>
+template <int MODE, int NBL = 2, int NKP = 16>
 __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t0, int n0, int lane, int pidx)
 {
     const int i = lane & 31, h = lane >> 5;
@@ -552,7 +554,8 @@ __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t
     const int rowbytes = Np * 4;
     const int lagbytes = K32 * Np * 4;
     const int woff = (h * Np + n0 + i) * 4; // per-lane part of the W address
-    float wA[16][2], wB[16][2];
+    float wA[NKP][2], wB[NKP][2];
+    constexpr int NQ = (2 * NKP + 7) / 8; // 8-row passes of the strip load that hold live k rows
 
     for (int kb = 0; kb < p.KB; ++kb) {
         for (int lb = 0; lb < LB; ++lb) {
@@ -560,26 +563,26 @@ __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t
             const int lend = (p.L < lbeg + 32) ? p.L : (lbeg + 32);
             const int npair = (lend - lbeg + 1) >> 1; // lags are processed in pairs; Wt is zero-padded to Lp
             const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wt + ((size_t)lbeg * K32 + kb * 32) * Np, (size_t)(2 * npair) * lagbytes);
-            conv2_load_w<NBL>(wA, wr, woff, 0, lagbytes, rowbytes);
+            conv2_load_w<NBL, NKP>(wA, wr, woff, 0, lagbytes, rowbytes);
             {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,96): 8 lanes per row, 8 rows per pass
                 const int r = lane >> 3, c = (lane & 7) * 4;
                 const float *src = p.Ht + (size_t)(kb * 32 + r) * TP + (p.PADL + t0 - lbeg - 32 + c);
                 float *dst = Hs + r * CONV3_STRIDE + c;
-                f32x4 v[12];
+                f32x4 v[3 * NQ];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) v[q * 3 + j] = *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * j);
                 __builtin_amdgcn_wave_barrier(); // every lane is done reading the previous strip
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4 *>(dst + (8 * q) * CONV3_STRIDE + 32 * j) = v[q * 3 + j];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const float *hsb = Hs + h * CONV3_STRIDE + 32 + i;
-            conv2_lag_pairs<MODE, CONV3_STRIDE, NBL>(acc, hsb, wA, wB, wr, woff, npair, kb == 0 && lb == 0, lagbytes, rowbytes);
+            conv2_lag_pairs<MODE, CONV3_STRIDE, NBL, NKP>(acc, hsb, wA, wB, wr, woff, npair, kb == 0 && lb == 0, lagbytes, rowbytes);
         }
     }
     if (NBL == 1) conv2_clear_dead<MODE>(acc);
@@ -919,6 +922,19 @@ __global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p, int gx, int 
         const int q = b - n_full, tile = n_full + (q >> 4), sub = q & 15;
         conv3_sixteenth<MODE>(p, Hs, (tile / gx) * 64 + (sub >> 2) * 16, (tile % gx) * 64 + (sub & 3) * 16, threadIdx.x, b);
     }
+}
+
+// C1 for few components (K <= 16, one k block): conv3's one-wave 64 x 64 tiles with the lag loop running over the NKP =
+// ceil(K / 2) k pairs that hold data instead of all 16 -- K = 5 issues 3/16 of the MFMAs of the padded k block.  Whole
+// tiles only (a launch of this size has no thin last round worth cutting up).
+template <int MODE, int NKP>
+__global__ __launch_bounds__(64, 3) void conv_small_kernel(ConvParams p, int gx)
+{
+    __shared__ __attribute__((aligned(16))) float Hs[32 * CONV3_STRIDE];
+    const int b = blockIdx.x;
+    const int n0 = (b % gx) * 64;
+    if (n0 + 32 < p.N) conv3_tile<MODE, 2, NKP>(p, Hs, (b / gx) * 64, n0, threadIdx.x, b);
+    else conv3_tile<MODE, 1, NKP>(p, Hs, (b / gx) * 64, n0, threadIdx.x, b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3421,3 +3437,5 @@ __global__ __launch_bounds__(256) void peer_allgather_kernel(CmfPtrTable send, f
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)
         recv[idx] = send.p[idx / count][idx % count];
 }
+
+#include "cmf_small_k.h"

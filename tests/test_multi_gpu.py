@@ -209,3 +209,48 @@ def test_bench_ranks_form_rehearsal_on_one_gpu(transport):
     assert line["comm"]["mode"] == "one-process-per-gpu" and line["comm"]["transport"] == "callbacks" and line["comm"]["nranks"] == 2
     assert line["comm"]["allreduce"]["avg_ms"] > 0
     assert ("fallback_from_rccl" in line["comm"]) == (transport == "rccl")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport,threads", [("peer", "1"), ("peer", "0"), ("loopback-streams", "1")])
+def test_bench_multi_form_rehearsal_peer_transport_and_enqueue_threads(transport, threads):
+    """`bench.py --gpus 4` on THIS box with the transports that give every shard its own stream (CMF_BENCH_TRANSPORT): the
+    supervisor starts the measurement in a child process, the first form of the ladder delivers, `comm` says which transport
+    carried the collectives and who enqueued, and the probe of the overlap form (default from 4 GPUs on) records both times."""
+    env = dict(os.environ, CMF_BENCH_DEVICES="0,0,0,0", CMF_BENCH_TRANSPORT=transport, CMF_ENQUEUE_THREADS=threads)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--sustain", "0",
+                        "--T", "8000"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and line["n_gpus"] == 4 and [a["ok"] for a in line["attempts"]] == [True]
+    assert line["comm"]["transport"] == transport and line["comm"]["enqueue"] == ("threads" if threads == "1" else "caller")
+    probe = line["allreduce_overlap_probe_ms"]
+    assert probe["single"] > 0 and probe["overlap"] > 0 and line["allreduce_overlap"] == (probe["overlap"] < probe["single"])
+    assert line["group_extras"] is None  # opt-in since round 4
+    c = line["comm"]["collectives"]
+    assert c["allgather_halo"]["avg_ms"] > 0 and c["allreduce_gram_payload"]["bytes"] < line["comm"]["allreduce"]["bytes"]
+
+
+@pytest.mark.gpu
+def test_bench_failure_after_group_creation_still_prints_the_line():
+    """First-contact diagnostics: the measurement itself (`--child multi`, what the supervisor starts) fails in its first
+    all-reduce -- provoked with the library's test hook on a 3-shard peer group -- and still prints ONE JSON line with
+    value null, the failing phase, cmf_last_error and `comm`, and exits non-zero (what the supervisor does with such a child
+    is covered on the CPU: tests/test_bench_supervisor.py)."""
+    env = dict(os.environ, CMF_BENCH_DEVICES="0,0,0", CMF_BENCH_TRANSPORT="peer", CMF_TEST_HOOKS="1", CMF_TEST_FAIL_SHARD="1", CMF_ALLREDUCE_OVERLAP="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    args = ["--gpus", "3", "--steps", "3", "--warmup", "1", "--sustain", "0", "--T", "6000"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--child", "multi"] + args, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 3, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["failed_phase"] == "warm-up steps" and "CMF_TEST_FAIL_SHARD" in line["cmf_last_error"]
+    assert line["comm"]["transport"] == "peer" and line["comm"]["nranks"] == 3 and line["n_gpus"] == 3
+    assert "failed in phase 'warm-up steps'" in p.stderr.decode()

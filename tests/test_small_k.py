@@ -1,0 +1,144 @@
+"""The few-component kernels (csrc/cmf_small_k.h; K <= 16, L <= 64 -- the shapes the reference publishes on: README.md K = 5,
+figures/fast_bcd/synthetic_comparison.jl:58-64 N = 250, K = 5, L = 20) against the fp64 oracle and against the general
+kernels they replace (option small_k = 0): primitives, single iterations, whole fits, T-sharded groups, HALS and PGD on top
+of them."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_FACTORS = 1e-4
+REL_LOSS = 1e-4
+REL_PRIM = 2e-6
+
+
+@pytest.fixture(scope="module")
+def cmf():
+    import cmf_jl_amd as m
+
+    assert m.load_library().cmf_device_count() >= 1
+    return m
+
+
+def frob_rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+# (N, T, K, L): every k-pair count of conv_small_kernel (1, 2, 3, 4, 6, 8), J = L*K below / at / above one 128-row m group and
+# above two, T shorter than a chunk / a strip / L, N crossing 32- and 128-column blocks, L at the strip limit
+SHAPES = [
+    (48, 300, 4, 8), (7, 23, 3, 4), (5, 9, 1, 1), (1, 17, 2, 5), (6, 3, 2, 5), (4, 5, 3, 5), (70, 257, 5, 10),
+    (250, 1500, 5, 20), (130, 700, 16, 20), (33, 400, 7, 19), (20, 200, 6, 40), (40, 333, 9, 15), (9, 1100, 2, 3),
+    (65, 520, 11, 12), (300, 260, 13, 7), (17, 150, 16, 64), (129, 900, 15, 33), (10, 64, 8, 16), (500, 2000, 5, 10),
+]
+
+
+@pytest.mark.parametrize("N,T,K,L", SHAPES)
+def test_single_iteration_small_k_vs_oracle_and_general_kernels(cmf, oracle, N, T, K, L):
+    rng = np.random.default_rng(N * 7 + T)
+    data = rng.random((N, T))
+    W0 = np.asfortranarray(rng.random((K, N, L)))
+    H0 = np.asfortranarray(rng.random((K, T)))
+    out = {}
+    for small in (1, 0):
+        rule = cmf.MultUpdate(data, W0, H0)
+        rule.set_option("small_k", small)
+        l0 = rule.compute_loss()
+        rule.update_motifs(l1W=0.1, l2W=0.5)
+        l1 = rule.update_feature_maps(l1H=0.1, l2H=0.2)
+        out[small] = (np.array([l0, l1]),) + rule.download()
+        rule.close()
+    W, H = W0.copy(), H0.copy()
+    orule = oracle.MultUpdate(data, W, H)
+    lo = [oracle.compute_loss(data, W, H)]
+    oracle.update_motifs(orule, data, W, H, l1W=0.1, l2W=0.5)
+    lo.append(oracle.update_feature_maps(orule, data, W, H, l1H=0.1, l2H=0.2))
+    for small in (1, 0):
+        np.testing.assert_allclose(out[small][0], lo, rtol=1e-5, err_msg=f"small_k={small}")
+        assert frob_rel(out[small][1], W) < 1e-5 and frob_rel(out[small][2], H) < 1e-5, f"small_k={small}"
+    assert frob_rel(out[1][1], out[0][1]) < 5e-6 and frob_rel(out[1][2], out[0][2]) < 5e-6
+
+
+@pytest.mark.parametrize("N,T,K,L,iters,reg", [(250, 4000, 5, 20, 40, 0), (500, 2000, 5, 10, 100, 1), (120, 900, 12, 25, 30, 1), (64, 700, 16, 8, 30, 0)])
+def test_fit_small_k(cmf, oracle, N, T, K, L, iters, reg):
+    """Whole fits (the reference's own protocol shape at a fifth of its T; BASELINE configs[0] with the README regularisers):
+    W, H, loss_hist within the north star's 1e-4 of the fp64 oracle, pipelined (cmf_iterate) and call by call."""
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2) if reg else dict(l1W=0.0, l2W=0.0, l1H=0.0, l2H=0.0)
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False, **kw)
+    rule = cmf.MultUpdate(data, W0, H0)
+    lg = [rule.compute_loss()] + list(rule.iterate(iters, **kw))
+    Wg, Hg = rule.download()
+    rule.upload(W0, H0)
+    lc = [rule.compute_loss()]
+    for _ in range(min(iters, 5)):
+        rule.update_motifs(l1W=kw["l1W"], l2W=kw["l2W"])
+        lc.append(rule.update_feature_maps(l1H=kw["l1H"], l2H=kw["l2H"]))
+    rule.close()
+    np.testing.assert_allclose(lg, lr, rtol=REL_LOSS)
+    np.testing.assert_array_equal(lc, lg[: len(lc)])  # the pipelined batch is the call-by-call loop, bit for bit
+    assert frob_rel(Wg, Wr) < REL_FACTORS and frob_rel(Hg, Hr) < REL_FACTORS
+    assert np.all(Wg >= cmf.EPSILON) and np.all(Hg >= cmf.EPSILON)
+
+
+@pytest.mark.parametrize("R,N,T,K,L", [(2, 250, 1500, 5, 20), (3, 40, 333, 5, 10), (4, 70, 600, 12, 16), (8, 33, 1100, 3, 7)])
+def test_groups_on_the_small_k_kernels(cmf, oracle, R, N, T, K, L):
+    """T-sharded groups (halos on both sides of the middle shards) on the few-component kernels: every transport a one-GPU box
+    has, plain and overlap form, against the oracle and bitwise among themselves."""
+    from cmf_jl_amd import _lib
+
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20), seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=6, check_convergence=False)
+    res = []
+    for tr in (_lib.CMF_COMM_LOOPBACK, _lib.CMF_COMM_PEER):
+        for overlap in (False, True):
+            rule = cmf.MultUpdate(data, W0, H0, devices=[0] * R, transport=tr)
+            rule.set_overlap(overlap)
+            ls = [rule.compute_loss()] + list(rule.iterate(6))
+            res.append((overlap, np.asarray(ls)) + rule.download())
+            rule.close()
+            np.testing.assert_allclose(ls, lr, rtol=REL_LOSS)
+            assert frob_rel(res[-1][2], Wr) < REL_FACTORS and frob_rel(res[-1][3], Hr) < REL_FACTORS
+    for r in res[2:]:
+        base = res[0] if not r[0] else res[1]
+        for a, b in zip(base[1:], r[1:]):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_primitives_and_other_rules_with_few_components(cmf, oracle):
+    """tensor_conv / tensor_transconv stand-alone, and the HALS and PGD rules (which share the conv / C2 / C3 launchers) at
+    K = 5: against the oracle."""
+    N, T, K, L = 90, 640, 5, 12
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=12, seed=3)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=1)
+    assert frob_rel(cmf.tensor_conv(W0, H0), oracle.tensor_conv(W0, H0)) < REL_PRIM
+    assert frob_rel(cmf.tensor_transconv(W0, data), oracle.tensor_transconv(W0, data)) < REL_PRIM
+    for alg, fit in ((":hals", oracle.c_fit_hals), (":pgd", None)):
+        res = cmf.fit_cnmf(data, L=L, K=K, alg=alg, max_itr=8, check_convergence=False, W_init=W0, H_init=H0)
+        if fit is None:
+            Wr, Hr, lr, _ = oracle.fit_pgd(data, W0, H0, max_itr=8)
+        else:
+            Wr, Hr, lr, _ = fit(data, W0, H0, max_itr=8, check_convergence=False)
+        np.testing.assert_allclose(res.loss_hist, lr, rtol=REL_LOSS, err_msg=alg)
+        assert frob_rel(res.W, Wr) < REL_FACTORS and frob_rel(res.H, Hr) < REL_FACTORS, alg
+
+
+def test_reference_protocol_shape_full_size(cmf, oracle):
+    """figures/fast_bcd/synthetic_comparison.jl:58-64 at full size (N = 250, T = 50000, K = 5, L = 20): 5 iterations against
+    the oracle, and the few-component kernels against the general ones."""
+    N, T, K, L = 250, 50000, 5, 20
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=20, seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=5, check_convergence=False)
+    out = {}
+    for small in (1, 0):
+        rule = cmf.MultUpdate(data, W0, H0)
+        rule.set_option("small_k", small)
+        ls = [rule.compute_loss()] + list(rule.iterate(5))
+        out[small] = (np.asarray(ls),) + rule.download()
+        rule.close()
+        np.testing.assert_allclose(ls, lr, rtol=REL_LOSS)
+        assert frob_rel(out[small][1], Wr) < REL_FACTORS and frob_rel(out[small][2], Hr) < REL_FACTORS
+    print("small_k vs general kernels: relW", frob_rel(out[1][1], out[0][1]), "relH", frob_rel(out[1][2], out[0][2]))
