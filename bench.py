@@ -216,6 +216,50 @@ def other_configs(cmf, rule, data, W0, H0, N, T, K, L, with_config3, device):
             hr.close()
     except Exception as e:  # noqa: BLE001
         res["configs[4]"] = {"error": repr(e)}
+    # The shapes the reference itself publishes on have FEW components (README.md: K = 5; figures/fast_bcd/synthetic_comparison.jl:58-64:
+    # N = 250, K = 5, L = 20, T up to 50000), and configs[0] is K = 5 too: they run on the few-component kernels (csrc/cmf_small_k.h,
+    # the MFMA axes carry the flattened (lag, component) index).  Reported with the roofline on USEFUL flops (2*K*N*S per
+    # contraction, 6 executed per iteration), next to the general kernels (option small_k = 0: K padded to a 32-wide MFMA axis).
+    def few_components(key, N_, T_, K_, L_, what):
+        try:
+            d_ = cmf.gen_synthetic(N=N_, T=T_, seed=1234, device=device)
+            W_, H_ = cmf.init_rand(d_, L=L_, K=K_, seed=0, device=device)
+            f1_ = 2.0 * K_ * N_ * (L_ * T_ - L_ * (L_ - 1) / 2)
+            rec = {"workload": f"N={N_} T={T_} K={K_} L={L_} alg=:mult ({what})", "steps": 50, "warmup": 3, "useful_flops_per_contraction": f1_}
+            for small in (1, 0):
+                r_ = cmf.MultUpdate(d_, W_, H_, device=device)
+                try:
+                    r_.set_option("small_k", small)
+                    r_.iterate(3, **zero)
+                    r_.synchronize()
+                    t0 = time.perf_counter()
+                    ls = r_.iterate(50, **zero)
+                    r_.synchronize()
+                    dt_ = (time.perf_counter() - t0) / 50
+                    if small:
+                        ks = {}
+                        for nm in ("conv_t", "conv_loss_store", "hxt", "transconv"):
+                            ms_, _ = r_.time_kernel(nm, reps=10)
+                            fl_ = f1_ * (2.0 if nm in ("hxt", "transconv") else 1.0)
+                            ks[nm] = {"avg_ms": ms_, "useful_tflops": fl_ / ms_ / 1e9, "frac": fl_ / ms_ / 1e9 / PEAK_FP32_MFMA_TFLOPS}
+                        dom = max(ks, key=lambda k_: ks[k_]["avg_ms"])
+                        rec.update(ms_per_step=1e3 * dt_, iters_per_s=1.0 / dt_, loss_last=float(ls[-1]), kernels_standalone=ks,
+                                   whole_iteration_useful_mfma_frac=6.0 * f1_ / dt_ / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+                                   roofline={"bound": "mfma", "kernel": dom + " (few-component kernels; hxt / transconv: both sources, incl. their slab sum / fold)",
+                                             "achieved": ks[dom]["useful_tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ks[dom]["frac"],
+                                             "traffic": None, "flops": "useful: 2*K*N*S per contraction and source",
+                                             "timing": "cmf_time_kernel: HIP events around 10 stand-alone launches"})
+                    else:
+                        rec.update(ms_per_step_general_kernels=1e3 * dt_, speedup_over_general_kernels=dt_ / (1e-3 * rec["ms_per_step"]))
+                finally:
+                    r_.close()
+            res[key] = rec
+        except Exception as e:  # noqa: BLE001
+            res[key] = {"error": repr(e)}
+
+    few_components("reference_protocol_shape", 250, 50000, 5, 20, "figures/fast_bcd/synthetic_comparison.jl:58-64")
+    few_components("configs[0]", CONFIGS[1]["N"], CONFIGS[1]["T"], CONFIGS[1]["K"], CONFIGS[1]["L"],
+                   "BASELINE.json configs[0]: the reference's CPU-runnable case; a problem this small is launch-latency bound on a GPU")
     if with_config3:
         try:  # config 3's problem on ONE GPU (its 8-GPU form gives every GPU exactly the config-2 shard)
             c3 = CONFIGS[3]

@@ -148,7 +148,8 @@ struct cmf_handle_s {
     // few components (K <= 16): the contractions on the flattened (lag, component) index (cmf_small_k.h)
     bool small_k = false;                   // option "small_k" (default on where the shape allows it)
     bool small_k_ok = false;                // the shape allows it
-    int sk_J = 0, sk_JP = 0, sk_MG = 1, sk_chunk_len = 16, sk_ngroups = 1, sk_TG = 128;
+    bool sk_tc_ok = false, sk_tc = false;   // ... and its C3 form (G GEMM + fold) has enough columns to fill the chip; sk_tc: in use
+    int sk_J = 0, sk_JP = 0, sk_MG = 1, sk_MBW = 4, sk_chunk_len = 16, sk_ngroups = 1, sk_TG = 128;
     float *sk_slabs = nullptr, *sk_Wj = nullptr, *sk_G = nullptr;
     int tc_S_full = 1, tc_S1_full = 1;      // fragment slabs of the general transconv kernel (tc_S / tc_S1 are 1 while small_k is on)
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
@@ -345,15 +346,23 @@ static void plan(cmf_handle_s *h, int n_cu)
     h->small_k_ok = d.K <= 16 && d.L <= SK_MAXL;
     if (h->small_k_ok) {
         h->sk_J = d.L * d.K;
-        h->sk_JP = (int)rup(h->sk_J, 128);
-        h->sk_MG = h->sk_JP / 128;
+        const int mblocks = (h->sk_J + 31) / 32;              // 32-row blocks that hold rows j
+        h->sk_MG = (mblocks + SK_MAXMBW - 1) / SK_MAXMBW;     // groups of at most SK_MAXMBW blocks ...
+        h->sk_MBW = (mblocks + h->sk_MG - 1) / h->sk_MG;      // ... as even as possible: the least padding
+        h->sk_JP = 32 * h->sk_MBW * h->sk_MG;
         h->sk_TG = (int)rup(d.Tl + d.L - 1, 128);
-        // C2: a wave = (n block, m group, source, time chunk); about two waves per SIMD, chunks of whole 16-row rounds, 4 chunks per workgroup
+        // C2: a wave = (n block, m group, source, time chunk).  Chunks of about 512 rows (four strips): many short waves, so that
+        // the rounds of the launch are short and its last one costs little -- but at least two waves per SIMD; chunks are whole
+        // 16-row rounds, 4 chunks per workgroup.
         const int64_t per_chunk = (int64_t)(d.Np / 32) * h->sk_MG * 2;
-        int64_t nch = std::max<int64_t>(4, (8LL * n_cu + per_chunk - 1) / per_chunk);
+        int64_t nch = std::max<int64_t>({(int64_t)4, (8LL * n_cu + per_chunk - 1) / per_chunk, (int64_t)(d.Tl + 511) / 512});
         h->sk_chunk_len = (int)std::max<int64_t>(16, rup((d.Tl + nch - 1) / nch, 16));
         nch = (d.Tl + h->sk_chunk_len - 1) / h->sk_chunk_len;
         h->sk_ngroups = (int)((nch + 3) / 4);
+        // C3: the G GEMM runs one wave per 32 columns, row group and source; with fewer than two waves per CU (short
+        // recordings: BASELINE configs[0] has T = 2000) the general kernel, which splits the reduction over n, is faster
+        // (measured at configs[0]: 20 us against 39)
+        h->sk_tc_ok = (int64_t)(h->sk_TG / 32) * h->sk_MG * 2 >= 2LL * n_cu;
     }
     // C1 (conv)
     h->conv_gx = d.Np / 128;
@@ -504,7 +513,8 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
         TRYB(dalloc_zero(&h->sk_G, (size_t)2 * h->sk_JP * h->sk_TG));
         static const bool off = getenv("CMF_SMALL_K") && atoi(getenv("CMF_SMALL_K")) == 0; // measurement knob: the general kernels for every K
         h->small_k = !off;
-        if (h->small_k) h->tc_S = h->tc_S1 = 1;
+        h->sk_tc = h->small_k && h->sk_tc_ok;
+        if (h->sk_tc) h->tc_S = h->tc_S1 = 1;
     }
     for (int v = 0; v < 2; ++v) {
         HIPB(hipMalloc(&h->tc_tab[v], h->tc_tab_host[v].size() * sizeof(int4)));
@@ -594,7 +604,7 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
         if (tiles3 / slots3 >= split_min_rounds) cut += split_extra;
         cut = std::min(cut, tiles3);
     }
-    if constexpr (MODE <= 3) {
+    {
         if (h->small_k) { // few components: one-wave tiles over the ceil(K/2) live k pairs per lag (conv_small_kernel)
             const int nkp = (d.K + 1) / 2;
             grid = dim3(tiles3);
@@ -663,7 +673,12 @@ static int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
     SkGemmParams p;
     p.Wj = h->sk_Wj; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.G = h->sk_G;
     p.TP = d.TP; p.PADL = d.PADL; p.JP = h->sk_JP; p.MG = h->sk_MG; p.TG = h->sk_TG; p.N2 = (int)rup(d.N, 2); p.Np = d.Np; p.nsrc = nsrc;
-    hipLaunchKernelGGL(g_gemm_small_kernel, dim3(h->sk_TG / 128, nsrc * h->sk_MG), dim3(256), 0, h->stream, p);
+    switch (h->sk_MBW) {
+#define CASE(M_) case M_: hipLaunchKernelGGL((g_gemm_small_kernel<M_>), dim3(h->sk_TG / 128, nsrc * h->sk_MG), dim3(256), 0, h->stream, p); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
+#undef CASE
+    default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk_MBW);
+    }
     KCHK("g_gemm_small_kernel");
     hipLaunchKernelGGL(fold_small_kernel, dim3((d.Tl + 63) / 64, nsrc), dim3(256), 0, h->stream, h->sk_G, h->hslabs, d.Tl, d.K, d.L, d.K32, h->sk_JP, h->sk_TG);
     KCHK("fold_small_kernel");
@@ -672,7 +687,7 @@ static int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
 
 static int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullptr)
 {
-    if (h->small_k) return launch_transconv_small(h, nsrc, xt0);
+    if (h->sk_tc) return launch_transconv_small(h, nsrc, xt0);
     ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_OTHER);
     const CmfDims &d = h->d;
     TcParams p;
@@ -722,7 +737,13 @@ static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int n
         p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.L = d.L; p.J = h->sk_J; p.JP = h->sk_JP; p.MG = h->sk_MG; p.Tl = d.Tl;
         p.chunk_len = h->sk_chunk_len; p.nsrc = nsrc;
         const size_t lds = std::max<size_t>((size_t)4 * (d.K + 1) * SK_HS_STRIDE, 4 * 16 * 64) * sizeof(float);
-        hipLaunchKernelGGL(hxt_small_kernel, dim3(d.Np / 32, h->sk_ngroups, nsrc * h->sk_MG), dim3(256), lds, h->stream, p);
+        const dim3 grid((d.Np / 32) * h->sk_MG, h->sk_ngroups, nsrc);
+        switch (h->sk_MBW) {
+#define CASE(M_) case M_: hipLaunchKernelGGL((hxt_small_kernel<M_>), grid, dim3(256), lds, h->stream, p); break;
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
+#undef CASE
+        default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk_MBW);
+        }
         KCHK("hxt_small_kernel");
         CmfLossCarry carry{};
         if (take_carry && h->carry.partial) { // a loss reduction deferred by cmf_iterate rides on this launch
@@ -1169,8 +1190,9 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->small_k = value != 0 && h->small_k_ok;
-        h->tc_S = h->small_k ? 1 : h->tc_S_full;
-        h->tc_S1 = h->small_k ? 1 : h->tc_S1_full;
+        h->sk_tc = h->small_k && (h->sk_tc_ok || value == 2); // (2: the few-component C3 form whatever T is -- tests, measurements)
+        h->tc_S = h->sk_tc ? 1 : h->tc_S_full;
+        h->tc_S1 = h->sk_tc ? 1 : h->tc_S1_full;
         h->est_kind = 0;
         return CMF_OK;
     }

@@ -928,7 +928,7 @@ __global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p, int gx, int 
 // ceil(K / 2) k pairs that hold data instead of all 16 -- K = 5 issues 3/16 of the MFMAs of the padded k block.  Whole
 // tiles only (a launch of this size has no thin last round worth cutting up).
 template <int MODE, int NKP>
-__global__ __launch_bounds__(64, 3) void conv_small_kernel(ConvParams p, int gx)
+__global__ __launch_bounds__(64, (NKP <= 4 && (MODE <= 2 || MODE == 5)) ? 4 : 3) void conv_small_kernel(ConvParams p, int gx)
 {
     __shared__ __attribute__((aligned(16))) float Hs[32 * CONV3_STRIDE];
     const int b = blockIdx.x;

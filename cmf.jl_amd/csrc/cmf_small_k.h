@@ -4,7 +4,8 @@
 // The kernels of cmf_kernels.h put the component index k on a 32-wide MFMA axis (C2, C3) or walk a whole 32-row k block
 // per lag (C1), so K = 5 issues 32/5 = 6.4 times the useful MFMAs.  Here the MFMA axes carry the FLATTENED index
 // j = l*K + k of the J = L*K (lag, component) pairs -- the rows of the reference's H_unfold / W_unfold
-// (src/common.jl:133-142) -- padded to JP = roundup(J, 128): K = 5, L = 20 fills 100 of 128 rows.
+// (src/common.jl:133-142) -- in MG groups of MBW 32-row blocks (MBW <= 6 blocks per wave, chosen so that the padding
+// JP - J = 32 * MBW * MG - J is smallest): K = 5, L = 20 fills 100 of 128 rows, K = 16, L = 20 all of 320.
 //
 //   C1  est[t][n]    = sum_j Hu[j][t] Wf[j][n]          conv_small_kernel (cmf_kernels.h): conv3's tiles, ceil(K/2) k pairs per lag
 //   C2  out[j][n]    = sum_t Hu[j][t] X[t][n]           hxt_small_kernel: A = Hu from a lag-shifted LDS strip, B = X rows
@@ -15,7 +16,7 @@
 // shared with the general path.  v_mfma_f32_32x32x2_f32 throughout (operand maps: cmf_kernels.h).
 #pragma once
 
-#define SK_MBW 4          // 32-row m blocks per wave: a wave owns 128 consecutive j
+#define SK_MAXMBW 6       // 32-row m blocks per wave (template parameter MBW): a wave owns 32 * MBW consecutive rows j
 #define SK_SC 128         // time rows per staged H strip of hxt_small_kernel
 #define SK_HS_STRIDE 201  // floats between the k rows of the strip (>= SK_SC + 64 + 1, odd: the lag-shifted reads of a wave spread over the banks)
 #define SK_MAXL 64        // the strip holds SK_SC + L - 1 <= 191 columns
@@ -30,14 +31,24 @@ struct SkHxtParams {
     int nsrc;
 };
 
-// C2.  grid (Np/32, chunks/4, nsrc*MG), 256 threads.  A wave = one 32-column n block x 128 rows j x one time chunk.
+// C2.  grid ((Np/32) * MG, chunks/4, nsrc), 256 threads.  A wave = one 32-column n block x 32*MBW rows j x one time chunk.
+// Placement (speed only): workgroup b runs on XCD b % 8, so the MG row groups of one n block -- which read the same X rows --
+// are put 8 apart in blockIdx.x when the n blocks come in multiples of 8: the same L2 serves them.
+template <int MBW>
 __global__ __launch_bounds__(256) void hxt_small_kernel(SkHxtParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float sk_lds[]; // 4 strips of (K+1) rows; reused for the chunk reduction
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int nb = blockIdx.x;
-    const int src = blockIdx.z % p.nsrc, mg = blockIdx.z / p.nsrc;
+    int nb, mg;
+    if ((gridDim.x / p.MG) % 8 == 0) {
+        mg = (blockIdx.x >> 3) % p.MG;
+        nb = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * p.MG));
+    } else {
+        nb = blockIdx.x / p.MG;
+        mg = blockIdx.x % p.MG;
+    }
+    const int src = blockIdx.z;
     const int Np = p.Np, TP = p.TP, K = p.K, L = p.L;
     const float *X = src ? p.X1 : p.X0;
     const int strip = (K + 1) * SK_HS_STRIDE;
@@ -45,18 +56,18 @@ __global__ __launch_bounds__(256) void hxt_small_kernel(SkHxtParams p)
     const int tc0 = (blockIdx.y * 4 + wave) * p.chunk_len;
 
     // per-lane read base of each m block: row j -> (l, k): Hs[k][c + (L-1) - l] is H[t0 + c - l][k]; rows j >= J read the zero row K
-    int abase[SK_MBW];
+    int abase[MBW];
 #pragma unroll
-    for (int mb = 0; mb < SK_MBW; ++mb) {
-        const int j = mg * 128 + mb * 32 + i;
+    for (int mb = 0; mb < MBW; ++mb) {
+        const int j = (mg * MBW + mb) * 32 + i;
         const int l = j / K, k = j - l * K;
         abase[mb] = (j < p.J) ? k * SK_HS_STRIDE + (L - 1) - l + h : K * SK_HS_STRIDE + h;
     }
     for (int c = lane; c < SK_HS_STRIDE; c += 64) Hs[K * SK_HS_STRIDE + c] = 0.f;
 
-    f32x16 acc[SK_MBW];
+    f32x16 acc[MBW];
 #pragma unroll
-    for (int mb = 0; mb < SK_MBW; ++mb)
+    for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
 
@@ -86,11 +97,11 @@ __global__ __launch_bounds__(256) void hxt_small_kernel(SkHxtParams p)
             for (int u = 0; u < 8; ++u) bn[u] = cmf_bload(xr, xoff, (s0 + nx + 2 * u) * Np * 4);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                float a[SK_MBW];
+                float a[MBW];
 #pragma unroll
-                for (int mb = 0; mb < SK_MBW; ++mb) a[mb] = Hs[abase[mb] + r0 + 2 * u];
+                for (int mb = 0; mb < MBW; ++mb) a[mb] = Hs[abase[mb] + r0 + 2 * u];
 #pragma unroll
-                for (int mb = 0; mb < SK_MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[u], acc[mb], 0, 0, 0);
+                for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[u], acc[mb], 0, 0, 0);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) b[u] = bn[u];
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(256) void hxt_small_kernel(SkHxtParams p)
     float *red = sk_lds; // [4 waves][16][64]
     float *slab = p.slabs + ((size_t)blockIdx.y * p.nsrc + src) * p.JP * Np;
 #pragma unroll
-    for (int mb = 0; mb < SK_MBW; ++mb) {
+    for (int mb = 0; mb < MBW; ++mb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[mb][r];
         __syncthreads();
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(256) void hxt_small_kernel(SkHxtParams p)
             float sum = red[r * 64 + lane];
 #pragma unroll
             for (int v = 1; v < 4; ++v) sum += red[(v * 16 + r) * 64 + lane];
-            const int j = mg * 128 + mb * 32 + cmf_crow(r, h);
+            const int j = (mg * MBW + mb) * 32 + cmf_crow(r, h);
             slab[(size_t)j * Np + nb * 32 + i] = sum;
         }
         __syncthreads();
@@ -174,9 +185,10 @@ struct SkGemmParams {
     int nsrc;
 };
 
-// C3, first half: G[j][t'] = sum_n Wj[n][j] XT[n][t'].  grid (TG/128, nsrc*MG), 256 threads; a wave = 128 rows j x 32 columns t'.
+// C3, first half: G[j][t'] = sum_n Wj[n][j] XT[n][t'].  grid (TG/128, nsrc*MG), 256 threads; a wave = 32*MBW rows j x 32 columns t'.
 // Both operands are read from global memory directly in MFMA layout (128 contiguous bytes per half-wave; Wj is L2-resident),
 // eight n pairs ahead.
+template <int MBW>
 __global__ __launch_bounds__(256) void g_gemm_small_kernel(SkGemmParams p)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -185,21 +197,21 @@ __global__ __launch_bounds__(256) void g_gemm_small_kernel(SkGemmParams p)
     const int tb = (blockIdx.x * 4 + wave) * 32;
     if (tb >= p.TG) return;
     const float *XT = src ? p.XT1 : p.XT0;
-    const __amdgpu_buffer_rsrc_t ar = cmf_rsrc(p.Wj + mg * 128, ((size_t)(p.Np - 1) * p.JP + 128) * 4);
+    const __amdgpu_buffer_rsrc_t ar = cmf_rsrc(p.Wj + mg * MBW * 32, ((size_t)(p.Np - 1) * p.JP + MBW * 32) * 4);
     const __amdgpu_buffer_rsrc_t br = cmf_rsrc(XT + p.PADL + tb, ((size_t)(p.Np - 1) * p.TP + 32) * 4);
     const int aoff = (h * p.JP + i) * 4, boff = (h * p.TP + i) * 4;
-    f32x16 acc[SK_MBW];
+    f32x16 acc[MBW];
 #pragma unroll
-    for (int mb = 0; mb < SK_MBW; ++mb)
+    for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
     constexpr int U = 4; // n pairs per round
-    float a[U][SK_MBW], b[U], an[U][SK_MBW], bn[U];
+    float a[U][MBW], b[U], an[U][MBW], bn[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         b[u] = cmf_bload(br, boff, (2 * u) * p.TP * 4);
 #pragma unroll
-        for (int mb = 0; mb < SK_MBW; ++mb) a[u][mb] = cmf_bload(ar, aoff + mb * 128, (2 * u) * p.JP * 4);
+        for (int mb = 0; mb < MBW; ++mb) a[u][mb] = cmf_bload(ar, aoff + mb * 128, (2 * u) * p.JP * 4);
     }
     const int nrounds = (p.N2 + 2 * U - 1) / (2 * U); // (the rows a last round reads past N2 are zero padding of both operands)
     for (int rd = 0; rd < nrounds; ++rd) {
@@ -208,22 +220,22 @@ __global__ __launch_bounds__(256) void g_gemm_small_kernel(SkGemmParams p)
         for (int u = 0; u < U; ++u) {
             bn[u] = cmf_bload(br, boff, (nx + 2 * u) * p.TP * 4);
 #pragma unroll
-            for (int mb = 0; mb < SK_MBW; ++mb) an[u][mb] = cmf_bload(ar, aoff + mb * 128, (nx + 2 * u) * p.JP * 4);
+            for (int mb = 0; mb < MBW; ++mb) an[u][mb] = cmf_bload(ar, aoff + mb * 128, (nx + 2 * u) * p.JP * 4);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int mb = 0; mb < SK_MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mb], b[u], acc[mb], 0, 0, 0);
+            for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mb], b[u], acc[mb], 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             b[u] = bn[u];
 #pragma unroll
-            for (int mb = 0; mb < SK_MBW; ++mb) a[u][mb] = an[u][mb];
+            for (int mb = 0; mb < MBW; ++mb) a[u][mb] = an[u][mb];
         }
     }
-    float *G = p.G + ((size_t)src * p.JP + mg * 128) * p.TG + tb;
+    float *G = p.G + ((size_t)src * p.JP + mg * MBW * 32) * p.TG + tb;
 #pragma unroll
-    for (int mb = 0; mb < SK_MBW; ++mb)
+    for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) G[(size_t)(mb * 32 + cmf_crow(r, h)) * p.TG + i] = acc[mb][r];
 }

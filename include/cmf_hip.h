@@ -185,6 +185,11 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *   "conv_split" (default 1: the tiles at the end of the one-wave kernel's grid -- a thin last round, and from four
  *       rounds on three more tiles per CU -- are cut into 32 x 32 quarter or 16 x 16 sixteenth tiles; 4 = quarter tiles
  *       only; 0 = whole tiles only): kernel selection of tensor_conv, for measurements.
+ *   "small_k" (default 1 where it applies: K <= 16 and L <= 64): the few-component kernels (csrc/cmf_small_k.h) -- the three
+ *       contractions of mult.jl:28-34,44-55 with the FLATTENED (lag, component) index on the MFMA axes instead of K padded to 32:
+ *       the shapes the reference publishes on (README.md K = 5; figures/fast_bcd/synthetic_comparison.jl:58-64) run 2-3 times
+ *       faster.  tensor_transconv keeps the general kernel when T is too short to fill the chip with its GEMM form; 2 = the
+ *       few-component form whatever T is; 0 = the general kernels for every K.  Same arithmetic, another summation order.
  *   "hals_prepare": allocate the HALS rule's scratch and check its shape limits now (see the HALS entries).
  *   "hals_gram" (default 2): where the HALS sweeps' projections come from.  2 = P of the H phase as denomH - numH of the MU
  *       quantities (one conv launch less; H within the residual form's accuracy), G of the W phase contracted from the

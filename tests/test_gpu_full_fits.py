@@ -57,7 +57,7 @@ def run_mu_against_fixture(cmf, g, data, W0, H0, label, devices=None, options=()
             rule.set_option(name, value)
         loss = [rule.compute_loss()] + list(rule.iterate(snap, **reg))
         Ws, Hs = rule.download()
-        drift_snap = (frob_rel(Ws, g["W_snap"]), frob_rel(Hs[:, cols], g["H_snap_cols"]))
+        drift_snap = (frob_rel(Ws[:, ::int(g["snap_n_stride"]), :], g["W_snap"]), frob_rel(Hs[:, cols], g["H_snap_cols"]))
         loss += list(rule.iterate(n - snap, **reg))
         W, H = rule.download()
     finally:

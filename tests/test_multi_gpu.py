@@ -2,7 +2,8 @@
 
 Every test here is gated on cmf_device_count() >= n and skips otherwise, so on the one-GPU box of the round-end run they
 skip and on an N-GPU node they need nobody's help: the one-process group (cmf_create_multi: ncclCommInitAll, a stream per
-device, collectives inside ncclGroupStart/End) and the one-process-per-GPU group (cmf_create_shard + cmf_comm_init_rccl:
+device; an enqueue worker thread per device issuing its own RCCL calls, or the calling thread with grouped calls; the
+opt-in peer transport) and the one-process-per-GPU group (cmf_create_shard + cmf_comm_init_rccl:
 ncclCommInitRank with LOCAL_RANK = device) against the fp64 oracle and against the same partition on loopback shards of
 GPU 0, call by call and as a cmf_iterate batch, with the all-reduce overlap form off and on.
 """
@@ -71,6 +72,45 @@ def test_one_process_group_over_rccl(oracle, n, overlap):
         assert frob_rel(W, Wr) < 1e-4 and frob_rel(H, Hr) < 1e-4
         np.testing.assert_allclose(losses, ref[mode][0], rtol=1e-5)
         assert frob_rel(W, ref[mode][1]) < 1e-5 and frob_rel(H, ref[mode][2]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4, 8])
+@pytest.mark.parametrize("transport,threads,overlap", [("rccl", 0, False), ("rccl", 0, True), ("peer", 1, False), ("peer", 0, True), ("peer", 1, True)])
+def test_one_process_group_forms_on_distinct_devices(oracle, n, transport, threads, overlap):
+    """The forms of a one-process group that round 4 added, on DISTINCT devices: the calling thread enqueueing every shard
+    with grouped RCCL calls (enqueue_threads = 0; the default -- a worker thread per device, RCCL's one-thread-per-device mode --
+    is what test_one_process_group_over_rccl runs), the overlap form on its own communicators, and the peer transport (direct
+    xGMI reads / writes between event fences) whose sums are in rank order: bitwise the loopback partition on GPU 0."""
+    _need_devices(n)
+    import cmf_jl_amd as cmf
+    from cmf_jl_amd import _lib
+
+    N, T, K, L, iters = 130, 1800, 32, 20, 6
+    data, W0, H0, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, 1)
+    base = cmf.MultUpdate(data, W0, H0, devices=[0] * n)
+    base.set_overlap(overlap)
+    ref = _run(base, "iterate", iters, REG)
+    base.close()
+    rule = cmf.MultUpdate(data, W0, H0, devices=list(range(n)), transport=_lib.CMF_COMM_PEER if transport == "peer" else _lib.CMF_COMM_RCCL)
+    rule.set_option("enqueue_threads", threads)
+    rule.set_overlap(overlap)
+    info = rule.comm_info()
+    assert f"transport={transport}" in info and f"enqueue={'threads' if threads else 'caller'}" in info
+    if transport == "rccl" and overlap:
+        assert "lanes=2" in info
+    losses, W, H = _run(rule, "iterate", iters, REG)
+    ms, nbytes = rule.time_kernel("allreduce", reps=5)
+    rule.close()
+    print(f"{transport} n={n} threads={threads} overlap={overlap}: all-reduce of {nbytes / 1e6:.1f} MB alone {1e3 * ms:.0f} us")
+    np.testing.assert_allclose(losses, lr, rtol=1e-4)
+    assert frob_rel(W, Wr) < 1e-4 and frob_rel(H, Hr) < 1e-4
+    if transport == "peer":
+        np.testing.assert_array_equal(losses, ref[0])
+        np.testing.assert_array_equal(W, ref[1])
+        np.testing.assert_array_equal(H, ref[2])
+    else:
+        np.testing.assert_allclose(losses, ref[0], rtol=1e-5)
 
 
 @pytest.mark.gpu

@@ -40,7 +40,7 @@ def test_single_iteration_small_k_vs_oracle_and_general_kernels(cmf, oracle, N, 
     W0 = np.asfortranarray(rng.random((K, N, L)))
     H0 = np.asfortranarray(rng.random((K, T)))
     out = {}
-    for small in (1, 0):
+    for small in (2, 1, 0):  # 2: every few-component kernel; 1: the default (C3 on the general kernel when T is short); 0: none
         rule = cmf.MultUpdate(data, W0, H0)
         rule.set_option("small_k", small)
         l0 = rule.compute_loss()
@@ -53,10 +53,10 @@ def test_single_iteration_small_k_vs_oracle_and_general_kernels(cmf, oracle, N, 
     lo = [oracle.compute_loss(data, W, H)]
     oracle.update_motifs(orule, data, W, H, l1W=0.1, l2W=0.5)
     lo.append(oracle.update_feature_maps(orule, data, W, H, l1H=0.1, l2H=0.2))
-    for small in (1, 0):
+    for small in (2, 1, 0):
         np.testing.assert_allclose(out[small][0], lo, rtol=1e-5, err_msg=f"small_k={small}")
         assert frob_rel(out[small][1], W) < 1e-5 and frob_rel(out[small][2], H) < 1e-5, f"small_k={small}"
-    assert frob_rel(out[1][1], out[0][1]) < 5e-6 and frob_rel(out[1][2], out[0][2]) < 5e-6
+    assert frob_rel(out[2][1], out[0][1]) < 5e-6 and frob_rel(out[2][2], out[0][2]) < 5e-6
 
 
 @pytest.mark.parametrize("N,T,K,L,iters,reg", [(250, 4000, 5, 20, 40, 0), (500, 2000, 5, 10, 100, 1), (120, 900, 12, 25, 30, 1), (64, 700, 16, 8, 30, 0)])
@@ -68,6 +68,7 @@ def test_fit_small_k(cmf, oracle, N, T, K, L, iters, reg):
     kw = dict(l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2) if reg else dict(l1W=0.0, l2W=0.0, l1H=0.0, l2H=0.0)
     Wr, Hr, lr, _ = oracle.fit_mult(data, W0, H0, max_itr=iters, check_convergence=False, **kw)
     rule = cmf.MultUpdate(data, W0, H0)
+    rule.set_option("small_k", 2)
     lg = [rule.compute_loss()] + list(rule.iterate(iters, **kw))
     Wg, Hg = rule.download()
     rule.upload(W0, H0)

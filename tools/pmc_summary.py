@@ -47,7 +47,7 @@ def main():
             v["effective_clock_GHz"] = v["GRBM_GUI_ACTIVE"] / 8 / v["avg_duration_us_under_pmc"] / 1e3
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
             v["mfma_pipe_busy_frac"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (v["GRBM_GUI_ACTIVE"] / 8)
-    keep = {k: v for k, v in res.items() if any(s in k for s in ("conv", "hxt", "transconv"))}
+    keep = {k: v for k, v in res.items() if any(s in k for s in ("conv", "hxt", "transconv", "g_gemm", "fold_small", "slab_sum"))}
     json.dump(keep, open(out, "w"), indent=1, sort_keys=True)
     for k, v in sorted(keep.items()):
         print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in v.items() if a in
