@@ -1842,7 +1842,8 @@ static int hals_ensure(cmf_handle_s *h)
         const char *env = getenv("CMF_HALS_PERSIST"); // 0 = the stage pipeline (the tests compare the two)
         int P = 0;
         if (!(env && atoi(env) == 0) && !h->hals_h_general) {
-            P = d.K > 1 ? std::min(4, (h->n_cu - d.K) / (d.K - 1)) : 1;
+            static const int pmax = getenv("CMF_HALS_PMAX") && atoi(getenv("CMF_HALS_PMAX")) > 0 ? atoi(getenv("CMF_HALS_PMAX")) : 4; // measurement knob
+            P = d.K > 1 ? std::min(pmax, (h->n_cu - d.K) / (d.K - 1)) : 1;
             if (env && atoi(env) > 1) P = std::min(P, atoi(env));
             const size_t lds = ((size_t)(d.K - 1) * (E + 64 + 2 * (d.L - 1)) + 1024) * sizeof(float);
             if (P < 2 && d.K > 1) P = 0; // too many rows for the chip: stage pipeline
