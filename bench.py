@@ -352,6 +352,9 @@ def child_env(extra, rank=None, world=None, port=None):
     return env
 
 
+LIVE_CHILDREN = []  # children of the attempt in flight: ended too when the supervisor itself is told to stop
+
+
 def stop_children(procs):
     """End exactly the processes started here (each its own session: its process group goes with it)."""
     import signal
@@ -397,6 +400,7 @@ def run_attempt(cmds_envs, timeout, should_abort=None):
         outs.append(fo)
         errs.append(fe)
         procs.append(subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, start_new_session=True, cwd=ROOT))
+    LIVE_CHILDREN[:] = procs
     t0, reason = time.time(), None
     while True:
         codes = [p_.poll() for p_ in procs]
@@ -414,6 +418,7 @@ def run_attempt(cmds_envs, timeout, should_abort=None):
             break
         time.sleep(0.2)
     stop_children(procs)
+    LIVE_CHILDREN[:] = []
 
     def text(f):
         f.seek(0)
@@ -437,6 +442,14 @@ def run_attempt(cmds_envs, timeout, should_abort=None):
 
 def supervise(args, form):
     """See the module docstring ("First contact").  This process never initialises the GPU."""
+    import signal
+
+    def on_term(signum, _frame):  # a launcher that gives up on this rank must not leave its measurement child on the GPU
+        stop_children(list(LIVE_CHILDREN))
+        sys.exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, on_term)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1") or 1)
     store = None

@@ -363,6 +363,9 @@ static void plan(cmf_handle_s *h, int n_cu)
         // recordings: BASELINE configs[0] has T = 2000) the general kernel, which splits the reduction over n, is faster
         // (measured at configs[0]: 20 us against 39)
         h->sk_tc_ok = (int64_t)(h->sk_TG / 32) * h->sk_MG * 2 >= 2LL * n_cu;
+        // ... and its G matrix (2 * JP * TG floats) must stay a modest share of the device: long recordings with many (lag,
+        // component) pairs keep the general kernel (8.3 M columns x 320 rows would be 42 GB)
+        if ((double)2 * h->sk_JP * h->sk_TG * 4.0 > 8e9) h->sk_tc_ok = false;
     }
     // C1 (conv)
     h->conv_gx = d.Np / 128;
@@ -510,7 +513,7 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     if (h->small_k_ok) {
         TRYB(dalloc_zero(&h->sk_slabs, (size_t)h->sk_ngroups * 2 * h->sk_JP * d.Np));
         TRYB(dalloc_zero(&h->sk_Wj, (size_t)d.Np * h->sk_JP));
-        TRYB(dalloc_zero(&h->sk_G, (size_t)2 * h->sk_JP * h->sk_TG));
+        if (h->sk_tc_ok) TRYB(dalloc_zero(&h->sk_G, (size_t)2 * h->sk_JP * h->sk_TG));
         static const bool off = getenv("CMF_SMALL_K") && atoi(getenv("CMF_SMALL_K")) == 0; // measurement knob: the general kernels for every K
         h->small_k = !off;
         h->sk_tc = h->small_k && h->sk_tc_ok;
@@ -1191,6 +1194,11 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         HIPCHK(hipStreamSynchronize(h->stream));
         h->small_k = value != 0 && h->small_k_ok;
         h->sk_tc = h->small_k && (h->sk_tc_ok || value == 2); // (2: the few-component C3 form whatever T is -- tests, measurements)
+        if (h->sk_tc && !h->sk_G) { // (not allocated with the handle when the shape did not ask for it)
+            float *G = nullptr;
+            CMFTRY(dalloc_zero(&G, (size_t)2 * h->sk_JP * h->sk_TG));
+            h->sk_G = G;
+        }
         h->tc_S = h->sk_tc ? 1 : h->tc_S_full;
         h->tc_S1 = h->sk_tc ? 1 : h->tc_S1_full;
         h->est_kind = 0;

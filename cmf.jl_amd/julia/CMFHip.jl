@@ -50,7 +50,10 @@ between calls and are written back into the caller's arrays after every `update_
 
 With `devices` the rule is a T-sharded group on several GPUs of the node (`cmf_create_multi`): this one Julia
 task keeps making the same two calls per iteration (alternating.jl:52,54) and the library runs the sharded
-iteration -- one RCCL all-reduce of [numW | denomW] and one H-halo all-gather per iteration.
+iteration -- one RCCL all-reduce of [numW | denomW] and one H-halo all-gather per iteration, enqueued by one worker thread
+per GPU inside the library.  `transport` (include/cmf_hip.h: CMF_COMM_*): 0 = RCCL for distinct devices (default),
+4 = direct peer access over xGMI instead of RCCL (opt-in).  `set_option!(rule, "allreduce_overlap", 1)` etc. forward to
+cmf_set_option.
 """
 mutable struct HIPMultUpdate <: AbstractCFUpdate
     handle::Ptr{Cvoid}
@@ -60,7 +63,7 @@ end
 
 function HIPMultUpdate(data::Matrix{Float64}, W::Tensor{Float64}, H::Matrix{Float64};
                        device::Integer=parse(Int, get(ENV, "LOCAL_RANK", "0")), devices=nothing,
-                       sync_every_call::Bool=true)
+                       transport::Integer=0, sync_every_call::Bool=true)
     K, N, L = size(W)
     T = size(data, 2)
     size(data, 1) == N || throw(DimensionMismatch("data has $(size(data,1)) rows, W has N=$N"))
@@ -74,7 +77,7 @@ function HIPMultUpdate(data::Matrix{Float64}, W::Tensor{Float64}, H::Matrix{Floa
         devs = Cint[d for d in devices]
         check(ccall((:cmf_create_multi, LIBCMF), Cint,
                     (Ref{Ptr{Cvoid}}, Cint, Ptr{Cint}, Cint, Int64, Int64, Int64, Int64, Ptr{Float64}),
-                    h, length(devs), devs, 0, N, T, K, L, data))   # 0 = CMF_COMM_AUTO: RCCL for distinct devices
+                    h, length(devs), devs, transport, N, T, K, L, data))   # 0 = CMF_COMM_AUTO: RCCL for distinct devices
     end
     check(ccall((:cmf_set_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], W, H))
     ss = Ref{Float64}(0.0)
@@ -233,6 +236,10 @@ function iterate!(rule::HIPMultUpdate, n::Integer; l1W=0, l2W=0, l1H=0, l2H=0, e
                 rule.handle, n, eval_mode ? 1 : 0, l1W, l2W, l1H, l2H, losses, C_NULL))
     return losses
 end
+
+"Library option (include/cmf_hip.h, cmf_set_option): \"reuse_est\", \"gram\", \"small_k\", \"allreduce_overlap\", \"enqueue_threads\", ..."
+set_option!(rule::HIPMultUpdate, name::AbstractString, value::Integer) =
+    check(ccall((:cmf_set_option, LIBCMF), Cint, (Ptr{Cvoid}, Cstring, Cint), rule.handle, name, value))
 
 "Library identification: \"cmf_hip gfx950 <version> abi=<n> src=<digest of the sources it was built from>\"."
 version() = unsafe_string(ccall((:cmf_version, LIBCMF), Cstring, ()))

@@ -103,3 +103,28 @@ def test_launcher_form_ranks_agree_through_the_store(tmp_path, plan, want_attemp
         assert any(r[0] == "1" and r[4] == "transport=host" for r in runs)
     if want_attempts == 3:
         assert any(r[0] == "2" and r[5] == "backend=gloo" for r in runs)
+
+
+def test_supervisor_told_to_stop_takes_its_child_along(tmp_path):
+    """SIGTERM to the supervising process (a launcher giving up on the rank): the measurement child, which runs in a session of
+    its own, is ended too instead of being left behind on the GPU."""
+    import signal
+    import time
+
+    log = tmp_path / "log"
+    env = dict(os.environ, CMF_BENCH_FAKE_CHILD=FAKE, FAKE_PLAN="hang", FAKE_LOG=str(log))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    t_end = time.time() + 60
+    while not log.exists() and time.time() < t_end:  # the child has started (it logs, then hangs)
+        time.sleep(0.1)
+    assert log.exists()
+    kids = subprocess.run(["pgrep", "-P", str(p.pid)], capture_output=True, text=True).stdout.split()
+    assert kids
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=30)
+    assert p.returncode == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for k in kids:
+        assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z", k
