@@ -95,13 +95,26 @@ __global__ __launch_bounds__(256) void hxt_small_kernel(SkHxtParams p)
             const int nx = (r0 + 16 < rows) ? r0 + 16 : r0;
 #pragma unroll
             for (int u = 0; u < 8; ++u) bn[u] = cmf_bload(xr, xoff, (s0 + nx + 2 * u) * Np * 4);
+            // software-pipelined like conv2_lag: the LDS reads of step u+1 are issued ahead of the MFMAs of step u
+            float a[MBW];
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb) a[mb] = Hs[abase[mb] + r0];
+            __builtin_amdgcn_sched_group_barrier(0x100, MBW, 0);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                float a[MBW];
+                float an[MBW];
 #pragma unroll
-                for (int mb = 0; mb < MBW; ++mb) a[mb] = Hs[abase[mb] + r0 + 2 * u];
+                for (int mb = 0; mb < MBW; ++mb) an[mb] = 0.f;
+                if (u + 1 < 8) {
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb) an[mb] = Hs[abase[mb] + r0 + 2 * (u + 1)];
+                    __builtin_amdgcn_sched_group_barrier(0x100, MBW, 0);
+                }
 #pragma unroll
                 for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[u], acc[mb], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MBW, 0);
+#pragma unroll
+                for (int mb = 0; mb < MBW; ++mb) a[mb] = an[mb];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) b[u] = bn[u];
@@ -205,7 +218,8 @@ __global__ __launch_bounds__(256) void g_gemm_small_kernel(SkGemmParams p)
     for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    constexpr int U = 4; // n pairs per round
+    constexpr int U = MBW <= 4 ? 8 : 4; // n pairs per round: the operands of a round are loaded a round ahead, and a round must be long
+                                        // enough (16-32 MFMAs per wave) to cover a trip to L2 / HBM
     float a[U][MBW], b[U], an[U][MBW], bn[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
