@@ -352,10 +352,11 @@ static void plan(cmf_handle_s *h, int n_cu)
         h->sk_JP = 32 * h->sk_MBW * h->sk_MG;
         h->sk_TG = (int)rup(d.Tl + d.L - 1, 128);
         // C2: a wave = (n block, m group, source, time chunk).  Chunks of about 512 rows (four strips): many short waves, so that
-        // the rounds of the launch are short and its last one costs little -- but at least two waves per SIMD; chunks are whole
+        // the rounds of the launch are short and its last one costs little -- but at least as many waves as are resident; chunks are whole
         // 16-row rounds, 4 chunks per workgroup.
         const int64_t per_chunk = (int64_t)(d.Np / 32) * h->sk_MG * 2;
-        int64_t nch = std::max<int64_t>({(int64_t)4, (8LL * n_cu + per_chunk - 1) / per_chunk, (int64_t)(d.Tl + 511) / 512});
+        const int64_t waves_per_cu = 8; // (more, shorter chunks than two waves per SIMD were measured: no gain at T = 50000, a loss at T = 2000)
+        int64_t nch = std::max<int64_t>({(int64_t)4, (waves_per_cu * n_cu + per_chunk - 1) / per_chunk, (int64_t)(d.Tl + 511) / 512});
         h->sk_chunk_len = (int)std::max<int64_t>(16, rup((d.Tl + nch - 1) / nch, 16));
         nch = (d.Tl + h->sk_chunk_len - 1) / h->sk_chunk_len;
         h->sk_ngroups = (int)((nch + 3) / 4);

@@ -35,7 +35,7 @@ struct SkHxtParams {
 // Placement (speed only): workgroup b runs on XCD b % 8, so the MG row groups of one n block -- which read the same X rows --
 // are put 8 apart in blockIdx.x when the n blocks come in multiples of 8: the same L2 serves them.
 template <int MBW>
-__global__ __launch_bounds__(256) void hxt_small_kernel(SkHxtParams p)
+__global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void hxt_small_kernel(SkHxtParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float sk_lds[]; // 4 strips of (K+1) rows; reused for the chunk reduction
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -87,14 +87,16 @@ __global__ __launch_bounds__(256) void hxt_small_kernel(SkHxtParams p)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // 8 steps (16 time rows) per round: the X operands of a round are loaded a round ahead
-        float b[8], bn[8];
+        // 8 steps (16 time rows) per round; the X operands of a round are loaded a round ahead into the OTHER of two register
+        // sets (a copy from a "next" set into the current one would make every round wait for its own prefetch)
+        float b0[8], b1[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) b[u] = cmf_bload(xr, xoff, (s0 + 2 * u) * Np * 4);
-        for (int r0 = 0; r0 < rows; r0 += 16) {
+        for (int u = 0; u < 8; ++u) b0[u] = cmf_bload(xr, xoff, (s0 + 2 * u) * Np * 4);
+        auto round = [&](const float (&bc)[8], float (&bn)[8], int r0) {
             const int nx = (r0 + 16 < rows) ? r0 + 16 : r0;
 #pragma unroll
             for (int u = 0; u < 8; ++u) bn[u] = cmf_bload(xr, xoff, (s0 + nx + 2 * u) * Np * 4);
+            __builtin_amdgcn_sched_barrier(0); // keep the prefetch at the top of the round (the scheduler otherwise sinks it below the MFMAs)
             // software-pipelined like conv2_lag: the LDS reads of step u+1 are issued ahead of the MFMAs of step u
             float a[MBW];
 #pragma unroll
@@ -111,13 +113,15 @@ __global__ __launch_bounds__(256) void hxt_small_kernel(SkHxtParams p)
                     __builtin_amdgcn_sched_group_barrier(0x100, MBW, 0);
                 }
 #pragma unroll
-                for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], b[u], acc[mb], 0, 0, 0);
+                for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bc[u], acc[mb], 0, 0, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, MBW, 0);
 #pragma unroll
                 for (int mb = 0; mb < MBW; ++mb) a[mb] = an[mb];
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) b[u] = bn[u];
+        };
+        for (int r0 = 0; r0 < rows; r0 += 32) {
+            round(b0, b1, r0);
+            if (r0 + 16 < rows) round(b1, b0, r0 + 16);
         }
     }
 
@@ -202,7 +206,7 @@ struct SkGemmParams {
 // Both operands are read from global memory directly in MFMA layout (128 contiguous bytes per half-wave; Wj is L2-resident),
 // eight n pairs ahead.
 template <int MBW>
-__global__ __launch_bounds__(256) void g_gemm_small_kernel(SkGemmParams p)
+__global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_small_kernel(SkGemmParams p)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -218,17 +222,16 @@ __global__ __launch_bounds__(256) void g_gemm_small_kernel(SkGemmParams p)
     for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    constexpr int U = MBW <= 4 ? 8 : 4; // n pairs per round: the operands of a round are loaded a round ahead, and a round must be long
-                                        // enough (16-32 MFMAs per wave) to cover a trip to L2 / HBM
-    float a[U][MBW], b[U], an[U][MBW], bn[U];
+    constexpr int U = 4; // n pairs per round; the operands of a round are loaded a round ahead into the other of two register sets
+    float a0[U][MBW], b0[U], a1[U][MBW], b1[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        b[u] = cmf_bload(br, boff, (2 * u) * p.TP * 4);
+        b0[u] = cmf_bload(br, boff, (2 * u) * p.TP * 4);
 #pragma unroll
-        for (int mb = 0; mb < MBW; ++mb) a[u][mb] = cmf_bload(ar, aoff + mb * 128, (2 * u) * p.JP * 4);
+        for (int mb = 0; mb < MBW; ++mb) a0[u][mb] = cmf_bload(ar, aoff + mb * 128, (2 * u) * p.JP * 4);
     }
     const int nrounds = (p.N2 + 2 * U - 1) / (2 * U); // (the rows a last round reads past N2 are zero padding of both operands)
-    for (int rd = 0; rd < nrounds; ++rd) {
+    auto round = [&](const float (&ac)[U][MBW], const float (&bc)[U], float (&an)[U][MBW], float (&bn)[U], int rd) {
         const int nx = ((rd + 1 < nrounds) ? rd + 1 : rd) * 2 * U;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -236,16 +239,15 @@ __global__ __launch_bounds__(256) void g_gemm_small_kernel(SkGemmParams p)
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) an[u][mb] = cmf_bload(ar, aoff + mb * 128, (nx + 2 * u) * p.JP * 4);
         }
+        __builtin_amdgcn_sched_barrier(0); // the prefetch stays in front of the round's MFMAs
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mb], b[u], acc[mb], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            b[u] = bn[u];
-#pragma unroll
-            for (int mb = 0; mb < MBW; ++mb) a[u][mb] = an[u][mb];
-        }
+            for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][mb], bc[u], acc[mb], 0, 0, 0);
+    };
+    for (int rd = 0; rd < nrounds; rd += 2) {
+        round(a0, b0, a1, b1, rd);
+        if (rd + 1 < nrounds) round(a1, b1, a0, b0, rd + 1);
     }
     float *G = p.G + ((size_t)src * p.JP + mg * MBW * 32) * p.TG + tb;
 #pragma unroll
