@@ -345,6 +345,11 @@ static void group_stop_workers(cmf_group_s *g)
 
 static bool group_wants_workers(const cmf_group_s *g)
 {
+    // (tests: a worker for a ONE-shard RCCL group too, so that a one-GPU box can show a worker thread issuing the RCCL calls of a
+    // communicator another thread created -- honoured only with CMF_TEST_HOOKS=1)
+    if (g->one_process && g->sh.size() == 1 && g->transport == CMF_TR_RCCL)
+        if (const char *hooks = getenv("CMF_TEST_HOOKS"))
+            if (atoi(hooks) == 1 && getenv("CMF_TEST_FORCE_WORKERS") && atoi(getenv("CMF_TEST_FORCE_WORKERS")) == 1) return true;
     if (!g->one_process || g->sh.size() < 2) return false;
     return g->transport == CMF_TR_RCCL || g->transport == CMF_TR_PEER || (g->transport == CMF_TR_LOOPBACK && g->loop_ms);
 }

@@ -221,3 +221,36 @@ def test_worker_errors_reach_the_caller(cmf, oracle):
     ls = [rule.compute_loss()] + list(rule.iterate(3))
     rule.close()
     np.testing.assert_allclose(ls, lr, rtol=1e-4)
+
+
+def test_rccl_calls_from_an_enqueue_worker_thread(cmf, oracle):
+    """What a one-GPU box can show of the worker form on RCCL: a 1-device RCCL group whose single shard is enqueued by a
+    worker thread (test hook), i.e. ncclAllReduce / ncclAllGather -- on both lanes with the overlap form -- issued from a
+    thread other than the one that created the communicators, through the job queue, with the pinned loss words polled by
+    the caller: results bitwise those of the same group enqueued by the calling thread."""
+    from cmf_jl_amd import _lib
+
+    data, W0, H0, Wr, Hr, lr = oracle_fit(oracle, 70, 517, 32, 20, 6, 0)
+    kw = dict(l1W=0.0, l2W=0.0, l1H=0.0, l2H=0.0)
+    res = {}
+    for forced in (0, 1):
+        os.environ["CMF_TEST_HOOKS"] = "1"
+        os.environ["CMF_TEST_FORCE_WORKERS"] = str(forced)
+        try:
+            try:
+                rule = cmf.MultUpdate(data, W0, H0, devices=[0], transport=_lib.CMF_COMM_RCCL)
+            except cmf.CMFError as e:
+                pytest.skip(f"no RCCL communicator on this box: {e}")
+            assert _info(rule)["enqueue"] == ("threads" if forced else "caller")
+            for overlap in (False, True):
+                rule.upload(W0, H0)
+                rule.set_overlap(overlap)
+                res[(forced, overlap)] = _mu(rule, "iterate", 6, kw) + (_mu(rule, "calls", 2, kw)[0],)
+            rule.close()
+        finally:
+            os.environ.pop("CMF_TEST_HOOKS", None)
+            os.environ.pop("CMF_TEST_FORCE_WORKERS", None)
+    for overlap in (False, True):
+        np.testing.assert_allclose(res[(1, overlap)][0], lr, rtol=1e-4)
+        for a, b in zip(res[(0, overlap)], res[(1, overlap)]):
+            np.testing.assert_array_equal(a, b)
