@@ -461,9 +461,16 @@ def supervise(args, form):
         from torch.distributed import PrefixStore, TCPStore
 
         agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
-        base = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world_size=None if agent else world,
-                        is_master=(rank == 0 and not agent), timeout=timedelta(seconds=300), wait_for_workers=False)
-        store = PrefixStore(f"cmfbench/{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}/{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}/", base)
+        try:
+            base = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world_size=None if agent else world,
+                            is_master=(rank == 0 and not agent), timeout=timedelta(seconds=300), wait_for_workers=False)
+            store = PrefixStore(f"cmfbench/{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}/{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}/", base)
+            store.set(f"hello/{rank}", "1")
+            store.wait([f"hello/{r}" for r in range(world)])  # every supervising rank is there: from here on they walk the ladder together
+        except Exception as e:  # noqa: BLE001 - no store, no agreement: every rank measures in the started process, as before round 4
+            print(f"bench.py rank {rank}: the supervising ranks could not meet through the launcher's store ({e!r}); measuring in this process",
+                  file=sys.stderr, flush=True)
+            return False
     attempts, line = [], None
     for a, (label, child_form, extra) in enumerate(LADDER[form]):
         rec = {"form": label, "env": extra}
@@ -546,7 +553,8 @@ def main():
     if args.child:
         form = args.child
     elif args.gpus > 1 and os.environ.get("CMF_BENCH_SUPERVISE", "1") != "0":
-        return supervise(args, form)
+        if supervise(args, form) is not False:  # (it exits with the line printed; False: it could not set itself up)
+            return
     progress = {"phase": "start", "rank": int(os.environ.get("RANK", "0"))}
     try:
         measure(args, form, progress)
