@@ -1560,6 +1560,11 @@ int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transpor
     else if (transport == CMF_COMM_LOOPBACK || transport == CMF_COMM_LOOPBACK_STREAMS) tr = CMF_TR_LOOPBACK;
     else if (transport == CMF_COMM_PEER) tr = CMF_TR_PEER;
     else return fail(CMF_ERR_ARG, "unknown transport %d", transport);
+    // (tests, with CMF_TEST_HOOKS=1: every loopback group of the process as a peer-transport group -- the whole group suite then runs
+    // on the peer protocol, its event fences and its kernels)
+    if (tr == CMF_TR_LOOPBACK && all_same && getenv("CMF_TEST_HOOKS") && atoi(getenv("CMF_TEST_HOOKS")) == 1 &&
+        getenv("CMF_LOOPBACK_AS_PEER") && atoi(getenv("CMF_LOOPBACK_AS_PEER")) == 1)
+        tr = CMF_TR_PEER;
     if (tr == CMF_TR_RCCL && !distinct) return fail(CMF_ERR_ARG, "RCCL needs distinct devices (a device is listed twice)");
     if (tr == CMF_TR_LOOPBACK && !all_same) return fail(CMF_ERR_ARG, "the loopback transport needs all shards on one device; list distinct devices for RCCL");
     if (tr == CMF_TR_PEER && !(distinct || all_same)) return fail(CMF_ERR_ARG, "the peer transport takes distinct devices, or one device for every shard (rehearsal)");
