@@ -1092,7 +1092,7 @@ int cmf_get_counter(cmf_handle h, const char *name, int64_t *value)
         if (std::strcmp(name, "enqueue_iters") == 0) { *value = g->enqueue_iters; return CMF_OK; } // ... over this many iterations
         if (std::strcmp(name, "worker_ns") == 0) {                                                  // busiest enqueue worker: time inside its jobs
             int64_t m = 0;
-            for (const auto &w : g->workers) m = std::max<int64_t>(m, w->busy_ns.load());
+            for (const auto &w : g->pool.w) m = std::max<int64_t>(m, w->busy_ns.load());
             *value = m;
             return CMF_OK;
         }
@@ -1729,7 +1729,7 @@ int cmf_comm_info(cmf_handle h, char *buf, int64_t len)
         const cmf_group_s *g = h->group;
         std::string ranks;
         for (size_t i = 0; i < g->rank.size(); ++i) ranks += (i ? "," : "") + std::to_string(g->rank[i]) + "@dev" + std::to_string(g->sh[i]->device);
-        const char *enq = g->workers.empty() ? "caller" : "threads"; // who enqueues the shards (cmf_group.h)
+        const char *enq = g->pool.empty() ? "caller" : "threads"; // who enqueues the shards (cmf_group.h)
         const int lanes = (g->transport == CMF_TR_RCCL && g->comm2.size() == g->sh.size()) ? 2 : 1; // communicators per shard
         if (g->transport == CMF_TR_RCCL) {
             int v = 0;

@@ -32,10 +32,10 @@
 // grouped RCCL calls.  The phases are written once, as lists of per-shard segments and collectives (GroupStep), and run
 // either way.
 #pragma once
-#include <condition_variable>
 #include <dlfcn.h>
 #include <memory>
 #include <mutex>
+#include "cmf_workers.h"
 
 // The handful of RCCL types this file passes through function pointers, declared here (values as in rccl.h of ROCm 7:
 // the NCCL ABI these have had since NCCL 2.0) so that the library builds -- and loads -- on hosts without the RCCL
@@ -122,23 +122,8 @@ enum { CMF_TR_LOOPBACK = 0, CMF_TR_RCCL = 1, CMF_TR_CALLBACKS = 2, CMF_TR_PEER =
 enum { CMF_ERR_ECHO = -1000 }; // internal: a worker that gave up because ANOTHER shard's job failed (never crosses the ABI)
 
 // ---- enqueue workers ----------------------------------------------------------------------------------------------
-// One thread per local shard of a one-process group (see the file comment).  Single producer (the thread that calls the
-// ABI -- a handle is used by one host thread at a time), single consumer.  A worker spins briefly for the next job and
-// then sleeps on a condition variable, so an idle group costs nothing.
-struct GroupWorker {
-    static constexpr uint32_t QN = 64;
-    std::thread th;
-    std::function<int()> q[QN];
-    std::atomic<uint32_t> head{0}, tail{0}; // consumer / producer positions (free running)
-    std::atomic<bool> quit{false}, asleep{false};
-    std::mutex mu;
-    std::condition_variable cv;
-    std::atomic<int> rc{CMF_OK};            // code of the first failed job since the last join
-    std::string err;                        // its message (written before rc is published)
-    int device = 0;
-    std::atomic<int64_t> busy_ns{0};        // time spent inside jobs (cmf_get_counter "worker_ns": the largest of the group)
-};
-
+// One thread per local shard of a one-process group (see the file comment); the queue, the meeting point and the abort
+// protocol live in cmf_workers.h (free of HIP: stress-tested under ThreadSanitizer on the CPU).
 struct cmf_group_s {
     int nranks = 1;
     int transport = CMF_TR_LOOPBACK;
@@ -180,9 +165,7 @@ struct cmf_group_s {
     // peer transport: events of the stream fences around its kernels, [lane][before | after the kernel][shard]
     hipEvent_t ev_peer[2][2][CMF_MAX_LOCAL] = {};
     // enqueue workers (empty: the calling thread enqueues every shard itself)
-    std::vector<std::unique_ptr<GroupWorker>> workers;
-    std::atomic<bool> abort{false};      // a job failed: workers waiting at a barrier give up, the poll for the loss ends
-    std::atomic<int> bar_count{0}, bar_gen{0};
+    CmfWorkerPool pool;
     int64_t enqueue_ns = 0, enqueue_iters = 0; // cmf_iterate: time the calling thread spent enqueueing / posting, and the iterations it covers
     int force_inline = 0;                // > 0: step lists run on the calling thread although workers exist (GroupInline)
     bool failed = false;                 // a wait for the group ran out (or a collective reported an error): streams and communicators
@@ -211,88 +194,26 @@ static int group_use(cmf_handle_s *s)
     return CMF_OK;
 }
 
-// ---- worker queue ---------------------------------------------------------------------------------------------------
-static void worker_main(cmf_group_s *g, GroupWorker *w)
-{
-    (void)hipSetDevice(w->device);
-    unsigned idle = 0;
-    for (;;) {
-        const uint32_t h = w->head.load(std::memory_order_relaxed);
-        if (h == w->tail.load(std::memory_order_acquire)) {
-            if (w->quit.load(std::memory_order_acquire)) return;
-            if (++idle < 20000) { __builtin_ia32_pause(); continue; }
-            std::unique_lock<std::mutex> lock(w->mu); // nothing for a while (~0.2 ms): sleep until the producer posts
-            w->asleep.store(true, std::memory_order_seq_cst);
-            w->cv.wait(lock, [&] { return h != w->tail.load(std::memory_order_acquire) || w->quit.load(std::memory_order_acquire); });
-            w->asleep.store(false, std::memory_order_seq_cst);
-            idle = 0;
-            continue;
-        }
-        idle = 0;
-        std::function<int()> &job = w->q[h % GroupWorker::QN];
-        // after a failure the rest of the batch is skipped: its kernels would run on half-made inputs
-        if (w->rc.load(std::memory_order_relaxed) == CMF_OK && !g->abort.load(std::memory_order_acquire)) {
-            const auto tj = std::chrono::steady_clock::now();
-            const int rc = job();
-            w->busy_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tj).count(), std::memory_order_relaxed);
-            if (rc != CMF_OK) {
-                w->err = g_err;
-                w->rc.store(rc, std::memory_order_release);
-                g->abort.store(true, std::memory_order_release);
-            }
-        }
-        job = nullptr;
-        w->head.store(h + 1, std::memory_order_release);
-    }
-}
-
-static void worker_post(GroupWorker *w, std::function<int()> job)
-{
-    const uint32_t t = w->tail.load(std::memory_order_relaxed);
-    while (t - w->head.load(std::memory_order_acquire) >= GroupWorker::QN) __builtin_ia32_pause(); // queue full: the worker is behind
-    w->q[t % GroupWorker::QN] = std::move(job);
-    w->tail.store(t + 1, std::memory_order_seq_cst);
-    if (w->asleep.load(std::memory_order_seq_cst)) {
-        std::lock_guard<std::mutex> lock(w->mu);
-        w->cv.notify_one();
-    }
-}
-
+// ---- worker pool glue ------------------------------------------------------------------------------------------------
 // have the workers taken everything that was posted?  (the device may still be running it)
-static bool group_enqueued(const cmf_group_s *g)
-{
-    for (const auto &w : g->workers)
-        if (w->head.load(std::memory_order_acquire) != w->tail.load(std::memory_order_acquire)) return false;
-    return true;
-}
+static bool group_enqueued(const cmf_group_s *g) { return cmf_pool_idle(g->pool); }
 
 // Wait until every worker has run every posted job; the first failure (in shard order) becomes this thread's error.
 // Bounded like every wait of the group (CMF_WAIT_TIMEOUT_S): a worker that does not come back from a collective call ends
 // in CMF_ERR_COMM and a group marked failed, not in a hang.
 static int group_join(cmf_group_s *g)
 {
-    if (g->workers.empty()) return CMF_OK;
-    const auto t_begin = std::chrono::steady_clock::now();
-    for (unsigned spins = 1; !group_enqueued(g); ++spins) {
-        if ((spins & 0xFFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > wait_timeout_s()) {
-            g->failed = true;
-            g->abort.store(true, std::memory_order_release);
-            return fail(CMF_ERR_COMM, "an enqueue worker of the group did not return within %.0f s (CMF_WAIT_TIMEOUT_S): a collective call is blocked on the host", wait_timeout_s());
-        }
-        __builtin_ia32_pause();
+    if (g->pool.empty()) return CMF_OK;
+    if (!cmf_pool_wait(g->pool, wait_timeout_s())) {
+        g->failed = true;
+        return fail(CMF_ERR_COMM, "an enqueue worker of the group did not return within %.0f s (CMF_WAIT_TIMEOUT_S): a collective call is blocked on the host", wait_timeout_s());
     }
-    int rc = CMF_OK;
-    for (int pass = 0; pass < 2 && rc == CMF_OK; ++pass) // the failure itself, not its echoes from the shards that waited for it
-        for (auto &w : g->workers) {
-            const int r = w->rc.load(std::memory_order_acquire);
-            if (r != CMF_OK && rc == CMF_OK && (pass == 1 || r != CMF_ERR_ECHO)) {
-                rc = r == CMF_ERR_ECHO ? CMF_ERR_STATE : r;
-                g_err = w->err;
-            }
-        }
-    for (auto &w : g->workers) w->rc.store(CMF_OK, std::memory_order_relaxed);
-    g->abort.store(false, std::memory_order_release);
-    g->bar_count.store(0, std::memory_order_relaxed); // (workers that left a barrier on abort did not complete it)
+    std::string err;
+    int rc = cmf_pool_collect(g->pool, CMF_ERR_ECHO, &err);
+    if (rc != CMF_OK) {
+        g_err = err;
+        if (rc == CMF_ERR_ECHO) rc = CMF_ERR_STATE;
+    }
     if (rc == CMF_ERR_COMM) g->failed = true;
     return rc;
 }
@@ -310,38 +231,11 @@ struct GroupInline {
 // another stream is told to wait for it).  Gives up when any job of the group has failed.
 static int group_barrier(cmf_group_s *g)
 {
-    const int n = (int)g->workers.size();
-    const int gen = g->bar_gen.load(std::memory_order_acquire);
-    if (g->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
-        g->bar_count.store(0, std::memory_order_relaxed);
-        g->bar_gen.fetch_add(1, std::memory_order_acq_rel);
-        return CMF_OK;
-    }
-    while (g->bar_gen.load(std::memory_order_acquire) == gen) {
-        if (g->abort.load(std::memory_order_acquire)) return fail(CMF_ERR_ECHO, "another shard of the group failed");
-        __builtin_ia32_pause();
-    }
-    return CMF_OK;
+    const int rc = cmf_pool_barrier(g->pool, CMF_ERR_ECHO);
+    return rc == 0 ? CMF_OK : fail(CMF_ERR_ECHO, "another shard of the group failed");
 }
 
-static void group_stop_workers(cmf_group_s *g)
-{
-    for (auto &w : g->workers) {
-        w->quit.store(true, std::memory_order_release);
-        {
-            std::lock_guard<std::mutex> lock(w->mu);
-            w->cv.notify_one();
-        }
-        if (!w->th.joinable()) continue;
-        if (g->failed && w->head.load(std::memory_order_acquire) != w->tail.load(std::memory_order_acquire)) {
-            w->th.detach(); // stuck inside a call that will never return: the thread (and its queue) is abandoned, not joined
-            (void)w.release();
-            continue;
-        }
-        w->th.join();
-    }
-    g->workers.clear();
-}
+static void group_stop_workers(cmf_group_s *g) { cmf_pool_stop(g->pool, g->failed); }
 
 static bool group_wants_workers(const cmf_group_s *g)
 {
@@ -356,13 +250,10 @@ static bool group_wants_workers(const cmf_group_s *g)
 
 static int group_start_workers(cmf_group_s *g)
 {
-    if (!g->workers.empty() || !group_wants_workers(g)) return CMF_OK;
-    for (size_t i = 0; i < g->sh.size(); ++i) {
-        g->workers.emplace_back(new GroupWorker());
-        GroupWorker *w = g->workers.back().get();
-        w->device = g->sh[i]->device;
-        w->th = std::thread(worker_main, g, w);
-    }
+    if (!g->pool.empty() || !group_wants_workers(g)) return CMF_OK;
+    g->pool.on_start = [g](size_t i) { (void)hipSetDevice(g->sh[i]->device); };
+    g->pool.last_error = []() { return g_err; };
+    cmf_pool_start(g->pool, g->sh.size());
     return CMF_OK;
 }
 
@@ -731,7 +622,7 @@ static int group_run_shard(cmf_group_s *g, const StepList &st, size_t i)
 static int group_run(cmf_group_s *g, StepList &&st)
 {
     if (st.empty()) return CMF_OK;
-    if (g->workers.empty() || g->force_inline > 0) {
+    if (g->pool.empty() || g->force_inline > 0) {
         for (const GroupStep &s : st) {
             RoctxRange range(s.name);
             if (s.seg)
@@ -745,8 +636,8 @@ static int group_run(cmf_group_s *g, StepList &&st)
         return CMF_OK;
     }
     auto shared = std::make_shared<StepList>(std::move(st));
-    for (size_t i = 0; i < g->workers.size(); ++i)
-        worker_post(g->workers[i].get(), [g, shared, i]() { return group_run_shard(g, *shared, i); });
+    for (size_t i = 0; i < g->pool.size(); ++i)
+        cmf_pool_post(g->pool, i, [g, shared, i]() { return group_run_shard(g, *shared, i); });
     return CMF_OK;
 }
 
@@ -825,7 +716,7 @@ static int group_sync(cmf_group_s *g)
 // of hanging it.
 static int group_health(cmf_group_s *g)
 {
-    if (g->abort.load(std::memory_order_acquire)) {
+    if (g->pool.abort.load(std::memory_order_acquire)) {
         const int rc = group_join(g);
         return rc != CMF_OK ? rc : fail(CMF_ERR_STATE, "an enqueue worker of the group gave up");
     }
