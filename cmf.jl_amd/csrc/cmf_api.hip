@@ -208,6 +208,7 @@ struct cmf_handle_s {
     hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;
     // pipelined loss read-back of cmf_iterate (single handle): two pinned slots + events
     double *h_ring = nullptr;
+    bool dev_stamps = false;              // set by cmf_fit around its pipelined batch: time_hist from HIP timing events on the stream
     CmfLossCarry carry{};                 // a loss reduction waiting for the next W phase's slab sum (cmf_iterate only)
 };
 
@@ -961,6 +962,43 @@ static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel
     }
 }
 
+// HIP timing events behind the iterations of a pipelined batch (cmf_fit's time_hist): begin() records the start, mark(it) goes
+// behind iteration it's loss conv, finish() turns them into seconds since the start.  Inactive unless begin() was called.
+struct DevStamps {
+    std::vector<hipEvent_t> ev;
+    bool active = false;
+    int begin(hipStream_t st, int64_t n)
+    {
+        if (n < 1 || n > 8192) return CMF_OK; // (a batch that long keeps the host stamps)
+        ev.assign((size_t)n + 1, nullptr);
+        for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+        HIPCHK(hipEventRecord(ev[0], st));
+        active = true;
+        return CMF_OK;
+    }
+    int mark(hipStream_t st, int64_t it)
+    {
+        if (active) HIPCHK(hipEventRecord(ev[(size_t)it + 1], st));
+        return CMF_OK;
+    }
+    int finish(double *stamps, int64_t n)
+    {
+        if (!active) return CMF_OK;
+        HIPCHK(hipEventSynchronize(ev[(size_t)n]));
+        for (int64_t it = 0; it < n; ++it) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[(size_t)it + 1]));
+            stamps[it] = 1e-3 * (double)ms;
+        }
+        return CMF_OK;
+    }
+    ~DevStamps()
+    {
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+
 #include "cmf_group.h"
 
 // A loss reduction deferred by cmf_iterate (CmfLossCarry) only lives between two phases of that call.  If the call
@@ -1430,6 +1468,12 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
     if (!h->h_ring) // two slots: written by the loss reduction, polled by the host
         HIPCHK(hipHostMalloc(&h->h_ring, 2 * sizeof(double), hipHostMallocCoherent));
     volatile unsigned long long *ring = reinterpret_cast<volatile unsigned long long *>(h->h_ring);
+    // cmf_fit's time_hist: a timing event behind every iteration's loss conv, so that entry i is the DEVICE time at which
+    // iteration i was complete (what the reference's wall clock around the two rule calls measures, alternating.jl:49,57-58),
+    // not the moment its loss reached the host half an iteration later.  An event costs the device a few microseconds per
+    // iteration, so only cmf_fit asks for it; cmf_iterate's own stamps stay host times.
+    DevStamps ds;
+    if (h->dev_stamps && stamps) CMFTRY(ds.begin(h->stream, n));
     auto collect = [&](int64_t it) -> int {
         const int slot = (int)(it & 1);
         CMFTRY(wait_words<unsigned long long>(h->stream, ring + slot, 1, CMF_SENTINEL64));
@@ -1462,10 +1506,11 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
         } else {
             CMFTRY(loss_partial_impl(h, nullptr, false, h->h_ring + slot)); // the reduction stores the sum into the pinned slot itself
         }
+        CMFTRY(ds.mark(h->stream, it));
         if (it > 0) CMFTRY(collect(it - 1));
     }
     if (n > 0) CMFTRY(collect(n - 1));
-    return CMF_OK;
+    return ds.finish(stamps, n);
 }
 
 int cmf_iterate(cmf_handle h, int64_t n_iter, int eval_mode, double l1W, double l2W, double l1H, double l2H,
@@ -1509,7 +1554,11 @@ int cmf_fit(cmf_handle h, int64_t max_itr, double max_time, int check_convergenc
     if (!check_convergence && std::isinf(max_time) && max_time > 0) {
         // neither stop test can fire (:45, :63-66): exactly max_itr iterations, run as one pipelined batch;
         // time_hist[i] = the moment the loss of iteration i reached the host
-        CMFTRY(cmf_iterate(h, max_itr, eval_mode, l1W, l2W, l1H, l2H, loss_hist + 1, time_hist + 1));
+        cmf_handle_s *hs = h->group ? h->group->sh[0] : h; // (a group's times are shard 0's)
+        hs->dev_stamps = true;
+        const int rc_it = cmf_iterate(h, max_itr, eval_mode, l1W, l2W, l1H, l2H, loss_hist + 1, time_hist + 1);
+        hs->dev_stamps = false;
+        CMFTRY(rc_it);
         *n_hist = max_itr + 1;
         return CMF_OK;
     }

@@ -947,12 +947,21 @@ static int group_iterate(cmf_group_s *g, int64_t n, int eval_mode, double l1W, d
     cmf_handle_s *s0 = g->sh[0];
     const std::function<int()> health = [g]() { return group_health(g); };
     const std::function<bool()> enqueued = [g]() { return group_enqueued(g); };
+    // cmf_fit's time_hist: timing events on shard 0's stream behind every iteration's loss conv (DevStamps, cmf_api.hip);
+    // whoever enqueues shard 0 records them
+    auto ds = std::make_shared<DevStamps>();
+    if (s0->dev_stamps && stamps) {
+        CMFTRY(group_join(g));
+        CMFTRY(group_use(s0));
+        CMFTRY(ds->begin(s0->stream, n));
+    }
     for (int64_t it = 0; it < n; ++it) {
         const bool last = (it + 1 == n);
         const auto t_enq = std::chrono::steady_clock::now();
         StepList st;
         build_update_motifs(g, st, l1W, l2W, it > 0 ? (int)((it - 1) & 1) : -1);
         build_update_feature_maps(g, st, l1H, l2H, !last);
+        if (ds->active) step_seg(st, "cmf:iteration stamp", [g, ds, it](size_t i) { return i == 0 ? ds->mark(g->sh[0]->stream, it) : CMF_OK; });
         double ss = 0.0;
         if (last) CMFTRY(group_loss_now(g, std::move(st), &ss));
         else {
@@ -977,7 +986,9 @@ static int group_iterate(cmf_group_s *g, int64_t n, int eval_mode, double l1W, d
             if (stamps) stamps[it] = now();
         }
     }
-    return group_join(g);
+    CMFTRY(group_join(g));
+    CMFTRY(group_use(s0));
+    return ds->finish(stamps, n);
 }
 
 static int group_set_factors(cmf_group_s *g, const double *W, const double *H)

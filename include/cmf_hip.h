@@ -235,9 +235,10 @@ int cmf_compute_loss(cmf_handle h, double *loss);
  * Valid on single-GPU and group handles (on a group with a finite max_time every rank follows rank 0's clock).
  * time_hist: with a stop test armed (check_convergence != 0 or a finite max_time) entry i is the reference's cumulative
  * wall-clock time around the two rule calls of iteration i (alternating.jl:49,57-58).  When neither test can fire the loop runs
- * as ONE pipelined cmf_iterate batch and entry i is the moment iteration i's loss reached the host -- about half an iteration
- * after that iteration's kernels finished, because the loss rides on the next W phase; the differences between consecutive
- * entries are still the per-iteration durations in steady state, and the last entry is the batch's total time. */
+ * as ONE pipelined cmf_iterate batch (the host never stalls the device between iterations) and entry i is the DEVICE time,
+ * from the start of the batch, at which iteration i was complete -- a HIP timing event recorded behind that iteration's loss
+ * conv (shard 0's stream on a group) -- i.e. the same quantity without the host in it.  (Batches of more than 8192 iterations
+ * keep host times: the moment each loss reached the host, half an iteration late.) */
 int cmf_fit(cmf_handle h, int64_t max_itr, double max_time,
             int check_convergence, int64_t patience, double tol, int eval_mode,
             double l1W, double l2W, double l1H, double l2H,

@@ -174,3 +174,39 @@ def test_pgd_ignores_readme_regularisers_like_the_reference(cmf, oracle):
     np.testing.assert_array_equal(a.W, b.W)
     Wr, Hr, lr, _ = oracle.fit_pgd(data, W0, H0, max_itr=6)
     np.testing.assert_allclose(a.loss_hist, lr, rtol=REL_LOSS)
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0, 0]])
+def test_cmf_fit_time_hist_is_device_time_per_iteration(cmf, oracle, devices):
+    """alternating.jl:49,57-58: time_hist[i] is the cumulative time of the first i iterations.  cmf_fit's pipelined batch (no stop
+    test armed) never stalls the device, so it takes the times from HIP timing events behind every iteration's loss conv: the
+    entries start at 0, grow strictly, their steps are the per-iteration DEVICE durations -- uniform in steady state and equal
+    to what a pipelined cmf_iterate batch of the same length needs per iteration -- and the losses are those of the loop with a
+    stop test armed (the reference's own structure, one synchronous call pair per iteration)."""
+    import time
+
+    N, T, K, L, iters = 600, 20000, 32, 20, 40
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=20, seed=1234)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=0)
+    rule = cmf.MultUpdate(data, W0, H0, devices=devices)
+    rule.iterate(3)
+    rule.upload(W0, H0)
+    lh, th, early = rule.fit_native(iters, np.inf, False, 3, 1e-4, False)   # pipelined batch: device times
+    rule.upload(W0, H0)
+    lh2, th2, _ = rule.fit_native(iters, 1e9, False, 3, 1e-4, False)        # a finite max_time arms the clock test: synchronous loop
+    rule.upload(W0, H0)
+    rule.synchronize()
+    t0 = time.perf_counter()
+    rule.iterate(iters)
+    rule.synchronize()
+    per_iter = (time.perf_counter() - t0) / iters
+    rule.close()
+    np.testing.assert_array_equal(lh, lh2)
+    assert th[0] == 0.0 and len(th) == iters + 1 and np.all(np.diff(th) > 0)
+    steps = np.diff(th)[1:]
+    assert steps.max() < 1.25 * np.median(steps)                         # steady: no host hiccup can enter a device time
+    assert abs(np.median(steps) - per_iter) < 0.1 * per_iter              # = the pipelined iteration time
+    assert abs(th[-1] - iters * per_iter) < 0.1 * iters * per_iter
+    assert np.median(np.diff(th2)) >= 0.95 * np.median(steps)             # the synchronous loop pays a host round trip per iteration on top
+    print(f"devices={devices}: pipelined {1e3 * per_iter:.3f} ms/iter, time_hist steps median {1e3 * np.median(steps):.3f} ms "
+          f"(max {1e3 * steps.max():.3f}), synchronous loop {1e3 * np.median(np.diff(th2)):.3f} ms")
