@@ -496,6 +496,10 @@ def supervise(args, form):
                     return False
 
             ok, reason, out0, errs = run_attempt([(child_command(args, "ranks"), env)], args.attempt_timeout, should_abort)
+            if ok and rank == 0:  # rank 0's outcome includes "its child printed a line with a value": all ranks must agree on THAT
+                got0 = last_json_line(out0)
+                if got0 is None or got0.get("value") is None:
+                    ok, reason = False, "no JSON line with a value on the child's stdout"
             if not ok:
                 store.set(f"failed{a}", "1")
             if not ok and (reason or "").startswith("FATAL"):

@@ -72,7 +72,7 @@ def test_everything_failed_still_prints_one_line():
     assert rec["attempts"][2]["child_line"]["comm"] == {"transport": "rccl"}
 
 
-@pytest.mark.parametrize("plan,want_attempts", [("ok", 1), ("fail@1,ok", 2), ("hang@0,fail@1,ok", 3)])
+@pytest.mark.parametrize("plan,want_attempts", [("ok", 1), ("fail@1,ok", 2), ("hang@0,fail@1,ok", 3), ("noline@0,ok", 2)])
 def test_launcher_form_ranks_agree_through_the_store(tmp_path, plan, want_attempts):
     """WORLD_SIZE == --gpus: every started process supervises its own child; a failure on ANY rank sends ALL of them to
     the next form (the healthy ranks' children are ended early through the store), and only rank 0 prints."""
