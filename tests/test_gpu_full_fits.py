@@ -93,6 +93,19 @@ def test_full_default_fit_at_the_metric_size(cmf, oracle, name):
     run_mu_against_fixture(cmf, g, data, W0, H0, name + " 8 shards", devices=[0] * 8)
 
 
+def test_config3_against_the_oracle(cmf, oracle):
+    """BASELINE.json configs[2] -- N=2000, T=400000, K=32, L=20, "T-sharded across 8xMI355X" -- against the fp64 oracle's committed
+    fit (6 iterations; the oracle needs minutes for each at this size): the whole problem on this one GPU, and as the 8 shards of
+    50000 columns the 8-GPU run gives one to each device (loopback transport), W, H, loss_hist within 1e-4."""
+    path = os.path.join(GOLDEN, "fit_config3_6.npz")
+    if not os.path.exists(path):
+        pytest.fail(f"{path} is missing: run tests/golden/make_golden_full.py mu_c3")
+    g = np.load(path)
+    data, W0, H0, _ = fixture_inputs(oracle, g)
+    run_mu_against_fixture(cmf, g, data, W0, H0, "fit_config3_6 unsharded")
+    run_mu_against_fixture(cmf, g, data, W0, H0, "fit_config3_6 8 shards", devices=[0] * 8)
+
+
 def test_hals_ten_iterations_at_config5_n_k_l(cmf, oracle):
     """BASELINE.json configs[4]'s N, K, L (2000, 32, 20) on T = 5000 columns, 10 HALS iterations (hals.jl:90-154) against
     the oracle's committed fit: the north star's 1e-4 on W, H, loss_hist, and the oracle's pattern of exact zeros."""
