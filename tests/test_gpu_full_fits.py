@@ -225,3 +225,32 @@ def test_cmf_fit_time_hist_is_device_time_per_iteration(cmf, oracle, devices):
     assert np.median(np.diff(th2)) >= 0.95 * np.median(steps)             # the synchronous loop pays a host round trip per iteration on top
     print(f"devices={devices}: pipelined {1e3 * per_iter:.3f} ms/iter, time_hist steps median {1e3 * np.median(steps):.3f} ms "
           f"(max {1e3 * steps.max():.3f}), synchronous loop {1e3 * np.median(np.diff(th2)):.3f} ms")
+
+
+@pytest.mark.parametrize("devices", [None, [0] * 8])
+def test_pgd_at_config2_size(cmf, oracle, devices):
+    """The PGD rule (pgd.jl:158-255) at BASELINE config 2's size, 12 iterations against the oracle's committed fit --
+    on one handle and as the 8-shard group: W, H within 1e-4, loss_hist within 1e-4 (i.e. every accept / reject decision of
+    the step-size state machine is the oracle's), and the step sizes at the end equal the oracle's."""
+    path = os.path.join(GOLDEN, "fit_pgd_config2_12.npz")
+    if not os.path.exists(path):
+        pytest.fail(f"{path} is missing: run tests/golden/make_golden_full.py pgd")
+    g = np.load(path)
+    data, W0, H0, (N, T, K, L) = fixture_inputs(oracle, g)
+    n, cols = int(g["max_itr"]), g["H_cols"]
+    rule = cmf.PGDUpdate(data, W0, H0, devices=devices)
+    loss = [rule.compute_loss()]
+    for _ in range(n):
+        rule.update_motifs()
+        loss.append(rule.update_feature_maps())
+    W, H = rule.download()
+    steps = rule.steps
+    rule.close()
+    lr = g["loss_hist"]
+    relW, relH = frob_rel(W, g["W"]), frob_rel(H[:, cols], g["H_at_cols"])
+    print(f"PGD devices={'8 shards' if devices else None}: after {n} iterations relW {relW:.2e} relH {relH:.2e} "
+          f"max rel loss {float(np.max(np.abs(np.asarray(loss) - lr) / lr)):.2e} (loss {lr[0]:.4f} -> {lr[-1]:.4f}), steps {steps}")
+    np.testing.assert_allclose(loss, lr, rtol=REL_LOSS)
+    assert relW < REL_FACTORS and relH < REL_FACTORS
+    np.testing.assert_allclose(np.linalg.norm(H), float(g["H_norm"]), rtol=REL_FACTORS)
+    np.testing.assert_allclose(steps, g["steps"], rtol=1e-12)
