@@ -91,6 +91,10 @@ def test_full_default_fit_at_the_metric_size(cmf, oracle, name):
     run_mu_against_fixture(cmf, g, data, W0, H0, name + " reuse_est=1")
     run_mu_against_fixture(cmf, g, data, W0, H0, name + " reuse_est=0", options=(("reuse_est", 0),))
     run_mu_against_fixture(cmf, g, data, W0, H0, name + " 8 shards", devices=[0] * 8)
+    # the optional Gram forms over the same whole fit: exact rewritings, so the same bar
+    run_mu_against_fixture(cmf, g, data, W0, H0, name + " gram=1", options=(("gram", 1),))
+    run_mu_against_fixture(cmf, g, data, W0, H0, name + " gram=2", options=(("gram", 2),))
+    run_mu_against_fixture(cmf, g, data, W0, H0, name + " gram=1, 8 shards, overlap", devices=[0] * 8, options=(("gram", 1), ("allreduce_overlap", 1)))
 
 
 def test_config3_against_the_oracle(cmf, oracle):
