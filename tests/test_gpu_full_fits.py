@@ -33,12 +33,21 @@ def frob_rel(a, b):
     return np.linalg.norm(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) / max(np.linalg.norm(b), 1e-300)
 
 
+_INPUTS = {}  # the config-2 inputs serve several fixtures: generated once per test module (10 s of C oracle each time)
+
+
 def fixture_inputs(oracle, g):
     """The fixture's inputs, regenerated: oracle C restatement of gen_synthetic (datasets/synthetic.jl:29-61) and
     init_rand (model.jl:113-125) with the recorded seeds, checked against the recorded checksums."""
     N, T, K, L = (int(g[k]) for k in ("N", "T", "K", "L"))
-    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, seed=int(g["data_seed"]))
-    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=int(g["init_seed"]))
+    key = (N, T, K, L, int(g["data_seed"]), int(g["init_seed"]))
+    if key not in _INPUTS:
+        data, _, _ = oracle.c_gen_synthetic(N=N, T=T, seed=int(g["data_seed"]))
+        W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=int(g["init_seed"]))
+        if N * T > 2e8:  # (config 3's 6.4 GB are used once)
+            _INPUTS.clear()
+        _INPUTS[key] = (data, W0, H0)
+    data, W0, H0 = _INPUTS[key]
     np.testing.assert_allclose(float(data.sum()), float(g["data_sum"]), rtol=1e-12)
     np.testing.assert_allclose(float(np.vdot(data, data)), float(g["data_sumsq"]), rtol=1e-12)
     np.testing.assert_allclose(float(W0.sum()), float(g["W0_sum"]), rtol=1e-11)
