@@ -287,14 +287,17 @@ def test_sharded_processes_host_callbacks(oracle, tmp_path, world, N, T, K, L, r
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("backend,mode", [("nccl", "calls"), ("gloo", "iterate")])
-def test_sharded_process_rccl_single_rank(oracle, tmp_path, backend, mode):
+@pytest.mark.parametrize("backend,mode,overlap", [("nccl", "calls", False), ("gloo", "iterate", False), ("gloo", "iterate", True), ("nccl", "calls", True)])
+def test_sharded_process_rccl_single_rank(oracle, tmp_path, backend, mode, overlap):
     """cmf_comm_unique_id + cmf_comm_init_rccl (ncclCommInitRank): the id travels through the torch.distributed group
-    (its RCCL backend or gloo -- it is only the rendezvous), the collectives are the library's own RCCL calls."""
+    (its RCCL backend or gloo -- it is only the rendezvous), the collectives are the library's own RCCL calls.  With the overlap
+    form the front end hands a SECOND id over the same way (cmf_comm_init_overlap): the communication stream's own communicator
+    (lanes=2 in cmf_comm_info)."""
     N, T, K, L, iters = 130, 900, 32, 20, 6
     out = str(tmp_path / "res.npz")
-    got = run_ranks(1, "hip", out, N, T, K, L, iters, 0, backend=backend, mode=mode, transport="rccl")
+    got = run_ranks(1, "hip", out, N, T, K, L, iters, 0, backend=backend, mode=mode, transport="rccl", overlap=overlap)
     assert "transport=rccl" in str(got["info"])
+    assert ("lanes=2" in str(got["info"])) == overlap and (f"overlap={int(overlap)}" in str(got["info"]))
     _, _, _, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, 0)
     np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
     assert frob_rel(got["W"], Wr) < 1e-4
