@@ -293,7 +293,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the no-reuse / Gram-form / other-config side measurements (profiling runs: keeps one launch shape per kernel)")
     ap.add_argument("--no-config3", action="store_true", help="skip config 3 (T=400000 on one GPU) in other_configs")
-    ap.add_argument("--attempt-timeout", type=float, default=float(os.environ.get("CMF_BENCH_ATTEMPT_TIMEOUT", "420")),
+    ap.add_argument("--attempt-timeout", type=float, default=float(os.environ.get("CMF_BENCH_ATTEMPT_TIMEOUT", "300")),
                     help="--gpus N > 1: seconds one attempt (one form of the ladder, in its own child process) may take")
     ap.add_argument("--child", default="", help=argparse.SUPPRESS)  # set by the supervisor: this process IS the measurement
     return ap.parse_args(argv)
