@@ -207,10 +207,25 @@ def other_configs(cmf, rule, data, W0, H0, N, T, K, L, with_config3, device):
             ls = hals_steps(hr, 5, zero)
             dt = (time.perf_counter() - t0) / 5
             spans = {nm: hr.kernel_times(nm) for nm in ("hals_h_pipeline", "hals_w_sweep")}
+            # the MFMA contraction launches of a HALS iteration (two thirds of it), in-loop HIP event times like the MU table:
+            # each is ONE contraction of 2*K*N*S flop (residual conv = tensor_conv + (est - data) + loss, hals.jl:41;
+            # hxt on the residual = G of the W sweep, hals.jl:104-110; transconv(W, data) = half of P, hals.jl:139-152)
+            f1 = 2.0 * K * N * (L * T - L * (L - 1) / 2)
+            hk = {}
+            for nm, fl in (("conv_resid", f1), ("hxt_resid", f1), ("transconv_1src", f1), ("hxt_hh", 2.0 * K * 32 * ((K + 31) // 32) * (L * T - L * (L - 1) / 2)),
+                           ("gram_denom_h", None), ("gram_tables", None), ("hals_h_pipeline", None), ("hals_w_sweep", None)):
+                kms, n_ = hr.kernel_times(nm)
+                if n_:
+                    hk[nm] = {"avg_ms": kms, "launches": n_, "share_of_step": kms * (n_ / 5.0) / (1e3 * dt)}
+                    if fl:
+                        hk[nm].update(flops_per_launch=fl, tflops=fl / kms / 1e9, frac=fl / kms / 1e9 / PEAK_FP32_MFMA_TFLOPS)
             hr.set_option("profile", 0)
             res["configs[4]"] = {"workload": "N=2000 T=50000 K=32 L=20 alg=:hals", "steps": 5, "warmup": 1, "ms_per_step": 1e3 * dt,
                                  "iters_per_s": 1.0 / dt, "loss_last": float(ls[-1]), "metric": "HALS iters/sec",
                                  "pipeline_reruns": hr.counter("hals_pipeline_reruns"),
+                                 "kernels": hk,
+                                 "kernels_note": "in-loop HIP event pairs (option profile) over the 5 timed iterations; frac = flops_per_launch / "
+                                                 "avg_ms / 157.3 TFLOP/s for the contraction launches; the two sweeps are dependency-latency bound (roofline block)",
                                  "roofline": hals_roofline(T, K, L, spans, 1e3 * dt)}
         finally:
             hr.close()
@@ -257,6 +272,50 @@ def other_configs(cmf, rule, data, W0, H0, N, T, K, L, with_config3, device):
         except Exception as e:  # noqa: BLE001
             res[key] = {"error": repr(e)}
 
+    # What one rank of the T-sharded run computes per iteration, measured on this one GPU: the same problem with T / 2, T / 4,
+    # T / 8 columns (a shard's kernels; its halo columns and the collectives are not in it), >= 200 back-to-back iterations
+    # each, in the reference formulation and in the Gram form (option gram = 1).  `speedup_before_communication`
+    # = the full problem's ms_per_step / the shard's: the ceiling the 8-GPU strong-scaling figure starts from.
+    def shard(div):
+        Ts = T // div
+        rec = {"T_shard": Ts, "steps": 200, "warmup": 5}
+        try:
+            d_ = cmf.gen_synthetic(N=N, T=Ts, seed=1234, device=device)
+            W_, H_ = cmf.init_rand(d_, L=L, K=K, seed=0, device=device)
+            r_ = cmf.MultUpdate(d_, W_, H_, device=device)
+            try:
+                f1_ = 2.0 * K * N * (L * Ts - L * (L - 1) / 2)
+                for gram in (0, 1):
+                    r_.upload(W_, H_)
+                    r_.set_option("gram", gram)
+                    r_.iterate(5, **zero)
+                    r_.synchronize()
+                    if not gram:
+                        r_.set_option("profile", 4)
+                    t0 = time.perf_counter()
+                    r_.iterate(200, **zero)
+                    r_.synchronize()
+                    dt_ = (time.perf_counter() - t0) / 200
+                    if gram:
+                        rec["ms_per_step_gram"] = 1e3 * dt_
+                    else:
+                        ks = {}
+                        for nm in ("conv_t", "conv_loss_store", "hxt", "transconv"):
+                            kms, n_ = r_.kernel_times(nm)
+                            if n_:
+                                fl_ = f1_ * (2.0 if nm in ("hxt", "transconv") else 1.0)
+                                ks[nm] = {"avg_ms": kms, "launches": n_, "frac": fl_ / kms / 1e9 / PEAK_FP32_MFMA_TFLOPS}
+                        r_.set_option("profile", 0)
+                        rec.update(ms_per_step=1e3 * dt_, kernels=ks, whole_iteration_mfma_frac=6.0 * f1_ / dt_ / (PEAK_FP32_MFMA_TFLOPS * 1e12))
+                r_.set_option("gram", 0)
+            finally:
+                r_.close()
+        except Exception as e:  # noqa: BLE001
+            rec["error"] = repr(e)
+        return rec
+
+    res["shards"] = {"what": "per-rank compute of the T-sharded run on ONE GPU (T/2, T/4, T/8 columns of config 2; no halo, no collective)",
+                     "T/2": shard(2), "T/4": shard(4), "T/8": shard(8)}
     few_components("reference_protocol_shape", 250, 50000, 5, 20, "figures/fast_bcd/synthetic_comparison.jl:58-64")
     few_components("configs[0]", CONFIGS[1]["N"], CONFIGS[1]["T"], CONFIGS[1]["K"], CONFIGS[1]["L"],
                    "BASELINE.json configs[0]: the reference's CPU-runnable case; a problem this small is launch-latency bound on a GPU")
@@ -279,6 +338,55 @@ def other_configs(cmf, rule, data, W0, H0, N, T, K, L, with_config3, device):
         except Exception as e:  # noqa: BLE001
             res["configs[2]"] = {"error": repr(e)}
     return res
+
+
+def measure_call_by_call(rule, W0, H0, reg_kw, nsteps, sync):
+    """ms per iteration of the reference's own loop shape (alternating.jl:51-59: update_motifs!; loss = update_feature_maps!,
+    the loss read by the host every iteration) in three forms: no write-back (W, H stay on the device: `sync_every_call=false`
+    + one download after the loop), write-back through cmf_arm_writeback (CMFHip.jl's default since round 5), and a
+    synchronous cmf_get_factors after every call (its default until round 4).  The arrays are checked against each other."""
+    import numpy as np
+    from cmf_jl_amd._lib import check, ptr
+
+    K, N, L = W0.shape
+    T = H0.shape[1]
+    W = np.zeros((K, N, L), order="F")
+    H = np.zeros((K, T), order="F")
+    rec = {"steps": nsteps, "what": "Python loop of cmf_update_motifs + cmf_update_feature_maps (loss synchronous), alternating.jl:51-59"}
+    kw_w = dict(l1W=reg_kw["l1W"], l2W=reg_kw["l2W"])
+    kw_h = dict(l1H=reg_kw["l1H"], l2H=reg_kw["l2H"])
+
+    def loop(n, after=None):
+        for _ in range(n):
+            rule.update_motifs(None, W, H, **kw_w)
+            rule.update_feature_maps(None, W, H, **kw_h)
+            if after:
+                after()
+
+    def timed_loop(after=None):
+        loop(2, after)
+        sync()
+        t0 = time.perf_counter()
+        loop(nsteps, after)
+        sync()
+        return 1e3 * (time.perf_counter() - t0) / nsteps
+
+    rule.upload(W0, H0)
+    rule.sync_every_call = False
+    rec["ms_per_step_call_by_call"] = timed_loop()
+    rule.upload(W0, H0)
+    rule.sync_every_call = True
+    try:
+        rec["ms_per_step_call_by_call_writeback"] = timed_loop()
+    finally:
+        rule.sync_every_call = False
+    Wd, Hd = rule.download()
+    rec["writeback_equals_get_factors"] = bool(np.array_equal(W, Wd) and np.array_equal(H, Hd))
+    rec["writeback_overlapped_calls"] = rule.counter("writeback_overlapped")
+    rule.upload(W0, H0)
+    rec["ms_per_step_call_by_call_get_factors"] = timed_loop(lambda: check(rule._lib.cmf_get_factors(rule._h, ptr(W), ptr(H))))
+    rec["writeback_bytes_per_step_fp64"] = 8 * (W.size + H.size)
+    return rec
 
 
 def parse_args(argv=None):
@@ -800,6 +908,17 @@ def measure(args, form, progress):
         dt_noreuse, _ = timed(1, max(3, args.steps // 2))
         dt_noreuse /= max(3, args.steps // 2)
         rule.set_option("reuse_est", 1)
+    # The drop-in path as CMF.jl's own `fit` drives it (alternating.jl:51-59): two rule calls per iteration, the loss synchronous --
+    # and, as CMFHip.jl does by default (sync_every_call), W and H written back into the caller's arrays by every
+    # update_feature_maps! call (cmf_arm_writeback: the download under the call's own kernels), next to the plain
+    # cmf_get_factors after every call that the binding used until round 4.
+    call_by_call = None
+    if extras:
+        progress["phase"] = "call-by-call side measurements"
+        try:
+            call_by_call = measure_call_by_call(rule, W0, H0, reg_kw, max(10, args.steps), sync)
+        except Exception as e:  # noqa: BLE001 - side measurements never cost the headline
+            call_by_call = {"error": repr(e)}
     # Optional Gram form of the denominators (executes 2.3 + 1 contractions): reported as
     # extra fields only, the headline value is the reference formulation above.
     dt_gram = dt_gram2 = None
@@ -910,6 +1029,12 @@ def measure(args, form, progress):
             "allreduce_overlap_probe_ms": ({k: (1e3 * v if isinstance(v, float) else v) for k, v in probe.items()} if probe else None),
             "ms_per_step_without_event_pairs": (1e3 * dt_unprofiled / args.steps) if dt_unprofiled else None,
             "ms_per_step_no_reuse": (1e3 * dt_noreuse) if dt_noreuse else None,
+            # the headline both ways: `value` executes 6 of mult.jl's 7 contractions (est reuse, bitwise identical results);
+            # the reference formulation recomputes est at mult.jl:28 (option reuse_est = 0: all 7 executed)
+            "value_reference_formulation": (1.0 / dt_noreuse) if dt_noreuse else None,
+            "ms_per_step_call_by_call": call_by_call.get("ms_per_step_call_by_call") if call_by_call else None,
+            "ms_per_step_call_by_call_writeback": call_by_call.get("ms_per_step_call_by_call_writeback") if call_by_call else None,
+            "call_by_call": call_by_call,
             "ms_per_step_gram": (1e3 * dt_gram) if dt_gram else None,
             "ms_per_step_gram_loss": (1e3 * dt_gram2) if dt_gram2 else None,
             "gram_note": "option gram=1: denomW/denomH through Gram matrices (exact rewriting, rounding-level differences), "
@@ -973,7 +1098,12 @@ def measure(args, form, progress):
             pass
         out["roofline"] = {"bound": "mfma", "kernel": DESCR[dom] + ("" if ngpu == 1 or alg != "mult" else f" on rank 0's shard of {Tl} columns"),
                            "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                           "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                           # executed flops of the WHOLE iteration (6 contractions with est reuse) / time / peak
+                           "frac_whole_iteration": out.get("whole_iteration_mfma_frac"),
+                           "frac_whole_iteration_reference_formulation": ((F_iter / dt_noreuse) / (ngpu * PEAK_FP32_MFMA_TFLOPS * 1e12)
+                                                                          if (alg == "mult" and dt_noreuse) else None),
+                           "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_flops_per_launch": kfl, "avg_launch_ms": avg_ms, "timing": src}
 
     if rank == 0 and alg == "hals":
@@ -1001,6 +1131,11 @@ def measure(args, form, progress):
         out["hbm"] = hbm
     if rank == 0 and extras and args.config == 2 and not args.T:
         out["other_configs"] = other_configs(cmf, rule, data, W0, H0, N, T, K, L, not args.no_config3, local_rank)
+        for k_, rec_ in out["other_configs"].get("shards", {}).items():
+            if isinstance(rec_, dict) and rec_.get("ms_per_step"):
+                rec_["speedup_before_communication"] = out["ms_per_step"] / rec_["ms_per_step"]
+                if rec_.get("ms_per_step_gram") and dt_gram:
+                    rec_["speedup_before_communication_gram"] = 1e3 * dt_gram / rec_["ms_per_step_gram"]
     if rank == 0:
         if args.cpu_seconds > 0 and ngpu == 1:
             try:

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcmf_hip.so")
 SOURCES = [os.path.join(CSRC, "cmf_api.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("cmf_kernels.h", "cmf_small_k.h", "cmf_group.h", "cmf_workers.h", "cmf_rng.h")] + [
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("cmf_kernels.h", "cmf_small_k.h", "cmf_group.h", "cmf_workers.h", "cmf_writeback.h", "cmf_rng.h")] + [
     os.path.join(ROOT, "include", "cmf_hip.h")]
 
 

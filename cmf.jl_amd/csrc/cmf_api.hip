@@ -3,6 +3,7 @@
 #include "cmf_hip.h"
 #include "cmf_kernels.h"
 #include "cmf_rng.h"
+#include "cmf_writeback.h"
 
 #include <algorithm>
 #include <atomic>
@@ -210,9 +211,12 @@ struct cmf_handle_s {
     double *h_ring = nullptr;
     bool dev_stamps = false;              // set by cmf_fit around its pipelined batch: time_hist from HIP timing events on the stream
     CmfLossCarry carry{};                 // a loss reduction waiting for the next W phase's slab sum (cmf_iterate only)
+    CmfWriteback *wb = nullptr;           // cmf_arm_writeback: the factors written into the caller's arrays behind a rule call
 };
 
 static int hals_ensure(cmf_handle_s *h);
+static void wb_free(cmf_handle_s *h);
+static int wb_after_H(cmf_handle_s *h); // hook: the kernels that make H final have been enqueued (cmf_writeback.h)
 static int gram_ensure(cmf_handle_s *h);
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
 static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked = false, bool loss_abs = false);
@@ -378,6 +382,8 @@ static void plan(cmf_handle_s *h, int n_cu)
 static void destroy_impl(cmf_handle_s *h)
 {
     if (!h) return;
+    if (!h->root_only) (void)hipSetDevice(h->device);
+    wb_free(h);
     if (h->root_only) { delete h; return; }
     (void)hipSetDevice(h->device);
     for (float *q : {h->sk_slabs, h->sk_Wj, h->sk_G})
@@ -550,9 +556,13 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
 // ------------------------------------------------------------------------------------------
 // kernel classes of the "profile" option
 enum { PROF_CONV = 0, PROF_CONV_T, PROF_CONV_LOSS, PROF_CONV_LOSS_STORE, PROF_HXT, PROF_TRANSCONV, PROF_HXT_NUM, PROF_HXT_DEN, PROF_OTHER,
-       PROF_HALS_PIPE, PROF_HALS_WSWEEP, PROF_NCLS };
+       PROF_HALS_PIPE, PROF_HALS_WSWEEP,
+       // the contraction launches of the HALS / PGD / Gram rules (one source, or on the stored residual)
+       PROF_CONV_RESID, PROF_HXT_RESID, PROF_HXT_HH, PROF_TRANSCONV_1, PROF_GRAM_DENOM_H, PROF_GRAM_TABLES, PROF_GRAM_W, PROF_NCLS };
 static const char *kProfNames[PROF_NCLS] = {"conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv", "hxt_num", "hxt_den", "other",
-                                            "hals_h_pipeline", "hals_w_sweep"};
+                                            "hals_h_pipeline", "hals_w_sweep",
+                                            "conv_resid", "hxt_resid", "hxt_hh", "transconv_1src", "gram_denom_h", "gram_tables", "gram_w"};
+static_assert(PROF_NCLS <= 32, "cmf_handle_s::prof_seen holds 32 classes");
 
 struct ProfScope {
     cmf_handle_s *h;
@@ -576,7 +586,7 @@ struct ProfScope {
 template <int MODE>
 static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const float *data = nullptr)
 {
-    ProfScope prof_(h, MODE == 0 ? PROF_CONV : MODE == 1 ? PROF_CONV_T : MODE == 2 ? PROF_CONV_LOSS : MODE == 3 ? PROF_CONV_LOSS_STORE : PROF_OTHER);
+    ProfScope prof_(h, MODE == 0 ? PROF_CONV : MODE == 1 ? PROF_CONV_T : MODE == 2 ? PROF_CONV_LOSS : MODE == 3 ? PROF_CONV_LOSS_STORE : PROF_CONV_RESID);
     const CmfDims &d = h->d;
     ConvParams p;
     p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = data ? data : h->X; p.partial = h->partial;
@@ -644,7 +654,8 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
 static int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int NpX, int nsrc, float *slabs, int nchunks, int chunk_len,
                          int main_rows = -1)
 {
-    ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : (nsrc == 1 && X0 == h->X) ? PROF_HXT_NUM : (nsrc == 1 && X0 == h->est && h->est_kind == 1) ? PROF_HXT_DEN : PROF_OTHER);
+    ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : (nsrc == 1 && X0 == h->X) ? PROF_HXT_NUM : (nsrc == 1 && X0 == h->est && h->est_kind == 1) ? PROF_HXT_DEN
+                          : (nsrc == 1 && X0 == h->est) ? PROF_HXT_RESID : (X0 == h->hals_HX && h->hals_HX) ? PROF_HXT_HH : PROF_OTHER);
     const CmfDims &d = h->d;
     HxtParams p;
     p.H = h->H; p.X0 = X0; p.X1 = X1; p.slabs = slabs;
@@ -670,7 +681,7 @@ static int launch_hxt(cmf_handle_s *h)
 // C3 for few components: Wj pack -> G = Wf x XT (a plain GEMM over n) -> out[t][k] = sum_l G[l*K+k][t+l], into hslabs [1][nsrc][Tl][K32]
 static int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
 {
-    ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_OTHER);
+    ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_TRANSCONV_1);
     const CmfDims &d = h->d;
     hipLaunchKernelGGL(wj_pack_kernel, dim3((unsigned)std::min<size_t>(1024, ((size_t)d.Np * h->sk_JP + 255) / 256)), dim3(256), 0, h->stream,
                        h->Wn, h->sk_Wj, d.Np, d.K, d.K32, h->sk_J, h->sk_JP);
@@ -693,7 +704,7 @@ static int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
 static int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullptr)
 {
     if (h->sk_tc) return launch_transconv_small(h, nsrc, xt0);
-    ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_OTHER);
+    ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_TRANSCONV_1);
     const CmfDims &d = h->d;
     TcParams p;
     p.Wn = h->Wn; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.slabs = h->hslabs;
@@ -736,7 +747,8 @@ static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int n
 {
     const CmfDims &d = h->d;
     if (h->small_k) { // few components: the rows j = l*K + k on the MFMA axis (hxt_small_kernel), compact slabs, their sum expanded to [L][K32][Np]
-        ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : (nsrc == 1 && X0 == h->X) ? PROF_HXT_NUM : (nsrc == 1 && X0 == h->est && h->est_kind == 1) ? PROF_HXT_DEN : PROF_OTHER);
+        ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : (nsrc == 1 && X0 == h->X) ? PROF_HXT_NUM : (nsrc == 1 && X0 == h->est && h->est_kind == 1) ? PROF_HXT_DEN
+                          : (nsrc == 1 && X0 == h->est) ? PROF_HXT_RESID : (X0 == h->hals_HX && h->hals_HX) ? PROF_HXT_HH : PROF_OTHER);
         SkHxtParams p;
         p.Ht = h->Ht; p.X0 = X0; p.X1 = X1; p.slabs = h->sk_slabs;
         p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.L = d.L; p.J = h->sk_J; p.JP = h->sk_JP; p.MG = h->sk_MG; p.Tl = d.Tl;
@@ -839,7 +851,7 @@ static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
     KCHK("h_update_kernel");
     h->est_kind = 0;
-    return CMF_OK;
+    return wb_after_H(h);
 }
 
 // the conv of mult.jl:55-57 with the loss fused: per-tile sums of (est - data)^2 -> h->partial
@@ -895,13 +907,13 @@ static int get_factors_impl(cmf_handle_s *h, double *W, double *H)
     const size_t nW = (size_t)d.L * d.N * d.K, nH = (size_t)d.Tl * d.K;
     CMFTRY(ensure_stage(h, std::max(nW, nH)));
     if (W) {
-        hipLaunchKernelGGL(unpack_W_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.N, d.K, d.L, h->Wn, d.Np, d.K32);
+        hipLaunchKernelGGL(unpack_W_kernel<double>, dim3(1024), dim3(256), 0, h->stream, h->stage, d.N, d.K, d.L, h->Wn, d.Np, d.K32);
         KCHK("unpack_W_kernel");
         HIPCHK(hipMemcpyAsync(W, h->stage, nW * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     if (H) {
-        hipLaunchKernelGGL(unpack_H_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.Tl, d.K, h->H, d.K32, d.PADL);
+        hipLaunchKernelGGL(unpack_H_kernel<double>, dim3(1024), dim3(256), 0, h->stream, h->stage, d.Tl, d.K, h->H, d.K32, d.PADL);
         KCHK("unpack_H_kernel");
         HIPCHK(hipMemcpyAsync(H, h->stage, nH * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -999,6 +1011,152 @@ struct DevStamps {
     }
 };
 
+// ------------------------------------------------------------------------------------------
+// write-back of the factors behind a rule call (cmf_writeback.h; cmf_arm_writeback)
+// ------------------------------------------------------------------------------------------
+static void wb_free(cmf_handle_s *h)
+{
+    CmfWriteback *wb = h->wb;
+    if (!wb) return;
+    if (!wb->pool.empty()) {
+        (void)cmf_pool_wait(wb->pool, 5.0);
+        cmf_pool_stop(wb->pool, true);
+    }
+    for (hipEvent_t e : {wb->ev_w_ready, wb->ev_h_ready, wb->ev_w_done, wb->ev_h_done})
+        if (e) (void)hipEventDestroy(e);
+    if (wb->pin_W) (void)hipHostFree(wb->pin_W);
+    if (wb->pin_H) (void)hipHostFree(wb->pin_H);
+    if (wb->dev_stage) (void)hipFree(wb->dev_stage);
+    if (wb->stream) (void)hipStreamDestroy(wb->stream);
+    delete wb;
+    h->wb = nullptr;
+}
+
+static int wb_alloc(cmf_handle_s *h, CmfWriteback *wb)
+{
+    const CmfDims &d = h->d;
+    wb->nW = (size_t)d.L * d.N * d.K;
+    wb->nH = (size_t)d.Tl * d.K;
+    HIPCHK(hipStreamCreateWithFlags(&wb->stream, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&wb->ev_w_ready, &wb->ev_h_ready, &wb->ev_w_done, &wb->ev_h_done})
+        HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    HIPCHK(hipHostMalloc((void **)&wb->pin_W, wb->nW * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&wb->pin_H, wb->nH * sizeof(float), hipHostMallocDefault));
+    if (d.K != d.K32) HIPCHK(hipMalloc((void **)&wb->dev_stage, std::max(wb->nW, wb->nH) * sizeof(float)));
+    const int dev = h->device;
+    wb->pool.on_start = [dev](size_t) { (void)hipSetDevice(dev); };
+    wb->pool.last_error = [] { return g_err; };
+    static const int nthr_env = getenv("CMF_WRITEBACK_THREADS") ? atoi(getenv("CMF_WRITEBACK_THREADS")) : 0;
+    cmf_pool_start(wb->pool, (size_t)std::min(16, std::max(1, nthr_env > 0 ? nthr_env : 4)));
+    return CMF_OK;
+}
+
+static int wb_ensure(cmf_handle_s *h)
+{
+    if (h->wb) return CMF_OK;
+    h->wb = new CmfWriteback();
+    if (h->group) return CMF_OK; // a group handle downloads synchronously (wb_finish): nothing of this is needed
+    const int rc = wb_alloc(h, h->wb);
+    if (rc != CMF_OK) wb_free(h);
+    return rc;
+}
+
+// W is final at the main stream's current position (update_motifs! has been enqueued): bring it to pinned memory on the copy stream
+static int wb_start_W(cmf_handle_s *h)
+{
+    CmfWriteback *wb = h->wb;
+    const CmfDims &d = h->d;
+    HIPCHK(hipEventRecord(wb->ev_w_ready, h->stream));
+    HIPCHK(hipStreamWaitEvent(wb->stream, wb->ev_w_ready, 0));
+    if (d.K == d.K32) { // Wn[l][n][k] with K32 = K: every lag is N * K contiguous floats in Julia's order
+        const size_t row = (size_t)d.N * d.K * sizeof(float);
+        HIPCHK(hipMemcpy2DAsync(wb->pin_W, row, h->Wn, (size_t)d.Np * d.K32 * sizeof(float), row, (size_t)d.L, hipMemcpyDeviceToHost, wb->stream));
+    } else {
+        hipLaunchKernelGGL(unpack_W_kernel<float>, dim3(256), dim3(256), 0, wb->stream, wb->dev_stage, d.N, d.K, d.L, h->Wn, d.Np, d.K32);
+        KCHK("unpack_W_kernel");
+        HIPCHK(hipMemcpyAsync(wb->pin_W, wb->dev_stage, wb->nW * sizeof(float), hipMemcpyDeviceToHost, wb->stream));
+    }
+    HIPCHK(hipEventRecord(wb->ev_w_done, wb->stream));
+    wb->w_started = true;
+    return CMF_OK;
+}
+
+static int wb_drain(cmf_handle_s *h)
+{
+    CmfWriteback *wb = h->wb;
+    if (!cmf_pool_wait(wb->pool, wait_timeout_s()))
+        return fail(CMF_ERR_HIP, "write-back: the helper threads did not finish within %.0f s", wait_timeout_s());
+    std::string err;
+    const int rc = cmf_pool_collect(wb->pool, -1, &err);
+    return rc == 0 ? CMF_OK : fail(rc, "write-back: %s", err.c_str());
+}
+
+// Hook of the rules' H phases: the kernels that make H final have just been enqueued on the main stream.
+static int wb_after_H(cmf_handle_s *h)
+{
+    CmfWriteback *wb = h->wb;
+    if (!wb || !wb->armed || h->group) return CMF_OK;
+    const CmfDims &d = h->d;
+    const bool again = wb->h_posted; // a second pass over H inside the same call (the HALS rerun): the helpers must be done with the staging
+    if (again) CMFTRY(wb_drain(h));
+    if (wb->dst_H) {
+        HIPCHK(hipEventRecord(wb->ev_h_ready, h->stream));
+        HIPCHK(hipStreamWaitEvent(wb->stream, wb->ev_h_ready, 0));
+        if (d.K == d.K32) { // H[PADL + t][k] with K32 = K is Julia's K x T order
+            HIPCHK(hipMemcpyAsync(wb->pin_H, h->H + (size_t)d.PADL * d.K32, wb->nH * sizeof(float), hipMemcpyDeviceToHost, wb->stream));
+        } else {
+            hipLaunchKernelGGL(unpack_H_kernel<float>, dim3(256), dim3(256), 0, wb->stream, wb->dev_stage, d.Tl, d.K, h->H, d.K32, d.PADL);
+            KCHK("unpack_H_kernel");
+            HIPCHK(hipMemcpyAsync(wb->pin_H, wb->dev_stage, wb->nH * sizeof(float), hipMemcpyDeviceToHost, wb->stream));
+        }
+        HIPCHK(hipEventRecord(wb->ev_h_done, wb->stream));
+    }
+    const size_t nthr = wb->pool.size();
+    const bool want_W = !again && wb->dst_W && wb->w_started;
+    for (size_t i = 0; i < nthr; ++i)
+        cmf_pool_post(wb->pool, i, [wb, i, nthr, want_W]() -> int {
+            auto slice = [&](size_t n, size_t *a, size_t *b) { // 16-element granules, the last helper takes the remainder
+                const size_t per = (n / nthr) & ~(size_t)15;
+                *a = i * per;
+                *b = i + 1 == nthr ? n : (i + 1) * per;
+            };
+            size_t a, b;
+            if (want_W) {
+                if (hipEventSynchronize(wb->ev_w_done) != hipSuccess) return fail(CMF_ERR_HIP, "the download of W failed");
+                slice(wb->nW, &a, &b);
+                cmf_widen(wb->pin_W + a, wb->dst_W + a, b - a);
+            }
+            if (wb->dst_H) {
+                if (hipEventSynchronize(wb->ev_h_done) != hipSuccess) return fail(CMF_ERR_HIP, "the download of H failed");
+                slice(wb->nH, &a, &b);
+                cmf_widen(wb->pin_H + a, wb->dst_H + a, b - a);
+            }
+            return CMF_OK;
+        });
+    if (!again) wb->hooked_calls += 1;
+    wb->h_posted = true;
+    return CMF_OK;
+}
+
+// End of a rule call that may carry an armed write-back: the caller's arrays are complete (or the call fails) and are not
+// touched after this returns.
+static int wb_finish(cmf_handle_s *h, int rc)
+{
+    CmfWriteback *wb = h ? h->wb : nullptr;
+    if (!wb || !wb->armed) return rc;
+    double *W = wb->dst_W, *H = wb->dst_H;
+    int rc2 = CMF_OK;
+    if (wb->h_posted) {
+        rc2 = wb_drain(h);
+    } else if (rc == CMF_OK) { // no hook on this path (group handles): the synchronous download
+        wb->armed = false;
+        rc2 = cmf_get_factors(h, W, H);
+    }
+    wb->armed = wb->h_posted = wb->w_started = false;
+    wb->dst_W = wb->dst_H = nullptr;
+    return rc != CMF_OK ? rc : rc2;
+}
+
 #include "cmf_group.h"
 
 // A loss reduction deferred by cmf_iterate (CmfLossCarry) only lives between two phases of that call.  If the call
@@ -1034,7 +1192,7 @@ extern "C" {
 #endif
 #define CMF_STR2(x) #x
 #define CMF_STR(x) CMF_STR2(x)
-const char *cmf_version(void) { return "cmf_hip gfx950 0.4.0 abi=" CMF_STR(CMF_ABI_VERSION) " src=" CMF_SRC_DIGEST; }
+const char *cmf_version(void) { return "cmf_hip gfx950 0.5.0 abi=" CMF_STR(CMF_ABI_VERSION) " src=" CMF_SRC_DIGEST; }
 const char *cmf_source_digest(void) { return CMF_SRC_DIGEST; }
 int cmf_abi_version(void) { return CMF_ABI_VERSION; }
 const char *cmf_last_error(void) { return g_err.c_str(); }
@@ -1124,6 +1282,8 @@ int cmf_get_counter(cmf_handle h, const char *name, int64_t *value)
 {
     if (!h || !name || !value) return fail(CMF_ERR_ARG, "NULL argument");
     if (std::strcmp(name, "hals_pipeline_reruns") == 0) { *value = h->hals_reruns; return CMF_OK; }
+    if (std::strcmp(name, "writeback_calls") == 0) { *value = h->wb ? h->wb->armed_calls : 0; return CMF_OK; }            // cmf_arm_writeback calls
+    if (std::strcmp(name, "writeback_overlapped") == 0) { *value = h->wb ? h->wb->hooked_calls : 0; return CMF_OK; }     // ... served by the copy stream behind the H update
     if (h->group) { // host cost of the pipelined iterations of a group (reading a counter resets nothing)
         cmf_group_s *g = h->group;
         if (std::strcmp(name, "enqueue_ns") == 0) { *value = g->enqueue_ns; return CMF_OK; }       // calling thread: enqueueing / posting
@@ -1300,7 +1460,7 @@ int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
     return w_apply_impl(h, l1W, l2W);
 }
 
-int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
+static int update_feature_maps_body(cmf_handle h, double l1H, double l2H, double *loss)
 {
     RoctxRange range("cmf_update_feature_maps");
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
@@ -1319,6 +1479,35 @@ int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
     double ss = 0.0;
     CMFTRY(loss_partial_impl(h, &ss));
     *loss = std::sqrt(ss) / h->data_norm;
+    return CMF_OK;
+}
+
+int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
+{
+    return wb_finish(h, update_feature_maps_body(h, l1H, l2H, loss));
+}
+
+int cmf_arm_writeback(cmf_handle h, double *W, double *H)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (!W && !H) { // disarm
+        if (h->wb && !h->group && h->wb->h_posted) (void)wb_drain(h);
+        if (h->wb) {
+            h->wb->armed = h->wb->h_posted = h->wb->w_started = false;
+            h->wb->dst_W = h->wb->dst_H = nullptr;
+        }
+        return CMF_OK;
+    }
+    if (h->group) CMFTRY(group_check_ready(h->group));
+    else CMFTRY(check_ready(h, false));
+    CMFTRY(wb_ensure(h));
+    CmfWriteback *wb = h->wb;
+    wb->dst_W = W;
+    wb->dst_H = H;
+    wb->armed = true;
+    wb->h_posted = wb->w_started = false;
+    wb->armed_calls += 1;
+    if (W && !h->group) CMFTRY(wb_start_W(h));
     return CMF_OK;
 }
 
@@ -1344,7 +1533,7 @@ int cmf_hals_update_motifs(cmf_handle h, double l1W, double l2W)
     return hals_w_impl(h, l1W, l2W);
 }
 
-int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
+static int hals_update_feature_maps_body(cmf_handle h, double l1H, double l2H, double *loss)
 {
     if (h && h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
@@ -1368,6 +1557,11 @@ int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *l
     }
     *loss = std::sqrt(ss) / h->data_norm;
     return CMF_OK;
+}
+
+int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
+{
+    return wb_finish(h, hals_update_feature_maps_body(h, l1H, l2H, loss));
 }
 
 int cmf_set_mask(cmf_handle h, const double *mask)
@@ -1422,7 +1616,7 @@ int cmf_pgd_update_motifs(cmf_handle h, double pen_sq, double pen_abs, int nonne
     return pgd_w_impl(h, pen_sq, pen_abs, nonneg);
 }
 
-int cmf_pgd_update_feature_maps(cmf_handle h, double pen_sq, double pen_abs, int nonneg, double *loss)
+static int pgd_update_feature_maps_body(cmf_handle h, double pen_sq, double pen_abs, int nonneg, double *loss)
 {
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
     if (h && h->group) {
@@ -1431,6 +1625,11 @@ int cmf_pgd_update_feature_maps(cmf_handle h, double pen_sq, double pen_abs, int
     }
     CMFTRY(check_ready(h, true));
     return pgd_h_impl(h, pen_sq, pen_abs, nonneg, loss);
+}
+
+int cmf_pgd_update_feature_maps(cmf_handle h, double pen_sq, double pen_abs, int nonneg, double *loss)
+{
+    return wb_finish(h, pgd_update_feature_maps_body(h, pen_sq, pen_abs, nonneg, loss));
 }
 
 int cmf_pgd_get_steps(cmf_handle h, double *stepW, double *stepH)
@@ -2102,7 +2301,7 @@ static int hals_h_sweep_general(cmf_handle_s *h, HalsRowParams q)
     return CMF_OK;
 }
 
-static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
+static int hals_h_enqueue(cmf_handle_s *h, double l1H, double l2H)
 {
     const CmfDims &d = h->d;
     CMFTRY(hals_ensure(h));
@@ -2169,6 +2368,12 @@ static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
     return hals_h_sweep_stage(h, q);
 }
 
+static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
+{
+    CMFTRY(hals_h_enqueue(h, l1H, l2H));
+    return wb_after_H(h);
+}
+
 // The persistent pipeline reported an expired wait (status word; the stream has drained): H and P hold a half-finished
 // sweep.  Restore H from the snapshot, rebuild P from the contractions that are still in place, and run the sweep on the
 // stage pipeline, which needs no co-residency.  The handle keeps to the stage pipeline from here on.
@@ -2183,12 +2388,14 @@ static int hals_h_rerun(cmf_handle_s *h)
     HIPCHK(hipMemcpyAsync(h->Ht, h->hals_snap + nH, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     CMFTRY(hals_h_project(h, false));
     h->est_kind = 0;
-    return hals_h_sweep_stage(h, hals_row_params(h, h->hals_l1, h->hals_l2));
+    CMFTRY(hals_h_sweep_stage(h, hals_row_params(h, h->hals_l1, h->hals_l2)));
+    return wb_after_H(h); // (an armed write-back has taken the half-finished H: take it again)
 }
 
 // ---- optional Gram form of the MU iteration ----------------------------------
 static int gram_tables(cmf_handle_s *h) // PW -> GW, GE (the lag-Gram taps of W; shared with HALS)
 {
+    ProfScope prof_(h, PROF_GRAM_TABLES);
     const CmfDims &d = h->d;
     hipLaunchKernelGGL(hals_pw_kernel, dim3(d.L * (d.L + 1) / 2, d.KB * d.KB), dim3(256), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
     KCHK("hals_pw_kernel");
@@ -2199,6 +2406,7 @@ static int gram_tables(cmf_handle_s *h) // PW -> GW, GE (the lag-Gram taps of W;
 
 static int gram_denom_h(cmf_handle_s *h, float *out)
 {
+    ProfScope prof_(h, PROF_GRAM_DENOM_H);
     const CmfDims &d = h->d;
     const size_t lds = (size_t)d.K32 * (64 + 2 * (d.L - 1)) * sizeof(float);
     if (lds > 96 * 1024) return fail(CMF_ERR_UNSUPPORTED, "Gram form: K*L too large for the LDS window");
@@ -2249,9 +2457,12 @@ static int gram_w_partial(cmf_handle_s *h, float *hh_out)
 static int gram_w_finish(cmf_handle_s *h, const float *HH, double l1W, double l2W, const float *tail_src, float *tail_dst, int tail_n)
 {
     const CmfDims &d = h->d;
-    hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 64, (d.L * d.KB + 1) / 2), dim3(256), 0, h->stream, HH, h->Wt, h->wslabs,
-                       d.L * d.K32, h->hals_NpH, d.Np);
-    KCHK("gram_w_kernel");
+    {
+        ProfScope prof_(h, PROF_GRAM_W);
+        hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 64, (d.L * d.KB + 1) / 2), dim3(256), 0, h->stream, HH, h->Wt, h->wslabs,
+                           d.L * d.K32, h->hals_NpH, d.Np);
+        KCHK("gram_w_kernel");
+    }
     return w_apply_impl(h, l1W, l2W, tail_src, tail_dst, tail_n, h->wslabs); // mult.jl:37-38
 }
 
@@ -2280,7 +2491,7 @@ static int gram_h_update(cmf_handle_s *h, double l1H, double l2H)
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
     KCHK("h_update_kernel");
     h->est_kind = 0;
-    return CMF_OK;
+    return wb_after_H(h);
 }
 
 static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss)
@@ -2409,6 +2620,7 @@ static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
     KCHK("pgd_h_apply_kernel");
     if (nonneg == 2) CMFTRY(pgd_unit_norm(h, false)); // pgd.jl:100-110
     h->est_kind = 0;
+    CMFTRY(wb_after_H(h));
     CMFTRY(pgd_finish(h, &h->pgd_stepH));
     *loss = std::sqrt(h->pgd_cur_loss / (h->data_norm * h->data_norm)); // pgd.jl:201
     return CMF_OK;

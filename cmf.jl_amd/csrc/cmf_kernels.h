@@ -3209,14 +3209,15 @@ __global__ void pack_W_kernel(const double *in, int N, int K, int L, float *Wt, 
         Wn[((size_t)l * Np + n) * K32 + k] = v;
     }
 }
-__global__ void unpack_W_kernel(double *out, int N, int K, int L, const float *Wn, int Np, int K32)
+template <typename O>
+__global__ void unpack_W_kernel(O *out, int N, int K, int L, const float *Wn, int Np, int K32)
 {
     size_t total = (size_t)L * N * K;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int k = (int)(idx % K);
         size_t r = idx / K;
         int n = (int)(r % N), l = (int)(r / N);
-        out[idx] = (double)Wn[((size_t)l * Np + n) * K32 + k];
+        out[idx] = (O)Wn[((size_t)l * Np + n) * K32 + k];
     }
 }
 // H fp64 [T][K] (k fastest) -> H[(PADL+t)][k], Ht[k][PADL+t]
@@ -3231,13 +3232,14 @@ __global__ void pack_H_kernel(const double *in, int Tl, int K, float *H, float *
         Ht[(size_t)k * TP + PADL + t] = v;
     }
 }
-__global__ void unpack_H_kernel(double *out, int Tl, int K, const float *H, int K32, int PADL)
+template <typename O>
+__global__ void unpack_H_kernel(O *out, int Tl, int K, const float *H, int K32, int PADL)
 {
     size_t total = (size_t)Tl * K;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int k = (int)(idx % K);
         int t = (int)(idx / K);
-        out[idx] = (double)H[(size_t)(PADL + t) * K32 + k];
+        out[idx] = (O)H[(size_t)(PADL + t) * K32 + k];
     }
 }
 // rows [tc, tc+ncols) of a [*][stride] fp32 row-major buffer (row offset row0) -> fp64 out[c*width + j]

@@ -185,6 +185,20 @@ class MultUpdate(AbstractCFUpdate):
         check(lib.cmf_get_data_sumsq(self._h, ctypes.byref(ss)))
         self.data_norm = math.sqrt(ss.value)  # mult.jl:13
 
+    # ``rule.sync_every_call = True`` (CMFHip.jl's default): every update_feature_maps call also writes the new factors into
+    # the W and H it is handed -- the reference's in-place semantics (mult.jl:37-38,51-52) for a caller that looks at its
+    # arrays between calls.  The download rides underneath the call's own kernels (cmf_arm_writeback).
+    sync_every_call = False
+
+    def _arm_writeback(self, W, H):
+        if not self.sync_every_call or (W is None and H is None):
+            return
+        for a, shape, nm in ((W, (self.K, self.N, self.L), "W"), (H, (self.K, self.T), "H")):
+            if a is not None and not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.shape == shape
+                                      and a.flags.f_contiguous and a.flags.writeable):
+                raise ValueError(f"sync_every_call: {nm} must be a writeable Float64 array of shape {shape} in Julia's (column-major) order")
+        check(self._lib.cmf_arm_writeback(self._h, None if W is None else ptr(W), None if H is None else ptr(H)))
+
     # -- the two rule methods -----------------------------------------------------------
     def update_motifs(self, data=None, W=None, H=None, l1W=0, l2W=0, **kwargs):
         """update_motifs!(rule, data, W, H; l1W=0, l2W=0): src/algs/mult.jl:23-39."""
@@ -193,6 +207,7 @@ class MultUpdate(AbstractCFUpdate):
     def update_feature_maps(self, data=None, W=None, H=None, l1H=0, l2H=0, **kwargs):
         """update_feature_maps!(rule, data, W, H; l1H=0, l2H=0) -> loss: src/algs/mult.jl:42-58."""
         loss = ctypes.c_double()
+        self._arm_writeback(W, H)
         check(self._lib.cmf_update_feature_maps(self._h, float(l1H), float(l2H), ctypes.byref(loss)))
         return loss.value
 
@@ -326,6 +341,7 @@ class HALSUpdate(MultUpdate):
     def update_feature_maps(self, data=None, W=None, H=None, l1H=0, l2H=0, **kwargs):
         """update_feature_maps!(rule::HALSUpdate, data, W, H; l1H=0, l2H=0) -> loss: src/algs/hals.jl:37-42."""
         loss = ctypes.c_double()
+        self._arm_writeback(W, H)
         check(self._lib.cmf_hals_update_feature_maps(self._h, float(l1H), float(l2H), ctypes.byref(loss)))
         return loss.value
 
@@ -453,6 +469,7 @@ class PGDUpdate(MultUpdate):
         self._select_loss(loss_func)
         sq, ab = _penalty_weights([] if penaltiesH is None else penaltiesH)
         loss = ctypes.c_double()
+        self._arm_writeback(W, H)
         check(self._lib.cmf_pgd_update_feature_maps(self._h, sq, ab, _nonneg_flag(constrH), ctypes.byref(loss)))
         return loss.value
 

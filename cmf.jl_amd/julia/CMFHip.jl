@@ -87,6 +87,17 @@ function HIPMultUpdate(data::Matrix{Float64}, W::Tensor{Float64}, H::Matrix{Floa
     return rule
 end
 
+# The reference's rules mutate W and H in place (mult.jl:37-38, :51-52) and `fit` hands the same arrays to every call
+# (alternating.jl:51-54).  With `sync_every_call` (default) the update_feature_maps! that follows writes the new factors into
+# W and H before it returns: cmf_arm_writeback borrows the two arrays until that call returns (hence GC.@preserve around both),
+# and the download runs underneath the call's own kernels -- W during the H phase's first contraction, H during the loss
+# conv, Float64 widening on helper threads -- instead of a 23 MB synchronous cmf_get_factors per iteration
+# (INTEGRATION.md section 2 quotes the measured cost of both).
+function arm_writeback(rule::HIPMultUpdate, W::Array{Float64}, H::Array{Float64})
+    rule.sync_every_call || return
+    check(ccall((:cmf_arm_writeback, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.handle, W, H))
+end
+
 # update_motifs!(rule, data, W, H; l1W=0, l2W=0)  -- src/algs/mult.jl:23-39, called at alternating.jl:52
 function update_motifs!(rule::HIPMultUpdate, data, W, H; l1W=0, l2W=0, kwargs...)
     check(ccall((:cmf_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64), rule.handle,
@@ -97,10 +108,10 @@ end
 # update_feature_maps!(rule, data, W, H; l1H=0, l2H=0) -> loss  -- src/algs/mult.jl:42-58, alternating.jl:54
 function update_feature_maps!(rule::HIPMultUpdate, data, W, H; l1H=0, l2H=0, kwargs...)
     loss = Ref{Float64}(0.0)
-    check(ccall((:cmf_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
-                rule.handle, reg(kwargs, :l1H, :l1_H, l1H), reg(kwargs, :l2H, :l2_H, l2H), loss))
-    if rule.sync_every_call   # keep the reference's in-place semantics for arbitrary callers
-        check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.handle, W, H))
+    GC.@preserve W H begin
+        arm_writeback(rule, W, H)
+        check(ccall((:cmf_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
+                    rule.handle, reg(kwargs, :l1H, :l1_H, l1H), reg(kwargs, :l2H, :l2_H, l2H), loss))
     end
     return loss[]
 end
@@ -126,10 +137,10 @@ end
 # update_feature_maps!(rule::HALSUpdate, ...; l1H=0, l2H=0) -> loss  -- src/algs/hals.jl:37-42
 function update_feature_maps!(rule::HIPHALSUpdate, data, W, H; l1H=0, l2H=0, kwargs...)
     loss = Ref{Float64}(0.0)
-    check(ccall((:cmf_hals_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
-                rule.inner.handle, reg(kwargs, :l1H, :l1_H, l1H), reg(kwargs, :l2H, :l2_H, l2H), loss))
-    if rule.inner.sync_every_call
-        check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.inner.handle, W, H))
+    GC.@preserve W H begin
+        arm_writeback(rule.inner, W, H)
+        check(ccall((:cmf_hals_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
+                    rule.inner.handle, reg(kwargs, :l1H, :l1_H, l1H), reg(kwargs, :l2H, :l2_H, l2H), loss))
     end
     return loss[]
 end
@@ -202,10 +213,10 @@ function update_feature_maps!(rule::HIPPGDUpdate, data, W, H; loss_func=SquareLo
     select_loss!(rule, loss_func)
     sq, ab = penalty_weights(penaltiesH)
     loss = Ref{Float64}(0.0)
-    check(ccall((:cmf_pgd_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Cint, Ref{Float64}),
-                rule.inner.handle, sq, ab, nonneg_flag(constrH), loss))
-    if rule.inner.sync_every_call
-        check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.inner.handle, W, H))
+    GC.@preserve W H begin
+        arm_writeback(rule.inner, W, H)
+        check(ccall((:cmf_pgd_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Cint, Ref{Float64}),
+                    rule.inner.handle, sq, ab, nonneg_flag(constrH), loss))
     end
     return loss[]
 end

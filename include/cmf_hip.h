@@ -44,14 +44,14 @@ typedef struct cmf_handle_s *cmf_handle;
 /* Version of this interface.  3 (round 3): the phase-split entries of version 1 (cmf_w_partial*, cmf_w_apply,
  * cmf_h_update, cmf_loss_partial*, cmf_halo_*, cmf_numden_ptr, cmf_set_data_norm) are gone -- a sharded iteration
  * runs behind the rule entries of a group handle (cmf_create_multi / cmf_comm_init_*); cmf_abi_version,
- * cmf_source_digest, cmf_synchronize, cmf_rccl_version, cmf_get_counter are new. */
-#define CMF_ABI_VERSION 4
+ * cmf_source_digest, cmf_synchronize, cmf_rccl_version, cmf_get_counter are new.  5 (round 5): cmf_arm_writeback. */
+#define CMF_ABI_VERSION 5
 int cmf_abi_version(void);
 
 /* Library / build identification: "cmf_hip gfx950 <version> abi=<n> src=<digest>". */
 const char *cmf_version(void);
 /* Hex SHA-256 prefix (16 characters) of the sources this library was compiled from (csrc/cmf_api.hip, csrc/cmf_kernels.h,
- * csrc/cmf_group.h, csrc/cmf_rng.h, include/cmf_hip.h, in that order, each preceded by its base name and a newline).
+ * csrc/cmf_small_k.h, csrc/cmf_group.h, csrc/cmf_workers.h, csrc/cmf_writeback.h, csrc/cmf_rng.h, include/cmf_hip.h, in that order, each preceded by its base name and a newline).
  * A loader that has the tree at hand recomputes it and refuses (or rebuilds) a stale binary -- cmf.jl_amd/_lib.py does;
  * "unknown" when the library was built without the build script. */
 const char *cmf_source_digest(void);
@@ -214,6 +214,20 @@ int cmf_get_data_sumsq(cmf_handle h, double *sumsq);
  * working copies live on the device between calls. */
 int cmf_set_factors(cmf_handle h, const double *W, const double *H);
 int cmf_get_factors(cmf_handle h, double *W, double *H);
+
+/* In-place semantics for a caller that drives the rule call by call (the reference's own `fit`, src/algs/alternating.jl:51-54,
+ * hands the SAME W and H arrays to every call and the rules mutate them: src/algs/mult.jl:37-38,51-52; hals.jl:110,153;
+ * pgd.jl:293).  cmf_arm_writeback(h, W, H), called after update_motifs! and immediately before update_feature_maps! of any
+ * rule (cmf_update_feature_maps, cmf_hals_update_feature_maps, cmf_pgd_update_feature_maps), makes THAT call also write the
+ * new factors into W (K x N x L) and H (K x T), bit for bit what cmf_get_factors returns, before it returns -- without the
+ * 23 MB synchronous fp64 download at config 2: W travels (fp32, pinned memory, a copy stream) underneath the H phase's first
+ * contraction, H underneath the loss conv, and helper threads widen to Float64 while the caller waits for the loss scalar.
+ * Either pointer may be NULL (that factor is not written); both NULL disarms.  EXCEPTION to "host pointers are borrowed for
+ * the duration of the call only": W and H are borrowed from this call until the next *_update_feature_maps call on the handle
+ * returns, and are written only inside that call.  One arm serves one call.  Group handles take the synchronous
+ * cmf_get_factors route inside the rule call (same results).  CMF_WRITEBACK_THREADS (default 4): the widening helpers.
+ * cmf_get_counter: "writeback_calls", "writeback_overlapped" (calls served by the copy stream). */
+int cmf_arm_writeback(cmf_handle h, double *W, double *H);
 
 /* ---- the update rule -------------------------------------------------------
  * update_motifs!(rule::MultUpdate, data, W, H; l1W=0, l2W=0)

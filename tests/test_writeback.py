@@ -1,0 +1,196 @@
+"""The reference's in-place semantics call by call: cmf_arm_writeback (include/cmf_hip.h).
+
+CMF.jl's `fit` hands the SAME W and H arrays to every rule call and the rules mutate them (src/algs/alternating.jl:51-54;
+mult.jl:37-38,51-52; hals.jl:110,153; pgd.jl:293), so the Julia binding writes the factors back after every
+update_feature_maps!.  Since round 5 that write-back rides underneath the call's own kernels (a copy stream + helper threads);
+what these tests pin: the caller's arrays are BIT FOR BIT what cmf_get_factors returns at that moment -- for every rule, for
+K on the direct-copy path (a multiple of 32) and on the pack-kernel path, call after call -- and the losses do not change.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from cmf_jl_amd._lib import check  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cmf():
+    import cmf_jl_amd as m
+
+    lib = m.load_library()
+    assert lib.cmf_device_count() >= 1, "no HIP device: the gpu tests need a real MI355X"
+    return m
+
+
+def problem(oracle, N, T, K, L, seed=3):
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 8), seed=seed)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=seed + 1)
+    return data, W0, H0
+
+
+def caller_arrays(W0, H0):
+    # NaN-filled: an element the write-back missed cannot pass for a value
+    return np.full(W0.shape, np.nan, order="F"), np.full(H0.shape, np.nan, order="F")
+
+
+SHAPES = [(130, 700, 32, 20), (70, 257, 5, 10), (37, 150, 33, 7), (260, 600, 64, 20), (9, 40, 2, 3), (2000, 3000, 32, 20)]
+
+
+@pytest.mark.parametrize("N,T,K,L", SHAPES)
+def test_mu_writeback_is_bitwise_get_factors(cmf, oracle, N, T, K, L):
+    data, W0, H0 = problem(oracle, N, T, K, L)
+    ref = cmf.MultUpdate(data, W0, H0)
+    rule = cmf.MultUpdate(data, W0, H0)
+    rule.sync_every_call = True
+    W, H = caller_arrays(W0, H0)
+    try:
+        for it in range(4):
+            ref.update_motifs(l1W=0.1 * (it % 2))
+            want = ref.update_feature_maps(l2H=0.05 * (it % 2))
+            rule.update_motifs(data, W, H, l1W=0.1 * (it % 2))
+            got = rule.update_feature_maps(data, W, H, l2H=0.05 * (it % 2))
+            assert got == want  # the write-back changes nothing in the arithmetic
+            Wd, Hd = rule.download()
+            assert np.array_equal(W, Wd) and np.array_equal(H, Hd), f"iteration {it}"
+            Wr, Hr = ref.download()
+            assert np.array_equal(W, Wr) and np.array_equal(H, Hr)
+        assert rule.counter("writeback_calls") == 4 and rule.counter("writeback_overlapped") == 4
+    finally:
+        ref.close()
+        rule.close()
+
+
+def test_writeback_of_one_factor_only_and_disarm(cmf, oracle):
+    data, W0, H0 = problem(oracle, 60, 300, 32, 8)
+    rule = cmf.MultUpdate(data, W0, H0)
+    lib, h = rule._lib, rule._h
+    pd = ctypes.POINTER(ctypes.c_double)
+    W, H = caller_arrays(W0, H0)
+    try:
+        rule.update_motifs()
+        check(lib.cmf_arm_writeback(h, None, H.ctypes.data_as(pd)))
+        rule.update_feature_maps()
+        Wd, Hd = rule.download()
+        assert np.array_equal(H, Hd) and np.isnan(W).all()
+        rule.update_motifs()
+        check(lib.cmf_arm_writeback(h, W.ctypes.data_as(pd), None))
+        rule.update_feature_maps()
+        Wd, Hd2 = rule.download()
+        assert np.array_equal(W, Wd) and np.array_equal(H, Hd)  # H untouched by the second call
+        # armed, then disarmed: the next call must not touch the arrays
+        W[...] = np.nan
+        H[...] = np.nan
+        rule.update_motifs()
+        check(lib.cmf_arm_writeback(h, W.ctypes.data_as(pd), H.ctypes.data_as(pd)))
+        check(lib.cmf_arm_writeback(h, None, None))
+        rule.update_feature_maps()
+        assert np.isnan(W).all() and np.isnan(H).all()
+        # one arm serves one call
+        check(lib.cmf_arm_writeback(h, W.ctypes.data_as(pd), H.ctypes.data_as(pd)))
+        rule.update_feature_maps()
+        assert not np.isnan(W).any()
+        W[...] = np.nan
+        rule.update_feature_maps()
+        assert np.isnan(W).all()
+    finally:
+        rule.close()
+
+
+@pytest.mark.parametrize("N,T,K,L", [(130, 700, 32, 20), (70, 257, 5, 10)])
+def test_hals_and_pgd_writeback(cmf, oracle, N, T, K, L):
+    data, W0, H0 = problem(oracle, N, T, K, L)
+    for make, kw in ((cmf.HALSUpdate, {}), (cmf.PGDUpdate, {}), (cmf.PGDUpdate, {"constrH": cmf.UnitNormConstraint()})):
+        ref = make(data, W0, H0)
+        rule = make(data, W0, H0)
+        rule.sync_every_call = True
+        W, H = caller_arrays(W0, H0)
+        try:
+            for it in range(3):
+                ref.update_motifs()
+                want = ref.update_feature_maps(**kw)
+                rule.update_motifs(data, W, H)
+                got = rule.update_feature_maps(data, W, H, **kw)
+                assert got == want
+                Wd, Hd = rule.download()
+                assert np.array_equal(W, Wd) and np.array_equal(H, Hd), (make.__name__, it)
+            assert rule.counter("writeback_overlapped") == 3
+        finally:
+            ref.close()
+            rule.close()
+
+
+def test_gram_form_writeback(cmf, oracle):
+    data, W0, H0 = problem(oracle, 130, 700, 32, 20)
+    for gram in (1, 2):
+        rule = cmf.MultUpdate(data, W0, H0)
+        rule.set_option("gram", gram)
+        rule.sync_every_call = True
+        W, H = caller_arrays(W0, H0)
+        try:
+            for _ in range(2):
+                rule.update_motifs(data, W, H)
+                rule.update_feature_maps(data, W, H)
+                Wd, Hd = rule.download()
+                assert np.array_equal(W, Wd) and np.array_equal(H, Hd)
+        finally:
+            rule.close()
+
+
+def test_group_handles_write_back_synchronously(cmf, oracle):
+    data, W0, H0 = problem(oracle, 60, 500, 32, 8)
+    ref = cmf.MultUpdate(data, W0, H0, devices=[0, 0, 0])
+    rule = cmf.MultUpdate(data, W0, H0, devices=[0, 0, 0])
+    rule.sync_every_call = True
+    W, H = caller_arrays(W0, H0)
+    try:
+        for _ in range(2):
+            ref.update_motifs()
+            want = ref.update_feature_maps()
+            rule.update_motifs(data, W, H)
+            assert rule.update_feature_maps(data, W, H) == want
+            Wd, Hd = rule.download()
+            assert np.array_equal(W, Wd) and np.array_equal(H, Hd)
+        assert rule.counter("writeback_calls") == 2 and rule.counter("writeback_overlapped") == 0
+    finally:
+        ref.close()
+        rule.close()
+
+
+def test_hals_rerun_takes_h_again(cmf, oracle):
+    """A persistent H pipeline whose wait ran out redoes the sweep from its snapshot after the first download of H has
+    been taken (DESIGN.md HALS): the write-back must deliver the H of the redone sweep."""
+    data, _, _ = oracle.c_gen_synthetic(N=40, T=600, K=3, L=8, seed=5)
+    W0, H0 = oracle.c_init_rand(data, L=8, K=4, seed=2)
+    rule = cmf.HALSUpdate(data, W0, H0)
+    rule.sync_every_call = True
+    W, H = caller_arrays(W0, H0)
+    try:
+        rule.update_motifs(data, W, H)
+        os.environ["CMF_HALS_DEBUG"] = "stall"
+        try:
+            rule.update_feature_maps(data, W, H)
+        finally:
+            os.environ.pop("CMF_HALS_DEBUG", None)
+        assert rule.counter("hals_pipeline_reruns") == 1
+        Wd, Hd = rule.download()
+        assert np.array_equal(W, Wd) and np.array_equal(H, Hd)
+    finally:
+        rule.close()
+
+
+def test_python_twin_refuses_arrays_it_cannot_hand_over(cmf, oracle):
+    data, W0, H0 = problem(oracle, 20, 100, 4, 5)
+    rule = cmf.MultUpdate(data, W0, H0)
+    rule.sync_every_call = True
+    try:
+        rule.update_motifs()
+        with pytest.raises(ValueError):
+            rule.update_feature_maps(data, np.zeros(W0.shape, order="C"), np.zeros(H0.shape, order="F"))
+        with pytest.raises(ValueError):
+            rule.update_feature_maps(data, np.zeros(W0.shape, order="F"), np.zeros(H0.shape, dtype=np.float32, order="F"))
+    finally:
+        rule.close()
