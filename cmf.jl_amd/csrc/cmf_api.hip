@@ -485,6 +485,24 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
                                          "kernels' 32-bit buffer offsets address");
     }
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // Measurement hook (tools/cu_mask_experiment.py; honoured only with CMF_TEST_HOOKS=1): CMF_EXP_CU_MASK="part/parts/x|c" runs
+    // this handle on a CU-masked stream -- part `part` of `parts` equal parts of the chip, cut by whole XCDs (x: CU bit j
+    // belongs to XCD j % 8) or inside every XCD (c) -- and plans its statically dealt kernels for that many CUs.
+    uint32_t cu_mask[8] = {0};
+    int cu_part = -1, cu_parts = 0;
+    char cu_mode = 'x';
+    if (const char *e = getenv("CMF_EXP_CU_MASK")) {
+        if (getenv("CMF_TEST_HOOKS") && atoi(getenv("CMF_TEST_HOOKS")) == 1 && sscanf(e, "%d/%d/%c", &cu_part, &cu_parts, &cu_mode) >= 2 &&
+            cu_parts >= 2 && cu_parts <= 8 && cu_part >= 0 && cu_part < cu_parts && h->n_cu % (8 * cu_parts) == 0) {
+            const int per_xcd = h->n_cu / 8;
+            for (int j = 0; j < h->n_cu; ++j) {
+                const int xcd = j % 8, idx = j / 8;
+                const bool mine = cu_mode == 'c' ? (idx * cu_parts / per_xcd == cu_part) : (xcd * cu_parts / 8 == cu_part);
+                if (mine) cu_mask[j / 32] |= 1u << (j % 32);
+            }
+            h->n_cu /= cu_parts;
+        } else cu_part = -1;
+    }
     plan(h, h->n_cu);
     // the C2 kernel addresses a time chunk of X with 32-bit byte offsets: keep chunks below 2 GiB
     while ((double)(h->hxt_chunk_len + 16 * h->hxt_LP + 8) * d.Np * 4.0 >= 2147483648.0) {
@@ -501,7 +519,8 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     auto bail = [&](int rc) { destroy_impl(h); return rc; };
 #define TRYB(expr) do { int rc__ = (expr); if (rc__ != CMF_OK) return bail(rc__); } while (0)
 #define HIPB(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(fail(CMF_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__))); } while (0)
-    HIPB(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    if (cu_part >= 0) HIPB(hipExtStreamCreateWithCUMask(&h->own_stream, 8, cu_mask));
+    else HIPB(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     HIPB(hipEventCreate(&h->ev0));
     HIPB(hipEventCreate(&h->ev1));
@@ -2135,6 +2154,25 @@ static int hals_ensure(cmf_handle_s *h)
     return CMF_OK;
 }
 
+// denomW = HH * W (gram_w_kernel): MB p blocks per workgroup, chosen so that the grid is about one workgroup per CU
+static int launch_gram_w(cmf_handle_s *h, const float *HH, float *out)
+{
+    const CmfDims &d = h->d;
+    const int nbp = d.L * d.KB, nbn = d.Np / 32;
+    int MB = 1;
+    for (int m = 5; m >= 2; --m)
+        if (nbp % m == 0 && (nbp / m) * nbn >= h->n_cu) { MB = m; break; }
+    const dim3 grid(nbn, nbp / MB);
+    const size_t lds = (size_t)4 * MB * 16 * 64 * sizeof(float);
+    switch (MB) {
+#define CASE(M_) case M_: hipLaunchKernelGGL((gram_w_kernel<M_>), grid, dim3(256), lds, h->stream, HH, h->Wt, out, d.L * d.K32, h->hals_NpH, d.Np); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5)
+#undef CASE
+    }
+    KCHK("gram_w_kernel");
+    return CMF_OK;
+}
+
 // HH = H_unfold * H_unfold' (hals.jl:56-60: the row norms are its diagonal) from the lag correlations of H with itself:
 // one C2 contraction on K32 columns, then an assembly pass with the right-end corrections (hals_hh_kernel)
 static int compute_hh(cmf_handle_s *h, float *out = nullptr)
@@ -2165,9 +2203,7 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     if (h->hals_gram == 1) {
         CMFTRY(hxt_contract(h, h->X, h->X, 1, h->numden));
         CMFTRY(compute_hh(h));
-        hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 64, (d.L * d.KB + 1) / 2), dim3(256), 0, h->stream, h->hals_HH, h->Wt, h->numden + LKN,
-                           d.L * d.K32, h->hals_NpH, d.Np);
-        KCHK("gram_w_kernel");
+        CMFTRY(launch_gram_w(h, h->hals_HH, h->numden + LKN));
         G = h->numden + LKN;
         Gsub = h->numden;
     } else {
@@ -2399,7 +2435,8 @@ static int gram_tables(cmf_handle_s *h) // PW -> GW, GE (the lag-Gram taps of W;
     const CmfDims &d = h->d;
     hipLaunchKernelGGL(hals_pw_kernel, dim3(d.L * (d.L + 1) / 2, d.KB * d.KB), dim3(256), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
     KCHK("hals_pw_kernel");
-    hipLaunchKernelGGL(hals_gw_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_PW, h->hals_GW, h->hals_GE, d.L, d.K32, h->hals_ne, d.Tl, h->hals_t_edge0);
+    hipLaunchKernelGGL(hals_gw_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_PW, h->hals_GW, h->hals_GE, d.L, d.K32, h->hals_ne, d.Tl, h->hals_t_edge0,
+                       h->hals_GWt, 2 * d.L); // (+ the taps as [k'][e][k], E = 2L - 1 padded to an even count, for gram_h_mfma_kernel)
     KCHK("hals_gw_kernel");
     return CMF_OK;
 }
@@ -2418,21 +2455,21 @@ static int gram_denom_h(cmf_handle_s *h, float *out)
     const int tile = 128 / fw;
     const size_t lds_m = ((size_t)d.K32 * (tile + 2 * (d.L - 1)) + (fw > 1 ? 4096 : 0)) * sizeof(float);
     const int ntile = lds_m <= 120 * 1024 ? h->hals_t_edge0 / tile : 0;
-    if (ntile > 0) {
-        const int Ep = 2 * d.L; // E = 2L - 1 taps padded to an even count
-        hipLaunchKernelGGL(gram_taps_t_kernel, dim3(256), dim3(256), 0, h->stream, h->hals_GW, h->hals_GWt, d.L, d.K32, Ep);
-        KCHK("gram_taps_t_kernel");
-        hipLaunchKernelGGL(gram_h_mfma_kernel, dim3(ntile, d.KB), dim3(256), lds_m, h->stream, h->Ht, h->hals_GWt, out, d.K, d.L, d.K32, d.TP, d.PADL, Ep, fw);
-        KCHK("gram_h_mfma_kernel");
-    }
     const int t_first = tile * ntile;
-    if (ntile > 0 && d.Tl - t_first <= 512) { // the usual case: a wave per leftover output
-        if (d.Tl > t_first) {
-            hipLaunchKernelGGL(gram_h_edge_kernel, dim3(d.Tl - t_first, d.K32 / 4), dim3(256), 0, h->stream, h->Ht, h->hals_GW, h->hals_GE, out,
-                               d.Tl, d.K, d.L, d.K32, d.TP, d.PADL, h->hals_ne, h->hals_t_edge0, t_first);
-            KCHK("gram_h_edge_kernel");
-        }
-        return CMF_OK;
+    if (ntile > 0) {
+        // the leftover columns (the right edge with its per-column taps, and what does not fill a tile), a wave per output:
+        // when they are few (the usual case) their workgroups ride at the end of the MFMA kernel's grid
+        const bool ride = d.Tl - t_first <= 512;
+        GramEdge edge;
+        edge.GW = h->hals_GW; edge.GE = h->hals_GE;
+        edge.Tl = d.Tl; edge.ne = h->hals_ne; edge.t_edge0 = h->hals_t_edge0; edge.t_first = t_first;
+        edge.n_main = ntile * d.KB; edge.kq = d.K32 / 4;
+        const int n_edge = ride ? (d.Tl - t_first) * edge.kq : 0;
+        const int Ep = 2 * d.L; // E = 2L - 1 taps padded to an even count (hals_gw_kernel wrote them as [k'][e][k])
+        hipLaunchKernelGGL(gram_h_mfma_kernel, dim3(edge.n_main + n_edge), dim3(256), lds_m, h->stream, h->Ht, h->hals_GWt, out, d.K, d.L, d.K32, d.TP, d.PADL,
+                           Ep, fw, ntile, edge);
+        KCHK("gram_h_mfma_kernel");
+        if (ride) return CMF_OK;
     }
     const int block0 = t_first / 64, nblock = (d.Tl + 63) / 64 - block0; // (a half block in front of it is simply formed twice)
     if (nblock > 0) {
@@ -2459,9 +2496,7 @@ static int gram_w_finish(cmf_handle_s *h, const float *HH, double l1W, double l2
     const CmfDims &d = h->d;
     {
         ProfScope prof_(h, PROF_GRAM_W);
-        hipLaunchKernelGGL(gram_w_kernel, dim3(d.Np / 64, (d.L * d.KB + 1) / 2), dim3(256), 0, h->stream, HH, h->Wt, h->wslabs,
-                           d.L * d.K32, h->hals_NpH, d.Np);
-        KCHK("gram_w_kernel");
+        CMFTRY(launch_gram_w(h, HH, h->wslabs));
     }
     return w_apply_impl(h, l1W, l2W, tail_src, tail_dst, tail_n, h->wslabs); // mult.jl:37-38
 }

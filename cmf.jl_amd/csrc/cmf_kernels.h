@@ -1801,7 +1801,7 @@ __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float
 __global__ __launch_bounds__(256) void hals_pw_kernel(const float *Wn, float *PW, int N, int L, int Np, int K32, int KB)
 {
     __shared__ float part[4][16][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (scalar: uniform loop bounds)
     const int i = lane & 31, h = lane >> 5;
     int l = 0, rem = blockIdx.x; // pair index -> (l, lp), l <= lp: row l of the upper triangle holds L - l pairs
     while (rem >= L - l) { rem -= L - l; ++l; }
@@ -1858,7 +1858,9 @@ __global__ __launch_bounds__(256) void hals_pw_kernel(const float *Wn, float *PW
 // with its neighbours); the edge tables are the running sums of the same walk over l -- Lt = l + 1 after lag l -- so all
 // ne + 1 tables cost L reads per thread.  (One thread per OUTPUT, with the tap index fastest, read every term of every
 // table separately: 23 us at K = 32, L = 20, independent of T.)
-__global__ void hals_gw_kernel(const float *PW, float *GW, float *GE, int L, int K32, int ne, int Tl, int t_edge0)
+// GWt (optional): the full-window taps once more as [k'][e][k] with the tap count padded to Ep = 2L (gram_h_mfma_kernel's B
+// operand; a separate transposing launch until round 4).
+__global__ void hals_gw_kernel(const float *PW, float *GW, float *GE, int L, int K32, int ne, int Tl, int t_edge0, float *GWt, int Ep)
 {
     const int E = 2 * L - 1;
     const size_t total = (size_t)K32 * K32 * E;
@@ -1887,6 +1889,11 @@ __global__ void hals_gw_kernel(const float *PW, float *GW, float *GE, int L, int
             }
         }
         GW[((size_t)k * K32 + kp) * E + ei] = s;
+        if (GWt) {
+            GWt[((size_t)kp * Ep + ei) * K32 + k] = s;
+            if (ei == E - 1)
+                for (int z = E; z < Ep; ++z) GWt[((size_t)kp * Ep + z) * K32 + k] = 0.f;
+        }
     }
 }
 
@@ -2896,52 +2903,54 @@ __global__ void pgd_h_kscale_kernel(float *H, float *Ht, const double *ss, int T
 // =============================================================================================
 
 // out[p][n] = sum_{p'} HH[p'][p] * Wt[p'][n]  (HH is symmetric: row p' is read, columns p0+i -> coalesced)
-// grid (Np/64, LK/64), block 256: ONE 64 x 64 output tile per workgroup; its four waves each take a quarter of the
-// reduction range p' for all 2 x 2 blocks of the tile (two A rows and two B rows feed four MFMAs: one 128-byte operand row
-// from L2 per MFMA) and add their partial sums through LDS in wave order (deterministic).  16 row pairs in flight under the
-// MFMAs of the batch before (two register sets).  History: one wave per 32 x 32 block with a load, wait, MFMA loop was a
-// chain of LK / 2 L2 round trips (99 us at LK = 640, Np = 2048, independent of T -- a fifth of a T/8 shard's Gram-form
-// iteration); a 32 x 32 block per workgroup with the reduction split was L2-bandwidth bound (two operand rows per MFMA,
-// 210 MB per launch: 36 us).
+// grid (Np/32, LK/(32*MB)), block 256: ONE tile of MB x 1 blocks of 32 x 32 (MB*32 rows p, 32 columns n) per workgroup; its
+// four waves each take a quarter of the reduction range p' for all MB blocks (one B row of Wt and MB A rows of HH feed MB
+// MFMAs: 1 + 1/MB 128-byte operand rows from L2 per MFMA), 8 row pairs in flight under the MFMAs of the batch before (two
+// register sets), and add their partial sums through LDS in wave order (deterministic) behind ONE barrier.  MB is chosen
+// by the launcher so that the grid is one workgroup per CU where the shape allows it (config 2: LK = 640, Np = 2048, MB = 5:
+// exactly 256 workgroups of 4 x 400 MFMAs -- the 64 x 64 tiles of rounds 3-4 were 320 workgroups on 256 CUs, 38 us for
+// 10.7 us of MFMA work).  Per output element the terms are added in the same order as in that kernel: bitwise the same sums.
+// History: one wave per 32 x 32 block with a load, wait, MFMA loop was a chain of LK / 2 L2 round trips (99 us at LK = 640,
+// Np = 2048, independent of T -- a fifth of a T/8 shard's Gram-form iteration); a 32 x 32 block per workgroup with the
+// reduction split was L2-bandwidth bound (two operand rows per MFMA, 210 MB per launch: 36 us).
+// dynamic LDS: 4 * MB * 16 * 64 floats.
+template <int MB>
 __global__ __launch_bounds__(256) void gram_w_kernel(const float *HH, const float *Wt, float *out, int LK, int NpH, int Np)
 {
-    __shared__ float part[4][16][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) float gw_part[]; // [4][MB][16][64]
+    // (the wave index as a SCALAR: with a divergent-looking `wave` every guarded load below became its own exec-masked basic
+    // block with a conservative wait behind it -- 26 us for 10.7 us of MFMA work)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int p0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const bool p_hi = p0 + 32 < LK; // LK is a multiple of 32, not always of 64: the second p block may not exist
-    f32x16 acc[2][2];
+    const int p0 = blockIdx.y * 32 * MB, n0 = blockIdx.x * 32;
+    f32x16 acc[MB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MB; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     const float *ap = HH + (size_t)h * NpH + p0 + i;
     const float *bp = Wt + (size_t)h * Np + n0 + i;
     const int q4 = (LK / 4 + 1) & ~1;            // this wave's share of the reduction rows (even)
     const int lo = wave * q4, hi = (lo + q4 < LK) ? lo + q4 : LK;
     constexpr int NB = 8;                        // row pairs per batch
-    float a0[2][NB], a1[2][NB], b0[2][NB], b1[2][NB];
+    float av[2][NB][MB], bv[2][NB];
     auto load = [&](int s, int pp0) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int pp = pp0 + 2 * q;
             const bool ok = pp < hi;
-            a0[s][q] = ok ? ap[(size_t)pp * NpH] : 0.f;
-            a1[s][q] = (ok && p_hi) ? ap[(size_t)pp * NpH + 32] : 0.f;
-            b0[s][q] = ok ? bp[(size_t)pp * Np] : 0.f;
-            b1[s][q] = ok ? bp[(size_t)pp * Np + 32] : 0.f;
+            const int ppc = ok ? pp : lo; // unconditional loads (a row pair this wave owns), a zero B operand behind the range
+            const float bx = bp[(size_t)ppc * Np];
+            bv[s][q] = ok ? bx : 0.f;
+#pragma unroll
+            for (int a = 0; a < MB; ++a) av[s][q][a] = ap[(size_t)ppc * NpH + 32 * a];
         }
     };
     auto mac = [&](int s) {
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s][q], b0[s][q], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s][q], b1[s][q], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][q], b0[s][q], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][q], b1[s][q], acc[1][1], 0, 0, 0);
-        }
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int a = 0; a < MB; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][q][a], bv[s][q], acc[a], 0, 0, 0);
     };
     if (lo < hi) load(0, lo);
     for (int pp0 = lo; pp0 < hi; pp0 += 4 * NB) {
@@ -2953,20 +2962,16 @@ __global__ __launch_bounds__(256) void gram_w_kernel(const float *HH, const floa
         }
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MB; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            __syncthreads(); // (the previous block's partial sums have been consumed)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[a][b][r];
-            __syncthreads();
-            if (a == 0 || p_hi)
-                for (int o = threadIdx.x; o < 16 * 64; o += 256) {
-                    const int r = o >> 6, ln = o & 63;
-                    const float v = ((part[0][r][ln] + part[1][r][ln]) + part[2][r][ln]) + part[3][r][ln];
-                    out[(size_t)(p0 + 32 * a + cmf_crow(r, ln >> 5)) * Np + n0 + 32 * b + (ln & 31)] = v;
-                }
-        }
+        for (int r = 0; r < 16; ++r) gw_part[((wave * MB + a) * 16 + r) * 64 + lane] = acc[a][r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < MB * 16 * 64; o += 256) {
+        const int a = o >> 10, r = (o >> 6) & 15, ln = o & 63;
+        const int e = (a * 16 + r) * 64 + ln;
+        const float v = ((gw_part[e] + gw_part[MB * 1024 + e]) + gw_part[2 * MB * 1024 + e]) + gw_part[3 * MB * 1024 + e];
+        out[(size_t)(p0 + 32 * a + cmf_crow(r, ln >> 5)) * Np + n0 + (ln & 31)] = v;
+    }
 }
 
 // out[t][k] = sum_{k',e} taps(t)[k][k'][e] * Ht[k'][PADL + t + e];  taps = GW (full window) or GE (edge columns)
@@ -3017,24 +3022,19 @@ __global__ __launch_bounds__(256) void gram_h_kernel(const float *Ht, const floa
 // load per FMA and restages the window for every four outputs: 317 us at config 5 against ~60 here.
 // grid (tiles of 128 columns that end at or before t_edge0, KB), block 256 (4 waves = 4 x 32 columns);
 // dynamic LDS: K32 * (128 + 2*(L-1)) floats.
-__global__ void gram_taps_t_kernel(const float *GW, float *GWt, int L, int K32, int Ep)
-{
-    const int E = 2 * L - 1;
-    const size_t total = (size_t)K32 * Ep * K32;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % K32), ei = (int)((idx / K32) % Ep), kp = (int)(idx / ((size_t)K32 * Ep));
-        GWt[idx] = ei < E ? GW[((size_t)k * K32 + kp) * E + ei] : 0.f;
-    }
-}
 // ... and for the few columns the tiles above leave over (the right edge with its per-column taps GE, and what does not
 // fill a tile of 128): one wave per output (t, k), its lanes over the K * E terms -- the taps of a column are K32 * E
 // contiguous floats -- and a DPP wave sum.  (The scalar kernel's edge path walks those terms one load at a time: 76 us
 // for 80 columns.)   grid (columns from t_first on, K32 / 4), block 256: wave w -> k = blockIdx.y * 4 + w
-__global__ __launch_bounds__(256) void gram_h_edge_kernel(const float *Ht, const float *GW, const float *GE, float *out,
-                                                           int Tl, int K, int L, int K32, int TP, int PADL, int ne, int t_edge0, int t_first)
+struct GramEdge { // the edge workgroups that ride at the end of gram_h_mfma_kernel's grid (n_main = its own workgroups)
+    const float *GW, *GE;
+    int Tl, ne, t_edge0, t_first, n_main, kq; // kq = K32 / 4 workgroups per column
+};
+__device__ __forceinline__ void gram_h_edge(const float *Ht, const float *GW, const float *GE, float *out,
+                                            int Tl, int K, int L, int K32, int TP, int PADL, int ne, int t_edge0, int t, int kblk)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t = t_first + blockIdx.x, k = blockIdx.y * 4 + wave;
+    const int k = kblk * 4 + wave;
     if (t >= Tl) return;
     const int E = 2 * L - 1;
     float x = 0.f;
@@ -3058,15 +3058,22 @@ __global__ __launch_bounds__(256) void gram_h_edge_kernel(const float *Ht, const
 // wave order), the workgroup's tile is then 128 / fw columns: a short shard (T/8 = 6250 columns: 48 tiles of 128) gets
 // fw times the waves, each with 1/fw of the dependent MFMA chain and of the tap stream (62 -> ~15 us at T = 6250).
 // dynamic LDS: K32 * (128 / fw + 2*(L-1)) floats for the H window (+ 4096 floats for the partial sums when fw > 1).
+// grid: n_tiles * KB workgroups of the MFMA form (tile fastest) + the edge workgroups behind them (GramEdge: one launch and
+// one kernel boundary less, and the latency-bound edge waves run beside the MFMA tiles instead of after them).
 __global__ __launch_bounds__(256) void gram_h_mfma_kernel(const float *Ht, const float *GWt, float *out, int K, int L, int K32, int TP, int PADL, int Ep,
-                                                           int fw)
+                                                           int fw, int n_tiles, GramEdge edge)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= edge.n_main) {
+        const int b = blockIdx.x - edge.n_main;
+        gram_h_edge(Ht, edge.GW, edge.GE, out, edge.Tl, K, L, K32, TP, PADL, edge.ne, edge.t_edge0, edge.t_first + b / edge.kq, b % edge.kq);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // (scalar: see gram_w_kernel)
     const int i = lane & 31, hh = lane >> 5;
     const int cw = 4 / fw, tile = 32 * cw;
     const int cg = wave % cw, fg = wave / cw; // column group and F group of this wave
-    const int t0 = blockIdx.x * tile, kbo = blockIdx.y;
+    const int t0 = ((int)blockIdx.x % n_tiles) * tile, kbo = (int)blockIdx.x / n_tiles;
     const int WN = tile + 2 * (L - 1);
     for (int base = 0; base < K32 * WN; base += 4 * 256) { // four loads in flight per thread, then the LDS writes
         float v[4];
@@ -3097,7 +3104,7 @@ __global__ __launch_bounds__(256) void gram_h_mfma_kernel(const float *Ht, const
     float bb[2][32];
     auto loadb = [&](float (&x)[32], int f0) {
 #pragma unroll
-        for (int q = 0; q < 32; ++q) x[q] = (f0 + q < f_hi) ? brow[(size_t)2 * (f0 + q) * K32] : 0.f;
+        for (int q = 0; q < 32; ++q) x[q] = brow[(size_t)2 * ((f0 + q < f_hi) ? f0 + q : f_lo) * K32]; // (unconditional; A is zero behind the range)
     };
     auto mac = [&](const float (&x)[32], int f0) {
         int kp = f0 / nstep, s2 = f0 - kp * nstep;
