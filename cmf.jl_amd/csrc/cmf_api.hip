@@ -151,7 +151,8 @@ struct cmf_handle_s {
     bool small_k_ok = false;                // the shape allows it
     bool sk_tc_ok = false, sk_tc = false;   // ... and its C3 form (G GEMM + fold) has enough columns to fill the chip; sk_tc: in use
     int sk_J = 0, sk_JP = 0, sk_MG = 1, sk_MBW = 4, sk_chunk_len = 16, sk_ngroups = 1, sk_TG = 128;
-    float *sk_slabs = nullptr, *sk_Wj = nullptr, *sk_G = nullptr;
+    int sk3_MG = 1, sk3_MBW = 4, sk3_Kg = 1, sk3_JP = 128; // C3: whole components per row group (g_gemm_fold_small_kernel)
+    float *sk_slabs = nullptr, *sk_Wj = nullptr;
     int tc_S_full = 1, tc_S1_full = 1;      // fragment slabs of the general transconv kernel (tc_S / tc_S1 are 1 while small_k is on)
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
     int conv_variant = 0;   // K % 32 == 0: 3 = one-wave workgroups (conv3_kernel), 2 = 128 x 128 tiles (conv2_kernel), 0 = per mode
@@ -368,10 +369,17 @@ static void plan(cmf_handle_s *h, int n_cu)
         // C3: the G GEMM runs one wave per 32 columns, row group and source; with fewer than two waves per CU (short
         // recordings: BASELINE configs[0] has T = 2000) the general kernel, which splits the reduction over n, is faster
         // (measured at configs[0]: 20 us against 39)
-        h->sk_tc_ok = (int64_t)(h->sk_TG / 32) * h->sk_MG * 2 >= 2LL * n_cu;
-        // ... and its G matrix (2 * JP * TG floats) must stay a modest share of the device: long recordings with many (lag,
-        // component) pairs keep the general kernel (8.3 M columns x 320 rows would be 42 GB)
-        if ((double)2 * h->sk_JP * h->sk_TG * 4.0 > 8e9) h->sk_tc_ok = false;
+        // Its row groups hold whole components (the lag sum of an output is folded inside one workgroup): Kg components of L rows
+        // each in at most SK_MAXMBW blocks of 32 rows.
+        h->sk3_MG = (d.K * d.L + 32 * SK_MAXMBW - 1) / (32 * SK_MAXMBW);
+        for (;; ++h->sk3_MG) {
+            h->sk3_Kg = (d.K + h->sk3_MG - 1) / h->sk3_MG;
+            if (h->sk3_Kg * d.L <= 32 * SK_MAXMBW) break;
+        }
+        h->sk3_MG = (d.K + h->sk3_Kg - 1) / h->sk3_Kg;
+        h->sk3_MBW = (h->sk3_Kg * d.L + 31) / 32;
+        h->sk3_JP = 32 * h->sk3_MBW * h->sk3_MG;
+        h->sk_tc_ok = (int64_t)(h->sk_TG / 32) * h->sk3_MG * 2 >= 2LL * n_cu;
     }
     // C1 (conv)
     h->conv_gx = d.Np / 128;
@@ -386,7 +394,7 @@ static void destroy_impl(cmf_handle_s *h)
     wb_free(h);
     if (h->root_only) { delete h; return; }
     (void)hipSetDevice(h->device);
-    for (float *q : {h->sk_slabs, h->sk_Wj, h->sk_G})
+    for (float *q : {h->sk_slabs, h->sk_Wj})
         if (q) (void)hipFree(q);
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
@@ -536,15 +544,14 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     TRYB(dalloc_zero(&h->wslabs, (size_t)std::max(2 * hxt_nslabs(h->hxt_nchunks), hxt_nslabs(h->hxt_nchunks1)) * d.L * d.K32 * d.Np));
     TRYB(dalloc_zero(&h->numden_own, (size_t)2 * d.L * d.K32 * d.Np));
     h->numden = h->numden_own;
-    TRYB(dalloc_zero(&h->hslabs, (size_t)std::max(2 * h->tc_S, h->tc_S1) * d.Tl * d.K32));
+    TRYB(dalloc_zero(&h->hslabs, (size_t)std::max(2 * std::max(h->tc_S, 2), std::max(h->tc_S1, 2)) * d.Tl * d.K32)); // (the few-component C3 writes 2 slabs)
     if (h->small_k_ok) {
         TRYB(dalloc_zero(&h->sk_slabs, (size_t)h->sk_ngroups * 2 * h->sk_JP * d.Np));
-        TRYB(dalloc_zero(&h->sk_Wj, (size_t)d.Np * h->sk_JP));
-        if (h->sk_tc_ok) TRYB(dalloc_zero(&h->sk_G, (size_t)2 * h->sk_JP * h->sk_TG));
+        TRYB(dalloc_zero(&h->sk_Wj, (size_t)d.Np * h->sk3_JP));
         static const bool off = getenv("CMF_SMALL_K") && atoi(getenv("CMF_SMALL_K")) == 0; // measurement knob: the general kernels for every K
         h->small_k = !off;
         h->sk_tc = h->small_k && h->sk_tc_ok;
-        if (h->sk_tc) h->tc_S = h->tc_S1 = 1;
+        if (h->sk_tc) h->tc_S = h->tc_S1 = 2;
     }
     for (int v = 0; v < 2; ++v) {
         HIPB(hipMalloc(&h->tc_tab[v], h->tc_tab_host[v].size() * sizeof(int4)));
@@ -697,26 +704,26 @@ static int launch_hxt(cmf_handle_s *h)
     return launch_hxt_on(h, h->X, h->est, h->d.Np, 2, h->wslabs, h->hxt_nchunks, h->hxt_chunk_len, h->hxt_main);
 }
 
-// C3 for few components: Wj pack -> G = Wf x XT (a plain GEMM over n) -> out[t][k] = sum_l G[l*K+k][t+l], into hslabs [1][nsrc][Tl][K32]
+// C3 for few components: Wj pack, then ONE launch that forms G = Wf x XT (a plain GEMM over n) tile by tile and folds the lag sum
+// out[t][k] = sum_l G[(k, l)][t + l] on chip, into hslabs [2][nsrc][Tl][K32]
 static int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
 {
     ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_TRANSCONV_1);
     const CmfDims &d = h->d;
-    hipLaunchKernelGGL(wj_pack_kernel, dim3((unsigned)std::min<size_t>(1024, ((size_t)d.Np * h->sk_JP + 255) / 256)), dim3(256), 0, h->stream,
-                       h->Wn, h->sk_Wj, d.Np, d.K, d.K32, h->sk_J, h->sk_JP);
+    hipLaunchKernelGGL(wj_pack_kernel, dim3((unsigned)std::min<size_t>(1024, ((size_t)d.Np * h->sk3_JP + 255) / 256)), dim3(256), 0, h->stream,
+                       h->Wn, h->sk_Wj, d.Np, d.K, d.L, d.K32, h->sk3_Kg, 32 * h->sk3_MBW, h->sk3_JP);
     KCHK("wj_pack_kernel");
     SkGemmParams p;
-    p.Wj = h->sk_Wj; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.G = h->sk_G;
-    p.TP = d.TP; p.PADL = d.PADL; p.JP = h->sk_JP; p.MG = h->sk_MG; p.TG = h->sk_TG; p.N2 = (int)rup(d.N, 2); p.Np = d.Np; p.nsrc = nsrc;
-    switch (h->sk_MBW) {
-#define CASE(M_) case M_: hipLaunchKernelGGL((g_gemm_small_kernel<M_>), dim3(h->sk_TG / 128, nsrc * h->sk_MG), dim3(256), 0, h->stream, p); break;
+    p.Wj = h->sk_Wj; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.out = h->hslabs;
+    p.TP = d.TP; p.PADL = d.PADL; p.JP = h->sk3_JP; p.MG = h->sk3_MG; p.TG = h->sk_TG; p.N2 = (int)rup(d.N, 2); p.Np = d.Np; p.nsrc = nsrc;
+    p.Tl = d.Tl; p.K = d.K; p.L = d.L; p.K32 = d.K32; p.Kg = h->sk3_Kg;
+    switch (h->sk3_MBW) {
+#define CASE(M_) case M_: hipLaunchKernelGGL((g_gemm_fold_small_kernel<M_>), dim3(h->sk_TG / 128 + 1, nsrc * h->sk3_MG), dim3(256), 0, h->stream, p); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
 #undef CASE
-    default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk_MBW);
+    default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk3_MBW);
     }
-    KCHK("g_gemm_small_kernel");
-    hipLaunchKernelGGL(fold_small_kernel, dim3((d.Tl + 63) / 64, nsrc), dim3(256), 0, h->stream, h->sk_G, h->hslabs, d.Tl, d.K, d.L, d.K32, h->sk_JP, h->sk_TG);
-    KCHK("fold_small_kernel");
+    KCHK("g_gemm_fold_small_kernel");
     return CMF_OK;
 }
 
@@ -1412,13 +1419,8 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         HIPCHK(hipStreamSynchronize(h->stream));
         h->small_k = value != 0 && h->small_k_ok;
         h->sk_tc = h->small_k && (h->sk_tc_ok || value == 2); // (2: the few-component C3 form whatever T is -- tests, measurements)
-        if (h->sk_tc && !h->sk_G) { // (not allocated with the handle when the shape did not ask for it)
-            float *G = nullptr;
-            CMFTRY(dalloc_zero(&G, (size_t)2 * h->sk_JP * h->sk_TG));
-            h->sk_G = G;
-        }
-        h->tc_S = h->sk_tc ? 1 : h->tc_S_full;
-        h->tc_S1 = h->sk_tc ? 1 : h->tc_S1_full;
+        h->tc_S = h->sk_tc ? 2 : h->tc_S_full; // (own block | the spill of the next block: g_gemm_fold_small_kernel)
+        h->tc_S1 = h->sk_tc ? 2 : h->tc_S1_full;
         h->est_kind = 0;
         return CMF_OK;
     }

@@ -178,41 +178,76 @@ __global__ __launch_bounds__(256) void slab_sum_small_kernel(float *out, const f
     if (carry.partial && blockIdx.x == gridDim.x - 1) cmf_block_loss_reduce(carry);
 }
 
-// Wj[n][j] = W[l][n][k] (j = l*K + k; zero for j >= J), from Wn [Lp][Np][K32]: the A operand of the C3 GEMM, j contiguous.
-__global__ __launch_bounds__(256) void wj_pack_kernel(const float *Wn, float *Wj, int Np, int K, int K32, int J, int JP)
+// C3 puts whole components into a row group: group g holds the components [g*Kg, (g+1)*Kg), its row kl*L + l is
+// (component g*Kg + kl, lag l), padded with zero rows to 32*MBW -- k-major, so that the L rows a folded output needs lie next to
+// each other (at most three components per 32-row block at L = 20) and no output is shared between two row groups.
+// Wj[n][g*32*MBW + kl*L + l] = W[l][n][g*Kg + kl], from Wn [Lp][Np][K32]: the A operand of the C3 GEMM, rows contiguous per n.
+__global__ __launch_bounds__(256) void wj_pack_kernel(const float *Wn, float *Wj, int Np, int K, int L, int K32, int Kg, int GR, int JP)
 {
     const size_t total = (size_t)Np * JP;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(idx % JP), n = (int)(idx / JP);
-        float v = 0.f;
-        if (j < J) {
-            const int l = j / K, k = j - l * K;
-            v = Wn[((size_t)l * Np + n) * K32 + k];
-        }
-        Wj[idx] = v;
+        const int jj = (int)(idx % JP), n = (int)(idx / JP);
+        const int g = jj / GR, rr = jj - g * GR;
+        const int kl = rr / L, l = rr - kl * L, k = g * Kg + kl;
+        Wj[idx] = (kl < Kg && k < K) ? Wn[((size_t)l * Np + n) * K32 + k] : 0.f;
     }
 }
+
+#define SK_TILE_STRIDE 132 // floats between the rows of the staged G block (128 columns + padding)
+#define SK_FOLD_COLS 192   // 128 + L - 1 <= 191 output columns of a workgroup (L <= SK_MAXL)
 
 struct SkGemmParams {
     const float *Wj;  // [Np][JP]
     const float *XT0; // dataT [Np][TP]
     const float *XT1; // estT  [Np][TP]
-    float *G;         // [nsrc][JP][TG]
-    int TP, PADL, JP, MG, TG, N2, Np; // N2 = roundup(N, 2): rows n >= N2 of XT and Wj are zero
-    int nsrc;
+    float *out;       // hslabs [2][nsrc][Tl][K32]: slab 0 = the part of out[t][k] from G columns of t's own 128-column block, slab 1 = the part
+                      // from the next block (the last L - 1 columns of a block only; zeros elsewhere)
+    int TP, PADL, JP, MG, TG, N2, Np, nsrc;
+    int Tl, K, L, K32, Kg;
 };
 
-// C3, first half: G[j][t'] = sum_n Wj[n][j] XT[n][t'].  grid (TG/128, nsrc*MG), 256 threads; a wave = 32*MBW rows j x 32 columns t'.
-// Both operands are read from global memory directly in MFMA layout (128 contiguous bytes per half-wave; Wj is L2-resident),
-// eight n pairs ahead.
+// C3 in ONE launch: out[t][k] = sum_l G[(k, l)][t + l] with G[(k, l)][t'] = sum_n W[l][n][k] XT[n][t'] (common.jl:71-81 with the
+// lag sum taken after the contraction over n).  grid (TG/128 + 1, nsrc*MG), 256 threads.  The four waves of a workgroup form
+// the G tile of 32*MBW rows x 128 columns t' in [c0, c0 + 128) exactly like a plain GEMM -- both operands read from global
+// memory directly in MFMA layout (128 contiguous bytes per half-wave; Wj is L2-resident), eight n pairs ahead -- and then FOLD it
+// on chip: the tile goes through LDS one 32-row block at a time, thread c adds, for output column t = c0 - (L-1) + c, the rows
+// of each component at the columns t + l that lie inside the tile (lag order inside a block, blocks in order: deterministic).
+// Outputs t >= c0 go to slab 0; the L - 1 columns in front of the tile -- whose other lags lie in the previous workgroup's
+// tile -- go to slab 1, which this workgroup also zero-fills for the rest of the previous block; h_update / the slab sums add
+// the two slabs.  G never exists in memory (until round 4: 2*JP*TG floats written by the GEMM and read back by a fold kernel,
+// as much HBM traffic as a pass over data), and no MFMA work is repeated.  The extra workgroup at the end of grid.x only
+// zero-fills slab 1 of the last block.
 template <int MBW>
-__global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_small_kernel(SkGemmParams p)
+__global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kernel(SkGemmParams p)
 {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ float tile[32 * SK_TILE_STRIDE];
+    __shared__ float outs[16 * SK_FOLD_COLS];
+    __shared__ short rowk[32 * SK_MAXMBW], rowl[32 * SK_MAXMBW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int src = blockIdx.y % p.nsrc, mg = blockIdx.y / p.nsrc;
-    const int tb = (blockIdx.x * 4 + wave) * 32;
-    if (tb >= p.TG) return;
+    const int c0 = blockIdx.x * 128;
+    const int L = p.L, K32 = p.K32, Tl = p.Tl;
+    const int kbase = mg * p.Kg;
+    const int kn = (p.K - kbase < p.Kg) ? p.K - kbase : p.Kg;       // components of this row group
+    const int kw = ((mg == p.MG - 1) ? K32 : kbase + kn) - kbase;   // columns k it writes: its components (+ the zero padding up to K32 for the last group)
+    float *slab0 = p.out + (size_t)src * Tl * K32 + kbase;
+    float *slab1 = slab0 + (size_t)p.nsrc * Tl * K32;
+    if (c0 >= p.TG) { // nothing spills into the last block
+        for (int e = tid; e < 128 * kw; e += 256) {
+            const int tt = e / kw, kk = e - tt * kw, t = c0 - 128 + tt;
+            if (t >= 0 && t < Tl) slab1[(size_t)t * K32 + kk] = 0.f;
+        }
+        return;
+    }
+    for (int r = tid; r < 32 * MBW; r += 256) {
+        const int kl = r / L;
+        rowk[r] = (short)(kl < kn ? kl : -1);
+        rowl[r] = (short)(r - kl * L);
+    }
+    for (int e = tid; e < 16 * SK_FOLD_COLS; e += 256) outs[e] = 0.f;
+
+    const int tb = c0 + wave * 32;
     const float *XT = src ? p.XT1 : p.XT0;
     const __amdgpu_buffer_rsrc_t ar = cmf_rsrc(p.Wj + mg * MBW * 32, ((size_t)(p.Np - 1) * p.JP + MBW * 32) * 4);
     const __amdgpu_buffer_rsrc_t br = cmf_rsrc(XT + p.PADL + tb, ((size_t)(p.Np - 1) * p.TP + 32) * 4);
@@ -249,32 +284,37 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_small_kernel(SkG
         round(a0, b0, a1, b1, rd);
         if (rd + 1 < nrounds) round(a1, b1, a0, b0, rd + 1);
     }
-    float *G = p.G + ((size_t)src * p.JP + mg * MBW * 32) * p.TG + tb;
-#pragma unroll
-    for (int mb = 0; mb < MBW; ++mb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) G[(size_t)(mb * 32 + cmf_crow(r, h)) * p.TG + i] = acc[mb][r];
-}
 
-// C3, second half: out[src][t][k] = sum_l G[src][l*K + k][t + l]  (k < K; zeros for K <= k < K32), t in [0, Tl).
-// grid (ceil(Tl/64), nsrc), 256 threads: thread (tt = tid % 64, kq = tid / 64) sums the components k = kq, kq + 4, ... of
-// column t (reads coalesced along t), the 64 x 32 tile goes out through LDS in rows of K32 (coalesced along k).
-__global__ __launch_bounds__(256) void fold_small_kernel(const float *G, float *out, int Tl, int K, int L, int K32, int JP, int TG)
-{
-    __shared__ float tile[64][33];
-    const int tt = threadIdx.x & 63, kq = threadIdx.x >> 6;
-    const int t0 = blockIdx.x * 64, src = blockIdx.y;
-    const float *Gs = G + (size_t)src * JP * TG;
-    for (int k = kq; k < 32; k += 4) {
-        float s = 0.f;
-        if (k < K && t0 + tt < Tl)
-            for (int l = 0; l < L; ++l) s += Gs[(size_t)(l * K + k) * TG + t0 + tt + l];
-        tile[tt][k] = s;
+    // the fold: thread c < 128 + L - 1 owns output column t = c0 - (L-1) + c
+    const int trel = tid - (L - 1);
+    const bool folder = tid < 128 + L - 1;
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb) {
+        __syncthreads(); // (the tables / the previous block's reads)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[cmf_crow(r, h) * SK_TILE_STRIDE + wave * 32 + i] = acc[mb][r];
+        __syncthreads();
+        if (folder) {
+            float s = 0.f;
+            int cur = -1;
+            for (int rl = 0; rl < 32; ++rl) {
+                const int k = rowk[mb * 32 + rl], col = trel + rowl[mb * 32 + rl];
+                if (k != cur) {
+                    if (cur >= 0) outs[cur * SK_FOLD_COLS + tid] += s;
+                    s = 0.f;
+                    cur = k;
+                }
+                if (k >= 0 && col >= 0 && col < 128) s += tile[rl * SK_TILE_STRIDE + col];
+            }
+            if (cur >= 0) outs[cur * SK_FOLD_COLS + tid] += s;
+        }
     }
     __syncthreads();
-    float *o = out + (size_t)src * Tl * K32;
-    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
-        const int t = e >> 5, k = e & 31;
-        if (t0 + t < Tl) o[(size_t)(t0 + t) * K32 + k] = tile[t][k];
+    for (int e = tid; e < 128 * kw; e += 256) {
+        const int tt = e / kw, kk = e - tt * kw;
+        const int t = c0 + tt; // own block: slab 0
+        if (t < Tl) slab0[(size_t)t * K32 + kk] = kk < kn ? outs[kk * SK_FOLD_COLS + tt + (L - 1)] : 0.f;
+        const int tp = c0 - 128 + tt; // previous block: slab 1 (its last L - 1 columns carry this tile's share)
+        if (tp >= 0 && tp < Tl) slab1[(size_t)tp * K32 + kk] = (kk < kn && tt >= 128 - (L - 1)) ? outs[kk * SK_FOLD_COLS + tt - (128 - (L - 1))] : 0.f;
     }
 }
