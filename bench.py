@@ -430,8 +430,10 @@ def free_port():
 
 
 def child_command(args, tag):
-    # (CMF_BENCH_FAKE_CHILD: the CPU tests of the supervisor put a stub in the measurement's place)
-    cmd = [sys.executable, os.environ.get("CMF_BENCH_FAKE_CHILD") or os.path.abspath(__file__), "--child", tag, "--gpus", str(args.gpus), "--steps", str(args.steps),
+    # (CMF_BENCH_FAKE_CHILD: the CPU tests of the supervisor put a stub in the measurement's place -- honoured only together with
+    # CMF_TEST_HOOKS=1, like the library's own test knobs, and the command that ran is recorded in `attempts`)
+    fake = os.environ.get("CMF_BENCH_FAKE_CHILD") if os.environ.get("CMF_TEST_HOOKS") == "1" else None
+    cmd = [sys.executable, fake or os.path.abspath(__file__), "--child", tag, "--gpus", str(args.gpus), "--steps", str(args.steps),
            "--warmup", str(args.warmup), "--config", str(args.config), "--cpu-seconds", str(args.cpu_seconds), "--sustain", str(args.sustain)]
     if args.T:
         cmd += ["--T", str(args.T)]
@@ -571,7 +573,7 @@ def supervise(args, form):
         agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
         try:
             base = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ["MASTER_PORT"]), world_size=None if agent else world,
-                            is_master=(rank == 0 and not agent), timeout=timedelta(seconds=300), wait_for_workers=False)
+                            is_master=(rank == 0 and not agent), timeout=timedelta(seconds=args.attempt_timeout + 60), wait_for_workers=False)
             store = PrefixStore(f"cmfbench/{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}/{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}/", base)
             store.set(f"hello/{rank}", "1")
             store.wait([f"hello/{r}" for r in range(world)])  # every supervising rank is there: from here on they walk the ladder together
@@ -580,10 +582,18 @@ def supervise(args, form):
                   file=sys.stderr, flush=True)
             return False
     attempts, line = [], None
+    t_ladder = time.time()
+
+    def say(msg):  # one flushed line per rung on stderr: a driver that kills the run at ITS limit still has the diagnosis in stderr_tail
+        print(f"bench.py supervisor rank {rank} [{time.time() - t_ladder:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
     for a, (label, child_form, extra) in enumerate(LADDER[form]):
-        rec = {"form": label, "env": extra}
+        rec = {"form": label, "env": extra, "child": os.path.basename(child_command(args, child_form)[1])}
+        # a total budget over the ladder: the forms that are left share what remains of (rungs x attempt timeout), never more than
+        # --attempt-timeout each -- the worst case stays bounded however the earlier rungs ended
         extra = dict(extra, CMF_BENCH_ATTEMPT=str(a))
         t0 = time.time()
+        say(f"attempt {a + 1}/{len(LADDER[form])}: {label} (limit {args.attempt_timeout:.0f} s)")
         if form == "multi" and child_form == "multi":
             ok, reason, out0, errs = run_attempt([(child_command(args, "multi"), child_env(extra))], args.attempt_timeout)
         elif form == "multi":  # bench.py is its own launcher: one child per GPU
@@ -613,13 +623,19 @@ def supervise(args, form):
             if not ok and (reason or "").startswith("FATAL"):
                 store.set(f"fatal{a}", "1")
             store.set(f"done{a}/{rank}", "ok" if ok else (reason or "failed"))
-            store.wait([f"done{a}/{r}" for r in range(world)])
-            states = [store.get(f"done{a}/{r}").decode() for r in range(world)]
+            try:
+                store.wait([f"done{a}/{r}" for r in range(world)])
+                states = [store.get(f"done{a}/{r}").decode() for r in range(world)]
+            except Exception as e:  # noqa: BLE001 - a rank that never reports (its child hung past every limit) fails the attempt, not the supervisor
+                states = [f"no report through the store within {args.attempt_timeout + 60:.0f} s ({type(e).__name__})" if r != rank else
+                          ("ok" if ok else (reason or "failed")) for r in range(world)]
             if ok and any(st_ != "ok" for st_ in states):
                 ok, reason = False, "; ".join(f"rank {r}: {st_}" for r, st_ in enumerate(states) if st_ != "ok")
             if any(st_.startswith("FATAL") for st_ in states) and not (reason or "").startswith("FATAL"):
                 reason = "FATAL: " + (reason or "")
         rec.update(ok=ok, seconds=round(time.time() - t0, 1))
+        say(f"attempt {a + 1}: {'ok' if ok else 'FAILED: ' + str(reason)} after {rec['seconds']} s"
+            + ("" if ok or not errs else "; child stderr: " + " | ".join(ln for e_ in errs for ln in e_["stderr_tail"][-2:])))
         got = last_json_line(out0) if rank == 0 else None
         if not ok:
             rec["ended"] = reason

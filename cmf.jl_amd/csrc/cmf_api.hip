@@ -1203,6 +1203,7 @@ struct CarryGuard { // error exits of cmf_iterate: leave no deferred reduction (
     ~CarryGuard()
     {
         if (!armed) return;
+        if (h && h->group) (void)group_join(h->group); // (enqueue workers may still be walking the batch: they read the carry records)
         drop_carry(h);
         if (h && h->group) h->group->num_ready = false;
     }

@@ -166,6 +166,7 @@ struct cmf_group_s {
     hipEvent_t ev_peer[2][2][CMF_MAX_LOCAL] = {};
     // enqueue workers (empty: the calling thread enqueues every shard itself)
     CmfWorkerPool pool;
+    int test_fail_shard = -1;             // test hook CMF_TEST_FAIL_SHARD (group_check_ready)
     int64_t enqueue_ns = 0, enqueue_iters = 0; // cmf_iterate: time the calling thread spent enqueueing / posting, and the iterations it covers
     int force_inline = 0;                // > 0: step lists run on the calling thread although workers exist (GroupInline)
     bool failed = false;                 // a wait for the group ran out (or a collective reported an error): streams and communicators
@@ -251,7 +252,9 @@ static bool group_wants_workers(const cmf_group_s *g)
 static int group_start_workers(cmf_group_s *g)
 {
     if (!g->pool.empty() || !group_wants_workers(g)) return CMF_OK;
-    g->pool.on_start = [g](size_t i) { (void)hipSetDevice(g->sh[i]->device); };
+    std::vector<int> devs;
+    for (cmf_handle_s *s : g->sh) devs.push_back(s->device);
+    g->pool.on_start = [devs](size_t i) { (void)hipSetDevice(devs[i]); }; // (by value: the closure lives in state the workers co-own)
     g->pool.last_error = []() { return g_err; };
     cmf_pool_start(g->pool, g->sh.size());
     return CMF_OK;
@@ -489,10 +492,8 @@ static int group_allgather(cmf_group_s *g, const std::vector<float *> &send, con
 static int shard_allreduce(cmf_group_s *g, size_t i, const std::vector<float *> &bufs, size_t off, size_t count, int lane)
 {
     const size_t nl = g->sh.size();
-    if (const char *hooks = getenv("CMF_TEST_HOOKS")) // tests: make one shard's collective call fail (honoured only with CMF_TEST_HOOKS=1)
-        if (atoi(hooks) == 1)
-            if (const char *e = getenv("CMF_TEST_FAIL_SHARD"))
-                if ((size_t)atoi(e) == i) return fail(CMF_ERR_STATE, "CMF_TEST_FAIL_SHARD: the all-reduce call of shard %zu was made to fail", i);
+    if (g->test_fail_shard >= 0 && (size_t)g->test_fail_shard == i) // tests (read by the calling thread in group_check_ready)
+        return fail(CMF_ERR_STATE, "CMF_TEST_FAIL_SHARD: the all-reduce call of shard %zu was made to fail", i);
     switch (g->transport) {
     case CMF_TR_RCCL:
         if (lane && g->comm2.size() != nl) return fail(CMF_ERR_STATE, "the communication stream has no communicator of its own");
@@ -693,6 +694,13 @@ static int group_gather_doubles(cmf_group_s *g, const std::vector<double> &vals,
 static int group_check_ready(cmf_group_s *g)
 {
     if (g->failed) return fail(CMF_ERR_COMM, "this group has failed (a collective did not complete, or a communicator reported an error): destroy the handle");
+    // test hook (honoured only with CMF_TEST_HOOKS=1): that shard's next all-reduce call fails.  The environment is read HERE, by
+    // the calling thread at a public entry -- never by the enqueue workers on the per-iteration path (getenv is not safe against
+    // a concurrent setenv of the host program)
+    g->test_fail_shard = -1;
+    if (const char *hooks = getenv("CMF_TEST_HOOKS"))
+        if (atoi(hooks) == 1)
+            if (const char *e = getenv("CMF_TEST_FAIL_SHARD")) g->test_fail_shard = atoi(e);
     for (cmf_handle_s *s : g->sh) {
         if (!s->factors_set) return fail(CMF_ERR_STATE, "factors not set: call cmf_set_factors first");
         if (!s->have_data) return fail(CMF_ERR_STATE, "handle was created without data");
@@ -1032,13 +1040,20 @@ static void bounded_stream_sync(hipStream_t st, bool failed)
 static void group_destroy(cmf_group_s *g)
 {
     if (!g) return;
-    (void)group_join(g); // (bounded; marks the group failed when a worker is stuck in a collective call)
-    group_stop_workers(g);
-    if (g->failed && g->transport == CMF_TR_RCCL && g_rccl.dl && g_rccl.CommAbort) { // unblocks collective kernels that wait for a peer
-        for (std::vector<ncclComm_t> *cs : {&g->comm, &g->comm2})
-            for (ncclComm_t &c : *cs)
-                if (c) { (void)g_rccl.CommAbort(c); c = nullptr; }
+    if (!g->failed) (void)group_join(g); // (bounded; marks the group failed when a worker is stuck in a collective call)
+    if (g->failed) {
+        // A failed group: FIRST abort the communicators -- that unblocks collective kernels that wait for a peer and wakes a worker
+        // out of a collective call that would never return -- THEN give the workers a short while to come back, and only detach
+        // one that still has not (its CmfWorker and the pool's shared state stay alive for it: cmf_workers.h).  (The full
+        // CMF_WAIT_TIMEOUT_S was already spent when the group was marked failed: not a second time here.)
+        if (g->transport == CMF_TR_RCCL && g_rccl.dl && g_rccl.CommAbort)
+            for (std::vector<ncclComm_t> *cs : {&g->comm, &g->comm2})
+                for (ncclComm_t &c : *cs)
+                    if (c) { (void)g_rccl.CommAbort(c); c = nullptr; }
+        g->pool.abort.store(true, std::memory_order_release);
+        if (!g->pool.empty()) (void)cmf_pool_wait(g->pool, 5.0);
     }
+    group_stop_workers(g); // (joins; abandon_busy only for a worker that is still inside its job)
     for (cmf_handle_s *s : g->sh) {
         (void)hipSetDevice(s->device);
         bounded_stream_sync(s->stream, g->failed);

@@ -36,19 +36,32 @@ struct CmfWorker {
     std::atomic<int64_t> busy_ns{0};        // time spent inside jobs
 };
 
-struct CmfWorkerPool {
-    std::vector<std::unique_ptr<CmfWorker>> w;
+// What a worker thread touches besides its own CmfWorker: co-owned by the pool and by every worker thread (shared_ptr), so
+// that a worker that had to be ABANDONED inside a call that never returned (cmf_pool_stop(..., true)) and wakes up later --
+// e.g. when its communicator is aborted -- never sees freed memory, whatever has happened to the pool's owner meanwhile.
+struct CmfPoolShared {
     std::atomic<bool> abort{false};         // a job failed (or a wait ran out): meeting points give up, batches are skipped
     std::atomic<int> bar_count{0}, bar_gen{0};
     std::function<void(size_t)> on_start;   // runs first on worker i's thread (bind the device)
     std::function<std::string()> last_error; // the calling thread's error text after a failed job (thread-local in the library)
+};
+
+struct CmfWorkerPool {
+    std::shared_ptr<CmfPoolShared> sh = std::make_shared<CmfPoolShared>();
+    std::vector<std::unique_ptr<CmfWorker>> w;
+    std::atomic<bool> &abort = sh->abort;
+    std::atomic<int> &bar_count = sh->bar_count, &bar_gen = sh->bar_gen;
+    std::function<void(size_t)> &on_start = sh->on_start;
+    std::function<std::string()> &last_error = sh->last_error;
+    CmfWorkerPool() = default;
+    CmfWorkerPool(const CmfWorkerPool &) = delete;
+    CmfWorkerPool &operator=(const CmfWorkerPool &) = delete;
     bool empty() const { return w.empty(); }
     size_t size() const { return w.size(); }
 };
 
-static void cmf_worker_main(CmfWorkerPool *pool, size_t i)
+static void cmf_worker_main(std::shared_ptr<CmfPoolShared> pool, CmfWorker *w, size_t i)
 {
-    CmfWorker *w = pool->w[i].get();
     if (pool->on_start) pool->on_start(i);
     unsigned idle = 0;
     for (;;) {
@@ -58,7 +71,9 @@ static void cmf_worker_main(CmfWorkerPool *pool, size_t i)
             if (++idle < 20000) { CMF_CPU_PAUSE(); continue; }
             std::unique_lock<std::mutex> lock(w->mu); // nothing for a while (~0.2 ms): sleep until the producer posts
             w->asleep.store(true, std::memory_order_seq_cst);
-            w->cv.wait(lock, [&] { return h != w->tail.load(std::memory_order_acquire) || w->quit.load(std::memory_order_acquire); });
+            // (seq_cst on both sides of the handshake with cmf_pool_post -- store asleep, load tail here; store tail, load asleep
+            // there -- so that at least one side sees the other's store on every architecture, not only on x86)
+            w->cv.wait(lock, [&] { return h != w->tail.load(std::memory_order_seq_cst) || w->quit.load(std::memory_order_acquire); });
             w->asleep.store(false, std::memory_order_seq_cst);
             idle = 0;
             continue;
@@ -83,7 +98,7 @@ static void cmf_worker_main(CmfWorkerPool *pool, size_t i)
 static void cmf_pool_start(CmfWorkerPool &pool, size_t n)
 {
     for (size_t i = 0; i < n; ++i) pool.w.emplace_back(new CmfWorker());
-    for (size_t i = 0; i < n; ++i) pool.w[i]->th = std::thread(cmf_worker_main, &pool, i);
+    for (size_t i = 0; i < n; ++i) pool.w[i]->th = std::thread(cmf_worker_main, pool.sh, pool.w[i].get(), i);
 }
 
 static void cmf_pool_post(CmfWorkerPool &pool, size_t i, std::function<int()> job)

@@ -82,3 +82,41 @@ def test_no_shipped_kernel_uses_scratch():
     assert not bad, bad
     big = {r["name"]: r for r in rows}
     assert big["void transconv_kernel<20>(TcParams)"]["vgpr"] + big["void transconv_kernel<20>(TcParams)"]["agpr"] <= 512
+
+
+def test_inventory_of_the_device_gated_multi_gpu_cases():
+    """The cases of tests/test_multi_gpu.py that need 2-8 distinct devices skip on a one-GPU box (31 `s` in the round-end run).
+    This CPU test counts them and checks that every one names, in its id, the launch form, the transport, who enqueues, what
+    runs and the device count -- so that the FIRST run on a node is attributable at a glance: a failing id reads
+    "one-process.rccl.caller.overlap.n4" (VERDICT round 4, item 5a)."""
+    import re
+    import subprocess
+
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_multi_gpu.py"), "--collect-only", "-q", "-m", "gpu"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=300)
+    ids = [ln.strip() for ln in p.stdout.splitlines() if "::" in ln]
+    assert ids, p.stdout + p.stderr
+    pat = re.compile(r"\[(one-process|per-process|bench-plain-launch)\.(rccl|peer)\.(workers|caller|ranks)\.([a-z_-]+)\.n([248])\]$")
+    gated = [i for i in ids if pat.search(i)]
+    assert len(gated) == 31, (len(gated), ids)
+    src = open(os.path.join(ROOT, "tests", "test_multi_gpu.py")).read()
+    for i in gated:  # ... and every one of them really is gated on the device count it names
+        fn = i.split("::")[1].split("[")[0]
+        body = src[src.index(f"def {fn}("):]
+        body = body[:body.index("\n\n\n") if "\n\n\n" in body else len(body)]
+        assert "_need_devices(n)" in body, fn
+    by = {}
+    for i in gated:
+        m = pat.search(i)
+        by.setdefault((m.group(1), m.group(2), m.group(3)), []).append(int(m.group(5)))
+    # every form x transport the library offers across devices appears at 2 devices AND at 8 (the driver's node)
+    for key in (("one-process", "rccl", "workers"), ("one-process", "rccl", "caller"), ("one-process", "peer", "workers"),
+                ("one-process", "peer", "caller"), ("per-process", "rccl", "ranks"), ("bench-plain-launch", "rccl", "workers")):
+        assert {2, 8} <= set(by[key]), (key, by.get(key))
+    # nothing that needs several devices hides behind an id that does not say so
+    others = [i for i in ids if i not in gated]
+    for i in others:
+        fn = i.split("::")[1].split("[")[0]
+        body = src[src.index(f"def {fn}("):]
+        body = body[:body.index("\n\n\n") if "\n\n\n" in body else len(body)]
+        assert "_need_devices(" not in body, fn

@@ -14,7 +14,7 @@ FAKE = os.path.join(ROOT, "tests", "_fake_bench_child.py")
 
 
 def run_bench(args, env_extra, timeout=120):
-    env = dict(os.environ, CMF_BENCH_FAKE_CHILD=FAKE, **env_extra)
+    env = dict(os.environ, CMF_BENCH_FAKE_CHILD=FAKE, CMF_TEST_HOOKS="1", **env_extra)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_USE_AGENT_STORE"):
         if k not in env_extra:
             env.pop(k, None)
@@ -82,7 +82,7 @@ def test_launcher_form_ranks_agree_through_the_store(tmp_path, plan, want_attemp
     log = tmp_path / "log"
     procs = []
     for r in range(2):
-        env = dict(os.environ, CMF_BENCH_FAKE_CHILD=FAKE, FAKE_PLAN=plan, FAKE_LOG=str(log), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+        env = dict(os.environ, CMF_BENCH_FAKE_CHILD=FAKE, CMF_TEST_HOOKS="1", FAKE_PLAN=plan, FAKE_LOG=str(log), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--attempt-timeout", "4"], env=env,
@@ -112,7 +112,7 @@ def test_supervisor_told_to_stop_takes_its_child_along(tmp_path):
     import time
 
     log = tmp_path / "log"
-    env = dict(os.environ, CMF_BENCH_FAKE_CHILD=FAKE, FAKE_PLAN="hang", FAKE_LOG=str(log))
+    env = dict(os.environ, CMF_BENCH_FAKE_CHILD=FAKE, CMF_TEST_HOOKS="1", FAKE_PLAN="hang", FAKE_LOG=str(log))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_USE_AGENT_STORE"):
         env.pop(k, None)
     p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -128,3 +128,31 @@ def test_supervisor_told_to_stop_takes_its_child_along(tmp_path):
     time.sleep(0.5)
     for k in kids:
         assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z", k
+
+
+def test_ladder_progress_goes_to_stderr_as_it_happens(tmp_path):
+    """One flushed stderr line when a rung starts and one when it ends: a driver that ends the run at
+    its own time limit still finds which form was running, and why the earlier ones ended, in the tail of stderr."""
+    p = run_bench(["--gpus", "2", "--attempt-timeout", "5"], {"FAKE_PLAN": "fail,ok"})
+    rec = the_line(p)
+    assert p.returncode == 0 and [a["ok"] for a in rec["attempts"]] == [False, True]
+    sup = [ln for ln in p.stderr.splitlines() if ln.startswith("bench.py supervisor rank 0")]
+    assert len(sup) == 4, p.stderr
+    assert "attempt 1/4: one process, an enqueue thread per GPU, RCCL (limit 5 s)" in sup[0]
+    assert "attempt 1: FAILED: child process(es) failed: #0 exit code 7" in sup[1] and "fake child: boom" in sup[1]
+    assert "attempt 2/4: one process, the calling thread enqueues every GPU" in sup[2] and "attempt 2: ok" in sup[3]
+    assert all(a["child"] == "_fake_bench_child.py" for a in rec["attempts"])  # the record says a stand-in ran
+
+
+def test_the_stand_in_child_needs_test_hooks(monkeypatch):
+    """CMF_BENCH_FAKE_CHILD alone must not replace the measurement (the library's own test knobs are gated the
+    same way)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    args = bench.parse_args(["--gpus", "2"])
+    monkeypatch.setenv("CMF_BENCH_FAKE_CHILD", FAKE)
+    monkeypatch.delenv("CMF_TEST_HOOKS", raising=False)
+    assert bench.child_command(args, "multi")[1] == os.path.join(ROOT, "bench.py")
+    monkeypatch.setenv("CMF_TEST_HOOKS", "1")
+    assert bench.child_command(args, "multi")[1] == FAKE

@@ -29,6 +29,13 @@ def _need_devices(n):
         pytest.skip(f"needs {n} HIP devices, this box has {have}")
 
 
+def _case(form, transport, who, what, n, *values):
+    """A device-count-gated case.  Its id names, in this order, the launch form (one-process | per-process | bench-plain-launch),
+    the transport (rccl | peer), who enqueues (workers | caller | ranks), what runs, and the device count -- so that the first
+    run on a node reads, failure by failure, as "which form on which transport" (tests/test_bench_routing.py checks the ids)."""
+    return pytest.param(*values, id=f"{form}.{transport}.{who}.{what}.n{n}")
+
+
 def _run(rule, mode, iters, kw):
     losses = [rule.compute_loss()]
     if mode == "calls":
@@ -42,8 +49,8 @@ def _run(rule, mode, iters, kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 4, 8])
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("n,overlap", [_case("one-process", "rccl", "workers", "overlap" if ov else "plain", n, n, ov)
+                                       for ov in (False, True) for n in (2, 4, 8)])
 def test_one_process_group_over_rccl(oracle, n, overlap):
     """MultUpdate(devices=range(n)) = cmf_create_multi over RCCL, vs the oracle (1e-4) and vs the same n-shard partition
     on loopback shards of GPU 0 (1e-5: same kernels, same shard shapes -- only the all-reduce's summation order differs)."""
@@ -75,8 +82,9 @@ def test_one_process_group_over_rccl(oracle, n, overlap):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 4, 8])
-@pytest.mark.parametrize("transport,threads,overlap", [("rccl", 0, False), ("rccl", 0, True), ("peer", 1, False), ("peer", 0, True), ("peer", 1, True)])
+@pytest.mark.parametrize("n,transport,threads,overlap", [
+    _case("one-process", tr, "workers" if th else "caller", "overlap" if ov else "plain", n, n, tr, th, ov)
+    for tr, th, ov in (("rccl", 0, False), ("rccl", 0, True), ("peer", 1, False), ("peer", 0, True), ("peer", 1, True)) for n in (2, 4, 8)])
 def test_one_process_group_forms_on_distinct_devices(oracle, n, transport, threads, overlap):
     """The forms of a one-process group that round 4 added, on DISTINCT devices: the calling thread enqueueing every shard
     with grouped RCCL calls (enqueue_threads = 0; the default -- a worker thread per device, RCCL's one-thread-per-device mode --
@@ -114,7 +122,7 @@ def test_one_process_group_forms_on_distinct_devices(oracle, n, transport, threa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 4, 8])
+@pytest.mark.parametrize("n", [_case("one-process", "rccl", "workers", "fit-and-shard-shapes", n, n) for n in (2, 4, 8)])
 def test_one_process_group_fit_and_shard_shapes(oracle, n):
     """cmf_fit (pipelined and with the convergence test) on an RCCL group of distinct devices, a T that does not divide
     evenly, K not a multiple of 32."""
@@ -138,8 +146,9 @@ def test_one_process_group_fit_and_shard_shapes(oracle, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,mode,overlap", [(2, "calls", False), (2, "iterate", True), (4, "iterate", False), (8, "iterate", False),
-                                            (2, "fit_timed", False)])
+@pytest.mark.parametrize("n,mode,overlap", [_case("per-process", "rccl", "ranks", mode + ("-overlap" if ov else ""), n, n, mode, ov)
+                                            for n, mode, ov in ((2, "calls", False), (2, "iterate", True), (4, "iterate", False),
+                                                                (8, "iterate", False), (2, "fit_timed", False))])
 def test_one_process_per_gpu_over_rccl(oracle, tmp_path, n, mode, overlap):
     """n processes, rank r on GPU r (LOCAL_RANK=r), torch.distributed `nccl` as the rendezvous, the library's own
     ncclCommInitRank communicator for the data path: ShardedMultUpdate against the oracle."""
@@ -156,7 +165,7 @@ def test_one_process_per_gpu_over_rccl(oracle, tmp_path, n, mode, overlap):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 8])
+@pytest.mark.parametrize("n", [_case("bench-plain-launch", "rccl", "workers", "supervised-ladder", n, n) for n in (2, 8)])
 def test_bench_plain_multi_gpu_launch(n):
     """`python bench.py --gpus n` with no launcher: the one-process form runs, RCCL reports n ranks in `comm`."""
     _need_devices(n)
