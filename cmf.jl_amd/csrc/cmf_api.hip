@@ -153,6 +153,7 @@ struct cmf_handle_s {
     int sk_J = 0, sk_JP = 0, sk_MG = 1, sk_MBW = 4, sk_chunk_len = 16, sk_ngroups = 1, sk_TG = 128;
     int sk3_MG = 1, sk3_MBW = 4, sk3_Kg = 1, sk3_JP = 128; // C3: whole components per row group (g_gemm_fold_small_kernel)
     float *sk_slabs = nullptr, *sk_Wj = nullptr;
+    bool sk_wj_fresh = false;               // sk_Wj holds the resident W (written by w_update_small_kernel; every other writer of W clears it)
     int tc_S_full = 1, tc_S1_full = 1;      // fragment slabs of the general transconv kernel (tc_S / tc_S1 are 1 while small_k is on)
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
     int conv_variant = 0;   // K % 32 == 0: 3 = one-wave workgroups (conv3_kernel), 2 = 128 x 128 tiles (conv2_kernel), 0 = per mode
@@ -710,9 +711,11 @@ static int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
 {
     ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_TRANSCONV_1);
     const CmfDims &d = h->d;
-    hipLaunchKernelGGL(wj_pack_kernel, dim3((unsigned)std::min<size_t>(1024, ((size_t)d.Np * h->sk3_JP + 255) / 256)), dim3(256), 0, h->stream,
-                       h->Wn, h->sk_Wj, d.Np, d.K, d.L, d.K32, h->sk3_Kg, 32 * h->sk3_MBW, h->sk3_JP);
-    KCHK("wj_pack_kernel");
+    if (!h->sk_wj_fresh) { // (w_update_small_kernel writes the packed operand itself; every other writer of W leaves it stale)
+        hipLaunchKernelGGL(wj_pack_kernel, dim3((unsigned)std::min<size_t>(1024, ((size_t)d.Np * h->sk3_JP + 255) / 256)), dim3(256), 0, h->stream,
+                           h->Wn, h->sk_Wj, d.Np, d.K, d.L, d.K32, h->sk3_Kg, 32 * h->sk3_MBW, h->sk3_JP);
+        KCHK("wj_pack_kernel");
+    }
     SkGemmParams p;
     p.Wj = h->sk_Wj; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.out = h->hslabs;
     p.TP = d.TP; p.PADL = d.PADL; p.JP = h->sk3_JP; p.MG = h->sk3_MG; p.TG = h->sk_TG; p.N2 = (int)rup(d.N, 2); p.Np = d.Np; p.nsrc = nsrc;
@@ -769,7 +772,7 @@ static int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nsl
 
 // The C2 contraction of one (nsrc = 1: X0) or two sources with H_shift, complete: kernel, slab sum, and the rows the kernel
 // leaves to the slab sum.   out: [nsrc][L][K32][Np]
-static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int nsrc, float *out, bool take_carry = false)
+static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int nsrc, float *out, bool take_carry = false, bool slabs_only = false)
 {
     const CmfDims &d = h->d;
     if (h->small_k) { // few components: the rows j = l*K + k on the MFMA axis (hxt_small_kernel), compact slabs, their sum expanded to [L][K32][Np]
@@ -788,6 +791,7 @@ static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int n
         default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk_MBW);
         }
         KCHK("hxt_small_kernel");
+        if (slabs_only) return CMF_OK; // (the caller's next launch sums the slabs itself: w_update_small_kernel)
         CmfLossCarry carry{};
         if (take_carry && h->carry.partial) { // a loss reduction deferred by cmf_iterate rides on this launch
             carry = h->carry;
@@ -853,8 +857,43 @@ static int w_partial_half_impl(cmf_handle_s *h, int den)
 }
 
 // den == NULL: denomW lies behind numW in h->numden (the layout of the [numW | denomW] all-reduce buffer)
+static int w_apply_impl_(cmf_handle_s *h, double l1W, double l2W, const float *tail_src, float *tail_dst, int tail_n, const float *den);
 static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W, const float *tail_src = nullptr, float *tail_dst = nullptr, int tail_n = 0,
                         const float *den = nullptr)
+{
+    h->sk_wj_fresh = false;
+    return w_apply_impl_(h, l1W, l2W, tail_src, tail_dst, tail_n, den);
+}
+
+// update_motifs! of the MU rule on a single handle (mult.jl:23-39).  Few components: conv (unless est is current), the C2
+// kernel, and ONE launch that sums its slabs, updates W and packs the C3 operand (w_update_small_kernel).
+static int w_phase_impl(cmf_handle_s *h, double l1W, double l2W)
+{
+    const CmfDims &d = h->d;
+    static const bool fuse = !(getenv("CMF_SMALL_K_FUSE_W") && atoi(getenv("CMF_SMALL_K_FUSE_W")) == 0); // measurement knob
+    if (!(h->small_k && fuse)) {
+        CMFTRY(w_partial_impl(h));
+        return w_apply_impl(h, l1W, l2W);
+    }
+    if (!(h->reuse_est && h->est_kind == 1))
+        CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
+    h->est_kind = 1;
+    CMFTRY(hxt_contract(h, h->X, h->est, 2, nullptr, false, true)); // mult.jl:31-34: the slabs only
+    CmfLossCarry carry{};
+    if (h->carry.partial) { // a loss reduction deferred by cmf_iterate rides on this launch
+        carry = h->carry;
+        h->carry = CmfLossCarry{};
+    }
+    hipLaunchKernelGGL(w_update_small_kernel, dim3(d.Np / 64, d.L), dim3(256), 0, h->stream, h->Wt, h->Wn, h->sk_tc ? h->sk_Wj : nullptr, h->sk_slabs,
+                       h->sk_ngroups, d.N, d.K, d.L, d.Np, d.K32, h->sk_JP, h->sk3_Kg, 32 * h->sk3_MBW, h->sk3_JP,
+                       (float)l1W, (float)(2.0 * l2W), carry); // mult.jl:37-38
+    KCHK("w_update_small_kernel");
+    h->est_kind = 0;
+    h->sk_wj_fresh = h->sk_tc;
+    return CMF_OK;
+}
+
+static int w_apply_impl_(cmf_handle_s *h, double l1W, double l2W, const float *tail_src, float *tail_dst, int tail_n, const float *den)
 {
     const CmfDims &d = h->d;
     dim3 grid(d.Np / 64, d.KB, d.L);
@@ -903,6 +942,7 @@ static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = tru
 static int set_factors_impl(cmf_handle_s *h, const double *W, const double *H)
 {
     if (!h || !W || !H) return fail(CMF_ERR_ARG, "NULL argument");
+    h->sk_wj_fresh = false;
     HIPCHK(hipSetDevice(h->device));
     const CmfDims &d = h->d;
     const size_t nW = (size_t)d.L * d.N * d.K, nH = (size_t)d.Tl * d.K;
@@ -1419,6 +1459,7 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->small_k = value != 0 && h->small_k_ok;
+        h->sk_wj_fresh = false;
         h->sk_tc = h->small_k && (h->sk_tc_ok || value == 2); // (2: the few-component C3 form whatever T is -- tests, measurements)
         h->tc_S = h->sk_tc ? 2 : h->tc_S_full; // (own block | the spill of the next block: g_gemm_fold_small_kernel)
         h->tc_S1 = h->sk_tc ? 2 : h->tc_S1_full;
@@ -1478,8 +1519,7 @@ int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
     CMFTRY(check_ready(h, true));
     if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator first (cmf_comm_init_rccl / cmf_comm_init_callbacks), or build the group with cmf_create_multi");
     if (h->gram) return gram_w_impl(h, l1W, l2W);
-    CMFTRY(w_partial_impl(h));
-    return w_apply_impl(h, l1W, l2W);
+    return w_phase_impl(h, l1W, l2W);
 }
 
 static int update_feature_maps_body(cmf_handle h, double l1H, double l2H, double *loss)
@@ -1712,8 +1752,7 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
             if (h->gram) {
                 CMFTRY(gram_w_impl(h, l1W, l2W));
             } else {
-                CMFTRY(w_partial_impl(h));
-                CMFTRY(w_apply_impl(h, l1W, l2W));
+                CMFTRY(w_phase_impl(h, l1W, l2W));
             }
         }
         RoctxRange h_range("cmf:H phase + loss conv (update_feature_maps!)");
@@ -2195,6 +2234,7 @@ static int compute_hh(cmf_handle_s *h, float *out = nullptr)
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
 {
     const CmfDims &d = h->d;
+    h->sk_wj_fresh = false;
     CMFTRY(hals_ensure(h));
     // G = resid * H_unfold' (hals.jl:104-110 needs resid * h).  resid = est - data, so G = denomW - numW of the MU path:
     // numW = H_shift * data' is ONE C2 contraction on the data, denomW = H_shift * est' = HH * W a small GEMM on the Gram
@@ -2602,6 +2642,7 @@ static int pgd_unit_norm(cmf_handle_s *h, bool is_W)
 static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg)
 {
     const CmfDims &d = h->d;
+    h->sk_wj_fresh = false;
     CMFTRY(pgd_check(h));
     if (nonneg < 0 || nonneg > 2) return fail(CMF_ERR_ARG, "constraint must be 0 (none), 1 (NonnegConstraint) or 2 (UnitNormConstraint)");
     const float gscale = h->pgd_loss_abs ? 1.f : 2.f; // pgd.jl:31-33 vs :42-44
@@ -3132,7 +3173,8 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
             CMFTRY(first ? launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext) : launch_conv<3>(h, h->est, d.Tl, h->conv_gy));
             h->stream = pair ? aux : keep;
             int rc = first ? launch_transconv(h, 1, h->XT)
-                           : launch_hxt_on(h, h->X, h->X, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1, h->hxt_main1);
+                           : h->small_k ? hxt_contract(h, h->X, h->X, 1, h->numden) // (few components: kernel + its slab sum)
+                                        : launch_hxt_on(h, h->X, h->X, d.Np, 1, h->wslabs, h->hxt_nchunks1, h->hxt_chunk_len1, h->hxt_main1);
             h->stream = keep;
             CMFTRY(rc);
             if (pair) {

@@ -377,13 +377,6 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvParams p)
 template <int NBL = 2, int NKP = 16>
 __device__ __forceinline__ void conv2_load_w(float (&w)[NKP][2], __amdgpu_buffer_rsrc_t wr, int woff, int lag, int lagbytes, int rowbytes)
 {
-#ifdef CMF_CONV_KNOCKOUT // timing experiments only (tools/conv_knockout.py): 1 = W loaded for lag 0 only
-    if ((CMF_CONV_KNOCKOUT & 1) && lag != 0) {
-#pragma unroll
-        for (int kp = 0; kp < NKP; ++kp) { asm volatile("" : "+v"(w[kp][0])); asm volatile("" : "+v"(w[kp][1])); }
-        return;
-    }
-#endif
 #pragma unroll
     for (int kp = 0; kp < NKP; ++kp) {
         w[kp][0] = cmf_bload(wr, woff, lag * lagbytes + kp * 2 * rowbytes);
@@ -402,9 +395,6 @@ __device__ __forceinline__ void conv2_lag(f32x16 (&acc)[2][2], const float *hsb,
 #pragma unroll
     for (int kp = 0; kp < NKP; ++kp) {
         float na0 = 0.f, na1 = 0.f;
-#ifdef CMF_CONV_KNOCKOUT // 2 = one H operand read per lag instead of sixteen
-        if (CMF_CONV_KNOCKOUT & 2) { na0 = a0; na1 = a1; asm volatile("" : "+v"(na0), "+v"(na1)); } else
-#endif
         if (kp + 1 < NKP) {
             na0 = hsb[(kp + 1) * 2 * STRIDE];
             na1 = hsb[(kp + 1) * 2 * STRIDE + 32];
@@ -467,20 +457,10 @@ __device__ __forceinline__ void conv2_clear_dead(f32x16 (&acc)[2][2])
     }
 }
 
-#ifdef CMF_CONV_STAMPS
-// debug builds only (tools/conv_stamps.hip): s_memtime stamps + HW_ID / XCC_ID per workgroup, 8 slots each
-__device__ unsigned long long *cmf_stamps;
-#define CMF_STAMP(slot) do { if (threadIdx.x == 0) { unsigned long long *st_ = cmf_stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8; \
-    st_[slot] = __builtin_amdgcn_s_memrealtime(); \
-    if ((slot) == 0) { st_[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); } } } while (0)
-#else
-#define CMF_STAMP(slot) do { } while (0)
-#endif
 
 template <int MODE>
 __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
 {
-    CMF_STAMP(0);
     __shared__ __attribute__((aligned(16))) float Hs[CONV_HS_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -506,11 +486,8 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
             const int npair = (lend - lbeg + 1) >> 1; // lags are processed in pairs; Wt is zero-padded to Lp
             // descriptor base: Wt[lbeg][kb*32][0]
             const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wt + ((size_t)lbeg * K32 + kb * 32) * Np, (size_t)(2 * npair) * lagbytes);
-            CMF_STAMP(5);
             if (!half) conv2_load_w<2>(wA, wr, woff, 0, lagbytes, rowbytes); else conv2_load_w<1>(wA, wr, woff, 0, lagbytes, rowbytes);
-            CMF_STAMP(6);
             __syncthreads(); // everyone is done with Hs of the previous block
-            CMF_STAMP(7);
             {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,160): 8 threads per row, 5 float4 each
                 const int r = tid >> 3, c = (tid & 7) * 4;
                 const float *src = p.Ht + (size_t)(kb * 32 + r) * TP + (p.PADL + t0 - lbeg - 32 + c);
@@ -522,16 +499,13 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
                 for (int j = 0; j < 5; ++j) *reinterpret_cast<f32x4 *>(dst + 32 * j) = v[j];
             }
             __syncthreads();
-            CMF_STAMP(1);
             const float *hsb = Hs + h * CONV_HS_STRIDE + 32 + wt * 64 + i;
             if (!half) conv2_lag_pairs<MODE, CONV_HS_STRIDE, 2>(acc, hsb, wA, wB, wr, woff, npair, kb == 0 && lb == 0, lagbytes, rowbytes);
             else conv2_lag_pairs<MODE, CONV_HS_STRIDE, 1>(acc, hsb, wA, wB, wr, woff, npair, kb == 0 && lb == 0, lagbytes, rowbytes);
         }
     }
     if (half) conv2_clear_dead<MODE>(acc);
-    CMF_STAMP(2);
     conv_epilogue<MODE>(acc, p, t0, n0, wt, wn, i, h, lane, wave, tid);
-    CMF_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -992,9 +966,6 @@ __device__ __forceinline__ void hxt_group(f32x16 (&acc)[2 * LP], const float (&E
     }
 }
 
-#ifndef CMF_HXT_INTERLEAVE
-#define CMF_HXT_INTERLEAVE 1
-#endif
 template <int LP>
 __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
 {
@@ -1055,7 +1026,6 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
         // The 3*LP loads of a group go one per two MFMAs beside its first 6*LP MFMAs (they are needed a group later, so they must not
         // trail to the end of this one): the two waves of a SIMD run in lockstep, and a burst of loads at the top of the
         // group leaves the MFMA pipe idle in both.
-#if CMF_HXT_INTERLEAVE
 #define HXT_SCHED()                                                                   \
     do {                                                                              \
         constexpr int per = (2 * LP * LP >= 9 * LP) ? 2 : ((2 * LP * LP >= 6 * LP) ? 1 : 0); /* the loads stay in the first part of the group */ \
@@ -1066,21 +1036,15 @@ __global__ __launch_bounds__(256, 1) void hxt_kernel(HxtParams p)
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * LP * LP - per * 3 * LP, 0);   \
         __builtin_amdgcn_sched_barrier(0);                                            \
     } while (0)
-#else
-#define HXT_SCHED() do { } while (0)
-#endif
         for (int g = 0; g < ngroups; g += 3) {
             const int g3 = (g + 3 < ngroups) ? g + 3 : g;
             hxt_load<LP>(E2, O2, B2, hr, xr, hoff, xoff, 2 * LP * (g + 2), K32, Np);
-            if (!CMF_HXT_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
             hxt_group<LP>(acc, E0, O0, E1, O1, B1);
             HXT_SCHED();
             hxt_load<LP>(E0, O0, B0, hr, xr, hoff, xoff, 2 * LP * (g + 3), K32, Np);
-            if (!CMF_HXT_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
             hxt_group<LP>(acc, E1, O1, E2, O2, B2);
             HXT_SCHED();
             hxt_load<LP>(E1, O1, B1, hr, xr, hoff, xoff, 2 * LP * (g3 + 1), K32, Np);
-            if (!CMF_HXT_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);
             hxt_group<LP>(acc, E2, O2, E0, O0, B0);
             HXT_SCHED();
         }
@@ -1155,9 +1119,6 @@ struct TcParams {
     const int4 *wtab; // [W] per wave: {first pair, first chunk in it, number of chunk units, fragment index of the first segment}
 };
 
-#ifndef CMF_TC_GLDS
-#define CMF_TC_GLDS 1 // X chunks go global -> LDS directly (no register stop-over): 157 VGPRs, 3 waves per SIMD
-#endif
 #define TC_ROW 160
 #define TC_CHUNK (8 * TC_ROW)
 
@@ -1225,7 +1186,6 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
     const int LB = (p.L + 31) >> 5;
     const size_t lagstride = (size_t)Np * K32;
     const int lagbytes = (int)(lagstride * 4);
-#if CMF_TC_GLDS
     // LDS byte address of this wave's region (wave-uniform)
     const unsigned lds_S = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)S);
     unsigned xoff[5]; // byte offset of this lane's float4 of an 8 x 160 chunk: element idx = lane + 64 q -> (row, column)
@@ -1234,7 +1194,6 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
         int idx = lane + 64 * q, row = idx / 40, c4 = idx - row * 40;
         xoff[q] = (unsigned)(row * TP + c4 * 4) * 4u;
     }
-#endif
 
     while (left > 0) {
         // pair index -> (t block, k block, source); the source is the fastest index
@@ -1254,20 +1213,11 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
 
         for (int lb = 0; lb < LB; ++lb) {
             const float *xsrc = XT + (size_t)nlo * TP + (p.PADL + t0 + 32 * lb);
-#if CMF_TC_GLDS
             // chunk 0 straight into LDS buffer 0 (global_load_lds: wave-uniform LDS base + lane * 16 bytes, which is
             // exactly the strip's layout: element idx = lane + 64 q of the 8 x 160 chunk)
             __builtin_amdgcn_wave_barrier(); // lag block > 0: the previous block's LDS reads are done
 #pragma unroll
             for (int q = 0; q < 5; ++q) cmf_glds16(reinterpret_cast<const char *>(xsrc) + xoff[q], lds_S + q * 1024);
-#else
-            f32x4 xr[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                int idx = lane + 64 * q, row = idx / 40, c4 = idx - row * 40;
-                xr[q] = *reinterpret_cast<const f32x4 *>(xsrc + (size_t)row * TP + c4 * 4);
-            }
-#endif
             // W operand for n pair `it`: Wn[lb*32 + l][nlo + 2*it + h][kb*32 + i]  (descriptor base: lag lb*32)
             const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wn + (size_t)(lb * 32) * lagstride, (size_t)LT * lagstride * 4);
             const int woff = (h * K32 + kb * 32 + i) * 4;
@@ -1276,7 +1226,6 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
             int buf = 0;
             for (int c = 0; c < nchunks; ++c) {
                 float *Sb = S + buf * TC_CHUNK;
-#if CMF_TC_GLDS
                 // chunk c was issued one iteration ago; only the W prefetch (LT loads) is younger
                 __builtin_amdgcn_s_waitcnt(0x0F70 | (LT & 15) | ((LT >> 4) << 14)); // vmcnt(LT), expcnt/lgkmcnt untouched
                 __builtin_amdgcn_wave_barrier();
@@ -1286,22 +1235,6 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
 #pragma unroll
                     for (int q = 0; q < 5; ++q) cmf_glds16(reinterpret_cast<const char *>(xs2) + xoff[q], Sn + q * 1024);
                 }
-#else
-#pragma unroll
-                for (int q = 0; q < 5; ++q)
-                    *reinterpret_cast<f32x4 *>(Sb + (lane + 64 * q) * 4) = xr[q];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                {   // next 8-row chunk into registers (clamped at the end of the range)
-                    const int cn = (c + 1 < nchunks) ? c + 1 : c;
-                    const float *xs2 = xsrc + (size_t)(8 * cn) * TP;
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) {
-                        int idx = lane + 64 * q, row = idx / 40, c4 = idx - row * 40;
-                        xr[q] = *reinterpret_cast<const f32x4 *>(xs2 + (size_t)row * TP + c4 * 4);
-                    }
-                }
-#endif
                 const int nrow = nlo + 8 * c;
                 const float *sa = Sb + h * TC_ROW + i;
                 tc_load_w<LT>(b1, wr, woff, nrow + 2, K32, lagbytes);

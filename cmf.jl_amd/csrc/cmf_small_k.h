@@ -178,6 +178,44 @@ __global__ __launch_bounds__(256) void slab_sum_small_kernel(float *out, const f
     if (carry.partial && blockIdx.x == gridDim.x - 1) cmf_block_loss_reduce(carry);
 }
 
+// E1 for few components on a single handle, in ONE launch behind the C2 kernel: the slabs of hxt_small_kernel are summed
+// (slab order, exactly as slab_sum_small_kernel adds them: bitwise the same numW / denomW), W is updated (mult.jl:37-38) in
+// both layouts, and the A operand of the C3 GEMM (Wj, layout of wj_pack_kernel) is written from the same values -- the slab
+// sum, the update and the pack were three launches of 5-7 us each on a 270 us iteration.  The last block also performs a loss
+// reduction deferred by cmf_iterate.  slabs: [nslabs][2][JP][Np].  grid (Np/64, L), block 256: thread (n = tid % 64, k = tid / 64 + 4 q).
+__global__ __launch_bounds__(256) void w_update_small_kernel(float *Wt, float *Wn, float *Wj, const float *slabs, int nslabs,
+                                                              int N, int K, int L, int Np, int K32, int JP, int Kg, int GR, int JP3,
+                                                              float l1, float two_l2, CmfLossCarry carry)
+{
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), l = blockIdx.y;
+    const size_t sstride = (size_t)2 * JP * Np;
+    for (int k = threadIdx.x >> 6; k < K; k += 4) {
+        const float *bn = slabs + (size_t)(l * K + k) * Np + n, *bd = bn + (size_t)JP * Np;
+        float num = bn[0], den = bd[0];
+        for (int s = 1; s < nslabs; s += 4) { // four slabs in flight, added in slab order
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t o = (size_t)((s + u < nslabs) ? s + u : s) * sstride;
+                a[u] = bn[o];
+                b[u] = bd[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s + u < nslabs) { num += a[u]; den += b[u]; }
+        }
+        const size_t it = ((size_t)l * K32 + k) * Np + n;
+        const float wn = (n < N) ? cmf_mu(Wt[it], num, den, l1, two_l2) : 0.f;
+        Wt[it] = wn;
+        Wn[((size_t)l * Np + n) * K32 + k] = wn;
+        if (Wj) {
+            const int g = k / Kg;
+            Wj[(size_t)n * JP3 + g * GR + (k - g * Kg) * L + l] = wn;
+        }
+    }
+    if (carry.partial && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) cmf_block_loss_reduce(carry);
+}
+
 // C3 puts whole components into a row group: group g holds the components [g*Kg, (g+1)*Kg), its row kl*L + l is
 // (component g*Kg + kl, lag l), padded with zero rows to 32*MBW -- k-major, so that the L rows a folded output needs lie next to
 // each other (at most three components per 32-row block at L = 20) and no output is shared between two row groups.

@@ -144,6 +144,53 @@ def test_hals_ten_iterations_at_config5_n_k_l(cmf, oracle, name):
         assert differ <= 1e-4 * np.asarray(b).size, differ
 
 
+def test_hals_over_the_plateau(cmf, oracle):
+    """HALS at BASELINE configs[4]'s N, K, L (2000, 32, 20) on T = 5000 columns for 40 iterations -- past the fast descent
+    (loss 0.558 -> 0.178 in 10 iterations) onto the plateau where exact zeros set in and stay (0.1740 -> 0.1732 over the last 15).
+    The reference CARRIES the residual across iterations (src/algs/hals.jl:37-42: rule.resids is updated in place by every
+    column / entry update) where the HIP path recomputes est per phase, so a drift would behave differently from the MU rule's:
+    this pins it against the fp64 C restatement's committed run (one residual array carried through all 40 iterations,
+    tests/golden/make_golden_full.py hals_plateau; numpy cross-check at iteration 1, equality with the oracle_fit_hals fixture
+    at iteration 10) at the snapshots 10, 20 and 40: the north star's 1e-4 on W, H and every loss so far, and the pattern of
+    exact zeros (clamp at 0: hals.jl:110,153).  Prints the drift curve."""
+    path = os.path.join(GOLDEN, "fit_hals_n2000_40.npz")
+    if not os.path.exists(path):
+        pytest.fail(f"{path} is missing: run tests/golden/make_golden_full.py hals_plateau")
+    g = np.load(path)
+    data, W0, H0, (N, T, K, L) = fixture_inputs(oracle, g)
+    n = int(g["max_itr"])
+    want = {int(it): (g[f"W_{int(it)}"], g[f"H_{int(it)}"]) for it in g["snaps"]}
+    want[n] = (g["W"], g["H"])
+    lr = g["loss_hist"]
+    rule = cmf.HALSUpdate(data, W0, H0)
+    curve = []
+    try:
+        loss = [rule.compute_loss()]
+        for it in range(1, n + 1):
+            rule.update_motifs()
+            loss.append(rule.update_feature_maps())
+            if it in want:
+                W, H = rule.download()
+                Wr, Hr = want[it]
+                relW, relH = frob_rel(W, Wr), frob_rel(H, Hr)
+                rel_loss = float(np.max(np.abs(np.asarray(loss) - lr[: it + 1]) / lr[: it + 1]))
+                zW = int(np.count_nonzero((W == 0) != (Wr == 0)))
+                zH = int(np.count_nonzero((H == 0) != (Hr == 0)))
+                curve.append((it, relW, relH, rel_loss, zW, zH, int(np.count_nonzero(Wr == 0)), int(np.count_nonzero(Hr == 0))))
+                assert relW < REL_FACTORS and relH < REL_FACTORS, curve[-1]
+                assert rel_loss < REL_LOSS, curve[-1]
+                # an entry that is exactly zero in fp64 may be a rounding-level positive in fp32 (and vice versa) only where the
+                # unclamped value is at rounding level: the share of such entries must stay negligible all along the plateau
+                assert zW <= 1e-4 * Wr.size and zH <= 1e-4 * Hr.size, curve[-1]
+        assert rule.counter("hals_pipeline_reruns") == 0
+    finally:
+        rule.close()
+    for it, relW, relH, rel_loss, zW, zH, nzW, nzH in curve:
+        print(f"HALS plateau N={N} T={T} K={K} L={L}, after {it:2d} iterations (loss {lr[it]:.5f}): relW {relW:.2e} relH {relH:.2e} "
+              f"max rel loss {rel_loss:.2e}; exact zeros W {nzW} H {nzH}, status differs in {zW} / {zH} entries")
+    assert [c[0] for c in curve] == sorted(want)
+
+
 @pytest.mark.parametrize("ext", ["h5", "npz"])
 def test_fit_to_disk_and_warm_start(cmf, oracle, tmp_path, ext):
     """SURVEY 8 f3 (src/model.jl:149-181 dataset names; :72-73 W_init / H_init): a fit on the HIP path goes to disk in the
