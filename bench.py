@@ -240,17 +240,17 @@ def other_configs(cmf, rule, data, W0, H0, N, T, K, L, with_config3, device):
             d_ = cmf.gen_synthetic(N=N_, T=T_, seed=1234, device=device)
             W_, H_ = cmf.init_rand(d_, L=L_, K=K_, seed=0, device=device)
             f1_ = 2.0 * K_ * N_ * (L_ * T_ - L_ * (L_ - 1) / 2)
-            rec = {"workload": f"N={N_} T={T_} K={K_} L={L_} alg=:mult ({what})", "steps": 50, "warmup": 3, "useful_flops_per_contraction": f1_}
+            rec = {"workload": f"N={N_} T={T_} K={K_} L={L_} alg=:mult ({what})", "steps": 200, "warmup": 20, "useful_flops_per_contraction": f1_}
             for small in (1, 0):
                 r_ = cmf.MultUpdate(d_, W_, H_, device=device)
                 try:
                     r_.set_option("small_k", small)
-                    r_.iterate(3, **zero)
+                    r_.iterate(20, **zero)  # (iterations of 0.06-0.3 ms: the first ten milliseconds of a loop run 4 % slower than its steady state)
                     r_.synchronize()
                     t0 = time.perf_counter()
-                    ls = r_.iterate(50, **zero)
+                    ls = r_.iterate(200, **zero)
                     r_.synchronize()
-                    dt_ = (time.perf_counter() - t0) / 50
+                    dt_ = (time.perf_counter() - t0) / 200
                     if small:
                         ks = {}
                         for nm in ("conv_t", "conv_loss_store", "hxt", "transconv"):

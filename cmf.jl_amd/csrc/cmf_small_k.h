@@ -76,9 +76,46 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void hxt_small_kernel(SkHxtP
     xrows = xrows < 0 ? 0 : (xrows > p.chunk_len + 2 ? p.chunk_len + 2 : xrows);
     const __amdgpu_buffer_rsrc_t xr = cmf_rsrc(X + (size_t)(p.PADL + (xrows ? tc0 : 0)) * Np, (size_t)xrows * Np * 4);
     const int xoff = (h * Np + nb * 32 + i) * 4;
+    // The X operands run through a ring of NS register sets of 8 rows pairs (one round = 16 time rows = 8 MFMA steps): the set
+    // of round r is loaded NS - 1 rounds ahead -- across the strip boundaries too -- because these loads come from HBM (every X
+    // element is used by exactly one wave) and one round of MFMAs (2048 cycles) does not cover that latency at two waves per
+    // SIMD (round 4 loaded one round ahead and started every 128-row strip with an exposed load).
+    constexpr int NS = 4;
+    float bx[NS][8];
+    const int nrounds = (p.Tl - tc0 <= 0) ? 0 : (((p.chunk_len < p.Tl - tc0 + 15 ? p.chunk_len : ((p.Tl - tc0 + 15) & ~15))) >> 4); // (X rows >= Tl are zero padding: nothing to add behind them)
+    auto xload = [&](float (&b)[8], int rd) {
+        const int rc = (rd < nrounds) ? rd : (nrounds ? nrounds - 1 : 0); // (behind the chunk: a row it owns, never used)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = cmf_bload(xr, xoff, (16 * rc + 2 * u) * Np * 4);
+    };
+#pragma unroll
+    for (int q = 0; q < NS - 1; ++q) xload(bx[q], q);
+    auto mround = [&](const float (&bc)[8], int r0) { // the MFMAs of one round on strip rows r0 .. r0 + 15
+        // software-pipelined like conv2_lag: the LDS reads of step u+1 are issued ahead of the MFMAs of step u
+        float a[MBW];
+#pragma unroll
+        for (int mb = 0; mb < MBW; ++mb) a[mb] = Hs[abase[mb] + r0];
+        __builtin_amdgcn_sched_group_barrier(0x100, MBW, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float an[MBW];
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb) an[mb] = 0.f;
+            if (u + 1 < 8) {
+#pragma unroll
+                for (int mb = 0; mb < MBW; ++mb) an[mb] = Hs[abase[mb] + r0 + 2 * (u + 1)];
+                __builtin_amdgcn_sched_group_barrier(0x100, MBW, 0);
+            }
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bc[u], acc[mb], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MBW, 0);
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb) a[mb] = an[mb];
+        }
+    };
     const int width = SK_SC + L - 1;
-    for (int s0 = 0; s0 < p.chunk_len && tc0 + s0 < p.Tl; s0 += SK_SC) { // (X rows >= Tl are zero padding: nothing to add behind them)
-        const int rows = (p.chunk_len - s0 < SK_SC) ? p.chunk_len - s0 : SK_SC; // a multiple of 16
+    for (int rd0 = 0; rd0 < nrounds; rd0 += SK_SC / 16) { // a strip = SK_SC / 16 = 8 rounds, a multiple of NS
+        const int s0 = rd0 * 16;
         __builtin_amdgcn_wave_barrier();
         // strip: Hs[k][c] = Ht[k][PADL + tc0 + s0 - (L-1) + c], c in [0, width)
         for (int k = 0; k < K; ++k) {
@@ -87,41 +124,16 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void hxt_small_kernel(SkHxtP
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // 8 steps (16 time rows) per round; the X operands of a round are loaded a round ahead into the OTHER of two register
-        // sets (a copy from a "next" set into the current one would make every round wait for its own prefetch)
-        float b0[8], b1[8];
+        for (int q0 = 0; q0 < SK_SC / 16 && rd0 + q0 < nrounds; q0 += NS) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) b0[u] = cmf_bload(xr, xoff, (s0 + 2 * u) * Np * 4);
-        auto round = [&](const float (&bc)[8], float (&bn)[8], int r0) {
-            const int nx = (r0 + 16 < rows) ? r0 + 16 : r0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) bn[u] = cmf_bload(xr, xoff, (s0 + nx + 2 * u) * Np * 4);
-            __builtin_amdgcn_sched_barrier(0); // keep the prefetch at the top of the round (the scheduler otherwise sinks it below the MFMAs)
-            // software-pipelined like conv2_lag: the LDS reads of step u+1 are issued ahead of the MFMAs of step u
-            float a[MBW];
-#pragma unroll
-            for (int mb = 0; mb < MBW; ++mb) a[mb] = Hs[abase[mb] + r0];
-            __builtin_amdgcn_sched_group_barrier(0x100, MBW, 0);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                float an[MBW];
-#pragma unroll
-                for (int mb = 0; mb < MBW; ++mb) an[mb] = 0.f;
-                if (u + 1 < 8) {
-#pragma unroll
-                    for (int mb = 0; mb < MBW; ++mb) an[mb] = Hs[abase[mb] + r0 + 2 * (u + 1)];
-                    __builtin_amdgcn_sched_group_barrier(0x100, MBW, 0);
+            for (int q = 0; q < NS; ++q) {
+                const int rd = rd0 + q0 + q;
+                if (rd < nrounds) {
+                    xload(bx[(q + NS - 1) % NS], rd + NS - 1);
+                    __builtin_amdgcn_sched_barrier(0); // keep the prefetch at the top of the round (the scheduler otherwise sinks it below the MFMAs)
+                    mround(bx[q], 16 * (q0 + q));
                 }
-#pragma unroll
-                for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bc[u], acc[mb], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MBW, 0);
-#pragma unroll
-                for (int mb = 0; mb < MBW; ++mb) a[mb] = an[mb];
             }
-        };
-        for (int r0 = 0; r0 < rows; r0 += 32) {
-            round(b0, b1, r0);
-            if (r0 + 16 < rows) round(b1, b0, r0 + 16);
         }
     }
 
@@ -295,32 +307,41 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
     for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    constexpr int U = 4; // n pairs per round; the operands of a round are loaded a round ahead into the other of two register sets
-    float a0[U][MBW], b0[U], a1[U][MBW], b1[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        b0[u] = cmf_bload(br, boff, (2 * u) * p.TP * 4);
-#pragma unroll
-        for (int mb = 0; mb < MBW; ++mb) a0[u][mb] = cmf_bload(ar, aoff + mb * 128, (2 * u) * p.JP * 4);
-    }
+    // U n pairs per round.  The A operand (Wj, L2-resident) is loaded one round ahead into the other of two register sets; the B
+    // operand (XT: every element is used by one wave, so it comes from HBM, in 128-byte pieces of rows TP floats apart) runs
+    // through a ring of three sets and is loaded TWO rounds ahead: one round of MFMAs (1024 cycles) does not cover that latency.
+    constexpr int U = 4, NSB = 3;
+    float a[2][U][MBW], b[NSB][U];
     const int nrounds = (p.N2 + 2 * U - 1) / (2 * U); // (the rows a last round reads past N2 are zero padding of both operands)
-    auto round = [&](const float (&ac)[U][MBW], const float (&bc)[U], float (&an)[U][MBW], float (&bn)[U], int rd) {
-        const int nx = ((rd + 1 < nrounds) ? rd + 1 : rd) * 2 * U;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            bn[u] = cmf_bload(br, boff, (nx + 2 * u) * p.TP * 4);
-#pragma unroll
-            for (int mb = 0; mb < MBW; ++mb) an[u][mb] = cmf_bload(ar, aoff + mb * 128, (nx + 2 * u) * p.JP * 4);
-        }
-        __builtin_amdgcn_sched_barrier(0); // the prefetch stays in front of the round's MFMAs
+    auto loadA = [&](float (&x)[U][MBW], int rd) {
+        const int nx = ((rd < nrounds) ? rd : nrounds - 1) * 2 * U;
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][mb], bc[u], acc[mb], 0, 0, 0);
+            for (int mb = 0; mb < MBW; ++mb) x[u][mb] = cmf_bload(ar, aoff + mb * 128, (nx + 2 * u) * p.JP * 4);
     };
-    for (int rd = 0; rd < nrounds; rd += 2) {
-        round(a0, b0, a1, b1, rd);
-        if (rd + 1 < nrounds) round(a1, b1, a0, b0, rd + 1);
+    auto loadB = [&](float (&x)[U], int rd) {
+        const int nx = ((rd < nrounds) ? rd : nrounds - 1) * 2 * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = cmf_bload(br, boff, (nx + 2 * u) * p.TP * 4);
+    };
+    loadB(b[0], 0);
+    loadB(b[1], 1);
+    loadA(a[0], 0);
+    for (int rd0 = 0; rd0 < nrounds; rd0 += 6) { // 6 = lcm(2, NSB): the set indices below are compile-time constants
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int rd = rd0 + q;
+            if (rd < nrounds) {
+                loadB(b[(q + 2) % NSB], rd + 2);
+                loadA(a[(q + 1) % 2], rd + 1);
+                __builtin_amdgcn_sched_barrier(0); // the prefetch stays in front of the round's MFMAs
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q % 2][u][mb], b[q % NSB][u], acc[mb], 0, 0, 0);
+            }
+        }
     }
 
     // the fold: thread c < 128 + L - 1 owns output column t = c0 - (L-1) + c
