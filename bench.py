@@ -43,8 +43,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_PROFILE = "r04_pmc_summary.json"  # rocprofv3 --pmc passes of this round's kernels (profiles/README.md)
-PMC_FALLBACK = "r03_pmc_summary.json"
+PMC_PROFILE = "r05_pmc_summary.json"  # rocprofv3 --pmc passes of this round's kernels (profiles/README.md)
+PMC_FALLBACK = "r04_pmc_summary.json"
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 CONFIGS = {
     1: dict(N=500, T=2000, K=5, L=10),

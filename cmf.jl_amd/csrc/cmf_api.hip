@@ -787,7 +787,8 @@ static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int n
         lds = std::max(lds, lds_min);
         const dim3 grid((d.Np / 32) * h->sk_MG, h->sk_ngroups, nsrc);
         switch (h->sk_MBW) {
-#define CASE(M_) case M_: hipLaunchKernelGGL((hxt_small_kernel<M_>), grid, dim3(256), lds, h->stream, p); break;
+#define CASE(M_) case M_: if (d.K <= SK_KEARLY) hipLaunchKernelGGL((hxt_small_kernel<M_, true>), grid, dim3(256), lds, h->stream, p); \
+                          else hipLaunchKernelGGL((hxt_small_kernel<M_, false>), grid, dim3(256), lds, h->stream, p); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
 #undef CASE
         default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk_MBW);

@@ -34,8 +34,13 @@ struct SkHxtParams {
 // C2.  grid ((Np/32) * MG, chunks/4, nsrc), 256 threads.  A wave = one 32-column n block x 32*MBW rows j x one time chunk.
 // Placement (speed only): workgroup b runs on XCD b % 8, so the MG row groups of one n block -- which read the same X rows --
 // are put 8 apart in blockIdx.x when the n blocks come in multiples of 8: the same L2 serves them.
-template <int MBW>
-__global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void hxt_small_kernel(SkHxtParams p)
+// EARLY (K <= SK_KEARLY): the NEXT strip's H rows are loaded into registers at the top of a strip's last round and written to
+// LDS at the boundary, so the boundary costs an LDS write instead of an exposed global load -- which, behind the X prefetch
+// ring, is an exposed HBM round trip (a wave's loads return in issue order), paid by the two waves of a SIMD at the same
+// moment (same program, started together: both stall, the MFMA pipe idles).
+#define SK_KEARLY 8
+template <int MBW, bool EARLY>
+__global__ __launch_bounds__(256, EARLY ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_small_kernel(SkHxtParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float sk_lds[]; // 4 strips of (K+1) rows; reused for the chunk reduction
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -114,21 +119,51 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void hxt_small_kernel(SkHxtP
         }
     };
     const int width = SK_SC + L - 1;
+    // strip: Hs[k][c] = Ht[k][PADL + tc0 + s0 - (L-1) + c], c in [0, width)
+    constexpr int KE = EARLY ? SK_KEARLY : 1;
+    float hreg[KE][3]; // (width <= 191: three 64-lane columns)
+    auto hload = [&](int s0) {
+#pragma unroll
+        for (int k = 0; k < KE; ++k)
+            if (k < K) {
+                const float *srcp = p.Ht + (size_t)k * TP + (p.PADL + tc0 + s0 - (L - 1));
+#pragma unroll
+                for (int q = 0; q < 3; ++q) hreg[k][q] = (lane + 64 * q < width) ? srcp[lane + 64 * q] : 0.f;
+            }
+    };
+    auto hstore = [&]() {
+#pragma unroll
+        for (int k = 0; k < KE; ++k)
+            if (k < K) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (lane + 64 * q < width) Hs[k * SK_HS_STRIDE + lane + 64 * q] = hreg[k][q];
+            }
+    };
+    if (EARLY && nrounds) hload(0);
     for (int rd0 = 0; rd0 < nrounds; rd0 += SK_SC / 16) { // a strip = SK_SC / 16 = 8 rounds, a multiple of NS
         const int s0 = rd0 * 16;
-        __builtin_amdgcn_wave_barrier();
-        // strip: Hs[k][c] = Ht[k][PADL + tc0 + s0 - (L-1) + c], c in [0, width)
-        for (int k = 0; k < K; ++k) {
-            const float *srcp = p.Ht + (size_t)k * TP + (p.PADL + tc0 + s0 - (L - 1));
-            for (int c = lane; c < width; c += 64) Hs[k * SK_HS_STRIDE + c] = srcp[c];
+        __builtin_amdgcn_wave_barrier(); // (a wave's LDS operations execute in issue order: the previous strip's reads are ahead of these writes)
+        if (EARLY) {
+            hstore();
+        } else {
+            for (int k = 0; k < K; ++k) {
+                const float *srcp = p.Ht + (size_t)k * TP + (p.PADL + tc0 + s0 - (L - 1));
+                for (int c = lane; c < width; c += 64) Hs[k * SK_HS_STRIDE + c] = srcp[c];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const int last = (nrounds - rd0 < SK_SC / 16 ? nrounds - rd0 : SK_SC / 16) - 1; // the strip's last round
         for (int q0 = 0; q0 < SK_SC / 16 && rd0 + q0 < nrounds; q0 += NS) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 const int rd = rd0 + q0 + q;
                 if (rd < nrounds) {
+                    if (EARLY && q0 + q == last && rd + 1 < nrounds) { // the next strip's H rows: in flight under this round's MFMAs
+                        hload(s0 + SK_SC);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     xload(bx[(q + NS - 1) % NS], rd + NS - 1);
                     __builtin_amdgcn_sched_barrier(0); // keep the prefetch at the top of the round (the scheduler otherwise sinks it below the MFMAs)
                     mround(bx[q], 16 * (q0 + q));
@@ -333,7 +368,7 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
         for (int q = 0; q < 6; ++q) {
             const int rd = rd0 + q;
             if (rd < nrounds) {
-                loadB(b[(q + 2) % NSB], rd + 2);
+                loadB(b[(q + 2) % NSB], rd + 2); // (A issued first, so that it does not queue behind this HBM load, measured slower: 84 -> 86 us)
                 loadA(a[(q + 1) % 2], rd + 1);
                 __builtin_amdgcn_sched_barrier(0); // the prefetch stays in front of the round's MFMAs
 #pragma unroll
