@@ -1101,33 +1101,41 @@ static void wb_free(cmf_handle_s *h)
     h->wb = nullptr;
 }
 
-static int wb_alloc(cmf_handle_s *h, CmfWriteback *wb)
+static int wb_alloc_copy(cmf_handle_s *h, CmfWriteback *wb, bool with_W) // the device side: copy stream, events, pinned staging
 {
     const CmfDims &d = h->d;
+    HIPCHK(hipSetDevice(h->device));
     wb->nW = (size_t)d.L * d.N * d.K;
     wb->nH = (size_t)d.Tl * d.K;
     HIPCHK(hipStreamCreateWithFlags(&wb->stream, hipStreamNonBlocking));
     for (hipEvent_t *e : {&wb->ev_w_ready, &wb->ev_h_ready, &wb->ev_w_done, &wb->ev_h_done})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    HIPCHK(hipHostMalloc((void **)&wb->pin_W, wb->nW * sizeof(float), hipHostMallocDefault));
+    if (with_W) HIPCHK(hipHostMalloc((void **)&wb->pin_W, wb->nW * sizeof(float), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&wb->pin_H, wb->nH * sizeof(float), hipHostMallocDefault));
-    if (d.K != d.K32) HIPCHK(hipMalloc((void **)&wb->dev_stage, std::max(wb->nW, wb->nH) * sizeof(float)));
-    const int dev = h->device;
-    wb->pool.on_start = [dev](size_t) { (void)hipSetDevice(dev); };
-    wb->pool.last_error = [] { return g_err; };
-    static const int nthr_env = getenv("CMF_WRITEBACK_THREADS") ? atoi(getenv("CMF_WRITEBACK_THREADS")) : 0;
-    cmf_pool_start(wb->pool, (size_t)std::min(16, std::max(1, nthr_env > 0 ? nthr_env : 4)));
+    if (d.K != d.K32) HIPCHK(hipMalloc((void **)&wb->dev_stage, std::max(with_W ? wb->nW : 0, wb->nH) * sizeof(float)));
+    wb->has_copy = true;
     return CMF_OK;
 }
 
-static int wb_ensure(cmf_handle_s *h)
+static void wb_start_pool(int device, CmfWriteback *wb) // the host side: the widening helpers
 {
-    if (h->wb) return CMF_OK;
-    h->wb = new CmfWriteback();
-    if (h->group) return CMF_OK; // a group handle downloads synchronously (wb_finish): nothing of this is needed
-    const int rc = wb_alloc(h, h->wb);
-    if (rc != CMF_OK) wb_free(h);
-    return rc;
+    if (!wb->pool.empty()) return;
+    wb->pool.on_start = [device](size_t) { (void)hipSetDevice(device); };
+    wb->pool.last_error = [] { return g_err; };
+    static const int nthr_env = getenv("CMF_WRITEBACK_THREADS") ? atoi(getenv("CMF_WRITEBACK_THREADS")) : 0;
+    cmf_pool_start(wb->pool, (size_t)std::min(16, std::max(1, nthr_env > 0 ? nthr_env : 4)));
+}
+
+// what == 1: copy resources (a handle with device state), 2: helpers (the handle the caller holds), 3: both
+static int wb_ensure(cmf_handle_s *h, int what, bool with_W = true)
+{
+    if (!h->wb) h->wb = new CmfWriteback();
+    if ((what & 1) && !h->wb->has_copy) {
+        const int rc = wb_alloc_copy(h, h->wb, with_W);
+        if (rc != CMF_OK) { wb_free(h); return rc; }
+    }
+    if (what & 2) wb_start_pool(h->device, h->wb);
+    return CMF_OK;
 }
 
 // W is final at the main stream's current position (update_motifs! has been enqueued): bring it to pinned memory on the copy stream
@@ -1164,9 +1172,10 @@ static int wb_drain(cmf_handle_s *h)
 static int wb_after_H(cmf_handle_s *h)
 {
     CmfWriteback *wb = h->wb;
-    if (!wb || !wb->armed || h->group) return CMF_OK;
+    if (!wb || !wb->armed || !wb->has_copy) return CMF_OK;
     const CmfDims &d = h->d;
-    const bool again = wb->h_posted; // a second pass over H inside the same call (the HALS rerun): the helpers must be done with the staging
+    const bool shard = h->group != nullptr; // a shard of a group: issue the copy and say so; the front handle's helpers do the rest
+    const bool again = !shard && wb->h_posted; // a second pass over H inside the same call (the HALS rerun): the helpers must be done with the staging
     if (again) CMFTRY(wb_drain(h));
     if (wb->dst_H) {
         HIPCHK(hipEventRecord(wb->ev_h_ready, h->stream));
@@ -1179,6 +1188,10 @@ static int wb_after_H(cmf_handle_s *h)
             HIPCHK(hipMemcpyAsync(wb->pin_H, wb->dev_stage, wb->nH * sizeof(float), hipMemcpyDeviceToHost, wb->stream));
         }
         HIPCHK(hipEventRecord(wb->ev_h_done, wb->stream));
+    }
+    if (shard) {
+        wb->h_issued.store(true, std::memory_order_release);
+        return CMF_OK;
     }
     const size_t nthr = wb->pool.size();
     const bool want_W = !again && wb->dst_W && wb->w_started;
@@ -1207,6 +1220,54 @@ static int wb_after_H(cmf_handle_s *h)
     return CMF_OK;
 }
 
+#include "cmf_group.h"
+
+// A group's MU H phase is about to be enqueued: post the widening of W (shard 0's copy was started when the write-back was armed)
+// and of every shard's column block of H to the front handle's helpers.  Helper j takes slice j of every block.
+static int wb_group_post(cmf_handle_s *h)
+{
+    CmfWriteback *wb = h->wb;
+    if (!wb || !wb->armed || !h->group) return CMF_OK;
+    cmf_group_s *g = h->group;
+    const size_t nthr = wb->pool.size();
+    const double tmo = wait_timeout_s();
+    for (size_t j = 0; j < nthr; ++j)
+        cmf_pool_post(wb->pool, j, [g, j, nthr, tmo]() -> int {
+            auto slice = [&](size_t n, size_t *a, size_t *b) {
+                const size_t per = (n / nthr) & ~(size_t)15;
+                *a = j * per;
+                *b = j + 1 == nthr ? n : (j + 1) * per;
+            };
+            for (size_t i = 0; i < g->sh.size(); ++i) {
+                CmfWriteback *sw = g->sh[i]->wb;
+                if (!sw || !sw->armed) continue;
+                (void)hipSetDevice(g->sh[i]->device);
+                size_t a, b;
+                if (sw->dst_W && sw->w_started) {
+                    if (hipEventSynchronize(sw->ev_w_done) != hipSuccess) return fail(CMF_ERR_HIP, "the download of W failed");
+                    slice(sw->nW, &a, &b);
+                    cmf_widen(sw->pin_W + a, sw->dst_W + a, b - a);
+                }
+                if (sw->dst_H) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    for (unsigned spins = 1; !sw->h_issued.load(std::memory_order_acquire); ++spins) { // (the copy is issued by whoever enqueues the shard)
+                        if (sw->cancel.load(std::memory_order_acquire)) return CMF_OK;
+                        if ((spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > tmo)
+                            return fail(CMF_ERR_HIP, "write-back: shard %zu never issued its copy of H", i);
+                        CMF_CPU_PAUSE();
+                    }
+                    if (hipEventSynchronize(sw->ev_h_done) != hipSuccess) return fail(CMF_ERR_HIP, "the download of H failed");
+                    slice(sw->nH, &a, &b);
+                    cmf_widen(sw->pin_H + a, sw->dst_H + a, b - a);
+                }
+            }
+            return CMF_OK;
+        });
+    wb->h_posted = true;
+    wb->hooked_calls += 1;
+    return CMF_OK;
+}
+
 // End of a rule call that may carry an armed write-back: the caller's arrays are complete (or the call fails) and are not
 // touched after this returns.
 static int wb_finish(cmf_handle_s *h, int rc)
@@ -1216,17 +1277,25 @@ static int wb_finish(cmf_handle_s *h, int rc)
     double *W = wb->dst_W, *H = wb->dst_H;
     int rc2 = CMF_OK;
     if (wb->h_posted) {
+        if (rc != CMF_OK && h->group) // the phase failed somewhere: a shard's copy may never be issued -- release the helpers that wait for it
+            for (cmf_handle_s *s : h->group->sh)
+                if (s->wb) s->wb->cancel.store(true, std::memory_order_release);
         rc2 = wb_drain(h);
-    } else if (rc == CMF_OK) { // no hook on this path (group handles): the synchronous download
+    } else if (rc == CMF_OK) { // no hook on this path (the PGD rule on a group): the synchronous download
         wb->armed = false;
         rc2 = cmf_get_factors(h, W, H);
     }
+    if (h->group)
+        for (cmf_handle_s *s : h->group->sh)
+            if (s->wb) {
+                s->wb->armed = s->wb->w_started = false;
+                s->wb->dst_W = s->wb->dst_H = nullptr;
+            }
     wb->armed = wb->h_posted = wb->w_started = false;
     wb->dst_W = wb->dst_H = nullptr;
     return rc != CMF_OK ? rc : rc2;
 }
 
-#include "cmf_group.h"
 
 // A loss reduction deferred by cmf_iterate (CmfLossCarry) only lives between two phases of that call.  If the call
 // failed in between, the record would be consumed by the next W phase and reduce partial sums that have been
@@ -1532,6 +1601,7 @@ static int update_feature_maps_body(cmf_handle h, double l1H, double l2H, double
     drop_carry(h);
     if (h && h->group) {
         CMFTRY(group_check_ready(h->group));
+        CMFTRY(wb_group_post(h)); // (an armed write-back: the helpers wait for every shard's copy of its block of H)
         double ss = 0.0;
         CMFTRY(group_update_feature_maps(h->group, l1H, l2H, &ss));
         *loss = std::sqrt(ss) / h->group->data_norm;
@@ -1563,14 +1633,38 @@ int cmf_arm_writeback(cmf_handle h, double *W, double *H)
         }
         return CMF_OK;
     }
-    if (h->group) CMFTRY(group_check_ready(h->group));
-    else CMFTRY(check_ready(h, false));
-    CMFTRY(wb_ensure(h));
+    if (h->group) {
+        cmf_group_s *g = h->group;
+        CMFTRY(group_check_ready(g));
+        CMFTRY(group_join(g)); // (the enqueue workers are idle: this thread may use the shards' streams)
+        CMFTRY(wb_ensure(h, 2));
+        for (size_t i = 0; i < g->sh.size(); ++i) { // every shard: its own column block of H (column-major: contiguous), shard 0 also W
+            cmf_handle_s *s = g->sh[i];
+            CMFTRY(wb_ensure(s, 1, i == 0));
+            CmfWriteback *sw = s->wb;
+            sw->dst_W = i == 0 ? W : nullptr;
+            sw->dst_H = !H ? nullptr : (g->one_process ? H + (size_t)g->t0[(size_t)g->rank[i]] * g->K : H);
+            sw->armed = true;
+            sw->w_started = false;
+            sw->h_issued.store(false, std::memory_order_relaxed);
+            sw->cancel.store(false, std::memory_order_relaxed);
+            if (sw->dst_W) {
+                CMFTRY(group_use(s));
+                CMFTRY(wb_start_W(s));
+            }
+        }
+    } else {
+        CMFTRY(check_ready(h, false));
+        CMFTRY(wb_ensure(h, 3));
+    }
     CmfWriteback *wb = h->wb;
-    wb->dst_W = W;
-    wb->dst_H = H;
+    if (!(h->group && !h->root_only)) { // (a per-process shard is its own front handle: its fields were set above)
+        wb->dst_W = W;
+        wb->dst_H = H;
+    }
     wb->armed = true;
-    wb->h_posted = wb->w_started = false;
+    wb->h_posted = false;
+    if (!h->group) wb->w_started = false;
     wb->armed_calls += 1;
     if (W && !h->group) CMFTRY(wb_start_W(h));
     return CMF_OK;

@@ -13,6 +13,10 @@
 // plain DMA transfers (no kernel shares the chip with the statically dealt contraction kernels); other K go through a small
 // pack kernel on the copy stream.  The caller's pointers are used only between the hook behind the H update and the return
 // of that same rule call.
+// T-sharded groups (the reference's `fit` driving 8 GPUs through one handle): every shard copies its own column block of H the
+// same way on its own device (shard 0 also W), and the helpers of the front handle widen block after block -- a synchronous
+// cmf_get_factors per call (1.6 MB + a stream synchronisation per shard, one after the other, and 10 MB of W) would cost more
+// than the 0.9 ms iteration it follows.
 #pragma once
 #include "cmf_workers.h"
 
@@ -29,7 +33,12 @@ struct CmfWriteback {
     size_t nW = 0, nH = 0;
     double *dst_W = nullptr, *dst_H = nullptr;       // the caller's arrays while armed
     bool armed = false, w_started = false, h_posted = false;
-    CmfWorkerPool pool;                              // the widening helpers
+    bool has_copy = false;                           // stream / events / staging exist (a handle with device state of its own)
+    // shards of a group: the hook behind a shard's H update runs on whoever enqueues that shard (its worker thread); it flags the
+    // copy as issued, and the helpers of the group's front handle -- posted before the phase is enqueued -- wait for the flag
+    // before they wait for the event (an event that has not been recorded yet reads as complete)
+    std::atomic<bool> h_issued{false}, cancel{false};
+    CmfWorkerPool pool;                              // the widening helpers (of a single handle, or of a group's front handle)
     int64_t armed_calls = 0, hooked_calls = 0;       // (cmf_get_counter: "writeback_calls", "writeback_overlapped")
 };
 

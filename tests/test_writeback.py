@@ -140,23 +140,57 @@ def test_gram_form_writeback(cmf, oracle):
             rule.close()
 
 
-def test_group_handles_write_back_synchronously(cmf, oracle):
-    data, W0, H0 = problem(oracle, 60, 500, 32, 8)
-    ref = cmf.MultUpdate(data, W0, H0, devices=[0, 0, 0])
-    rule = cmf.MultUpdate(data, W0, H0, devices=[0, 0, 0])
+@pytest.mark.parametrize("transport,threads,gram", [(2, 1, 0), (3, 1, 0), (3, 0, 0), (4, 1, 0), (3, 1, 1)])
+def test_group_handles_write_back_per_shard(cmf, oracle, transport, threads, gram):
+    """A T-sharded group (the reference's `fit` driving several GPUs through one handle): every shard copies its own column
+    block of H on its own copy stream behind its H update -- issued by whoever enqueues the shard: its worker thread, or the
+    calling thread -- shard 0 also W, and the front handle's helpers widen block after block.  Loopback (one shared stream),
+    a stream per shard with and without enqueue workers, the peer transport, and the Gram form: the caller's arrays are bit for
+    bit cmf_get_factors, the losses those of an unarmed group."""
+    data, W0, H0 = problem(oracle, 60, 700, 32, 8)
+    ref = cmf.MultUpdate(data, W0, H0, devices=[0, 0, 0], transport=transport)
+    rule = cmf.MultUpdate(data, W0, H0, devices=[0, 0, 0], transport=transport)
+    for r in (ref, rule):
+        if transport != 2:
+            r.set_option("enqueue_threads", threads)
+        r.set_option("gram", gram)
     rule.sync_every_call = True
     W, H = caller_arrays(W0, H0)
     try:
-        for _ in range(2):
+        for _ in range(3):
             ref.update_motifs()
             want = ref.update_feature_maps()
             rule.update_motifs(data, W, H)
             assert rule.update_feature_maps(data, W, H) == want
             Wd, Hd = rule.download()
             assert np.array_equal(W, Wd) and np.array_equal(H, Hd)
-        assert rule.counter("writeback_calls") == 2 and rule.counter("writeback_overlapped") == 0
+        assert rule.counter("writeback_calls") == 3 and rule.counter("writeback_overlapped") == 3
+        # a batch in between leaves nothing armed behind, and the next armed call is right again
+        rule.iterate(2)
+        ref.iterate(2)
+        rule.update_motifs(data, W, H)
+        rule.update_feature_maps(data, W, H)
+        Wd, Hd = rule.download()
+        assert np.array_equal(W, Wd) and np.array_equal(H, Hd)
     finally:
         ref.close()
+        rule.close()
+
+
+def test_pgd_on_a_group_writes_back_synchronously(cmf, oracle):
+    """The PGD rule's group path has no hook: the arrays are filled by the synchronous download inside the call."""
+    data, W0, H0 = problem(oracle, 60, 500, 32, 8)
+    rule = cmf.PGDUpdate(data, W0, H0, devices=[0, 0])
+    rule.sync_every_call = True
+    W, H = caller_arrays(W0, H0)
+    try:
+        for _ in range(2):
+            rule.update_motifs(data, W, H)
+            rule.update_feature_maps(data, W, H)
+            Wd, Hd = rule.download()
+            assert np.array_equal(W, Wd) and np.array_equal(H, Hd)
+        assert rule.counter("writeback_calls") == 2 and rule.counter("writeback_overlapped") == 0
+    finally:
         rule.close()
 
 
