@@ -935,6 +935,21 @@ def measure(args, form, progress):
             call_by_call = measure_call_by_call(rule, W0, H0, reg_kw, max(10, args.steps), sync)
         except Exception as e:  # noqa: BLE001 - side measurements never cost the headline
             call_by_call = {"error": repr(e)}
+        # ... and the same loop on the 8-shard partition `--gpus 8` runs, rehearsed on THIS GPU (loopback transport with a stream and
+        # an enqueue worker per shard; the shards share the device, so the iteration is ~8 shard iterations long): the ABSOLUTE extra
+        # time per iteration of each way to deliver W and H says what the reference's `fit` would pay per iteration on a node
+        if args.config == 2 and not args.T and isinstance(call_by_call, dict) and "error" not in call_by_call:
+            g8 = None
+            try:
+                g8 = cmf.MultUpdate(data, W0, H0, devices=[local_rank] * 8, transport=3)
+                rec8 = measure_call_by_call(g8, W0, H0, reg_kw, 10, g8.synchronize)
+                rec8["what"] = "8 loopback shards on one GPU (cmf_create_multi, a stream and an enqueue worker per shard): " + rec8["what"]
+                call_by_call["rehearsal_8_loopback_shards"] = rec8
+            except Exception as e:  # noqa: BLE001
+                call_by_call["rehearsal_8_loopback_shards"] = {"error": repr(e)}
+            finally:
+                if g8 is not None:
+                    g8.close()
     # Optional Gram form of the denominators (executes 2.3 + 1 contractions): reported as
     # extra fields only, the headline value is the reference formulation above.
     dt_gram = dt_gram2 = None
