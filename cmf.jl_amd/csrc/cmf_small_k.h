@@ -307,7 +307,6 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
 {
     __shared__ float tile[32 * SK_TILE_STRIDE];
     __shared__ float outs[16 * SK_FOLD_COLS];
-    __shared__ short rowk[32 * SK_MAXMBW], rowl[32 * SK_MAXMBW];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int src = blockIdx.y % p.nsrc, mg = blockIdx.y / p.nsrc;
@@ -324,11 +323,6 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
             if (t >= 0 && t < Tl) slab1[(size_t)t * K32 + kk] = 0.f;
         }
         return;
-    }
-    for (int r = tid; r < 32 * MBW; r += 256) {
-        const int kl = r / L;
-        rowk[r] = (short)(kl < kn ? kl : -1);
-        rowl[r] = (short)(r - kl * L);
     }
     for (int e = tid; e < 16 * SK_FOLD_COLS; e += 256) outs[e] = 0.f;
 
@@ -384,23 +378,26 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
     const bool folder = tid < 128 + L - 1;
 #pragma unroll
     for (int mb = 0; mb < MBW; ++mb) {
-        __syncthreads(); // (the tables / the previous block's reads)
+        __syncthreads(); // (the zero fill of outs / the previous block's reads)
 #pragma unroll
         for (int r = 0; r < 16; ++r) tile[cmf_crow(r, h) * SK_TILE_STRIDE + wave * 32 + i] = acc[mb][r];
         __syncthreads();
         if (folder) {
+            // row r = 32 mb + rl of the group is (component kk, lag ll) = (r / L, r % L): the same for every thread, so the
+            // bookkeeping runs on the scalar unit (a table in LDS cost two broadcast reads per row)
+            int kk = (32 * mb) / L, ll = 32 * mb - kk * L;
             float s = 0.f;
-            int cur = -1;
             for (int rl = 0; rl < 32; ++rl) {
-                const int k = rowk[mb * 32 + rl], col = trel + rowl[mb * 32 + rl];
-                if (k != cur) {
-                    if (cur >= 0) outs[cur * SK_FOLD_COLS + tid] += s;
+                const unsigned col = (unsigned)(trel + ll);
+                if (kk < kn && col < 128u) s += tile[rl * SK_TILE_STRIDE + col];
+                if (++ll == L) {
+                    if (kk < kn) outs[kk * SK_FOLD_COLS + tid] += s;
                     s = 0.f;
-                    cur = k;
+                    ll = 0;
+                    ++kk;
                 }
-                if (k >= 0 && col >= 0 && col < 128) s += tile[rl * SK_TILE_STRIDE + col];
             }
-            if (cur >= 0) outs[cur * SK_FOLD_COLS + tid] += s;
+            if (ll != 0 && kk < kn) outs[kk * SK_FOLD_COLS + tid] += s; // (a component that continues in the next block)
         }
     }
     __syncthreads();
