@@ -354,7 +354,8 @@ static void plan(cmf_handle_s *h, int n_cu)
     if (h->small_k_ok) {
         h->sk_J = d.L * d.K;
         const int mblocks = (h->sk_J + 31) / 32;              // 32-row blocks that hold rows j
-        h->sk_MG = (mblocks + SK_MAXMBW - 1) / SK_MAXMBW;     // groups of at most SK_MAXMBW blocks ...
+        static const int c2max = getenv("CMF_SK_C2_MAXMBW") && atoi(getenv("CMF_SK_C2_MAXMBW")) > 0 ? std::min(atoi(getenv("CMF_SK_C2_MAXMBW")), SK_MAXMBW_C2) : SK_MAXMBW_C2; // measurement knob
+        h->sk_MG = (mblocks + c2max - 1) / c2max;             // groups of at most SK_MAXMBW_C2 blocks ...
         h->sk_MBW = (mblocks + h->sk_MG - 1) / h->sk_MG;      // ... as even as possible: the least padding
         h->sk_JP = 32 * h->sk_MBW * h->sk_MG;
         h->sk_TG = (int)rup(d.Tl + d.L - 1, 128);
@@ -787,9 +788,9 @@ static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int n
         lds = std::max(lds, lds_min);
         const dim3 grid((d.Np / 32) * h->sk_MG, h->sk_ngroups, nsrc);
         switch (h->sk_MBW) {
-#define CASE(M_) case M_: if (d.K <= SK_KEARLY) hipLaunchKernelGGL((hxt_small_kernel<M_, true>), grid, dim3(256), lds, h->stream, p); \
+#define CASE(M_) case M_: if (d.K <= SK_KEARLY && M_ <= 8) hipLaunchKernelGGL((hxt_small_kernel<M_, (M_ <= 8)>), grid, dim3(256), lds, h->stream, p); /* (9 or 10 blocks + the early strip registers do not fit two waves per SIMD) */ \
                           else hipLaunchKernelGGL((hxt_small_kernel<M_, false>), grid, dim3(256), lds, h->stream, p); break;
-            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
 #undef CASE
         default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk_MBW);
         }

@@ -16,7 +16,9 @@
 // shared with the general path.  v_mfma_f32_32x32x2_f32 throughout (operand maps: cmf_kernels.h).
 #pragma once
 
-#define SK_MAXMBW 6       // 32-row m blocks per wave (template parameter MBW): a wave owns 32 * MBW consecutive rows j
+#define SK_MAXMBW 6       // 32-row m blocks per wave (template parameter MBW): a wave owns 32 * MBW consecutive rows j (C3)
+#define SK_MAXMBW_C2 10   // ... of the C2 kernel: K = 16, L = 20 (320 rows) in ONE row group, so that X is read once (two groups of
+                          // five blocks each re-read it: 0.51 of the roof on useful flops; 160 accumulator registers, two waves per SIMD)
 #define SK_SC 128         // time rows per staged H strip of hxt_small_kernel
 #define SK_HS_STRIDE 201  // floats between the k rows of the strip (>= SK_SC + 64 + 1, odd: the lag-shifted reads of a wave spread over the banks)
 #define SK_MAXL 64        // the strip holds SK_SC + L - 1 <= 191 columns
@@ -40,7 +42,7 @@ struct SkHxtParams {
 // moment (same program, started together: both stall, the MFMA pipe idles).
 #define SK_KEARLY 8
 template <int MBW, bool EARLY>
-__global__ __launch_bounds__(256, EARLY ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_small_kernel(SkHxtParams p)
+__global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_small_kernel(SkHxtParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float sk_lds[]; // 4 strips of (K+1) rows; reused for the chunk reduction
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
