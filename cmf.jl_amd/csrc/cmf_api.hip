@@ -2574,7 +2574,7 @@ static int gram_tables(cmf_handle_s *h) // PW -> GW, GE (the lag-Gram taps of W;
 {
     ProfScope prof_(h, PROF_GRAM_TABLES);
     const CmfDims &d = h->d;
-    hipLaunchKernelGGL(hals_pw_kernel, dim3(d.L * (d.L + 1) / 2, d.KB * d.KB), dim3(256), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
+    hipLaunchKernelGGL(hals_pw_kernel, dim3(d.L * (d.L + 1) / 2, d.KB * d.KB), dim3(64 * PW_NW), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
     KCHK("hals_pw_kernel");
     hipLaunchKernelGGL(hals_gw_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_PW, h->hals_GW, h->hals_GE, d.L, d.K32, h->hals_ne, d.Tl, h->hals_t_edge0,
                        h->hals_GWt, 2 * d.L); // (+ the taps as [k'][e][k], E = 2L - 1 padded to an even count, for gram_h_mfma_kernel)

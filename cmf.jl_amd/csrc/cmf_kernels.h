@@ -1726,22 +1726,27 @@ __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float
 }
 
 // PW[l][l'][k][k'] = sum_n Wn[l][n][k] * Wn[l'][n][k'] on the MFMA pipe: one WORKGROUP per (l <= l', k block, k' block),
-// its four waves take every fourth batch of 32 rows of n and add their partial sums through LDS in wave order
+// its PW_NW = 8 waves take every eighth batch of 32 rows of n and add their partial sums through LDS in wave order
 // (deterministic); the pair (l', l) is the transpose and is written from the same result.  Both operands are 128-byte rows
-// of Wn read straight from L2.  grid (L*(L+1)/2, KB*KB), block 256
+// of Wn read straight from L2.  grid (L*(L+1)/2, KB*KB), block 64 * PW_NW.  (Four waves until round 4: 210 workgroups are fewer than
+// the chip's SIMDs, so the launch lasts as long as ONE wave's chain of N / 8 MFMAs and its L2 round trips: 17.8 us at N = 2000.)
 // (Round 2 ran one wave per ordered pair: L*L waves of N/2 dependent MFMAs each -- 27 us of MFMA issue per wave at
 // N = 2000 whatever the chip does, 55 us measured, independent of T.)
-__global__ __launch_bounds__(256) void hals_pw_kernel(const float *Wn, float *PW, int N, int L, int Np, int K32, int KB)
+#define PW_NW 8
+__global__ __launch_bounds__(64 * PW_NW) void hals_pw_kernel(const float *Wn, float *PW, int N, int L, int Np, int K32, int KB)
 {
-    __shared__ float part[4][16][64];
+    __shared__ float part[PW_NW][16][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (scalar: uniform loop bounds)
     const int i = lane & 31, h = lane >> 5;
     int l = 0, rem = blockIdx.x; // pair index -> (l, lp), l <= lp: row l of the upper triangle holds L - l pairs
     while (rem >= L - l) { rem -= L - l; ++l; }
     const int lp = l + rem;
     const int kb = blockIdx.y / KB, kbp = blockIdx.y % KB;
-    const float *a = Wn + ((size_t)l * Np + h) * K32 + kb * 32 + i;
-    const float *b = Wn + ((size_t)lp * Np + h) * K32 + kbp * 32 + i;
+    // buffer loads with scalar row offsets (no 64-bit address per load: with plain pointers the 32 loads of a batch in flight cost
+    // 64 address registers on top of their 32 destinations, more than 8 waves per workgroup can have)
+    const __amdgpu_buffer_rsrc_t ar = cmf_rsrc(Wn + (size_t)l * Np * K32, (size_t)Np * K32 * 4);
+    const __amdgpu_buffer_rsrc_t br = cmf_rsrc(Wn + (size_t)lp * Np * K32, (size_t)Np * K32 * 4);
+    const int aoff = (h * K32 + kb * 32 + i) * 4, boff = (h * K32 + kbp * 32 + i) * 4;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -1752,8 +1757,8 @@ __global__ __launch_bounds__(256) void hals_pw_kernel(const float *Wn, float *PW
     auto load = [&](float (&x)[16], float (&y)[16], int n0) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            x[q] = a[(size_t)(n0 + 2 * q) * K32];
-            y[q] = b[(size_t)(n0 + 2 * q) * K32];
+            x[q] = cmf_bload(ar, aoff, (n0 + 2 * q) * K32 * 4);
+            y[q] = cmf_bload(br, boff, (n0 + 2 * q) * K32 * 4);
         }
     };
     auto mac = [&](const float (&x)[16], const float (&y)[16]) {
@@ -1763,7 +1768,7 @@ __global__ __launch_bounds__(256) void hals_pw_kernel(const float *Wn, float *PW
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[q + 1], y[q + 1], acc1, 0, 0, 0);
         }
     };
-    const int first = 32 * wave, step = 128; // batches wave, wave + 4, ...
+    const int first = 32 * wave, step = 32 * PW_NW; // batches wave, wave + PW_NW, ...
     if (first < NB) load(av[0], bv[0], first);
     for (int n0 = first; n0 < NB; n0 += 2 * step) {
         if (n0 + step < NB) load(av[1], bv[1], n0 + step);
@@ -1776,9 +1781,11 @@ __global__ __launch_bounds__(256) void hals_pw_kernel(const float *Wn, float *PW
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc0[r] + acc1[r];
     __syncthreads();
-    for (int o = threadIdx.x; o < 16 * 64; o += 256) {
+    for (int o = threadIdx.x; o < 16 * 64; o += 64 * PW_NW) {
         const int r = o >> 6, ln = o & 63;
-        const float v = ((part[0][r][ln] + part[1][r][ln]) + part[2][r][ln]) + part[3][r][ln];
+        float v = part[0][r][ln];
+#pragma unroll
+        for (int w = 1; w < PW_NW; ++w) v += part[w][r][ln];
         const int k = kb * 32 + cmf_crow(r, ln >> 5), kp = kbp * 32 + (ln & 31);
         PW[(((size_t)l * L + lp) * K32 + k) * K32 + kp] = v;
         if (l != lp) PW[(((size_t)lp * L + l) * K32 + kp) * K32 + k] = v;
@@ -2861,8 +2868,10 @@ __global__ __launch_bounds__(256) void gram_w_kernel(const float *HH, const floa
     for (int a = 0; a < MB; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-    const float *ap = HH + (size_t)h * NpH + p0 + i;
-    const float *bp = Wt + (size_t)h * Np + n0 + i;
+    // (buffer loads with scalar row offsets: no 64-bit address arithmetic per load)
+    const __amdgpu_buffer_rsrc_t ar = cmf_rsrc(HH, (size_t)LK * NpH * 4);
+    const __amdgpu_buffer_rsrc_t br = cmf_rsrc(Wt, (size_t)LK * Np * 4);
+    const int aoff = (h * NpH + p0 + i) * 4, boff = (h * Np + n0 + i) * 4;
     const int q4 = (LK / 4 + 1) & ~1;            // this wave's share of the reduction rows (even)
     const int lo = wave * q4, hi = (lo + q4 < LK) ? lo + q4 : LK;
     constexpr int NB = 8;                        // row pairs per batch
@@ -2873,10 +2882,10 @@ __global__ __launch_bounds__(256) void gram_w_kernel(const float *HH, const floa
             const int pp = pp0 + 2 * q;
             const bool ok = pp < hi;
             const int ppc = ok ? pp : lo; // unconditional loads (a row pair this wave owns), a zero B operand behind the range
-            const float bx = bp[(size_t)ppc * Np];
+            const float bx = cmf_bload(br, boff, ppc * Np * 4);
             bv[s][q] = ok ? bx : 0.f;
 #pragma unroll
-            for (int a = 0; a < MB; ++a) av[s][q][a] = ap[(size_t)ppc * NpH + 32 * a];
+            for (int a = 0; a < MB; ++a) av[s][q][a] = cmf_bload(ar, aoff + 128 * a, ppc * NpH * 4);
         }
     };
     auto mac = [&](int s) {
@@ -3033,11 +3042,12 @@ __global__ __launch_bounds__(256) void gram_h_mfma_kernel(const float *Ht, const
     const int Fq = ((F + fw - 1) / fw + 31) & ~31; // this wave's share, in whole chunks
     const int f_lo = fg * Fq, f_hi = (f_lo + Fq < F) ? f_lo + Fq : F;
     const float *arow = smem_dyn + cg * 32 + i + hh;                 // + kp * WN + 2 * s
-    const float *brow = GWt + (size_t)hh * K32 + kbo * 32 + i;       // + 2 * f * K32
+    const __amdgpu_buffer_rsrc_t brr = cmf_rsrc(GWt, (size_t)K32 * Ep * K32 * 4); // B rows: + 2 * f * K32 floats (scalar offsets)
+    const int broff = (hh * K32 + kbo * 32 + i) * 4;
     float bb[2][32];
     auto loadb = [&](float (&x)[32], int f0) {
 #pragma unroll
-        for (int q = 0; q < 32; ++q) x[q] = brow[(size_t)2 * ((f0 + q < f_hi) ? f0 + q : f_lo) * K32]; // (unconditional; A is zero behind the range)
+        for (int q = 0; q < 32; ++q) x[q] = cmf_bload(brr, broff, 2 * ((f0 + q < f_hi) ? f0 + q : f_lo) * K32 * 4); // (unconditional; A is zero behind the range)
     };
     auto mac = [&](const float (&x)[32], int f0) {
         int kp = f0 / nstep, s2 = f0 - kp * nstep;
