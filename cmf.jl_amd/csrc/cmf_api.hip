@@ -1781,6 +1781,7 @@ static int pgd_update_feature_maps_body(cmf_handle h, double pen_sq, double pen_
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
     if (h && h->group) {
         CMFTRY(group_check_ready(h->group));
+        CMFTRY(wb_group_post(h)); // (an armed write-back: the helpers wait for every shard's copy of its block of H)
         return group_pgd_h(h, h->group, pen_sq, pen_abs, nonneg, loss);
     }
     CMFTRY(check_ready(h, true));
@@ -2976,6 +2977,10 @@ static int group_pgd_h(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double p
             hipLaunchKernelGGL(pgd_h_kscale_kernel, dim3(1024), dim3(256), 0, s->stream, s->H, s->Ht, s->pgd_knorm, d.Tl, d.K, d.K32, d.TP, d.PADL);
             KCHK("pgd_h_kscale_kernel");
         }
+    }
+    for (cmf_handle_s *s : g->sh) { // (an armed write-back: every shard's block of H is final here)
+        CMFTRY(group_use(s));
+        CMFTRY(wb_after_H(s));
     }
     CMFTRY(group_exchange_halos(g));
     CMFTRY(group_pgd_finish(st, g, &st->pgd_stepH));

@@ -224,9 +224,9 @@ int cmf_get_factors(cmf_handle h, double *W, double *H);
  * contraction, H underneath the loss conv, and helper threads widen to Float64 while the caller waits for the loss scalar.
  * Either pointer may be NULL (that factor is not written); both NULL disarms.  EXCEPTION to "host pointers are borrowed for
  * the duration of the call only": W and H are borrowed from this call until the next *_update_feature_maps call on the handle
- * returns, and are written only inside that call.  One arm serves one call.  On a group handle (MU rule, either formulation)
+ * returns, and are written only inside that call.  One arm serves one call.  On a group handle (MU rule in either formulation, PGD rule)
  * every shard copies its own column block of H on its own device the same way (shard 0 also W) and the handle's helpers widen
- * block after block; the PGD rule on a group takes the synchronous cmf_get_factors route inside the rule call (same results).
+ * block after block.
  * CMF_WRITEBACK_THREADS (default 4): the widening helpers.
  * cmf_get_counter: "writeback_calls", "writeback_overlapped" (calls served by the copy stream). */
 int cmf_arm_writeback(cmf_handle h, double *W, double *H);

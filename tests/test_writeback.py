@@ -177,20 +177,27 @@ def test_group_handles_write_back_per_shard(cmf, oracle, transport, threads, gra
         rule.close()
 
 
-def test_pgd_on_a_group_writes_back_synchronously(cmf, oracle):
-    """The PGD rule's group path has no hook: the arrays are filled by the synchronous download inside the call."""
+@pytest.mark.parametrize("constr", [None, "unitnorm"])
+def test_pgd_on_a_group_writes_back_per_shard(cmf, oracle, constr):
+    """The PGD rule on a T-sharded group (pgd.jl:180-202 with H cut along T), with and without the UnitNorm rescaling that follows
+    the step: the copies start behind the LAST kernel that writes a shard's H."""
     data, W0, H0 = problem(oracle, 60, 500, 32, 8)
-    rule = cmf.PGDUpdate(data, W0, H0, devices=[0, 0])
+    kw = {"constrH": cmf.UnitNormConstraint()} if constr else {}
+    ref = cmf.PGDUpdate(data, W0, H0, devices=[0, 0, 0])
+    rule = cmf.PGDUpdate(data, W0, H0, devices=[0, 0, 0])
     rule.sync_every_call = True
     W, H = caller_arrays(W0, H0)
     try:
-        for _ in range(2):
+        for _ in range(3):
+            ref.update_motifs()
+            want = ref.update_feature_maps(**kw)
             rule.update_motifs(data, W, H)
-            rule.update_feature_maps(data, W, H)
+            assert rule.update_feature_maps(data, W, H, **kw) == want
             Wd, Hd = rule.download()
             assert np.array_equal(W, Wd) and np.array_equal(H, Hd)
-        assert rule.counter("writeback_calls") == 2 and rule.counter("writeback_overlapped") == 0
+        assert rule.counter("writeback_calls") == 3 and rule.counter("writeback_overlapped") == 3
     finally:
+        ref.close()
         rule.close()
 
 
