@@ -957,10 +957,10 @@ def measure(args, form, progress):
         nrep = max(3, args.steps // 2)
         rule.upload(W0, H0)
         rule.set_option("gram", 1)
-        dt_gram, lg = timed(1, nrep)
+        dt_gram, lg = timed(5, nrep)  # (a few warm-up iterations: the side measurements before this one leave the device idle for a moment)
         dt_gram /= nrep
         rule.set_option("gram", 2)
-        dt_gram2, _ = timed(1, nrep)
+        dt_gram2, _ = timed(3, nrep)
         dt_gram2 /= nrep
         rule.set_option("gram", 0)
 
