@@ -235,3 +235,24 @@ def test_python_twin_refuses_arrays_it_cannot_hand_over(cmf, oracle):
             rule.update_feature_maps(data, np.zeros(W0.shape, order="F"), np.zeros(H0.shape, dtype=np.float32, order="F"))
     finally:
         rule.close()
+
+
+def test_armed_handle_can_be_destroyed_and_rearmed(cmf, oracle):
+    """An arm that is never followed by its rule call must not leave anything behind: the handle is destroyed cleanly (the W
+    copy in flight included), and arming again replaces the pointers."""
+    data, W0, H0 = problem(oracle, 60, 300, 32, 8)
+    pd = ctypes.POINTER(ctypes.c_double)
+    for devices in (None, [0, 0]):
+        rule = cmf.MultUpdate(data, W0, H0, devices=devices)
+        W, H = caller_arrays(W0, H0)
+        W2, H2 = caller_arrays(W0, H0)
+        rule.update_motifs()
+        check(rule._lib.cmf_arm_writeback(rule._h, W.ctypes.data_as(pd), H.ctypes.data_as(pd)))
+        check(rule._lib.cmf_arm_writeback(rule._h, W2.ctypes.data_as(pd), H2.ctypes.data_as(pd)))  # the second arm wins
+        rule.update_feature_maps()
+        Wd, Hd = rule.download()
+        assert np.array_equal(W2, Wd) and np.array_equal(H2, Hd) and np.isnan(W).all() and np.isnan(H).all()
+        rule.update_motifs()
+        check(rule._lib.cmf_arm_writeback(rule._h, W.ctypes.data_as(pd), H.ctypes.data_as(pd)))
+        rule.close()  # armed, never served
+        assert np.isnan(W).all() and np.isnan(H).all()
