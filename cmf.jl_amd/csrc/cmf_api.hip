@@ -650,8 +650,15 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     {
         if (h->small_k) { // few components: one-wave tiles over the ceil(K/2) live k pairs per lag (conv_small_kernel)
             const int nkp = (d.K + 1) / 2;
-            grid = dim3(tiles3);
-#define CASE(NKP_) hipLaunchKernelGGL((conv_small_kernel<MODE, NKP_>), grid, dim3(64), 0, h->stream, p, gx3)
+            // the tiles beyond whole rounds of one tile per SIMD slot-triple (3 per SIMD) go out as quarter pieces at the end of the
+            // grid, when they are few (at most one tile per SIMD: otherwise whole tiles balance well enough)
+            static const int sk_split = getenv("CMF_SMALL_K_CONV_SPLIT") ? atoi(getenv("CMF_SMALL_K_CONV_SPLIT")) : 1; // measurement knob
+            const int per_round = 4 * h->n_cu;                          // one tile per SIMD
+            const int remq = tiles3 % per_round;
+            const int cutq = (sk_split && h->conv_split && tiles3 >= per_round && remq > 0 && remq <= per_round / 4) ? remq : 0;
+            const int n_full = tiles3 - cutq;
+            grid = dim3(n_full + 4 * cutq);
+#define CASE(NKP_) hipLaunchKernelGGL((conv_small_kernel<MODE, NKP_>), grid, dim3(64), 0, h->stream, p, gx3, n_full)
             if (nkp <= 1) CASE(1); else if (nkp == 2) CASE(2); else if (nkp == 3) CASE(3); else if (nkp == 4) CASE(4);
             else if (nkp <= 6) CASE(6); else CASE(8);
 #undef CASE
@@ -1388,6 +1395,11 @@ int cmf_destroy(cmf_handle h)
 {
     if (h && h->group) {
         cmf_group_s *g = h->group;
+        if (h->wb && !h->wb->pool.empty()) { // write-back helpers read the group's shards: none may outlive the group
+            for (cmf_handle_s *s : g->sh)
+                if (s->wb) s->wb->cancel.store(true, std::memory_order_release);
+            (void)cmf_pool_wait(h->wb->pool, 5.0);
+        }
         std::vector<cmf_handle_s *> shards = g->sh;
         group_destroy(g); // detaches the shards from the group's buffers
         for (cmf_handle_s *s : shards) {

@@ -643,16 +643,16 @@ __device__ __forceinline__ void conv_epilogue_block(const f32x16 &acc, const Con
 
 // one lag of a quarter tile: 16 k pairs, one MFMA each, into the single accumulator -- the same k / lag order per
 // output element as conv2_lag, so a quarter tile's results are bitwise those of the 64 x 64 tile path
-template <int MODE, bool FIRST = false>
-__device__ __forceinline__ void convq_lag(f32x16 &acc, const float *hsb, const float (&w)[16])
+template <int MODE, bool FIRST = false, int NKP = 16>
+__device__ __forceinline__ void convq_lag(f32x16 &acc, const float *hsb, const float (&w)[NKP])
 {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float a0 = hsb[0];
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
-    for (int kp = 0; kp < 16; ++kp) {
+    for (int kp = 0; kp < NKP; ++kp) {
         float na0 = 0.f;
-        if (kp + 1 < 16) {
+        if (kp + 1 < NKP) {
             na0 = hsb[(kp + 1) * 2 * CONV3_STRIDE];
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
@@ -664,14 +664,16 @@ __device__ __forceinline__ void convq_lag(f32x16 &acc, const float *hsb, const f
     }
 }
 
-__device__ __forceinline__ void convq_load_w(float (&w)[16], __amdgpu_buffer_rsrc_t wr, int woff, int lag, int lagbytes, int rowbytes)
+template <int NKP = 16>
+__device__ __forceinline__ void convq_load_w(float (&w)[NKP], __amdgpu_buffer_rsrc_t wr, int woff, int lag, int lagbytes, int rowbytes)
 {
 #pragma unroll
-    for (int kp = 0; kp < 16; ++kp) w[kp] = cmf_bload(wr, woff, lag * lagbytes + kp * 2 * rowbytes);
+    for (int kp = 0; kp < NKP; ++kp) w[kp] = cmf_bload(wr, woff, lag * lagbytes + kp * 2 * rowbytes);
 }
 
 // A quarter tile: one wave, one 32 (t) x 32 (n) block at (t0, n0); H strip = 32 k rows x 64 columns (32 + the 32-lag halo)
-template <int MODE>
+// NKP: k pairs per lag that hold data (16 = a whole k block; the few-component kernel passes ceil(K / 2): rows k >= K of Ht and Wt are zero)
+template <int MODE, int NKP = 16>
 __device__ __forceinline__ void conv3_quarter(const ConvParams &p, float *Hs, int t0, int n0, int lane, int pidx)
 {
     const int i = lane & 31, h = lane >> 5;
@@ -682,26 +684,27 @@ __device__ __forceinline__ void conv3_quarter(const ConvParams &p, float *Hs, in
     const int rowbytes = Np * 4;
     const int lagbytes = K32 * Np * 4;
     const int woff = (h * Np + n0 + i) * 4;
-    float wA[16], wB[16];
+    float wA[NKP], wB[NKP];
+    constexpr int NQ = (2 * NKP + 7) / 8 < 4 ? (2 * NKP + 7) / 8 : 4; // 8-row passes of the strip load that hold live k rows
     for (int kb = 0; kb < p.KB; ++kb) {
         for (int lb = 0; lb < LB; ++lb) {
             const int lbeg = lb * 32;
             const int lend = (p.L < lbeg + 32) ? p.L : (lbeg + 32);
             const int npair = (lend - lbeg + 1) >> 1;
             const __amdgpu_buffer_rsrc_t wr = cmf_rsrc(p.Wt + ((size_t)lbeg * K32 + kb * 32) * Np, (size_t)(2 * npair) * lagbytes);
-            convq_load_w(wA, wr, woff, 0, lagbytes, rowbytes);
+            convq_load_w<NKP>(wA, wr, woff, 0, lagbytes, rowbytes);
             {   // H strip: Hs[r][c] = Ht[kb*32 + r][PADL + t0 - lbeg - 32 + c], c in [0,64): 8 lanes per row, 8 rows per pass
                 const int r = lane >> 3, c = (lane & 7) * 4;
                 const float *src = p.Ht + (size_t)(kb * 32 + r) * TP + (p.PADL + t0 - lbeg - 32 + c);
                 float *dst = Hs + r * CONV3_STRIDE + c;
                 f32x4 v[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) v[q * 2 + j] = *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * j);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4 *>(dst + (8 * q) * CONV3_STRIDE + 32 * j) = v[q * 2 + j];
             }
@@ -710,22 +713,22 @@ __device__ __forceinline__ void conv3_quarter(const ConvParams &p, float *Hs, in
             const float *hsb = Hs + h * CONV3_STRIDE + 32 + i;
             int pr = 0;
             if (kb == 0 && lb == 0) {
-                convq_load_w(wB, wr, woff, 1, lagbytes, rowbytes);
+                convq_load_w<NKP>(wB, wr, woff, 1, lagbytes, rowbytes);
                 __builtin_amdgcn_sched_barrier(0);
-                convq_lag<MODE, true>(acc, hsb, wA);
-                convq_load_w(wA, wr, woff, (1 < npair) ? 2 : 0, lagbytes, rowbytes);
+                convq_lag<MODE, true, NKP>(acc, hsb, wA);
+                convq_load_w<NKP>(wA, wr, woff, (1 < npair) ? 2 : 0, lagbytes, rowbytes);
                 __builtin_amdgcn_sched_barrier(0);
-                convq_lag<MODE>(acc, hsb - 1, wB);
+                convq_lag<MODE, false, NKP>(acc, hsb - 1, wB);
                 pr = 1;
             }
             for (; pr < npair; ++pr) {
                 const int l0 = 2 * pr;
-                convq_load_w(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
+                convq_load_w<NKP>(wB, wr, woff, l0 + 1, lagbytes, rowbytes);
                 __builtin_amdgcn_sched_barrier(0);
-                convq_lag<MODE>(acc, hsb - l0, wA);
-                convq_load_w(wA, wr, woff, (pr + 1 < npair) ? l0 + 2 : l0, lagbytes, rowbytes);
+                convq_lag<MODE, false, NKP>(acc, hsb - l0, wA);
+                convq_load_w<NKP>(wA, wr, woff, (pr + 1 < npair) ? l0 + 2 : l0, lagbytes, rowbytes);
                 __builtin_amdgcn_sched_barrier(0);
-                convq_lag<MODE>(acc, hsb - l0 - 1, wB);
+                convq_lag<MODE, false, NKP>(acc, hsb - l0 - 1, wB);
             }
         }
     }
@@ -899,16 +902,23 @@ __global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p, int gx, int 
 }
 
 // C1 for few components (K <= 16, one k block): conv3's one-wave 64 x 64 tiles with the lag loop running over the NKP =
-// ceil(K / 2) k pairs that hold data instead of all 16 -- K = 5 issues 3/16 of the MFMAs of the padded k block.  Whole
-// tiles only (a launch of this size has no thin last round worth cutting up).
+// ceil(K / 2) k pairs that hold data instead of all 16 -- K = 5 issues 3/16 of the MFMAs of the padded k block.
+// grid: n_full whole tiles + 4 quarter pieces for each of the remaining tiles, dispatched last (conv3_kernel's scheme): the
+// reference's protocol shape is 3128 tiles on 1024 SIMDs -- 3.05 per SIMD, so that a handful of SIMDs ran a fourth whole tile
+// while the chip waited (36 us for 19.5 us of MFMA issue per SIMD); in quarters the excess is a quarter tile on a quarter of the SIMDs.
 template <int MODE, int NKP>
-__global__ __launch_bounds__(64, (NKP <= 4 && (MODE <= 2 || MODE == 5)) ? 4 : 3) void conv_small_kernel(ConvParams p, int gx)
+__global__ __launch_bounds__(64, (NKP <= 4 && (MODE <= 1 || MODE == 5)) ? 4 : 3) void conv_small_kernel(ConvParams p, int gx, int n_full)
 {
     __shared__ __attribute__((aligned(16))) float Hs[32 * CONV3_STRIDE];
     const int b = blockIdx.x;
-    const int n0 = (b % gx) * 64;
-    if (n0 + 32 < p.N) conv3_tile<MODE, 2, NKP>(p, Hs, (b / gx) * 64, n0, threadIdx.x, b);
-    else conv3_tile<MODE, 1, NKP>(p, Hs, (b / gx) * 64, n0, threadIdx.x, b);
+    if (b < n_full) {
+        const int n0 = (b % gx) * 64;
+        if (n0 + 32 < p.N) conv3_tile<MODE, 2, NKP>(p, Hs, (b / gx) * 64, n0, threadIdx.x, b);
+        else conv3_tile<MODE, 1, NKP>(p, Hs, (b / gx) * 64, n0, threadIdx.x, b);
+    } else {
+        const int q = b - n_full, tile = n_full + (q >> 2), sub = q & 3;
+        conv3_quarter<MODE, NKP>(p, Hs, (tile / gx) * 64 + (sub >> 1) * 32, (tile % gx) * 64 + (sub & 1) * 32, threadIdx.x, b);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
