@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(256) void h_update_kernel(float *H, float *Ht, cons
     const f32x4 *sd = reinterpret_cast<const f32x4 *>(denp);
     const size_t ns4 = num_stride / 4, ds4 = den_stride / 4;
     f32x4 num = {0.f, 0.f, 0.f, 0.f}, den = {0.f, 0.f, 0.f, 0.f};
-    if (t < Tl) {
+    if (t < Tl && k < K) { // (a group of four components that lies wholly in the padding of the k block reads nothing: K = 5 of 32)
         const size_t idx = ((size_t)t * K32 + k) / 4;
         for (int s = g; s < Snum; s += 4) num += sn[(size_t)s * ns4 + idx];
         for (int s = g; s < Sden; s += 4) den += sd[(size_t)s * ds4 + idx];
@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(256) void h_update_kernel(float *H, float *Ht, cons
             den += red[q][e][1];
         }
         f32x4 hn = {0.f, 0.f, 0.f, 0.f};
-        if (t < Tl) {
+        if (t < Tl && k < K) { // (the padding stays the zero it is)
             f32x4 *hp = reinterpret_cast<f32x4 *>(H + (size_t)(PADL + t) * K32 + k);
             const f32x4 x = *hp;
 #pragma unroll

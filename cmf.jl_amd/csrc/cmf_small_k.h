@@ -227,42 +227,58 @@ __global__ __launch_bounds__(256) void slab_sum_small_kernel(float *out, const f
     if (carry.partial && blockIdx.x == gridDim.x - 1) cmf_block_loss_reduce(carry);
 }
 
-// E1 for few components on a single handle, in ONE launch behind the C2 kernel: the slabs of hxt_small_kernel are summed
-// (slab order, exactly as slab_sum_small_kernel adds them: bitwise the same numW / denomW), W is updated (mult.jl:37-38) in
-// both layouts, and the A operand of the C3 GEMM (Wj, layout of wj_pack_kernel) is written from the same values -- the slab
-// sum, the update and the pack were three launches of 5-7 us each on a 270 us iteration.  The last block also performs a loss
-// reduction deferred by cmf_iterate.  slabs: [nslabs][2][JP][Np].  grid (Np/64, L), block 256: thread (n = tid % 64, k = tid / 64 + 4 q).
+// E1 for few components on a single handle, in ONE launch behind the C2 kernel: the slabs of hxt_small_kernel are summed, W is
+// updated (mult.jl:37-38) in both layouts, and the A operand of the C3 GEMM (Wj, layout of wj_pack_kernel) is written from the same
+// values -- the slab sum, the update and the pack were three launches of 5-8 us each on a 250 us iteration.  The last block also
+// performs a loss reduction deferred by cmf_iterate.  slabs: [nslabs][2][JP][Np].
+// grid (Np/64, L, K), block 256: one (lag, component) row and 64 units per workgroup; its four 64-thread groups each sum every fourth
+// slab (all loads of a thread independent and in flight together) and are combined in a fixed order through LDS, so the result does
+// not depend on timing.  (The first form -- one workgroup per lag, the slabs added one after the other by each thread -- was 80
+// workgroups of dependent loads: 14 us, as long as the three launches it replaced.)
 __global__ __launch_bounds__(256) void w_update_small_kernel(float *Wt, float *Wn, float *Wj, const float *slabs, int nslabs,
                                                               int N, int K, int L, int Np, int K32, int JP, int Kg, int GR, int JP3,
                                                               float l1, float two_l2, CmfLossCarry carry)
 {
-    const int n = blockIdx.x * 64 + (threadIdx.x & 63), l = blockIdx.y;
+    __shared__ float red[3][64][2];
+    const int nn = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + nn, l = blockIdx.y, k = blockIdx.z;
     const size_t sstride = (size_t)2 * JP * Np;
-    for (int k = threadIdx.x >> 6; k < K; k += 4) {
-        const float *bn = slabs + (size_t)(l * K + k) * Np + n, *bd = bn + (size_t)JP * Np;
-        float num = bn[0], den = bd[0];
-        for (int s = 1; s < nslabs; s += 4) { // four slabs in flight, added in slab order
-            float a[4], b[4];
+    const float *bn = slabs + (size_t)(l * K + k) * Np + n, *bd = bn + (size_t)JP * Np;
+    float num = 0.f, den = 0.f;
+    for (int s0 = g; s0 < nslabs; s0 += 32) { // eight slabs of this group per pass
+        float a[8], b[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const size_t o = (size_t)((s + u < nslabs) ? s + u : s) * sstride;
-                a[u] = bn[o];
-                b[u] = bd[o];
-            }
+        for (int u = 0; u < 8; ++u) {
+            const int sl = s0 + 4 * u;
+            const size_t o = (size_t)(sl < nslabs ? sl : 0) * sstride;
+            a[u] = bn[o];
+            b[u] = bd[o];
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (s + u < nslabs) { num += a[u]; den += b[u]; }
+        for (int u = 0; u < 8; ++u)
+            if (s0 + 4 * u < nslabs) { num += a[u]; den += b[u]; }
+    }
+    if (g > 0) {
+        red[g - 1][nn][0] = num;
+        red[g - 1][nn][1] = den;
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            num += red[q][nn][0];
+            den += red[q][nn][1];
         }
         const size_t it = ((size_t)l * K32 + k) * Np + n;
         const float wn = (n < N) ? cmf_mu(Wt[it], num, den, l1, two_l2) : 0.f;
         Wt[it] = wn;
         Wn[((size_t)l * Np + n) * K32 + k] = wn;
         if (Wj) {
-            const int g = k / Kg;
-            Wj[(size_t)n * JP3 + g * GR + (k - g * Kg) * L + l] = wn;
+            const int gq = k / Kg;
+            Wj[(size_t)n * JP3 + gq * GR + (k - gq * Kg) * L + l] = wn;
         }
     }
-    if (carry.partial && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) cmf_block_loss_reduce(carry);
+    if (carry.partial && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) cmf_block_loss_reduce(carry);
 }
 
 // C3 puts whole components into a row group: group g holds the components [g*Kg, (g+1)*Kg), its row kl*L + l is
@@ -316,7 +332,10 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
     const int L = p.L, K32 = p.K32, Tl = p.Tl;
     const int kbase = mg * p.Kg;
     const int kn = (p.K - kbase < p.Kg) ? p.K - kbase : p.Kg;       // components of this row group
-    const int kw = ((mg == p.MG - 1) ? K32 : kbase + kn) - kbase;   // columns k it writes: its components (+ the zero padding up to K32 for the last group)
+    // columns k it writes: its components (+, for the last group, the zeros up to the next multiple of 4: h_update reads whole groups of
+    // four components; the columns behind that are zero in every slab since the handle was made -- every writer of hslabs writes
+    // zeros there -- and writing them again was 19 MB per launch at K = 5)
+    const int kw = ((mg == p.MG - 1) ? ((p.K + 3) & ~3) : kbase + kn) - kbase;
     float *slab0 = p.out + (size_t)src * Tl * K32 + kbase;
     float *slab1 = slab0 + (size_t)p.nsrc * Tl * K32;
     if (c0 >= p.TG) { // nothing spills into the last block
