@@ -151,6 +151,7 @@ struct cmf_handle_s {
     bool small_k_ok = false;                // the shape allows it
     bool sk_tc_ok = false, sk_tc = false;   // ... and its C3 form (G GEMM + fold) has enough columns to fill the chip; sk_tc: in use
     int sk_J = 0, sk_JP = 0, sk_MG = 1, sk_MBW = 4, sk_chunk_len = 16, sk_ngroups = 1, sk_TG = 128;
+    int sk_RV = 0;                          // C2: the last sk_RV rows j on the VALU instead of in a padded MFMA block (hxt_small_kernel)
     int sk3_MG = 1, sk3_MBW = 4, sk3_Kg = 1, sk3_JP = 128; // C3: whole components per row group (g_gemm_fold_small_kernel)
     float *sk_slabs = nullptr, *sk_Wj = nullptr;
     bool sk_wj_fresh = false;               // sk_Wj holds the resident W (written by w_update_small_kernel; every other writer of W clears it)
@@ -358,6 +359,13 @@ static void plan(cmf_handle_s *h, int n_cu)
         h->sk_MG = (mblocks + c2max - 1) / c2max;             // groups of at most SK_MAXMBW_C2 blocks ...
         h->sk_MBW = (mblocks + h->sk_MG - 1) / h->sk_MG;      // ... as even as possible: the least padding
         h->sk_JP = 32 * h->sk_MBW * h->sk_MG;
+        // a last block of at most SK_RVT live rows goes to the VALU (one row group, 2-4 blocks, K <= SK_KEARLY: the kernel variants that exist)
+        static const bool rv_on = !(getenv("CMF_SK_VALU_ROWS") && atoi(getenv("CMF_SK_VALU_ROWS")) == 0); // measurement knob
+        h->sk_RV = 0;
+        if (rv_on && h->sk_MG == 1 && h->sk_MBW >= 2 && h->sk_MBW <= 4 && d.K <= SK_KEARLY && h->sk_J % 32 >= 1 && h->sk_J % 32 <= SK_RVT) {
+            h->sk_RV = h->sk_J % 32;
+            h->sk_MBW -= 1; // (sk_JP keeps the padded row count: the slabs' rows)
+        }
         h->sk_TG = (int)rup(d.Tl + d.L - 1, 128);
         // C2: a wave = (n block, m group, source, time chunk).  Chunks of about 512 rows (four strips): many short waves, so that
         // the rounds of the launch are short and its last one costs little -- but at least as many waves as are resident; chunks are whole
@@ -789,13 +797,14 @@ static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int n
         SkHxtParams p;
         p.Ht = h->Ht; p.X0 = X0; p.X1 = X1; p.slabs = h->sk_slabs;
         p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.L = d.L; p.J = h->sk_J; p.JP = h->sk_JP; p.MG = h->sk_MG; p.Tl = d.Tl;
-        p.chunk_len = h->sk_chunk_len; p.nsrc = nsrc;
+        p.chunk_len = h->sk_chunk_len; p.nsrc = nsrc; p.RV = h->sk_RV;
         size_t lds = std::max<size_t>((size_t)4 * (d.K + 1) * SK_HS_STRIDE, 4 * 16 * 64) * sizeof(float);
         static const size_t lds_min = getenv("CMF_SK_HXT_LDS") ? (size_t)atol(getenv("CMF_SK_HXT_LDS")) : 0; // measurement knob: workgroups per CU through the LDS request
         lds = std::max(lds, lds_min);
         const dim3 grid((d.Np / 32) * h->sk_MG, h->sk_ngroups, nsrc);
         switch (h->sk_MBW) {
-#define CASE(M_) case M_: if (d.K <= SK_KEARLY && M_ <= 8) hipLaunchKernelGGL((hxt_small_kernel<M_, (M_ <= 8)>), grid, dim3(256), lds, h->stream, p); /* (9 or 10 blocks + the early strip registers do not fit two waves per SIMD) */ \
+#define CASE(M_) case M_: if (h->sk_RV) hipLaunchKernelGGL((hxt_small_kernel<(M_ <= 3 ? M_ : 3), true, SK_RVT>), grid, dim3(256), lds, h->stream, p); /* (1-3 MFMA blocks + VALU rows) */ \
+                          else if (d.K <= SK_KEARLY && M_ <= 8) hipLaunchKernelGGL((hxt_small_kernel<M_, (M_ <= 8)>), grid, dim3(256), lds, h->stream, p); /* (9 or 10 blocks + the early strip registers do not fit two waves per SIMD) */ \
                           else hipLaunchKernelGGL((hxt_small_kernel<M_, false>), grid, dim3(256), lds, h->stream, p); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
 #undef CASE

@@ -29,6 +29,7 @@ struct SkHxtParams {
     const float *X1;  // est  [TP][Np]
     float *slabs;     // [gridDim.y][nsrc][JP][Np]
     int Np, TP, PADL, K, L, J, JP, MG, Tl;
+    int RV;           // rows j in [32 * MBW, 32 * MBW + RV) are contracted on the VALU (RVT kernels; MG = 1)
     int chunk_len;    // rows per wave, a multiple of 16; 4 waves of a workgroup = 4 consecutive chunks, added through LDS
     int nsrc;
 };
@@ -40,8 +41,14 @@ struct SkHxtParams {
 // LDS at the boundary, so the boundary costs an LDS write instead of an exposed global load -- which, behind the X prefetch
 // ring, is an exposed HBM round trip (a wave's loads return in issue order), paid by the two waves of a SIMD at the same
 // moment (same program, started together: both stall, the MFMA pipe idles).
+// RVT > 0: the last RV <= RVT rows j of the (single) row group are not padded to a 32-row MFMA block but contracted on the
+// VALU beside the MFMAs: K = 5, L = 20 is 100 rows = 3 blocks + 4 rows -- a fourth block would multiply 28 rows of zeros
+// (a quarter of the launch's MFMAs).  Lane (i, h) holds X[t + h][n0 + i] for the MFMA's B operand already; a VALU row costs one
+// broadcast LDS read (issued a step ahead, like the A operands) and one FMA per step, hidden under the step's MBW MFMAs; the
+// two halves of the wave (the two time parities) are added at the end.
 #define SK_KEARLY 8
-template <int MBW, bool EARLY>
+#define SK_RVT 4
+template <int MBW, bool EARLY, int RVT = 0>
 __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_small_kernel(SkHxtParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float sk_lds[]; // 4 strips of (K+1) rows; reused for the chunk reduction
@@ -71,6 +78,16 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
         abase[mb] = (j < p.J) ? k * SK_HS_STRIDE + (L - 1) - l + h : K * SK_HS_STRIDE + h;
     }
     for (int c = lane; c < SK_HS_STRIDE; c += 64) Hs[K * SK_HS_STRIDE + c] = 0.f;
+    constexpr int RVN = RVT > 0 ? RVT : 1;
+    int vbase[RVN];
+    float accv[RVN];
+#pragma unroll
+    for (int r = 0; r < RVN; ++r) {
+        const int j = MBW * 32 + r;
+        const int l = j / K, k = j - l * K;
+        vbase[r] = (RVT > 0 && r < p.RV && j < p.J) ? k * SK_HS_STRIDE + (L - 1) - l + h : K * SK_HS_STRIDE + h;
+        accv[r] = 0.f;
+    }
 
     f32x16 acc[MBW];
 #pragma unroll
@@ -99,25 +116,39 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
     for (int q = 0; q < NS - 1; ++q) xload(bx[q], q);
     auto mround = [&](const float (&bc)[8], int r0) { // the MFMAs of one round on strip rows r0 .. r0 + 15
         // software-pipelined like conv2_lag: the LDS reads of step u+1 are issued ahead of the MFMAs of step u
-        float a[MBW];
+        float a[MBW], va[RVN];
 #pragma unroll
         for (int mb = 0; mb < MBW; ++mb) a[mb] = Hs[abase[mb] + r0];
-        __builtin_amdgcn_sched_group_barrier(0x100, MBW, 0);
+#pragma unroll
+        for (int r = 0; r < RVN; ++r) va[r] = RVT > 0 ? Hs[vbase[r] + r0] : 0.f;
+        __builtin_amdgcn_sched_group_barrier(0x100, MBW + RVT, 0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            float an[MBW];
+            float an[MBW], van[RVN];
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) an[mb] = 0.f;
+#pragma unroll
+            for (int r = 0; r < RVN; ++r) van[r] = 0.f;
             if (u + 1 < 8) {
 #pragma unroll
                 for (int mb = 0; mb < MBW; ++mb) an[mb] = Hs[abase[mb] + r0 + 2 * (u + 1)];
-                __builtin_amdgcn_sched_group_barrier(0x100, MBW, 0);
+                if (RVT > 0) {
+#pragma unroll
+                    for (int r = 0; r < RVN; ++r) van[r] = Hs[vbase[r] + r0 + 2 * (u + 1)];
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, MBW + RVT, 0);
             }
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bc[u], acc[mb], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, MBW, 0);
+            if (RVT > 0) { // the VALU rows of this step (operands read a step ago)
+#pragma unroll
+                for (int r = 0; r < RVN; ++r) accv[r] = cmf_fma_opaque(va[r], bc[u], accv[r]); // (opaque: the SLP vectoriser packs plain FMAs into v_pk_fma_f32 and reorders the step around them)
+            }
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) a[mb] = an[mb];
+#pragma unroll
+            for (int r = 0; r < RVN; ++r) va[r] = van[r];
         }
     };
     const int width = SK_SC + L - 1;
@@ -193,6 +224,17 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
             slab[(size_t)j * Np + nb * 32 + i] = sum;
         }
         __syncthreads();
+    }
+    if (RVT > 0) { // the VALU rows: the two time parities of a wave, then the 4 chunks in chunk order
+#pragma unroll
+        for (int r = 0; r < RVN; ++r) red[(wave * 16 + r) * 64 + lane] = accv[r] + __shfl_xor(accv[r], 32);
+        __syncthreads();
+        for (int r = wave; r < RVT; r += 4) {
+            float sum = red[r * 64 + lane];
+#pragma unroll
+            for (int v = 1; v < 4; ++v) sum += red[(v * 16 + r) * 64 + lane];
+            if (r < p.RV && h == 0) slab[(size_t)(MBW * 32 + r) * Np + nb * 32 + i] = sum;
+        }
     }
 }
 
