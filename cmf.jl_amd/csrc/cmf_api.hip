@@ -153,6 +153,7 @@ struct cmf_handle_s {
     int sk_J = 0, sk_JP = 0, sk_MG = 1, sk_MBW = 4, sk_chunk_len = 16, sk_ngroups = 1, sk_TG = 128;
     int sk_RV = 0;                          // C2: the last sk_RV rows j on the VALU instead of in a padded MFMA block (hxt_small_kernel)
     int sk3_MG = 1, sk3_MBW = 4, sk3_Kg = 1, sk3_JP = 128; // C3: whole components per row group (g_gemm_fold_small_kernel)
+    int sk3_GR = 128, sk3_RV = 0;           // rows of a row group in Wj (32-row blocks); the last sk3_RV live rows on the VALU (sk3_MBW then counts the MFMA blocks only)
     float *sk_slabs = nullptr, *sk_Wj = nullptr;
     bool sk_wj_fresh = false;               // sk_Wj holds the resident W (written by w_update_small_kernel; every other writer of W clears it)
     int tc_S_full = 1, tc_S1_full = 1;      // fragment slabs of the general transconv kernel (tc_S / tc_S1 are 1 while small_k is on)
@@ -388,7 +389,15 @@ static void plan(cmf_handle_s *h, int n_cu)
         }
         h->sk3_MG = (d.K + h->sk3_Kg - 1) / h->sk3_Kg;
         h->sk3_MBW = (h->sk3_Kg * d.L + 31) / 32;
-        h->sk3_JP = 32 * h->sk3_MBW * h->sk3_MG;
+        h->sk3_GR = 32 * h->sk3_MBW;
+        h->sk3_JP = h->sk3_GR * h->sk3_MG;
+        // (as in C2: a last block of at most SK_RVT live rows goes to the VALU; their Wj columns lie in the fold tile's LDS during the main loop)
+        h->sk3_RV = 0;
+        if (rv_on && h->sk3_MG == 1 && h->sk3_MBW >= 2 && h->sk3_MBW <= 4 && (h->sk3_Kg * d.L) % 32 >= 1 && (h->sk3_Kg * d.L) % 32 <= SK_RVT &&
+            (8 * ((rup(d.N, 2) + 7) / 8) + 2) * 4 <= 32 * SK_TILE_STRIDE) {
+            h->sk3_RV = (h->sk3_Kg * d.L) % 32;
+            h->sk3_MBW -= 1;
+        }
         h->sk_tc_ok = (int64_t)(h->sk_TG / 32) * h->sk3_MG * 2 >= 2LL * n_cu;
     }
     // C1 (conv)
@@ -729,15 +738,17 @@ static int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
     const CmfDims &d = h->d;
     if (!h->sk_wj_fresh) { // (w_update_small_kernel writes the packed operand itself; every other writer of W leaves it stale)
         hipLaunchKernelGGL(wj_pack_kernel, dim3((unsigned)std::min<size_t>(1024, ((size_t)d.Np * h->sk3_JP + 255) / 256)), dim3(256), 0, h->stream,
-                           h->Wn, h->sk_Wj, d.Np, d.K, d.L, d.K32, h->sk3_Kg, 32 * h->sk3_MBW, h->sk3_JP);
+                           h->Wn, h->sk_Wj, d.Np, d.K, d.L, d.K32, h->sk3_Kg, h->sk3_GR, h->sk3_JP);
         KCHK("wj_pack_kernel");
     }
     SkGemmParams p;
     p.Wj = h->sk_Wj; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.out = h->hslabs;
     p.TP = d.TP; p.PADL = d.PADL; p.JP = h->sk3_JP; p.MG = h->sk3_MG; p.TG = h->sk_TG; p.N2 = (int)rup(d.N, 2); p.Np = d.Np; p.nsrc = nsrc;
-    p.Tl = d.Tl; p.K = d.K; p.L = d.L; p.K32 = d.K32; p.Kg = h->sk3_Kg;
+    p.Tl = d.Tl; p.K = d.K; p.L = d.L; p.K32 = d.K32; p.Kg = h->sk3_Kg; p.RV = h->sk3_RV;
+    const dim3 grid(h->sk_TG / 128 + 1, nsrc * h->sk3_MG);
     switch (h->sk3_MBW) {
-#define CASE(M_) case M_: hipLaunchKernelGGL((g_gemm_fold_small_kernel<M_>), dim3(h->sk_TG / 128 + 1, nsrc * h->sk3_MG), dim3(256), 0, h->stream, p); break;
+#define CASE(M_) case M_: if (h->sk3_RV) hipLaunchKernelGGL((g_gemm_fold_small_kernel<(M_ <= 3 ? M_ : 3), SK_RVT>), grid, dim3(256), 0, h->stream, p); /* (1-3 MFMA blocks + VALU rows) */ \
+                 else hipLaunchKernelGGL((g_gemm_fold_small_kernel<M_>), grid, dim3(256), 0, h->stream, p); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
 #undef CASE
     default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk3_MBW);
@@ -905,7 +916,7 @@ static int w_phase_impl(cmf_handle_s *h, double l1W, double l2W)
         h->carry = CmfLossCarry{};
     }
     hipLaunchKernelGGL(w_update_small_kernel, dim3(d.Np / 64, d.L, d.K), dim3(256), 0, h->stream, h->Wt, h->Wn, h->sk_tc ? h->sk_Wj : nullptr, h->sk_slabs,
-                       h->sk_ngroups, d.N, d.K, d.L, d.Np, d.K32, h->sk_JP, h->sk3_Kg, 32 * h->sk3_MBW, h->sk3_JP,
+                       h->sk_ngroups, d.N, d.K, d.L, d.Np, d.K32, h->sk_JP, h->sk3_Kg, h->sk3_GR, h->sk3_JP,
                        (float)l1W, (float)(2.0 * l2W), carry); // mult.jl:37-38
     KCHK("w_update_small_kernel");
     h->est_kind = 0;

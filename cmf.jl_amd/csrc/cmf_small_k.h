@@ -349,6 +349,7 @@ struct SkGemmParams {
                       // from the next block (the last L - 1 columns of a block only; zeros elsewhere)
     int TP, PADL, JP, MG, TG, N2, Np, nsrc;
     int Tl, K, L, K32, Kg;
+    int RV;           // rows [32 * MBW, 32 * MBW + RV) of the (single) row group are contracted on the VALU (RVT kernels)
 };
 
 // C3 in ONE launch: out[t][k] = sum_l G[(k, l)][t + l] with G[(k, l)][t'] = sum_n W[l][n][k] XT[n][t'] (common.jl:71-81 with the
@@ -362,10 +363,15 @@ struct SkGemmParams {
 // the two slabs.  G never exists in memory (until round 4: 2*JP*TG floats written by the GEMM and read back by a fold kernel,
 // as much HBM traffic as a pass over data), and no MFMA work is repeated.  The extra workgroup at the end of grid.x only
 // zero-fills slab 1 of the last block.
-template <int MBW>
+// RVT > 0 (one row group): the last RV <= RVT rows of the group are not padded to a 32-row MFMA block (K = 5, L = 20: 100 rows, a
+// fourth block with 4 live rows) but contracted on the VALU, next to the MFMAs of the other blocks: their Wj columns lie in LDS
+// (in the tile's space, which the fold uses only afterwards), one broadcast b128 read per n pair gives a lane the RVT values
+// of its n parity, read one step ahead; the two parities meet in the epilogue and the rows go through the fold as a short block.
+template <int MBW, int RVT = 0>
 __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kernel(SkGemmParams p)
 {
-    __shared__ float tile[32 * SK_TILE_STRIDE];
+    static_assert(RVT == 0 || RVT == 4, "the VALU rows are read as one b128");
+    __shared__ __attribute__((aligned(16))) float tile[32 * SK_TILE_STRIDE];
     __shared__ float outs[16 * SK_FOLD_COLS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -405,6 +411,17 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
     constexpr int U = 4, NSB = 3;
     float a[2][U][MBW], b[NSB][U];
     const int nrounds = (p.N2 + 2 * U - 1) / (2 * U); // (the rows a last round reads past N2 are zero padding of both operands)
+    float accv[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 *wl = reinterpret_cast<const f32x4 *>(tile) + h; // wl[n] = Wj[n][32 MBW .. + 4) (zero rows behind N: the host checks that 8 nrounds + 2 rows fit)
+    if (RVT > 0) {
+        for (int e = tid; e < (8 * nrounds + 2) * 4; e += 256) {
+            const int n = e >> 2, r = e & 3;
+            tile[e] = (n < p.Np && r < p.RV) ? p.Wj[(size_t)n * p.JP + MBW * 32 + r] : 0.f;
+        }
+        __syncthreads();
+        wv = wl[0];
+    }
     auto loadA = [&](float (&x)[U][MBW], int rd) {
         const int nx = ((rd < nrounds) ? rd : nrounds - 1) * 2 * U;
 #pragma unroll
@@ -429,9 +446,21 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
                 loadA(a[(q + 1) % 2], rd + 1);
                 __builtin_amdgcn_sched_barrier(0); // the prefetch stays in front of the round's MFMAs
 #pragma unroll
-                for (int u = 0; u < U; ++u)
+                for (int u = 0; u < U; ++u) {
+                    f32x4 wvn = wv;
+                    if (RVT > 0) {
+                        wvn = wl[rd * 2 * U + 2 * (u + 1)]; // the next step's VALU operands
+                        __builtin_amdgcn_sched_barrier(0); // (sched_group_barrier does not classify the asm FMAs: without a full barrier they are hoisted to right behind their operands' reads)
+                    }
 #pragma unroll
                     for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q % 2][u][mb], b[q % NSB][u], acc[mb], 0, 0, 0);
+                    if (RVT > 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accv[r] = cmf_fma_opaque(wv[r], b[q % NSB][u], accv[r]); // (opaque: see hxt_small_kernel)
+                        __builtin_amdgcn_sched_barrier(0);
+                        wv = wvn;
+                    }
+                }
             }
         }
     }
@@ -440,17 +469,26 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
     const int trel = tid - (L - 1);
     const bool folder = tid < 128 + L - 1;
 #pragma unroll
-    for (int mb = 0; mb < MBW; ++mb) {
-        __syncthreads(); // (the zero fill of outs / the previous block's reads)
+    for (int mb = 0; mb < MBW + (RVT > 0 ? 1 : 0); ++mb) {
+        __syncthreads(); // (the zero fill of outs / the previous block's reads / the main loops' reads of the VALU rows' operands)
+        if (mb < MBW) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tile[cmf_crow(r, h) * SK_TILE_STRIDE + wave * 32 + i] = acc[mb][r];
+            for (int r = 0; r < 16; ++r) tile[cmf_crow(r, h) * SK_TILE_STRIDE + wave * 32 + i] = acc[mb < MBW ? mb : 0][r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float g = accv[r] + __shfl_xor(accv[r], 32); // the two n parities
+                if (h == 0) tile[r * SK_TILE_STRIDE + wave * 32 + i] = g;
+            }
+        }
         __syncthreads();
+        const int nrows = mb < MBW ? 32 : p.RV;
         if (folder) {
             // row r = 32 mb + rl of the group is (component kk, lag ll) = (r / L, r % L): the same for every thread, so the
             // bookkeeping runs on the scalar unit (a table in LDS cost two broadcast reads per row)
             int kk = (32 * mb) / L, ll = 32 * mb - kk * L;
             float s = 0.f;
-            for (int rl = 0; rl < 32; ++rl) {
+            for (int rl = 0; rl < nrows; ++rl) {
                 const unsigned col = (unsigned)(trel + ll);
                 if (kk < kn && col < 128u) s += tile[rl * SK_TILE_STRIDE + col];
                 if (++ll == L) {
