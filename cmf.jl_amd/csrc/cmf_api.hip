@@ -1116,8 +1116,12 @@ static void wb_free(cmf_handle_s *h)
     CmfWriteback *wb = h->wb;
     if (!wb) return;
     if (!wb->pool.empty()) {
-        (void)cmf_pool_wait(wb->pool, 5.0);
+        const bool idle = cmf_pool_wait(wb->pool, 5.0);
         cmf_pool_stop(wb->pool, true);
+        if (!idle) { // a helper is stuck in a wait on the device: it still reads this record and its staging -- leaked, never freed under it
+            h->wb = nullptr;
+            return;
+        }
     }
     for (hipEvent_t e : {wb->ev_w_ready, wb->ev_h_ready, wb->ev_w_done, wb->ev_h_done})
         if (e) (void)hipEventDestroy(e);
@@ -1418,7 +1422,8 @@ int cmf_destroy(cmf_handle h)
         if (h->wb && !h->wb->pool.empty()) { // write-back helpers read the group's shards: none may outlive the group
             for (cmf_handle_s *s : g->sh)
                 if (s->wb) s->wb->cancel.store(true, std::memory_order_release);
-            (void)cmf_pool_wait(h->wb->pool, 5.0);
+            if (!cmf_pool_wait(h->wb->pool, 5.0)) // (stuck in a wait on a device: the group is leaked rather than freed under the helper)
+                return fail(CMF_ERR_HIP, "cmf_destroy: a write-back helper is stuck in a device wait; the group was not freed");
         }
         std::vector<cmf_handle_s *> shards = g->sh;
         group_destroy(g); // detaches the shards from the group's buffers
@@ -1655,17 +1660,21 @@ int cmf_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss)
     return wb_finish(h, update_feature_maps_body(h, l1H, l2H, loss));
 }
 
-int cmf_arm_writeback(cmf_handle h, double *W, double *H)
+static void wb_disarm(cmf_handle_s *h)
 {
-    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
-    if (!W && !H) { // disarm
-        if (h->wb && !h->group && h->wb->h_posted) (void)wb_drain(h);
-        if (h->wb) {
-            h->wb->armed = h->wb->h_posted = h->wb->w_started = false;
-            h->wb->dst_W = h->wb->dst_H = nullptr;
-        }
-        return CMF_OK;
-    }
+    if (h->wb && h->wb->h_posted) (void)wb_drain(h);
+    auto clear = [](CmfWriteback *wb) {
+        if (!wb) return;
+        wb->armed = wb->h_posted = wb->w_started = false;
+        wb->dst_W = wb->dst_H = nullptr;
+    };
+    if (h->group)
+        for (cmf_handle_s *s : h->group->sh) clear(s->wb);
+    clear(h->wb);
+}
+
+static int wb_arm(cmf_handle_s *h, double *W, double *H)
+{
     if (h->group) {
         cmf_group_s *g = h->group;
         CMFTRY(group_check_ready(g));
@@ -1701,6 +1710,18 @@ int cmf_arm_writeback(cmf_handle h, double *W, double *H)
     wb->armed_calls += 1;
     if (W && !h->group) CMFTRY(wb_start_W(h));
     return CMF_OK;
+}
+
+int cmf_arm_writeback(cmf_handle h, double *W, double *H)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (!W && !H) {
+        wb_disarm(h);
+        return CMF_OK;
+    }
+    const int rc = wb_arm(h, W, H);
+    if (rc != CMF_OK) wb_disarm(h); // (nothing half-armed keeps the caller's pointers)
+    return rc;
 }
 
 int cmf_compute_loss(cmf_handle h, double *loss)

@@ -30,6 +30,8 @@ SHAPES = [
     (48, 300, 4, 8), (7, 23, 3, 4), (5, 9, 1, 1), (1, 17, 2, 5), (6, 3, 2, 5), (4, 5, 3, 5), (70, 257, 5, 10),
     (250, 1500, 5, 20), (130, 700, 16, 20), (33, 400, 7, 19), (20, 200, 6, 40), (40, 333, 9, 15), (9, 1100, 2, 3),
     (65, 520, 11, 12), (300, 260, 13, 7), (17, 150, 16, 64), (129, 900, 15, 33), (10, 64, 8, 16), (500, 2000, 5, 10),
+    # rows on the VALU (K*L = 32 m + 1 .. 4): 1, 2, 3, 4 rows behind 2, 2, 1, 1 MFMA blocks; N at / beyond what C3 keeps of Wj in LDS
+    (60, 500, 5, 13), (31, 420, 2, 33), (90, 610, 5, 7), (45, 380, 3, 12), (1040, 200, 4, 25), (1100, 300, 4, 25),
 ]
 
 
