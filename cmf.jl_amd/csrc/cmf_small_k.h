@@ -352,6 +352,42 @@ struct SkGemmParams {
     int RV;           // rows [32 * MBW, 32 * MBW + RV) of the (single) row group are contracted on the VALU (RVT kernels)
 };
 
+// One staged block of the G tile folded into outs: thread (output column t = c0 - (L-1) + tid) adds rows row0 .. row0 + nrows of the
+// group -- row r is (component, lag) = (r / L, r % L), the same for every thread, so the bookkeeping is scalar -- at columns
+// trel + lag.  All NR reads are issued FIRST, branch-free (column clamped, value masked): as a loop of guarded reads the fold was a
+// chain of NR dependent LDS round trips per block, 13.7 us of a 64 us launch at K = 5, L = 20 (in-kernel stamps, round 5); the
+// sums are taken in the same order as before (bitwise the same result).
+template <int NR>
+__device__ __forceinline__ void sk_fold_rows(const float *tile, float *outs, int trel, int tid, int L, int kn, int row0, int nrows)
+{
+    const int kk0 = row0 / L, ll0 = row0 - kk0 * L;
+    float v[NR];
+    int ll = ll0;
+#pragma unroll
+    for (int rl = 0; rl < NR; ++rl) {
+        const unsigned col = (unsigned)(trel + ll);
+        const float x = tile[rl * SK_TILE_STRIDE + (col < 128u ? col : 0u)];
+        v[rl] = col < 128u ? x : 0.f;
+        ll = (ll + 1 == L) ? 0 : ll + 1;
+    }
+    int kk = kk0;
+    ll = ll0;
+    float s = 0.f;
+#pragma unroll
+    for (int rl = 0; rl < NR; ++rl) {
+        if (rl < nrows) {
+            s += v[rl];
+            if (++ll == L) {
+                if (kk < kn) outs[kk * SK_FOLD_COLS + tid] += s;
+                s = 0.f;
+                ll = 0;
+                ++kk;
+            }
+        }
+    }
+    if (ll != 0 && kk < kn) outs[kk * SK_FOLD_COLS + tid] += s; // (a component that continues in the next block)
+}
+
 // C3 in ONE launch: out[t][k] = sum_l G[(k, l)][t + l] with G[(k, l)][t'] = sum_n W[l][n][k] XT[n][t'] (common.jl:71-81 with the
 // lag sum taken after the contraction over n).  grid (TG/128 + 1, nsrc*MG), 256 threads.  The four waves of a workgroup form
 // the G tile of 32*MBW rows x 128 columns t' in [c0, c0 + 128) exactly like a plain GEMM -- both operands read from global
@@ -482,23 +518,9 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
             }
         }
         __syncthreads();
-        const int nrows = mb < MBW ? 32 : p.RV;
         if (folder) {
-            // row r = 32 mb + rl of the group is (component kk, lag ll) = (r / L, r % L): the same for every thread, so the
-            // bookkeeping runs on the scalar unit (a table in LDS cost two broadcast reads per row)
-            int kk = (32 * mb) / L, ll = 32 * mb - kk * L;
-            float s = 0.f;
-            for (int rl = 0; rl < nrows; ++rl) {
-                const unsigned col = (unsigned)(trel + ll);
-                if (kk < kn && col < 128u) s += tile[rl * SK_TILE_STRIDE + col];
-                if (++ll == L) {
-                    if (kk < kn) outs[kk * SK_FOLD_COLS + tid] += s;
-                    s = 0.f;
-                    ll = 0;
-                    ++kk;
-                }
-            }
-            if (ll != 0 && kk < kn) outs[kk * SK_FOLD_COLS + tid] += s; // (a component that continues in the next block)
+            if (mb < MBW) sk_fold_rows<32>(tile, outs, trel, tid, L, kn, 32 * mb, 32);
+            else sk_fold_rows<4>(tile, outs, trel, tid, L, kn, 32 * mb, p.RV);
         }
     }
     __syncthreads();
