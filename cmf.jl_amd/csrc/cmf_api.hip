@@ -153,6 +153,7 @@ struct cmf_handle_s {
     int sk_J = 0, sk_JP = 0, sk_MG = 1, sk_MBW = 4, sk_chunk_len = 16, sk_ngroups = 1, sk_TG = 128;
     int sk_RV = 0;                          // C2: the last sk_RV rows j on the VALU instead of in a padded MFMA block (hxt_small_kernel)
     int sk3_MG = 1, sk3_MBW = 4, sk3_Kg = 1, sk3_JP = 128; // C3: whole components per row group (g_gemm_fold_small_kernel)
+    int sk3_NS = 1, sk3_RPS = 1;            // short recordings: C3's reduction over n in sk3_NS pieces of sk3_RPS rounds of 8 rows (2 slabs per piece)
     int sk3_GR = 128, sk3_RV = 0;           // rows of a row group in Wj (32-row blocks); the last sk3_RV live rows on the VALU (sk3_MBW then counts the MFMA blocks only)
     float *sk_slabs = nullptr, *sk_Wj = nullptr;
     bool sk_wj_fresh = false;               // sk_Wj holds the resident W (written by w_update_small_kernel; every other writer of W clears it)
@@ -398,7 +399,19 @@ static void plan(cmf_handle_s *h, int n_cu)
             h->sk3_RV = (h->sk3_Kg * d.L) % 32;
             h->sk3_MBW -= 1;
         }
-        h->sk_tc_ok = (int64_t)(h->sk_TG / 32) * h->sk3_MG * 2 >= 2LL * n_cu;
+        // Short recordings (BASELINE configs[0]: T = 2000 is 128 waves for 1024 SIMDs): the reduction over n is cut into up to 8 pieces,
+        // each a workgroup row of its own writing its own pair of slabs (h_update adds the slabs in order: deterministic), until there
+        // are two waves per SIMD; a piece keeps at least 8 rounds of 8 rows (measured over T = 1000 .. 25000: profiles/r05_small_k_n_split.txt).
+        {
+            const int64_t waves = (int64_t)(h->sk_TG / 32) * h->sk3_MG * 2;
+            const int rounds = (int)((rup(d.N, 2) + 7) / 8);
+            static const int ns_max = getenv("CMF_SK_C3_NSPLIT") ? std::max(1, std::min(8, atoi(getenv("CMF_SK_C3_NSPLIT")))) : 8; // measurement knob
+            int ns = (int)std::min<int64_t>({(int64_t)ns_max, (8LL * n_cu + waves - 1) / waves, (int64_t)std::max(1, rounds / 8)});
+            ns = std::max(ns, 1);
+            h->sk3_RPS = (rounds + ns - 1) / ns;
+            h->sk3_NS = (rounds + h->sk3_RPS - 1) / h->sk3_RPS; // (no empty piece)
+            h->sk_tc_ok = waves * h->sk3_NS >= 2LL * n_cu;
+        }
     }
     // C1 (conv)
     h->conv_gx = d.Np / 128;
@@ -563,14 +576,14 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     TRYB(dalloc_zero(&h->wslabs, (size_t)std::max(2 * hxt_nslabs(h->hxt_nchunks), hxt_nslabs(h->hxt_nchunks1)) * d.L * d.K32 * d.Np));
     TRYB(dalloc_zero(&h->numden_own, (size_t)2 * d.L * d.K32 * d.Np));
     h->numden = h->numden_own;
-    TRYB(dalloc_zero(&h->hslabs, (size_t)std::max(2 * std::max(h->tc_S, 2), std::max(h->tc_S1, 2)) * d.Tl * d.K32)); // (the few-component C3 writes 2 slabs)
+    TRYB(dalloc_zero(&h->hslabs, (size_t)std::max(2 * std::max(h->tc_S, 2 * h->sk3_NS), std::max(h->tc_S1, 2 * h->sk3_NS)) * d.Tl * d.K32)); // (the few-component C3 writes 2 slabs per piece of its reduction)
     if (h->small_k_ok) {
         TRYB(dalloc_zero(&h->sk_slabs, (size_t)h->sk_ngroups * 2 * h->sk_JP * d.Np));
         TRYB(dalloc_zero(&h->sk_Wj, (size_t)d.Np * h->sk3_JP));
         static const bool off = getenv("CMF_SMALL_K") && atoi(getenv("CMF_SMALL_K")) == 0; // measurement knob: the general kernels for every K
         h->small_k = !off;
         h->sk_tc = h->small_k && h->sk_tc_ok;
-        if (h->sk_tc) h->tc_S = h->tc_S1 = 2;
+        if (h->sk_tc) h->tc_S = h->tc_S1 = 2 * h->sk3_NS;
     }
     for (int v = 0; v < 2; ++v) {
         HIPB(hipMalloc(&h->tc_tab[v], h->tc_tab_host[v].size() * sizeof(int4)));
@@ -745,7 +758,8 @@ static int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
     p.Wj = h->sk_Wj; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.out = h->hslabs;
     p.TP = d.TP; p.PADL = d.PADL; p.JP = h->sk3_JP; p.MG = h->sk3_MG; p.TG = h->sk_TG; p.N2 = (int)rup(d.N, 2); p.Np = d.Np; p.nsrc = nsrc;
     p.Tl = d.Tl; p.K = d.K; p.L = d.L; p.K32 = d.K32; p.Kg = h->sk3_Kg; p.RV = h->sk3_RV;
-    const dim3 grid(h->sk_TG / 128 + 1, nsrc * h->sk3_MG);
+    p.NS = h->sk3_NS; p.RPS = h->sk3_RPS;
+    const dim3 grid(h->sk_TG / 128 + 1, nsrc * h->sk3_MG * h->sk3_NS);
     switch (h->sk3_MBW) {
 #define CASE(M_) case M_: if (h->sk3_RV) hipLaunchKernelGGL((g_gemm_fold_small_kernel<(M_ <= 3 ? M_ : 3), SK_RVT>), grid, dim3(256), 0, h->stream, p); /* (1-3 MFMA blocks + VALU rows) */ \
                  else hipLaunchKernelGGL((g_gemm_fold_small_kernel<M_>), grid, dim3(256), 0, h->stream, p); break;
@@ -1571,8 +1585,8 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         h->small_k = value != 0 && h->small_k_ok;
         h->sk_wj_fresh = false;
         h->sk_tc = h->small_k && (h->sk_tc_ok || value == 2); // (2: the few-component C3 form whatever T is -- tests, measurements)
-        h->tc_S = h->sk_tc ? 2 : h->tc_S_full; // (own block | the spill of the next block: g_gemm_fold_small_kernel)
-        h->tc_S1 = h->sk_tc ? 2 : h->tc_S1_full;
+        h->tc_S = h->sk_tc ? 2 * h->sk3_NS : h->tc_S_full; // (own block | the spill of the next block, per piece of the reduction: g_gemm_fold_small_kernel)
+        h->tc_S1 = h->sk_tc ? 2 * h->sk3_NS : h->tc_S1_full;
         h->est_kind = 0;
         return CMF_OK;
     }

@@ -350,6 +350,7 @@ struct SkGemmParams {
     int TP, PADL, JP, MG, TG, N2, Np, nsrc;
     int Tl, K, L, K32, Kg;
     int RV;           // rows [32 * MBW, 32 * MBW + RV) of the (single) row group are contracted on the VALU (RVT kernels)
+    int NS, RPS;      // short recordings: the reduction over n is cut into NS pieces of RPS rounds (8 rows of n each), piece q writes slabs 2q, 2q + 1
 };
 
 // One staged block of the G tile folded into outs: thread (output column t = c0 - (L-1) + tid) adds rows row0 .. row0 + nrows of the
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
     __shared__ float outs[16 * SK_FOLD_COLS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const int src = blockIdx.y % p.nsrc, mg = blockIdx.y / p.nsrc;
+    const int src = blockIdx.y % p.nsrc, mg = (blockIdx.y / p.nsrc) % p.MG, q = blockIdx.y / (p.nsrc * p.MG);
     const int c0 = blockIdx.x * 128;
     const int L = p.L, K32 = p.K32, Tl = p.Tl;
     const int kbase = mg * p.Kg;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
     // four components; the columns behind that are zero in every slab since the handle was made -- every writer of hslabs writes
     // zeros there -- and writing them again was 19 MB per launch at K = 5)
     const int kw = ((mg == p.MG - 1) ? ((p.K + 3) & ~3) : kbase + kn) - kbase;
-    float *slab0 = p.out + (size_t)src * Tl * K32 + kbase;
+    float *slab0 = p.out + ((size_t)2 * q * p.nsrc + src) * Tl * K32 + kbase;
     float *slab1 = slab0 + (size_t)p.nsrc * Tl * K32;
     if (c0 >= p.TG) { // nothing spills into the last block
         for (int e = tid; e < 128 * kw; e += 256) {
@@ -433,8 +434,9 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
 
     const int tb = c0 + wave * 32;
     const float *XT = src ? p.XT1 : p.XT0;
-    const __amdgpu_buffer_rsrc_t ar = cmf_rsrc(p.Wj + mg * MBW * 32, ((size_t)(p.Np - 1) * p.JP + MBW * 32) * 4);
-    const __amdgpu_buffer_rsrc_t br = cmf_rsrc(XT + p.PADL + tb, ((size_t)(p.Np - 1) * p.TP + 32) * 4);
+    const int n0 = q * p.RPS * 8; // first row of n of this piece (0: the whole reduction)
+    const __amdgpu_buffer_rsrc_t ar = cmf_rsrc(p.Wj + (size_t)n0 * p.JP + mg * MBW * 32, ((size_t)(p.Np - 1 - n0) * p.JP + MBW * 32) * 4);
+    const __amdgpu_buffer_rsrc_t br = cmf_rsrc(XT + (size_t)n0 * p.TP + p.PADL + tb, ((size_t)(p.Np - 1 - n0) * p.TP + 32) * 4);
     const int aoff = (h * p.JP + i) * 4, boff = (h * p.TP + i) * 4;
     f32x16 acc[MBW];
 #pragma unroll
@@ -446,14 +448,15 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
     // through a ring of three sets and is loaded TWO rounds ahead: one round of MFMAs (1024 cycles) does not cover that latency.
     constexpr int U = 4, NSB = 3;
     float a[2][U][MBW], b[NSB][U];
-    const int nrounds = (p.N2 + 2 * U - 1) / (2 * U); // (the rows a last round reads past N2 are zero padding of both operands)
+    const int nr_all = (p.N2 + 2 * U - 1) / (2 * U) - q * p.RPS; // (the rows a last round reads past N2 are zero padding of both operands)
+    const int nrounds = nr_all < p.RPS ? nr_all : p.RPS;     // >= 1: the host cuts no empty piece
     float accv[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 wv = {0.f, 0.f, 0.f, 0.f};
     const f32x4 *wl = reinterpret_cast<const f32x4 *>(tile) + h; // wl[n] = Wj[n][32 MBW .. + 4) (zero rows behind N: the host checks that 8 nrounds + 2 rows fit)
     if (RVT > 0) {
         for (int e = tid; e < (8 * nrounds + 2) * 4; e += 256) {
             const int n = e >> 2, r = e & 3;
-            tile[e] = (n < p.Np && r < p.RV) ? p.Wj[(size_t)n * p.JP + MBW * 32 + r] : 0.f;
+            tile[e] = (n0 + n < p.Np && r < p.RV) ? p.Wj[(size_t)(n0 + n) * p.JP + MBW * 32 + r] : 0.f;
         }
         __syncthreads();
         wv = wl[0];

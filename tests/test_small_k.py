@@ -25,7 +25,8 @@ def frob_rel(a, b):
 
 
 # (N, T, K, L): every k-pair count of conv_small_kernel (1, 2, 3, 4, 6, 8), J = L*K below / at / above one 128-row m group and
-# above two, T shorter than a chunk / a strip / L, N crossing 32- and 128-column blocks, L at the strip limit
+# above two, T shorter than a chunk / a strip / L, N crossing 32- and 128-column blocks, L at the strip limit; with small_k = 2 C3's
+# reduction over n runs in 1 .. 8 pieces on these short recordings (2 slabs per piece), alone and with several row groups / VALU rows
 SHAPES = [
     (48, 300, 4, 8), (7, 23, 3, 4), (5, 9, 1, 1), (1, 17, 2, 5), (6, 3, 2, 5), (4, 5, 3, 5), (70, 257, 5, 10),
     (250, 1500, 5, 20), (130, 700, 16, 20), (33, 400, 7, 19), (20, 200, 6, 40), (40, 333, 9, 15), (9, 1100, 2, 3),
