@@ -55,6 +55,8 @@ CONFIGS = {
 }
 
 
+T_PROCESS_START = time.time()
+
 def route(gpus, world_size):
     """Which form of the run (gpus, WORLD_SIZE) asks for:
     "single" -- one GPU, one process; "multi" -- ONE process drives `gpus` GPUs (cmf_create_multi, RCCL ncclCommInitAll):
@@ -1174,6 +1176,7 @@ def measure(args, form, progress):
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line for it
                 out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
+        out["bench_wall_s"] = round(time.time() - T_PROCESS_START, 1)  # the whole run of this process: extras and the CPU baseline included
         print(json.dumps(out), flush=True)
     for r in (replicas or [rule]):
         r.close()
