@@ -823,7 +823,8 @@ static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int n
         p.Ht = h->Ht; p.X0 = X0; p.X1 = X1; p.slabs = h->sk_slabs;
         p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.L = d.L; p.J = h->sk_J; p.JP = h->sk_JP; p.MG = h->sk_MG; p.Tl = d.Tl;
         p.chunk_len = h->sk_chunk_len; p.nsrc = nsrc; p.RV = h->sk_RV;
-        size_t lds = std::max<size_t>((size_t)4 * (d.K + 1) * SK_HS_STRIDE, 4 * 16 * 64) * sizeof(float);
+        const bool early = h->sk_RV || (d.K <= SK_KEARLY && h->sk_MBW <= 8); // (the kernel variant: one strip per wave; otherwise two shorter ones filled by LDS-DMA)
+        size_t lds = std::max<size_t>(early ? (size_t)4 * (d.K + 1) * SK_HS_STRIDE : (size_t)8 * (d.K + 1) * SK_HS_STRIDE_DMA, 4 * 16 * 64) * sizeof(float);
         static const size_t lds_min = getenv("CMF_SK_HXT_LDS") ? (size_t)atol(getenv("CMF_SK_HXT_LDS")) : 0; // measurement knob: workgroups per CU through the LDS request
         lds = std::max(lds, lds_min);
         const dim3 grid((d.Np / 32) * h->sk_MG, h->sk_ngroups, nsrc);

@@ -22,6 +22,19 @@
 #define SK_SC 128         // time rows per staged H strip of hxt_small_kernel
 #define SK_HS_STRIDE 201  // floats between the k rows of the strip (>= SK_SC + 64 + 1, odd: the lag-shifted reads of a wave spread over the banks)
 #define SK_MAXL 64        // the strip holds SK_SC + L - 1 <= 191 columns
+#define SK_SC_DMA 64      // K > SK_KEARLY: strips of 64 time rows in TWO LDS buffers, the next one filled by LDS-DMA during the current one
+#define SK_HS_STRIDE_DMA 129 // (>= SK_SC_DMA + 63 + 1, odd)
+
+// global -> LDS without registers, one dword per lane: LDS address = lds_base + 4 * lane (cmf_glds16 for the rules of the game:
+// the compiler does not see the load in flight; completion is awaited by a counted s_waitcnt vmcnt)
+__device__ __forceinline__ void cmf_glds4(const void *gsrc, unsigned lds_base)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_base)
+                 : "memory");
+}
 
 struct SkHxtParams {
     const float *Ht;  // [K32][TP]
@@ -41,6 +54,9 @@ struct SkHxtParams {
 // LDS at the boundary, so the boundary costs an LDS write instead of an exposed global load -- which, behind the X prefetch
 // ring, is an exposed HBM round trip (a wave's loads return in issue order), paid by the two waves of a SIMD at the same
 // moment (same program, started together: both stall, the MFMA pipe idles).
+// !EARLY (K > SK_KEARLY: the early registers -- 48 at K = 16 beside 160 accumulators -- do not fit): the strips are 64 rows long and
+// live in TWO LDS buffers; the next strip is brought global -> LDS by LDS-DMA (no registers) at the top of the current one, four rounds
+// of X prefetches ahead of its first use, so that the boundary is a buffer swap.
 // RVT > 0: the last RV <= RVT rows j of the (single) row group are not padded to a 32-row MFMA block but contracted on the
 // VALU beside the MFMAs: K = 5, L = 20 is 100 rows = 3 blocks + 4 rows -- a fourth block would multiply 28 rows of zeros
 // (a quarter of the launch's MFMAs).  Lane (i, h) holds X[t + h][n0 + i] for the MFMA's B operand already; a VALU row costs one
@@ -65,8 +81,10 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
     const int src = blockIdx.z;
     const int Np = p.Np, TP = p.TP, K = p.K, L = p.L;
     const float *X = src ? p.X1 : p.X0;
-    const int strip = (K + 1) * SK_HS_STRIDE;
-    float *Hs = sk_lds + wave * strip;
+    constexpr bool DMA = !EARLY;
+    constexpr int SC = DMA ? SK_SC_DMA : SK_SC, HST = DMA ? SK_HS_STRIDE_DMA : SK_HS_STRIDE;
+    const int strip = (K + 1) * HST;
+    float *Hs = sk_lds + wave * strip * (DMA ? 2 : 1); // (DMA: two buffers per wave)
     const int tc0 = (blockIdx.y * 4 + wave) * p.chunk_len;
 
     // per-lane read base of each m block: row j -> (l, k): Hs[k][c + (L-1) - l] is H[t0 + c - l][k]; rows j >= J read the zero row K
@@ -75,9 +93,11 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
     for (int mb = 0; mb < MBW; ++mb) {
         const int j = (mg * MBW + mb) * 32 + i;
         const int l = j / K, k = j - l * K;
-        abase[mb] = (j < p.J) ? k * SK_HS_STRIDE + (L - 1) - l + h : K * SK_HS_STRIDE + h;
+        abase[mb] = (j < p.J) ? k * HST + (L - 1) - l + h : K * HST + h;
     }
-    for (int c = lane; c < SK_HS_STRIDE; c += 64) Hs[K * SK_HS_STRIDE + c] = 0.f;
+    for (int c = lane; c < HST; c += 64) Hs[K * HST + c] = 0.f;
+    if (DMA)
+        for (int c = lane; c < HST; c += 64) Hs[strip + K * HST + c] = 0.f;
     constexpr int RVN = RVT > 0 ? RVT : 1;
     int vbase[RVN];
     float accv[RVN];
@@ -85,7 +105,7 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
     for (int r = 0; r < RVN; ++r) {
         const int j = MBW * 32 + r;
         const int l = j / K, k = j - l * K;
-        vbase[r] = (RVT > 0 && r < p.RV && j < p.J) ? k * SK_HS_STRIDE + (L - 1) - l + h : K * SK_HS_STRIDE + h;
+        vbase[r] = (RVT > 0 && r < p.RV && j < p.J) ? k * HST + (L - 1) - l + h : K * HST + h;
         accv[r] = 0.f;
     }
 
@@ -112,8 +132,21 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
 #pragma unroll
         for (int u = 0; u < 8; ++u) b[u] = cmf_bload(xr, xoff, (16 * rc + 2 * u) * Np * 4);
     };
+    // DMA: strip s0 -> buffer dst; two dwords per lane and row k (width <= 127: the second one's lanes behind the width land in the
+    // row's padding); 2 K untracked loads, awaited by the counted vmcnt below
+    const unsigned lds_Hs = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float *)Hs);
+    auto hdma = [&](int s0, int buf) {
+        const float *srcp = p.Ht + (p.PADL + tc0 + s0 - (L - 1)) + lane;
+        const unsigned dst = lds_Hs + (unsigned)(buf * strip) * 4u;
+        for (int k = 0; k < K; ++k) {
+            cmf_glds4(srcp + (size_t)k * TP, dst + (unsigned)(k * HST) * 4u);
+            cmf_glds4(srcp + (size_t)k * TP + 64, dst + (unsigned)(k * HST + 64) * 4u);
+        }
+    };
+    if (DMA && nrounds) hdma(0, 0); // (in front of the ring's first NS - 1 sets: the counted wait at the top of a pass holds for the first one too)
 #pragma unroll
     for (int q = 0; q < NS - 1; ++q) xload(bx[q], q);
+    int dma_s0 = -1, dma_buf = 0; // >= 0: the strip the next round issues behind its first step
     auto mround = [&](const float (&bc)[8], int r0) { // the MFMAs of one round on strip rows r0 .. r0 + 15
         // software-pipelined like conv2_lag: the LDS reads of step u+1 are issued ahead of the MFMAs of step u
         float a[MBW], va[RVN];
@@ -141,6 +174,12 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bc[u], acc[mb], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, MBW, 0);
+            if (DMA && u == 0 && dma_s0 >= 0) { // behind the round's wait for its X set: nothing waits on these loads before the next round's
+                __builtin_amdgcn_sched_barrier(0);
+                hdma(dma_s0, dma_buf);
+                dma_s0 = -1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (RVT > 0) { // the VALU rows of this step (operands read a step ago)
 #pragma unroll
                 for (int r = 0; r < RVN; ++r) accv[r] = cmf_fma_opaque(va[r], bc[u], accv[r]); // (opaque: the SLP vectoriser packs plain FMAs into v_pk_fma_f32 and reorders the step around them)
@@ -151,7 +190,7 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
             for (int r = 0; r < RVN; ++r) va[r] = van[r];
         }
     };
-    const int width = SK_SC + L - 1;
+    const int width = SC + L - 1;
     // strip: Hs[k][c] = Ht[k][PADL + tc0 + s0 - (L-1) + c], c in [0, width)
     constexpr int KE = EARLY ? SK_KEARLY : 1;
     float hreg[KE][3]; // (width <= 191: three 64-lane columns)
@@ -170,31 +209,39 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
             if (k < K) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
-                    if (lane + 64 * q < width) Hs[k * SK_HS_STRIDE + lane + 64 * q] = hreg[k][q];
+                    if (lane + 64 * q < width) Hs[k * HST + lane + 64 * q] = hreg[k][q];
             }
     };
     if (EARLY && nrounds) hload(0);
-    for (int rd0 = 0; rd0 < nrounds; rd0 += SK_SC / 16) { // a strip = SK_SC / 16 = 8 rounds, a multiple of NS
+    float *const Hs0 = Hs;
+    for (int rd0 = 0; rd0 < nrounds; rd0 += SC / 16) { // a strip = SC / 16 rounds, a multiple of NS
         const int s0 = rd0 * 16;
         __builtin_amdgcn_wave_barrier(); // (a wave's LDS operations execute in issue order: the previous strip's reads are ahead of these writes)
-        if (EARLY) {
-            hstore();
-        } else {
-            for (int k = 0; k < K; ++k) {
-                const float *srcp = p.Ht + (size_t)k * TP + (p.PADL + tc0 + s0 - (L - 1));
-                for (int c = lane; c < width; c += 64) Hs[k * SK_HS_STRIDE + c] = srcp[c];
+        if (DMA) {
+            // The strip of this pass was issued behind the first step of the previous pass (the first one: in front of the ring's
+            // first sets), with 3 x 8 X prefetches behind it: a wave's loads return in issue order, so it has landed once at most
+            // those 24 are outstanding -- a wait that holds back no X load.  (Issued at the TOP of a pass, in front of the round's own
+            // wait for its X set, the compiler's counted wait -- which does not know these loads -- would wait for them too.)
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (24 & 15) | ((24 >> 4) << 14)); // vmcnt(24)
+            const int buf = (rd0 / (SC / 16)) & 1;
+            Hs = Hs0 + buf * strip;
+            if (rd0 + SC / 16 < nrounds) { // (the other buffer's last readers -- the MFMAs of the pass before -- have their operands)
+                dma_s0 = s0 + SC;
+                dma_buf = buf ^ 1;
             }
+        } else if (EARLY) {
+            hstore();
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int last = (nrounds - rd0 < SK_SC / 16 ? nrounds - rd0 : SK_SC / 16) - 1; // the strip's last round
-        for (int q0 = 0; q0 < SK_SC / 16 && rd0 + q0 < nrounds; q0 += NS) {
+        const int last = (nrounds - rd0 < SC / 16 ? nrounds - rd0 : SC / 16) - 1; // the strip's last round
+        for (int q0 = 0; q0 < SC / 16 && rd0 + q0 < nrounds; q0 += NS) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 const int rd = rd0 + q0 + q;
                 if (rd < nrounds) {
                     if (EARLY && q0 + q == last && rd + 1 < nrounds) { // the next strip's H rows: in flight under this round's MFMAs
-                        hload(s0 + SK_SC);
+                        hload(s0 + SC);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     xload(bx[(q + NS - 1) % NS], rd + NS - 1);
