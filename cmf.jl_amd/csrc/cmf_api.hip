@@ -361,10 +361,10 @@ static void plan(cmf_handle_s *h, int n_cu)
         h->sk_MG = (mblocks + c2max - 1) / c2max;             // groups of at most SK_MAXMBW_C2 blocks ...
         h->sk_MBW = (mblocks + h->sk_MG - 1) / h->sk_MG;      // ... as even as possible: the least padding
         h->sk_JP = 32 * h->sk_MBW * h->sk_MG;
-        // a last block of at most SK_RVT live rows goes to the VALU (one row group, 2-4 blocks, K <= SK_KEARLY: the kernel variants that exist)
+        // a last block of at most SK_RVT live rows goes to the VALU (one row group of 2-4 blocks: the kernel variants that exist)
         static const bool rv_on = !(getenv("CMF_SK_VALU_ROWS") && atoi(getenv("CMF_SK_VALU_ROWS")) == 0); // measurement knob
         h->sk_RV = 0;
-        if (rv_on && h->sk_MG == 1 && h->sk_MBW >= 2 && h->sk_MBW <= 4 && d.K <= SK_KEARLY && h->sk_J % 32 >= 1 && h->sk_J % 32 <= SK_RVT) {
+        if (rv_on && h->sk_MG == 1 && h->sk_MBW >= 2 && h->sk_MBW <= 4 && h->sk_J % 32 >= 1 && h->sk_J % 32 <= SK_RVT) {
             h->sk_RV = h->sk_J % 32;
             h->sk_MBW -= 1; // (sk_JP keeps the padded row count: the slabs' rows)
         }
@@ -823,15 +823,13 @@ static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int n
         p.Ht = h->Ht; p.X0 = X0; p.X1 = X1; p.slabs = h->sk_slabs;
         p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.L = d.L; p.J = h->sk_J; p.JP = h->sk_JP; p.MG = h->sk_MG; p.Tl = d.Tl;
         p.chunk_len = h->sk_chunk_len; p.nsrc = nsrc; p.RV = h->sk_RV;
-        const bool early = h->sk_RV || (d.K <= SK_KEARLY && h->sk_MBW <= 8); // (the kernel variant: one strip per wave; otherwise two shorter ones filled by LDS-DMA)
-        size_t lds = std::max<size_t>(early ? (size_t)4 * (d.K + 1) * SK_HS_STRIDE : (size_t)8 * (d.K + 1) * SK_HS_STRIDE_DMA, 4 * 16 * 64) * sizeof(float);
+        size_t lds = std::max<size_t>((size_t)8 * (d.K + 1) * SK_HS_STRIDE, 4 * 16 * 64) * sizeof(float); // (two strips per wave | the chunk reduction)
         static const size_t lds_min = getenv("CMF_SK_HXT_LDS") ? (size_t)atol(getenv("CMF_SK_HXT_LDS")) : 0; // measurement knob: workgroups per CU through the LDS request
         lds = std::max(lds, lds_min);
         const dim3 grid((d.Np / 32) * h->sk_MG, h->sk_ngroups, nsrc);
         switch (h->sk_MBW) {
-#define CASE(M_) case M_: if (h->sk_RV) hipLaunchKernelGGL((hxt_small_kernel<(M_ <= 3 ? M_ : 3), true, SK_RVT>), grid, dim3(256), lds, h->stream, p); /* (1-3 MFMA blocks + VALU rows) */ \
-                          else if (d.K <= SK_KEARLY && M_ <= 8) hipLaunchKernelGGL((hxt_small_kernel<M_, (M_ <= 8)>), grid, dim3(256), lds, h->stream, p); /* (9 or 10 blocks + the early strip registers do not fit two waves per SIMD) */ \
-                          else hipLaunchKernelGGL((hxt_small_kernel<M_, false>), grid, dim3(256), lds, h->stream, p); break;
+#define CASE(M_) case M_: if (h->sk_RV) hipLaunchKernelGGL((hxt_small_kernel<(M_ <= 3 ? M_ : 3), SK_RVT>), grid, dim3(256), lds, h->stream, p); /* (1-3 MFMA blocks + VALU rows) */ \
+                          else hipLaunchKernelGGL((hxt_small_kernel<M_>), grid, dim3(256), lds, h->stream, p); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
 #undef CASE
         default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk_MBW);

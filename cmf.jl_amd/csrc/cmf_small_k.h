@@ -19,11 +19,9 @@
 #define SK_MAXMBW 6       // 32-row m blocks per wave (template parameter MBW): a wave owns 32 * MBW consecutive rows j (C3)
 #define SK_MAXMBW_C2 10   // ... of the C2 kernel: K = 16, L = 20 (320 rows) in ONE row group, so that X is read once (two groups of
                           // five blocks each re-read it: 0.51 of the roof on useful flops; 160 accumulator registers, two waves per SIMD)
-#define SK_SC 128         // time rows per staged H strip of hxt_small_kernel
-#define SK_HS_STRIDE 201  // floats between the k rows of the strip (>= SK_SC + 64 + 1, odd: the lag-shifted reads of a wave spread over the banks)
-#define SK_MAXL 64        // the strip holds SK_SC + L - 1 <= 191 columns
-#define SK_SC_DMA 64      // K > SK_KEARLY: strips of 64 time rows in TWO LDS buffers, the next one filled by LDS-DMA during the current one
-#define SK_HS_STRIDE_DMA 129 // (>= SK_SC_DMA + 63 + 1, odd)
+#define SK_SC 64          // time rows per staged H strip of hxt_small_kernel: TWO LDS buffers per wave, the next strip filled by LDS-DMA during the current one
+#define SK_HS_STRIDE 129  // floats between the k rows of a strip (>= SK_SC + 63 + 1, odd: the lag-shifted reads of a wave spread over the banks)
+#define SK_MAXL 64        // a strip holds SK_SC + L - 1 <= 127 columns
 
 // global -> LDS without registers, one dword per lane: LDS address = lds_base + 4 * lane (cmf_glds16 for the rules of the game:
 // the compiler does not see the load in flight; completion is awaited by a counted s_waitcnt vmcnt)
@@ -50,24 +48,22 @@ struct SkHxtParams {
 // C2.  grid ((Np/32) * MG, chunks/4, nsrc), 256 threads.  A wave = one 32-column n block x 32*MBW rows j x one time chunk.
 // Placement (speed only): workgroup b runs on XCD b % 8, so the MG row groups of one n block -- which read the same X rows --
 // are put 8 apart in blockIdx.x when the n blocks come in multiples of 8: the same L2 serves them.
-// EARLY (K <= SK_KEARLY): the NEXT strip's H rows are loaded into registers at the top of a strip's last round and written to
-// LDS at the boundary, so the boundary costs an LDS write instead of an exposed global load -- which, behind the X prefetch
-// ring, is an exposed HBM round trip (a wave's loads return in issue order), paid by the two waves of a SIMD at the same
-// moment (same program, started together: both stall, the MFMA pipe idles).
-// !EARLY (K > SK_KEARLY: the early registers -- 48 at K = 16 beside 160 accumulators -- do not fit): the strips are 64 rows long and
-// live in TWO LDS buffers; the next strip is brought global -> LDS by LDS-DMA (no registers) at the top of the current one, four rounds
-// of X prefetches ahead of its first use, so that the boundary is a buffer swap.
+// The A operand comes from a wave-private strip of H in LDS: Hs[k][c] = Ht[k][t0 - (L-1) + c] for SK_SC time rows, read at lag-shifted
+// offsets.  Two strip buffers per wave: the NEXT strip is brought global -> LDS by LDS-DMA (no registers) behind the first step of the
+// current one, three rounds of X prefetches ahead of its first use, so that a strip boundary is a buffer swap and a counted wait that
+// holds back nothing.  (Until round 5 the strip was loaded through registers: at the boundary itself -- an exposed HBM round trip behind
+// the X prefetch ring, since a wave's loads return in issue order, paid by the two waves of a SIMD at the same moment -- then, for K <= 8,
+// early into 3 K registers; the DMA form is as fast or faster at every K and is the only one left: K = 16: 0.60 -> 0.74 of the roof.)
 // RVT > 0: the last RV <= RVT rows j of the (single) row group are not padded to a 32-row MFMA block but contracted on the
 // VALU beside the MFMAs: K = 5, L = 20 is 100 rows = 3 blocks + 4 rows -- a fourth block would multiply 28 rows of zeros
 // (a quarter of the launch's MFMAs).  Lane (i, h) holds X[t + h][n0 + i] for the MFMA's B operand already; a VALU row costs one
 // broadcast LDS read (issued a step ahead, like the A operands) and one FMA per step, hidden under the step's MBW MFMAs; the
 // two halves of the wave (the two time parities) are added at the end.
-#define SK_KEARLY 8
 #define SK_RVT 4
-template <int MBW, bool EARLY, int RVT = 0>
-__global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_small_kernel(SkHxtParams p)
+template <int MBW, int RVT = 0>
+__global__ __launch_bounds__(256, MBW > 6 ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_small_kernel(SkHxtParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float sk_lds[]; // 4 strips of (K+1) rows; reused for the chunk reduction
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[]; // 4 x 2 strips of (K+1) rows; reused for the chunk reduction
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
     int nb, mg;
@@ -81,10 +77,9 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
     const int src = blockIdx.z;
     const int Np = p.Np, TP = p.TP, K = p.K, L = p.L;
     const float *X = src ? p.X1 : p.X0;
-    constexpr bool DMA = !EARLY;
-    constexpr int SC = DMA ? SK_SC_DMA : SK_SC, HST = DMA ? SK_HS_STRIDE_DMA : SK_HS_STRIDE;
+    constexpr int SC = SK_SC, HST = SK_HS_STRIDE;
     const int strip = (K + 1) * HST;
-    float *Hs = sk_lds + wave * strip * (DMA ? 2 : 1); // (DMA: two buffers per wave)
+    float *Hs = sk_lds + wave * strip * 2; // (two buffers per wave)
     const int tc0 = (blockIdx.y * 4 + wave) * p.chunk_len;
 
     // per-lane read base of each m block: row j -> (l, k): Hs[k][c + (L-1) - l] is H[t0 + c - l][k]; rows j >= J read the zero row K
@@ -95,9 +90,7 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
         const int l = j / K, k = j - l * K;
         abase[mb] = (j < p.J) ? k * HST + (L - 1) - l + h : K * HST + h;
     }
-    for (int c = lane; c < HST; c += 64) Hs[K * HST + c] = 0.f;
-    if (DMA)
-        for (int c = lane; c < HST; c += 64) Hs[strip + K * HST + c] = 0.f;
+    for (int c = lane; c < HST; c += 64) Hs[K * HST + c] = Hs[strip + K * HST + c] = 0.f;
     constexpr int RVN = RVT > 0 ? RVT : 1;
     int vbase[RVN];
     float accv[RVN];
@@ -143,7 +136,7 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
             cmf_glds4(srcp + (size_t)k * TP + 64, dst + (unsigned)(k * HST + 64) * 4u);
         }
     };
-    if (DMA && nrounds) hdma(0, 0); // (in front of the ring's first NS - 1 sets: the counted wait at the top of a pass holds for the first one too)
+    if (nrounds) hdma(0, 0); // (in front of the ring's first NS - 1 sets: the counted wait at the top of a pass holds for the first one too)
 #pragma unroll
     for (int q = 0; q < NS - 1; ++q) xload(bx[q], q);
     int dma_s0 = -1, dma_buf = 0; // >= 0: the strip the next round issues behind its first step
@@ -174,7 +167,7 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bc[u], acc[mb], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, MBW, 0);
-            if (DMA && u == 0 && dma_s0 >= 0) { // behind the round's wait for its X set: nothing waits on these loads before the next round's
+            if (u == 0 && dma_s0 >= 0) { // behind the round's wait for its X set: nothing waits on these loads before the next round's
                 __builtin_amdgcn_sched_barrier(0);
                 hdma(dma_s0, dma_buf);
                 dma_s0 = -1;
@@ -192,32 +185,11 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
     };
     const int width = SC + L - 1;
     // strip: Hs[k][c] = Ht[k][PADL + tc0 + s0 - (L-1) + c], c in [0, width)
-    constexpr int KE = EARLY ? SK_KEARLY : 1;
-    float hreg[KE][3]; // (width <= 191: three 64-lane columns)
-    auto hload = [&](int s0) {
-#pragma unroll
-        for (int k = 0; k < KE; ++k)
-            if (k < K) {
-                const float *srcp = p.Ht + (size_t)k * TP + (p.PADL + tc0 + s0 - (L - 1));
-#pragma unroll
-                for (int q = 0; q < 3; ++q) hreg[k][q] = (lane + 64 * q < width) ? srcp[lane + 64 * q] : 0.f;
-            }
-    };
-    auto hstore = [&]() {
-#pragma unroll
-        for (int k = 0; k < KE; ++k)
-            if (k < K) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    if (lane + 64 * q < width) Hs[k * HST + lane + 64 * q] = hreg[k][q];
-            }
-    };
-    if (EARLY && nrounds) hload(0);
     float *const Hs0 = Hs;
     for (int rd0 = 0; rd0 < nrounds; rd0 += SC / 16) { // a strip = SC / 16 rounds, a multiple of NS
         const int s0 = rd0 * 16;
         __builtin_amdgcn_wave_barrier(); // (a wave's LDS operations execute in issue order: the previous strip's reads are ahead of these writes)
-        if (DMA) {
+        {
             // The strip of this pass was issued behind the first step of the previous pass (the first one: in front of the ring's
             // first sets), with 3 x 8 X prefetches behind it: a wave's loads return in issue order, so it has landed once at most
             // those 24 are outstanding -- a wait that holds back no X load.  (Issued at the TOP of a pass, in front of the round's own
@@ -229,21 +201,14 @@ __global__ __launch_bounds__(256, (EARLY || MBW > 6) ? 2 : (MBW <= 4 ? 4 : 3)) v
                 dma_s0 = s0 + SC;
                 dma_buf = buf ^ 1;
             }
-        } else if (EARLY) {
-            hstore();
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int last = (nrounds - rd0 < SC / 16 ? nrounds - rd0 : SC / 16) - 1; // the strip's last round
         for (int q0 = 0; q0 < SC / 16 && rd0 + q0 < nrounds; q0 += NS) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 const int rd = rd0 + q0 + q;
                 if (rd < nrounds) {
-                    if (EARLY && q0 + q == last && rd + 1 < nrounds) { // the next strip's H rows: in flight under this round's MFMAs
-                        hload(s0 + SC);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                     xload(bx[(q + NS - 1) % NS], rd + NS - 1);
                     __builtin_amdgcn_sched_barrier(0); // keep the prefetch at the top of the round (the scheduler otherwise sinks it below the MFMAs)
                     mround(bx[q], 16 * (q0 + q));

@@ -32,7 +32,9 @@ SHAPES = [
     (250, 1500, 5, 20), (130, 700, 16, 20), (33, 400, 7, 19), (20, 200, 6, 40), (40, 333, 9, 15), (9, 1100, 2, 3),
     (65, 520, 11, 12), (300, 260, 13, 7), (17, 150, 16, 64), (129, 900, 15, 33), (10, 64, 8, 16), (500, 2000, 5, 10),
     # rows on the VALU (K*L = 32 m + 1 .. 4): 1, 2, 3, 4 rows behind 2, 2, 1, 1 MFMA blocks; N at / beyond what C3 keeps of Wj in LDS
-    (60, 500, 5, 13), (31, 420, 2, 33), (90, 610, 5, 7), (45, 380, 3, 12), (1040, 200, 4, 25), (1100, 300, 4, 25),
+    (60, 500, 5, 13), (31, 420, 2, 33), (90, 610, 5, 7), (45, 380, 3, 12), (1040, 200, 4, 25), (1100, 300, 4, 25), (50, 300, 11, 3),
+    # recordings of several 64-row H strips per wave (the double-buffered LDS-DMA strips of C2): chunks of 5 and of 20 rounds
+    (40, 9000, 4, 9), (36, 20000, 10, 6),
 ]
 
 
