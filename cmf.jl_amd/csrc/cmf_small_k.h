@@ -2,18 +2,18 @@
 // (README.md: K = 5; figures/fast_bcd/synthetic_comparison.jl:58-64: N = 250, K = 5, L = 20, T <= 50000).
 //
 // The kernels of cmf_kernels.h put the component index k on a 32-wide MFMA axis (C2, C3) or walk a whole 32-row k block
-// per lag (C1), so K = 5 issues 32/5 = 6.4 times the useful MFMAs.  Here the MFMA axes carry the FLATTENED index
-// j = l*K + k of the J = L*K (lag, component) pairs -- the rows of the reference's H_unfold / W_unfold
-// (src/common.jl:133-142) -- in MG groups of MBW 32-row blocks (MBW <= 6 blocks per wave, chosen so that the padding
-// JP - J = 32 * MBW * MG - J is smallest): K = 5, L = 20 fills 100 of 128 rows, K = 16, L = 20 all of 320.
+// per lag (C1), so K = 5 issues 32/5 = 6.4 times the useful MFMAs.  Here the MFMA axes carry the FLATTENED index of the
+// (lag, component) pairs -- the rows of the reference's H_unfold / W_unfold (src/common.jl:133-142) -- in blocks of 32 rows:
+// K = 5, L = 20 fills 100 of 128 rows (and the last 4 of them run on the VALU instead of in a fourth block), K = 16, L = 20 all of 320.
 //
 //   C1  est[t][n]    = sum_j Hu[j][t] Wf[j][n]          conv_small_kernel (cmf_kernels.h): conv3's tiles, ceil(K/2) k pairs per lag
-//   C2  out[j][n]    = sum_t Hu[j][t] X[t][n]           hxt_small_kernel: A = Hu from a lag-shifted LDS strip, B = X rows
-//   C3  out[t][k]    = sum_l G[l*K+k][t+l],  G[j][t'] = sum_n Wf[j][n] XT[n][t']
-//                                                       g_gemm_small_kernel (a plain GEMM) + fold_small_kernel (the shifted sum)
+//   C2  out[j][n]    = sum_t Hu[j][t] X[t][n]           hxt_small_kernel: j = l*K + k; A = Hu from lag-shifted LDS strips (LDS-DMA), B = X rows
+//   C3  out[t][k]    = sum_l G[(k,l)][t+l],  G[(k,l)][t'] = sum_n Wf[(k,l)][n] XT[n][t']
+//                                                       g_gemm_fold_small_kernel: the G tile (k-major rows) is folded on chip, one launch
 // with Hu[j][t] = H[t-l][k], Wf[j][n] = W[l][k][n].  Results land in the buffers the element-wise update kernels already read
-// (numden [2][L][K32][Np] through slab_sum_small_kernel, hslabs [1][2][Tl][K32]), so everything around the contractions is
-// shared with the general path.  v_mfma_f32_32x32x2_f32 throughout (operand maps: cmf_kernels.h).
+// (the C2 slabs are summed by w_update_small_kernel -- or slab_sum_small_kernel into numden [2][L][K32][Np] --, C3 writes
+// hslabs [2 per piece of its reduction][nsrc][Tl][K32]), so everything around the contractions is shared with the general path.
+// v_mfma_f32_32x32x2_f32 throughout (operand maps: cmf_kernels.h).
 #pragma once
 
 #define SK_MAXMBW 6       // 32-row m blocks per wave (template parameter MBW): a wave owns 32 * MBW consecutive rows j (C3)
