@@ -373,7 +373,7 @@ static void plan(cmf_handle_s *h, int n_cu)
         // the rounds of the launch are short and its last one costs little -- but at least as many waves as are resident; chunks are whole
         // 16-row rounds, 4 chunks per workgroup.
         const int64_t per_chunk = (int64_t)(d.Np / 32) * h->sk_MG * 2;
-        const int64_t waves_per_cu = 8; // (more, shorter chunks than two waves per SIMD were measured: no gain at T = 50000, a loss at T = 2000)
+        const int64_t waves_per_cu = 8; // (more, shorter chunks than two waves per SIMD were measured, again with the LDS-DMA strips that leave room for four: 12 and 16 per CU lose 3-15 %)
         int64_t nch = std::max<int64_t>({(int64_t)4, (waves_per_cu * n_cu + per_chunk - 1) / per_chunk, (int64_t)(d.Tl + 511) / 512});
         h->sk_chunk_len = (int)std::max<int64_t>(16, rup((d.Tl + nch - 1) / nch, 16));
         nch = (d.Tl + h->sk_chunk_len - 1) / h->sk_chunk_len;
