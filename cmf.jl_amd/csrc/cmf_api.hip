@@ -1439,7 +1439,8 @@ int cmf_destroy(cmf_handle h)
                 return fail(CMF_ERR_HIP, "cmf_destroy: a write-back helper is stuck in a device wait; the group was not freed");
         }
         std::vector<cmf_handle_s *> shards = g->sh;
-        group_destroy(g); // detaches the shards from the group's buffers
+        if (!group_destroy(g)) // detaches the shards from the group's buffers
+            return fail(CMF_ERR_COMM, "cmf_destroy: an enqueue worker is stuck inside a call that does not return; the group and its shards were not freed");
         for (cmf_handle_s *s : shards) {
             s->group = nullptr;
             if (s != h) destroy_impl(s);
@@ -1512,7 +1513,7 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         if (std::strcmp(name, "enqueue_threads") == 0) { // 1: an enqueue worker per shard (cmf_group.h), 0: the calling thread enqueues every shard
             CMFTRY(group_sync(g));
             if (value) return group_start_workers(g);
-            group_stop_workers(g);
+            (void)group_stop_workers(g); // (the group has just been synchronised: nobody is inside a job)
             return CMF_OK;
         }
         if (std::strcmp(name, "gram") == 0) {
@@ -2157,7 +2158,7 @@ static int comm_attach(cmf_handle_s *h, int nranks, int rank, int transport, con
     g->sh.push_back(h);
     g->rank.push_back(rank);
     g->ar_cb = ar; g->ag_cb = ag; g->cb_user = user;
-    auto bail = [&](int rc) { group_destroy(g); h->group = nullptr; return rc; };
+    auto bail = [&](int rc) { (void)group_destroy(g); h->group = nullptr; return rc; };
     int rc = group_prepare_shard(h);
     if (rc != CMF_OK) return bail(rc);
     if (transport == CMF_TR_RCCL) {

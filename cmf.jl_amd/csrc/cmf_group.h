@@ -236,7 +236,7 @@ static int group_barrier(cmf_group_s *g)
     return rc == 0 ? CMF_OK : fail(CMF_ERR_ECHO, "another shard of the group failed");
 }
 
-static void group_stop_workers(cmf_group_s *g) { cmf_pool_stop(g->pool, g->failed); }
+static size_t group_stop_workers(cmf_group_s *g) { return cmf_pool_stop(g->pool, g->failed); }
 
 static bool group_wants_workers(const cmf_group_s *g)
 {
@@ -1037,9 +1037,11 @@ static void bounded_stream_sync(hipStream_t st, bool failed)
         std::this_thread::sleep_for(std::chrono::milliseconds(5));
 }
 
-static void group_destroy(cmf_group_s *g)
+// false: a worker had to be abandoned inside a job that never returned -- its job holds pointers to the group and its shards, so
+// NOTHING of them is freed (leaked on purpose: a late wake-up must not find freed memory); the caller leaves the handles alone too.
+static bool group_destroy(cmf_group_s *g)
 {
-    if (!g) return;
+    if (!g) return true;
     if (!g->failed) (void)group_join(g); // (bounded; marks the group failed when a worker is stuck in a collective call)
     if (g->failed) {
         // A failed group: FIRST abort the communicators -- that unblocks collective kernels that wait for a peer and wakes a worker
@@ -1053,7 +1055,7 @@ static void group_destroy(cmf_group_s *g)
         g->pool.abort.store(true, std::memory_order_release);
         if (!g->pool.empty()) (void)cmf_pool_wait(g->pool, 5.0);
     }
-    group_stop_workers(g); // (joins; abandon_busy only for a worker that is still inside its job)
+    if (group_stop_workers(g) != 0) return false; // (joins; abandon_busy only for a worker that is still inside its job)
     for (cmf_handle_s *s : g->sh) {
         (void)hipSetDevice(s->device);
         bounded_stream_sync(s->stream, g->failed);
@@ -1087,6 +1089,7 @@ static void group_destroy(cmf_group_s *g)
                 if (e) (void)hipEventDestroy(e);
     }
     delete g;
+    return true;
 }
 
 // streams / events of the overlap form and common post-construction steps of a shard that joins a group

@@ -175,8 +175,10 @@ static int cmf_pool_barrier(CmfWorkerPool &pool, int echo)
 
 // Ends the threads.  abandon_busy: a worker that still holds a job (stuck inside a call that will never return) is detached and
 // its queue leaked instead of joined.
-static void cmf_pool_stop(CmfWorkerPool &pool, bool abandon_busy)
+// Returns how many workers had to be abandoned inside a job (abandon_busy): whatever their jobs captured must then stay alive.
+static size_t cmf_pool_stop(CmfWorkerPool &pool, bool abandon_busy)
 {
+    size_t abandoned = 0;
     for (auto &w : pool.w) {
         w->quit.store(true, std::memory_order_release);
         {
@@ -187,9 +189,11 @@ static void cmf_pool_stop(CmfWorkerPool &pool, bool abandon_busy)
         if (abandon_busy && w->head.load(std::memory_order_acquire) != w->tail.load(std::memory_order_acquire)) {
             w->th.detach();
             (void)w.release();
+            ++abandoned;
             continue;
         }
         w->th.join();
     }
     pool.w.clear();
+    return abandoned;
 }
