@@ -685,7 +685,8 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
             static const int sk_split = getenv("CMF_SMALL_K_CONV_SPLIT") ? atoi(getenv("CMF_SMALL_K_CONV_SPLIT")) : 1; // measurement knob
             const int per_round = 4 * h->n_cu;                          // one tile per SIMD
             const int remq = tiles3 % per_round;
-            const int cutq = (sk_split && h->conv_split && tiles3 >= per_round && remq > 0 && remq <= per_round / 4) ? remq : 0;
+            int cutq = (sk_split && h->conv_split && tiles3 >= per_round && remq > 0 && remq <= per_round / 4) ? remq : 0;
+            if (sk_split && h->conv_split && tiles3 < per_round) cutq = tiles3; // fewer tiles than SIMDs (short recordings): quarter pieces only (configs[0]: 9-12 -> 5-8 us)
             const int n_full = tiles3 - cutq;
             grid = dim3(n_full + 4 * cutq);
 #define CASE(NKP_) hipLaunchKernelGGL((conv_small_kernel<MODE, NKP_>), grid, dim3(64), 0, h->stream, p, gx3, n_full)
