@@ -206,6 +206,11 @@ struct cmf_handle_s {
     std::vector<hipEvent_t> prof_pool;
     int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data, 3 mask .* (tensor_conv(W,H) - data),
                             // 4 sign(tensor_conv(W,H) - data), 5 mask .* sign(...)  (the AbsoluteLoss gradient)
+    int64_t est_gen = 0;    // counts the assignments of est_kind (set_est): whatever changes H, W or est passes through one
+    int64_t spec_gen = -1;  // est_gen for which the C2 contraction of the NEXT update_motifs! has already been enqueued (w_speculate); -1: none
+    int last_rule_call = 0; // 1: cmf_update_motifs, 2: cmf_update_feature_maps (MU rule, single handle): speculation follows the alternation only
+    bool speculate = true;  // option "speculate"
+    int64_t spec_hits = 0;  // update_motifs! calls that found their contraction done (cmf_get_counter "speculated_contractions")
 
     // T-sharded groups (cmf_group.h): the handle the caller holds fronts a group when `group` is set
     struct cmf_group_s *group = nullptr;
@@ -221,6 +226,11 @@ struct cmf_handle_s {
 
 static int hals_ensure(cmf_handle_s *h);
 static void wb_free(cmf_handle_s *h);
+static inline void set_est(cmf_handle_s *h, int kind) // every change of what est holds (and with it: of H, W) passes through here
+{
+    h->est_kind = kind;
+    ++h->est_gen;
+}
 static int wb_after_H(cmf_handle_s *h); // hook: the kernels that make H final have been enqueued (cmf_writeback.h)
 static int gram_ensure(cmf_handle_s *h);
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
@@ -723,6 +733,7 @@ static int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int 
     ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : (nsrc == 1 && X0 == h->X) ? PROF_HXT_NUM : (nsrc == 1 && X0 == h->est && h->est_kind == 1) ? PROF_HXT_DEN
                           : (nsrc == 1 && X0 == h->est) ? PROF_HXT_RESID : (X0 == h->hals_HX && h->hals_HX) ? PROF_HXT_HH : PROF_OTHER);
     const CmfDims &d = h->d;
+    h->spec_gen = -1; // (the slabs of a speculated contraction are being overwritten)
     HxtParams p;
     p.H = h->H; p.X0 = X0; p.X1 = X1; p.slabs = slabs;
     p.Np = NpX; p.K32 = d.K32; p.KB = d.KB; p.PADL = d.PADL; p.L = d.L; p.Tl = main_rows >= 0 ? main_rows : d.Tl; p.chunk_len = chunk_len;
@@ -817,6 +828,7 @@ static int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nsl
 static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int nsrc, float *out, bool take_carry = false, bool slabs_only = false)
 {
     const CmfDims &d = h->d;
+    h->spec_gen = -1; // (the slabs / sums of a speculated contraction are being overwritten)
     if (h->small_k) { // few components: the rows j = l*K + k on the MFMA axis (hxt_small_kernel), compact slabs, their sum expanded to [L][K32][Np]
         ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : (nsrc == 1 && X0 == h->X) ? PROF_HXT_NUM : (nsrc == 1 && X0 == h->est && h->est_kind == 1) ? PROF_HXT_DEN
                           : (nsrc == 1 && X0 == h->est) ? PROF_HXT_RESID : (X0 == h->hals_HX && h->hals_HX) ? PROF_HXT_HH : PROF_OTHER);
@@ -876,12 +888,23 @@ static int check_ready(cmf_handle_s *h, bool need_data)
     return CMF_OK;
 }
 
+// The C2 contraction of update_motifs! has already been enqueued for exactly this state (w_speculate, behind the loss conv of the
+// update_feature_maps! before): est is current and nothing has touched H, W, est or the slabs since.
+static bool w_speculated(cmf_handle_s *h)
+{
+    const bool hit = h->spec_gen >= 0 && h->spec_gen == h->est_gen && h->reuse_est && h->est_kind == 1 && !h->carry.partial;
+    h->spec_gen = -1;
+    if (hit) h->spec_hits += 1;
+    return hit;
+}
+
 static int w_partial_impl(cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
+    if (w_speculated(h)) return CMF_OK;
     if (!(h->reuse_est && h->est_kind == 1))
         CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
-    h->est_kind = 1;
+    set_est(h, 1);
     return hxt_contract(h, h->X, h->est, 2, h->numden, true); // mult.jl:31-34
 }
 
@@ -895,7 +918,7 @@ static int w_partial_half_impl(cmf_handle_s *h, int den)
     if (den) {
         if (!(h->reuse_est && h->est_kind == 1))
             CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
-        h->est_kind = 1;
+        set_est(h, 1);
     }
     const float *src = den ? h->est : h->X;
     return hxt_contract(h, src, src, 1, h->numden + (den ? LKN : 0), den != 0); // mult.jl:31-34, one source
@@ -920,10 +943,12 @@ static int w_phase_impl(cmf_handle_s *h, double l1W, double l2W)
         CMFTRY(w_partial_impl(h));
         return w_apply_impl(h, l1W, l2W);
     }
-    if (!(h->reuse_est && h->est_kind == 1))
-        CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
-    h->est_kind = 1;
-    CMFTRY(hxt_contract(h, h->X, h->est, 2, nullptr, false, true)); // mult.jl:31-34: the slabs only
+    if (!w_speculated(h)) {
+        if (!(h->reuse_est && h->est_kind == 1))
+            CMFTRY(launch_conv<0>(h, h->est, d.Tl, h->conv_gy)); // mult.jl:28 (skipped when est is still current)
+        set_est(h, 1);
+        CMFTRY(hxt_contract(h, h->X, h->est, 2, nullptr, false, true)); // mult.jl:31-34: the slabs only
+    }
     CmfLossCarry carry{};
     if (h->carry.partial) { // a loss reduction deferred by cmf_iterate rides on this launch
         carry = h->carry;
@@ -933,7 +958,7 @@ static int w_phase_impl(cmf_handle_s *h, double l1W, double l2W)
                        h->sk_ngroups, d.N, d.K, d.L, d.Np, d.K32, h->sk_JP, h->sk3_Kg, h->sk3_GR, h->sk3_JP,
                        (float)l1W, (float)(2.0 * l2W), carry); // mult.jl:37-38
     KCHK("w_update_small_kernel");
-    h->est_kind = 0;
+    set_est(h, 0);
     h->sk_wj_fresh = h->sk_tc;
     return CMF_OK;
 }
@@ -946,7 +971,7 @@ static int w_apply_impl_(cmf_handle_s *h, double l1W, double l2W, const float *t
     hipLaunchKernelGGL(w_update_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden, den,
                        d.N, d.K, d.L, d.Np, d.K32, (float)l1W, (float)(2.0 * l2W), tail_src, tail_dst, tail_n); // mult.jl:37-38
     KCHK("w_update_kernel");
-    h->est_kind = 0;
+    set_est(h, 0);
     return CMF_OK;
 }
 
@@ -960,7 +985,7 @@ static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
     hipLaunchKernelGGL(h_update_kernel, grid, dim3(256), 0, h->stream, h->H, h->Ht, h->hslabs, 2 * TK, h->tc_S, h->hslabs + TK, 2 * TK, h->tc_S,
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
     KCHK("h_update_kernel");
-    h->est_kind = 0;
+    set_est(h, 0);
     return wb_after_H(h);
 }
 
@@ -970,18 +995,59 @@ static int launch_loss_conv(cmf_handle_s *h)
     const CmfDims &d = h->d;
     if (h->reuse_est && !h->gram) { // (the Gram form never reads est: nothing to keep)
         CMFTRY(launch_conv<3>(h, h->est, d.Tl, h->conv_gy)); // est kept for the next update_motifs!
-        h->est_kind = 1;
+        set_est(h, 1);
         return CMF_OK;
     }
     return launch_conv<2>(h, nullptr, d.Tl, h->conv_gy);
 }
 
-static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = true, double *host_out = nullptr)
+// Behind the loss conv of update_feature_maps! (est is current, H final): enqueue the C2 contraction the NEXT update_motifs! starts
+// with (mult.jl:31-34 needs H, data and est only -- l1W, l2W enter the element-wise update), so that the device works on it while the
+// loss travels to the host, the caller's loop comes round and the next call is made: on the reference's own problem sizes an
+// iteration is a few launches long and that round trip was an eighth of it.  Used only when the caller alternates the two rule calls
+// (the call before this one was update_motifs!); a caller that stops pays one contraction nobody reads.
+static int w_speculate(cmf_handle_s *h)
 {
+    static const bool fuse = !(getenv("CMF_SMALL_K_FUSE_W") && atoi(getenv("CMF_SMALL_K_FUSE_W")) == 0);
+    if (!(h->reuse_est && h->est_kind == 1) || h->gram || h->group || h->carry.partial) return CMF_OK;
+    if (h->small_k && fuse) CMFTRY(hxt_contract(h, h->X, h->est, 2, nullptr, false, true));
+    else CMFTRY(hxt_contract(h, h->X, h->est, 2, h->numden, true));
+    h->spec_gen = h->est_gen;
+    return CMF_OK;
+}
+
+static int ensure_ring(cmf_handle_s *h) // pinned words a loss reduction stores into and the host polls (0, 1: cmf_iterate's pipeline; 2: a synchronous read)
+{
+    if (!h->h_ring) HIPCHK(hipHostMalloc(&h->h_ring, 3 * sizeof(double), hipHostMallocCoherent));
+    return CMF_OK;
+}
+
+template <typename U>
+static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel, const std::function<int()> *health = nullptr,
+                      const std::function<bool()> *enqueued = nullptr);
+
+// The loss conv (mult.jl:55-57) and the reduction of its per-tile sums.  readback: the calling thread returns with the sum -- the
+// reduction stores it into a pinned word that the host polls (no copy operation and no stream synchronisation behind the last
+// kernel: a rule call on a small problem is a few launches long, and the reference's loop makes one such read per iteration).
+static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = true, double *host_out = nullptr, bool speculate = false)
+{
+    static const bool poll = !(getenv("CMF_LOSS_POLL") && atoi(getenv("CMF_LOSS_POLL")) == 0); // measurement knob: 0 = copy + hipStreamSynchronize
+    volatile unsigned long long *word = nullptr;
+    if (readback && poll && !host_out) {
+        CMFTRY(ensure_ring(h));
+        host_out = h->h_ring + 2;
+        word = reinterpret_cast<volatile unsigned long long *>(host_out);
+        *word = CMF_SENTINEL64;
+    }
     CMFTRY(launch_loss_conv(h));
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, host_out);
     KCHK("loss_reduce_kernel");
-    return readback ? read_scalar(h, 0, sumsq) : CMF_OK;
+    if (speculate) CMFTRY(w_speculate(h)); // (enqueued behind the reduction: the loss does not wait for it)
+    if (!readback) return CMF_OK;
+    if (!word) return read_scalar(h, 0, sumsq);
+    CMFTRY(wait_words<unsigned long long>(h->stream, word, 1, CMF_SENTINEL64, nullptr, nullptr));
+    *sumsq = h->h_ring[2];
+    return CMF_OK;
 }
 
 static int set_factors_impl(cmf_handle_s *h, const double *W, const double *H)
@@ -1006,7 +1072,7 @@ static int set_factors_impl(cmf_handle_s *h, const double *W, const double *H)
     KCHK("pack_H_kernel");
     HIPCHK(hipStreamSynchronize(h->stream));
     h->factors_set = true;
-    h->est_kind = 0;
+    set_est(h, 0);
     return CMF_OK;
 }
 
@@ -1051,8 +1117,7 @@ static double wait_timeout_s()
 }
 
 template <typename U>
-static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel, const std::function<int()> *health = nullptr,
-                      const std::function<bool()> *enqueued = nullptr)
+static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel, const std::function<int()> *health, const std::function<bool()> *enqueued)
 {
     auto all_there = [&]() {
         for (int j = 0; j < n; ++j)
@@ -1475,6 +1540,7 @@ int cmf_get_counter(cmf_handle h, const char *name, int64_t *value)
     if (!h || !name || !value) return fail(CMF_ERR_ARG, "NULL argument");
     if (std::strcmp(name, "hals_pipeline_reruns") == 0) { *value = h->hals_reruns; return CMF_OK; }
     if (std::strcmp(name, "writeback_calls") == 0) { *value = h->wb ? h->wb->armed_calls : 0; return CMF_OK; }            // cmf_arm_writeback calls
+    if (std::strcmp(name, "speculated_contractions") == 0) { *value = h->spec_hits; return CMF_OK; }                         // update_motifs! calls whose C2 contraction was already enqueued
     if (std::strcmp(name, "writeback_overlapped") == 0) { *value = h->wb ? h->wb->hooked_calls : 0; return CMF_OK; }     // ... served by the copy stream behind the H update
     if (h->group) { // host cost of the pipelined iterations of a group (reading a counter resets nothing)
         cmf_group_s *g = h->group;
@@ -1535,7 +1601,7 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
                 if (value && i < g->red.size() && g->red[i])
                     HIPCHK(hipMemsetAsync(g->red[i] + g->LKN2 / 2, 0, (size_t)g->HHsz * sizeof(float), s->stream));
                 s->gram = value;
-                s->est_kind = 0;
+                set_est(s, 0);
                 s->carry = CmfLossCarry{};
             }
             g->gram = value;
@@ -1557,18 +1623,18 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         if (value < 0 || value > 2) return fail(CMF_ERR_ARG, "gram must be 0, 1 or 2");
         if (value && h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "the Gram form is not available on sharded handles");
         h->gram = value;
-        h->est_kind = 0;
+        set_est(h, 0);
         return CMF_OK;
     }
     if (std::strcmp(name, "conv_kernel") == 0) { // K % 32 == 0 only: 0 = chosen per mode (default), 3 = one-wave workgroups, 2 = 128 x 128 tiles
         if (value != 0 && value != 2 && value != 3) return fail(CMF_ERR_ARG, "conv_kernel must be 0 (per mode), 2 or 3");
         h->conv_variant = value;
-        h->est_kind = 0;
+        set_est(h, 0);
         return CMF_OK;
     }
     if (std::strcmp(name, "hals_gram") == 0) { // HALS projections as differences of the MU quantities: 2 (default) = H phase, 1 = both phases, 0 = neither
         h->hals_gram = (value == 1 || value == 2) ? value : 0; // 2 = the H phase only
-        h->est_kind = 0;
+        set_est(h, 0);
         return CMF_OK;
     }
     if (std::strcmp(name, "hals_prepare") == 0) { // allocate the HALS scratch and check its shape limits now (rule construction)
@@ -1577,7 +1643,7 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
     }
     if (std::strcmp(name, "conv_split") == 0) { // 0 = never cut the one-wave conv kernel's last round into quarter tiles
         h->conv_split = value;
-        h->est_kind = 0;
+        set_est(h, 0);
         return CMF_OK;
     }
     if (std::strcmp(name, "small_k") == 0) { // K <= 16: 1 = the few-component kernels (cmf_small_k.h; default), 0 = the general kernels
@@ -1588,12 +1654,17 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         h->sk_tc = h->small_k && (h->sk_tc_ok || value == 2); // (2: the few-component C3 form whatever T is -- tests, measurements)
         h->tc_S = h->sk_tc ? 2 * h->sk3_NS : h->tc_S_full; // (own block | the spill of the next block, per piece of the reduction: g_gemm_fold_small_kernel)
         h->tc_S1 = h->sk_tc ? 2 * h->sk3_NS : h->tc_S1_full;
-        h->est_kind = 0;
+        set_est(h, 0);
         return CMF_OK;
     }
     if (std::strcmp(name, "reuse_est") == 0) {
         h->reuse_est = value != 0;
-        h->est_kind = 0;
+        set_est(h, 0);
+        return CMF_OK;
+    }
+    if (std::strcmp(name, "speculate") == 0) { // 1 (default): update_feature_maps! enqueues the next update_motifs!'s contraction behind its loss conv when the caller alternates the two calls
+        h->speculate = value != 0;
+        h->spec_gen = -1;
         return CMF_OK;
     }
     if (std::strcmp(name, "profile") == 0) { // (re)start or stop the in-loop kernel timing; collected times are dropped
@@ -1644,6 +1715,7 @@ int cmf_update_motifs(cmf_handle h, double l1W, double l2W)
     CMFTRY(check_ready(h, true));
     if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator first (cmf_comm_init_rccl / cmf_comm_init_callbacks), or build the group with cmf_create_multi");
     if (h->gram) return gram_w_impl(h, l1W, l2W);
+    h->last_rule_call = 1;
     return w_phase_impl(h, l1W, l2W);
 }
 
@@ -1663,9 +1735,12 @@ static int update_feature_maps_body(cmf_handle h, double l1H, double l2H, double
     CMFTRY(check_ready(h, true));
     if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator first (cmf_comm_init_rccl / cmf_comm_init_callbacks), or build the group with cmf_create_multi");
     if (h->gram) return gram_h_impl(h, l1H, l2H, loss);
+    static const bool spec_env = !(getenv("CMF_SPECULATE_W") && atoi(getenv("CMF_SPECULATE_W")) == 0); // measurement knob
+    const bool speculate = spec_env && h->speculate && h->last_rule_call == 1; // the caller alternates: update_motifs! comes next
+    h->last_rule_call = 2;
     CMFTRY(h_update_impl(h, l1H, l2H));
     double ss = 0.0;
-    CMFTRY(loss_partial_impl(h, &ss));
+    CMFTRY(loss_partial_impl(h, &ss, true, nullptr, speculate));
     *loss = std::sqrt(ss) / h->data_norm;
     return CMF_OK;
 }
@@ -1774,7 +1849,7 @@ static int hals_update_feature_maps_body(cmf_handle h, double l1H, double l2H, d
             hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, (double *)nullptr);
             KCHK("loss_reduce_kernel");
             CMFTRY(read_scalar(h, 0, &ss));
-            h->est_kind = 0;
+            set_est(h, 0);
         } else {
             CMFTRY(resid_and_loss(h, &ss)); // ... and the residual kept for the next W phase
         }
@@ -1799,7 +1874,7 @@ int cmf_set_mask(cmf_handle h, const double *mask)
     HIPCHK(hipSetDevice(h->device));
     if (h->sharded) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator first (cmf_comm_init_rccl / cmf_comm_init_callbacks)");
     const CmfDims &d = h->d;
-    h->est_kind = 0;
+    set_est(h, 0);
     if (!mask) { // back to the plain SquareLoss
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->M) (void)hipFree(h->M);
@@ -1826,9 +1901,9 @@ int cmf_pgd_set_loss(cmf_handle h, int loss_kind)
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
     if (loss_kind != 0 && loss_kind != 1) return fail(CMF_ERR_ARG, "loss_kind must be 0 (SquareLoss) or 1 (AbsoluteLoss)");
     if (h->pgd_loss_abs != loss_kind) {
-        h->est_kind = 0;
+        set_est(h, 0);
         if (h->group)
-            for (cmf_handle_s *s : h->group->sh) s->est_kind = 0;
+            for (cmf_handle_s *s : h->group->sh) set_est(s, 0);
     }
     h->pgd_loss_abs = loss_kind;
     return CMF_OK;
@@ -1893,8 +1968,7 @@ static int iterate_single(cmf_handle_s *h, int64_t n, int eval_mode, double l1W,
         }
         return CMF_OK;
     }
-    if (!h->h_ring) // two slots: written by the loss reduction, polled by the host
-        HIPCHK(hipHostMalloc(&h->h_ring, 2 * sizeof(double), hipHostMallocCoherent));
+    CMFTRY(ensure_ring(h)); // (slots 0, 1: written by the loss reductions of this loop, polled by the host)
     volatile unsigned long long *ring = reinterpret_cast<volatile unsigned long long *>(h->h_ring);
     // cmf_fit's time_hist: a timing event behind every iteration's loss conv, so that entry i is the DEVICE time at which
     // iteration i was complete (what the reference's wall clock around the two rule calls measures, alternating.jl:49,57-58),
@@ -2178,7 +2252,7 @@ static int comm_attach(cmf_handle_s *h, int nranks, int rank, int transport, con
     h->group = g;
     if (h->factors_set) { // factors were set before the communicator existed: the neighbours' halos are still missing
         g->halos_current = false;
-        h->est_kind = 0;
+        set_est(h, 0);
     }
     return CMF_OK;
 }
@@ -2247,7 +2321,7 @@ static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked, bool loss
     CMFTRY(rc);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, (double *)nullptr);
     KCHK("loss_reduce_kernel");
-    h->est_kind = 2 + (masked ? 1 : 0) + (loss_abs ? 2 : 0);
+    set_est(h, 2 + (masked ? 1 : 0) + (loss_abs ? 2 : 0));
     return sumsq ? read_scalar(h, 0, sumsq) : CMF_OK;
 }
 
@@ -2429,7 +2503,7 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
         hipLaunchKernelGGL(hals_w_sweep_gen_kernel, dim3(d.N), dim3(256), lds_g, h->stream, h->Wt, h->Wn, G, Gsub, h->hals_HH,
                            d.N, d.K, d.L, d.Np, d.K32, h->hals_NpH, (float)l1W, (float)l2W);
         KCHK("hals_w_sweep_gen_kernel");
-        h->est_kind = 0;
+        set_est(h, 0);
         return CMF_OK;
     }
     const int nq = (d.L * d.K32 + 63) / 64; // <= 32 here (hals_ensure)
@@ -2451,7 +2525,7 @@ static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
     else SWEEP(32, 4);
 #undef SWEEP
     KCHK("hals_w_sweep_reg_kernel");
-    h->est_kind = 0;
+    set_est(h, 0);
     return CMF_OK;
 }
 
@@ -2556,7 +2630,7 @@ static int hals_h_enqueue(cmf_handle_s *h, double l1H, double l2H)
     CMFTRY(hals_h_project(h, true));
     const HalsRowParams q = hals_row_params(h, l1H, l2H);
     h->hals_l1 = l1H; h->hals_l2 = l2H;
-    h->est_kind = 0;
+    set_est(h, 0);
     if (h->hals_h_general) {
         ProfScope prof_(h, PROF_HALS_PIPE);
         return hals_h_sweep_general(h, q);
@@ -2633,7 +2707,7 @@ static int hals_h_rerun(cmf_handle_s *h)
     HIPCHK(hipMemcpyAsync(h->H, h->hals_snap, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->Ht, h->hals_snap + nH, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     CMFTRY(hals_h_project(h, false));
-    h->est_kind = 0;
+    set_est(h, 0);
     CMFTRY(hals_h_sweep_stage(h, hals_row_params(h, h->hals_l1, h->hals_l2)));
     return wb_after_H(h); // (an armed write-back has taken the half-finished H: take it again)
 }
@@ -2735,7 +2809,7 @@ static int gram_h_update(cmf_handle_s *h, double l1H, double l2H)
                        h->hslabs, TK, h->tc_S1, h->gram_numden_h + TK, (size_t)0, 1,
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
     KCHK("h_update_kernel");
-    h->est_kind = 0;
+    set_est(h, 0);
     return wb_after_H(h);
 }
 
@@ -2828,7 +2902,7 @@ static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
                        d.N, d.K, d.Np, d.K32, (float)h->pgd_stepW, nonneg == 1);                         // pgd.jl:237-241
     KCHK("pgd_w_apply_kernel");
     if (nonneg == 2) CMFTRY(pgd_unit_norm(h, true));                                                     // pgd.jl:100-110
-    h->est_kind = 0;
+    set_est(h, 0);
     return pgd_finish(h, &h->pgd_stepW);
 }
 
@@ -2865,7 +2939,7 @@ static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
                        d.Tl, d.K, d.K32, d.PADL, d.TP, (float)h->pgd_stepH, nonneg == 1);
     KCHK("pgd_h_apply_kernel");
     if (nonneg == 2) CMFTRY(pgd_unit_norm(h, false)); // pgd.jl:100-110
-    h->est_kind = 0;
+    set_est(h, 0);
     CMFTRY(wb_after_H(h));
     CMFTRY(pgd_finish(h, &h->pgd_stepH));
     *loss = std::sqrt(h->pgd_cur_loss / (h->data_norm * h->data_norm)); // pgd.jl:201
@@ -2974,7 +3048,7 @@ static int group_pgd_w(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double p
                            d.N, d.K, d.Np, d.K32, (float)st->pgd_stepW, nonneg == 1);                    // pgd.jl:237-241
         KCHK("pgd_w_apply_kernel");
         if (nonneg == 2) CMFTRY(pgd_unit_norm(s, true));                                                 // pgd.jl:100-110 (W is replicated)
-        s->est_kind = 0;
+        set_est(s, 0);
     }
     return group_pgd_finish(st, g, &st->pgd_stepW);
 }
@@ -3035,7 +3109,7 @@ static int group_pgd_h(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double p
             KCHK("pgd_h_knorm_kernel");
             kn.push_back(s->pgd_knorm);
         }
-        s->est_kind = 0;
+        set_est(s, 0);
     }
     if (nonneg == 2) {
         CMFTRY(group_sum_doubles(g, kn, g->sh[0]->d.K));
@@ -3065,7 +3139,7 @@ static int group_set_mask(cmf_group_s *g, const double *mask)
         cmf_handle_s *s = g->sh[i];
         const CmfDims &d = s->d;
         CMFTRY(group_use(s));
-        s->est_kind = 0;
+        set_est(s, 0);
         if (!mask) {
             if (s->M) (void)hipFree(s->M);
             if (s->MT) (void)hipFree(s->MT);
@@ -3369,7 +3443,7 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
         (void)hipStreamDestroy(aux);
         (void)hipEventDestroy(fork);
         (void)hipEventDestroy(join);
-        h->est_kind = 0;
+        set_est(h, 0);
         return rc;
     }
     int which = nm == "conv" ? 0 : nm == "hxt" ? 1 : nm == "transconv" ? 2 : nm == "conv_t" ? 3 : nm == "conv_loss" ? 4
@@ -3393,7 +3467,7 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *avg_ms = (double)ms / reps;
-    if (which == 0 || which == 5) h->est_kind = 1; // est now holds plain tensor_conv(W, H), whatever it held before (a residual on HALS / PGD handles)
+    if (which == 0 || which == 5) set_est(h, 1); // est now holds plain tensor_conv(W, H), whatever it held before (a residual on HALS / PGD handles)
     *flops = (which == 1 || which == 2) ? 2.0 * f1 : f1;
     return CMF_OK;
 }

@@ -1,0 +1,109 @@
+"""The C2 contraction of the next update_motifs! enqueued behind the loss conv of update_feature_maps! (option "speculate",
+include/cmf_hip.h): identical results whatever the caller does between the two calls."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cmf():
+    import cmf_jl_amd as m
+
+    return m
+
+
+def problem(cmf, N, T, K, L, seed=3):
+    data = cmf.gen_synthetic(N=N, T=T, seed=seed)
+    W0, H0 = cmf.init_rand(data, L=L, K=K, seed=1)
+    return data, W0, H0
+
+
+def run(cmf, data, W0, H0, script, speculate):
+    """script: a list of steps; returns every loss and the factors after every step that produces them."""
+    rule = cmf.MultUpdate(data, W0, H0)
+    rule.set_option("speculate", speculate)
+    out = []
+    try:
+        for step in script:
+            if step == "W":
+                rule.update_motifs(l1W=0.05, l2W=0.1)
+            elif step == "H":
+                out.append(rule.update_feature_maps(l1H=0.02, l2H=0.3))
+            elif step == "W2":  # other regularisation than the call before: the contraction does not depend on it
+                rule.update_motifs(l1W=0.5, l2W=0.0)
+            elif step == "get":
+                out.extend(rule.download())
+            elif step == "set":
+                W, H = rule.download()
+                rule.upload(np.asfortranarray(W * 0.5 + 0.01), np.asfortranarray(H * 2.0))
+            elif step == "loss":
+                out.append(rule.compute_loss())
+            elif step == "iterate":
+                out.extend(rule.iterate(3))
+            elif step == "gram":
+                rule.set_option("gram", 1)
+            elif step == "nogram":
+                rule.set_option("gram", 0)
+            elif step == "small0":
+                rule.set_option("small_k", 0)
+            elif step == "noreuse":
+                rule.set_option("reuse_est", 0)
+            elif step == "conv":
+                rule.time_kernel("conv", reps=1)  # est = tensor_conv(W, H) written again
+            else:
+                raise AssertionError(step)
+        out.extend(rule.download())
+        hits = rule.counter("speculated_contractions")
+    finally:
+        rule.close()
+    return out, hits
+
+
+SCRIPTS = [
+    (["W", "H"] * 6, 5),                                  # the reference's loop: every update_motifs! but the first finds its contraction done
+    (["W", "H", "W2", "H", "W", "H"], 2),                 # l1W / l2W may change from call to call
+    (["W", "H", "H", "W", "H", "W", "H"], 1),             # H twice in a row (a refit of H): the first speculation is stale, no second one (no alternation)
+    (["W", "H", "get", "W", "H", "get", "W", "H"], 2),    # reading the factors in between changes nothing
+    (["W", "H", "set", "W", "H", "W", "H"], 1),           # new factors: discarded
+    (["W", "H", "loss", "W", "H", "conv", "W", "H"], 0),  # a loss / a conv of its own rewrites est (same values, new generation): discarded
+    (["W", "H", "iterate", "W", "H", "W", "H"], 2),       # the pipelined loop consumes the speculation (first W phase), then call by call again
+    (["W", "H", "gram", "W", "H", "nogram", "W", "H", "W", "H"], 1),
+    (["W", "H", "noreuse", "W", "H", "W", "H"], 0),
+]
+
+
+@pytest.mark.parametrize("N,T,K,L", [(96, 1500, 32, 8), (70, 2600, 5, 12), (130, 900, 12, 10)])
+@pytest.mark.parametrize("case", range(len(SCRIPTS)))
+def test_speculated_contraction_changes_nothing(cmf, N, T, K, L, case):
+    script, want_hits = SCRIPTS[case]
+    data, W0, H0 = problem(cmf, N, T, K, L)
+    ref, hits0 = run(cmf, data, W0, H0, script, 0)
+    got, hits1 = run(cmf, data, W0, H0, script, 1)
+    assert hits0 == 0
+    assert hits1 == want_hits, (script, hits1)
+    assert len(ref) == len(got)
+    for a, b in zip(ref, got):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_small_k_off_in_between(cmf):
+    """Switching the kernel family between the two calls: the slabs the speculation filled belong to the other family."""
+    data, W0, H0 = problem(cmf, 70, 2600, 5, 12)
+    script = ["W", "H", "small0", "W", "H", "W", "H"]
+    ref, _ = run(cmf, data, W0, H0, script, 0)
+    got, hits = run(cmf, data, W0, H0, script, 1)
+    assert hits == 1
+    for a, b in zip(ref, got):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_other_rules_do_not_speculate(cmf):
+    data, W0, H0 = problem(cmf, 64, 1200, 8, 6)
+    for cls in (cmf.HALSUpdate, cmf.PGDUpdate):
+        rule = cls(data, W0, H0)
+        for _ in range(3):
+            rule.update_motifs()
+            rule.update_feature_maps()
+        assert rule.counter("speculated_contractions") == 0
+        rule.close()
