@@ -1099,6 +1099,25 @@ static int get_factors_impl(cmf_handle_s *h, double *W, double *H)
 }
 
 
+// The sum of n per-tile partials -> d_scalar[slot], and to the calling thread when v is given (polled pinned word, like loss_partial_impl).
+static int reduce_partials(cmf_handle_s *h, const double *partial, int n, int slot, double *v)
+{
+    static const bool poll = !(getenv("CMF_LOSS_POLL") && atoi(getenv("CMF_LOSS_POLL")) == 0);
+    double *host_out = nullptr;
+    if (v && poll) {
+        CMFTRY(ensure_ring(h));
+        host_out = h->h_ring + 2;
+        *reinterpret_cast<volatile unsigned long long *>(host_out) = CMF_SENTINEL64;
+    }
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, partial, n, h->d_scalar + slot, host_out);
+    KCHK("loss_reduce_kernel");
+    if (!v) return CMF_OK;
+    if (!host_out) return read_scalar(h, slot, v);
+    CMFTRY(wait_words<unsigned long long>(h->stream, reinterpret_cast<volatile unsigned long long *>(host_out), 1, CMF_SENTINEL64, nullptr, nullptr));
+    *v = h->h_ring[2];
+    return CMF_OK;
+}
+
 // Wait until a kernel has replaced the sentinel pattern in `n` consecutive words of pinned host memory (a loss
 // read-back).  Polling instead of an event keeps barrier packets and cache write-backs out of the stream; the stream is
 // queried now and then so that a failed launch surfaces as an error instead of a hang.  `health` (optional) is called at
@@ -1846,14 +1865,12 @@ static int hals_update_feature_maps_body(cmf_handle h, double l1H, double l2H, d
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (h->hals_gram == 1) { // hals.jl:41: norm(resids)/data_norm -- the conv with the loss fused in its epilogue, nothing stored
             CMFTRY(launch_conv<2>(h, nullptr, h->d.Tl, h->conv_gy));
-            hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, (double *)nullptr);
-            KCHK("loss_reduce_kernel");
-            CMFTRY(read_scalar(h, 0, &ss));
+            CMFTRY(reduce_partials(h, h->partial, h->conv_partials, 0, &ss));
             set_est(h, 0);
         } else {
             CMFTRY(resid_and_loss(h, &ss)); // ... and the residual kept for the next W phase
         }
-        // (the stream has been synchronised by the loss read-back)  A bounded wait of the persistent H pipeline ran out:
+        // (the loss has arrived: every kernel in front of its reduction has completed)  A bounded wait of the persistent H pipeline ran out:
         // redo the sweep from the snapshot on the stage pipeline and take the loss again; counted in "hals_pipeline_reruns"
         if (attempt == 0 && h->hals_status && *h->hals_status) CMFTRY(hals_h_rerun(h));
         else break;
@@ -2319,10 +2336,8 @@ static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked, bool loss
                     : launch_conv<4>(h, h->est, d.Tl, h->conv_gy);
     h->pgd_loss_abs_now = 0;
     CMFTRY(rc);
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, h->conv_partials, h->d_scalar, (double *)nullptr);
-    KCHK("loss_reduce_kernel");
     set_est(h, 2 + (masked ? 1 : 0) + (loss_abs ? 2 : 0));
-    return sumsq ? read_scalar(h, 0, sumsq) : CMF_OK;
+    return reduce_partials(h, h->partial, h->conv_partials, 0, sumsq);
 }
 
 static int ensure_resid(cmf_handle_s *h, bool masked = false, bool loss_abs = false)

@@ -248,7 +248,7 @@ function iterate!(rule::HIPMultUpdate, n::Integer; l1W=0, l2W=0, l1H=0, l2H=0, e
     return losses
 end
 
-"Library option (include/cmf_hip.h, cmf_set_option): \"reuse_est\", \"gram\", \"small_k\", \"allreduce_overlap\", \"enqueue_threads\", ..."
+"Library option (include/cmf_hip.h, cmf_set_option): \"reuse_est\", \"speculate\", \"gram\", \"small_k\", \"allreduce_overlap\", \"enqueue_threads\", ..."
 set_option!(rule::HIPMultUpdate, name::AbstractString, value::Integer) =
     check(ccall((:cmf_set_option, LIBCMF), Cint, (Ptr{Cvoid}, Cstring, Cint), rule.handle, name, value))
 

@@ -797,10 +797,13 @@ def test_gram_form_100_iterations_config1(cmf, oracle):
 def test_in_loop_kernel_timing(cmf, oracle):
     """Option "profile": HIP event pairs around the contraction launches of the rule entries (bench.py's roofline
     source).  Counts follow the iteration structure (est reuse: one conv_t, one conv_loss_store, one hxt and one
-    transconv per iteration, plus the first iteration's plain conv); results are unchanged."""
+    transconv per iteration, plus the first iteration's plain conv); results are unchanged.  (Option "speculate" off on the
+    counted handle: it moves every hxt launch behind the loss conv of the call before and adds one nobody reads at the end --
+    the unprofiled reference handle runs with it.)"""
     W0, H0, data = rand_problem(11, 130, 900, 32, 20)
     ref = cmf.MultUpdate(data, W0, H0)
     rule = cmf.MultUpdate(data, W0, H0)
+    rule.set_option("speculate", 0)
     rule.set_option("profile", 1)
     for _ in range(3):
         ref.update_motifs(); ref.update_feature_maps()
