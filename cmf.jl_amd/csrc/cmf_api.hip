@@ -383,7 +383,12 @@ static void plan(cmf_handle_s *h, int n_cu)
         // the rounds of the launch are short and its last one costs little -- but at least as many waves as are resident; chunks are whole
         // 16-row rounds, 4 chunks per workgroup.
         const int64_t per_chunk = (int64_t)(d.Np / 32) * h->sk_MG * 2;
-        const int64_t waves_per_cu = 8; // (more, shorter chunks than two waves per SIMD were measured, again with the LDS-DMA strips that leave room for four: 12 and 16 per CU lose 3-15 %)
+        // two waves per SIMD, or one when the launch is short (under ~800 MFMAs per SIMD: the per-wave prologue -- strip, X ring -- and the
+        // chunk reduction weigh more than the second wave's latency hiding; measured 250 x 6250 .. 50000, K = 5 and 12:
+        // profiles/r05_c2_dma_strips.txt).  More, shorter chunks (12, 16 per CU) lose 3-15 % everywhere.
+        const int64_t mfma_per_simd = (int64_t)(d.Np / 32) * h->sk_MG * 2 * ((d.Tl + 15) / 16) * 8 * h->sk_MBW / (4LL * n_cu);
+        static const int64_t wpc_env = getenv("CMF_SK_C2_WPC") ? atol(getenv("CMF_SK_C2_WPC")) : 0; // measurement knob
+        const int64_t waves_per_cu = wpc_env > 0 ? wpc_env : (mfma_per_simd < 800 ? 4 : 8);
         int64_t nch = std::max<int64_t>({(int64_t)4, (waves_per_cu * n_cu + per_chunk - 1) / per_chunk, (int64_t)(d.Tl + 511) / 512});
         h->sk_chunk_len = (int)std::max<int64_t>(16, rup((d.Tl + nch - 1) / nch, 16));
         nch = (d.Tl + h->sk_chunk_len - 1) / h->sk_chunk_len;
