@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -206,6 +208,9 @@ struct cmf_handle_s {
     std::vector<hipEvent_t> prof_pool;
     int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data, 3 mask .* (tensor_conv(W,H) - data),
                             // 4 sign(tensor_conv(W,H) - data), 5 mask .* sign(...)  (the AbsoluteLoss gradient)
+    void *arena = nullptr;  // the small buffers of the handle as ONE device allocation (cmf_create): 21 hipFree calls cost 1.3 ms, one 0.16
+    size_t arena_bytes = 0;
+    bool own_stream_masked = false; // (test hook: a CU-masked stream is not pooled)
     int64_t est_gen = 0;    // counts the assignments of est_kind (set_est): whatever changes H, W or est passes through one
     int64_t spec_gen = -1;  // est_gen for which the C2 contraction of the NEXT update_motifs! has already been enqueued (w_speculate); -1: none
     int last_rule_call = 0; // 1: cmf_update_motifs, 2: cmf_update_feature_maps (MU rule, single handle): speculation follows the alternation only
@@ -270,6 +275,31 @@ static int ensure_stage(cmf_handle_s *h, size_t elems)
     HIPCHK(hipMalloc(&h->stage, elems * sizeof(double)));
     h->stage_elems = elems;
     return CMF_OK;
+}
+
+// A pool of non-blocking streams per device, shared by the handles of the process: creating a stream costs 1.4 ms and destroying one
+// 1.1 ms on this runtime (tools/alloc_cost.hip) -- more than a whole 100-iteration fit of the reference's README example takes -- and
+// init_rand, parameter_sweep and every fit_cnmf make and drop handles.  A released stream has been synchronised; at most 32 are kept.
+static std::mutex g_stream_mu;
+static std::map<int, std::vector<hipStream_t>> g_stream_pool;
+static hipError_t stream_acquire(int device, hipStream_t *s)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        auto &v = g_stream_pool[device];
+        if (!v.empty()) { *s = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+static void stream_release(int device, hipStream_t s)
+{
+    if (!s) return;
+    if (hipStreamSynchronize(s) == hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        auto &v = g_stream_pool[device];
+        if (v.size() < 32) { v.push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
 }
 
 template <typename T>
@@ -441,21 +471,26 @@ static void destroy_impl(cmf_handle_s *h)
     wb_free(h);
     if (h->root_only) { delete h; return; }
     (void)hipSetDevice(h->device);
+    auto mine = [&](const void *q) { // not a piece of the arena
+        return q && !(h->arena && static_cast<const char *>(q) >= static_cast<const char *>(h->arena) &&
+                      static_cast<const char *>(q) < static_cast<const char *>(h->arena) + h->arena_bytes);
+    };
     for (float *q : {h->sk_slabs, h->sk_Wj})
-        if (q) (void)hipFree(q);
+        if (mine(q)) (void)hipFree(q);
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
                       h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3],
                       h->gram_numden_h, h->pgd_gradH, h->M, h->MT, h->hals_snap, h->hals_HX, h->hals_cslabs, h->hals_C, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE, h->hals_GWt};
     for (float *p : fbufs)
-        if (p) (void)hipFree(p);
+        if (mine(p)) (void)hipFree(p);
     for (int v = 0; v < 2; ++v)
         if (h->tc_tab[v]) (void)hipFree(h->tc_tab[v]);
-    if (h->partial) (void)hipFree(h->partial);
+    if (mine(h->partial)) (void)hipFree(h->partial);
     if (h->hals_flags) (void)hipFree(h->hals_flags);
     if (h->hals_status) (void)hipHostFree(h->hals_status);
     if (h->pgd_knorm) (void)hipFree(h->pgd_knorm);
-    if (h->d_scalar_own) (void)hipFree(h->d_scalar_own);
+    if (mine(h->d_scalar_own)) (void)hipFree(h->d_scalar_own);
+    if (h->arena) (void)hipFree(h->arena);
     if (h->h_scalar) (void)hipHostFree(h->h_scalar);
     if (h->stage) (void)hipFree(h->stage);
     for (auto &r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -465,8 +500,9 @@ static void destroy_impl(cmf_handle_s *h)
     if (h->ev_c0) (void)hipEventDestroy(h->ev_c0);
     if (h->ev_c1) (void)hipEventDestroy(h->ev_c1);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
-    if (h->own_comm_stream) (void)hipStreamDestroy(h->own_comm_stream);
-    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    stream_release(h->device, h->own_comm_stream);
+    if (h->own_stream_masked) (void)hipStreamDestroy(h->own_stream);
+    else stream_release(h->device, h->own_stream);
     delete h;
 }
 
@@ -574,27 +610,36 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     auto bail = [&](int rc) { destroy_impl(h); return rc; };
 #define TRYB(expr) do { int rc__ = (expr); if (rc__ != CMF_OK) return bail(rc__); } while (0)
 #define HIPB(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(fail(CMF_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__))); } while (0)
-    if (cu_part >= 0) HIPB(hipExtStreamCreateWithCUMask(&h->own_stream, 8, cu_mask));
-    else HIPB(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    if (cu_part >= 0) { HIPB(hipExtStreamCreateWithCUMask(&h->own_stream, 8, cu_mask)); h->own_stream_masked = true; }
+    else HIPB(stream_acquire(h->device, &h->own_stream));
     h->stream = h->own_stream;
     HIPB(hipEventCreate(&h->ev0));
     HIPB(hipEventCreate(&h->ev1));
+    // the buffers a handle has, zero-filled: the small ones (under 32 MB each) as ONE allocation in 256-byte granules -- on a small
+    // problem that is all of them, and creating and destroying the handle costs less than a millisecond instead of seven --, the large
+    // ones on their own (one 2.5 GB allocation for config 2 took 10 ms longer than its parts)
+    struct Want { void **pp; size_t bytes; };
+    std::vector<Want> wants;
+    int want_rc = CMF_OK;
+    auto want = [&](auto **pp, size_t n) {
+        if (n * sizeof(**pp) >= ((size_t)32 << 20)) { if (want_rc == CMF_OK) want_rc = dalloc_zero(pp, n); }
+        else wants.push_back({reinterpret_cast<void **>(pp), n * sizeof(**pp)});
+    };
     const size_t TPNp = (size_t)d.TP * d.Np;
-    TRYB(dalloc_zero(&h->H, (size_t)d.TP * d.K32));
-    TRYB(dalloc_zero(&h->Ht, (size_t)d.K32 * d.TP));
-    TRYB(dalloc_zero(&h->Wt, (size_t)d.Lp * d.K32 * d.Np));
-    TRYB(dalloc_zero(&h->Wn, (size_t)d.Lp * d.Np * d.K32));
-    TRYB(dalloc_zero(&h->X, TPNp));
-    TRYB(dalloc_zero(&h->XT, TPNp));
-    TRYB(dalloc_zero(&h->est, TPNp));
-    TRYB(dalloc_zero(&h->estT, TPNp));
-    TRYB(dalloc_zero(&h->wslabs, (size_t)std::max(2 * hxt_nslabs(h->hxt_nchunks), hxt_nslabs(h->hxt_nchunks1)) * d.L * d.K32 * d.Np));
-    TRYB(dalloc_zero(&h->numden_own, (size_t)2 * d.L * d.K32 * d.Np));
-    h->numden = h->numden_own;
-    TRYB(dalloc_zero(&h->hslabs, (size_t)std::max(2 * std::max(h->tc_S, 2 * h->sk3_NS), std::max(h->tc_S1, 2 * h->sk3_NS)) * d.Tl * d.K32)); // (the few-component C3 writes 2 slabs per piece of its reduction)
+    want(&h->H, (size_t)d.TP * d.K32);
+    want(&h->Ht, (size_t)d.K32 * d.TP);
+    want(&h->Wt, (size_t)d.Lp * d.K32 * d.Np);
+    want(&h->Wn, (size_t)d.Lp * d.Np * d.K32);
+    want(&h->X, TPNp);
+    want(&h->XT, TPNp);
+    want(&h->est, TPNp);
+    want(&h->estT, TPNp);
+    want(&h->wslabs, (size_t)std::max(2 * hxt_nslabs(h->hxt_nchunks), hxt_nslabs(h->hxt_nchunks1)) * d.L * d.K32 * d.Np);
+    want(&h->numden_own, (size_t)2 * d.L * d.K32 * d.Np);
+    want(&h->hslabs, (size_t)std::max(2 * std::max(h->tc_S, 2 * h->sk3_NS), std::max(h->tc_S1, 2 * h->sk3_NS)) * d.Tl * d.K32); // (the few-component C3 writes 2 slabs per piece of its reduction)
     if (h->small_k_ok) {
-        TRYB(dalloc_zero(&h->sk_slabs, (size_t)h->sk_ngroups * 2 * h->sk_JP * d.Np));
-        TRYB(dalloc_zero(&h->sk_Wj, (size_t)d.Np * h->sk3_JP));
+        want(&h->sk_slabs, (size_t)h->sk_ngroups * 2 * h->sk_JP * d.Np);
+        want(&h->sk_Wj, (size_t)d.Np * h->sk3_JP);
         static const bool off = getenv("CMF_SMALL_K") && atoi(getenv("CMF_SMALL_K")) == 0; // measurement knob: the general kernels for every K
         h->small_k = !off;
         h->sk_tc = h->small_k && h->sk_tc_ok;
@@ -605,12 +650,29 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
         HIPB(hipMemcpy(h->tc_tab[v], h->tc_tab_host[v].data(), h->tc_tab_host[v].size() * sizeof(int4), hipMemcpyHostToDevice));
     }
     for (int w = 0; w < 4; ++w) {
-        TRYB(dalloc_zero(&h->halo_own[w], (size_t)std::max(1, d.L - 1) * d.K32));
-        h->halo[w] = h->halo_own[w];
+        want(&h->halo_own[w], (size_t)std::max(1, d.L - 1) * d.K32);
     }
-    TRYB(dalloc_zero(&h->partial, n_partial(h)));
-    TRYB(dalloc_zero(&h->d_scalar_own, 4));
-    h->d_scalar = h->d_scalar_own;
+    want(&h->partial, n_partial(h));
+    want(&h->d_scalar_own, 4);
+    TRYB(want_rc);
+    {
+        size_t total = 0;
+        for (const Want &w : wants) total += (w.bytes + 255) & ~(size_t)255;
+        HIPB(hipMalloc(&h->arena, total));
+        h->arena_bytes = total;
+        // (hipMemset of device memory runs on the null stream and may return before it has finished; the handle's work runs on
+        // non-blocking streams, which the null stream does not order)
+        HIPB(hipMemset(h->arena, 0, total));
+        HIPB(hipStreamSynchronize(nullptr));
+        size_t off = 0;
+        for (const Want &w : wants) {
+            *w.pp = static_cast<char *>(h->arena) + off;
+            off += (w.bytes + 255) & ~(size_t)255;
+        }
+        h->numden = h->numden_own;
+        for (int w = 0; w < 4; ++w) h->halo[w] = h->halo_own[w];
+        h->d_scalar = h->d_scalar_own;
+    }
     HIPB(hipHostMalloc(&h->h_scalar, 4 * sizeof(double)));
     if (data) {
         TRYB(upload_cols(h, data, 0, Tl, true, true));
@@ -1231,7 +1293,7 @@ static void wb_free(cmf_handle_s *h)
     if (wb->pin_W) (void)hipHostFree(wb->pin_W);
     if (wb->pin_H) (void)hipHostFree(wb->pin_H);
     if (wb->dev_stage) (void)hipFree(wb->dev_stage);
-    if (wb->stream) (void)hipStreamDestroy(wb->stream);
+    stream_release(h->device, wb->stream);
     delete wb;
     h->wb = nullptr;
 }
@@ -1242,7 +1304,7 @@ static int wb_alloc_copy(cmf_handle_s *h, CmfWriteback *wb, bool with_W) // the 
     HIPCHK(hipSetDevice(h->device));
     wb->nW = (size_t)d.L * d.N * d.K;
     wb->nH = (size_t)d.Tl * d.K;
-    HIPCHK(hipStreamCreateWithFlags(&wb->stream, hipStreamNonBlocking));
+    HIPCHK(stream_acquire(h->device, &wb->stream));
     for (hipEvent_t *e : {&wb->ev_w_ready, &wb->ev_h_ready, &wb->ev_w_done, &wb->ev_h_done})
         HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     if (with_W) HIPCHK(hipHostMalloc((void **)&wb->pin_W, wb->nW * sizeof(float), hipHostMallocDefault));

@@ -1096,7 +1096,7 @@ static bool group_destroy(cmf_group_s *g)
 static int group_prepare_shard(cmf_handle_s *s)
 {
     CMFTRY(group_use(s));
-    if (!s->own_comm_stream) HIPCHK(hipStreamCreateWithFlags(&s->own_comm_stream, hipStreamNonBlocking));
+    if (!s->own_comm_stream) HIPCHK(stream_acquire(s->device, &s->own_comm_stream));
     s->comm_stream = s->own_comm_stream;
     if (!s->ev_c0) HIPCHK(hipEventCreateWithFlags(&s->ev_c0, hipEventDisableTiming));
     if (!s->ev_c1) HIPCHK(hipEventCreateWithFlags(&s->ev_c1, hipEventDisableTiming));
