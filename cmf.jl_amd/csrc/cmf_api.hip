@@ -211,6 +211,7 @@ struct cmf_handle_s {
     void *arena = nullptr;  // the small buffers of the handle as ONE device allocation (cmf_create): 21 hipFree calls cost 1.3 ms, one 0.16
     size_t arena_bytes = 0;
     bool own_stream_masked = false; // (test hook: a CU-masked stream is not pooled)
+    bool streams_may_hang = false;  // set on the shards of a FAILED group: their streams are not waited for when they are given back
     int64_t est_gen = 0;    // counts the assignments of est_kind (set_est): whatever changes H, W or est passes through one
     int64_t spec_gen = -1;  // est_gen for which the C2 contraction of the NEXT update_motifs! has already been enqueued (w_speculate); -1: none
     int last_rule_call = 0; // 1: cmf_update_motifs, 2: cmf_update_feature_maps (MU rule, single handle): speculation follows the alternation only
@@ -291,10 +292,11 @@ static hipError_t stream_acquire(int device, hipStream_t *s)
     }
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
-static void stream_release(int device, hipStream_t s)
+static void stream_release(int device, hipStream_t s, bool may_wait = true)
 {
     if (!s) return;
-    if (hipStreamSynchronize(s) == hipSuccess) {
+    // (may_wait = false: a shard of a failed group -- its stream may never drain; hipStreamDestroy does not wait for it)
+    if ((may_wait ? hipStreamSynchronize(s) : hipStreamQuery(s)) == hipSuccess) {
         std::lock_guard<std::mutex> lock(g_stream_mu);
         auto &v = g_stream_pool[device];
         if (v.size() < 32) { v.push_back(s); return; }
@@ -500,9 +502,9 @@ static void destroy_impl(cmf_handle_s *h)
     if (h->ev_c0) (void)hipEventDestroy(h->ev_c0);
     if (h->ev_c1) (void)hipEventDestroy(h->ev_c1);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
-    stream_release(h->device, h->own_comm_stream);
+    stream_release(h->device, h->own_comm_stream, !h->streams_may_hang);
     if (h->own_stream_masked) (void)hipStreamDestroy(h->own_stream);
-    else stream_release(h->device, h->own_stream);
+    else stream_release(h->device, h->own_stream, !h->streams_may_hang);
     delete h;
 }
 
@@ -1293,7 +1295,7 @@ static void wb_free(cmf_handle_s *h)
     if (wb->pin_W) (void)hipHostFree(wb->pin_W);
     if (wb->pin_H) (void)hipHostFree(wb->pin_H);
     if (wb->dev_stage) (void)hipFree(wb->dev_stage);
-    stream_release(h->device, wb->stream);
+    stream_release(h->device, wb->stream, !h->streams_may_hang);
     delete wb;
     h->wb = nullptr;
 }

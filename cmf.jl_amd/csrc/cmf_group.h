@@ -1058,6 +1058,7 @@ static bool group_destroy(cmf_group_s *g)
     if (group_stop_workers(g) != 0) return false; // (joins; abandon_busy only for a worker that is still inside its job)
     for (cmf_handle_s *s : g->sh) {
         (void)hipSetDevice(s->device);
+        s->streams_may_hang = g->failed;
         bounded_stream_sync(s->stream, g->failed);
         if (s->comm_stream) bounded_stream_sync(s->comm_stream, g->failed);
     }
