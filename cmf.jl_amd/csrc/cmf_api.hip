@@ -399,7 +399,7 @@ static void plan(cmf_handle_s *h, int n_cu)
     if (h->small_k_ok) {
         h->sk_J = d.L * d.K;
         const int mblocks = (h->sk_J + 31) / 32;              // 32-row blocks that hold rows j
-        static const int c2max = getenv("CMF_SK_C2_MAXMBW") && atoi(getenv("CMF_SK_C2_MAXMBW")) > 0 ? std::min(atoi(getenv("CMF_SK_C2_MAXMBW")), SK_MAXMBW_C2) : SK_MAXMBW_C2; // measurement knob
+        const int c2max = SK_MAXMBW_C2;
         h->sk_MG = (mblocks + c2max - 1) / c2max;             // groups of at most SK_MAXMBW_C2 blocks ...
         h->sk_MBW = (mblocks + h->sk_MG - 1) / h->sk_MG;      // ... as even as possible: the least padding
         h->sk_JP = 32 * h->sk_MBW * h->sk_MG;
@@ -419,8 +419,7 @@ static void plan(cmf_handle_s *h, int n_cu)
         // chunk reduction weigh more than the second wave's latency hiding; measured 250 x 6250 .. 50000, K = 5 and 12:
         // profiles/r05_c2_dma_strips.txt).  More, shorter chunks (12, 16 per CU) lose 3-15 % everywhere.
         const int64_t mfma_per_simd = (int64_t)(d.Np / 32) * h->sk_MG * 2 * ((d.Tl + 15) / 16) * 8 * h->sk_MBW / (4LL * n_cu);
-        static const int64_t wpc_env = getenv("CMF_SK_C2_WPC") ? atol(getenv("CMF_SK_C2_WPC")) : 0; // measurement knob
-        const int64_t waves_per_cu = wpc_env > 0 ? wpc_env : (mfma_per_simd < 800 ? 4 : 8);
+        const int64_t waves_per_cu = mfma_per_simd < 800 ? 4 : 8;
         int64_t nch = std::max<int64_t>({(int64_t)4, (waves_per_cu * n_cu + per_chunk - 1) / per_chunk, (int64_t)(d.Tl + 511) / 512});
         h->sk_chunk_len = (int)std::max<int64_t>(16, rup((d.Tl + nch - 1) / nch, 16));
         nch = (d.Tl + h->sk_chunk_len - 1) / h->sk_chunk_len;
@@ -906,8 +905,6 @@ static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int n
         p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.L = d.L; p.J = h->sk_J; p.JP = h->sk_JP; p.MG = h->sk_MG; p.Tl = d.Tl;
         p.chunk_len = h->sk_chunk_len; p.nsrc = nsrc; p.RV = h->sk_RV;
         size_t lds = std::max<size_t>((size_t)8 * (d.K + 1) * SK_HS_STRIDE, 4 * 16 * 64) * sizeof(float); // (two strips per wave | the chunk reduction)
-        static const size_t lds_min = getenv("CMF_SK_HXT_LDS") ? (size_t)atol(getenv("CMF_SK_HXT_LDS")) : 0; // measurement knob: workgroups per CU through the LDS request
-        lds = std::max(lds, lds_min);
         const dim3 grid((d.Np / 32) * h->sk_MG, h->sk_ngroups, nsrc);
         switch (h->sk_MBW) {
 #define CASE(M_) case M_: if (h->sk_RV) hipLaunchKernelGGL((hxt_small_kernel<(M_ <= 3 ? M_ : 3), SK_RVT>), grid, dim3(256), lds, h->stream, p); /* (1-3 MFMA blocks + VALU rows) */ \
@@ -1007,8 +1004,7 @@ static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W, const float *ta
 static int w_phase_impl(cmf_handle_s *h, double l1W, double l2W)
 {
     const CmfDims &d = h->d;
-    static const bool fuse = !(getenv("CMF_SMALL_K_FUSE_W") && atoi(getenv("CMF_SMALL_K_FUSE_W")) == 0); // measurement knob
-    if (!(h->small_k && fuse)) {
+    if (!h->small_k) {
         CMFTRY(w_partial_impl(h));
         return w_apply_impl(h, l1W, l2W);
     }
@@ -1077,9 +1073,8 @@ static int launch_loss_conv(cmf_handle_s *h)
 // (the call before this one was update_motifs!); a caller that stops pays one contraction nobody reads.
 static int w_speculate(cmf_handle_s *h)
 {
-    static const bool fuse = !(getenv("CMF_SMALL_K_FUSE_W") && atoi(getenv("CMF_SMALL_K_FUSE_W")) == 0);
     if (!(h->reuse_est && h->est_kind == 1) || h->gram || h->group || h->carry.partial) return CMF_OK;
-    if (h->small_k && fuse) CMFTRY(hxt_contract(h, h->X, h->est, 2, nullptr, false, true));
+    if (h->small_k) CMFTRY(hxt_contract(h, h->X, h->est, 2, nullptr, false, true));
     else CMFTRY(hxt_contract(h, h->X, h->est, 2, h->numden, true));
     h->spec_gen = h->est_gen;
     return CMF_OK;
