@@ -395,7 +395,7 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--T", type=int, default=0, help="override T (debugging only; invalidates the metric)")
@@ -887,28 +887,40 @@ def measure(args, form, progress):
                     break
             rule.set_overlap("overlap" in probe and probe["overlap"] < probe["single"])
             progress["partial"] = {"allreduce_overlap_probe_ms": {k: (1e3 * v if isinstance(v, float) else v) for k, v in probe.items()}}
-    # The timed region carries HIP event pairs around every fourth launch of each contraction kernel (option "profile": events on the
-    # launch stream), so the per-kernel durations of the roofline block are measured live over these very steps.
+    # The timed region carries HIP event pairs (option "profile": events on the launch stream) around every fourth launch of the
+    # DOMINANT kernel only -- the roofline block's duration is measured live over these very steps -- because an event pair idles the
+    # device a few microseconds: pairs around all four contraction kernels cost 0.5 % of the step.  The other kernels' durations (the
+    # `kernels` table) are taken the same way over a second pass of the same K steps right behind the timed one.
     prof = rule
+    one_class = alg == "mult" and form == "single"
     progress["phase"] = "warm-up steps"
     timed(args.warmup, 0)
     progress["phase"] = "timed steps"
+    prof.set_option("profile_mask", (1 << 5) if one_class else 0)  # class 5 = "transconv"
     prof.set_option("profile", 4 if alg == "mult" else 1)  # every 4th launch of each class (HALS: every span)
     dt, losses = timed(0, args.steps)
     progress.setdefault("partial", {}).update(ms_per_step=1e3 * dt / args.steps, iters_per_s=args.steps / dt, loss_last=float(losses[-1]) if len(losses) else None)
     progress["phase"] = "side measurements after the timed steps"
+    names = ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "hxt_num", "hxt_den", "transconv", "hals_h_pipeline", "hals_w_sweep")
     inloop = {}
-    for name in ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "hxt_num", "hxt_den", "transconv", "hals_h_pipeline", "hals_w_sweep"):
+    for name in names:
         kms, n = prof.kernel_times(name)
         if n:
             inloop[name] = (kms, n)
     prof.set_option("profile", 0)
+    prof.set_option("profile_mask", 0)
     hals_spans = {}
     if alg != "mult":
         hals_spans, inloop = inloop, {}
-    dt_unprofiled = None
-    if alg == "mult" and form == "single":
-        dt_unprofiled, _ = timed(0, args.steps)
+    dt_allpairs = None
+    if one_class:  # second pass: every contraction kernel bracketed (the dominant kernel keeps its figure from the timed steps)
+        prof.set_option("profile", 4)
+        dt_allpairs, _ = timed(0, args.steps)
+        for name in names:
+            kms, n = prof.kernel_times(name)
+            if n and name not in inloop:
+                inloop[name] = (kms, n)
+        prof.set_option("profile", 0)
     # Steady state: the timed region above is ~0.1 s; run back-to-back iterations for several seconds more (same call) so that
     # the figure also holds at the clock the card settles to (and the driver's GPU-busy sampling has something to see).
     sustained = None
@@ -1060,7 +1072,7 @@ def measure(args, form, progress):
                          "are executed, results bitwise identical; ms_per_step_no_reuse runs all 7",
             "allreduce_overlap": (bool(rule.overlap) if sharded else None),
             "allreduce_overlap_probe_ms": ({k: (1e3 * v if isinstance(v, float) else v) for k, v in probe.items()} if probe else None),
-            "ms_per_step_without_event_pairs": (1e3 * dt_unprofiled / args.steps) if dt_unprofiled else None,
+            "ms_per_step_second_pass_all_event_pairs": (1e3 * dt_allpairs / args.steps) if dt_allpairs else None,
             "ms_per_step_no_reuse": (1e3 * dt_noreuse) if dt_noreuse else None,
             # the headline both ways: `value` executes 6 of mult.jl's 7 contractions (est reuse, bitwise identical results);
             # the reference formulation recomputes est at mult.jl:28 (option reuse_est = 0: all 7 executed)
@@ -1115,9 +1127,14 @@ def measure(args, form, progress):
                 tab[name] = {"avg_ms": kms, "launches": n, "tflops": kfl / kms / 1e9, "frac": kfl / kms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
                              "share_of_step": kms * args.steps / (1e3 * dt)}
             out["kernels"] = tab
-            dom = max(tab, key=lambda k: tab[k]["avg_ms"])  # every class runs once per step
+            # every class runs once per step; hxt and transconv are within 1 % of each other: the roofline block stays on the one that is
+            # bracketed inside the timed steps
+            dom = "transconv" if (one_class and "transconv" in tab) else max(tab, key=lambda k: tab[k]["avg_ms"])
             ach, avg_ms, kfl = tab[dom]["tflops"], tab[dom]["avg_ms"], f1 * (2.0 if dom in ("hxt", "transconv") else 1.0)
-            src = "HIP event pairs around each launch inside the timed region"
+            src = ("HIP event pairs around every 4th launch of this kernel inside the timed region (the other rows of `kernels`: the same over a second pass of the K steps)"
+                   if one_class else "HIP event pairs around each launch inside the timed region")
+            for name in tab:
+                tab[name]["measured_in"] = "timed steps" if (not one_class or name == dom) else "second pass of the same steps"
         else:  # HALS: see the latency-bound block below; the MFMA kernels are timed stand-alone
             dom, ach, avg_ms, kfl = "conv", kern["conv"]["tflops"], kern["conv"]["avg_ms"], f1
             src = "cmf_time_kernel: HIP events around 5 stand-alone launches"

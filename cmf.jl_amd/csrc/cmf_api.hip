@@ -204,6 +204,7 @@ struct cmf_handle_s {
     int prof_every = 1;          // bracket every n-th launch of a class (option value n)
     int prof_seen[32] = {0};
     struct ProfRec { hipEvent_t a, b; int cls; };
+    unsigned prof_mask = 0; // option "profile_mask"
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data, 3 mask .* (tensor_conv(W,H) - data),
@@ -706,6 +707,7 @@ struct ProfScope {
     ProfScope(cmf_handle_s *h_, int cls) : h(h_)
     {
         if (!h->prof || h->prof_recs.size() >= 8192) return;
+        if (h->prof_mask && !((h->prof_mask >> cls) & 1u)) return;
         if ((h->prof_seen[cls]++ % h->prof_every) != 0) return;
         hipEvent_t ev[2] = {nullptr, nullptr};
         for (int q = 0; q < 2; ++q) {
@@ -1748,6 +1750,10 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
     if (std::strcmp(name, "speculate") == 0) { // 1 (default): update_feature_maps! enqueues the next update_motifs!'s contraction behind its loss conv when the caller alternates the two calls
         h->speculate = value != 0;
         h->spec_gen = -1;
+        return CMF_OK;
+    }
+    if (std::strcmp(name, "profile_mask") == 0) { // which kernel classes "profile" times (bit i: class i of cmf_kernel_times' names in their order; 0 = all)
+        h->prof_mask = (unsigned)value;
         return CMF_OK;
     }
     if (std::strcmp(name, "profile") == 0) { // (re)start or stop the in-loop kernel timing; collected times are dropped

@@ -204,6 +204,9 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       on W, H and loss_hist; hals_gram = 1 does NOT -- it is held to 3e-4 in the tests (measured: W 4-8e-5, H up to
  *       1.4e-4) and exists for measurements only.
  *   "profile" (n): bracket every n-th contraction launch with HIP events (cmf_kernel_times); 0 stops.
+ *   "profile_mask" (bits): the kernel classes "profile" times -- bit i = the i-th name of cmf_kernel_times ("conv", "conv_t",
+ *       "conv_loss", "conv_loss_store", "hxt", "transconv", ...); 0 (default) = all.  (An event pair idles the device a few
+ *       microseconds: bench.py times only the dominant kernel inside its timed steps.)
  *   "allreduce_overlap" (group handles, default 0): 1 = numW (which needs H only) is contracted and all-reduced on a
  *       second stream right after the H update, underneath the loss conv and the denominator contraction, so only
  *       the denomW half of the all-reduce stays exposed; costs a second C2 launch per iteration. */
