@@ -44,6 +44,53 @@ __global__ void chain(float *out, unsigned long long *cycles, float a, float b)
                                "v_writelane_b32 %6, s20, 3"
                                : "+v"(v), "+v"(w), "+v"(V), "+v"(vnr), "+v"(mh), "=&v"(sidx), "+v"(dv) : : "s20");)
             v += V + dv;
+        } else if (KIND == 9) { // a sweep step that WALKS THE LANES instead of shifting the state: column j lives in lane j; the chain is
+            // readlane(d, j-1) -> fma(c1 * d_{j-1} + U) -> max(., -h); off the chain: keep lane j of d, U += d_{j-1} * taps, shift the taps
+            float U = w + threadIdx.x, g = w, mh = -w, dacc = 0.f, t = 0.f;
+            REP16(asm volatile("v_readlane_b32 s20, %0, 5\n\t"
+                               "v_fma_f32 %6, s20, %1, %2\n\t"
+                               "v_max_f32 %0, %6, %4\n\t"
+                               "v_cndmask_b32 %5, %5, %0, vcc\n\t"
+                               "v_fma_f32 %2, s20, %3, %2\n\t"
+                               "s_nop 0\n\t"
+                               "v_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                               : "+v"(v), "+v"(w), "+v"(U), "+v"(g), "+v"(mh), "+v"(dacc), "+v"(t) : : "s20", "vcc");)
+            v += U + dacc + g;
+        } else if (KIND == 10) { // the same with two columns' worth of taps per DPP shift left out (pre-shifted tap registers): 5 instructions
+            float U = w + threadIdx.x, g = w, mh = -w, dacc = 0.f, t = 0.f;
+            REP16(asm volatile("v_readlane_b32 s20, %0, 5\n\t"
+                               "v_fma_f32 %6, s20, %1, %2\n\t"
+                               "v_max_f32 %0, %6, %4\n\t"
+                               "v_cndmask_b32 %5, %5, %0, vcc\n\t"
+                               "v_fma_f32 %2, s20, %3, %2"
+                               : "+v"(v), "+v"(w), "+v"(U), "+v"(g), "+v"(mh), "+v"(dacc), "+v"(t) : : "s20", "vcc");)
+            v += U + dacc + g;
+        } else if (KIND == 11) { // ... the taps of the step read from an LDS table (ds_read_b32 three steps ahead) instead of held in 64 registers
+            __shared__ float tab[64 * 8];
+            tab[threadIdx.x] = w;
+            float U = w + threadIdx.x, g = w, g2 = w, mh = -w, dacc = 0.f, t = 0.f;
+            unsigned addr = threadIdx.x * 4;
+            REP16(asm volatile("ds_read_b32 %7, %8 offset:256\n\t"
+                               "v_readlane_b32 s20, %0, 5\n\t"
+                               "v_fma_f32 %6, s20, %1, %2\n\t"
+                               "v_max_f32 %0, %6, %4\n\t"
+                               "v_cndmask_b32 %5, %5, %0, vcc\n\t"
+                               "s_waitcnt lgkmcnt(3)\n\t"
+                               "v_fma_f32 %2, s20, %3, %2"
+                               : "+v"(v), "+v"(w), "+v"(U), "+v"(g), "+v"(mh), "+v"(dacc), "+v"(t), "=v"(g2) : "v"(addr) : "s20", "vcc");)
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            v += U + dacc + g + g2;
+        } else if (KIND == 12) { // the walking step as the compiler emits it for gfx950 (hazard nops: VALU -> v_readlane, SGPR written by VALU -> VALU)
+            float U = w + threadIdx.x, g = w, mh = -w, dacc = 0.f, t = v;
+            REP16(asm volatile("v_max_f32 %0, %6, %4\n\t"
+                               "s_nop 0\n\t"
+                               "v_readlane_b32 s20, %0, 5\n\t"
+                               "v_writelane_b32 %5, s20, 5\n\t"
+                               "s_nop 1\n\t"
+                               "v_fma_f32 %6, s20, %1, %2\n\t"
+                               "v_fmac_f32 %2, s20, %3"
+                               : "+v"(v), "+v"(w), "+v"(U), "+v"(g), "+v"(mh), "+v"(dacc), "+v"(t) : : "s20");)
+            v += U + dacc + g + t;
         } else if (KIND == 7) { // v_readlane with immediate -> fma
             REP16(asm volatile("v_readlane_b32 s20, %0, 5\n\tv_fma_f32 %0, s20, %1, %0" : "+v"(v) : "v"(w) : "s20");)
         }
@@ -87,5 +134,9 @@ int main()
     run<7>("v_readlane imm -> v_fma(sgpr)", 2);
     run<6>("v_readfirstlane -> v_mov(sgpr)", 2);
     run<8>("HALS sweep step, V form (9 instr)", 9);
+    run<9>("sweep step walking the lanes (6 instr)", 6);
+    run<10>("... with pre-shifted taps (5 instr)", 5);
+    run<11>("... the taps from an LDS table (5 + ds_read)", 6);
+    run<12>("walking step as compiled (5 instr + hazard nops)", 5);
     return 0;
 }
