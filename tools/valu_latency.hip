@@ -7,6 +7,21 @@
 #define REP16(x) x x x x x x x x x x x x x x x x
 #define N_OUTER 64
 
+// the walking step unrolled over 16 lanes with a tap register of its own per step (what hals_h_row_sweep would hold), J as an immediate
+template <int J>
+__device__ __forceinline__ void walk16(float &v, float w, float &U, const float (&g)[16], float mh, float &dacc, float &t)
+{
+    asm volatile("v_max_f32 %0, %5, %3\n\t"
+                 "s_nop 0\n\t"
+                 "v_readlane_b32 s20, %0, %6\n\t"
+                 "s_nop 1\n\t"
+                 "v_fma_f32 %5, s20, %1, %2\n\t"
+                 "v_fmac_f32 %2, s20, %7\n\t"
+                 "v_writelane_b32 %4, s20, %6"
+                 : "+v"(v), "+v"(w), "+v"(U), "+v"(mh), "+v"(dacc), "+v"(t) : "n"(J), "v"(g[J]) : "s20");
+    if constexpr (J + 1 < 16) walk16<J + 1>(v, w, U, g, mh, dacc, t);
+}
+
 template <int KIND>
 __global__ void chain(float *out, unsigned long long *cycles, float a, float b)
 {
@@ -91,6 +106,13 @@ __global__ void chain(float *out, unsigned long long *cycles, float a, float b)
                                "v_fmac_f32 %2, s20, %3"
                                : "+v"(v), "+v"(w), "+v"(U), "+v"(g), "+v"(mh), "+v"(dacc), "+v"(t) : : "s20");)
             v += U + dacc + g + t;
+        } else if (KIND == 13) { // the same, lanes 0..15 and 16 tap registers
+            float U = w + threadIdx.x, mh = -w, dacc = 0.f, t = v;
+            float g[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) g[j] = w + j;
+            walk16<0>(v, w, U, g, mh, dacc, t);
+            v += U + dacc + t;
         } else if (KIND == 7) { // v_readlane with immediate -> fma
             REP16(asm volatile("v_readlane_b32 s20, %0, 5\n\tv_fma_f32 %0, s20, %1, %0" : "+v"(v) : "v"(w) : "s20");)
         }
@@ -138,5 +160,6 @@ int main()
     run<10>("... with pre-shifted taps (5 instr)", 5);
     run<11>("... the taps from an LDS table (5 + ds_read)", 6);
     run<12>("walking step as compiled (5 instr + hazard nops)", 5);
+    run<13>("... lanes 0..15, a tap register per step", 5);
     return 0;
 }
