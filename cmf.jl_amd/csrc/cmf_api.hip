@@ -769,7 +769,10 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
             if (sk_split && h->conv_split && tiles3 < per_round) cutq = tiles3; // fewer tiles than SIMDs (short recordings): quarter pieces only (configs[0]: 9-12 -> 5-8 us)
             const int n_full = tiles3 - cutq;
             grid = dim3(n_full + 4 * cutq);
-#define CASE(NKP_) hipLaunchKernelGGL((conv_small_kernel<MODE, NKP_>), grid, dim3(64), 0, h->stream, p, gx3, n_full)
+            // (loss + store on a short launch: the data tile is requested before the MFMA loop, conv3_tile)
+            const bool pre = MODE == 3 && nkp <= 4 && tiles3 <= 4 * per_round;
+#define CASE(NKP_) do { if (pre) hipLaunchKernelGGL((conv_small_kernel<MODE, NKP_, (MODE == 3 && NKP_ <= 4)>), grid, dim3(64), 0, h->stream, p, gx3, n_full); \
+                        else hipLaunchKernelGGL((conv_small_kernel<MODE, NKP_>), grid, dim3(64), 0, h->stream, p, gx3, n_full); } while (0)
             if (nkp <= 1) CASE(1); else if (nkp == 2) CASE(2); else if (nkp == 3) CASE(3); else if (nkp == 4) CASE(4);
             else if (nkp <= 6) CASE(6); else CASE(8);
 #undef CASE

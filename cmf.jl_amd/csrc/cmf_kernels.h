@@ -97,9 +97,9 @@ __device__ __forceinline__ void cmf_bstore(float v, __amdgpu_buffer_rsrc_t r, in
 // what a workgroup at the edge of its life is short of, see conv2_kernel), and nothing wide for the compiler to hoist
 // out of a tile loop.  In the [t][n] layout the descriptor ends at row T_store, so the rows of a partial last tile
 // that do not exist are dropped by the bounds check instead of by per-element branches.
-template <int MODE, int WAVES = 4>
-__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvParams &p, int t0, int n0, int wt, int wn,
-                                              int i, int h, int lane, int wave, int tid, int pidx = -1)
+template <int MODE, int WAVES = 4, bool PRE = false>
+__device__ __forceinline__ void conv_epilogue_(f32x16 (&acc)[2][2], const ConvParams &p, int t0, int n0, int wt, int wn,
+                                               int i, int h, int lane, int wave, int tid, int pidx, const float (&pre)[2][2][16])
 {
     if (pidx < 0) pidx = blockIdx.y * gridDim.x + blockIdx.x; // slot of this tile's loss partial
     const int Np = p.Np, TP = p.TP;
@@ -140,7 +140,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int so = (((gt + ti) * 32 + (r & 3) + 8 * (r >> 2)) * Np + (gn + ni) * 32) * 4;
-                                dv[ti][ni][r] = LOSS ? cmf_bload(rd, voff, so) : 0.f; // rows past T_store read as 0 (masked below)
+                                dv[ti][ni][r] = !LOSS ? 0.f : (PRE && !MASKED) ? pre[gt + ti][gn + ni][r] // (the caller loaded the data tile under its MFMA loop: conv3_tile)
+                                                                               : cmf_bload(rd, voff, so); // rows past T_store read as 0 (masked below)
                                 mv[ti][ni][r] = MASKED ? cmf_bload(rm, voff, so) : 1.f;
                             }
 #pragma unroll
@@ -236,6 +237,14 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvPar
             }
     }
 }
+template <int MODE, int WAVES = 4>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][2], const ConvParams &p, int t0, int n0, int wt, int wn,
+                                              int i, int h, int lane, int wave, int tid, int pidx = -1)
+{
+    const float none[2][2][16] = {};
+    conv_epilogue_<MODE, WAVES, false>(acc, p, t0, n0, wt, wn, i, h, lane, wave, tid, pidx, none);
+}
+
 
 template <int MODE, int NKP_CT>
 __global__ __launch_bounds__(256) void conv_kernel(ConvParams p)
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
 // end of the launch shrink fourfold.  Main loop and epilogue are conv2's.
 // ---------------------------------------------------------------------------------------------
 #define CONV3_STRIDE 96
-template <int MODE, int NBL = 2, int NKP = 16>
+template <int MODE, int NBL = 2, int NKP = 16, bool PREQ = false>
 __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t0, int n0, int lane, int pidx)
 {
     const int i = lane & 31, h = lane >> 5;
@@ -530,6 +539,27 @@ __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t
     const int woff = (h * Np + n0 + i) * 4; // per-lane part of the W address
     float wA[NKP][2], wB[NKP][2];
     constexpr int NQ = (2 * NKP + 7) / 8; // 8-row passes of the strip load that hold live k rows
+    // Few components (NKP <= 4), loss + store, SHORT launches (PREQ: the host asks for it when there are at most four tiles per SIMD):
+    // the tile's MFMA loop is short (240 MFMAs at K = 5, L = 20) and the data tile the loss needs was loaded in the epilogue, an exposed
+    // HBM round trip per tile; here it is requested before the loop (64 registers that the few k pairs leave free) with the epilogue's
+    // descriptor and offsets, and the epilogue finds it there (protocol shape: 37.8 -> 35.8 us).  On a launch of many rounds (N = 2000:
+    // eight tiles per SIMD slot, bandwidth-bound) the W rows of the first lags queue behind these 64 loads and it costs 7 %: not used there.
+    constexpr bool PRE = (PREQ && MODE == 3 && NKP <= 4 && NBL == 2);
+    float dpre[2][2][16];
+    if (PRE) {
+        int rows = p.T_store - t0;
+        rows = rows < 0 ? 0 : (rows > 64 ? 64 : rows);
+        const size_t origin = (size_t)(p.PADL + t0) * Np + n0;
+        const __amdgpu_buffer_rsrc_t rd = cmf_rsrc(p.data + origin, rows ? ((size_t)(rows - 1) * Np + 64) * 4 : 0);
+        const int voff = (4 * h * Np + i) * 4;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dpre[ti][ni][r] = cmf_bload(rd, voff, ((ti * 32 + (r & 3) + 8 * (r >> 2)) * Np + ni * 32) * 4);
+    }
 
     for (int kb = 0; kb < p.KB; ++kb) {
         for (int lb = 0; lb < LB; ++lb) {
@@ -560,7 +590,8 @@ __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t
         }
     }
     if (NBL == 1) conv2_clear_dead<MODE>(acc);
-    conv_epilogue<MODE, 1>(acc, p, t0, n0, 0, 0, i, h, lane, 0, lane, pidx);
+    if constexpr (PRE) conv_epilogue_<MODE, 1, true>(acc, p, t0, n0, 0, 0, i, h, lane, 0, lane, pidx, dpre);
+    else conv_epilogue<MODE, 1>(acc, p, t0, n0, 0, 0, i, h, lane, 0, lane, pidx);
 }
 
 // One 32 x 32 block of the epilogue (the quarter tiles of conv3_kernel): acc[r] is t = tb + crow(r,h), n = nb + i, or
@@ -906,14 +937,14 @@ __global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p, int gx, int 
 // grid: n_full whole tiles + 4 quarter pieces for each of the remaining tiles, dispatched last (conv3_kernel's scheme): the
 // reference's protocol shape is 3128 tiles on 1024 SIMDs -- 3.05 per SIMD, so that a handful of SIMDs ran a fourth whole tile
 // while the chip waited (36 us for 19.5 us of MFMA issue per SIMD); in quarters the excess is a quarter tile on a quarter of the SIMDs.
-template <int MODE, int NKP>
+template <int MODE, int NKP, bool PREQ = false>
 __global__ __launch_bounds__(64, (NKP <= 4 && (MODE <= 1 || MODE == 5)) ? 4 : 3) void conv_small_kernel(ConvParams p, int gx, int n_full)
 {
     __shared__ __attribute__((aligned(16))) float Hs[32 * CONV3_STRIDE];
     const int b = blockIdx.x;
     if (b < n_full) {
         const int n0 = (b % gx) * 64;
-        if (n0 + 32 < p.N) conv3_tile<MODE, 2, NKP>(p, Hs, (b / gx) * 64, n0, threadIdx.x, b);
+        if (n0 + 32 < p.N) conv3_tile<MODE, 2, NKP, PREQ>(p, Hs, (b / gx) * 64, n0, threadIdx.x, b);
         else conv3_tile<MODE, 1, NKP>(p, Hs, (b / gx) * 64, n0, threadIdx.x, b);
     } else {
         const int q = b - n_full, tile = n_full + (q >> 2), sub = q & 3;
