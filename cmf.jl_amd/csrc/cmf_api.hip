@@ -1648,6 +1648,13 @@ int cmf_set_stream(cmf_handle h, void *hip_stream)
 {
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
     if (h->group) return fail(CMF_ERR_STATE, "a group handle runs on its own per-device streams");
+    if ((hipStream_t)hip_stream != h->stream) {
+        // what is still running on the stream so far -- since round 5 a rule call may return with a speculated contraction in flight
+        // (option "speculate") -- is not ordered with the new stream: wait for it, and let nothing speculated carry over
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->spec_gen = -1;
+    }
     h->stream = (hipStream_t)hip_stream;
     return CMF_OK;
 }

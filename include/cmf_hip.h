@@ -162,7 +162,8 @@ int cmf_get_counter(cmf_handle h, const char *name, int64_t *value);
 /* Run all work of this handle on an existing HIP stream (hipStream_t passed
  * as void*), e.g. torch's current stream.  NULL is the HIP null (legacy
  * default) stream -- which is what torch's default "current stream" is.
- * A new handle runs on a private non-blocking stream until this is called.
+ * A new handle runs on a private non-blocking stream until this is called.  A change of stream first waits for what the handle
+ * has enqueued on the stream it leaves (a rule call may return with the next call's contraction in flight: option "speculate").
  * Group handles refuse it (CMF_ERR_STATE): they run on their own per-shard streams, and that includes the handle
  * cmf_create returns for a recording longer than one handle addresses (T > 8.3 M columns at K <= 64, see cmf_create) --
  * a caller that orders work through torch's current stream must cmf_synchronize such a handle instead. */

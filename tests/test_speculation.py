@@ -107,3 +107,38 @@ def test_other_rules_do_not_speculate(cmf):
             rule.update_feature_maps()
         assert rule.counter("speculated_contractions") == 0
         rule.close()
+
+
+def test_stream_switch_between_the_two_calls(cmf):
+    """cmf_set_stream while a speculated contraction may still be in flight on the old stream: the switch waits for it and nothing
+    speculated carries over to the new stream (include/cmf_hip.h: cmf_set_stream)."""
+    import ctypes
+
+    from cmf_jl_amd._lib import check
+
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself is linked to (a second one -- torch's -- would not see the device)
+    data, W0, H0 = problem(cmf, 200, 6000, 32, 10)
+    ref = cmf.MultUpdate(data, W0, H0)
+    rule = cmf.MultUpdate(data, W0, H0)
+    streams = []
+    for _ in range(2):
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0  # hipStreamNonBlocking
+        streams.append(st)
+    try:
+        for it in range(4):
+            ref.update_motifs()
+            want = ref.update_feature_maps()
+            rule.update_motifs()
+            got = rule.update_feature_maps()  # returns with the next contraction enqueued behind the loss conv
+            assert got == want
+            check(rule._lib.cmf_set_stream(rule._h, streams[it % 2]))
+        Wa, Ha = ref.download()
+        Wb, Hb = rule.download()
+        assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
+        assert rule.counter("speculated_contractions") == 0 and ref.counter("speculated_contractions") == 3
+    finally:
+        ref.close()
+        rule.close()
+        for st in streams:
+            hip.hipStreamDestroy(st)
