@@ -113,6 +113,18 @@ __global__ void chain(float *out, unsigned long long *cycles, float a, float b)
             for (int j = 0; j < 16; ++j) g[j] = w + j;
             walk16<0>(v, w, U, g, mh, dacc, t);
             v += U + dacc + t;
+        } else if (KIND == 14) { // the window form without the per-step entry of a column (zero-fill shift, the next 32 columns put in at once
+            // every 32 steps: L <= 33): the v_mov and the rotation of the entering values drop out -- 7 instructions
+            float V = w + threadIdx.x, mh = -w, dv = 0.f;
+            REP16(asm volatile("v_readfirstlane_b32 s20, %0\n\t"
+                               "v_mov_b32_dpp %4, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                               "v_fma_f32 %2, s20, %1, %4\n\t"
+                               "v_fma_f32 %0, %1, %0, %4\n\t"
+                               "v_mov_b32_dpp %3, %3 wave_rol:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                               "v_max_f32 %0, %0, %3\n\t"
+                               "v_writelane_b32 %5, s20, 3"
+                               : "+v"(v), "+v"(w), "+v"(V), "+v"(mh), "=&v"(sidx), "+v"(dv) : : "s20");)
+            v += V + dv;
         } else if (KIND == 7) { // v_readlane with immediate -> fma
             REP16(asm volatile("v_readlane_b32 s20, %0, 5\n\tv_fma_f32 %0, s20, %1, %0" : "+v"(v) : "v"(w) : "s20");)
         }
@@ -161,5 +173,6 @@ int main()
     run<11>("... the taps from an LDS table (5 + ds_read)", 6);
     run<12>("walking step as compiled (5 instr + hazard nops)", 5);
     run<13>("... lanes 0..15, a tap register per step", 5);
+    run<14>("window form, columns entering 32 at a time (7 instr)", 7);
     return 0;
 }
