@@ -377,6 +377,8 @@ def measure_call_by_call(rule, W0, H0, reg_kw, nsteps, sync):
     rule.sync_every_call = False
     rec["ms_per_step_call_by_call"] = timed_loop()
     rule.upload(W0, H0)
+    W[...] = W0  # (under sync_every_call the rule reads the arrays it is handed: they start as the initial factors, like `fit`'s copies)
+    H[...] = H0
     rule.sync_every_call = True
     try:
         rec["ms_per_step_call_by_call_writeback"] = timed_loop()

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libcmf_hip.so")
 
 CMF_OK, CMF_ERR_ARG, CMF_ERR_HIP, CMF_ERR_STATE, CMF_ERR_UNSUPPORTED, CMF_ERR_COMM = 0, 1, 2, 3, 4, 5
 CMF_COMM_AUTO, CMF_COMM_RCCL, CMF_COMM_LOOPBACK, CMF_COMM_LOOPBACK_STREAMS, CMF_COMM_PEER = 0, 1, 2, 3, 4
-ABI_VERSION = 5  # CMF_ABI_VERSION of include/cmf_hip.h
+ABI_VERSION = 6  # CMF_ABI_VERSION of include/cmf_hip.h
 
 # host-collective callbacks of cmf_comm_init_callbacks (include/cmf_hip.h)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int64)
@@ -30,7 +30,7 @@ SYMBOLS = [
     "cmf_rccl_version", "cmf_get_counter",
     "cmf_comm_unique_id", "cmf_comm_init_rccl", "cmf_comm_init_overlap", "cmf_comm_init_callbacks", "cmf_comm_info", "cmf_shard_bounds",
     "cmf_set_option", "cmf_get_data_sumsq",
-    "cmf_set_factors", "cmf_get_factors", "cmf_arm_writeback",
+    "cmf_set_factors", "cmf_get_factors", "cmf_arm_writeback", "cmf_fingerprint",
     "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_iterate", "cmf_fit", "cmf_converged",
     "cmf_hals_update_motifs", "cmf_hals_update_feature_maps",
     "cmf_pgd_reset", "cmf_set_mask", "cmf_pgd_set_loss", "cmf_pgd_update_motifs", "cmf_pgd_update_feature_maps", "cmf_pgd_get_steps",
@@ -105,6 +105,7 @@ def load():
     sig("cmf_set_factors", [vp, pd, pd])
     sig("cmf_get_factors", [vp, pd, pd])
     sig("cmf_arm_writeback", [vp, pd, pd])
+    sig("cmf_fingerprint", [pd, i64, i64, ctypes.POINTER(u64)])
     sig("cmf_update_motifs", [vp, dbl, dbl])
     sig("cmf_update_feature_maps", [vp, dbl, dbl, pd])
     sig("cmf_compute_loss", [vp, pd])

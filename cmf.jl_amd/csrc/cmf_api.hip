@@ -158,7 +158,8 @@ struct cmf_handle_s {
     int sk3_NS = 1, sk3_RPS = 1;            // short recordings: C3's reduction over n in sk3_NS pieces of sk3_RPS rounds of 8 rows (2 slabs per piece)
     int sk3_GR = 128, sk3_RV = 0;           // rows of a row group in Wj (32-row blocks); the last sk3_RV live rows on the VALU (sk3_MBW then counts the MFMA blocks only)
     float *sk_slabs = nullptr, *sk_Wj = nullptr;
-    bool sk_wj_fresh = false;               // sk_Wj holds the resident W (written by w_update_small_kernel; every other writer of W clears it)
+    int64_t sk_wj_gen = -1;                 // est_gen at which sk_Wj was packed from the resident W (w_update_small_kernel, wj_pack_kernel): every writer of W
+                                            // passes through set_est, so a stale operand cannot be taken for a fresh one (-1: never packed)
     int tc_S_full = 1, tc_S1_full = 1;      // fragment slabs of the general transconv kernel (tc_S / tc_S1 are 1 while small_k is on)
     int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
     int conv_variant = 0;   // K % 32 == 0: 3 = one-wave workgroups (conv3_kernel), 2 = 128 x 128 tiles (conv2_kernel), 0 = per mode
@@ -233,6 +234,7 @@ struct cmf_handle_s {
 
 static int hals_ensure(cmf_handle_s *h);
 static void wb_free(cmf_handle_s *h);
+static void wb_disarm(cmf_handle_s *h);
 static inline void set_est(cmf_handle_s *h, int kind) // every change of what est holds (and with it: of H, W) passes through here
 {
     h->est_kind = kind;
@@ -834,10 +836,11 @@ static int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
 {
     ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_TRANSCONV_1);
     const CmfDims &d = h->d;
-    if (!h->sk_wj_fresh) { // (w_update_small_kernel writes the packed operand itself; every other writer of W leaves it stale)
+    if (h->sk_wj_gen != h->est_gen) { // (w_update_small_kernel writes the packed operand itself; whatever else touched W, H or est since: pack again)
         hipLaunchKernelGGL(wj_pack_kernel, dim3((unsigned)std::min<size_t>(1024, ((size_t)d.Np * h->sk3_JP + 255) / 256)), dim3(256), 0, h->stream,
                            h->Wn, h->sk_Wj, d.Np, d.K, d.L, d.K32, h->sk3_Kg, h->sk3_GR, h->sk3_JP);
         KCHK("wj_pack_kernel");
+        h->sk_wj_gen = h->est_gen;
     }
     SkGemmParams p;
     p.Wj = h->sk_Wj; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.out = h->hslabs;
@@ -1000,7 +1003,6 @@ static int w_apply_impl_(cmf_handle_s *h, double l1W, double l2W, const float *t
 static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W, const float *tail_src = nullptr, float *tail_dst = nullptr, int tail_n = 0,
                         const float *den = nullptr)
 {
-    h->sk_wj_fresh = false;
     return w_apply_impl_(h, l1W, l2W, tail_src, tail_dst, tail_n, den);
 }
 
@@ -1029,7 +1031,7 @@ static int w_phase_impl(cmf_handle_s *h, double l1W, double l2W)
                        (float)l1W, (float)(2.0 * l2W), carry); // mult.jl:37-38
     KCHK("w_update_small_kernel");
     set_est(h, 0);
-    h->sk_wj_fresh = h->sk_tc;
+    h->sk_wj_gen = h->sk_tc ? h->est_gen : -1;
     return CMF_OK;
 }
 
@@ -1121,25 +1123,29 @@ static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = tru
 
 static int set_factors_impl(cmf_handle_s *h, const double *W, const double *H)
 {
-    if (!h || !W || !H) return fail(CMF_ERR_ARG, "NULL argument");
-    h->sk_wj_fresh = false;
+    if (!h || (!W && !H)) return fail(CMF_ERR_ARG, "NULL argument");
+    if ((!W || !H) && !h->factors_set) return fail(CMF_ERR_STATE, "the first cmf_set_factors needs both W and H");
     HIPCHK(hipSetDevice(h->device));
     const CmfDims &d = h->d;
     const size_t nW = (size_t)d.L * d.N * d.K, nH = (size_t)d.Tl * d.K;
     CMFTRY(ensure_stage(h, std::max(nW, nH)));
-    // padding must be zero: clear, then scatter the valid entries
-    HIPCHK(hipMemsetAsync(h->Wt, 0, (size_t)d.Lp * d.K32 * d.Np * sizeof(float), h->stream));
-    HIPCHK(hipMemsetAsync(h->Wn, 0, (size_t)d.Lp * d.Np * d.K32 * sizeof(float), h->stream));
-    HIPCHK(hipMemsetAsync(h->H, 0, (size_t)d.TP * d.K32 * sizeof(float), h->stream));
-    HIPCHK(hipMemsetAsync(h->Ht, 0, (size_t)d.K32 * d.TP * sizeof(float), h->stream));
-    HIPCHK(hipMemcpyAsync(h->stage, W, nW * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(pack_W_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.N, d.K, d.L, h->Wt, h->Wn, d.Np, d.K32);
-    KCHK("pack_W_kernel");
-    HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpyAsync(h->stage, H, nH * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(pack_H_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.Tl, d.K, h->H, h->Ht, d.K32, d.TP, d.PADL);
-    KCHK("pack_H_kernel");
-    HIPCHK(hipStreamSynchronize(h->stream));
+    // padding must be zero: clear, then scatter the valid entries (a NULL factor keeps its resident value)
+    if (W) {
+        HIPCHK(hipMemsetAsync(h->Wt, 0, (size_t)d.Lp * d.K32 * d.Np * sizeof(float), h->stream));
+        HIPCHK(hipMemsetAsync(h->Wn, 0, (size_t)d.Lp * d.Np * d.K32 * sizeof(float), h->stream));
+        HIPCHK(hipMemcpyAsync(h->stage, W, nW * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(pack_W_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.N, d.K, d.L, h->Wt, h->Wn, d.Np, d.K32);
+        KCHK("pack_W_kernel");
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (H) {
+        HIPCHK(hipMemsetAsync(h->H, 0, (size_t)d.TP * d.K32 * sizeof(float), h->stream));
+        HIPCHK(hipMemsetAsync(h->Ht, 0, (size_t)d.K32 * d.TP * sizeof(float), h->stream));
+        HIPCHK(hipMemcpyAsync(h->stage, H, nH * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(pack_H_kernel, dim3(1024), dim3(256), 0, h->stream, h->stage, d.Tl, d.K, h->H, h->Ht, d.K32, d.TP, d.PADL);
+        KCHK("pack_H_kernel");
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     h->factors_set = true;
     set_est(h, 0);
     return CMF_OK;
@@ -1360,8 +1366,14 @@ static int wb_start_W(cmf_handle_s *h)
 static int wb_drain(cmf_handle_s *h)
 {
     CmfWriteback *wb = h->wb;
-    if (!cmf_pool_wait(wb->pool, wait_timeout_s()))
+    if (wb->poisoned.load(std::memory_order_acquire)) return fail(CMF_ERR_HIP, "write-back: a helper thread of this handle never returned");
+    if (!cmf_pool_wait(wb->pool, wait_timeout_s())) {
+        // A helper is stuck in a wait on the device.  When it wakes up it must neither widen into arrays the caller has taken back nor
+        // into the arrays of a later arm: the record is poisoned (helpers look at the flag behind every wait and leave), keeps its
+        // pointers -- a helper reads only the copies in its own closure -- and takes no further arms (wb_arm).
+        wb->poisoned.store(true, std::memory_order_release);
         return fail(CMF_ERR_HIP, "write-back: the helper threads did not finish within %.0f s", wait_timeout_s());
+    }
     std::string err;
     const int rc = cmf_pool_collect(wb->pool, -1, &err);
     return rc == 0 ? CMF_OK : fail(rc, "write-back: %s", err.c_str());
@@ -1394,8 +1406,9 @@ static int wb_after_H(cmf_handle_s *h)
     }
     const size_t nthr = wb->pool.size();
     const bool want_W = !again && wb->dst_W && wb->w_started;
+    double *const dst_W = wb->dst_W, *const dst_H = wb->dst_H; // (the helpers use these copies: the record's fields belong to the calling thread)
     for (size_t i = 0; i < nthr; ++i)
-        cmf_pool_post(wb->pool, i, [wb, i, nthr, want_W]() -> int {
+        cmf_pool_post(wb->pool, i, [wb, i, nthr, want_W, dst_W, dst_H]() -> int {
             auto slice = [&](size_t n, size_t *a, size_t *b) { // 16-element granules, the last helper takes the remainder
                 const size_t per = (n / nthr) & ~(size_t)15;
                 *a = i * per;
@@ -1404,13 +1417,15 @@ static int wb_after_H(cmf_handle_s *h)
             size_t a, b;
             if (want_W) {
                 if (hipEventSynchronize(wb->ev_w_done) != hipSuccess) return fail(CMF_ERR_HIP, "the download of W failed");
+                if (wb->poisoned.load(std::memory_order_acquire)) return CMF_OK; // (the call gave up on this helper: the arrays are the caller's again)
                 slice(wb->nW, &a, &b);
-                cmf_widen(wb->pin_W + a, wb->dst_W + a, b - a);
+                cmf_widen(wb->pin_W + a, dst_W + a, b - a);
             }
-            if (wb->dst_H) {
+            if (dst_H) {
                 if (hipEventSynchronize(wb->ev_h_done) != hipSuccess) return fail(CMF_ERR_HIP, "the download of H failed");
+                if (wb->poisoned.load(std::memory_order_acquire)) return CMF_OK;
                 slice(wb->nH, &a, &b);
-                cmf_widen(wb->pin_H + a, wb->dst_H + a, b - a);
+                cmf_widen(wb->pin_H + a, dst_H + a, b - a);
             }
             return CMF_OK;
         });
@@ -1430,8 +1445,11 @@ static int wb_group_post(cmf_handle_s *h)
     cmf_group_s *g = h->group;
     const size_t nthr = wb->pool.size();
     const double tmo = wait_timeout_s();
+    struct Dst { double *W, *H; };
+    std::vector<Dst> dst; // (the helpers use these copies of the shards' pointers: the records' fields belong to the calling thread)
+    for (cmf_handle_s *s : g->sh) dst.push_back(s->wb && s->wb->armed ? Dst{s->wb->w_started ? s->wb->dst_W : nullptr, s->wb->dst_H} : Dst{nullptr, nullptr});
     for (size_t j = 0; j < nthr; ++j)
-        cmf_pool_post(wb->pool, j, [g, j, nthr, tmo]() -> int {
+        cmf_pool_post(wb->pool, j, [g, wb, j, nthr, tmo, dst]() -> int {
             auto slice = [&](size_t n, size_t *a, size_t *b) {
                 const size_t per = (n / nthr) & ~(size_t)15;
                 *a = j * per;
@@ -1439,15 +1457,16 @@ static int wb_group_post(cmf_handle_s *h)
             };
             for (size_t i = 0; i < g->sh.size(); ++i) {
                 CmfWriteback *sw = g->sh[i]->wb;
-                if (!sw || !sw->armed) continue;
+                if (!sw || (!dst[i].W && !dst[i].H)) continue;
                 (void)hipSetDevice(g->sh[i]->device);
                 size_t a, b;
-                if (sw->dst_W && sw->w_started) {
+                if (dst[i].W) {
                     if (hipEventSynchronize(sw->ev_w_done) != hipSuccess) return fail(CMF_ERR_HIP, "the download of W failed");
+                    if (wb->poisoned.load(std::memory_order_acquire)) return CMF_OK;
                     slice(sw->nW, &a, &b);
-                    cmf_widen(sw->pin_W + a, sw->dst_W + a, b - a);
+                    cmf_widen(sw->pin_W + a, dst[i].W + a, b - a);
                 }
-                if (sw->dst_H) {
+                if (dst[i].H) {
                     const auto t0 = std::chrono::steady_clock::now();
                     for (unsigned spins = 1; !sw->h_issued.load(std::memory_order_acquire); ++spins) { // (the copy is issued by whoever enqueues the shard)
                         if (sw->cancel.load(std::memory_order_acquire)) return CMF_OK;
@@ -1456,8 +1475,9 @@ static int wb_group_post(cmf_handle_s *h)
                         CMF_CPU_PAUSE();
                     }
                     if (hipEventSynchronize(sw->ev_h_done) != hipSuccess) return fail(CMF_ERR_HIP, "the download of H failed");
+                    if (wb->poisoned.load(std::memory_order_acquire)) return CMF_OK;
                     slice(sw->nH, &a, &b);
-                    cmf_widen(sw->pin_H + a, sw->dst_H + a, b - a);
+                    cmf_widen(sw->pin_H + a, dst[i].H + a, b - a);
                 }
             }
             return CMF_OK;
@@ -1490,7 +1510,7 @@ static int wb_finish(cmf_handle_s *h, int rc)
                 s->wb->armed = s->wb->w_started = false;
                 s->wb->dst_W = s->wb->dst_H = nullptr;
             }
-    wb->armed = wb->h_posted = wb->w_started = false;
+    wb->armed = wb->h_posted = wb->w_started = false; // (a poisoned record stays unarmed for good: wb_arm refuses it)
     wb->dst_W = wb->dst_H = nullptr;
     return rc != CMF_OK ? rc : rc2;
 }
@@ -1530,7 +1550,7 @@ extern "C" {
 #endif
 #define CMF_STR2(x) #x
 #define CMF_STR(x) CMF_STR2(x)
-const char *cmf_version(void) { return "cmf_hip gfx950 0.5.0 abi=" CMF_STR(CMF_ABI_VERSION) " src=" CMF_SRC_DIGEST; }
+const char *cmf_version(void) { return "cmf_hip gfx950 0.6.0 abi=" CMF_STR(CMF_ABI_VERSION) " src=" CMF_SRC_DIGEST; }
 const char *cmf_source_digest(void) { return CMF_SRC_DIGEST; }
 int cmf_abi_version(void) { return CMF_ABI_VERSION; }
 const char *cmf_last_error(void) { return g_err.c_str(); }
@@ -1745,7 +1765,7 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->small_k = value != 0 && h->small_k_ok;
-        h->sk_wj_fresh = false;
+        h->sk_wj_gen = -1;
         h->sk_tc = h->small_k && (h->sk_tc_ok || value == 2); // (2: the few-component C3 form whatever T is -- tests, measurements)
         h->tc_S = h->sk_tc ? 2 * h->sk3_NS : h->tc_S_full; // (own block | the spill of the next block, per piece of the reduction: g_gemm_fold_small_kernel)
         h->tc_S1 = h->sk_tc ? 2 * h->sk3_NS : h->tc_S1_full;
@@ -1789,7 +1809,8 @@ int cmf_get_data_sumsq(cmf_handle h, double *sumsq)
 
 int cmf_set_factors(cmf_handle h, const double *W, const double *H)
 {
-    if (!h || !W || !H) return fail(CMF_ERR_ARG, "NULL argument");
+    if (!h || (!W && !H)) return fail(CMF_ERR_ARG, "NULL argument");
+    if (h->wb && h->wb->armed) wb_disarm(h); // (a W copy in flight would deliver the factor this call replaces)
     drop_carry(h);
     if (h->group) return group_set_factors(h->group, W, H);
     return set_factors_impl(h, W, H);
@@ -1864,6 +1885,9 @@ static void wb_disarm(cmf_handle_s *h)
 
 static int wb_arm(cmf_handle_s *h, double *W, double *H)
 {
+    if (h->wb && h->wb->poisoned.load(std::memory_order_acquire))
+        return fail(CMF_ERR_STATE, "write-back: a helper thread of this handle never returned from an earlier call; the handle takes no further "
+                                   "write-backs (cmf_get_factors still works)");
     if (h->group) {
         cmf_group_s *g = h->group;
         CMFTRY(group_check_ready(g));
@@ -2117,6 +2141,9 @@ int cmf_iterate(cmf_handle h, int64_t n_iter, int eval_mode, double l1W, double 
     RoctxRange range("cmf_iterate");
     if (!h || !losses) return fail(CMF_ERR_ARG, "NULL argument");
     if (n_iter < 0) return fail(CMF_ERR_ARG, "n_iter must be >= 0");
+    // An armed write-back serves the next *_update_feature_maps CALL only (include/cmf_hip.h): this loop runs the H phases itself, and
+    // its hooks would post the helpers into the caller's arrays every iteration with nobody draining them.
+    if (h->wb && h->wb->armed) wb_disarm(h);
     drop_carry(h);
     CarryGuard guard{h};
     int rc;
@@ -2145,6 +2172,7 @@ int cmf_fit(cmf_handle h, int64_t max_itr, double max_time, int check_convergenc
         if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator (cmf_comm_init_*) first");
     }
     if (converged_early) *converged_early = 0;
+    if (h->wb && h->wb->armed) wb_disarm(h); // (as in cmf_iterate: the loop's own rule calls are not the caller's)
     int64_t len = 0;
     CMFTRY(cmf_compute_loss(h, &loss_hist[0])); // alternating.jl:37
     time_hist[0] = 0.0;                        // :38
@@ -2570,7 +2598,6 @@ static int compute_hh(cmf_handle_s *h, float *out = nullptr)
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
 {
     const CmfDims &d = h->d;
-    h->sk_wj_fresh = false;
     CMFTRY(hals_ensure(h));
     // G = resid * H_unfold' (hals.jl:104-110 needs resid * h).  resid = est - data, so G = denomW - numW of the MU path:
     // numW = H_shift * data' is ONE C2 contraction on the data, denomW = H_shift * est' = HH * W a small GEMM on the Gram
@@ -2716,6 +2743,27 @@ static int hals_h_sweep_general(cmf_handle_s *h, HalsRowParams q)
     return CMF_OK;
 }
 
+// The whole H sweep as ONE persistent launch on h->stream (hals_h_persist_kernel): flags cleared, K sweepers + (K-1) * P pullers
+static int hals_persist_launch(cmf_handle_s *h, const HalsRowParams &q, int debug = 0, unsigned long long *stamps = nullptr)
+{
+    const CmfDims &d = h->d;
+    HalsPersistParams pp;
+    pp.row = q;
+    pp.Dall = h->hals_D;
+    pp.flags = h->hals_flags;
+    pp.host_status = h->hals_status;
+    pp.K = d.K; pp.P = h->hals_pullers; pp.nblk = (d.Tl + 63) / 64;
+    pp.debug = debug;
+    pp.stamps = stamps;
+    const size_t nflags = (size_t)(d.K + d.K * pp.P + 1) * HALS_FLAG_STRIDE;
+    const size_t lds = std::max((size_t)(d.K - 1) * (2 * d.L - 1 + 64 + 2 * (d.L - 1)) + 1024, (size_t)h->hals_ne * (d.L + 1)) * sizeof(float);
+    ProfScope prof_(h, PROF_HALS_PIPE);
+    HIPCHK(hipMemsetAsync(h->hals_flags, 0, nflags * sizeof(int), h->stream));
+    hipLaunchKernelGGL(hals_h_persist_kernel, dim3(d.K + (d.K - 1) * pp.P), dim3(1024), lds, h->stream, pp);
+    KCHK("hals_h_persist_kernel");
+    return CMF_OK;
+}
+
 static int hals_h_enqueue(cmf_handle_s *h, double l1H, double l2H)
 {
     const CmfDims &d = h->d;
@@ -2738,40 +2786,27 @@ static int hals_h_enqueue(cmf_handle_s *h, double l1H, double l2H)
         if (!h->hals_snap) CMFTRY(dalloc_zero(&h->hals_snap, 2 * nH));
         HIPCHK(hipMemcpyAsync(h->hals_snap, h->H, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->hals_snap + nH, h->Ht, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        HalsPersistParams pp;
-        pp.row = q;
-        pp.Dall = h->hals_D;
-        pp.flags = h->hals_flags;
-        pp.host_status = h->hals_status;
-        pp.K = d.K; pp.P = h->hals_pullers; pp.nblk = (d.Tl + 63) / 64;
-        pp.debug = 0;
+        int debug = 0;
         if (const char *dbg = getenv("CMF_HALS_DEBUG")) { // timing experiments only (results are wrong)
-            if (std::strcmp(dbg, "nogate") == 0) pp.debug = 1;  // sweepers alone: no row waits for anything
-            if (std::strcmp(dbg, "nopull") == 0) pp.debug = 2;  // pullers raise their flags without doing the work
-            if (std::strcmp(dbg, "stall") == 0) pp.debug = 3;   // pullers leave at once: every sweeper's wait must run out (tests)
+            if (std::strcmp(dbg, "nogate") == 0) debug = 1;  // sweepers alone: no row waits for anything
+            if (std::strcmp(dbg, "nopull") == 0) debug = 2;  // pullers raise their flags without doing the work
+            if (std::strcmp(dbg, "stall") == 0) debug = 3;   // pullers leave at once: every sweeper's wait must run out (tests)
         }
-        const size_t nflags = (size_t)(d.K + d.K * pp.P + 1) * HALS_FLAG_STRIDE;
-        const size_t lds = std::max((size_t)(d.K - 1) * (2 * d.L - 1 + 64 + 2 * (d.L - 1)) + 1024, (size_t)h->hals_ne * (d.L + 1)) * sizeof(float);
-        pp.stamps = nullptr;
+        unsigned long long *stamps = nullptr;
         const char *stamp_path = getenv("CMF_HALS_STAMPS"); // debug: dump s_memtime stamps of this launch to a file
-        const size_t nstamps = (size_t)d.K * pp.nblk * 5;
+        const size_t nstamps = (size_t)d.K * ((d.Tl + 63) / 64) * 5;
         if (stamp_path) {
-            HIPCHK(hipMalloc((void **)&pp.stamps, nstamps * sizeof(unsigned long long)));
-            HIPCHK(hipMemsetAsync(pp.stamps, 0, nstamps * sizeof(unsigned long long), h->stream));
+            HIPCHK(hipMalloc((void **)&stamps, nstamps * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(stamps, 0, nstamps * sizeof(unsigned long long), h->stream));
         }
-        {
-            ProfScope prof_(h, PROF_HALS_PIPE);
-            HIPCHK(hipMemsetAsync(h->hals_flags, 0, nflags * sizeof(int), h->stream));
-            hipLaunchKernelGGL(hals_h_persist_kernel, dim3(d.K + (d.K - 1) * pp.P), dim3(1024), lds, h->stream, pp);
-            KCHK("hals_h_persist_kernel");
-        }
+        CMFTRY(hals_persist_launch(h, q, debug, stamps));
         if (stamp_path) {
             std::vector<unsigned long long> st(nstamps);
             HIPCHK(hipStreamSynchronize(h->stream));
-            HIPCHK(hipMemcpy(st.data(), pp.stamps, nstamps * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            (void)hipFree(pp.stamps);
+            HIPCHK(hipMemcpy(st.data(), stamps, nstamps * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            (void)hipFree(stamps);
             if (FILE *f = fopen(stamp_path, "wb")) {
-                const long long hdr[2] = {d.K, pp.nblk};
+                const long long hdr[2] = {d.K, (d.Tl + 63) / 64};
                 fwrite(hdr, sizeof(hdr), 1, f);
                 fwrite(st.data(), sizeof(unsigned long long), nstamps, f);
                 fclose(f);
@@ -2978,7 +3013,6 @@ static int pgd_unit_norm(cmf_handle_s *h, bool is_W)
 static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg)
 {
     const CmfDims &d = h->d;
-    h->sk_wj_fresh = false;
     CMFTRY(pgd_check(h));
     if (nonneg < 0 || nonneg > 2) return fail(CMF_ERR_ARG, "constraint must be 0 (none), 1 (NonnegConstraint) or 2 (UnitNormConstraint)");
     const float gscale = h->pgd_loss_abs ? 1.f : 2.f; // pgd.jl:31-33 vs :42-44
@@ -3327,6 +3361,44 @@ static void parallel_for(size_t n, const std::function<void(size_t, size_t)> &fn
     for (auto &x : th) x.join();
 }
 
+// ---- fingerprints of the caller's arrays (include/cmf_hip.h: cmf_fingerprint) --------------------------------------------------
+static inline uint64_t fp_mix(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+int cmf_fingerprint(const double *a, int64_t n, int64_t line_stride, uint64_t *fp)
+{
+    if (!a || !fp || n < 0) return fail(CMF_ERR_ARG, "bad argument");
+    if (line_stride < 1) line_stride = 1;
+    // 64-byte lines of 8 doubles; every line_stride-th line is hashed together with its index, the hashes are added (order-free, so
+    // the lines can be dealt to threads), and the last line and the length always count
+    const int64_t nlines = (n + 7) / 8;
+    const int64_t nsel = (nlines + line_stride - 1) / line_stride;
+    auto line_hash = [&](int64_t line) -> uint64_t {
+        uint64_t hsh = fp_mix(0x9e3779b97f4a7c15ULL * (uint64_t)(line + 1));
+        const int64_t e0 = line * 8, e1 = std::min<int64_t>(n, e0 + 8);
+        for (int64_t e = e0; e < e1; ++e) {
+            uint64_t bits;
+            std::memcpy(&bits, a + e, 8);
+            hsh = fp_mix(hsh ^ bits) + 0x2545f4914f6cdd1dULL;
+        }
+        return hsh;
+    };
+    std::mutex mu;
+    uint64_t total = fp_mix((uint64_t)n);
+    parallel_for((size_t)nsel, [&](size_t i0, size_t i1) {
+        uint64_t acc = 0;
+        for (size_t i = i0; i < i1; ++i) acc += line_hash((int64_t)i * line_stride);
+        std::lock_guard<std::mutex> lock(mu);
+        total += acc;
+    });
+    if (nlines > 0 && (nlines - 1) % line_stride != 0) total += line_hash(nlines - 1);
+    *fp = total;
+    return CMF_OK;
+}
+
 int cmf_init_rand(int device, int64_t N, int64_t T, int64_t K, int64_t L, uint64_t seed, const double *data, double *W, double *H)
 {
     // src/model.jl:113-125
@@ -3538,6 +3610,70 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
         (void)hipStreamDestroy(aux);
         (void)hipEventDestroy(fork);
         (void)hipEventDestroy(join);
+        set_est(h, 0);
+        return rc;
+    }
+    if (nm.rfind("hals_overlap", 0) == 0) {
+        // Bound experiment: the HALS H row pipeline (K + (K-1)P workgroups, VALU only) with the first
+        // pct % of the residual conv's tile rows on a second, CU-masked stream AT THE SAME TIME -- no dependency between them,
+        // timing only, the handle's state is garbage afterwards -- and the rest of the conv on the whole chip behind both.
+        // "hals_overlap:<pct>:<mode>": mode 0 = pipeline on a stream masked to 20 CUs of every XCD, conv part on the other 12;
+        // 1 = pipeline on the handle's own (unmasked) stream, only the conv part masked; pct = 0: the two kernels back to back.
+        int pct = 40, mode = 0;
+        (void)sscanf(name, "hals_overlap:%d:%d", &pct, &mode);
+        CMFTRY(hals_ensure(h));
+        if (h->hals_pullers <= 0) return fail(CMF_ERR_STATE, "hals_overlap needs the persistent H pipeline");
+        uint32_t mask_a[8] = {0}, mask_b[8] = {0};
+        for (int j = 0; j < h->n_cu && j < 256; ++j) (((j / 8) < 20) ? mask_a : mask_b)[j / 32] |= 1u << (j % 32);
+        hipStream_t sa = nullptr, sb = nullptr, keep = h->stream;
+        hipEvent_t fork = nullptr, ja = nullptr, jb = nullptr;
+        HIPCHK(hipExtStreamCreateWithCUMask(&sa, 8, mask_a));
+        HIPCHK(hipExtStreamCreateWithCUMask(&sb, 8, mask_b));
+        HIPCHK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ja, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&jb, hipEventDisableTiming));
+        const HalsRowParams q = hals_row_params(h, 0.0, 0.0);
+        const int rows_t = (d.Tl + 63) / 64, ra = std::min(rows_t, std::max(0, rows_t * pct / 100));
+        auto once = [&]() -> int {
+            if (ra == 0) {
+                CMFTRY(hals_persist_launch(h, q));
+                return launch_conv<4>(h, h->est, d.Tl, h->conv_gy);
+            }
+            HIPCHK(hipEventRecord(fork, keep));
+            HIPCHK(hipStreamWaitEvent(sb, fork, 0));
+            if (mode == 0) HIPCHK(hipStreamWaitEvent(sa, fork, 0));
+            h->stream = mode == 0 ? sa : keep;
+            int rc = hals_persist_launch(h, q);
+            h->stream = sb;
+            if (rc == CMF_OK) rc = launch_conv<4>(h, h->est, std::min(d.Tl, ra * 64), h->conv_gy);
+            h->stream = keep;
+            CMFTRY(rc);
+            if (mode == 0) { HIPCHK(hipEventRecord(ja, sa)); HIPCHK(hipStreamWaitEvent(keep, ja, 0)); }
+            HIPCHK(hipEventRecord(jb, sb));
+            HIPCHK(hipStreamWaitEvent(keep, jb, 0));
+            if (ra < rows_t) CMFTRY(launch_conv<4>(h, h->est, d.Tl - ra * 64, h->conv_gy));
+            return CMF_OK;
+        };
+        int rc = once();
+        if (rc == CMF_OK) {
+            HIPCHK(hipEventRecord(h->ev0, keep));
+            for (int r = 0; r < reps && rc == CMF_OK; ++r) rc = once();
+            HIPCHK(hipEventRecord(h->ev1, keep));
+            HIPCHK(hipEventSynchronize(h->ev1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+            *avg_ms = (double)ms / reps;
+            *flops = f1;
+        }
+        h->stream = keep;
+        (void)hipStreamSynchronize(sa);
+        (void)hipStreamSynchronize(sb);
+        (void)hipStreamDestroy(sa);
+        (void)hipStreamDestroy(sb);
+        (void)hipEventDestroy(fork);
+        (void)hipEventDestroy(ja);
+        (void)hipEventDestroy(jb);
+        if (h->hals_status) *h->hals_status = 0;
         set_est(h, 0);
         return rc;
     }

@@ -1005,7 +1005,7 @@ static int group_set_factors(cmf_group_s *g, const double *W, const double *H)
     for (size_t i = 0; i < g->sh.size(); ++i) {
         cmf_handle_s *s = g->sh[i];
         // one process: H is the global K x T matrix (column-major: a shard's columns are contiguous)
-        const double *Hs = g->one_process ? H + (size_t)g->t0[(size_t)g->rank[i]] * g->K : H;
+        const double *Hs = (H && g->one_process) ? H + (size_t)g->t0[(size_t)g->rank[i]] * g->K : H;
         CMFTRY(set_factors_impl(s, W, Hs));
     }
     g->num_ready = false;

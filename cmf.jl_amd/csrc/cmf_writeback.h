@@ -38,6 +38,7 @@ struct CmfWriteback {
     // copy as issued, and the helpers of the group's front handle -- posted before the phase is enqueued -- wait for the flag
     // before they wait for the event (an event that has not been recorded yet reads as complete)
     std::atomic<bool> h_issued{false}, cancel{false};
+    std::atomic<bool> poisoned{false};               // a drain ran out with a helper still inside a device wait: the helpers leave without widening, no further arms
     CmfWorkerPool pool;                              // the widening helpers (of a single handle, or of a group's front handle)
     int64_t armed_calls = 0, hooked_calls = 0;       // (cmf_get_counter: "writeback_calls", "writeback_overlapped")
 };

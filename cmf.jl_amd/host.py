@@ -184,31 +184,97 @@ class MultUpdate(AbstractCFUpdate):
         ss = ctypes.c_double()
         check(lib.cmf_get_data_sumsq(self._h, ctypes.byref(ss)))
         self.data_norm = math.sqrt(ss.value)  # mult.jl:13
+        # what the rule has read from the caller's arrays (the rule calls compare their arguments with it under sync_every_call)
+        self._seen = {"W": self._fingerprint(W), "H": self._fingerprint(H)}
 
     # ``rule.sync_every_call = True`` (CMFHip.jl's default): every update_feature_maps call also writes the new factors into
     # the W and H it is handed -- the reference's in-place semantics (mult.jl:37-38,51-52) for a caller that looks at its
     # arrays between calls.  The download rides underneath the call's own kernels (cmf_arm_writeback).
     sync_every_call = False
+    # The reference's rules READ their W and H arguments (mult.jl:23,42); here the working copies are device-resident.  Under
+    # sync_every_call the two are kept equivalent: every rule call fingerprints the arrays it is handed (cmf_fingerprint) and
+    # compares with what the rule last read from / wrote into the caller's arrays -- arrays with other contents (other arrays, or
+    # the same ones edited by the caller) are uploaded first (``reuploads`` counts).  "sample": one 64-byte line per 4 KB (bulk edits -- rescaling, a new
+    # initialisation, zeroed rows -- are seen, a single poked element may not be); "full": every element (+ ~1 ms per call at
+    # config 2); "none": the round-5 behaviour (the caller calls upload()).
+    verify_args = "sample"
+    # W reaches the caller's array when update_feature_maps returns (the write-back), not when update_motifs does: in between
+    # the caller's W is the one update_motifs started from.  A caller that edits W there gets a clear error -- unless
+    # strict_inplace is set: update_motifs then also downloads W (synchronously: + ~0.5 ms at config 2), so the caller sees the
+    # reference's state at every point and its edits are honoured like the reference's (tests/test_dropin_contract.py).
+    strict_inplace = False
+    reuploads = 0
+    _seen = None       # {"W": fingerprint, "H": fingerprint} of the caller's arrays as this rule last read or wrote them
+    _w_pending = False  # update_motifs has run and W has not been written back yet
 
-    def _arm_writeback(self, W, H):
-        if not self.sync_every_call or (W is None and H is None):
-            return
+    def _fingerprint(self, a):
+        fp = ctypes.c_uint64()
+        check(self._lib.cmf_fingerprint(ptr(a), a.size, 1 if self.verify_args == "full" else 64, ctypes.byref(fp)))
+        return fp.value  # (contents only: `fit` deep-copies the initial factors, alternating.jl:33-34 -- equal arrays at another address are the same factors)
+
+    def _check_arrays(self, W, H):
         for a, shape, nm in ((W, (self.K, self.N, self.L), "W"), (H, (self.K, self.T), "H")):
             if a is not None and not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.shape == shape
                                       and a.flags.f_contiguous and a.flags.writeable):
                 raise ValueError(f"sync_every_call: {nm} must be a writeable Float64 array of shape {shape} in Julia's (column-major) order")
+
+    def _sync_args(self, W, H):
+        """The rule reads its arguments (mult.jl:23,42): arrays this rule has not seen in this state are uploaded first."""
+        if not self.sync_every_call or self.verify_args == "none" or W is None or H is None:
+            return
+        self._check_arrays(W, H)
+        now = {"W": self._fingerprint(W), "H": self._fingerprint(H)}
+        if self._seen is None:  # (after upload(): the arrays a rule call is handed are taken as they are)
+            self._seen = {"W": None, "H": None}
+        dW, dH = now["W"] != self._seen["W"], now["H"] != self._seen["H"]
+        if dW and self._w_pending:
+            raise RuntimeError(
+                "W was modified (or another array was passed) between update_motifs and update_feature_maps: with sync_every_call the "
+                "caller's W holds the motifs update_motifs started from until update_feature_maps returns, so the edit was made to an "
+                "outdated W.  Set rule.strict_inplace = True (update_motifs then writes W back and edits are honoured like the "
+                "reference's, mult.jl:42), or call rule.upload(W, H) with the factors you mean (INTEGRATION.md section 3).")
+        if dW or dH:
+            check(self._lib.cmf_set_factors(self._h, ptr(W) if dW else None, ptr(H) if dH else None))
+            self.reuploads += 1
+        self._seen = now
+
+    def _after_motifs(self, W):
+        if not self.sync_every_call or self.verify_args == "none" or W is None:
+            return
+        if self.strict_inplace:
+            self._check_arrays(W, None)
+            check(self._lib.cmf_get_factors(self._h, ptr(W), None))
+            if self._seen is not None:
+                self._seen["W"] = self._fingerprint(W)
+        else:
+            self._w_pending = True
+
+    def _after_feature_maps(self, W, H):
+        if not self.sync_every_call or self.verify_args == "none" or W is None or H is None:
+            return
+        self._seen = {"W": self._fingerprint(W), "H": self._fingerprint(H)}  # (the write-back has just filled them)
+        self._w_pending = False
+
+    def _arm_writeback(self, W, H):
+        if not self.sync_every_call or (W is None and H is None):
+            return
+        self._check_arrays(W, H)
         check(self._lib.cmf_arm_writeback(self._h, None if W is None else ptr(W), None if H is None else ptr(H)))
 
     # -- the two rule methods -----------------------------------------------------------
     def update_motifs(self, data=None, W=None, H=None, l1W=0, l2W=0, **kwargs):
         """update_motifs!(rule, data, W, H; l1W=0, l2W=0): src/algs/mult.jl:23-39."""
+        self._sync_args(W, H)
         check(self._lib.cmf_update_motifs(self._h, float(l1W), float(l2W)))
+        self._after_motifs(W)
 
     def update_feature_maps(self, data=None, W=None, H=None, l1H=0, l2H=0, **kwargs):
         """update_feature_maps!(rule, data, W, H; l1H=0, l2H=0) -> loss: src/algs/mult.jl:42-58."""
         loss = ctypes.c_double()
+        self._sync_args(W, H)
         self._arm_writeback(W, H)
         check(self._lib.cmf_update_feature_maps(self._h, float(l1H), float(l2H), ctypes.byref(loss)))
+        self._after_feature_maps(W, H)
         return loss.value
 
     # -- helpers ------------------------------------------------------------------------
@@ -263,6 +329,7 @@ class MultUpdate(AbstractCFUpdate):
         W = farr(W, (self.K, self.N, self.L))
         H = farr(H, (self.K, self.T))
         check(self._lib.cmf_set_factors(self._h, ptr(W), ptr(H)))
+        self._seen, self._w_pending = None, False  # (the next rule call takes the arrays it is handed as they are)
 
     def download(self, W=None, H=None):
         """Write the resident factors into W, H (in place when given) and return them."""
@@ -336,13 +403,17 @@ class HALSUpdate(MultUpdate):
 
     def update_motifs(self, data=None, W=None, H=None, l1W=0, l2W=0, **kwargs):
         """update_motifs!(rule::HALSUpdate, data, W, H; l1W=0, l2W=0): src/algs/hals.jl:31-34."""
+        self._sync_args(W, H)
         check(self._lib.cmf_hals_update_motifs(self._h, float(l1W), float(l2W)))
+        self._after_motifs(W)
 
     def update_feature_maps(self, data=None, W=None, H=None, l1H=0, l2H=0, **kwargs):
         """update_feature_maps!(rule::HALSUpdate, data, W, H; l1H=0, l2H=0) -> loss: src/algs/hals.jl:37-42."""
         loss = ctypes.c_double()
+        self._sync_args(W, H)
         self._arm_writeback(W, H)
         check(self._lib.cmf_hals_update_feature_maps(self._h, float(l1H), float(l2H), ctypes.byref(loss)))
+        self._after_feature_maps(W, H)
         return loss.value
 
     def fit_native(self, *a, **kw):
@@ -461,7 +532,9 @@ class PGDUpdate(MultUpdate):
         penaltiesW=[SquarePenalty(1)]): src/algs/pgd.jl:158-177."""
         self._select_loss(loss_func)
         sq, ab = _penalty_weights([SquarePenalty(1)] if penaltiesW is None else penaltiesW)
+        self._sync_args(W, H)
         check(self._lib.cmf_pgd_update_motifs(self._h, sq, ab, _nonneg_flag(constrW)))
+        self._after_motifs(W)
 
     def update_feature_maps(self, data=None, W=None, H=None, loss_func=None, constrH=NonnegConstraint, penaltiesH=None, **kwargs):
         """update_feature_maps!(rule::PGDUpdate, ...; constrH=NonnegConstraint(), penaltiesH=[]) -> loss:
@@ -469,8 +542,10 @@ class PGDUpdate(MultUpdate):
         self._select_loss(loss_func)
         sq, ab = _penalty_weights([] if penaltiesH is None else penaltiesH)
         loss = ctypes.c_double()
+        self._sync_args(W, H)
         self._arm_writeback(W, H)
         check(self._lib.cmf_pgd_update_feature_maps(self._h, sq, ab, _nonneg_flag(constrH), ctypes.byref(loss)))
+        self._after_feature_maps(W, H)
         return loss.value
 
     @property

@@ -59,11 +59,28 @@ mutable struct HIPMultUpdate <: AbstractCFUpdate
     handle::Ptr{Cvoid}
     data_norm::Float64
     sync_every_call::Bool
+    # The reference's rules READ the W and H they are handed (mult.jl:23,42).  Under sync_every_call every rule call fingerprints
+    # its arguments (cmf_fingerprint) and compares with what this rule last read from / wrote into the caller's arrays; other
+    # arrays, or arrays the caller has edited, are uploaded first (`reuploads` counts them).
+    verify_args::Symbol      # :sample (one 64-byte line per 4 KB: bulk edits are seen, a single poked element may not be), :full, :none
+    strict_inplace::Bool     # update_motifs! also writes W back (synchronous download), so edits between the two calls are honoured
+    seen_W::UInt64           # fingerprints of the caller's arrays as this rule last read or wrote them (contents only: `fit`
+    seen_H::UInt64           # deep-copies the initial factors, alternating.jl:33-34 -- equal arrays elsewhere are the same factors)
+    w_pending::Bool          # update_motifs! has run and W has not been written back yet
+    reuploads::Int
+end
+
+function fingerprint(rule::HIPMultUpdate, a::Array{Float64})
+    fp = Ref{UInt64}(0)
+    check(ccall((:cmf_fingerprint, LIBCMF), Cint, (Ptr{Float64}, Int64, Int64, Ref{UInt64}),
+                a, length(a), rule.verify_args == :full ? 1 : 64, fp))
+    return fp[]
 end
 
 function HIPMultUpdate(data::Matrix{Float64}, W::Tensor{Float64}, H::Matrix{Float64};
                        device::Integer=parse(Int, get(ENV, "LOCAL_RANK", "0")), devices=nothing,
-                       transport::Integer=0, sync_every_call::Bool=true)
+                       transport::Integer=0, sync_every_call::Bool=true, verify_args::Symbol=:sample,
+                       strict_inplace::Bool=false)
     K, N, L = size(W)
     T = size(data, 2)
     size(data, 1) == N || throw(DimensionMismatch("data has $(size(data,1)) rows, W has N=$N"))
@@ -82,7 +99,9 @@ function HIPMultUpdate(data::Matrix{Float64}, W::Tensor{Float64}, H::Matrix{Floa
     check(ccall((:cmf_set_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), h[], W, H))
     ss = Ref{Float64}(0.0)
     check(ccall((:cmf_get_data_sumsq, LIBCMF), Cint, (Ptr{Cvoid}, Ref{Float64}), h[], ss))
-    rule = HIPMultUpdate(h[], sqrt(ss[]), sync_every_call)
+    rule = HIPMultUpdate(h[], sqrt(ss[]), sync_every_call, verify_args, strict_inplace, UInt64(0), UInt64(0), false, 0)
+    rule.seen_W = fingerprint(rule, W)   # what cmf_set_factors has just read
+    rule.seen_H = fingerprint(rule, H)
     finalizer(r -> (r.handle != C_NULL && ccall((:cmf_destroy, LIBCMF), Cint, (Ptr{Cvoid},), r.handle); r.handle = C_NULL), rule)
     return rule
 end
@@ -98,10 +117,59 @@ function arm_writeback(rule::HIPMultUpdate, W::Array{Float64}, H::Array{Float64}
     check(ccall((:cmf_arm_writeback, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.handle, W, H))
 end
 
+# The rule reads its arguments (mult.jl:23,42): arrays this rule has not seen in this state are uploaded first.
+# W reaches the caller's array when update_feature_maps! returns (the write-back), not when update_motifs! does -- in between
+# the caller's W is the one update_motifs! started from, so an edit made there is an edit of an outdated W: a clear error,
+# unless the rule was built with strict_inplace=true (update_motifs! then downloads W synchronously, + ~0.5 ms at config 2).
+# INTEGRATION.md section 3 states the contract; tests/test_dropin_contract.py pins it on the Python twin.
+function sync_args!(rule::HIPMultUpdate, W::Array{Float64}, H::Array{Float64})
+    (rule.sync_every_call && rule.verify_args != :none) || return
+    nowW, nowH = fingerprint(rule, W), fingerprint(rule, H)
+    dW, dH = nowW != rule.seen_W, nowH != rule.seen_H
+    if dW && rule.w_pending
+        error("W was modified (or another array was passed) between update_motifs! and update_feature_maps!: with " *
+              "sync_every_call the caller's W holds the motifs update_motifs! started from until update_feature_maps! " *
+              "returns.  Build the rule with strict_inplace=true, or call upload!(rule, W, H).")
+    end
+    if dW || dH
+        check(ccall((:cmf_set_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.handle,
+                    dW ? pointer(W) : Ptr{Float64}(C_NULL), dH ? pointer(H) : Ptr{Float64}(C_NULL)))
+        rule.reuploads += 1
+    end
+    rule.seen_W, rule.seen_H = nowW, nowH
+end
+
+function after_motifs!(rule::HIPMultUpdate, W::Array{Float64})
+    (rule.sync_every_call && rule.verify_args != :none) || return
+    if rule.strict_inplace
+        check(ccall((:cmf_get_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.handle, W, Ptr{Float64}(C_NULL)))
+        rule.seen_W = fingerprint(rule, W)
+    else
+        rule.w_pending = true
+    end
+end
+
+function after_feature_maps!(rule::HIPMultUpdate, W::Array{Float64}, H::Array{Float64})
+    (rule.sync_every_call && rule.verify_args != :none) || return
+    rule.seen_W, rule.seen_H = fingerprint(rule, W), fingerprint(rule, H)   # (the write-back has just filled them)
+    rule.w_pending = false
+end
+
+"upload!(rule, W, H): make W, H the resident factors (cmf_set_factors); the next rule call takes its arguments as they are."
+function upload!(rule::HIPMultUpdate, W::Array{Float64}, H::Array{Float64})
+    check(ccall((:cmf_set_factors, LIBCMF), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), rule.handle, W, H))
+    rule.seen_W, rule.seen_H = fingerprint(rule, W), fingerprint(rule, H)
+    rule.w_pending = false
+end
+
 # update_motifs!(rule, data, W, H; l1W=0, l2W=0)  -- src/algs/mult.jl:23-39, called at alternating.jl:52
 function update_motifs!(rule::HIPMultUpdate, data, W, H; l1W=0, l2W=0, kwargs...)
-    check(ccall((:cmf_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64), rule.handle,
-                reg(kwargs, :l1W, :l1_W, l1W), reg(kwargs, :l2W, :l2_W, l2W)))
+    GC.@preserve W H begin
+        sync_args!(rule, W, H)
+        check(ccall((:cmf_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64), rule.handle,
+                    reg(kwargs, :l1W, :l1_W, l1W), reg(kwargs, :l2W, :l2_W, l2W)))
+        after_motifs!(rule, W)
+    end
     return W
 end
 
@@ -109,9 +177,11 @@ end
 function update_feature_maps!(rule::HIPMultUpdate, data, W, H; l1H=0, l2H=0, kwargs...)
     loss = Ref{Float64}(0.0)
     GC.@preserve W H begin
+        sync_args!(rule, W, H)
         arm_writeback(rule, W, H)
         check(ccall((:cmf_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
                     rule.handle, reg(kwargs, :l1H, :l1_H, l1H), reg(kwargs, :l2H, :l2_H, l2H), loss))
+        after_feature_maps!(rule, W, H)
     end
     return loss[]
 end
@@ -129,8 +199,12 @@ HIPHALSUpdate(data, W, H; kwargs...) = HIPHALSUpdate(HIPMultUpdate(data, W, H; k
 
 # update_motifs!(rule::HALSUpdate, ...; l1W=0, l2W=0)  -- src/algs/hals.jl:31-34
 function update_motifs!(rule::HIPHALSUpdate, data, W, H; l1W=0, l2W=0, kwargs...)
-    check(ccall((:cmf_hals_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64), rule.inner.handle,
-                reg(kwargs, :l1W, :l1_W, l1W), reg(kwargs, :l2W, :l2_W, l2W)))
+    GC.@preserve W H begin
+        sync_args!(rule.inner, W, H)
+        check(ccall((:cmf_hals_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64), rule.inner.handle,
+                    reg(kwargs, :l1W, :l1_W, l1W), reg(kwargs, :l2W, :l2_W, l2W)))
+        after_motifs!(rule.inner, W)
+    end
     return W
 end
 
@@ -138,9 +212,11 @@ end
 function update_feature_maps!(rule::HIPHALSUpdate, data, W, H; l1H=0, l2H=0, kwargs...)
     loss = Ref{Float64}(0.0)
     GC.@preserve W H begin
+        sync_args!(rule.inner, W, H)
         arm_writeback(rule.inner, W, H)
         check(ccall((:cmf_hals_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Ref{Float64}),
                     rule.inner.handle, reg(kwargs, :l1H, :l1_H, l1H), reg(kwargs, :l2H, :l2_H, l2H), loss))
+        after_feature_maps!(rule.inner, W, H)
     end
     return loss[]
 end
@@ -202,8 +278,12 @@ function update_motifs!(rule::HIPPGDUpdate, data, W, H; loss_func=SquareLoss(), 
                         penaltiesW=[SquarePenalty(1)], kwargs...)
     select_loss!(rule, loss_func)
     sq, ab = penalty_weights(penaltiesW)
-    check(ccall((:cmf_pgd_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Cint),
-                rule.inner.handle, sq, ab, nonneg_flag(constrW)))
+    GC.@preserve W H begin
+        sync_args!(rule.inner, W, H)
+        check(ccall((:cmf_pgd_update_motifs, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Cint),
+                    rule.inner.handle, sq, ab, nonneg_flag(constrW)))
+        after_motifs!(rule.inner, W)
+    end
     return W
 end
 
@@ -214,9 +294,11 @@ function update_feature_maps!(rule::HIPPGDUpdate, data, W, H; loss_func=SquareLo
     sq, ab = penalty_weights(penaltiesH)
     loss = Ref{Float64}(0.0)
     GC.@preserve W H begin
+        sync_args!(rule.inner, W, H)
         arm_writeback(rule.inner, W, H)
         check(ccall((:cmf_pgd_update_feature_maps, LIBCMF), Cint, (Ptr{Cvoid}, Float64, Float64, Cint, Ref{Float64}),
                     rule.inner.handle, sq, ab, nonneg_flag(constrH), loss))
+        after_feature_maps!(rule.inner, W, H)
     end
     return loss[]
 end

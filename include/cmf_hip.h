@@ -44,8 +44,9 @@ typedef struct cmf_handle_s *cmf_handle;
 /* Version of this interface.  3 (round 3): the phase-split entries of version 1 (cmf_w_partial*, cmf_w_apply,
  * cmf_h_update, cmf_loss_partial*, cmf_halo_*, cmf_numden_ptr, cmf_set_data_norm) are gone -- a sharded iteration
  * runs behind the rule entries of a group handle (cmf_create_multi / cmf_comm_init_*); cmf_abi_version,
- * cmf_source_digest, cmf_synchronize, cmf_rccl_version, cmf_get_counter are new.  5 (round 5): cmf_arm_writeback. */
-#define CMF_ABI_VERSION 5
+ * cmf_source_digest, cmf_synchronize, cmf_rccl_version, cmf_get_counter are new.  5 (round 5): cmf_arm_writeback.  6 (round 6):
+ * cmf_fingerprint; cmf_set_factors takes one NULL factor. */
+#define CMF_ABI_VERSION 6
 int cmf_abi_version(void);
 
 /* Library / build identification: "cmf_hip gfx950 <version> abi=<n> src=<digest>". */
@@ -221,9 +222,18 @@ int cmf_get_data_sumsq(cmf_handle h, double *sumsq);
  * W (K x N x L) and H (K x T_local) in / out.  `fit` deep-copies the
  * initial factors and the rule mutates them in place
  * (src/algs/alternating.jl:33-34, src/algs/mult.jl:37-38,51-52): here the
- * working copies live on the device between calls. */
+ * working copies live on the device between calls.  cmf_set_factors: one of W, H may be NULL once both have been set -- that
+ * factor keeps its resident value (a caller that edited only H between two rule calls uploads only H).  cmf_get_factors: either
+ * may be NULL (not downloaded). */
 int cmf_set_factors(cmf_handle h, const double *W, const double *H);
 int cmf_get_factors(cmf_handle h, double *W, double *H);
+/* The reference's rules READ the W and H they are handed (src/algs/mult.jl:23,42; hals.jl:31,37; pgd.jl:158,180); here the working
+ * copies are device-resident, so a binding that wants the reference's semantics must notice when the caller hands it other arrays,
+ * or arrays it has edited, and upload them first.  cmf_fingerprint is the cheap test the bindings use (CMFHip.jl `sync_args!`,
+ * host.py `_sync_args`): a 64-bit fingerprint of a Float64 array of n elements over every line_stride-th 64-byte line (8 elements),
+ * the last line and n itself (line_stride 1 = every element; the bindings' default 64 reads one line per 4 KB: 360 KB of the 23 MB
+ * of factors at config 2).  Host arithmetic only (no handle, no device); equal arrays give equal fingerprints on every machine. */
+int cmf_fingerprint(const double *a, int64_t n, int64_t line_stride, uint64_t *fingerprint);
 
 /* In-place semantics for a caller that drives the rule call by call (the reference's own `fit`, src/algs/alternating.jl:51-54,
  * hands the SAME W and H arrays to every call and the rules mutate them: src/algs/mult.jl:37-38,51-52; hals.jl:110,153;
@@ -234,7 +244,10 @@ int cmf_get_factors(cmf_handle h, double *W, double *H);
  * contraction, H underneath the loss conv, and helper threads widen to Float64 while the caller waits for the loss scalar.
  * Either pointer may be NULL (that factor is not written); both NULL disarms.  EXCEPTION to "host pointers are borrowed for
  * the duration of the call only": W and H are borrowed from this call until the next *_update_feature_maps call on the handle
- * returns, and are written only inside that call.  One arm serves one call.  On a group handle (MU rule in either formulation, PGD rule)
+ * returns, and are written only inside that call.  One arm serves one call; cmf_iterate and cmf_fit (which run H phases of their own, not the
+ * caller's rule calls) drop an arm that is still standing at their entry and write nothing.  If a helper thread ever fails to return within
+ * CMF_WAIT_TIMEOUT_S (a hung device), the call fails and the handle refuses further arms (CMF_ERR_STATE); cmf_get_factors still works.
+ * On a group handle (MU rule in either formulation, PGD rule)
  * every shard copies its own column block of H on its own device the same way (shard 0 also W) and the handle's helpers widen
  * block after block.
  * CMF_WRITEBACK_THREADS (default 4): the widening helpers.

@@ -92,4 +92,4 @@ def test_c_driver_other_rules(tmp_path, fixture, ndev, rule):
     np.testing.assert_array_equal(outs[0][1], outs[1][1])  # the two passes repeat the same arithmetic
     if ndev:
         assert f"nranks={ndev}" in log
-    assert "abi=5" in log and "src=" in log
+    assert "abi=6" in log and "src=" in log

@@ -55,7 +55,7 @@ def test_library_carries_the_digest_of_the_tree():
     want = build.source_digest()
     assert lib.cmf_source_digest().decode() == want and build.embedded_digest() == want
     assert f"src={want}" in lib.cmf_version().decode() and f"abi={lib.cmf_abi_version()}" in lib.cmf_version().decode()
-    assert lib.cmf_abi_version() == 5
+    assert lib.cmf_abi_version() == 6
     assert not build.is_stale()
     v = ctypes.c_int64()
     assert lib.cmf_get_counter(None, b"x", ctypes.byref(v)) == 1  # CMF_ERR_ARG: needs a handle

@@ -29,6 +29,7 @@ JL2C = {
     "Ref{Cint}": {"int *"},
     "Ptr{Int64}": {"int64_t *"},
     "Ref{Int64}": {"int64_t *"},
+    "Ref{UInt64}": {"uint64_t *"},
     "Ptr{UInt8}": {"char *", "void *", "const void *", "const char *"},
 }
 
