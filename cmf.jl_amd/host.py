@@ -150,9 +150,15 @@ class MultUpdate(AbstractCFUpdate):
     one device several times puts that many shards on it (loopback transport; tests).
     """
 
-    def __init__(self, data, W, H, device=None, devices=None, transport=_lib.CMF_COMM_AUTO):
+    def __init__(self, data, W, H, device=None, devices=None, transport=_lib.CMF_COMM_AUTO, sync_every_call=None, verify_args=None,
+                 strict_inplace=None):
         lib = _lib.load()
         self._lib = lib
+        for name, val in (("sync_every_call", sync_every_call), ("verify_args", verify_args), ("strict_inplace", strict_inplace)):
+            if val is not None:  # (CMFHip.jl's constructor keywords; the class attributes below are the defaults)
+                setattr(self, name, val)
+        if self.verify_args not in ("sample", "full", "none"):
+            raise ValueError('verify_args must be "sample", "full" or "none"')
         self._h = ctypes.c_void_p()
         data = farr(data)
         if data.ndim != 2:
@@ -210,7 +216,7 @@ class MultUpdate(AbstractCFUpdate):
     def _fingerprint(self, a):
         fp = ctypes.c_uint64()
         check(self._lib.cmf_fingerprint(ptr(a), a.size, 1 if self.verify_args == "full" else 64, ctypes.byref(fp)))
-        return fp.value  # (contents only: `fit` deep-copies the initial factors, alternating.jl:33-34 -- equal arrays at another address are the same factors)
+        return (self.verify_args, fp.value)  # (contents only, tagged with the form that was taken -- a rule switched to another form uploads once: `fit` deep-copies the initial factors, alternating.jl:33-34 -- equal arrays at another address are the same factors)
 
     def _check_arrays(self, W, H):
         for a, shape, nm in ((W, (self.K, self.N, self.L), "W"), (H, (self.K, self.T), "H")):
@@ -393,8 +399,8 @@ class HALSUpdate(MultUpdate):
     ``+ l2`` regularisation and the incremental-residual loss are the reference's.
     """
 
-    def __init__(self, data, W, H, device=None):
-        super().__init__(data, W, H, device=device)
+    def __init__(self, data, W, H, device=None, **kw):
+        super().__init__(data, W, H, device=device, **kw)
         try:  # the rule constructor (hals.jl:18-28): scratch + the shape limits of the on-chip sweeps, reported here
             self.set_option("hals_prepare", 1)
         except Exception:
@@ -496,8 +502,8 @@ class PGDUpdate(MultUpdate):
     GPUs like MultUpdate does (one all-reduce of the partial gradW per iteration; the long recordings of
     notebooks/test_mouse.ipynb are fitted with this rule)."""
 
-    def __init__(self, data, W, H, device=None, devices=None, transport=_lib.CMF_COMM_AUTO):
-        super().__init__(data, W, H, device=device, devices=devices, transport=transport)
+    def __init__(self, data, W, H, device=None, devices=None, transport=_lib.CMF_COMM_AUTO, **kw):
+        super().__init__(data, W, H, device=device, devices=devices, transport=transport, **kw)
         check(self._lib.cmf_pgd_reset(self._h))
         self._mask_key = None
 

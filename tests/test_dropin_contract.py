@@ -62,11 +62,8 @@ def problem(oracle, N=70, T=400, K=32, L=8, seed=5):
     return data, W0, H0
 
 
-def make(cmf, oracle, data, W0, H0, **attrs):
-    rule = cmf.MultUpdate(data, W0, H0)
-    rule.sync_every_call = True
-    for k, v in attrs.items():
-        setattr(rule, k, v)
+def make(cmf, oracle, data, W0, H0, **kw):
+    rule = cmf.MultUpdate(data, W0, H0, sync_every_call=True, **kw)  # (CMFHip.jl's constructor keywords)
     W, H = np.array(W0, order="F", copy=True), np.array(H0, order="F", copy=True)
     Wo, Ho = W0.copy(), H0.copy()
     return rule, W, H, oracle.MultUpdate(data, Wo, Ho), Wo, Ho
