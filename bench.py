@@ -147,7 +147,7 @@ def cpu_baseline(data, W0, H0, budget_s):
 def hals_roofline(T, K, L, spans, ms_per_step):
     """The dominant part of a HALS iteration is the K*T strictly ordered H entry updates (hals.jl:121-154), run as a
     software pipeline over the rows (one persistent launch, hals_h_persist_kernel: a sweeper wave per row, puller
-    workgroups applying the cross-row terms, flags in memory between them; CMF_HALS_PERSIST=0 selects the older
+    workgroups applying the cross-row terms, flags in memory between them; option "hals_persist" = 0 selects the older
     one-launch-per-stage form).  Its bound is dependency latency, not MFMA or HBM: entry (k, t) needs (k, t-1) and the
     push of (k-1, t+L-1), so the critical path is T + (K-1)(L-1) dependent steps.  A step of the sweep is 9 single-wave
     instructions whose chain is one FMA and one MAX; in isolation it issues in 43 cycles (tools/valu_latency.hip,
@@ -160,8 +160,7 @@ def hals_roofline(T, K, L, spans, ms_per_step):
     peak_steps = CLK / STEP_CYCLES
     ach_steps = crit_steps / (pipe_ms * 1e-3) if pipe_ms else 0.0
     return {"bound": "dependency-latency",
-            "kernel": ("hals_h_stage_kernel" if os.environ.get("CMF_HALS_PERSIST") == "0" else "hals_h_persist_kernel")
-                      + " row pipeline (K*T ordered entry updates of H, hals.jl:121-154)",
+            "kernel": "hals_h_persist_kernel row pipeline (K*T ordered entry updates of H, hals.jl:121-154)",
             "achieved": ach_steps, "peak": peak_steps, "unit": "critical-path steps/s", "frac": ach_steps / peak_steps,
             "traffic": None, "critical_path_steps": crit_steps, "step_cycles_model": STEP_CYCLES,
             "pipeline_span_ms": pipe_ms, "pipeline_spans_timed": n_pipe, "pipeline_floor_ms": 1e3 * crit_steps / peak_steps,

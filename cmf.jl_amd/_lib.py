@@ -29,7 +29,7 @@ SYMBOLS = [
     "cmf_create", "cmf_create_shard", "cmf_create_multi", "cmf_destroy", "cmf_synchronize", "cmf_set_stream",
     "cmf_rccl_version", "cmf_get_counter",
     "cmf_comm_unique_id", "cmf_comm_init_rccl", "cmf_comm_init_overlap", "cmf_comm_init_callbacks", "cmf_comm_info", "cmf_shard_bounds",
-    "cmf_set_option", "cmf_get_data_sumsq",
+    "cmf_set_option", "cmf_option_names", "cmf_get_data_sumsq",
     "cmf_set_factors", "cmf_get_factors", "cmf_arm_writeback", "cmf_fingerprint",
     "cmf_update_motifs", "cmf_update_feature_maps", "cmf_compute_loss", "cmf_iterate", "cmf_fit", "cmf_converged",
     "cmf_hals_update_motifs", "cmf_hals_update_feature_maps",
@@ -101,6 +101,7 @@ def load():
     sig("cmf_destroy", [vp])
     sig("cmf_set_stream", [vp, vp])
     sig("cmf_set_option", [vp, ctypes.c_char_p, cint])
+    sig("cmf_option_names", [ctypes.c_char_p, i64])
     sig("cmf_get_data_sumsq", [vp, pd])
     sig("cmf_set_factors", [vp, pd, pd])
     sig("cmf_get_factors", [vp, pd, pd])

@@ -35,6 +35,21 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// The library's test hooks (include/cmf_hip.h lists them): integer variables of the environment that count ONLY together with
+// CMF_TEST_HOOKS=1, so that a stray variable in a production environment changes nothing.  Read by the calling thread at public
+// entries only (getenv is not safe against a concurrent setenv of the host program).
+static bool test_hooks_on()
+{
+    const char *hooks = getenv("CMF_TEST_HOOKS");
+    return hooks && atoi(hooks) == 1;
+}
+static long long test_hook(const char *name, long long dflt)
+{
+    if (!test_hooks_on()) return dflt;
+    const char *e = getenv(name);
+    return e ? atoll(e) : dflt;
+}
+
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -179,6 +194,10 @@ struct cmf_handle_s {
                                             // one conv launch fewer, H within the residual form's bars), 1 = G of the W phase too (~20x the rounding
                                             // error in W: opt-in), 0 = both contracted from the stored residual
     bool hals_w_general = false, hals_h_general = false; // shapes beyond the on-chip sweeps' limits: the general sweep kernels
+    // options "hals_persist" (1 = the persistent pipeline where it fits, 0 = the stage pipeline, n > 1 = at most n pullers per row),
+    // "hals_general" (bit 0 / 1: the general W / H sweeps at any shape), "hals_seg" / "hals_lag" (the stage pipeline's segment length
+    // and schedule), "hals_debug" (CMF_TEST_HOOKS=1 only: 3 = the pullers leave at once, so that every bounded wait must run out)
+    int hals_opt_persist = 1, hals_opt_general = 0, hals_opt_seg = 384, hals_opt_lag = 2, hals_debug = 0;
     int hals_pullers = 0;                   // persistent H pipeline: puller workgroups per row (0 = stage pipeline)
     int *hals_flags = nullptr;              // its progress flags (device)
     int *hals_status = nullptr;             // pinned host word: 1 = a wait of the persistent pipeline ran out
@@ -212,7 +231,6 @@ struct cmf_handle_s {
                             // 4 sign(tensor_conv(W,H) - data), 5 mask .* sign(...)  (the AbsoluteLoss gradient)
     void *arena = nullptr;  // the small buffers of the handle as ONE device allocation (cmf_create): 21 hipFree calls cost 1.3 ms, one 0.16
     size_t arena_bytes = 0;
-    bool own_stream_masked = false; // (test hook: a CU-masked stream is not pooled)
     bool streams_may_hang = false;  // set on the shards of a FAILED group: their streams are not waited for when they are given back
     int64_t est_gen = 0;    // counts the assignments of est_kind (set_est): whatever changes H, W or est passes through one
     int64_t spec_gen = -1;  // est_gen for which the C2 contraction of the NEXT update_motifs! has already been enqueued (w_speculate); -1: none
@@ -232,7 +250,9 @@ struct cmf_handle_s {
     CmfWriteback *wb = nullptr;           // cmf_arm_writeback: the factors written into the caller's arrays behind a rule call
 };
 
+#define HALS_PMAX 4 // puller workgroups per row of the persistent H pipeline (4 -> 7 measured the same span: profiles/r04_hals_pullers_sweep.txt)
 static int hals_ensure(cmf_handle_s *h);
+static void hals_plan(cmf_handle_s *h);
 static void wb_free(cmf_handle_s *h);
 static void wb_disarm(cmf_handle_s *h);
 static inline void set_est(cmf_handle_s *h, int kind) // every change of what est holds (and with it: of H, W) passes through here
@@ -346,8 +366,7 @@ static void plan(cmf_handle_s *h, int n_cu)
         const int64_t units_all = (d.Tl + unit - 1) / unit, units_whole = d.Tl / unit;
         int64_t per = (units_all + nch - 1) / nch;
         *main_rows = d.Tl;
-        static const bool exact = !(getenv("CMF_HXT_EXACT") && atoi(getenv("CMF_HXT_EXACT")) == 0); // measurement knob
-        if (exact && units_whole > 0 && (units_whole + nch - 1) / nch < per) {
+        if (units_whole > 0 && (units_whole + nch - 1) / nch < per) {
             per = (units_whole + nch - 1) / nch;
             *main_rows = (int)(units_whole * unit);
         }
@@ -407,9 +426,8 @@ static void plan(cmf_handle_s *h, int n_cu)
         h->sk_MBW = (mblocks + h->sk_MG - 1) / h->sk_MG;      // ... as even as possible: the least padding
         h->sk_JP = 32 * h->sk_MBW * h->sk_MG;
         // a last block of at most SK_RVT live rows goes to the VALU (one row group of 2-4 blocks: the kernel variants that exist)
-        static const bool rv_on = !(getenv("CMF_SK_VALU_ROWS") && atoi(getenv("CMF_SK_VALU_ROWS")) == 0); // measurement knob
         h->sk_RV = 0;
-        if (rv_on && h->sk_MG == 1 && h->sk_MBW >= 2 && h->sk_MBW <= 4 && h->sk_J % 32 >= 1 && h->sk_J % 32 <= SK_RVT) {
+        if (h->sk_MG == 1 && h->sk_MBW >= 2 && h->sk_MBW <= 4 && h->sk_J % 32 >= 1 && h->sk_J % 32 <= SK_RVT) {
             h->sk_RV = h->sk_J % 32;
             h->sk_MBW -= 1; // (sk_JP keeps the padded row count: the slabs' rows)
         }
@@ -443,7 +461,7 @@ static void plan(cmf_handle_s *h, int n_cu)
         h->sk3_JP = h->sk3_GR * h->sk3_MG;
         // (as in C2: a last block of at most SK_RVT live rows goes to the VALU; their Wj columns lie in the fold tile's LDS during the main loop)
         h->sk3_RV = 0;
-        if (rv_on && h->sk3_MG == 1 && h->sk3_MBW >= 2 && h->sk3_MBW <= 4 && (h->sk3_Kg * d.L) % 32 >= 1 && (h->sk3_Kg * d.L) % 32 <= SK_RVT &&
+        if (h->sk3_MG == 1 && h->sk3_MBW >= 2 && h->sk3_MBW <= 4 && (h->sk3_Kg * d.L) % 32 >= 1 && (h->sk3_Kg * d.L) % 32 <= SK_RVT &&
             (8 * ((rup(d.N, 2) + 7) / 8) + 2) * 4 <= 32 * SK_TILE_STRIDE) {
             h->sk3_RV = (h->sk3_Kg * d.L) % 32;
             h->sk3_MBW -= 1;
@@ -454,8 +472,7 @@ static void plan(cmf_handle_s *h, int n_cu)
         {
             const int64_t waves = (int64_t)(h->sk_TG / 32) * h->sk3_MG * 2;
             const int rounds = (int)((rup(d.N, 2) + 7) / 8);
-            static const int ns_max = getenv("CMF_SK_C3_NSPLIT") ? std::max(1, std::min(8, atoi(getenv("CMF_SK_C3_NSPLIT")))) : 8; // measurement knob
-            int ns = (int)std::min<int64_t>({(int64_t)ns_max, (8LL * n_cu + waves - 1) / waves, (int64_t)std::max(1, rounds / 8)});
+            int ns = (int)std::min<int64_t>({(int64_t)8, (8LL * n_cu + waves - 1) / waves, (int64_t)std::max(1, rounds / 8)});
             ns = std::max(ns, 1);
             h->sk3_RPS = (rounds + ns - 1) / ns;
             h->sk3_NS = (rounds + h->sk3_RPS - 1) / h->sk3_RPS; // (no empty piece)
@@ -505,8 +522,7 @@ static void destroy_impl(cmf_handle_s *h)
     if (h->ev_c1) (void)hipEventDestroy(h->ev_c1);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
     stream_release(h->device, h->own_comm_stream, !h->streams_may_hang);
-    if (h->own_stream_masked) (void)hipStreamDestroy(h->own_stream);
-    else stream_release(h->device, h->own_stream, !h->streams_may_hang);
+    stream_release(h->device, h->own_stream, !h->streams_may_hang);
     delete h;
 }
 
@@ -580,24 +596,6 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
                                          "kernels' 32-bit buffer offsets address");
     }
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    // Measurement hook (tools/cu_mask_experiment.py; honoured only with CMF_TEST_HOOKS=1): CMF_EXP_CU_MASK="part/parts/x|c" runs
-    // this handle on a CU-masked stream -- part `part` of `parts` equal parts of the chip, cut by whole XCDs (x: CU bit j
-    // belongs to XCD j % 8) or inside every XCD (c) -- and plans its statically dealt kernels for that many CUs.
-    uint32_t cu_mask[8] = {0};
-    int cu_part = -1, cu_parts = 0;
-    char cu_mode = 'x';
-    if (const char *e = getenv("CMF_EXP_CU_MASK")) {
-        if (getenv("CMF_TEST_HOOKS") && atoi(getenv("CMF_TEST_HOOKS")) == 1 && sscanf(e, "%d/%d/%c", &cu_part, &cu_parts, &cu_mode) >= 2 &&
-            cu_parts >= 2 && cu_parts <= 8 && cu_part >= 0 && cu_part < cu_parts && h->n_cu % (8 * cu_parts) == 0) {
-            const int per_xcd = h->n_cu / 8;
-            for (int j = 0; j < h->n_cu; ++j) {
-                const int xcd = j % 8, idx = j / 8;
-                const bool mine = cu_mode == 'c' ? (idx * cu_parts / per_xcd == cu_part) : (xcd * cu_parts / 8 == cu_part);
-                if (mine) cu_mask[j / 32] |= 1u << (j % 32);
-            }
-            h->n_cu /= cu_parts;
-        } else cu_part = -1;
-    }
     plan(h, h->n_cu);
     // the C2 kernel addresses a time chunk of X with 32-bit byte offsets: keep chunks below 2 GiB
     while ((double)(h->hxt_chunk_len + 16 * h->hxt_LP + 8) * d.Np * 4.0 >= 2147483648.0) {
@@ -614,8 +612,7 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     auto bail = [&](int rc) { destroy_impl(h); return rc; };
 #define TRYB(expr) do { int rc__ = (expr); if (rc__ != CMF_OK) return bail(rc__); } while (0)
 #define HIPB(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(fail(CMF_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__))); } while (0)
-    if (cu_part >= 0) { HIPB(hipExtStreamCreateWithCUMask(&h->own_stream, 8, cu_mask)); h->own_stream_masked = true; }
-    else HIPB(stream_acquire(h->device, &h->own_stream));
+    HIPB(stream_acquire(h->device, &h->own_stream));
     h->stream = h->own_stream;
     HIPB(hipEventCreate(&h->ev0));
     HIPB(hipEventCreate(&h->ev1));
@@ -644,8 +641,7 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
     if (h->small_k_ok) {
         want(&h->sk_slabs, (size_t)h->sk_ngroups * 2 * h->sk_JP * d.Np);
         want(&h->sk_Wj, (size_t)d.Np * h->sk3_JP);
-        static const bool off = getenv("CMF_SMALL_K") && atoi(getenv("CMF_SMALL_K")) == 0; // measurement knob: the general kernels for every K
-        h->small_k = !off;
+        h->small_k = true; // (option "small_k": 0 = the general kernels for every K)
         h->sk_tc = h->small_k && h->sk_tc_ok;
         if (h->sk_tc) h->tc_S = h->tc_S1 = 2 * h->sk3_NS;
     }
@@ -732,8 +728,7 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = data ? data : h->X; p.partial = h->partial;
     p.mask = (MODE == 7) ? h->MT : h->M;
     p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = T_store;
-    static const bool dead_skip = !(getenv("CMF_CONV_DEADSKIP") && atoi(getenv("CMF_CONV_DEADSKIP")) == 0); // measurement knob
-    p.N = dead_skip ? d.N : d.Np;
+    p.N = d.N; // (n blocks that are all padding are skipped)
     p.loss_abs = (MODE >= 4) ? h->pgd_loss_abs_now : 0;
     dim3 grid(h->conv_gx, gy), block(256);
     // measured at config 2 (tools/time_kernels.py): the one-wave kernel wins for the epilogues that read data
@@ -750,9 +745,7 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     // dynamic dispatch the waves of a SIMD are out of step and the launch ends in a ragged drain one tile long; small
     // pieces at the end of the queue fill it (measured at config 2, 8.1 rounds: -1.5 % in every mode).
     // Below 4 rounds the extra cut costs more than it fills (T/4 and T/8 shards: +1-4 %).
-    static const int split_extra_env = getenv("CMF_CONV_SPLIT_EXTRA") ? atoi(getenv("CMF_CONV_SPLIT_EXTRA")) : -1;
-    static const int split_min_rounds = getenv("CMF_CONV_SPLIT_MINR") ? atoi(getenv("CMF_CONV_SPLIT_MINR")) : 4;
-    const int split_extra = split_extra_env >= 0 ? split_extra_env : 3 * h->n_cu;
+    const int split_min_rounds = 4, split_extra = 3 * h->n_cu; // (profiles/r02*_conv_split*: the sweep these came from)
     int cut = 0;
     if (h->conv_split) {
         if (rem3 > 0 && rem3 <= 3 * h->n_cu) cut = rem3;
@@ -764,11 +757,10 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
             const int nkp = (d.K + 1) / 2;
             // the tiles beyond whole rounds of one tile per SIMD slot-triple (3 per SIMD) go out as quarter pieces at the end of the
             // grid, when they are few (at most one tile per SIMD: otherwise whole tiles balance well enough)
-            static const int sk_split = getenv("CMF_SMALL_K_CONV_SPLIT") ? atoi(getenv("CMF_SMALL_K_CONV_SPLIT")) : 1; // measurement knob
             const int per_round = 4 * h->n_cu;                          // one tile per SIMD
             const int remq = tiles3 % per_round;
-            int cutq = (sk_split && h->conv_split && tiles3 >= per_round && remq > 0 && remq <= per_round / 4) ? remq : 0;
-            if (sk_split && h->conv_split && tiles3 < per_round) cutq = tiles3; // fewer tiles than SIMDs (short recordings): quarter pieces only (configs[0]: 9-12 -> 5-8 us)
+            int cutq = (h->conv_split && tiles3 >= per_round && remq > 0 && remq <= per_round / 4) ? remq : 0;
+            if (h->conv_split && tiles3 < per_round) cutq = tiles3; // fewer tiles than SIMDs (short recordings): quarter pieces only (configs[0]: 9-12 -> 5-8 us)
             const int n_full = tiles3 - cutq;
             grid = dim3(n_full + 4 * cutq);
             // (loss + store on a short launch: the data tile is requested before the MFMA loop, conv3_tile)
@@ -1102,9 +1094,8 @@ static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel
 // kernel: a rule call on a small problem is a few launches long, and the reference's loop makes one such read per iteration).
 static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = true, double *host_out = nullptr, bool speculate = false)
 {
-    static const bool poll = !(getenv("CMF_LOSS_POLL") && atoi(getenv("CMF_LOSS_POLL")) == 0); // measurement knob: 0 = copy + hipStreamSynchronize
     volatile unsigned long long *word = nullptr;
-    if (readback && poll && !host_out) {
+    if (readback && !host_out) {
         CMFTRY(ensure_ring(h));
         host_out = h->h_ring + 2;
         word = reinterpret_cast<volatile unsigned long long *>(host_out);
@@ -1177,9 +1168,8 @@ static int get_factors_impl(cmf_handle_s *h, double *W, double *H)
 // The sum of n per-tile partials -> d_scalar[slot], and to the calling thread when v is given (polled pinned word, like loss_partial_impl).
 static int reduce_partials(cmf_handle_s *h, const double *partial, int n, int slot, double *v)
 {
-    static const bool poll = !(getenv("CMF_LOSS_POLL") && atoi(getenv("CMF_LOSS_POLL")) == 0);
     double *host_out = nullptr;
-    if (v && poll) {
+    if (v) {
         CMFTRY(ensure_ring(h));
         host_out = h->h_ring + 2;
         *reinterpret_cast<volatile unsigned long long *>(host_out) = CMF_SENTINEL64;
@@ -1327,7 +1317,7 @@ static void wb_start_pool(int device, CmfWriteback *wb) // the host side: the wi
     if (!wb->pool.empty()) return;
     wb->pool.on_start = [device](size_t) { (void)hipSetDevice(device); };
     wb->pool.last_error = [] { return g_err; };
-    static const int nthr_env = getenv("CMF_WRITEBACK_THREADS") ? atoi(getenv("CMF_WRITEBACK_THREADS")) : 0;
+    static const int nthr_env = [] { const char *e = getenv("CMF_WRITEBACK_THREADS"); return e ? atoi(e) : 0; }();
     cmf_pool_start(wb->pool, (size_t)std::min(16, std::max(1, nthr_env > 0 ? nthr_env : 4)));
 }
 
@@ -1568,10 +1558,7 @@ static int64_t max_columns_per_handle(int64_t K)
 {
     // tests take the long-recording paths at small sizes; the knob is honoured only together with CMF_TEST_HOOKS=1, so that
     // a stray variable in a production environment cannot move the cut point
-    if (const char *hooks = getenv("CMF_TEST_HOOKS"))
-        if (atoi(hooks) == 1)
-            if (const char *e = getenv("CMF_MAX_COLUMNS"))
-                if (atoll(e) > 0) return atoll(e);
+    if (const long long forced = test_hook("CMF_MAX_COLUMNS", 0); forced > 0) return forced;
     const int64_t K32 = 32 * ((K + 31) / 32);
     const int64_t by_est = ((int64_t)1 << 31) / (64 * 4), by_h = ((int64_t)1 << 31) / (K32 * 4);
     return std::min(by_est, by_h) - 4096; // (left lag halo and tile padding)
@@ -1679,6 +1666,20 @@ int cmf_set_stream(cmf_handle h, void *hip_stream)
     return CMF_OK;
 }
 
+// every name cmf_set_option knows (cmf_option_names; tests/test_library_abi.py walks the table)
+static const char *const kOptionNames[] = {"reuse_est", "speculate", "gram", "conv_kernel", "conv_split", "small_k", "hals_prepare", "hals_gram",
+                                           "hals_persist", "hals_general", "hals_seg", "hals_lag", "hals_debug", "profile", "profile_mask",
+                                           "allreduce_overlap", "enqueue_threads"};
+int cmf_option_names(char *buf, int64_t len)
+{
+    if (!buf || len < 1) return fail(CMF_ERR_ARG, "bad buffer");
+    std::string all;
+    for (const char *n : kOptionNames) all += (all.empty() ? "" : ",") + std::string(n);
+    if ((int64_t)all.size() + 1 > len) return fail(CMF_ERR_ARG, "buffer too small: %zu bytes needed", all.size() + 1);
+    std::memcpy(buf, all.c_str(), all.size() + 1);
+    return CMF_OK;
+}
+
 int cmf_set_option(cmf_handle h, const char *name, int value)
 {
     if (!h || !name) return fail(CMF_ERR_ARG, "NULL argument");
@@ -1733,7 +1734,7 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         g->num_ready = false;
         return CMF_OK;
     }
-    if (std::strcmp(name, "allreduce_overlap") == 0) return CMF_OK; // single GPU: nothing to overlap
+    if (std::strcmp(name, "allreduce_overlap") == 0 || std::strcmp(name, "enqueue_threads") == 0) return CMF_OK; // single GPU: nothing to overlap, nobody else to enqueue
     if (std::strcmp(name, "gram") == 0) {
         if (value < 0 || value > 2) return fail(CMF_ERR_ARG, "gram must be 0, 1 or 2");
         if (value && h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "the Gram form is not available on sharded handles");
@@ -1750,6 +1751,20 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
     if (std::strcmp(name, "hals_gram") == 0) { // HALS projections as differences of the MU quantities: 2 (default) = H phase, 1 = both phases, 0 = neither
         h->hals_gram = (value == 1 || value == 2) ? value : 0; // 2 = the H phase only
         set_est(h, 0);
+        return CMF_OK;
+    }
+    if (std::strcmp(name, "hals_persist") == 0 || std::strcmp(name, "hals_general") == 0 || std::strcmp(name, "hals_seg") == 0 ||
+        std::strcmp(name, "hals_lag") == 0 || std::strcmp(name, "hals_debug") == 0) {
+        if (value < 0) return fail(CMF_ERR_ARG, "%s must be >= 0", name);
+        if (name[5] == 'd') { // "hals_debug": results are wrong by design -- tests of the bounded waits only
+            if (value && !test_hooks_on()) return fail(CMF_ERR_STATE, "hals_debug needs CMF_TEST_HOOKS=1");
+            h->hals_debug = value;
+            return CMF_OK;
+        }
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        (name[5] == 'p' ? h->hals_opt_persist : name[5] == 'g' ? h->hals_opt_general : name[5] == 's' ? h->hals_opt_seg : h->hals_opt_lag) = value;
+        if (h->hals_ready) hals_plan(h);
         return CMF_OK;
     }
     if (std::strcmp(name, "hals_prepare") == 0) { // allocate the HALS scratch and check its shape limits now (rule construction)
@@ -1855,8 +1870,7 @@ static int update_feature_maps_body(cmf_handle h, double l1H, double l2H, double
     CMFTRY(check_ready(h, true));
     if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator first (cmf_comm_init_rccl / cmf_comm_init_callbacks), or build the group with cmf_create_multi");
     if (h->gram) return gram_h_impl(h, l1H, l2H, loss);
-    static const bool spec_env = !(getenv("CMF_SPECULATE_W") && atoi(getenv("CMF_SPECULATE_W")) == 0); // measurement knob
-    const bool speculate = spec_env && h->speculate && h->last_rule_call == 1; // the caller alternates: update_motifs! comes next
+    const bool speculate = h->speculate && h->last_rule_call == 1; // the caller alternates: update_motifs! comes next
     h->last_rule_call = 2;
     CMFTRY(h_update_impl(h, l1H, l2H));
     double ss = 0.0;
@@ -2235,11 +2249,6 @@ int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transpor
     else if (transport == CMF_COMM_LOOPBACK || transport == CMF_COMM_LOOPBACK_STREAMS) tr = CMF_TR_LOOPBACK;
     else if (transport == CMF_COMM_PEER) tr = CMF_TR_PEER;
     else return fail(CMF_ERR_ARG, "unknown transport %d", transport);
-    // (tests, with CMF_TEST_HOOKS=1: every loopback group of the process as a peer-transport group -- the whole group suite then runs
-    // on the peer protocol, its event fences and its kernels)
-    if (tr == CMF_TR_LOOPBACK && all_same && getenv("CMF_TEST_HOOKS") && atoi(getenv("CMF_TEST_HOOKS")) == 1 &&
-        getenv("CMF_LOOPBACK_AS_PEER") && atoi(getenv("CMF_LOOPBACK_AS_PEER")) == 1)
-        tr = CMF_TR_PEER;
     if (tr == CMF_TR_RCCL && !distinct) return fail(CMF_ERR_ARG, "RCCL needs distinct devices (a device is listed twice)");
     if (tr == CMF_TR_LOOPBACK && !all_same) return fail(CMF_ERR_ARG, "the loopback transport needs all shards on one device; list distinct devices for RCCL");
     if (tr == CMF_TR_PEER && !(distinct || all_same)) return fail(CMF_ERR_ARG, "the peer transport takes distinct devices, or one device for every shard (rehearsal)");
@@ -2289,7 +2298,7 @@ int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transpor
         if (rc != CMF_OK) return bail(rc);
     }
     // CMF_LOOPBACK_STREAMS=1 turns every loopback group of the process into the stream-per-shard form (tests)
-    g->loop_ms = tr == CMF_TR_LOOPBACK && (transport == CMF_COMM_LOOPBACK_STREAMS || (getenv("CMF_LOOPBACK_STREAMS") && atoi(getenv("CMF_LOOPBACK_STREAMS")) == 1));
+    g->loop_ms = tr == CMF_TR_LOOPBACK && transport == CMF_COMM_LOOPBACK_STREAMS;
     if (tr == CMF_TR_LOOPBACK && !g->loop_ms) // one device: every shard works on shard 0's streams, so the kernels of the loopback collectives are ordered
         for (cmf_handle_s *s : g->sh) { s->stream = g->sh[0]->stream; s->comm_stream = g->sh[0]->comm_stream; }
     if (tr == CMF_TR_RCCL) {
@@ -2495,67 +2504,62 @@ static int gram_ensure(cmf_handle_s *h)
     return CMF_OK;
 }
 
+// Which sweep kernels run and how (re-planned whenever one of the "hals_*" options changes; no allocation here).
+// The reference takes any K, L (hals.jl:90-154).  The fast on-chip sweeps have shape limits: the H sweep slides a 64-column
+// window along a row with the L-1 pending columns in the lanes of one wave (L <= 64); the W sweep keeps the L*Kpad projected
+// state of a unit in registers (up to 32 slots per lane) and K*L new values per unit in LDS.  Outside them the general sweeps
+// run (hals_w_sweep_gen_kernel / hals_h_row_gen_kernel): the same recurrences in the same order with the state in LDS /
+// global memory -- slower, no shape limit.
+static void hals_plan(cmf_handle_s *h)
+{
+    const CmfDims &d = h->d;
+    const int E = 2 * d.L - 1;
+    h->hals_w_general = ((int64_t)d.L * d.K32 > 2048) || ((size_t)4 * d.K * d.L * HALS_NG * sizeof(float) > 64 * 1024) || (h->hals_opt_general & 1);
+    h->hals_h_general = d.L > 64 || (h->hals_opt_general & 2);
+    // stage pipeline: segment length (multiple of 64, >= 256 so that the sweeps and pushes of one stage touch disjoint columns: see
+    // hals_h_stage_kernel); measured at config 5: 8.60 ms (256), 8.13 (320 and 384), 8.56 (512)
+    h->hals_seg = (int)rup(std::max(h->hals_opt_seg, 256), 64);
+    h->hals_nseg = (d.Tl + h->hals_seg - 1) / h->hals_seg;
+    // persistent H pipeline (hals_h_persist_kernel): K sweepers + (K-1) * P pullers, one workgroup per CU, all resident
+    int P = 0;
+    if (h->hals_opt_persist != 0 && !h->hals_h_general) {
+        P = d.K > 1 ? std::min(HALS_PMAX, (h->n_cu - d.K) / (d.K - 1)) : 1;
+        if (h->hals_opt_persist > 1) P = std::min(P, h->hals_opt_persist);
+        const size_t lds = ((size_t)(d.K - 1) * (E + 64 + 2 * (d.L - 1)) + 1024) * sizeof(float);
+        if (P < 2 && d.K > 1) P = 0; // too many rows for the chip: stage pipeline
+        if (lds > 120 * 1024) P = 0;
+        // the grid's workgroups wait for each other: all of them must be resident at once.  Ask the runtime how many
+        // 1024-thread workgroups with this much LDS a CU takes instead of assuming one (a device with fewer usable CUs, or
+        // a kernel whose registers no longer allow 1024 threads, would otherwise only show as an expired wait).
+        while (P >= (d.K > 1 ? 2 : 1)) {
+            int per_cu = 0;
+            const size_t lds_run = std::max((size_t)(d.K - 1) * (2 * d.L - 1 + 64 + 2 * (d.L - 1)) + 1024, (size_t)h->hals_ne * (d.L + 1)) * sizeof(float);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hals_h_persist_kernel, 1024, lds_run) != hipSuccess) per_cu = 0;
+            if ((long long)per_cu * h->n_cu >= (long long)d.K + (long long)(d.K - 1) * P) break;
+            --P;
+        }
+        if (P < 2 && d.K > 1) P = 0;
+        if (P < 1) P = 0;
+    }
+    h->hals_pullers = P;
+}
+
 static int hals_ensure(cmf_handle_s *h)
 {
     if (h->hals_ready) return CMF_OK;
     const CmfDims &d = h->d;
     if (h->sharded && h->T_global != d.Tl) return fail(CMF_ERR_STATE, "HALS needs an unsharded handle (the H sweep is sequential along T)");
-    if (const char *env = getenv("CMF_HALS_GRAM")) h->hals_gram = (atoi(env) == 1 || atoi(env) == 2) ? atoi(env) : 0; // (tests compare the forms)
-    const int E = 2 * d.L - 1;
     CMFTRY(gram_ensure(h));
     h->hals_TPp = (int)rup(d.Tl, 64) + (int)std::max<int64_t>(256, rup(d.L, 64) + 128); // (the general row sweep reads a ring of roundup(L, 64) + 64 columns ahead)
     CMFTRY(dalloc_zero(&h->hals_PT, (size_t)d.K32 * h->hals_TPp));
     CMFTRY(dalloc_zero(&h->hals_D, (size_t)d.K32 * h->hals_TPp)); // per row: rows run concurrently
-    // Which sweep kernels run (the reference takes any K, L: hals.jl:90-154).  The fast on-chip sweeps have shape limits:
-    // the H sweep slides a 64-column window along a row with the L-1 pending columns in the lanes of one wave (L <= 64);
-    // the W sweep keeps the L*Kpad projected state of a unit in registers (up to 32 slots per lane) and K*L new values per
-    // unit in LDS.  Outside them the general sweeps run (hals_w_sweep_gen_kernel / hals_h_row_gen_kernel): the same
-    // recurrences in the same order with the state in LDS / global memory -- slower, no shape limit.
-    h->hals_w_general = ((int64_t)d.L * d.K32 > 2048) || ((size_t)4 * d.K * d.L * HALS_NG * sizeof(float) > 64 * 1024);
-    h->hals_h_general = d.L > 64;
-    if (const char *env = getenv("CMF_HALS_GENERAL")) { // tests: force the general sweeps at any shape
-        if (atoi(env) & 1) h->hals_w_general = true;
-        if (atoi(env) & 2) h->hals_h_general = true;
+    {   // the persistent pipeline's flags (for the largest puller count a plan may choose) and its status word
+        const size_t nflags = (size_t)(d.K + d.K * HALS_PMAX + 1) * HALS_FLAG_STRIDE;
+        HIPCHK(hipMalloc((void **)&h->hals_flags, nflags * sizeof(int)));
+        HIPCHK(hipHostMalloc((void **)&h->hals_status, sizeof(int), hipHostMallocDefault));
+        *h->hals_status = 0;
     }
-    {   // row pipeline: segment length (multiple of 64, >= 256 so that the sweeps and pushes of one stage
-        // touch disjoint columns: see hals_h_stage_kernel)
-        const char *env = getenv("CMF_HALS_SEG");
-        int seg = env ? atoi(env) : 384; // measured at config 5: 8.60 ms (256), 8.13 (320 and 384), 8.56 (512)
-        seg = (int)rup(std::max(seg, 256), 64);
-        h->hals_seg = seg;
-        h->hals_nseg = (d.Tl + seg - 1) / seg;
-    }
-    {   // persistent H pipeline (hals_h_persist_kernel): K sweepers + (K-1) * P pullers, one workgroup per CU, all resident
-        const char *env = getenv("CMF_HALS_PERSIST"); // 0 = the stage pipeline (the tests compare the two)
-        int P = 0;
-        if (!(env && atoi(env) == 0) && !h->hals_h_general) {
-            static const int pmax = getenv("CMF_HALS_PMAX") && atoi(getenv("CMF_HALS_PMAX")) > 0 ? atoi(getenv("CMF_HALS_PMAX")) : 4; // measurement knob
-            P = d.K > 1 ? std::min(pmax, (h->n_cu - d.K) / (d.K - 1)) : 1;
-            if (env && atoi(env) > 1) P = std::min(P, atoi(env));
-            const size_t lds = ((size_t)(d.K - 1) * (E + 64 + 2 * (d.L - 1)) + 1024) * sizeof(float);
-            if (P < 2 && d.K > 1) P = 0; // too many rows for the chip: stage pipeline
-            if (lds > 120 * 1024) P = 0;
-            // the grid's workgroups wait for each other: all of them must be resident at once.  Ask the runtime how many
-            // 1024-thread workgroups with this much LDS a CU takes instead of assuming one (a device with fewer usable CUs, or
-            // a kernel whose registers no longer allow 1024 threads, would otherwise only show as an expired wait).
-            while (P >= (d.K > 1 ? 2 : 1)) {
-                int per_cu = 0;
-                const size_t lds_run = std::max((size_t)(d.K - 1) * (2 * d.L - 1 + 64 + 2 * (d.L - 1)) + 1024, (size_t)h->hals_ne * (d.L + 1)) * sizeof(float);
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hals_h_persist_kernel, 1024, lds_run) != hipSuccess) per_cu = 0;
-                if ((long long)per_cu * h->n_cu >= (long long)d.K + (long long)(d.K - 1) * P) break;
-                --P;
-            }
-            if (P < 2 && d.K > 1) P = 0;
-            if (P < 1) P = 0;
-        }
-        h->hals_pullers = P;
-        if (P > 0) {
-            const size_t nflags = (size_t)(d.K + d.K * P + 1) * HALS_FLAG_STRIDE;
-            HIPCHK(hipMalloc((void **)&h->hals_flags, nflags * sizeof(int)));
-            HIPCHK(hipHostMalloc((void **)&h->hals_status, sizeof(int), hipHostMallocDefault));
-            *h->hals_status = 0;
-        }
-    }
+    hals_plan(h);
     h->hals_ready = true;
     return CMF_OK;
 }
@@ -2703,15 +2707,11 @@ static int hals_h_sweep_stage(cmf_handle_s *h, const HalsRowParams &q)
     sp.Dall = h->hals_D;
     sp.K = d.K; sp.seg = h->hals_seg; sp.nseg = h->hals_nseg;
     sp.CB = (h->hals_seg + 2 * (d.L - 1) + 255) / 256;
-    const char *lag_env = getenv("CMF_HALS_LAG"); // 3 = the unshifted round-1 schedule (tests compare the two)
-    sp.lag = (lag_env && atoi(lag_env) == 3) ? 3 : 2;
+    sp.lag = h->hals_opt_lag == 3 ? 3 : 2; // (3 = the unshifted round-1 schedule: the tests compare the two)
     sp.skew = sp.lag == 2 ? 128 : 0; // see hals_h_stage_kernel
     // the last row's last segment, +1 for the pushes of the last sweeps (no-ops for the last row)
     const int nstages = (d.Tl + sp.skew * (d.K - 1) + h->hals_seg - 1) / h->hals_seg + sp.lag * (d.K - 1) + 1;
     dim3 grid(d.K + d.K * sp.CB, std::max(1, d.K - 1));
-    if (const char *dbg = getenv("CMF_HALS_DEBUG")) { // timing experiments only (results are wrong): "nopush" launches the sweeps alone
-        if (std::strcmp(dbg, "nopush") == 0) grid = dim3(d.K, 1);
-    }
     for (int stage = 0; stage < nstages; ++stage) {
         sp.stage = stage;
         hipLaunchKernelGGL(hals_h_stage_kernel, grid, dim3(256), 0, h->stream, sp);
@@ -2786,32 +2786,7 @@ static int hals_h_enqueue(cmf_handle_s *h, double l1H, double l2H)
         if (!h->hals_snap) CMFTRY(dalloc_zero(&h->hals_snap, 2 * nH));
         HIPCHK(hipMemcpyAsync(h->hals_snap, h->H, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->hals_snap + nH, h->Ht, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        int debug = 0;
-        if (const char *dbg = getenv("CMF_HALS_DEBUG")) { // timing experiments only (results are wrong)
-            if (std::strcmp(dbg, "nogate") == 0) debug = 1;  // sweepers alone: no row waits for anything
-            if (std::strcmp(dbg, "nopull") == 0) debug = 2;  // pullers raise their flags without doing the work
-            if (std::strcmp(dbg, "stall") == 0) debug = 3;   // pullers leave at once: every sweeper's wait must run out (tests)
-        }
-        unsigned long long *stamps = nullptr;
-        const char *stamp_path = getenv("CMF_HALS_STAMPS"); // debug: dump s_memtime stamps of this launch to a file
-        const size_t nstamps = (size_t)d.K * ((d.Tl + 63) / 64) * 5;
-        if (stamp_path) {
-            HIPCHK(hipMalloc((void **)&stamps, nstamps * sizeof(unsigned long long)));
-            HIPCHK(hipMemsetAsync(stamps, 0, nstamps * sizeof(unsigned long long), h->stream));
-        }
-        CMFTRY(hals_persist_launch(h, q, debug, stamps));
-        if (stamp_path) {
-            std::vector<unsigned long long> st(nstamps);
-            HIPCHK(hipStreamSynchronize(h->stream));
-            HIPCHK(hipMemcpy(st.data(), stamps, nstamps * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            (void)hipFree(stamps);
-            if (FILE *f = fopen(stamp_path, "wb")) {
-                const long long hdr[2] = {d.K, (d.Tl + 63) / 64};
-                fwrite(hdr, sizeof(hdr), 1, f);
-                fwrite(st.data(), sizeof(unsigned long long), nstamps, f);
-                fclose(f);
-            }
-        }
+        CMFTRY(hals_persist_launch(h, q, h->hals_debug));
         return CMF_OK;
     }
     ProfScope prof_(h, PROF_HALS_PIPE); // the whole row pipeline (nstages launches) as one timed span
@@ -2833,6 +2808,7 @@ static int hals_h_rerun(cmf_handle_s *h)
     const size_t nH = (size_t)d.TP * d.K32;
     *h->hals_status = 0;
     h->hals_pullers = 0;
+    h->hals_opt_persist = 0; // (a later re-plan keeps to it)
     h->hals_reruns += 1;
     HIPCHK(hipMemcpyAsync(h->H, h->hals_snap, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->Ht, h->hals_snap + nH, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
@@ -2864,8 +2840,7 @@ static int gram_denom_h(cmf_handle_s *h, float *out)
     // columns with the full lag window, in tiles of 128 / fw: the MFMA kernel on the transposed taps; the rest (the right edge
     // with its per-column taps, and what does not fill a tile): the scalar kernel.  fw waves share the MFMA chain of an
     // output block: short handles (a T/8 shard) need the extra waves to fill the chip.
-    static const int fw_env = getenv("CMF_GRAM_FW") ? atoi(getenv("CMF_GRAM_FW")) : 0; // measurement knob
-    const int fw = (fw_env == 1 || fw_env == 2 || fw_env == 4) ? fw_env : (d.Tl < 16384 ? 4 : (d.Tl < 100000 ? 2 : 1));
+    const int fw = d.Tl < 16384 ? 4 : (d.Tl < 100000 ? 2 : 1);
     const int tile = 128 / fw;
     const size_t lds_m = ((size_t)d.K32 * (tile + 2 * (d.L - 1)) + (fw > 1 ? 4096 : 0)) * sizeof(float);
     const int ntile = lds_m <= 120 * 1024 ? h->hals_t_edge0 / tile : 0;
@@ -3042,8 +3017,7 @@ static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg
     if (nonneg < 0 || nonneg > 2) return fail(CMF_ERR_ARG, "constraint must be 0 (none), 1 (NonnegConstraint) or 2 (UnitNormConstraint)");
     const float gscale = h->pgd_loss_abs ? 1.f : 2.f;
     if (!h->pgd_gradH) CMFTRY(dalloc_zero(&h->pgd_gradH, (size_t)d.Tl * d.K32));
-    static const bool no_transpose = getenv("CMF_PGD_TRANSPOSE") && atoi(getenv("CMF_PGD_TRANSPOSE")) == 0; // measurement knob
-    if (!no_transpose && h->est_kind == 2 + (h->M ? 1 : 0) + (h->pgd_loss_abs ? 2 : 0)) {
+    if (h->est_kind == 2 + (h->M ? 1 : 0) + (h->pgd_loss_abs ? 2 : 0)) {
         // est already holds this residual for the resident W, H (stored by the conv that closed the W phase, pgd.jl:245): the
         // H phase's est of pgd.jl:230 is the same array, only tensor_transconv wants it transposed
         hipLaunchKernelGGL(transpose_rows_kernel, dim3(d.Np / 64, (d.Tl + 63) / 64), dim3(256), 0, h->stream, h->est, h->estT, d.Tl, d.Np, d.TP, d.PADL);
@@ -3194,8 +3168,7 @@ static int group_pgd_h(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double p
         CMFTRY(group_use(s));
         if (!s->pgd_gradH) CMFTRY(dalloc_zero(&s->pgd_gradH, (size_t)d.Tl * d.K32));
         // the transposed residual on the shard's columns AND its right lag halo (transconv reads est[:, t .. t+L-1])
-        static const bool no_transpose = getenv("CMF_PGD_TRANSPOSE") && atoi(getenv("CMF_PGD_TRANSPOSE")) == 0; // measurement knob
-        if (!no_transpose && s->est_kind == 2 + (s->M ? 1 : 0) + (st->pgd_loss_abs ? 2 : 0)) {
+        if (s->est_kind == 2 + (s->M ? 1 : 0) + (st->pgd_loss_abs ? 2 : 0)) {
             // the shard's own columns are in est already (the conv that closed the W phase): transposed, not convolved again;
             // the <= L-1 halo columns are formed directly (resid_halo_kernel)
             hipLaunchKernelGGL(transpose_rows_kernel, dim3(d.Np / 64, (d.Tl + 63) / 64), dim3(256), 0, s->stream, s->est, s->estT, d.Tl, d.Np, d.TP, d.PADL);

@@ -243,8 +243,7 @@ static bool group_wants_workers(const cmf_group_s *g)
     // (tests: a worker for a ONE-shard RCCL group too, so that a one-GPU box can show a worker thread issuing the RCCL calls of a
     // communicator another thread created -- honoured only with CMF_TEST_HOOKS=1)
     if (g->one_process && g->sh.size() == 1 && g->transport == CMF_TR_RCCL)
-        if (const char *hooks = getenv("CMF_TEST_HOOKS"))
-            if (atoi(hooks) == 1 && getenv("CMF_TEST_FORCE_WORKERS") && atoi(getenv("CMF_TEST_FORCE_WORKERS")) == 1) return true;
+        if (test_hook("CMF_TEST_FORCE_WORKERS", 0) == 1) return true;
     if (!g->one_process || g->sh.size() < 2) return false;
     return g->transport == CMF_TR_RCCL || g->transport == CMF_TR_PEER || (g->transport == CMF_TR_LOOPBACK && g->loop_ms);
 }
@@ -697,10 +696,7 @@ static int group_check_ready(cmf_group_s *g)
     // test hook (honoured only with CMF_TEST_HOOKS=1): that shard's next all-reduce call fails.  The environment is read HERE, by
     // the calling thread at a public entry -- never by the enqueue workers on the per-iteration path (getenv is not safe against
     // a concurrent setenv of the host program)
-    g->test_fail_shard = -1;
-    if (const char *hooks = getenv("CMF_TEST_HOOKS"))
-        if (atoi(hooks) == 1)
-            if (const char *e = getenv("CMF_TEST_FAIL_SHARD")) g->test_fail_shard = atoi(e);
+    g->test_fail_shard = (int)test_hook("CMF_TEST_FAIL_SHARD", -1);
     for (cmf_handle_s *s : g->sh) {
         if (!s->factors_set) return fail(CMF_ERR_STATE, "factors not set: call cmf_set_factors first");
         if (!s->have_data) return fail(CMF_ERR_STATE, "handle was created without data");

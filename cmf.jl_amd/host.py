@@ -651,7 +651,7 @@ def fit(alg, data, L, K, W_init, H_init, verbose=False, **kwargs):
 # --------------------------------------------------------------------------------------
 _REG_ALIASES = {"l1_W": "l1W", "l2_W": "l2W", "l1_H": "l1H", "l2_H": "l2H"}  # README.md:44-52 -> mult.jl:23,42
 _KNOWN_KW = {"seed", "W_init", "H_init", "check_convergence", "patience", "eval_mode", "tol", "verbose",
-             "l1W", "l2W", "l1H", "l2H", "device", "devices",
+             "l1W", "l2W", "l1H", "l2H", "device", "devices", "options",
              "loss_func", "constrW", "constrH", "penaltiesW", "penaltiesH"}  # PGDUpdate (pgd.jl:158-202)
 
 
@@ -691,6 +691,7 @@ def fit_cnmf(data, L=10, K=5, alg=MultUpdate, max_itr=100, max_time=math.inf, **
                       "(the reference ignores them silently)", stacklevel=2)
     device = kw.pop("device", None)
     devices = kw.pop("devices", None)  # several GPUs of this node: the T-sharded group form of the :mult rule
+    options = kw.pop("options", None)  # {name: value} for cmf_set_option on the rule (include/cmf_hip.h lists them)
     rule_type = _resolve_alg(alg)
     data = farr(data)
 
@@ -708,6 +709,8 @@ def fit_cnmf(data, L=10, K=5, alg=MultUpdate, max_itr=100, max_time=math.inf, **
         rule = (rule_type(data, W_init, H_init, device=device) if issubclass(rule_type, MultUpdate)
                 else rule_type(data, W_init, H_init))
     try:
+        for name, value in (options or {}).items():
+            rule.set_option(name, value)
         opt = AlternatingOptimizer(rule, max_itr, max_time)  # :78-82
         loop_kw = {k: v for k, v in kw.items() if k not in ("seed", "W_init", "H_init")}
         return fit(opt, data, L, K, W_init, H_init, **loop_kw)  # :84

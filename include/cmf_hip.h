@@ -21,6 +21,18 @@
  *   - A handle is not re-entrant: one host thread at a time.
  *   - There is no CPU fallback: without a usable HIP device every compute
  *     entry fails with CMF_ERR_HIP.
+ *   - Environment.  Everything that selects a code path is an OPTION (cmf_set_option; cmf_option_names lists them).  The library
+ *     reads these variables and no others:
+ *         CMF_WAIT_TIMEOUT_S     bound of every host-side wait (loss words, helper threads, collectives): seconds, default 300
+ *         CMF_WRITEBACK_THREADS  widening helpers of cmf_arm_writeback: default 4, at most 16
+ *         CMF_ENQUEUE_THREADS    0: the calling thread enqueues every shard of a one-process group (see cmf_create_multi)
+ *         CMF_RCCL_LIB           path of the RCCL to dlopen ("none": behave as if there were no RCCL)
+ *         CMF_ROCTX              1: load the roctx marker library and bracket phases and collectives; 0: never; unset: only if the
+ *                                process has already mapped it (a profiler)
+ *         CMF_TEST_HOOKS         1: honour the test hooks below (and the option "hals_debug"); anything else: they do not exist
+ *           CMF_MAX_COLUMNS        columns one handle holds before cmf_create cuts the recording into shards (tests of that path)
+ *           CMF_TEST_FORCE_WORKERS 1: an enqueue worker for a ONE-shard RCCL group too
+ *           CMF_TEST_FAIL_SHARD    that shard's next all-reduce call fails (tests of the failure path)
  */
 #ifndef CMF_HIP_H
 #define CMF_HIP_H
@@ -45,7 +57,9 @@ typedef struct cmf_handle_s *cmf_handle;
  * cmf_h_update, cmf_loss_partial*, cmf_halo_*, cmf_numden_ptr, cmf_set_data_norm) are gone -- a sharded iteration
  * runs behind the rule entries of a group handle (cmf_create_multi / cmf_comm_init_*); cmf_abi_version,
  * cmf_source_digest, cmf_synchronize, cmf_rccl_version, cmf_get_counter are new.  5 (round 5): cmf_arm_writeback.  6 (round 6):
- * cmf_fingerprint; cmf_set_factors takes one NULL factor. */
+ * cmf_fingerprint, cmf_option_names; cmf_set_factors takes one NULL factor; the measurement variables of the environment are gone
+ * (CMF_HALS_*, CMF_CONV_*, CMF_SK_*, CMF_GRAM_FW, CMF_PGD_TRANSPOSE, CMF_LOSS_POLL, CMF_SPECULATE_W, CMF_SMALL_K, CMF_HXT_EXACT,
+ * CMF_LOOPBACK_*): what tests still select is an option. */
 #define CMF_ABI_VERSION 6
 int cmf_abi_version(void);
 
@@ -199,6 +213,14 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       faster.  tensor_transconv keeps the general kernel when T is too short to fill the chip with its GEMM form; 2 = the
  *       few-component form whatever T is; 0 = the general kernels for every K.  Same arithmetic, another summation order.
  *   "hals_prepare": allocate the HALS rule's scratch and check its shape limits now (see the HALS entries).
+ *   "hals_persist" (default 1): how the H sweep of the HALS rule runs.  1 = as ONE persistent launch where its grid fits the chip
+ *       (K sweepers + 4 (K-1) pullers, one workgroup per CU), 0 = one launch per pipeline stage, n > 1 = the persistent launch with at
+ *       most n puller workgroups per row.  "hals_seg" (default 384; rounded up to a multiple of 64, at least 256) and "hals_lag"
+ *       (default 2; 3 = the unshifted schedule) shape the stage pipeline; "hals_general" (default 0; bit 0 / bit 1) forces the general
+ *       W / H sweeps at shapes the on-chip sweeps cover.  All four give the reference's visiting order and agree to rounding (the
+ *       tests compare them); they exist for tests and measurements.  "hals_debug" (needs CMF_TEST_HOOKS=1; results are WRONG by
+ *       design): 3 = the pullers of the persistent launch leave at once, so that every bounded wait runs out (the test of that
+ *       path); 1 / 2 = no gating / pullers skip their work (timing).
  *   "hals_gram" (default 2): where the HALS sweeps' projections come from.  2 = P of the H phase as denomH - numH of the MU
  *       quantities (one conv launch less; H within the residual form's accuracy), G of the W phase contracted from the
  *       stored residual; 0 = both from the residual; 1 = both as differences (no residual at all, but about 20x the
@@ -213,6 +235,8 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       second stream right after the H update, underneath the loss conv and the denominator contraction, so only
  *       the denomW half of the all-reduce stays exposed; costs a second C2 launch per iteration. */
 int cmf_set_option(cmf_handle h, const char *name, int value);
+/* The names cmf_set_option accepts, comma-separated (truncation is an error: CMF_ERR_ARG; 512 bytes are plenty). */
+int cmf_option_names(char *buf, int64_t len);
 
 /* sum(data.^2) (fp64) over the columns this handle owns -- over all shards on a group handle
  * (data_norm: src/algs/mult.jl:13). */
@@ -250,7 +274,7 @@ int cmf_fingerprint(const double *a, int64_t n, int64_t line_stride, uint64_t *f
  * On a group handle (MU rule in either formulation, PGD rule)
  * every shard copies its own column block of H on its own device the same way (shard 0 also W) and the handle's helpers widen
  * block after block.
- * CMF_WRITEBACK_THREADS (default 4): the widening helpers.
+ * CMF_WRITEBACK_THREADS (environment, default 4): the widening helpers.
  * cmf_get_counter: "writeback_calls", "writeback_overlapped" (calls served by the copy stream). */
 int cmf_arm_writeback(cmf_handle h, double *W, double *H);
 
@@ -308,7 +332,7 @@ int cmf_iterate(cmf_handle h, int64_t n_iter, int eval_mode, double l1W, double 
  * the CUs -- cmf_hals_update_feature_maps restores H from the snapshot taken at the start of the sweep, redoes the sweep
  * with one launch per pipeline stage (no co-residency needed; the handle keeps to that form afterwards) and returns
  * CMF_OK; cmf_get_counter(h, "hals_pipeline_reruns") counts these events.
- * Environment CMF_HALS_PERSIST=0 selects the one-launch-per-stage pipeline from the start. */
+ * cmf_set_option(h, "hals_persist", 0) selects the one-launch-per-stage pipeline from the start. */
 int cmf_hals_update_motifs(cmf_handle h, double l1W, double l2W);
 int cmf_hals_update_feature_maps(cmf_handle h, double l1H, double l2H, double *loss);
 

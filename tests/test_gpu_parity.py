@@ -407,7 +407,7 @@ def test_hals_shapes_beyond_the_on_chip_sweeps(cmf, oracle, N, T, K, L, reg):
 
 @pytest.mark.parametrize("N,T,K,L", [(96, 700, 5, 10), (130, 900, 32, 20), (37, 150, 33, 7), (64, 100, 4, 33)])
 def test_hals_general_sweeps_agree_with_the_on_chip_sweeps(cmf, oracle, N, T, K, L):
-    """The general sweeps forced (CMF_HALS_GENERAL) at shapes the on-chip sweeps cover: same order of updates, so the two
+    """The general sweeps forced (option "hals_general") at shapes the on-chip sweeps cover: same order of updates, so the two
     agree to rounding; both against the oracle."""
     import os
 
@@ -416,11 +416,8 @@ def test_hals_general_sweeps_agree_with_the_on_chip_sweeps(cmf, oracle, N, T, K,
     reg = dict(l1W=0.05, l2W=0.1, l1H=0.05, l2H=0.1)
     out = {}
     for general in ("0", "3"):
-        os.environ["CMF_HALS_GENERAL"] = general
-        try:
-            rule = cmf.HALSUpdate(data, W0, H0)
-        finally:
-            os.environ.pop("CMF_HALS_GENERAL", None)
+        rule = cmf.HALSUpdate(data, W0, H0)
+        rule.set_option("hals_general", int(general))
         ls = []
         for _ in range(3):
             rule.update_motifs(l1W=reg["l1W"], l2W=reg["l2W"])
@@ -445,11 +442,8 @@ def test_hals_general_sweeps_on_ragged_shapes(cmf, oracle, N, T, K, L):
 
     data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=min(L, 20) if L > 1 else 2, seed=9)
     W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=4)
-    os.environ["CMF_HALS_GENERAL"] = "3"
-    try:
-        rule = cmf.HALSUpdate(data, W0, H0)
-    finally:
-        os.environ.pop("CMF_HALS_GENERAL", None)
+    rule = cmf.HALSUpdate(data, W0, H0)
+    rule.set_option("hals_general", 3)
     ls = []
     for _ in range(2):
         rule.update_motifs(l1W=0.05, l2W=0.1)
@@ -484,22 +478,17 @@ def test_hals_config5_full_size(cmf, config2):
 
     data, W0, H0 = config2
     runs = {}
-    for name, env in (("persist", {}), ("persist2", {"CMF_HALS_PERSIST": "2"}),
-                      ("stage256", {"CMF_HALS_PERSIST": "0", "CMF_HALS_SEG": "256"}),
-                      ("stage1024", {"CMF_HALS_PERSIST": "0", "CMF_HALS_SEG": "1024"}),
-                      ("stage384lag3", {"CMF_HALS_PERSIST": "0", "CMF_HALS_SEG": "384", "CMF_HALS_LAG": "3"}),
-                      ("resid", {"CMF_HALS_GRAM": "0"}),  # both projections contracted from the stored residual
-                      ("gram", {"CMF_HALS_GRAM": "1"})):  # both as differences of the MU quantities (opt-in)
-        os.environ.update(env)
-        try:
-            r = cmf.fit_cnmf(data, L=20, K=32, alg=":hals", max_itr=3, check_convergence=False, W_init=W0, H_init=H0)
-            if name in ("persist", "stage256"):  # same configuration twice: bit for bit
-                r2 = cmf.fit_cnmf(data, L=20, K=32, alg=":hals", max_itr=3, check_convergence=False, W_init=W0, H_init=H0)
-                np.testing.assert_array_equal(r.loss_hist, r2.loss_hist)
-                np.testing.assert_array_equal(r.H, r2.H)
-        finally:
-            for key in env:
-                os.environ.pop(key, None)
+    for name, opts in (("persist", {}), ("persist2", {"hals_persist": 2}),
+                       ("stage256", {"hals_persist": 0, "hals_seg": 256}),
+                       ("stage1024", {"hals_persist": 0, "hals_seg": 1024}),
+                       ("stage384lag3", {"hals_persist": 0, "hals_seg": 384, "hals_lag": 3}),
+                       ("resid", {"hals_gram": 0}),  # both projections contracted from the stored residual
+                       ("gram", {"hals_gram": 1})):  # both as differences of the MU quantities (opt-in)
+        r = cmf.fit_cnmf(data, L=20, K=32, alg=":hals", max_itr=3, check_convergence=False, W_init=W0, H_init=H0, options=opts)
+        if name in ("persist", "stage256"):  # same configuration twice: bit for bit
+            r2 = cmf.fit_cnmf(data, L=20, K=32, alg=":hals", max_itr=3, check_convergence=False, W_init=W0, H_init=H0, options=opts)
+            np.testing.assert_array_equal(r.loss_hist, r2.loss_hist)
+            np.testing.assert_array_equal(r.H, r2.H)
         runs[name] = r
     a = runs["persist"]
     assert np.all(np.diff(a.loss_hist) < 0) and a.loss_hist[-1] < 0.25
@@ -961,7 +950,7 @@ def test_medium_sizes_two_iterations(cmf, oracle, N, T, K, L):
 
 def test_hals_persistent_pipeline_waits_are_bounded(cmf, oracle):
     """The persistent H pipeline's workgroups wait for each other through flags in memory; a wait that is never satisfied
-    (here: the puller workgroups leave without doing their work, CMF_HALS_DEBUG=stall) must run out and drain the grid --
+    (here: the puller workgroups leave without doing their work, option "hals_debug" = 3 under CMF_TEST_HOOKS=1) must run out and drain the grid --
     not hang the device -- and the call must still deliver the sweep: H is restored from the snapshot taken at its start,
     the sweep is redone on the stage pipeline, the event is counted, the result is the oracle's."""
     import os
@@ -976,11 +965,15 @@ def test_hals_persistent_pipeline_waits_are_bounded(cmf, oracle):
     rule = cmf.HALSUpdate(data, W0, H0)
     assert rule.counter("hals_pipeline_reruns") == 0
     rule.update_motifs()
-    os.environ["CMF_HALS_DEBUG"] = "stall"
+    with pytest.raises(Exception, match="CMF_TEST_HOOKS"):
+        rule.set_option("hals_debug", 3)  # (a wrong-results switch does not exist without the hooks)
+    os.environ["CMF_TEST_HOOKS"] = "1"
     try:
+        rule.set_option("hals_debug", 3)
         loss = rule.update_feature_maps()
+        rule.set_option("hals_debug", 0)
     finally:
-        os.environ.pop("CMF_HALS_DEBUG", None)
+        os.environ.pop("CMF_TEST_HOOKS", None)
     assert rule.counter("hals_pipeline_reruns") == 1
     Wg, Hg = rule.download()
     _, _, lh, _ = oracle.c_fit_hals(data, W0, H0, max_itr=2, check_convergence=False)

@@ -109,3 +109,62 @@ def test_results_as_hdf5_in_the_reference_schema(cmf, tmp_path):
     with pytest.raises(KeyError):
         _hdf5.write_file(str(tmp_path / "partial.h5"), {"W": r.W})
         cmf.load_model(str(tmp_path / "partial.h5"))
+
+
+def option_names(lib):
+    buf = ctypes.create_string_buffer(1024)
+    assert lib.cmf_option_names(buf, 1024) == 0
+    return buf.value.decode().split(",")
+
+
+def test_every_code_path_choice_is_a_documented_option_and_the_environment_is_nine_variables(cmf):
+    """Round 6: the measurement knobs read from the environment are gone.  Whatever selects a code path is a cmf_set_option name
+    that the header documents (cmf_option_names is the table), and the sources read exactly the variables the header lists."""
+    lib = cmf.load_library()
+    names = option_names(lib)
+    assert len(names) == len(set(names)) >= 15
+    hdr = open(os.path.join(ROOT, "include", "cmf_hip.h")).read()
+    for n in names:
+        assert f'"{n}"' in hdr, f"option {n} is not documented in include/cmf_hip.h"
+    assert lib.cmf_option_names(ctypes.create_string_buffer(8), 8) != 0  # truncation is an error, not a silent cut
+    csrc = os.path.join(ROOT, "cmf.jl_amd", "csrc")
+    text = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)))
+    code = re.sub(r"//[^\n]*", "", text)
+    assert len(re.findall(r"\bgetenv\s*\(", code)) <= 10
+    read = set(re.findall(r'getenv\("(CMF_[A-Z_]+)"\)', code)) | set(re.findall(r'test_hook\("(CMF_[A-Z_]+)"', code))
+    listed = set(re.findall(r"^ \*\s+(CMF_[A-Z_]+)\s", hdr[: hdr.index("#ifndef CMF_HIP_H")], flags=re.M))
+    assert read == listed, (sorted(read - listed), sorted(listed - read))
+    assert len(read) == 9
+    # ... and nothing else in the repository still sets a variable the library no longer reads
+    stale = re.compile(r"CMF_(HALS_[A-Z]+|CONV_[A-Z_]+|SK_[A-Z_0-9]+|GRAM_FW|PGD_TRANSPOSE|LOSS_POLL|SPECULATE_W|SMALL_K\b|HXT_EXACT|LOOPBACK_[A-Z_]+|EXP_CU_MASK)")
+    for sub in ("tests", "tools", "cmf.jl_amd", "."):
+        d = os.path.join(ROOT, sub)
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".py", ".sh", ".jl", ".hip", ".h", ".c")) and f != os.path.basename(__file__):
+                m = stale.search(open(os.path.join(d, f), errors="replace").read())
+                assert not m, f"{sub}/{f} still mentions {m.group(0)}"
+
+
+@pytest.mark.gpu
+def test_every_option_name_is_accepted_and_unknown_names_are_refused(cmf, oracle):
+    data, _, _ = oracle.c_gen_synthetic(N=24, T=200, K=3, L=6, seed=2)
+    W0, H0 = oracle.c_init_rand(data, L=6, K=4, seed=1)
+    lib = cmf.load_library()
+    defaults = {"reuse_est": 1, "speculate": 1, "gram": 0, "conv_kernel": 0, "conv_split": 1, "small_k": 1, "hals_prepare": 1, "hals_gram": 2,
+                "hals_persist": 1, "hals_general": 0, "hals_seg": 384, "hals_lag": 2, "hals_debug": 0, "profile": 0, "profile_mask": 0,
+                "allreduce_overlap": 0, "enqueue_threads": 1}
+    assert sorted(defaults) == sorted(option_names(lib))
+    for devices in (None, [0, 0]):
+        rule = cmf.MultUpdate(data, W0, H0, devices=devices)
+        try:
+            ref = rule.iterate(2)
+            for name, value in defaults.items():
+                if devices is not None and name.startswith("hals_"):
+                    continue  # (the HALS rule does not shard: its options belong to single handles)
+                rule.set_option(name, value)
+            with pytest.raises(cmf.CMFError):
+                rule.set_option("no_such_option", 1)
+            rule.upload(W0, H0)
+            assert np.array_equal(rule.iterate(2), ref)  # the defaults are the defaults
+        finally:
+            rule.close()

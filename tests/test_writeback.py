@@ -217,11 +217,13 @@ def test_hals_rerun_takes_h_again(cmf, oracle):
     W, H = caller_arrays(W0, H0)
     try:
         rule.update_motifs(data, W, H)
-        os.environ["CMF_HALS_DEBUG"] = "stall"
+        os.environ["CMF_TEST_HOOKS"] = "1"
         try:
+            rule.set_option("hals_debug", 3)
             rule.update_feature_maps(data, W, H)
+            rule.set_option("hals_debug", 0)
         finally:
-            os.environ.pop("CMF_HALS_DEBUG", None)
+            os.environ.pop("CMF_TEST_HOOKS", None)
         assert rule.counter("hals_pipeline_reruns") == 1
         Wd, Hd = rule.download()
         assert np.array_equal(W, Wd) and np.array_equal(H, Hd)

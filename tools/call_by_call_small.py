@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Call-by-call MU iterations (the reference's loop: update_motifs!, loss = update_feature_maps!) on small problems, where the host
 round trip per iteration matters: ms per iteration against the pipelined cmf_iterate.
-    python3 tools/call_by_call_small.py            (CMF_LOSS_POLL=0 / CMF_SPECULATE_W=0 switch the two latency measures off)"""
+    python3 tools/call_by_call_small.py [speculate=1]      (0: option "speculate" off; the polled loss word has no switch any more --
+round 5's comparison of both is profiles/r05_call_by_call_small.txt)"""
 import os
 import sys
 import time
@@ -14,6 +15,7 @@ for N, T, K, L in [(500, 2000, 5, 10), (250, 6250, 5, 20), (250, 50000, 5, 20), 
     data = cmf.gen_synthetic(N=N, T=T, seed=1234)
     W0, H0 = cmf.init_rand(data, L=L, K=K, seed=0)
     rule = cmf.MultUpdate(data, W0, H0)
+    rule.set_option("speculate", int(sys.argv[1]) if len(sys.argv) > 1 else 1)
     rule.iterate(20)
     best = 1e9
     for _ in range(5):
