@@ -198,6 +198,15 @@ struct cmf_handle_s {
     // "hals_general" (bit 0 / 1: the general W / H sweeps at any shape), "hals_seg" / "hals_lag" (the stage pipeline's segment length
     // and schedule), "hals_debug" (CMF_TEST_HOOKS=1 only: 3 = the pullers leave at once, so that every bounded wait must run out)
     int hals_opt_persist = 1, hals_opt_general = 0, hals_opt_seg = 384, hals_opt_lag = 2, hals_debug = 0;
+    // The residual conv CHASING the row pipeline (option "hals_chase" = per cent of its tile rows, 0 = off): the pipeline runs on a
+    // stream masked to the CUs its K + (K-1)P workgroups need, the first tile rows of the conv on a stream masked to the other CUs,
+    // each tile waiting for the last row's progress flag (conv3_chase_kernel); the rest of the conv follows on the whole chip.
+    int hals_opt_chase = 65;
+    hipStream_t hals_sA = nullptr, hals_sB = nullptr; // CU-masked: pipeline | chasing conv (created at the first chased sweep)
+    hipEvent_t hals_ev[3] = {nullptr, nullptr, nullptr}; // fork, pipeline done, chasing part done
+    int hals_mask_aper = 0;                 // CUs per XCD the pipeline's stream is masked to (the streams are remade when the plan changes)
+    int hals_cuB = 0;                       // CUs of the chasing stream (the launch plans its tail pieces for them)
+    int hals_chased_rows = 0, hals_chased_partials = 0; // tile rows / loss partials the chasing launch of the sweep in flight covers (0: none)
     int hals_pullers = 0;                   // persistent H pipeline: puller workgroups per row (0 = stage pipeline)
     int *hals_flags = nullptr;              // its progress flags (device)
     int *hals_status = nullptr;             // pinned host word: 1 = a wait of the persistent pipeline ran out
@@ -264,6 +273,7 @@ static int wb_after_H(cmf_handle_s *h); // hook: the kernels that make H final h
 static int gram_ensure(cmf_handle_s *h);
 static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
 static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked = false, bool loss_abs = false);
+static int hals_resid_and_loss(cmf_handle_s *h, double *sumsq);
 static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W);
 static int gram_w_partial(cmf_handle_s *h, float *hh_out);
 static int gram_w_finish(cmf_handle_s *h, const float *HH, double l1W, double l2W, const float *tail_src = nullptr, float *tail_dst = nullptr,
@@ -507,6 +517,10 @@ static void destroy_impl(cmf_handle_s *h)
     for (int v = 0; v < 2; ++v)
         if (h->tc_tab[v]) (void)hipFree(h->tc_tab[v]);
     if (mine(h->partial)) (void)hipFree(h->partial);
+    for (hipStream_t st : {h->hals_sA, h->hals_sB})
+        if (st) { if (!h->streams_may_hang) (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t e : h->hals_ev)
+        if (e) (void)hipEventDestroy(e);
     if (h->hals_flags) (void)hipFree(h->hals_flags);
     if (h->hals_status) (void)hipHostFree(h->hals_status);
     if (h->pgd_knorm) (void)hipFree(h->pgd_knorm);
@@ -791,6 +805,38 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
     } else hipLaunchKernelGGL((conv_kernel<MODE, 0>), grid, block, 0, h->stream, p);
     h->conv_partials = (int)(grid.x * grid.y);
     KCHK("conv_kernel");
+    return CMF_OK;
+}
+
+// The one-wave conv tiles of tile rows [row0, row0 + nrows) on h->stream (conv3_chase_kernel; K a multiple of 32): the tail of the
+// grid is cut into pieces for a chip of n_cu CUs like launch_conv does.  gate != NULL: every tile waits for *gate >= its row + 1 (the
+// HALS row pipeline's last progress flag) and reads H with agent-scope loads.  Loss partials pidx0 ... pidx0 + *npartials - 1.
+template <int MODE>
+static int launch_conv_rows(cmf_handle_s *h, float *out, int row0, int nrows, int pidx0, int n_cu, const int *gate, int *abort_word,
+                            int *host_status, int *npartials)
+{
+    ProfScope prof_(h, PROF_CONV_RESID);
+    const CmfDims &d = h->d;
+    ConvParams p;
+    p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = h->X; p.partial = h->partial; p.mask = h->M;
+    p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = d.Tl;
+    p.N = d.N;
+    p.loss_abs = 0;
+    const int gx3 = d.Np / 64, tiles3 = gx3 * nrows, slots3 = 12 * n_cu;
+    const int rem3 = tiles3 % slots3;
+    int cut = 0;
+    if (h->conv_split) {
+        if (rem3 > 0 && rem3 <= 3 * n_cu) cut = rem3;
+        if (tiles3 / slots3 >= 4) cut += 3 * n_cu;
+        cut = std::min(cut, tiles3);
+    }
+    const int n_full = tiles3 - cut;
+    const int pieces = (cut > 0 && cut < n_cu && h->conv_split != 4) ? 16 : 4;
+    const int grid = n_full + pieces * cut;
+    if ((size_t)(pidx0 + grid) > n_partial(h)) return fail(CMF_ERR_STATE, "internal: loss partial buffer too small for a split conv");
+    hipLaunchKernelGGL((conv3_chase_kernel<MODE>), dim3(grid), dim3(64), 0, h->stream, p, gx3, n_full, pieces, row0, pidx0, gate, abort_word, host_status);
+    KCHK("conv3_chase_kernel");
+    *npartials = grid;
     return CMF_OK;
 }
 
@@ -1668,7 +1714,7 @@ int cmf_set_stream(cmf_handle h, void *hip_stream)
 
 // every name cmf_set_option knows (cmf_option_names; tests/test_library_abi.py walks the table)
 static const char *const kOptionNames[] = {"reuse_est", "speculate", "gram", "conv_kernel", "conv_split", "small_k", "hals_prepare", "hals_gram",
-                                           "hals_persist", "hals_general", "hals_seg", "hals_lag", "hals_debug", "profile", "profile_mask",
+                                           "hals_persist", "hals_general", "hals_seg", "hals_lag", "hals_debug", "hals_chase", "profile", "profile_mask",
                                            "allreduce_overlap", "enqueue_threads"};
 int cmf_option_names(char *buf, int64_t len)
 {
@@ -1754,11 +1800,21 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         return CMF_OK;
     }
     if (std::strcmp(name, "hals_persist") == 0 || std::strcmp(name, "hals_general") == 0 || std::strcmp(name, "hals_seg") == 0 ||
-        std::strcmp(name, "hals_lag") == 0 || std::strcmp(name, "hals_debug") == 0) {
+        std::strcmp(name, "hals_lag") == 0 || std::strcmp(name, "hals_debug") == 0 || std::strcmp(name, "hals_chase") == 0) {
         if (value < 0) return fail(CMF_ERR_ARG, "%s must be >= 0", name);
         if (name[5] == 'd') { // "hals_debug": results are wrong by design -- tests of the bounded waits only
             if (value && !test_hooks_on()) return fail(CMF_ERR_STATE, "hals_debug needs CMF_TEST_HOOKS=1");
             h->hals_debug = value;
+            return CMF_OK;
+        }
+        if (name[5] == 'c') { // "hals_chase": per cent of the residual conv's tile rows that chase the row pipeline
+            if (value > 100) return fail(CMF_ERR_ARG, "hals_chase is a percentage (0 = off)");
+            h->hals_opt_chase = value;
+            if (h->hals_ready) {
+                HIPCHK(hipSetDevice(h->device));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                hals_plan(h);
+            }
             return CMF_OK;
         }
         HIPCHK(hipSetDevice(h->device));
@@ -1986,7 +2042,7 @@ static int hals_update_feature_maps_body(cmf_handle h, double l1H, double l2H, d
             CMFTRY(reduce_partials(h, h->partial, h->conv_partials, 0, &ss));
             set_est(h, 0);
         } else {
-            CMFTRY(resid_and_loss(h, &ss)); // ... and the residual kept for the next W phase
+            CMFTRY(hals_resid_and_loss(h, &ss)); // ... and the residual kept for the next W phase (part of it may have chased the sweep)
         }
         // (the loss has arrived: every kernel in front of its reduction has completed)  A bounded wait of the persistent H pipeline ran out:
         // redo the sweep from the snapshot on the stage pipeline and take the loss again; counted in "hals_pipeline_reruns"
@@ -2540,6 +2596,10 @@ static void hals_plan(cmf_handle_s *h)
         }
         if (P < 2 && d.K > 1) P = 0;
         if (P < 1) P = 0;
+        // With the residual conv chasing the pipeline (hals_chase_rows) a CU is worth more on the conv's side: three pullers per row
+        // instead of four cost the pipeline 1 % (1.44 -> 1.455 ms at config 5; two: 2.07 ms) and give the chasing launch 128 CUs
+        // instead of 96 (profiles/r06_hals_chase.txt: 4.35 -> 4.27 ms per iteration)
+        if (P == 4 && h->hals_opt_persist == 1 && h->hals_opt_chase > 0 && d.K % 32 == 0 && !h->small_k && d.Tl >= 4096) P = 3;
     }
     h->hals_pullers = P;
 }
@@ -2744,7 +2804,7 @@ static int hals_h_sweep_general(cmf_handle_s *h, HalsRowParams q)
 }
 
 // The whole H sweep as ONE persistent launch on h->stream (hals_h_persist_kernel): flags cleared, K sweepers + (K-1) * P pullers
-static int hals_persist_launch(cmf_handle_s *h, const HalsRowParams &q, int debug = 0, unsigned long long *stamps = nullptr)
+static int hals_persist_launch(cmf_handle_s *h, const HalsRowParams &q, int debug = 0, bool clear_flags = true)
 {
     const CmfDims &d = h->d;
     HalsPersistParams pp;
@@ -2754,14 +2814,91 @@ static int hals_persist_launch(cmf_handle_s *h, const HalsRowParams &q, int debu
     pp.host_status = h->hals_status;
     pp.K = d.K; pp.P = h->hals_pullers; pp.nblk = (d.Tl + 63) / 64;
     pp.debug = debug;
-    pp.stamps = stamps;
+    pp.stamps = nullptr;
     const size_t nflags = (size_t)(d.K + d.K * pp.P + 1) * HALS_FLAG_STRIDE;
     const size_t lds = std::max((size_t)(d.K - 1) * (2 * d.L - 1 + 64 + 2 * (d.L - 1)) + 1024, (size_t)h->hals_ne * (d.L + 1)) * sizeof(float);
     ProfScope prof_(h, PROF_HALS_PIPE);
-    HIPCHK(hipMemsetAsync(h->hals_flags, 0, nflags * sizeof(int), h->stream));
+    if (clear_flags) HIPCHK(hipMemsetAsync(h->hals_flags, 0, nflags * sizeof(int), h->stream));
     hipLaunchKernelGGL(hals_h_persist_kernel, dim3(d.K + (d.K - 1) * pp.P), dim3(1024), lds, h->stream, pp);
     KCHK("hals_h_persist_kernel");
     return CMF_OK;
+}
+
+// How many tile rows of the residual conv chase the row pipeline (0: none).  Needs the persistent pipeline, the one-wave conv
+// tiles (K a multiple of 32), the residual the conv stores (hals_gram != 1), and CUs left over beside the pipeline's.
+static int hals_chase_rows(cmf_handle_s *h)
+{
+    const CmfDims &d = h->d;
+    if (h->hals_opt_chase <= 0 || h->hals_pullers <= 0 || d.K % 32 != 0 || h->small_k || h->hals_gram == 1 || h->hals_debug == 1 || h->hals_debug == 2) return 0;
+    if (h->n_cu % 8 != 0 || h->n_cu > 256) return 0;
+    const int per_xcd = h->n_cu / 8, need = (d.K + (d.K - 1) * h->hals_pullers + 7) / 8;
+    if (per_xcd - need < 4) return 0;
+    const int rows_t = (d.Tl + 63) / 64;
+    if (rows_t < 64) return 0; // (short recordings: the pipeline's span is a few tile rows of conv)
+    return std::min(rows_t, (int)((long long)rows_t * std::min(h->hals_opt_chase, 100) / 100));
+}
+
+// The persistent sweep with the first `ra` tile rows of the residual conv (hals.jl:41's residual, the loss fused) chasing it.
+static int hals_persist_chased(cmf_handle_s *h, const HalsRowParams &q, int ra)
+{
+    const CmfDims &d = h->d;
+    const int per_xcd = h->n_cu / 8, a_per = (d.K + (d.K - 1) * h->hals_pullers + 7) / 8;
+    if (h->hals_sA && h->hals_mask_aper != a_per) { // (another puller count since: other masks)
+        for (hipStream_t *st : {&h->hals_sA, &h->hals_sB}) {
+            HIPCHK(hipStreamSynchronize(*st));
+            HIPCHK(hipStreamDestroy(*st));
+            *st = nullptr;
+        }
+    }
+    if (!h->hals_sA) {
+        // CU mask bit j = CU j / 8 of XCD j % 8 (profiles/r05_cu_mask_experiment.txt: cutting INSIDE every XCD partitions the chip cleanly)
+        uint32_t mask_a[8] = {0}, mask_b[8] = {0};
+        for (int j = 0; j < h->n_cu; ++j) (((j / 8) < a_per) ? mask_a : mask_b)[j / 32] |= 1u << (j % 32);
+        HIPCHK(hipExtStreamCreateWithCUMask(&h->hals_sA, 8, mask_a));
+        HIPCHK(hipExtStreamCreateWithCUMask(&h->hals_sB, 8, mask_b));
+        for (hipEvent_t &e : h->hals_ev)
+            if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->hals_cuB = 8 * (per_xcd - a_per);
+        h->hals_mask_aper = a_per;
+    }
+    hipStream_t keep = h->stream;
+    const size_t nflags = (size_t)(d.K + d.K * h->hals_pullers + 1) * HALS_FLAG_STRIDE;
+    HIPCHK(hipMemsetAsync(h->hals_flags, 0, nflags * sizeof(int), keep)); // (in front of the fork: both launches see cleared flags)
+    HIPCHK(hipEventRecord(h->hals_ev[0], keep));
+    HIPCHK(hipStreamWaitEvent(h->hals_sA, h->hals_ev[0], 0));
+    HIPCHK(hipStreamWaitEvent(h->hals_sB, h->hals_ev[0], 0));
+    int *prog_last = h->hals_flags + (size_t)(d.K - 1) * HALS_FLAG_STRIDE;
+    int *abort_word = h->hals_flags + (size_t)(d.K + d.K * h->hals_pullers) * HALS_FLAG_STRIDE;
+    h->stream = h->hals_sA;
+    int rc = hals_persist_launch(h, q, h->hals_debug, false);
+    h->stream = h->hals_sB;
+    int nA = 0;
+    if (rc == CMF_OK) rc = launch_conv_rows<4>(h, h->est, 0, ra, 0, h->hals_cuB, prog_last, abort_word, h->hals_status, &nA);
+    h->stream = keep;
+    CMFTRY(rc);
+    HIPCHK(hipEventRecord(h->hals_ev[1], h->hals_sA));
+    HIPCHK(hipEventRecord(h->hals_ev[2], h->hals_sB));
+    HIPCHK(hipStreamWaitEvent(keep, h->hals_ev[1], 0)); // H is final behind the pipeline; the chasing launch is joined in front of the
+                                                         // loss reduction (hals_resid_and_loss): the rest of the conv starts beside it
+    h->hals_chased_rows = ra;
+    h->hals_chased_partials = nA;
+    return CMF_OK;
+}
+
+// The residual and the loss behind an H sweep: all of the conv, or what the chasing launch has left (same tiles, same per-tile sums;
+// the partials of the two launches lie one behind the other and are added in that order: reproducible)
+static int hals_resid_and_loss(cmf_handle_s *h, double *sumsq)
+{
+    const CmfDims &d = h->d;
+    const int ra = h->hals_chased_rows, nA = h->hals_chased_partials, rows_t = (d.Tl + 63) / 64;
+    h->hals_chased_rows = h->hals_chased_partials = 0;
+    if (ra <= 0) return resid_and_loss(h, sumsq);
+    int nB = 0;
+    if (ra < rows_t) CMFTRY(launch_conv_rows<4>(h, h->est, ra, rows_t - ra, nA, h->n_cu, nullptr, nullptr, nullptr, &nB));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->hals_ev[2], 0));
+    h->conv_partials = nA + nB;
+    set_est(h, 2);
+    return reduce_partials(h, h->partial, h->conv_partials, 0, sumsq);
 }
 
 static int hals_h_enqueue(cmf_handle_s *h, double l1H, double l2H)
@@ -2786,6 +2923,8 @@ static int hals_h_enqueue(cmf_handle_s *h, double l1H, double l2H)
         if (!h->hals_snap) CMFTRY(dalloc_zero(&h->hals_snap, 2 * nH));
         HIPCHK(hipMemcpyAsync(h->hals_snap, h->H, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->hals_snap + nH, h->Ht, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        h->hals_chased_rows = h->hals_chased_partials = 0;
+        if (const int ra = hals_chase_rows(h)) return hals_persist_chased(h, q, ra);
         CMFTRY(hals_persist_launch(h, q, h->hals_debug));
         return CMF_OK;
     }
@@ -2807,6 +2946,7 @@ static int hals_h_rerun(cmf_handle_s *h)
     const CmfDims &d = h->d;
     const size_t nH = (size_t)d.TP * d.K32;
     *h->hals_status = 0;
+    h->hals_chased_rows = h->hals_chased_partials = 0;
     h->hals_pullers = 0;
     h->hals_opt_persist = 0; // (a later re-plan keeps to it)
     h->hals_reruns += 1;

@@ -81,6 +81,20 @@ struct ConvParams {
     int loss_abs; // residual modes (4-7) only: 1 = AbsoluteLoss (pgd.jl:41-47): store sign(est - data) [.* mask], sum |.|
 };
 
+// agent-scope accesses (global_load / global_store ... sc1): the hand-off forms of MI355X_MICROARCH.md "inter-workgroup visibility"
+__device__ __forceinline__ int cmf_load_sc1(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float cmf_load_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cmf_store_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cmf_store_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cmf_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// a float4 of a buffer another workgroup of a CONCURRENT kernel has published: four agent-scope loads (bypass this CU's L1)
+__device__ __forceinline__ f32x4 cmf_load4_sc1(const float *p)
+{
+    f32x4 v;
+    v[0] = cmf_load_sc1(p); v[1] = cmf_load_sc1(p + 1); v[2] = cmf_load_sc1(p + 2); v[3] = cmf_load_sc1(p + 3);
+    return v;
+}
+
 #define CONV_TRANSPOSED(MODE) ((MODE) == 1 || (MODE) == 5 || (MODE) == 7)
 #define CONV_HS_STRIDE 160
 #define CONV_HS_FLOATS (32 * CONV_HS_STRIDE)
@@ -525,7 +539,9 @@ __global__ __launch_bounds__(256, 3) void conv2_kernel(ConvParams p)
 // end of the launch shrink fourfold.  Main loop and epilogue are conv2's.
 // ---------------------------------------------------------------------------------------------
 #define CONV3_STRIDE 96
-template <int MODE, int NBL = 2, int NKP = 16, bool PREQ = false>
+// SC1: the H strip is read with agent-scope loads -- Ht is being written by a CONCURRENT kernel (the HALS row pipeline) whose
+// sweepers have published the tile's columns (conv3_chase_kernel)
+template <int MODE, int NBL = 2, int NKP = 16, bool PREQ = false, bool SC1 = false>
 __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t0, int n0, int lane, int pidx)
 {
     const int i = lane & 31, h = lane >> 5;
@@ -576,7 +592,8 @@ __device__ __forceinline__ void conv3_tile(const ConvParams &p, float *Hs, int t
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) v[q * 3 + j] = *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * j);
+                    for (int j = 0; j < 3; ++j)
+                        v[q * 3 + j] = SC1 ? cmf_load4_sc1(src + (size_t)(8 * q) * TP + 32 * j) : *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * j);
                 __builtin_amdgcn_wave_barrier(); // every lane is done reading the previous strip
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
@@ -704,7 +721,7 @@ __device__ __forceinline__ void convq_load_w(float (&w)[NKP], __amdgpu_buffer_rs
 
 // A quarter tile: one wave, one 32 (t) x 32 (n) block at (t0, n0); H strip = 32 k rows x 64 columns (32 + the 32-lag halo)
 // NKP: k pairs per lag that hold data (16 = a whole k block; the few-component kernel passes ceil(K / 2): rows k >= K of Ht and Wt are zero)
-template <int MODE, int NKP = 16>
+template <int MODE, int NKP = 16, bool SC1 = false>
 __device__ __forceinline__ void conv3_quarter(const ConvParams &p, float *Hs, int t0, int n0, int lane, int pidx)
 {
     const int i = lane & 31, h = lane >> 5;
@@ -732,7 +749,8 @@ __device__ __forceinline__ void conv3_quarter(const ConvParams &p, float *Hs, in
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) v[q * 2 + j] = *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * j);
+                    for (int j = 0; j < 2; ++j)
+                        v[q * 2 + j] = SC1 ? cmf_load4_sc1(src + (size_t)(8 * q) * TP + 32 * j) : *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * j);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
@@ -860,7 +878,7 @@ __device__ __forceinline__ void conv16_load_w(float (&w)[8], __amdgpu_buffer_rsr
     for (int ks = 0; ks < 8; ++ks) w[ks] = cmf_bload(wr, woff, lag * lagbytes + ks * 4 * rowbytes);
 }
 
-template <int MODE>
+template <int MODE, bool SC1 = false>
 __device__ __forceinline__ void conv3_sixteenth(const ConvParams &p, float *Hs, int t0, int n0, int lane, int pidx)
 {
     const int j = lane & 15, kq = lane >> 4;
@@ -887,7 +905,8 @@ __device__ __forceinline__ void conv3_sixteenth(const ConvParams &p, float *Hs, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) v[q * 2 + jj] = *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * jj);
+                    for (int jj = 0; jj < 2; ++jj)
+                        v[q * 2 + jj] = SC1 ? cmf_load4_sc1(src + (size_t)(8 * q) * TP + 32 * jj) : *reinterpret_cast<const f32x4 *>(src + (size_t)(8 * q) * TP + 32 * jj);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -929,6 +948,50 @@ __global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p, int gx, int 
     } else {
         const int q = b - n_full, tile = n_full + (q >> 4), sub = q & 15;
         conv3_sixteenth<MODE>(p, Hs, (tile / gx) * 64 + (sub >> 2) * 16, (tile % gx) * 64 + (sub & 3) * 16, threadIdx.x, b);
+    }
+}
+
+// conv3_kernel on tile rows [row0, ...) of the recording, optionally CHASING the HALS row pipeline (hals_h_persist_kernel) that is
+// still writing H on other CUs: tile row r (columns 64 r .. 64 r + 63) reads H[:, 64 r - (L-1) .. 64 r + 63], final once the sweeper of
+// the LAST row of H has published block r (rows above are further ahead by construction of the pipeline, and a sweeper publishes a
+// block only after its agent-scope stores of H and D have completed).  gate != NULL: every workgroup first waits -- bounded, like
+// every wait of the pipeline -- until *gate >= r + 1, then reads the strip with agent-scope loads.  A wait that runs out, or a
+// pipeline that has aborted, ends the workgroup without output: the host sees the status word and redoes sweep and conv.
+// gate == NULL: plain offset tiles (the part of the conv that runs behind the pipeline).  pidx0: first loss partial of this launch.
+template <int MODE>
+__global__ __launch_bounds__(64, 3) void conv3_chase_kernel(ConvParams p, int gx, int n_full, int pieces, int row0, int pidx0,
+                                                            const int *gate, int *abort_word, int *host_status)
+{
+    __shared__ __attribute__((aligned(16))) float Hs[32 * CONV3_STRIDE];
+    const int b = blockIdx.x;
+    const int tile = b < n_full ? b : n_full + ((b - n_full) >> (pieces == 4 ? 2 : 4));
+    const int row = row0 + tile / gx, n0 = (tile % gx) * 64;
+    if (gate) {
+        bool ok = false;
+#pragma nounroll
+        for (int n = 0; n < (1 << 19); ++n) { // ~2 s: three orders of magnitude above the pipeline's span
+            const int v = cmf_load_sc1(gate), a = cmf_load_sc1(abort_word);
+            ok = v >= row + 1;
+            if ((int)ok | (int)(a != 0)) break;
+            __builtin_amdgcn_s_sleep(100); // (~3 us: a thousand waiting waves must not flood the flag's channel)
+        }
+        if (!ok) {
+            if (threadIdx.x == 0) {
+                cmf_store_sc1(abort_word, 1);
+                __hip_atomic_store(host_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+    }
+    if (b < n_full) {
+        if (n0 + 32 < p.N) conv3_tile<MODE, 2, 16, false, true>(p, Hs, row * 64, n0, threadIdx.x, pidx0 + b);
+        else conv3_tile<MODE, 1, 16, false, true>(p, Hs, row * 64, n0, threadIdx.x, pidx0 + b);
+    } else if (pieces == 4) {
+        const int sub = (b - n_full) & 3;
+        conv3_quarter<MODE, 16, true>(p, Hs, row * 64 + (sub >> 1) * 32, n0 + (sub & 1) * 32, threadIdx.x, pidx0 + b);
+    } else {
+        const int sub = (b - n_full) & 15;
+        conv3_sixteenth<MODE, true>(p, Hs, row * 64 + (sub >> 2) * 16, n0 + (sub & 3) * 16, threadIdx.x, pidx0 + b);
     }
 }
 
@@ -1933,11 +1996,6 @@ __device__ __forceinline__ float cmf_lane0(float v)
 // other loop leaves on seeing it, so the grid always drains.
 #define HALS_FLAG_STRIDE 32      // ints: one 128-byte line per flag
 #define HALS_POLL_LIMIT (1 << 21) // ~2 s of polling: three orders of magnitude above the longest legitimate wait
-__device__ __forceinline__ int cmf_load_sc1(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float cmf_load_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void cmf_store_sc1(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void cmf_store_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void cmf_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // wait until *flag >= need; false when the pipeline was aborted (or this wait ran out and aborted it)
 __device__ __forceinline__ bool hals_wait_flag(const int *flag, int need, int *abort_word, int *host_status)
@@ -1961,6 +2019,7 @@ struct HalsNoSync {
     static constexpr bool PERSIST = false;
     __device__ __forceinline__ float load_p(const float *p) const { return *p; }
     __device__ __forceinline__ void store_d(float *p, float v) const { *p = v; }
+    __device__ __forceinline__ void store_h(float *p, float v) const { *p = v; }
     __device__ __forceinline__ bool gate(int) const { return true; }
     __device__ __forceinline__ int gate_issue(int) const { return 0; }
     __device__ __forceinline__ bool gate_check(int, int) const { return true; }
@@ -1980,6 +2039,9 @@ struct HalsFlagSync {
     __device__ __forceinline__ void stamp(int blk) const { if (stamps && threadIdx.x == 0) stamps[blk] = __builtin_amdgcn_s_memrealtime(); }
     __device__ __forceinline__ float load_p(const float *p) const { return cmf_load_sc1(p); }
     __device__ __forceinline__ void store_d(float *p, float v) const { cmf_store_sc1(p, v); }
+    // H' (the conv's operand layout) is stored agent-scope too: a conv launch on other CUs may be chasing the last row's progress flag
+    // (conv3_chase_kernel) and reads the columns a sweeper has published while this kernel is still running
+    __device__ __forceinline__ void store_h(float *p, float v) const { cmf_store_sc1(p, v); }
     __device__ __forceinline__ bool gate(int c) const // block c of this row's P is complete
     {
         if (!pulled || c >= nblk) return true;
@@ -2048,7 +2110,7 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
         int tb_prev = -1;
         auto store_prev = [&]() {
             if (tb_prev < 0) return;
-            Hrow[tb_prev + lane] = hnew_prev;
+            sy.store_h(Hrow + tb_prev + lane, hnew_prev);
             q.H[(size_t)(q.PADL + tb_prev + lane) * q.K32 + k] = hnew_prev;
             sy.store_d(q.D + tb_prev + lane, dvec_prev);
         };
@@ -2152,7 +2214,7 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
     // holds the column t' with t' % 64 == j; the taps rotate instead of the window.
     if (t_first >= t_stop) {
         if (t_first > tb && tb + lane < t_first) { // (L = 1: no edge) the partial block closed the row
-            Hrow[tb + lane] = hnew0;
+            sy.store_h(Hrow + tb + lane, hnew0);
             q.H[(size_t)(q.PADL + tb + lane) * q.K32 + k] = hnew0;
             sy.store_d(q.D + tb + lane, dreg0);
         }
@@ -2179,7 +2241,7 @@ __device__ __forceinline__ void hals_h_row_sweep(const HalsRowParams &q, int lan
         if (idx == 63 || t == t_stop - 1) {
             const int t0 = t - idx;
             if (t0 + lane < q.Tl) {
-                Hrow[t0 + lane] = hnew;
+                sy.store_h(Hrow + t0 + lane, hnew);
                 q.H[(size_t)(q.PADL + t0 + lane) * q.K32 + k] = hnew;
                 sy.store_d(q.D + t0 + lane, dreg);
             }

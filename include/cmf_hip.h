@@ -221,6 +221,13 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       tests compare them); they exist for tests and measurements.  "hals_debug" (needs CMF_TEST_HOOKS=1; results are WRONG by
  *       design): 3 = the pullers of the persistent launch leave at once, so that every bounded wait runs out (the test of that
  *       path); 1 / 2 = no gating / pullers skip their work (timing).
+ *   "hals_chase" (default 65; 0 = off): per cent of the tile rows of the residual conv behind the H sweep (hals.jl:41: the residual
+ *       and the loss) that CHASE the persistent row pipeline instead of waiting for it: the pipeline (K + 4 (K-1) workgroups, VALU
+ *       only) runs on a stream masked to the CUs it needs, those tile rows on a stream masked to the others, each tile waiting for
+ *       the last row's progress flag; the rest of the conv follows on the whole chip (the pipeline then runs with three pullers per row instead of four: +1 % of its
+ *       span for 32 more CUs on the conv's side).  The same arithmetic per tile (the two launches cut
+ *       other tiles of their grids' tails into pieces: sums agree to rounding; run to run the results are bit for bit the same).
+ *       K a multiple of 32, T >= 4096.
  *   "hals_gram" (default 2): where the HALS sweeps' projections come from.  2 = P of the H phase as denomH - numH of the MU
  *       quantities (one conv launch less; H within the residual form's accuracy), G of the W phase contracted from the
  *       stored residual; 0 = both from the residual; 1 = both as differences (no residual at all, but about 20x the

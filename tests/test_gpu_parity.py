@@ -478,7 +478,7 @@ def test_hals_config5_full_size(cmf, config2):
 
     data, W0, H0 = config2
     runs = {}
-    for name, opts in (("persist", {}), ("persist2", {"hals_persist": 2}),
+    for name, opts in (("persist", {}), ("persist2", {"hals_persist": 2}), ("nochase", {"hals_chase": 0}),
                        ("stage256", {"hals_persist": 0, "hals_seg": 256}),
                        ("stage1024", {"hals_persist": 0, "hals_seg": 1024}),
                        ("stage384lag3", {"hals_persist": 0, "hals_seg": 384, "hals_lag": 3}),
@@ -985,4 +985,66 @@ def test_hals_persistent_pipeline_waits_are_bounded(cmf, oracle):
     loss2 = rule.update_feature_maps()
     assert rule.counter("hals_pipeline_reruns") == 1
     assert abs(loss2 - lh[2]) <= 1e-4 * lh[2]
+    rule.close()
+
+
+def test_hals_residual_conv_chasing_the_row_pipeline(cmf, oracle):
+    """Option "hals_chase": the first tile rows of the residual conv run on the CUs the persistent H pipeline leaves free, each tile
+    waiting for the LAST row's progress flag and reading H with agent-scope loads while the pipeline is still sweeping.  Same
+    arithmetic per tile as the one-launch conv: W, H and the losses are those of chase = 0 to rounding, run to run bit for bit, and
+    the oracle's."""
+    N, T, K, L = 130, 9000, 32, 20
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=20, seed=3)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=1)
+    out = {}
+    for name, chase in (("off", 0), ("on", 65), ("on2", 65), ("most", 95)):
+        rule = cmf.HALSUpdate(data, W0, H0)
+        rule.set_option("hals_chase", chase)
+        ls = []
+        for _ in range(3):
+            rule.update_motifs(l1W=0.05, l2W=0.1)
+            ls.append(rule.update_feature_maps(l1H=0.05, l2H=0.1))
+        assert rule.counter("hals_pipeline_reruns") == 0
+        out[name] = (np.array(ls),) + rule.download()
+        rule.close()
+    for a, b in zip(out["on"], out["on2"]):
+        assert np.array_equal(a, b)  # reproducible
+    for name in ("on", "most"):
+        # (the chased form runs three pullers per row instead of four: the cross-row sums are associated differently -- rounding level)
+        np.testing.assert_allclose(out[name][0], out["off"][0], rtol=1e-6)
+        assert frob_rel(out[name][1], out["off"][1]) < 1e-6 and frob_rel(out[name][2], out["off"][2]) < 1e-6
+    Wr, Hr, lr, _ = oracle.c_fit_hals(data, W0, H0, max_itr=3, check_convergence=False, l1W=0.05, l2W=0.1, l1H=0.05, l2H=0.1)
+    np.testing.assert_allclose(out["on"][0], lr[1:], rtol=1e-4)
+    assert frob_rel(out["on"][1], Wr) < 1e-4 and frob_rel(out["on"][2], Hr) < 1e-4
+
+
+def test_hals_chasing_conv_leaves_when_the_pipeline_aborts(cmf, oracle):
+    """The chasing tiles' waits are bounded like the pipeline's own: when the pipeline aborts (its pullers leave at once: every
+    sweeper's wait runs out) the chasing launch sees the abort word and drains, the sweep and the conv are redone, the result is the
+    unchased one's."""
+    import os
+
+    N, T, K, L = 40, 5000, 32, 8
+    data, _, _ = oracle.c_gen_synthetic(N=N, T=T, K=3, L=8, seed=5)
+    W0, H0 = oracle.c_init_rand(data, L=L, K=K, seed=2)
+    ref = cmf.HALSUpdate(data, W0, H0)
+    ref.set_option("hals_chase", 0)
+    ref.update_motifs()
+    want = ref.update_feature_maps()
+    Wref, Href = ref.download()
+    ref.close()
+    rule = cmf.HALSUpdate(data, W0, H0)
+    rule.update_motifs()
+    os.environ["CMF_TEST_HOOKS"] = "1"
+    try:
+        rule.set_option("hals_debug", 3)
+        got = rule.update_feature_maps()
+        rule.set_option("hals_debug", 0)
+    finally:
+        os.environ.pop("CMF_TEST_HOOKS", None)
+    assert rule.counter("hals_pipeline_reruns") == 1
+    Wg, Hg = rule.download()
+    assert abs(got - want) <= 1e-6 * want and frob_rel(Hg, Href) < 1e-6 and np.array_equal(Wg, Wref)  # (W: the same first W sweep)
+    rule.update_motifs()
+    rule.update_feature_maps()  # the handle stays usable
     rule.close()
