@@ -18,13 +18,15 @@ for it in range(n):
     rule.upload(W1, H0)
     loss = rule.update_feature_maps()
     _, H = rule.download()
+    rule.update_motifs()  # reads the residual the conv behind the sweep stored -- most of it by tiles CHASING the sweep (option
+    W2, _ = rule.download()  # hals_chase): a tile that ever read a column of H before it was final shows up in the loss and here
     if ref is None:
-        ref, ref_loss = H.copy(), loss
-    elif not (np.array_equal(H, ref) and loss == ref_loss):
+        ref, ref_loss, ref_W2 = H.copy(), loss, W2.copy()
+    elif not (np.array_equal(H, ref) and loss == ref_loss and np.array_equal(W2, ref_W2)):
         bad += 1
         d = np.argwhere(H != ref)
         print(f"run {it}: {len(d)} entries differ, first at {d[:3].tolist()}, max |diff| {np.abs(H - ref).max():.3e}, loss {loss} vs {ref_loss}", flush=True)
-print(f"{n} H sweeps at N={N}, T={T}, K={K}, L={L}: {bad} differ from the first")
+print(f"{n} H sweeps (+ the chasing residual conv and the W sweep that reads its residual) at N={N}, T={T}, K={K}, L={L}: {bad} differ from the first", flush=True)
 
 # the small shapes of the parity tests, whole iterations (W and H phases), 60 repeats each
 shapes = [(12, 40, 3, 6), (48, 300, 4, 8), (30, 70, 2, 1), (9, 5, 2, 8), (130, 700, 32, 20), (37, 200, 33, 7), (200, 1500, 5, 10),
