@@ -49,7 +49,8 @@ for arg in sys.argv[1:] or ["0", "30", "40", "45", "50", "55", "60"]:
         rule.update_feature_maps()
     pipe, _ = rule.kernel_times("hals_h_pipeline")
     conv, nconv = rule.kernel_times("conv_resid")
-    print(f"hals_chase={arg:>5s}: {1e3 * dt:.3f} ms per HALS iteration; pipeline {pipe:.3f} ms, conv launches {conv:.3f} ms (mean of {nconv}); "
+    wsw, _ = rule.kernel_times("hals_w_sweep")
+    print(f"hals_chase={arg:>5s}: {1e3 * dt:.3f} ms per HALS iteration; W sweep {wsw:.3f} ms, pipeline {pipe:.3f} ms, conv launches {conv:.3f} ms (mean of {nconv}); "
           f"first 3 iterations against the first run: loss {dl:.1e}, W {dw:.1e}, H {dh:.1e}; reruns {rule.counter('hals_pipeline_reruns')}; loss {loss:.6f}",
           flush=True)
     rule.close()
