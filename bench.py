@@ -875,7 +875,7 @@ def measure(args, form, progress):
     probe = None
     sharded = alg == "mult" and ngpu > 1
     if sharded:
-        # Two forms of the W phase exist (cmf_group.h): one all-reduce of [numW | denomW] after both contractions, or
+        # Two forms of the W phase exist (cmf_groups.hip): one all-reduce of [numW | denomW] after both contractions, or
         # numW contracted and all-reduced right after the H update, underneath the loss conv and the denominator
         # contraction.  "0" (default): everything on one stream, the plain single all-reduce; "1": the overlap form;
         # "probe": time a few steps of each (max over ranks, so every rank takes the same decision), keep the faster.

@@ -1,296 +1,12 @@
-// cmf_api.hip -- host side of libcmf_hip.so: the C ABI of include/cmf_hip.h over the gfx950
-// kernels in cmf_kernels.h.  No CPU fallback exists: every compute entry needs a HIP device.
-#include "cmf_hip.h"
-#include "cmf_kernels.h"
-#include "cmf_rng.h"
-#include "cmf_writeback.h"
+// cmf_api.hip -- the C ABI of include/cmf_hip.h for the MU rule, handles, launchers of the MU kernels, write-back, measurement.
+// (round 6: one of three translation units -- cmf_rules.hip holds the HALS / Gram / PGD rules, cmf_groups.hip the T-sharded groups;
+// cmf_internal.h what they share.)
+#include "cmf_internal.h"
 
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <functional>
-#include <map>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-
-// ------------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-
-static int fail(int code, const char *fmt, ...)
-{
-    char buf[1024];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
-
-// The library's test hooks (include/cmf_hip.h lists them): integer variables of the environment that count ONLY together with
-// CMF_TEST_HOOKS=1, so that a stray variable in a production environment changes nothing.  Read by the calling thread at public
-// entries only (getenv is not safe against a concurrent setenv of the host program).
-static bool test_hooks_on()
-{
-    const char *hooks = getenv("CMF_TEST_HOOKS");
-    return hooks && atoi(hooks) == 1;
-}
-static long long test_hook(const char *name, long long dflt)
-{
-    if (!test_hooks_on()) return dflt;
-    const char *e = getenv(name);
-    return e ? atoll(e) : dflt;
-}
-
-#define HIPCHK(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
-            return fail(CMF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-#define KCHK(name)                                                                                \
-    do {                                                                                          \
-        hipError_t e_ = hipGetLastError();                                                        \
-        if (e_ != hipSuccess)                                                                     \
-            return fail(CMF_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_));     \
-    } while (0)
-#define CMFTRY(expr)              \
-    do {                          \
-        int rc_ = (expr);         \
-        if (rc_ != CMF_OK) return rc_; \
-    } while (0)
-
-static inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-
-// ------------------------------------------------------------------------------------------
-// roctx ranges (tracing)
-// ------------------------------------------------------------------------------------------
-// The phases of an iteration and every collective are bracketed with roctx ranges on the thread that enqueues them, so that
-// a `rocprofv3 --marker-trace --kernel-trace` timeline of a multi-GPU run reads as "W phase | all-reduce | H phase | halo
-// all-gather | loss conv" per shard.  The marker library is bound at run time and only when it is wanted: a copy the
-// process has already mapped (the profiler preloads it) is used, CMF_ROCTX=1 loads it on request; otherwise a range is
-// two predictable branches.
-#include <dlfcn.h>
-struct RoctxApi {
-    int (*push)(const char *) = nullptr;
-    int (*pop)() = nullptr;
-};
-static const RoctxApi &roctx_api()
-{
-    static const RoctxApi api = [] {
-        RoctxApi a;
-        const char *env = getenv("CMF_ROCTX");
-        if (env && atoi(env) == 0 && *env) return a; // CMF_ROCTX=0: never
-        void *dl = nullptr;
-        for (const char *nm : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
-            dl = dlopen(nm, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
-            if (dl) break;
-        }
-        if (!dl && env && atoi(env) == 1)
-            for (const char *nm : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/libroctx64.so.4"}) {
-                dl = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-                if (dl) break;
-            }
-        if (!dl) return a;
-        a.push = reinterpret_cast<int (*)(const char *)>(dlsym(dl, "roctxRangePushA"));
-        a.pop = reinterpret_cast<int (*)()>(dlsym(dl, "roctxRangePop"));
-        if (!a.push || !a.pop) a.push = nullptr, a.pop = nullptr;
-        return a;
-    }();
-    return api;
-}
-struct RoctxRange {
-    bool on;
-    explicit RoctxRange(const char *name) : on(roctx_api().push != nullptr)
-    {
-        if (on) roctx_api().push(name);
-    }
-    RoctxRange(const char *fmt, int a) : on(roctx_api().push != nullptr)
-    {
-        if (!on) return;
-        char buf[96];
-        snprintf(buf, sizeof(buf), fmt, a);
-        roctx_api().push(buf);
-    }
-    ~RoctxRange()
-    {
-        if (on) roctx_api().pop();
-    }
-};
-
-// ------------------------------------------------------------------------------------------
-// handle
-// ------------------------------------------------------------------------------------------
-struct cmf_handle_s {
-    int device = 0;
-    CmfDims d{};
-    int64_t t_offset = 0, T_global = 0;
-    int halo_r = 0;       // data / H right halo columns actually present (0 on the last shard)
-    bool has_left = false; // a left neighbour exists (t_offset > 0)
-    bool sharded = false;
-
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-
-    float *H = nullptr, *Ht = nullptr, *Wt = nullptr, *Wn = nullptr;
-    float *X = nullptr, *XT = nullptr, *est = nullptr, *estT = nullptr;
-    float *wslabs = nullptr; // [nchunks][2][L][K32][Np]
-    float *numden = nullptr; // [2][L][K32][Np]   (summed; the all-reduce buffer)
-    float *numden_own = nullptr;
-    float *hslabs = nullptr; // [S][2][Tl][K32]
-    float *halo[4] = {nullptr, nullptr, nullptr, nullptr};
-    float *halo_own[4] = {nullptr, nullptr, nullptr, nullptr};
-    double *partial = nullptr; // loss partials
-    double *d_scalar = nullptr; // device double[4]
-    double *d_scalar_own = nullptr;
-    double *h_scalar = nullptr; // pinned host double[4]
-    double *stage = nullptr;    // fp64 staging for layout conversion
-    size_t stage_elems = 0;
-
-    // launch plans
-    int hxt_LP = 1, hxt_groups = 1, hxt_nchunks = 1, hxt_chunk_len = 2;
-    int tc_LT = 4, tc_S = 1, tc_W = 4;   // fragment slabs and participating waves of the two-source transconv
-    int tc_S1 = 1, tc_W1 = 4;            // ... when only one source is contracted
-    std::vector<int4> tc_tab_host[2];    // per-wave work tables of the two variants ([0]: two sources, [1]: one)
-    int4 *tc_tab[2] = {nullptr, nullptr};
-    int hxt_nchunks1 = 1, hxt_chunk_len1 = 6; // time chunks when only one source is contracted
-    int hxt_main = 0, hxt_main1 = 0;          // rows the C2 kernel contracts in the two forms; the < 6*LP rows behind them are added by the slab sum
-    // few components (K <= 16): the contractions on the flattened (lag, component) index (cmf_small_k.h)
-    bool small_k = false;                   // option "small_k" (default on where the shape allows it)
-    bool small_k_ok = false;                // the shape allows it
-    bool sk_tc_ok = false, sk_tc = false;   // ... and its C3 form (G GEMM + fold) has enough columns to fill the chip; sk_tc: in use
-    int sk_J = 0, sk_JP = 0, sk_MG = 1, sk_MBW = 4, sk_chunk_len = 16, sk_ngroups = 1, sk_TG = 128;
-    int sk_RV = 0;                          // C2: the last sk_RV rows j on the VALU instead of in a padded MFMA block (hxt_small_kernel)
-    int sk3_MG = 1, sk3_MBW = 4, sk3_Kg = 1, sk3_JP = 128; // C3: whole components per row group (g_gemm_fold_small_kernel)
-    int sk3_NS = 1, sk3_RPS = 1;            // short recordings: C3's reduction over n in sk3_NS pieces of sk3_RPS rounds of 8 rows (2 slabs per piece)
-    int sk3_GR = 128, sk3_RV = 0;           // rows of a row group in Wj (32-row blocks); the last sk3_RV live rows on the VALU (sk3_MBW then counts the MFMA blocks only)
-    float *sk_slabs = nullptr, *sk_Wj = nullptr;
-    int64_t sk_wj_gen = -1;                 // est_gen at which sk_Wj was packed from the resident W (w_update_small_kernel, wj_pack_kernel): every writer of W
-                                            // passes through set_est, so a stale operand cannot be taken for a fresh one (-1: never packed)
-    int tc_S_full = 1, tc_S1_full = 1;      // fragment slabs of the general transconv kernel (tc_S / tc_S1 are 1 while small_k is on)
-    int conv_gx = 1, conv_gy = 1, conv_gy_ext = 1;
-    int conv_variant = 0;   // K % 32 == 0: 3 = one-wave workgroups (conv3_kernel), 2 = 128 x 128 tiles (conv2_kernel), 0 = per mode
-    int conv_partials = 1;  // loss partials written by the last conv launch
-    int conv_split = 1;     // option "conv_split": 0 = whole tiles only, 1 = quarter / sixteenth tiles for the thin last round of the
-                            // one-wave conv kernel, 4 = quarter tiles only
-    int n_cu = 256;
-
-    // HALS scratch (allocated on first use)
-    bool hals_ready = false;
-    bool gram_ready = false;                // the scratch the Gram form and HALS share (gram_ensure)
-    int hals_NpH = 0, hals_NpC = 0, hals_TPp = 0, hals_ne = 0, hals_t_edge0 = 0, hals_nch = 1, hals_clen = 6;
-    float *hals_HX = nullptr, *hals_cslabs = nullptr, *hals_C = nullptr, *hals_HH = nullptr, *hals_PT = nullptr, *hals_D = nullptr;
-    float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr, *hals_GWt = nullptr;
-    int hals_seg = 256, hals_nseg = 1;      // column segments of the pipelined H sweep
-    int hals_gram = 2;                      // the sweeps' projections as differences of the MU quantities: 2 = P of the H phase only (default:
-                                            // one conv launch fewer, H within the residual form's bars), 1 = G of the W phase too (~20x the rounding
-                                            // error in W: opt-in), 0 = both contracted from the stored residual
-    bool hals_w_general = false, hals_h_general = false; // shapes beyond the on-chip sweeps' limits: the general sweep kernels
-    // options "hals_persist" (1 = the persistent pipeline where it fits, 0 = the stage pipeline, n > 1 = at most n pullers per row),
-    // "hals_general" (bit 0 / 1: the general W / H sweeps at any shape), "hals_seg" / "hals_lag" (the stage pipeline's segment length
-    // and schedule), "hals_debug" (CMF_TEST_HOOKS=1 only: 3 = the pullers leave at once, so that every bounded wait must run out)
-    int hals_opt_persist = 1, hals_opt_general = 0, hals_opt_seg = 384, hals_opt_lag = 2, hals_debug = 0;
-    // The residual conv CHASING the row pipeline (option "hals_chase" = per cent of its tile rows, 0 = off): the pipeline runs on a
-    // stream masked to the CUs its K + (K-1)P workgroups need, the first tile rows of the conv on a stream masked to the other CUs,
-    // each tile waiting for the last row's progress flag (conv3_chase_kernel); the rest of the conv follows on the whole chip.
-    int hals_opt_chase = 65;
-    hipStream_t hals_sA = nullptr, hals_sB = nullptr; // CU-masked: pipeline | chasing conv (created at the first chased sweep)
-    hipEvent_t hals_ev[3] = {nullptr, nullptr, nullptr}; // fork, pipeline done, chasing part done
-    int hals_mask_aper = 0;                 // CUs per XCD the pipeline's stream is masked to (the streams are remade when the plan changes)
-    int hals_cuB = 0;                       // CUs of the chasing stream (the launch plans its tail pieces for them)
-    int hals_chased_rows = 0, hals_chased_partials = 0; // tile rows / loss partials the chasing launch of the sweep in flight covers (0: none)
-    int hals_pullers = 0;                   // persistent H pipeline: puller workgroups per row (0 = stage pipeline)
-    int *hals_flags = nullptr;              // its progress flags (device)
-    int *hals_status = nullptr;             // pinned host word: 1 = a wait of the persistent pipeline ran out
-    float *hals_snap = nullptr;             // [2][TP][K32]: H and Ht as they were when the persistent sweep started
-    double hals_l1 = 0.0, hals_l2 = 0.0;    // regularisers of the sweep in flight (for a rerun)
-    int64_t hals_reruns = 0;                // H sweeps redone on the stage pipeline after such an expiry (cmf_get_counter)
-
-    // PGD rule state (pgd.jl:139-154)
-    double pgd_stepW = 5.0, pgd_stepH = 5.0, pgd_cur_loss = -1.0;
-    float *pgd_gradH = nullptr;
-    int pgd_loss_abs_now = 0;  // loss kind of the residual conv being launched (set by resid_and_loss / the PGD H phase)
-    int pgd_loss_abs = 0;      // 0 SquareLoss (pgd.jl:29-36), 1 AbsoluteLoss (pgd.jl:41-47)
-    double *pgd_knorm = nullptr; // [K32] per-component sums of squares of UnitNormConstraint (pgd.jl:100-110)
-    float *M = nullptr, *MT = nullptr; // mask of MaskedLoss (pgd.jl:58-70) in the layouts of X and XT; null = no mask
-
-    double data_sumsq = 0.0, data_norm = 0.0;
-    bool factors_set = false;
-    bool have_data = false;
-    bool reuse_est = true;  // option "reuse_est"
-    int gram = 0;           // option "gram": 0 off, 1 Gram-form denominators, 2 also the loss from Gram sums
-    float *gram_numden_h = nullptr; // [1][2][Tl][K32]: numH | denomH in the h_update slab layout
-    // in-loop kernel timing (option "profile"): HIP event pairs around the contraction launches, on the launch stream
-    bool prof = false;
-    int prof_every = 1;          // bracket every n-th launch of a class (option value n)
-    int prof_seen[32] = {0};
-    struct ProfRec { hipEvent_t a, b; int cls; };
-    unsigned prof_mask = 0; // option "profile_mask"
-    std::vector<ProfRec> prof_recs;
-    std::vector<hipEvent_t> prof_pool;
-    int est_kind = 0;       // what est[t][n] holds for the resident W, H: 0 nothing, 1 tensor_conv(W,H), 2 tensor_conv(W,H) - data, 3 mask .* (tensor_conv(W,H) - data),
-                            // 4 sign(tensor_conv(W,H) - data), 5 mask .* sign(...)  (the AbsoluteLoss gradient)
-    void *arena = nullptr;  // the small buffers of the handle as ONE device allocation (cmf_create): 21 hipFree calls cost 1.3 ms, one 0.16
-    size_t arena_bytes = 0;
-    bool streams_may_hang = false;  // set on the shards of a FAILED group: their streams are not waited for when they are given back
-    int64_t est_gen = 0;    // counts the assignments of est_kind (set_est): whatever changes H, W or est passes through one
-    int64_t spec_gen = -1;  // est_gen for which the C2 contraction of the NEXT update_motifs! has already been enqueued (w_speculate); -1: none
-    int last_rule_call = 0; // 1: cmf_update_motifs, 2: cmf_update_feature_maps (MU rule, single handle): speculation follows the alternation only
-    bool speculate = true;  // option "speculate"
-    int64_t spec_hits = 0;  // update_motifs! calls that found their contraction done (cmf_get_counter "speculated_contractions")
-
-    // T-sharded groups (cmf_group.h): the handle the caller holds fronts a group when `group` is set
-    struct cmf_group_s *group = nullptr;
-    bool root_only = false;               // cmf_create_multi's front handle: no device state of its own
-    hipStream_t own_comm_stream = nullptr, comm_stream = nullptr; // overlap form: the numW all-reduce runs here
-    hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;
-    // pipelined loss read-back of cmf_iterate (single handle): two pinned slots + events
-    double *h_ring = nullptr;
-    bool dev_stamps = false;              // set by cmf_fit around its pipelined batch: time_hist from HIP timing events on the stream
-    CmfLossCarry carry{};                 // a loss reduction waiting for the next W phase's slab sum (cmf_iterate only)
-    CmfWriteback *wb = nullptr;           // cmf_arm_writeback: the factors written into the caller's arrays behind a rule call
-};
-
-#define HALS_PMAX 4 // puller workgroups per row of the persistent H pipeline (4 -> 7 measured the same span: profiles/r04_hals_pullers_sweep.txt)
-static int hals_ensure(cmf_handle_s *h);
-static void hals_plan(cmf_handle_s *h);
 static void wb_free(cmf_handle_s *h);
 static void wb_disarm(cmf_handle_s *h);
-static inline void set_est(cmf_handle_s *h, int kind) // every change of what est holds (and with it: of H, W) passes through here
-{
-    h->est_kind = kind;
-    ++h->est_gen;
-}
-static int wb_after_H(cmf_handle_s *h); // hook: the kernels that make H final have been enqueued (cmf_writeback.h)
-static int gram_ensure(cmf_handle_s *h);
-static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
-static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked = false, bool loss_abs = false);
-static int hals_resid_and_loss(cmf_handle_s *h, double *sumsq);
-static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W);
-static int gram_w_partial(cmf_handle_s *h, float *hh_out);
-static int gram_w_finish(cmf_handle_s *h, const float *HH, double l1W, double l2W, const float *tail_src = nullptr, float *tail_dst = nullptr,
-                         int tail_n = 0);
-static int gram_h_update(cmf_handle_s *h, double l1H, double l2H);
-static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss);
-static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg);
-static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg, double *loss);
-static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H);
-static int hals_h_rerun(cmf_handle_s *h);
-static int gram_denom_h(cmf_handle_s *h, float *out);
-static int gram_tables(cmf_handle_s *h);
-static int group_pgd_w(cmf_handle_s *st, struct cmf_group_s *g, double pen_sq, double pen_abs, int nonneg);
-static int group_pgd_h(cmf_handle_s *st, struct cmf_group_s *g, double pen_sq, double pen_abs, int nonneg, double *loss);
-static int group_set_mask(struct cmf_group_s *g, const double *mask);
 
-static size_t n_partial(const cmf_handle_s *h)
+size_t n_partial(const cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
     size_t n = (size_t)(64 * h->conv_gx) * (size_t)std::max(h->conv_gy, h->conv_gy_ext); // conv loss partials (64 x 64 tiles, their quarters or sixteenths)
@@ -316,7 +32,7 @@ static int ensure_stage(cmf_handle_s *h, size_t elems)
 // init_rand, parameter_sweep and every fit_cnmf make and drop handles.  A released stream has been synchronised; at most 32 are kept.
 static std::mutex g_stream_mu;
 static std::map<int, std::vector<hipStream_t>> g_stream_pool;
-static hipError_t stream_acquire(int device, hipStream_t *s)
+hipError_t stream_acquire(int device, hipStream_t *s)
 {
     {
         std::lock_guard<std::mutex> lock(g_stream_mu);
@@ -337,24 +53,8 @@ static void stream_release(int device, hipStream_t s, bool may_wait = true)
     (void)hipStreamDestroy(s);
 }
 
-template <typename T>
-static int dalloc_zero(T **p, size_t n)
-{
-    HIPCHK(hipMalloc(p, n * sizeof(T)));
-    HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
-    // hipMemset of device memory runs on the null stream and may return before it has finished; the handle's work runs on
-    // non-blocking streams, which the null stream does not order -- a lagging fill would wipe what they wrote meanwhile
-    HIPCHK(hipStreamSynchronize(nullptr));
-    return CMF_OK;
-}
 
-// the C2 kernel adds CG consecutive time chunks inside a workgroup: it writes nchunks / CG slabs
-static int hxt_cg(int nchunks) { return nchunks % 4 == 0 ? 4 : (nchunks % 2 == 0 ? 2 : 1); }
-static int hxt_nslabs(int nchunks) { return nchunks / hxt_cg(nchunks); }
-
-static const int kHxtLP[] = {1, 2, 3, 4, 5, 6, 8}; // 2*LP*16 accumulator registers must fit the 256 AGPRs
-
-static void plan(cmf_handle_s *h, int n_cu)
+void plan(cmf_handle_s *h, int n_cu)
 {
     const CmfDims &d = h->d;
     // C2 (hxt): lags per launch group = 2*LP; pick the LP that wastes the fewest padded lags
@@ -541,8 +241,8 @@ static void destroy_impl(cmf_handle_s *h)
 }
 
 // upload `ncols` columns (fp64, N x ncols column-major) starting at local column tc
-static int upload_cols(cmf_handle_s *h, const double *src, int64_t tc, int64_t ncols, bool rows_layout, bool accumulate_sumsq,
-                       float *rows_dst = nullptr, float *cols_dst = nullptr)
+int upload_cols(cmf_handle_s *h, const double *src, int64_t tc, int64_t ncols, bool rows_layout, bool accumulate_sumsq,
+                       float *rows_dst, float *cols_dst)
 {
     if (!rows_dst) rows_dst = h->X;
     if (!cols_dst) cols_dst = h->XT;
@@ -571,7 +271,7 @@ static int upload_cols(cmf_handle_s *h, const double *src, int64_t tc, int64_t n
     return CMF_OK;
 }
 
-static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64_t K, int64_t L,
+int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64_t K, int64_t L,
                        const double *data, int64_t t_offset, int64_t T_global, bool sharded)
 {
     if (!out) return fail(CMF_ERR_ARG, "handle pointer is NULL");
@@ -703,145 +403,9 @@ static int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64
 // ------------------------------------------------------------------------------------------
 // kernel launchers
 // ------------------------------------------------------------------------------------------
-// kernel classes of the "profile" option
-enum { PROF_CONV = 0, PROF_CONV_T, PROF_CONV_LOSS, PROF_CONV_LOSS_STORE, PROF_HXT, PROF_TRANSCONV, PROF_HXT_NUM, PROF_HXT_DEN, PROF_OTHER,
-       PROF_HALS_PIPE, PROF_HALS_WSWEEP,
-       // the contraction launches of the HALS / PGD / Gram rules (one source, or on the stored residual)
-       PROF_CONV_RESID, PROF_HXT_RESID, PROF_HXT_HH, PROF_TRANSCONV_1, PROF_GRAM_DENOM_H, PROF_GRAM_TABLES, PROF_GRAM_W, PROF_NCLS };
-static const char *kProfNames[PROF_NCLS] = {"conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv", "hxt_num", "hxt_den", "other",
-                                            "hals_h_pipeline", "hals_w_sweep",
-                                            "conv_resid", "hxt_resid", "hxt_hh", "transconv_1src", "gram_denom_h", "gram_tables", "gram_w"};
-static_assert(PROF_NCLS <= 32, "cmf_handle_s::prof_seen holds 32 classes");
 
-struct ProfScope {
-    cmf_handle_s *h;
-    hipEvent_t b = nullptr;
-    ProfScope(cmf_handle_s *h_, int cls) : h(h_)
-    {
-        if (!h->prof || h->prof_recs.size() >= 8192) return;
-        if (h->prof_mask && !((h->prof_mask >> cls) & 1u)) return;
-        if ((h->prof_seen[cls]++ % h->prof_every) != 0) return;
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        for (int q = 0; q < 2; ++q) {
-            if (!h->prof_pool.empty()) { ev[q] = h->prof_pool.back(); h->prof_pool.pop_back(); }
-            else if (hipEventCreate(&ev[q]) != hipSuccess) { if (q == 1) h->prof_pool.push_back(ev[0]); return; }
-        }
-        (void)hipEventRecord(ev[0], h->stream);
-        h->prof_recs.push_back({ev[0], ev[1], cls});
-        b = ev[1];
-    }
-    ~ProfScope() { if (b) (void)hipEventRecord(b, h->stream); }
-};
-
-template <int MODE>
-static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const float *data = nullptr)
-{
-    ProfScope prof_(h, MODE == 0 ? PROF_CONV : MODE == 1 ? PROF_CONV_T : MODE == 2 ? PROF_CONV_LOSS : MODE == 3 ? PROF_CONV_LOSS_STORE : PROF_CONV_RESID);
-    const CmfDims &d = h->d;
-    ConvParams p;
-    p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = data ? data : h->X; p.partial = h->partial;
-    p.mask = (MODE == 7) ? h->MT : h->M;
-    p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = T_store;
-    p.N = d.N; // (n blocks that are all padding are skipped)
-    p.loss_abs = (MODE >= 4) ? h->pgd_loss_abs_now : 0;
-    dim3 grid(h->conv_gx, gy), block(256);
-    // measured at config 2 (tools/time_kernels.py): the one-wave kernel wins for the epilogues that read data
-    // (0.924 vs 0.931 ms loss only, 0.936 vs 0.943 ms loss + store), the 128 x 128 tiles for the store-only ones
-    // (0.911 vs 0.932 ms est, 0.910 vs 0.924 ms est')
-    constexpr bool reads_data = (MODE >= 2); // every mode but the two plain stores loads a data (and mask) tile in its epilogue
-    // The one-wave kernel can cut the tiles of its thin last round into quarter tiles (conv3_kernel).  That pays when
-    // the remainder is small against the 12 wave slots per CU -- short shards: 3136 tiles on 3072 slots at T/8 -- and
-    // then decides the variant for every mode; a remainder above 3 tiles per CU is left as whole tiles.
-    const int gx3 = d.Np / 64, tiles3 = gx3 * ((T_store + 63) / 64), slots3 = 12 * h->n_cu;
-    const int rem3 = tiles3 % slots3;
-    // The tiles at the end of the grid are cut into one-wave pieces: the remainder of the last round when it is thin
-    // (at most 3 tiles per CU), and, from `split_min_rounds` rounds on, `split_extra` more -- after several rounds of
-    // dynamic dispatch the waves of a SIMD are out of step and the launch ends in a ragged drain one tile long; small
-    // pieces at the end of the queue fill it (measured at config 2, 8.1 rounds: -1.5 % in every mode).
-    // Below 4 rounds the extra cut costs more than it fills (T/4 and T/8 shards: +1-4 %).
-    const int split_min_rounds = 4, split_extra = 3 * h->n_cu; // (profiles/r02*_conv_split*: the sweep these came from)
-    int cut = 0;
-    if (h->conv_split) {
-        if (rem3 > 0 && rem3 <= 3 * h->n_cu) cut = rem3;
-        if (tiles3 / slots3 >= split_min_rounds) cut += split_extra;
-        cut = std::min(cut, tiles3);
-    }
-    {
-        if (h->small_k) { // few components: one-wave tiles over the ceil(K/2) live k pairs per lag (conv_small_kernel)
-            const int nkp = (d.K + 1) / 2;
-            // the tiles beyond whole rounds of one tile per SIMD slot-triple (3 per SIMD) go out as quarter pieces at the end of the
-            // grid, when they are few (at most one tile per SIMD: otherwise whole tiles balance well enough)
-            const int per_round = 4 * h->n_cu;                          // one tile per SIMD
-            const int remq = tiles3 % per_round;
-            int cutq = (h->conv_split && tiles3 >= per_round && remq > 0 && remq <= per_round / 4) ? remq : 0;
-            if (h->conv_split && tiles3 < per_round) cutq = tiles3; // fewer tiles than SIMDs (short recordings): quarter pieces only (configs[0]: 9-12 -> 5-8 us)
-            const int n_full = tiles3 - cutq;
-            grid = dim3(n_full + 4 * cutq);
-            // (loss + store on a short launch: the data tile is requested before the MFMA loop, conv3_tile)
-            const bool pre = MODE == 3 && nkp <= 4 && tiles3 <= 4 * per_round;
-#define CASE(NKP_) do { if (pre) hipLaunchKernelGGL((conv_small_kernel<MODE, NKP_, (MODE == 3 && NKP_ <= 4)>), grid, dim3(64), 0, h->stream, p, gx3, n_full); \
-                        else hipLaunchKernelGGL((conv_small_kernel<MODE, NKP_>), grid, dim3(64), 0, h->stream, p, gx3, n_full); } while (0)
-            if (nkp <= 1) CASE(1); else if (nkp == 2) CASE(2); else if (nkp == 3) CASE(3); else if (nkp == 4) CASE(4);
-            else if (nkp <= 6) CASE(6); else CASE(8);
-#undef CASE
-            h->conv_partials = (int)grid.x;
-            KCHK("conv_small_kernel");
-            return CMF_OK;
-        }
-    }
-    const bool split = cut > 0;
-    const int variant = (h->conv_variant && MODE <= 2) ? h->conv_variant : ((reads_data || split) ? 3 : 2);
-    if (d.K % 32 == 0 && variant == 3) {
-        const int n_full = tiles3 - cut;
-        // quarter tiles reach every SIMD only from one tile per CU on; below that, sixteenth tiles
-        const int pieces = (split && cut < h->n_cu && h->conv_split != 4) ? 16 : 4;
-        grid = dim3(n_full + pieces * (tiles3 - n_full));
-        hipLaunchKernelGGL((conv3_kernel<MODE>), grid, dim3(64), 0, h->stream, p, gx3, n_full, pieces);
-    } else if (d.K % 32 == 0) {
-        // the 128 x 128 kernel exists for the epilogues that only store or only sum (est, est', loss): with a data tile
-        // read AND a store in the epilogue (mode 3 and the residual modes) it needs more than the 168 registers three
-        // workgroups per CU leave (it spilled to scratch), and the one-wave kernel won those modes anyway
-        if constexpr (MODE <= 2) hipLaunchKernelGGL((conv2_kernel<MODE>), grid, block, 0, h->stream, p);
-    } else hipLaunchKernelGGL((conv_kernel<MODE, 0>), grid, block, 0, h->stream, p);
-    h->conv_partials = (int)(grid.x * grid.y);
-    KCHK("conv_kernel");
-    return CMF_OK;
-}
-
-// The one-wave conv tiles of tile rows [row0, row0 + nrows) on h->stream (conv3_chase_kernel; K a multiple of 32): the tail of the
-// grid is cut into pieces for a chip of n_cu CUs like launch_conv does.  gate != NULL: every tile waits for *gate >= its row + 1 (the
-// HALS row pipeline's last progress flag) and reads H with agent-scope loads.  Loss partials pidx0 ... pidx0 + *npartials - 1.
-template <int MODE>
-static int launch_conv_rows(cmf_handle_s *h, float *out, int row0, int nrows, int pidx0, int n_cu, const int *gate, int *abort_word,
-                            int *host_status, int *npartials)
-{
-    ProfScope prof_(h, PROF_CONV_RESID);
-    const CmfDims &d = h->d;
-    ConvParams p;
-    p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = h->X; p.partial = h->partial; p.mask = h->M;
-    p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = d.Tl;
-    p.N = d.N;
-    p.loss_abs = 0;
-    const int gx3 = d.Np / 64, tiles3 = gx3 * nrows, slots3 = 12 * n_cu;
-    const int rem3 = tiles3 % slots3;
-    int cut = 0;
-    if (h->conv_split) {
-        if (rem3 > 0 && rem3 <= 3 * n_cu) cut = rem3;
-        if (tiles3 / slots3 >= 4) cut += 3 * n_cu;
-        cut = std::min(cut, tiles3);
-    }
-    const int n_full = tiles3 - cut;
-    const int pieces = (cut > 0 && cut < n_cu && h->conv_split != 4) ? 16 : 4;
-    const int grid = n_full + pieces * cut;
-    if ((size_t)(pidx0 + grid) > n_partial(h)) return fail(CMF_ERR_STATE, "internal: loss partial buffer too small for a split conv");
-    hipLaunchKernelGGL((conv3_chase_kernel<MODE>), dim3(grid), dim3(64), 0, h->stream, p, gx3, n_full, pieces, row0, pidx0, gate, abort_word, host_status);
-    KCHK("conv3_chase_kernel");
-    *npartials = grid;
-    return CMF_OK;
-}
-
-static int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int NpX, int nsrc, float *slabs, int nchunks, int chunk_len,
-                         int main_rows = -1)
+int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int NpX, int nsrc, float *slabs, int nchunks, int chunk_len,
+                         int main_rows)
 {
     ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : (nsrc == 1 && X0 == h->X) ? PROF_HXT_NUM : (nsrc == 1 && X0 == h->est && h->est_kind == 1) ? PROF_HXT_DEN
                           : (nsrc == 1 && X0 == h->est) ? PROF_HXT_RESID : (X0 == h->hals_HX && h->hals_HX) ? PROF_HXT_HH : PROF_OTHER);
@@ -868,36 +432,7 @@ static int launch_hxt(cmf_handle_s *h)
     return launch_hxt_on(h, h->X, h->est, h->d.Np, 2, h->wslabs, h->hxt_nchunks, h->hxt_chunk_len, h->hxt_main);
 }
 
-// C3 for few components: Wj pack, then ONE launch that forms G = Wf x XT (a plain GEMM over n) tile by tile and folds the lag sum
-// out[t][k] = sum_l G[(k, l)][t + l] on chip, into hslabs [2][nsrc][Tl][K32]
-static int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
-{
-    ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_TRANSCONV_1);
-    const CmfDims &d = h->d;
-    if (h->sk_wj_gen != h->est_gen) { // (w_update_small_kernel writes the packed operand itself; whatever else touched W, H or est since: pack again)
-        hipLaunchKernelGGL(wj_pack_kernel, dim3((unsigned)std::min<size_t>(1024, ((size_t)d.Np * h->sk3_JP + 255) / 256)), dim3(256), 0, h->stream,
-                           h->Wn, h->sk_Wj, d.Np, d.K, d.L, d.K32, h->sk3_Kg, h->sk3_GR, h->sk3_JP);
-        KCHK("wj_pack_kernel");
-        h->sk_wj_gen = h->est_gen;
-    }
-    SkGemmParams p;
-    p.Wj = h->sk_Wj; p.XT0 = xt0 ? xt0 : h->XT; p.XT1 = h->estT; p.out = h->hslabs;
-    p.TP = d.TP; p.PADL = d.PADL; p.JP = h->sk3_JP; p.MG = h->sk3_MG; p.TG = h->sk_TG; p.N2 = (int)rup(d.N, 2); p.Np = d.Np; p.nsrc = nsrc;
-    p.Tl = d.Tl; p.K = d.K; p.L = d.L; p.K32 = d.K32; p.Kg = h->sk3_Kg; p.RV = h->sk3_RV;
-    p.NS = h->sk3_NS; p.RPS = h->sk3_RPS;
-    const dim3 grid(h->sk_TG / 128 + 1, nsrc * h->sk3_MG * h->sk3_NS);
-    switch (h->sk3_MBW) {
-#define CASE(M_) case M_: if (h->sk3_RV) hipLaunchKernelGGL((g_gemm_fold_small_kernel<(M_ <= 3 ? M_ : 3), SK_RVT>), grid, dim3(256), 0, h->stream, p); /* (1-3 MFMA blocks + VALU rows) */ \
-                 else hipLaunchKernelGGL((g_gemm_fold_small_kernel<M_>), grid, dim3(256), 0, h->stream, p); break;
-        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
-#undef CASE
-    default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk3_MBW);
-    }
-    KCHK("g_gemm_fold_small_kernel");
-    return CMF_OK;
-}
-
-static int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullptr)
+int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0)
 {
     if (h->sk_tc) return launch_transconv_small(h, nsrc, xt0);
     ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_TRANSCONV_1);
@@ -922,8 +457,8 @@ static int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullpt
     return CMF_OK;
 }
 
-static int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nslabs, size_t stride, bool take_carry = false,
-                           CmfHxtTail tail = CmfHxtTail{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0})
+int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nslabs, size_t stride, bool take_carry,
+                           CmfHxtTail tail)
 {
     size_t n4 = stride / 4;
     int blocks = (int)std::min<size_t>(2048, (n4 + 255) / 256);
@@ -939,39 +474,11 @@ static int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nsl
 
 // The C2 contraction of one (nsrc = 1: X0) or two sources with H_shift, complete: kernel, slab sum, and the rows the kernel
 // leaves to the slab sum.   out: [nsrc][L][K32][Np]
-static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int nsrc, float *out, bool take_carry = false, bool slabs_only = false)
+int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int nsrc, float *out, bool take_carry, bool slabs_only)
 {
     const CmfDims &d = h->d;
     h->spec_gen = -1; // (the slabs / sums of a speculated contraction are being overwritten)
-    if (h->small_k) { // few components: the rows j = l*K + k on the MFMA axis (hxt_small_kernel), compact slabs, their sum expanded to [L][K32][Np]
-        ProfScope prof_(h, (nsrc == 2 && X0 == h->X) ? PROF_HXT : (nsrc == 1 && X0 == h->X) ? PROF_HXT_NUM : (nsrc == 1 && X0 == h->est && h->est_kind == 1) ? PROF_HXT_DEN
-                          : (nsrc == 1 && X0 == h->est) ? PROF_HXT_RESID : (X0 == h->hals_HX && h->hals_HX) ? PROF_HXT_HH : PROF_OTHER);
-        SkHxtParams p;
-        p.Ht = h->Ht; p.X0 = X0; p.X1 = X1; p.slabs = h->sk_slabs;
-        p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.L = d.L; p.J = h->sk_J; p.JP = h->sk_JP; p.MG = h->sk_MG; p.Tl = d.Tl;
-        p.chunk_len = h->sk_chunk_len; p.nsrc = nsrc; p.RV = h->sk_RV;
-        size_t lds = std::max<size_t>((size_t)8 * (d.K + 1) * SK_HS_STRIDE, 4 * 16 * 64) * sizeof(float); // (two strips per wave | the chunk reduction)
-        const dim3 grid((d.Np / 32) * h->sk_MG, h->sk_ngroups, nsrc);
-        switch (h->sk_MBW) {
-#define CASE(M_) case M_: if (h->sk_RV) hipLaunchKernelGGL((hxt_small_kernel<(M_ <= 3 ? M_ : 3), SK_RVT>), grid, dim3(256), lds, h->stream, p); /* (1-3 MFMA blocks + VALU rows) */ \
-                          else hipLaunchKernelGGL((hxt_small_kernel<M_>), grid, dim3(256), lds, h->stream, p); break;
-            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
-#undef CASE
-        default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk_MBW);
-        }
-        KCHK("hxt_small_kernel");
-        if (slabs_only) return CMF_OK; // (the caller's next launch sums the slabs itself: w_update_small_kernel)
-        CmfLossCarry carry{};
-        if (take_carry && h->carry.partial) { // a loss reduction deferred by cmf_iterate rides on this launch
-            carry = h->carry;
-            h->carry = CmfLossCarry{};
-        }
-        const size_t n4 = (size_t)nsrc * d.L * d.K32 * d.Np / 4;
-        hipLaunchKernelGGL(slab_sum_small_kernel, dim3((unsigned)std::min<size_t>(2048, (n4 + 255) / 256)), dim3(256), 0, h->stream, out, h->sk_slabs,
-                           h->sk_ngroups, nsrc, d.L, d.K, d.K32, d.Np, h->sk_JP, carry);
-        KCHK("slab_sum_small_kernel");
-        return CMF_OK;
-    }
+    if (h->small_k) return hxt_contract_small(h, X0, X1, nsrc, out, take_carry, slabs_only); // few components (cmf_small.hip)
     const int nch = nsrc == 2 ? h->hxt_nchunks : h->hxt_nchunks1, clen = nsrc == 2 ? h->hxt_chunk_len : h->hxt_chunk_len1;
     const int main_rows = nsrc == 2 ? h->hxt_main : h->hxt_main1;
     CMFTRY(launch_hxt_on(h, X0, X1, d.Np, nsrc, h->wslabs, nch, clen, main_rows));
@@ -979,7 +486,7 @@ static int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int n
     return launch_slab_sum(h, out, h->wslabs, hxt_nslabs(nch), (size_t)nsrc * d.L * d.K32 * d.Np, take_carry, tail);
 }
 
-static int read_scalar(cmf_handle_s *h, int slot, double *v)
+int read_scalar(cmf_handle_s *h, int slot, double *v)
 {
     HIPCHK(hipMemcpyAsync(h->h_scalar + slot, h->d_scalar + slot, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1010,7 +517,7 @@ static bool w_speculated(cmf_handle_s *h)
     return hit;
 }
 
-static int w_partial_impl(cmf_handle_s *h)
+int w_partial_impl(cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
     if (w_speculated(h)) return CMF_OK;
@@ -1023,7 +530,7 @@ static int w_partial_impl(cmf_handle_s *h)
 // The two halves of w_partial_impl as separate steps (same arithmetic, the sources contracted one at a time): the
 // numerator needs H only, so a sharded host can compute and all-reduce it while the loss conv and the denominator
 // contraction are still running.
-static int w_partial_half_impl(cmf_handle_s *h, int den)
+int w_partial_half_impl(cmf_handle_s *h, int den)
 {
     const CmfDims &d = h->d;
     const size_t LKN = (size_t)d.L * d.K32 * d.Np;
@@ -1038,8 +545,8 @@ static int w_partial_half_impl(cmf_handle_s *h, int den)
 
 // den == NULL: denomW lies behind numW in h->numden (the layout of the [numW | denomW] all-reduce buffer)
 static int w_apply_impl_(cmf_handle_s *h, double l1W, double l2W, const float *tail_src, float *tail_dst, int tail_n, const float *den);
-static int w_apply_impl(cmf_handle_s *h, double l1W, double l2W, const float *tail_src = nullptr, float *tail_dst = nullptr, int tail_n = 0,
-                        const float *den = nullptr)
+int w_apply_impl(cmf_handle_s *h, double l1W, double l2W, const float *tail_src, float *tail_dst, int tail_n,
+                        const float *den)
 {
     return w_apply_impl_(h, l1W, l2W, tail_src, tail_dst, tail_n, den);
 }
@@ -1085,7 +592,7 @@ static int w_apply_impl_(cmf_handle_s *h, double l1W, double l2W, const float *t
     return CMF_OK;
 }
 
-static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
+int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
 {
     const CmfDims &d = h->d;
     CMFTRY(launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext)); // mult.jl:44 (est with the new W)
@@ -1100,7 +607,7 @@ static int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
 }
 
 // the conv of mult.jl:55-57 with the loss fused: per-tile sums of (est - data)^2 -> h->partial
-static int launch_loss_conv(cmf_handle_s *h)
+int launch_loss_conv(cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
     if (h->reuse_est && !h->gram) { // (the Gram form never reads est: nothing to keep)
@@ -1131,14 +638,11 @@ static int ensure_ring(cmf_handle_s *h) // pinned words a loss reduction stores 
     return CMF_OK;
 }
 
-template <typename U>
-static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel, const std::function<int()> *health = nullptr,
-                      const std::function<bool()> *enqueued = nullptr);
 
 // The loss conv (mult.jl:55-57) and the reduction of its per-tile sums.  readback: the calling thread returns with the sum -- the
 // reduction stores it into a pinned word that the host polls (no copy operation and no stream synchronisation behind the last
 // kernel: a rule call on a small problem is a few launches long, and the reference's loop makes one such read per iteration).
-static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = true, double *host_out = nullptr, bool speculate = false)
+int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback, double *host_out, bool speculate)
 {
     volatile unsigned long long *word = nullptr;
     if (readback && !host_out) {
@@ -1158,7 +662,7 @@ static int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = tru
     return CMF_OK;
 }
 
-static int set_factors_impl(cmf_handle_s *h, const double *W, const double *H)
+int set_factors_impl(cmf_handle_s *h, const double *W, const double *H)
 {
     if (!h || (!W && !H)) return fail(CMF_ERR_ARG, "NULL argument");
     if ((!W || !H) && !h->factors_set) return fail(CMF_ERR_STATE, "the first cmf_set_factors needs both W and H");
@@ -1188,7 +692,7 @@ static int set_factors_impl(cmf_handle_s *h, const double *W, const double *H)
     return CMF_OK;
 }
 
-static int get_factors_impl(cmf_handle_s *h, double *W, double *H)
+int get_factors_impl(cmf_handle_s *h, double *W, double *H)
 {
     if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
     CMFTRY(check_ready(h, false));
@@ -1212,7 +716,7 @@ static int get_factors_impl(cmf_handle_s *h, double *W, double *H)
 
 
 // The sum of n per-tile partials -> d_scalar[slot], and to the calling thread when v is given (polled pinned word, like loss_partial_impl).
-static int reduce_partials(cmf_handle_s *h, const double *partial, int n, int slot, double *v)
+int reduce_partials(cmf_handle_s *h, const double *partial, int n, int slot, double *v)
 {
     double *host_out = nullptr;
     if (v) {
@@ -1236,7 +740,7 @@ static int reduce_partials(cmf_handle_s *h, const double *partial, int n, int sl
 // by shard 0 only and a peer that faulted would otherwise leave the host spinning here.  `enqueued` (optional): false while
 // enqueue workers of the group have not yet handed all posted work to the streams.  The wait is bounded
 // (CMF_WAIT_TIMEOUT_S seconds, default 300): a collective that can never complete ends in CMF_ERR_COMM, not in a hang.
-static double wait_timeout_s()
+double wait_timeout_s()
 {
     static const double t = [] {
         const char *e = getenv("CMF_WAIT_TIMEOUT_S");
@@ -1245,77 +749,6 @@ static double wait_timeout_s()
     }();
     return t;
 }
-
-template <typename U>
-static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel, const std::function<int()> *health, const std::function<bool()> *enqueued)
-{
-    auto all_there = [&]() {
-        for (int j = 0; j < n; ++j)
-            if (p[j] == sentinel) return false;
-        return true;
-    };
-    const auto t_begin = std::chrono::steady_clock::now();
-    for (unsigned spins = 1;; ++spins) {
-        if (all_there()) {
-            std::atomic_thread_fence(std::memory_order_acquire);
-            return CMF_OK;
-        }
-        if ((spins & 0xFFF) == 0) {
-            // (enqueue workers that are still posting leave the stream idle: only a stream that has been given all its work
-            // and has drained it proves that the words will never come)
-            const hipError_t e = (enqueued && !(*enqueued)()) ? hipErrorNotReady : hipStreamQuery(stream);
-            if (e == hipSuccess) { // everything enqueued has run: the words must be there now
-                if (all_there()) return CMF_OK;
-                return fail(CMF_ERR_HIP, "the stream drained without posting the loss");
-            }
-            if (e != hipErrorNotReady) return fail(CMF_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
-            if (health) CMFTRY((*health)());
-            if ((spins & 0xFFFFF) == 0 &&
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > wait_timeout_s())
-                return fail(health ? CMF_ERR_COMM : CMF_ERR_HIP, "no loss arrived within %.0f s (CMF_WAIT_TIMEOUT_S): %s", wait_timeout_s(),
-                            health ? "a collective of the group did not complete -- is every rank / device of the group still running?"
-                                   : "the device did not finish the iteration");
-        }
-        __builtin_ia32_pause();
-    }
-}
-
-// HIP timing events behind the iterations of a pipelined batch (cmf_fit's time_hist): begin() records the start, mark(it) goes
-// behind iteration it's loss conv, finish() turns them into seconds since the start.  Inactive unless begin() was called.
-struct DevStamps {
-    std::vector<hipEvent_t> ev;
-    bool active = false;
-    int begin(hipStream_t st, int64_t n)
-    {
-        if (n < 1 || n > 8192) return CMF_OK; // (a batch that long keeps the host stamps)
-        ev.assign((size_t)n + 1, nullptr);
-        for (auto &e : ev) HIPCHK(hipEventCreate(&e));
-        HIPCHK(hipEventRecord(ev[0], st));
-        active = true;
-        return CMF_OK;
-    }
-    int mark(hipStream_t st, int64_t it)
-    {
-        if (active) HIPCHK(hipEventRecord(ev[(size_t)it + 1], st));
-        return CMF_OK;
-    }
-    int finish(double *stamps, int64_t n)
-    {
-        if (!active) return CMF_OK;
-        HIPCHK(hipEventSynchronize(ev[(size_t)n]));
-        for (int64_t it = 0; it < n; ++it) {
-            float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[(size_t)it + 1]));
-            stamps[it] = 1e-3 * (double)ms;
-        }
-        return CMF_OK;
-    }
-    ~DevStamps()
-    {
-        for (hipEvent_t e : ev)
-            if (e) (void)hipEventDestroy(e);
-    }
-};
 
 // ------------------------------------------------------------------------------------------
 // write-back of the factors behind a rule call (cmf_writeback.h; cmf_arm_writeback)
@@ -1416,7 +849,7 @@ static int wb_drain(cmf_handle_s *h)
 }
 
 // Hook of the rules' H phases: the kernels that make H final have just been enqueued on the main stream.
-static int wb_after_H(cmf_handle_s *h)
+int wb_after_H(cmf_handle_s *h)
 {
     CmfWriteback *wb = h->wb;
     if (!wb || !wb->armed || !wb->has_copy) return CMF_OK;
@@ -1470,7 +903,6 @@ static int wb_after_H(cmf_handle_s *h)
     return CMF_OK;
 }
 
-#include "cmf_group.h"
 
 // A group's MU H phase is about to be enqueued: post the widening of W (shard 0's copy was started when the write-back was armed)
 // and of every shard's column block of H to the front handle's helpers.  Helper j takes slice j of every block.
@@ -1579,7 +1011,6 @@ struct CarryGuard { // error exits of cmf_iterate: leave no deferred reduction (
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
-extern "C" {
 
 #ifndef CMF_SRC_DIGEST
 #define CMF_SRC_DIGEST "unknown" // cmf.jl_amd/build.py passes -DCMF_SRC_DIGEST=... (cmf_source_digest, include/cmf_hip.h)
@@ -2284,1120 +1715,6 @@ int cmf_fit(cmf_handle h, int64_t max_itr, double max_time, int check_convergenc
     return CMF_OK;
 }
 
-// ---- groups: construction ---------------------------------------------------------------------------------------
-int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transport,
-                     int64_t N, int64_t T, int64_t K, int64_t L, const double *data)
-{
-    if (!out) return fail(CMF_ERR_ARG, "handle pointer is NULL");
-    *out = nullptr;
-    if (!devices || !data) return fail(CMF_ERR_ARG, "NULL argument");
-    if (ndev < 1 || ndev > CMF_MAX_LOCAL) return fail(CMF_ERR_ARG, "ndev must be 1..%d (got %d)", CMF_MAX_LOCAL, ndev);
-    if (N < 1 || T < 1 || K < 1 || L < 1) return fail(CMF_ERR_ARG, "N, T, K, L must all be >= 1");
-    bool all_same = true, distinct = true;
-    for (int i = 0; i < ndev; ++i)
-        for (int j = 0; j < i; ++j) {
-            if (devices[i] != devices[j]) all_same = false;
-            else distinct = false;
-        }
-    int tr;
-    if (transport == CMF_COMM_AUTO) tr = (ndev > 1 && distinct) ? CMF_TR_RCCL : CMF_TR_LOOPBACK;
-    else if (transport == CMF_COMM_RCCL) tr = CMF_TR_RCCL;
-    else if (transport == CMF_COMM_LOOPBACK || transport == CMF_COMM_LOOPBACK_STREAMS) tr = CMF_TR_LOOPBACK;
-    else if (transport == CMF_COMM_PEER) tr = CMF_TR_PEER;
-    else return fail(CMF_ERR_ARG, "unknown transport %d", transport);
-    if (tr == CMF_TR_RCCL && !distinct) return fail(CMF_ERR_ARG, "RCCL needs distinct devices (a device is listed twice)");
-    if (tr == CMF_TR_LOOPBACK && !all_same) return fail(CMF_ERR_ARG, "the loopback transport needs all shards on one device; list distinct devices for RCCL");
-    if (tr == CMF_TR_PEER && !(distinct || all_same)) return fail(CMF_ERR_ARG, "the peer transport takes distinct devices, or one device for every shard (rehearsal)");
-    if (tr == CMF_TR_PEER && ndev > 1 && distinct) {
-        // every device maps every other one's memory (xGMI): the transport's kernels read and write the peers' buffers directly
-        for (int i = 0; i < ndev; ++i) {
-            HIPCHK(hipSetDevice(devices[i]));
-            for (int j = 0; j < ndev; ++j) {
-                if (i == j) continue;
-                int can = 0;
-                HIPCHK(hipDeviceCanAccessPeer(&can, devices[i], devices[j]));
-                if (!can) return fail(CMF_ERR_COMM, "device %d cannot access device %d's memory: the peer transport needs peer access between all devices of the group", devices[i], devices[j]);
-                const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
-                    return fail(CMF_ERR_HIP, "hipDeviceEnablePeerAccess(%d) on device %d failed: %s", devices[j], devices[i], hipGetErrorString(e));
-                (void)hipGetLastError();
-            }
-        }
-    }
-    std::vector<int64_t> t0, t1;
-    group_partition(T, ndev, L, t0, t1);
-    for (int r = 0; r < ndev; ++r)
-        if (ndev > 1 && t1[r] - t0[r] < std::max<int64_t>(L - 1, 1))
-            return fail(CMF_ERR_UNSUPPORTED, "T=%lld is too short to shard over %d devices with L=%lld (every shard needs >= L-1 columns)",
-                        (long long)T, ndev, (long long)L);
-
-    cmf_group_s *g = new cmf_group_s();
-    cmf_handle_s *root = new cmf_handle_s();
-    root->root_only = true;
-    root->group = g;
-    root->device = devices[0];
-    g->nranks = ndev;
-    g->transport = tr;
-    g->one_process = true;
-    g->N = N; g->T = T; g->K = K; g->L = L;
-    g->t0 = t0; g->t1 = t1;
-    auto bail = [&](int rc) { cmf_destroy(root); return rc; };
-    for (int r = 0; r < ndev; ++r) {
-        cmf_handle_s *s = nullptr;
-        // column-major N x T: the block [t0, t1 + halo_r) is contiguous
-        int rc = create_impl(&s, devices[r], N, t1[r] - t0[r], K, L, data + (size_t)t0[r] * N, t0[r], T, ndev > 1);
-        if (rc != CMF_OK) return bail(rc);
-        g->sh.push_back(s);
-        g->rank.push_back(r);
-        s->group = g;
-        rc = group_prepare_shard(s);
-        if (rc != CMF_OK) return bail(rc);
-    }
-    // CMF_LOOPBACK_STREAMS=1 turns every loopback group of the process into the stream-per-shard form (tests)
-    g->loop_ms = tr == CMF_TR_LOOPBACK && transport == CMF_COMM_LOOPBACK_STREAMS;
-    if (tr == CMF_TR_LOOPBACK && !g->loop_ms) // one device: every shard works on shard 0's streams, so the kernels of the loopback collectives are ordered
-        for (cmf_handle_s *s : g->sh) { s->stream = g->sh[0]->stream; s->comm_stream = g->sh[0]->comm_stream; }
-    if (tr == CMF_TR_RCCL) {
-        int rc = rccl_load();
-        if (rc != CMF_OK) return bail(rc);
-        g->comm.assign((size_t)ndev, nullptr);
-        (void)hipGetLastError(); // RCCL reports a stale (already handled) HIP error of this thread as its own
-        ncclResult_t r_ = g_rccl.CommInitAll(g->comm.data(), ndev, devices);
-        if (r_ != ncclSuccess) return bail(fail(CMF_ERR_COMM, "ncclCommInitAll failed: %s (RCCL from %s; if the process holds two HIP runtimes -- e.g. PyTorch imported after this library -- import torch first)", g_rccl.GetErrorString(r_), g_rccl.path.c_str()));
-    }
-    int rc = group_alloc_buffers(g);
-    if (rc == CMF_OK) rc = group_finish_norm(g);
-    // an enqueue worker per shard wherever every shard has its own stream (cmf_group.h); CMF_ENQUEUE_THREADS=0: the calling
-    // thread enqueues all shards (option "enqueue_threads" switches later)
-    const char *et = getenv("CMF_ENQUEUE_THREADS");
-    if (rc == CMF_OK && !(et && atoi(et) == 0)) rc = group_start_workers(g);
-    if (rc != CMF_OK) return bail(rc);
-    *out = root;
-    return CMF_OK;
-}
-
-// The overlap form's communication stream gets a communicator of its own (cmf_group.h, lane 1).  One process per shard:
-// every rank calls this with the SAME second id (rank 0's cmf_comm_unique_id, handed over like the first); groups from
-// cmf_create_multi create theirs themselves when the option is switched on and need not call it (id128 may be NULL).
-int cmf_comm_init_overlap(cmf_handle h, const void *id128)
-{
-    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
-    if (!h->group) return fail(CMF_ERR_STATE, "the handle belongs to no group");
-    if (h->group->transport != CMF_TR_RCCL) return CMF_OK; // the other transports order their lanes with events
-    if (!h->group->one_process && !id128) return fail(CMF_ERR_ARG, "id128 is NULL");
-    return group_ensure_lane1(h->group, id128);
-}
-
-int cmf_comm_unique_id(void *id128)
-{
-    if (!id128) return fail(CMF_ERR_ARG, "id128 is NULL");
-    CMFTRY(rccl_load());
-    ncclUniqueId id;
-    RCCLCHK(g_rccl.GetUniqueId(&id));
-    std::memcpy(id128, &id, sizeof(id));
-    return CMF_OK;
-}
-
-static int comm_attach(cmf_handle_s *h, int nranks, int rank, int transport, const void *id128,
-                       cmf_allreduce_fn ar, cmf_allgather_fn ag, void *user)
-{
-    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
-    if (h->group) return fail(CMF_ERR_STATE, "the handle already belongs to a group");
-    if (!h->sharded) return fail(CMF_ERR_STATE, "cmf_comm_init_* needs a handle from cmf_create_shard");
-    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(CMF_ERR_ARG, "bad rank %d of %d", rank, nranks);
-    const CmfDims &d = h->d;
-    // the shard's place in the global partition must match what the other ranks assume
-    std::vector<int64_t> t0, t1;
-    group_partition(h->T_global, nranks, d.L, t0, t1);
-    if (t0[(size_t)rank] != h->t_offset || t1[(size_t)rank] - t0[(size_t)rank] != d.Tl)
-        return fail(CMF_ERR_ARG, "rank %d of %d must own columns [%lld, %lld) of T=%lld, the handle owns [%lld, %lld)", rank, nranks,
-                    (long long)t0[(size_t)rank], (long long)t1[(size_t)rank], (long long)h->T_global,
-                    (long long)h->t_offset, (long long)(h->t_offset + d.Tl));
-    CMFTRY(group_use(h));
-    cmf_group_s *g = new cmf_group_s();
-    g->nranks = nranks;
-    g->transport = transport;
-    g->one_process = false;
-    g->N = d.N; g->T = h->T_global; g->K = d.K; g->L = d.L;
-    g->t0 = t0; g->t1 = t1;
-    g->sh.push_back(h);
-    g->rank.push_back(rank);
-    g->ar_cb = ar; g->ag_cb = ag; g->cb_user = user;
-    auto bail = [&](int rc) { (void)group_destroy(g); h->group = nullptr; return rc; };
-    int rc = group_prepare_shard(h);
-    if (rc != CMF_OK) return bail(rc);
-    if (transport == CMF_TR_RCCL) {
-        rc = rccl_load();
-        if (rc != CMF_OK) return bail(rc);
-        ncclUniqueId id;
-        std::memcpy(&id, id128, sizeof(id));
-        g->comm.assign(1, nullptr);
-        (void)hipGetLastError(); // RCCL reports a stale (already handled) HIP error of this thread as its own
-        ncclResult_t r_ = g_rccl.CommInitRank(&g->comm[0], nranks, id, rank);
-        if (r_ != ncclSuccess) return bail(fail(CMF_ERR_COMM, "ncclCommInitRank failed: %s (RCCL from %s; if the process holds two HIP runtimes -- e.g. PyTorch imported after this library -- import torch first)", g_rccl.GetErrorString(r_), g_rccl.path.c_str()));
-    }
-    rc = group_alloc_buffers(g);
-    if (rc == CMF_OK) rc = group_finish_norm(g);
-    if (rc != CMF_OK) return bail(rc);
-    h->group = g;
-    if (h->factors_set) { // factors were set before the communicator existed: the neighbours' halos are still missing
-        g->halos_current = false;
-        set_est(h, 0);
-    }
-    return CMF_OK;
-}
-
-int cmf_comm_init_rccl(cmf_handle h, int nranks, int rank, const void *id128)
-{
-    if (!id128) return fail(CMF_ERR_ARG, "id128 is NULL");
-    return comm_attach(h, nranks, rank, CMF_TR_RCCL, id128, nullptr, nullptr, nullptr);
-}
-
-int cmf_comm_init_callbacks(cmf_handle h, int nranks, int rank, cmf_allreduce_fn allreduce, cmf_allgather_fn allgather, void *user)
-{
-    if (!allreduce || !allgather) return fail(CMF_ERR_ARG, "NULL callback");
-    return comm_attach(h, nranks, rank, CMF_TR_CALLBACKS, nullptr, allreduce, allgather, user);
-}
-
-int cmf_comm_info(cmf_handle h, char *buf, int64_t len)
-{
-    if (!h || !buf || len < 1) return fail(CMF_ERR_ARG, "bad argument");
-    char tmp[1024];
-    if (!h->group) {
-        snprintf(tmp, sizeof(tmp), "transport=none nranks=1");
-    } else {
-        const cmf_group_s *g = h->group;
-        std::string ranks;
-        for (size_t i = 0; i < g->rank.size(); ++i) ranks += (i ? "," : "") + std::to_string(g->rank[i]) + "@dev" + std::to_string(g->sh[i]->device);
-        const char *enq = g->pool.empty() ? "caller" : "threads"; // who enqueues the shards (cmf_group.h)
-        const int lanes = (g->transport == CMF_TR_RCCL && g->comm2.size() == g->sh.size()) ? 2 : 1; // communicators per shard
-        if (g->transport == CMF_TR_RCCL) {
-            int v = 0;
-            (void)g_rccl.GetVersion(&v);
-            snprintf(tmp, sizeof(tmp), "transport=rccl version=%d lib=%s nranks=%d local=%zu ranks=%s overlap=%d enqueue=%s lanes=%d failed=%d", v,
-                     g_rccl.path.c_str(), g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap, enq, lanes, (int)g->failed);
-        } else {
-            snprintf(tmp, sizeof(tmp), "transport=%s nranks=%d local=%zu ranks=%s overlap=%d enqueue=%s lanes=%d failed=%d",
-                     g->transport == CMF_TR_LOOPBACK ? (g->loop_ms ? "loopback-streams" : "loopback") : (g->transport == CMF_TR_PEER ? "peer" : "callbacks"),
-                     g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap, enq, lanes, (int)g->failed);
-        }
-    }
-    snprintf(buf, (size_t)len, "%s", tmp);
-    return CMF_OK;
-}
-
-int cmf_shard_bounds(cmf_handle h, int rank, int64_t *t0, int64_t *t1)
-{
-    if (!h || !t0 || !t1) return fail(CMF_ERR_ARG, "NULL argument");
-    if (!h->group) {
-        *t0 = h->t_offset;
-        *t1 = h->t_offset + h->d.Tl;
-        return CMF_OK;
-    }
-    if (rank < 0 || rank >= h->group->nranks) return fail(CMF_ERR_ARG, "rank %d out of range", rank);
-    *t0 = h->group->t0[(size_t)rank];
-    *t1 = h->group->t1[(size_t)rank];
-    return CMF_OK;
-}
-
-// est := tensor_conv(W,H) - data (the residual hals.jl / pgd.jl carry), with the loss sum in d_scalar[0]
-static int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked, bool loss_abs)
-{
-    const CmfDims &d = h->d;
-    h->pgd_loss_abs_now = loss_abs ? 1 : 0;
-    int rc = masked ? launch_conv<6>(h, h->est, d.Tl, h->conv_gy) // pgd.jl:64-70
-                    : launch_conv<4>(h, h->est, d.Tl, h->conv_gy);
-    h->pgd_loss_abs_now = 0;
-    CMFTRY(rc);
-    set_est(h, 2 + (masked ? 1 : 0) + (loss_abs ? 2 : 0));
-    return reduce_partials(h, h->partial, h->conv_partials, 0, sumsq);
-}
-
-static int ensure_resid(cmf_handle_s *h, bool masked = false, bool loss_abs = false)
-{
-    return h->est_kind == 2 + (masked ? 1 : 0) + (loss_abs ? 2 : 0) ? CMF_OK : resid_and_loss(h, nullptr, masked, loss_abs);
-}
-
-// ---- HALS (src/algs/hals.jl) -------------------------------------------------------------------
-// Scratch that the Gram form of the MU rule and the HALS rule share: H as its own X operand and the lag correlations
-// (compute_hh), HH, the lag-Gram taps of W (PW -> GW, GE, GWt).  Shard-aware: only the shard that holds the global right
-// edge has truncated lag windows (edge taps GE, cut terms of HH).
-static int gram_ensure(cmf_handle_s *h)
-{
-    if (h->gram_ready) return CMF_OK;
-    const CmfDims &d = h->d;
-    const int E = 2 * d.L - 1;
-    const bool has_edge = !h->sharded || h->t_offset + d.Tl == h->T_global;
-    h->hals_NpH = (int)rup((int64_t)d.L * d.K32, 128);
-    h->hals_t_edge0 = has_edge ? std::max(0, d.Tl - d.L + 1) : d.Tl;
-    h->hals_ne = d.Tl - h->hals_t_edge0;
-    h->hals_NpC = (int)rup(d.K32, 128); // pitch of H as the X operand of its own lag correlations (compute_hh)
-    if ((double)d.L * d.K32 * h->hals_NpH * 4.0 >= 2147483648.0 || (double)d.TP * h->hals_NpC * 4.0 >= 2147483648.0)
-        return fail(CMF_ERR_UNSUPPORTED, "Gram form: (L*K)^2 or T*K exceeds the 2 GiB the kernels' 32-bit buffer offsets address");
-    {   // time chunks of that launch: fill the resident wave slots -- but no chunk shorter than two rotations of the C2
-        // kernel's register ring, and the chunk count a multiple of 4 so that four chunks are added inside a workgroup
-        // (trailing chunks that start behind Tl do nothing): at K = 32 the launch has 8 waves per chunk, and one rotation
-        // per chunk meant 209 slabs of one chunk each at T = 6250 for the slab sum to walk through (30 us)
-        const int slots = 4 * h->n_cu * (h->hxt_LP <= 5 ? 2 : 1);
-        int64_t wpc = (int64_t)(h->hals_NpC / 32) * d.KB * h->hxt_groups;
-        int nch = (int)std::max<int64_t>(1, (slots + wpc / 2) / wpc);
-        int64_t clen = std::max<int64_t>(rup((d.Tl + nch - 1) / nch, 6 * h->hxt_LP), 12 * h->hxt_LP);
-        h->hals_clen = (int)clen;
-        nch = (int)((d.Tl + clen - 1) / clen);
-        h->hals_nch = nch >= 4 ? (int)rup(nch, 4) : nch;
-    }
-    const size_t LKN = (size_t)d.L * d.K32 * h->hals_NpH;
-    const size_t LKC = (size_t)d.L * d.K32 * h->hals_NpC;
-    CMFTRY(dalloc_zero(&h->hals_HX, (size_t)d.TP * h->hals_NpC));
-    CMFTRY(dalloc_zero(&h->hals_cslabs, (size_t)hxt_nslabs(h->hals_nch) * LKC));
-    CMFTRY(dalloc_zero(&h->hals_C, LKC));
-    CMFTRY(dalloc_zero(&h->hals_HH, LKN));
-    CMFTRY(dalloc_zero(&h->hals_PW, (size_t)d.L * d.L * d.K32 * d.K32));
-    CMFTRY(dalloc_zero(&h->hals_GW, (size_t)d.K32 * d.K32 * E));
-    CMFTRY(dalloc_zero(&h->hals_GE, (size_t)d.K32 * std::max(1, h->hals_ne) * d.K32 * E));
-    CMFTRY(dalloc_zero(&h->hals_GWt, (size_t)d.K32 * (E + 1) * d.K32)); // the full-window taps as [k'][e][k] for gram_h_mfma_kernel
-    h->gram_ready = true;
-    return CMF_OK;
-}
-
-// Which sweep kernels run and how (re-planned whenever one of the "hals_*" options changes; no allocation here).
-// The reference takes any K, L (hals.jl:90-154).  The fast on-chip sweeps have shape limits: the H sweep slides a 64-column
-// window along a row with the L-1 pending columns in the lanes of one wave (L <= 64); the W sweep keeps the L*Kpad projected
-// state of a unit in registers (up to 32 slots per lane) and K*L new values per unit in LDS.  Outside them the general sweeps
-// run (hals_w_sweep_gen_kernel / hals_h_row_gen_kernel): the same recurrences in the same order with the state in LDS /
-// global memory -- slower, no shape limit.
-static void hals_plan(cmf_handle_s *h)
-{
-    const CmfDims &d = h->d;
-    const int E = 2 * d.L - 1;
-    h->hals_w_general = ((int64_t)d.L * d.K32 > 2048) || ((size_t)4 * d.K * d.L * HALS_NG * sizeof(float) > 64 * 1024) || (h->hals_opt_general & 1);
-    h->hals_h_general = d.L > 64 || (h->hals_opt_general & 2);
-    // stage pipeline: segment length (multiple of 64, >= 256 so that the sweeps and pushes of one stage touch disjoint columns: see
-    // hals_h_stage_kernel); measured at config 5: 8.60 ms (256), 8.13 (320 and 384), 8.56 (512)
-    h->hals_seg = (int)rup(std::max(h->hals_opt_seg, 256), 64);
-    h->hals_nseg = (d.Tl + h->hals_seg - 1) / h->hals_seg;
-    // persistent H pipeline (hals_h_persist_kernel): K sweepers + (K-1) * P pullers, one workgroup per CU, all resident
-    int P = 0;
-    if (h->hals_opt_persist != 0 && !h->hals_h_general) {
-        P = d.K > 1 ? std::min(HALS_PMAX, (h->n_cu - d.K) / (d.K - 1)) : 1;
-        if (h->hals_opt_persist > 1) P = std::min(P, h->hals_opt_persist);
-        const size_t lds = ((size_t)(d.K - 1) * (E + 64 + 2 * (d.L - 1)) + 1024) * sizeof(float);
-        if (P < 2 && d.K > 1) P = 0; // too many rows for the chip: stage pipeline
-        if (lds > 120 * 1024) P = 0;
-        // the grid's workgroups wait for each other: all of them must be resident at once.  Ask the runtime how many
-        // 1024-thread workgroups with this much LDS a CU takes instead of assuming one (a device with fewer usable CUs, or
-        // a kernel whose registers no longer allow 1024 threads, would otherwise only show as an expired wait).
-        while (P >= (d.K > 1 ? 2 : 1)) {
-            int per_cu = 0;
-            const size_t lds_run = std::max((size_t)(d.K - 1) * (2 * d.L - 1 + 64 + 2 * (d.L - 1)) + 1024, (size_t)h->hals_ne * (d.L + 1)) * sizeof(float);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, hals_h_persist_kernel, 1024, lds_run) != hipSuccess) per_cu = 0;
-            if ((long long)per_cu * h->n_cu >= (long long)d.K + (long long)(d.K - 1) * P) break;
-            --P;
-        }
-        if (P < 2 && d.K > 1) P = 0;
-        if (P < 1) P = 0;
-        // With the residual conv chasing the pipeline (hals_chase_rows) a CU is worth more on the conv's side: three pullers per row
-        // instead of four cost the pipeline 1 % (1.44 -> 1.455 ms at config 5; two: 2.07 ms) and give the chasing launch 128 CUs
-        // instead of 96 (profiles/r06_hals_chase.txt: 4.35 -> 4.27 ms per iteration)
-        if (P == 4 && h->hals_opt_persist == 1 && h->hals_opt_chase > 0 && d.K % 32 == 0 && !h->small_k && d.Tl >= 4096) P = 3;
-    }
-    h->hals_pullers = P;
-}
-
-static int hals_ensure(cmf_handle_s *h)
-{
-    if (h->hals_ready) return CMF_OK;
-    const CmfDims &d = h->d;
-    if (h->sharded && h->T_global != d.Tl) return fail(CMF_ERR_STATE, "HALS needs an unsharded handle (the H sweep is sequential along T)");
-    CMFTRY(gram_ensure(h));
-    h->hals_TPp = (int)rup(d.Tl, 64) + (int)std::max<int64_t>(256, rup(d.L, 64) + 128); // (the general row sweep reads a ring of roundup(L, 64) + 64 columns ahead)
-    CMFTRY(dalloc_zero(&h->hals_PT, (size_t)d.K32 * h->hals_TPp));
-    CMFTRY(dalloc_zero(&h->hals_D, (size_t)d.K32 * h->hals_TPp)); // per row: rows run concurrently
-    {   // the persistent pipeline's flags (for the largest puller count a plan may choose) and its status word
-        const size_t nflags = (size_t)(d.K + d.K * HALS_PMAX + 1) * HALS_FLAG_STRIDE;
-        HIPCHK(hipMalloc((void **)&h->hals_flags, nflags * sizeof(int)));
-        HIPCHK(hipHostMalloc((void **)&h->hals_status, sizeof(int), hipHostMallocDefault));
-        *h->hals_status = 0;
-    }
-    hals_plan(h);
-    h->hals_ready = true;
-    return CMF_OK;
-}
-
-// denomW = HH * W (gram_w_kernel): MB p blocks per workgroup, chosen so that the grid is about one workgroup per CU
-static int launch_gram_w(cmf_handle_s *h, const float *HH, float *out)
-{
-    const CmfDims &d = h->d;
-    const int nbp = d.L * d.KB, nbn = d.Np / 32;
-    int MB = 1;
-    for (int m = 5; m >= 2; --m)
-        if (nbp % m == 0 && (nbp / m) * nbn >= h->n_cu) { MB = m; break; }
-    const dim3 grid(nbn, nbp / MB);
-    const size_t lds = (size_t)4 * MB * 16 * 64 * sizeof(float);
-    switch (MB) {
-#define CASE(M_) case M_: hipLaunchKernelGGL((gram_w_kernel<M_>), grid, dim3(256), lds, h->stream, HH, h->Wt, out, d.L * d.K32, h->hals_NpH, d.Np); break;
-        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5)
-#undef CASE
-    }
-    KCHK("gram_w_kernel");
-    return CMF_OK;
-}
-
-// HH = H_unfold * H_unfold' (hals.jl:56-60: the row norms are its diagonal) from the lag correlations of H with itself:
-// one C2 contraction on K32 columns, then an assembly pass with the right-end corrections (hals_hh_kernel)
-static int compute_hh(cmf_handle_s *h, float *out = nullptr)
-{
-    const CmfDims &d = h->d;
-    const bool shard = h->sharded && h->T_global != d.Tl; // out = this shard's additive share of HH (hals_hh_kernel)
-    hipLaunchKernelGGL(hals_hx_kernel, dim3(1024), dim3(256), 0, h->stream, h->H, h->hals_HX, d.TP, d.K32, h->hals_NpC, d.PADL, d.Tl);
-    KCHK("hals_hx_kernel");
-    CMFTRY(launch_hxt_on(h, h->hals_HX, h->hals_HX, h->hals_NpC, 1, h->hals_cslabs, h->hals_nch, h->hals_clen));
-    CMFTRY(launch_slab_sum(h, h->hals_C, h->hals_cslabs, hxt_nslabs(h->hals_nch), (size_t)d.L * d.K32 * h->hals_NpC));
-    hipLaunchKernelGGL(hals_hh_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_C, h->H, out ? out : h->hals_HH, d.Tl, d.L, d.K, d.K32,
-                       h->hals_NpC, h->hals_NpH, d.PADL, shard ? 1 : 0, (h->t_offset + d.Tl == h->T_global) ? 1 : 0);
-    KCHK("hals_hh_kernel");
-    return CMF_OK;
-}
-
-static int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
-{
-    const CmfDims &d = h->d;
-    CMFTRY(hals_ensure(h));
-    // G = resid * H_unfold' (hals.jl:104-110 needs resid * h).  resid = est - data, so G = denomW - numW of the MU path:
-    // numW = H_shift * data' is ONE C2 contraction on the data, denomW = H_shift * est' = HH * W a small GEMM on the Gram
-    // matrix the sweep needs anyway -- no residual in this phase; but the difference of two quantities several times its
-    // size carries ~20x the rounding error through the 640 dependent column updates of the sweep (parity tests), so this
-    // is opt-in (hals_gram = 1) and the default contracts G from the residual the loss conv stores anyway.
-    const size_t LKN = (size_t)d.L * d.K32 * d.Np;
-    const float *G = h->numden, *Gsub = nullptr;
-    if (h->hals_gram == 1) {
-        CMFTRY(hxt_contract(h, h->X, h->X, 1, h->numden));
-        CMFTRY(compute_hh(h));
-        CMFTRY(launch_gram_w(h, h->hals_HH, h->numden + LKN));
-        G = h->numden + LKN;
-        Gsub = h->numden;
-    } else {
-        CMFTRY(ensure_resid(h));
-        CMFTRY(hxt_contract(h, h->est, h->est, 1, h->numden));
-        CMFTRY(compute_hh(h));
-    }
-    // the K*L sequential column updates, k outer / lag inner (hals.jl:90-97)
-    if (h->hals_w_general) { // L * Kpad beyond the register-resident sweep: one workgroup per unit, the state in LDS
-        const size_t lds_g = (size_t)d.L * d.K32 * sizeof(float);
-        if (lds_g > 64 * 1024) return fail(CMF_ERR_UNSUPPORTED, "HALS W sweep: L * Kpad = %d exceeds the 16384 state entries of a workgroup's LDS", d.L * d.K32);
-        ProfScope prof_(h, PROF_HALS_WSWEEP);
-        hipLaunchKernelGGL(hals_w_sweep_gen_kernel, dim3(d.N), dim3(256), lds_g, h->stream, h->Wt, h->Wn, G, Gsub, h->hals_HH,
-                           d.N, d.K, d.L, d.Np, d.K32, h->hals_NpH, (float)l1W, (float)l2W);
-        KCHK("hals_w_sweep_gen_kernel");
-        set_est(h, 0);
-        return CMF_OK;
-    }
-    const int nq = (d.L * d.K32 + 63) / 64; // <= 32 here (hals_ensure)
-    dim3 grid((d.N + 4 * HALS_NG - 1) / (4 * HALS_NG)), block(256);
-    const size_t lds = (size_t)4 * d.K * d.L * HALS_NG * sizeof(float); // <= 64 KB
-    ProfScope prof_(h, PROF_HALS_WSWEEP);
-#define SWEEP(NQ_, WD_)                                                                                                     \
-    hipLaunchKernelGGL((hals_w_sweep_reg_kernel<NQ_, WD_>), grid, block, lds, h->stream, h->Wt, h->Wn, G, Gsub, h->hals_HH, \
-                   d.N, d.K, d.L, d.Np, d.K32, h->hals_NpH, (float)l1W, (float)l2W)
-    if (nq <= 2) SWEEP(2, 8);
-    else if (nq <= 4) SWEEP(4, 8);
-    else if (nq <= 6) SWEEP(6, 8);
-    else if (nq <= 8) SWEEP(8, 8);
-    else if (nq <= 10) SWEEP(10, 8);
-    else if (nq <= 12) SWEEP(12, 8);
-    else if (nq <= 16) SWEEP(16, 8);
-    else if (nq <= 20) SWEEP(20, 4);
-    else if (nq <= 24) SWEEP(24, 4);
-    else SWEEP(32, 4);
-#undef SWEEP
-    KCHK("hals_w_sweep_reg_kernel");
-    set_est(h, 0);
-    return CMF_OK;
-}
-
-// P = transconv(W, resid) (hals.jl:152 needs <W_k window, resid window>) = denomH - numH of the MU path:
-// numH = transconv(W, data) is ONE C3 contraction on the data, denomH = transconv(W, conv(W, H)) comes from the lag-Gram
-// taps applied to H (gram_h_kernel) -- no transposed residual, i.e. one conv launch (1 ms) less per iteration, and the
-// H sweep's short recurrences (L-1 columns) do not amplify the cancellation: H stays within the residual form's test
-// bars (1.8e-5 against the fp64 restatement where the residual form has 1.2e-5).  hals_gram = 0: P as one C3 contraction
-// on the transposed residual.  `contract` = false repeats only the last step (P from the slabs that are still there).
-static int hals_h_project(cmf_handle_s *h, bool contract)
-{
-    const CmfDims &d = h->d;
-    const size_t TK = (size_t)d.Tl * d.K32;
-    const bool gram = h->hals_gram && (size_t)d.K32 * (64 + 2 * (d.L - 1)) * sizeof(float) <= 96 * 1024; // (gram_denom_h's LDS window)
-    if (gram) {
-        if (!h->gram_numden_h) CMFTRY(dalloc_zero(&h->gram_numden_h, 2 * TK));
-        if (contract) {
-            CMFTRY(launch_transconv(h, 1, h->XT));
-            CMFTRY(gram_denom_h(h, h->gram_numden_h + TK));
-        }
-        hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, h->gram_numden_h + TK,
-                           h->tc_S1, d.Tl, d.K32, h->hals_TPp);
-    } else {
-        if (contract) {
-            CMFTRY(launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT));
-            CMFTRY(launch_transconv(h, 1, h->estT));
-        }
-        hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, (const float *)nullptr,
-                           h->tc_S1, d.Tl, d.K32, h->hals_TPp);
-    }
-    KCHK("hals_p_init_kernel");
-    return CMF_OK;
-}
-
-static HalsRowParams hals_row_params(cmf_handle_s *h, double l1H, double l2H)
-{
-    const CmfDims &d = h->d;
-    HalsRowParams q;
-    q.PT = h->hals_PT; q.H = h->H; q.Ht = h->Ht; q.D = h->hals_D; q.GW = h->hals_GW; q.GE = h->hals_GE;
-    q.k = 0; q.t_begin = 0; q.t_end = d.Tl;
-    q.Tl = d.Tl; q.L = d.L; q.K32 = d.K32; q.TP = d.TP; q.TPp = h->hals_TPp; q.PADL = d.PADL; q.ne = h->hals_ne; q.t_edge0 = h->hals_t_edge0;
-    q.l1 = (float)l1H; q.l2 = (float)l2H;
-    return q;
-}
-
-// hals.jl:124-125 (k outer, t inner) as a software pipeline over the rows, one launch per stage (hals_h_stage_kernel);
-// the order of every update is the reference's.  No co-residency requirement.
-static int hals_h_sweep_stage(cmf_handle_s *h, const HalsRowParams &q)
-{
-    const CmfDims &d = h->d;
-    HalsStageParams sp;
-    sp.row = q;
-    sp.Dall = h->hals_D;
-    sp.K = d.K; sp.seg = h->hals_seg; sp.nseg = h->hals_nseg;
-    sp.CB = (h->hals_seg + 2 * (d.L - 1) + 255) / 256;
-    sp.lag = h->hals_opt_lag == 3 ? 3 : 2; // (3 = the unshifted round-1 schedule: the tests compare the two)
-    sp.skew = sp.lag == 2 ? 128 : 0; // see hals_h_stage_kernel
-    // the last row's last segment, +1 for the pushes of the last sweeps (no-ops for the last row)
-    const int nstages = (d.Tl + sp.skew * (d.K - 1) + h->hals_seg - 1) / h->hals_seg + sp.lag * (d.K - 1) + 1;
-    dim3 grid(d.K + d.K * sp.CB, std::max(1, d.K - 1));
-    for (int stage = 0; stage < nstages; ++stage) {
-        sp.stage = stage;
-        hipLaunchKernelGGL(hals_h_stage_kernel, grid, dim3(256), 0, h->stream, sp);
-        KCHK("hals_h_stage_kernel");
-    }
-    return CMF_OK;
-}
-
-// Any L (the on-chip sweeps stop at L = 64): row after row, each swept by one wave with its pending window in LDS
-// (hals_h_row_gen_kernel), its changes then added to the later rows' projections (hals_h_push_gen_kernel) -- the literal
-// k outer / t inner order of hals.jl:124-125, 2K launches.
-static int hals_h_sweep_general(cmf_handle_s *h, HalsRowParams q)
-{
-    const CmfDims &d = h->d;
-    const int M = (int)rup(d.L, 64) + 64;
-    const size_t lds = (size_t)(M + d.L) * sizeof(float);
-    if (lds > 64 * 1024) return fail(CMF_ERR_UNSUPPORTED, "HALS H sweep: L = %d exceeds the LDS window of the general row sweep", d.L);
-    for (int k = 0; k < d.K; ++k) {
-        q.k = k;
-        q.D = h->hals_D + (size_t)k * q.TPp;
-        hipLaunchKernelGGL(hals_h_row_gen_kernel, dim3(1), dim3(64), lds, h->stream, q);
-        KCHK("hals_h_row_gen_kernel");
-        if (k + 1 < d.K) {
-            hipLaunchKernelGGL(hals_h_push_gen_kernel, dim3((d.Tl + 255) / 256, d.K - 1 - k), dim3(256), 0, h->stream, h->hals_PT, q.D, h->hals_GW,
-                               h->hals_GE, k, d.Tl, d.L, d.K32, q.TPp, q.ne, q.t_edge0);
-            KCHK("hals_h_push_gen_kernel");
-        }
-    }
-    return CMF_OK;
-}
-
-// The whole H sweep as ONE persistent launch on h->stream (hals_h_persist_kernel): flags cleared, K sweepers + (K-1) * P pullers
-static int hals_persist_launch(cmf_handle_s *h, const HalsRowParams &q, int debug = 0, bool clear_flags = true)
-{
-    const CmfDims &d = h->d;
-    HalsPersistParams pp;
-    pp.row = q;
-    pp.Dall = h->hals_D;
-    pp.flags = h->hals_flags;
-    pp.host_status = h->hals_status;
-    pp.K = d.K; pp.P = h->hals_pullers; pp.nblk = (d.Tl + 63) / 64;
-    pp.debug = debug;
-    pp.stamps = nullptr;
-    const size_t nflags = (size_t)(d.K + d.K * pp.P + 1) * HALS_FLAG_STRIDE;
-    const size_t lds = std::max((size_t)(d.K - 1) * (2 * d.L - 1 + 64 + 2 * (d.L - 1)) + 1024, (size_t)h->hals_ne * (d.L + 1)) * sizeof(float);
-    ProfScope prof_(h, PROF_HALS_PIPE);
-    if (clear_flags) HIPCHK(hipMemsetAsync(h->hals_flags, 0, nflags * sizeof(int), h->stream));
-    hipLaunchKernelGGL(hals_h_persist_kernel, dim3(d.K + (d.K - 1) * pp.P), dim3(1024), lds, h->stream, pp);
-    KCHK("hals_h_persist_kernel");
-    return CMF_OK;
-}
-
-// How many tile rows of the residual conv chase the row pipeline (0: none).  Needs the persistent pipeline, the one-wave conv
-// tiles (K a multiple of 32), the residual the conv stores (hals_gram != 1), and CUs left over beside the pipeline's.
-static int hals_chase_rows(cmf_handle_s *h)
-{
-    const CmfDims &d = h->d;
-    if (h->hals_opt_chase <= 0 || h->hals_pullers <= 0 || d.K % 32 != 0 || h->small_k || h->hals_gram == 1 || h->hals_debug == 1 || h->hals_debug == 2) return 0;
-    if (h->n_cu % 8 != 0 || h->n_cu > 256) return 0;
-    const int per_xcd = h->n_cu / 8, need = (d.K + (d.K - 1) * h->hals_pullers + 7) / 8;
-    if (per_xcd - need < 4) return 0;
-    const int rows_t = (d.Tl + 63) / 64;
-    if (rows_t < 64) return 0; // (short recordings: the pipeline's span is a few tile rows of conv)
-    return std::min(rows_t, (int)((long long)rows_t * std::min(h->hals_opt_chase, 100) / 100));
-}
-
-// The persistent sweep with the first `ra` tile rows of the residual conv (hals.jl:41's residual, the loss fused) chasing it.
-static int hals_persist_chased(cmf_handle_s *h, const HalsRowParams &q, int ra)
-{
-    const CmfDims &d = h->d;
-    const int per_xcd = h->n_cu / 8, a_per = (d.K + (d.K - 1) * h->hals_pullers + 7) / 8;
-    if (h->hals_sA && h->hals_mask_aper != a_per) { // (another puller count since: other masks)
-        for (hipStream_t *st : {&h->hals_sA, &h->hals_sB}) {
-            HIPCHK(hipStreamSynchronize(*st));
-            HIPCHK(hipStreamDestroy(*st));
-            *st = nullptr;
-        }
-    }
-    if (!h->hals_sA) {
-        // CU mask bit j = CU j / 8 of XCD j % 8 (profiles/r05_cu_mask_experiment.txt: cutting INSIDE every XCD partitions the chip cleanly)
-        uint32_t mask_a[8] = {0}, mask_b[8] = {0};
-        for (int j = 0; j < h->n_cu; ++j) (((j / 8) < a_per) ? mask_a : mask_b)[j / 32] |= 1u << (j % 32);
-        HIPCHK(hipExtStreamCreateWithCUMask(&h->hals_sA, 8, mask_a));
-        HIPCHK(hipExtStreamCreateWithCUMask(&h->hals_sB, 8, mask_b));
-        for (hipEvent_t &e : h->hals_ev)
-            if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->hals_cuB = 8 * (per_xcd - a_per);
-        h->hals_mask_aper = a_per;
-    }
-    hipStream_t keep = h->stream;
-    const size_t nflags = (size_t)(d.K + d.K * h->hals_pullers + 1) * HALS_FLAG_STRIDE;
-    HIPCHK(hipMemsetAsync(h->hals_flags, 0, nflags * sizeof(int), keep)); // (in front of the fork: both launches see cleared flags)
-    HIPCHK(hipEventRecord(h->hals_ev[0], keep));
-    HIPCHK(hipStreamWaitEvent(h->hals_sA, h->hals_ev[0], 0));
-    HIPCHK(hipStreamWaitEvent(h->hals_sB, h->hals_ev[0], 0));
-    int *prog_last = h->hals_flags + (size_t)(d.K - 1) * HALS_FLAG_STRIDE;
-    int *abort_word = h->hals_flags + (size_t)(d.K + d.K * h->hals_pullers) * HALS_FLAG_STRIDE;
-    h->stream = h->hals_sA;
-    int rc = hals_persist_launch(h, q, h->hals_debug, false);
-    h->stream = h->hals_sB;
-    int nA = 0;
-    if (rc == CMF_OK) rc = launch_conv_rows<4>(h, h->est, 0, ra, 0, h->hals_cuB, prog_last, abort_word, h->hals_status, &nA);
-    h->stream = keep;
-    CMFTRY(rc);
-    HIPCHK(hipEventRecord(h->hals_ev[1], h->hals_sA));
-    HIPCHK(hipEventRecord(h->hals_ev[2], h->hals_sB));
-    HIPCHK(hipStreamWaitEvent(keep, h->hals_ev[1], 0)); // H is final behind the pipeline; the chasing launch is joined in front of the
-                                                         // loss reduction (hals_resid_and_loss): the rest of the conv starts beside it
-    h->hals_chased_rows = ra;
-    h->hals_chased_partials = nA;
-    return CMF_OK;
-}
-
-// The residual and the loss behind an H sweep: all of the conv, or what the chasing launch has left (same tiles, same per-tile sums;
-// the partials of the two launches lie one behind the other and are added in that order: reproducible)
-static int hals_resid_and_loss(cmf_handle_s *h, double *sumsq)
-{
-    const CmfDims &d = h->d;
-    const int ra = h->hals_chased_rows, nA = h->hals_chased_partials, rows_t = (d.Tl + 63) / 64;
-    h->hals_chased_rows = h->hals_chased_partials = 0;
-    if (ra <= 0) return resid_and_loss(h, sumsq);
-    int nB = 0;
-    if (ra < rows_t) CMFTRY(launch_conv_rows<4>(h, h->est, ra, rows_t - ra, nA, h->n_cu, nullptr, nullptr, nullptr, &nB));
-    HIPCHK(hipStreamWaitEvent(h->stream, h->hals_ev[2], 0));
-    h->conv_partials = nA + nB;
-    set_est(h, 2);
-    return reduce_partials(h, h->partial, h->conv_partials, 0, sumsq);
-}
-
-static int hals_h_enqueue(cmf_handle_s *h, double l1H, double l2H)
-{
-    const CmfDims &d = h->d;
-    CMFTRY(hals_ensure(h));
-    // the lag-Gram taps of W (GW, and GE for the truncated windows at the right edge)
-    CMFTRY(gram_tables(h));
-    CMFTRY(hals_h_project(h, true));
-    const HalsRowParams q = hals_row_params(h, l1H, l2H);
-    h->hals_l1 = l1H; h->hals_l2 = l2H;
-    set_est(h, 0);
-    if (h->hals_h_general) {
-        ProfScope prof_(h, PROF_HALS_PIPE);
-        return hals_h_sweep_general(h, q);
-    }
-    if (h->hals_pullers > 0) { // the whole sweep as one persistent launch (hals_h_persist_kernel)
-        // Its workgroups wait for each other and every wait is bounded; if one runs out (the grid did not become resident:
-        // another process or stream holds CUs) the sweep is redone from this snapshot on the stage pipeline
-        // (cmf_hals_update_feature_maps looks at the status word once the stream has drained).
-        const size_t nH = (size_t)d.TP * d.K32;
-        if (!h->hals_snap) CMFTRY(dalloc_zero(&h->hals_snap, 2 * nH));
-        HIPCHK(hipMemcpyAsync(h->hals_snap, h->H, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->hals_snap + nH, h->Ht, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        h->hals_chased_rows = h->hals_chased_partials = 0;
-        if (const int ra = hals_chase_rows(h)) return hals_persist_chased(h, q, ra);
-        CMFTRY(hals_persist_launch(h, q, h->hals_debug));
-        return CMF_OK;
-    }
-    ProfScope prof_(h, PROF_HALS_PIPE); // the whole row pipeline (nstages launches) as one timed span
-    return hals_h_sweep_stage(h, q);
-}
-
-static int hals_h_impl(cmf_handle_s *h, double l1H, double l2H)
-{
-    CMFTRY(hals_h_enqueue(h, l1H, l2H));
-    return wb_after_H(h);
-}
-
-// The persistent pipeline reported an expired wait (status word; the stream has drained): H and P hold a half-finished
-// sweep.  Restore H from the snapshot, rebuild P from the contractions that are still in place, and run the sweep on the
-// stage pipeline, which needs no co-residency.  The handle keeps to the stage pipeline from here on.
-static int hals_h_rerun(cmf_handle_s *h)
-{
-    const CmfDims &d = h->d;
-    const size_t nH = (size_t)d.TP * d.K32;
-    *h->hals_status = 0;
-    h->hals_chased_rows = h->hals_chased_partials = 0;
-    h->hals_pullers = 0;
-    h->hals_opt_persist = 0; // (a later re-plan keeps to it)
-    h->hals_reruns += 1;
-    HIPCHK(hipMemcpyAsync(h->H, h->hals_snap, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->Ht, h->hals_snap + nH, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    CMFTRY(hals_h_project(h, false));
-    set_est(h, 0);
-    CMFTRY(hals_h_sweep_stage(h, hals_row_params(h, h->hals_l1, h->hals_l2)));
-    return wb_after_H(h); // (an armed write-back has taken the half-finished H: take it again)
-}
-
-// ---- optional Gram form of the MU iteration ----------------------------------
-static int gram_tables(cmf_handle_s *h) // PW -> GW, GE (the lag-Gram taps of W; shared with HALS)
-{
-    ProfScope prof_(h, PROF_GRAM_TABLES);
-    const CmfDims &d = h->d;
-    hipLaunchKernelGGL(hals_pw_kernel, dim3(d.L * (d.L + 1) / 2, d.KB * d.KB), dim3(64 * PW_NW), 0, h->stream, h->Wn, h->hals_PW, d.N, d.L, d.Np, d.K32, d.KB);
-    KCHK("hals_pw_kernel");
-    hipLaunchKernelGGL(hals_gw_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_PW, h->hals_GW, h->hals_GE, d.L, d.K32, h->hals_ne, d.Tl, h->hals_t_edge0,
-                       h->hals_GWt, 2 * d.L); // (+ the taps as [k'][e][k], E = 2L - 1 padded to an even count, for gram_h_mfma_kernel)
-    KCHK("hals_gw_kernel");
-    return CMF_OK;
-}
-
-static int gram_denom_h(cmf_handle_s *h, float *out)
-{
-    ProfScope prof_(h, PROF_GRAM_DENOM_H);
-    const CmfDims &d = h->d;
-    const size_t lds = (size_t)d.K32 * (64 + 2 * (d.L - 1)) * sizeof(float);
-    if (lds > 96 * 1024) return fail(CMF_ERR_UNSUPPORTED, "Gram form: K*L too large for the LDS window");
-    // columns with the full lag window, in tiles of 128 / fw: the MFMA kernel on the transposed taps; the rest (the right edge
-    // with its per-column taps, and what does not fill a tile): the scalar kernel.  fw waves share the MFMA chain of an
-    // output block: short handles (a T/8 shard) need the extra waves to fill the chip.
-    const int fw = d.Tl < 16384 ? 4 : (d.Tl < 100000 ? 2 : 1);
-    const int tile = 128 / fw;
-    const size_t lds_m = ((size_t)d.K32 * (tile + 2 * (d.L - 1)) + (fw > 1 ? 4096 : 0)) * sizeof(float);
-    const int ntile = lds_m <= 120 * 1024 ? h->hals_t_edge0 / tile : 0;
-    const int t_first = tile * ntile;
-    if (ntile > 0) {
-        // the leftover columns (the right edge with its per-column taps, and what does not fill a tile), a wave per output:
-        // when they are few (the usual case) their workgroups ride at the end of the MFMA kernel's grid
-        const bool ride = d.Tl - t_first <= 512;
-        GramEdge edge;
-        edge.GW = h->hals_GW; edge.GE = h->hals_GE;
-        edge.Tl = d.Tl; edge.ne = h->hals_ne; edge.t_edge0 = h->hals_t_edge0; edge.t_first = t_first;
-        edge.n_main = ntile * d.KB; edge.kq = d.K32 / 4;
-        const int n_edge = ride ? (d.Tl - t_first) * edge.kq : 0;
-        const int Ep = 2 * d.L; // E = 2L - 1 taps padded to an even count (hals_gw_kernel wrote them as [k'][e][k])
-        hipLaunchKernelGGL(gram_h_mfma_kernel, dim3(edge.n_main + n_edge), dim3(256), lds_m, h->stream, h->Ht, h->hals_GWt, out, d.K, d.L, d.K32, d.TP, d.PADL,
-                           Ep, fw, ntile, edge);
-        KCHK("gram_h_mfma_kernel");
-        if (ride) return CMF_OK;
-    }
-    const int block0 = t_first / 64, nblock = (d.Tl + 63) / 64 - block0; // (a half block in front of it is simply formed twice)
-    if (nblock > 0) {
-        hipLaunchKernelGGL(gram_h_kernel, dim3(nblock, d.K32 / 4), dim3(256), lds, h->stream, h->Ht, h->hals_GW, h->hals_GE, out,
-                           d.Tl, d.K, d.L, d.K32, d.TP, d.PADL, h->hals_ne, h->hals_t_edge0, block0);
-        KCHK("gram_h_kernel");
-    }
-    return CMF_OK;
-}
-
-// W phase of the Gram form in two steps, so that a T-sharded group can put its all-reduce between them:
-//   gram_w_partial  numW = H_shift * data' (mult.jl:32; ONE C2 contraction on this handle's columns) -> h->numden[0, LKN),
-//                   and HH = H_unfold * H_unfold' (on a shard: its additive share, see hals_hh_kernel) -> hh_out
-//   gram_w_finish   denomW = H_shift * est' (mult.jl:33) = HH * W -> h->wslabs (free once the slabs are summed), W update
-static int gram_w_partial(cmf_handle_s *h, float *hh_out)
-{
-    CMFTRY(gram_ensure(h));
-    CMFTRY(hxt_contract(h, h->X, h->X, 1, h->numden, true)); // (+ a loss reduction deferred by cmf_iterate)
-    return compute_hh(h, hh_out);
-}
-
-static int gram_w_finish(cmf_handle_s *h, const float *HH, double l1W, double l2W, const float *tail_src, float *tail_dst, int tail_n)
-{
-    const CmfDims &d = h->d;
-    {
-        ProfScope prof_(h, PROF_GRAM_W);
-        CMFTRY(launch_gram_w(h, HH, h->wslabs));
-    }
-    return w_apply_impl(h, l1W, l2W, tail_src, tail_dst, tail_n, h->wslabs); // mult.jl:37-38
-}
-
-static int gram_w_impl(cmf_handle_s *h, double l1W, double l2W)
-{
-    CMFTRY(gram_w_partial(h, nullptr));
-    return gram_w_finish(h, h->hals_HH, l1W, l2W);
-}
-
-// H phase of the Gram form without the loss (mult.jl:44-52)
-static int gram_h_update(cmf_handle_s *h, double l1H, double l2H)
-{
-    const CmfDims &d = h->d;
-    CMFTRY(gram_ensure(h));
-    const size_t TK = (size_t)d.Tl * d.K32;
-    if (!h->gram_numden_h) CMFTRY(dalloc_zero(&h->gram_numden_h, 2 * TK));
-    // numH = tensor_transconv(W, data) (mult.jl:47): one C3 contraction; its fragment slabs are summed by the H update
-    // (gram = 2 needs the sum itself for <H, numH>)
-    CMFTRY(launch_transconv(h, 1, h->XT));
-    if (h->gram == 2) CMFTRY(launch_slab_sum(h, h->gram_numden_h, h->hslabs, h->tc_S1, TK));
-    // denomH = tensor_transconv(W, tensor_conv(W, H)) (mult.jl:44,48) through the lag-Gram taps of W
-    CMFTRY(gram_tables(h));
-    CMFTRY(gram_denom_h(h, h->gram_numden_h + TK));
-    hipLaunchKernelGGL(h_update_kernel, dim3((d.Tl + HUPD_T - 1) / HUPD_T, d.KB), dim3(256), 0, h->stream, h->H, h->Ht,
-                       h->hslabs, TK, h->tc_S1, h->gram_numden_h + TK, (size_t)0, 1,
-                       d.Tl, d.K, d.K32, d.PADL, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
-    KCHK("h_update_kernel");
-    set_est(h, 0);
-    return wb_after_H(h);
-}
-
-static int gram_h_impl(cmf_handle_s *h, double l1H, double l2H, double *loss)
-{
-    const CmfDims &d = h->d;
-    CMFTRY(gram_h_update(h, l1H, l2H));
-    const size_t TK = (size_t)d.Tl * d.K32;
-    double ss = 0.0;
-    if (h->gram == 2) {
-        // ||est - data||^2 = <H, denomH(H)> - 2 <H, numH> + ||data||^2 with the NEW H (adjointness of conv/transconv)
-        CMFTRY(gram_denom_h(h, h->gram_numden_h + TK));
-        const int nb = (int)((TK + 1023) / 1024);
-        if ((size_t)2 * nb > n_partial(h)) return fail(CMF_ERR_UNSUPPORTED, "Gram loss: partial buffer too small");
-        hipLaunchKernelGGL(gram_dot_kernel, dim3(nb), dim3(256), 0, h->stream, h->H, h->gram_numden_h, h->gram_numden_h + TK, h->partial,
-                           d.Tl, d.K, d.K32, d.PADL, nb);
-        KCHK("gram_dot_kernel");
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->d_scalar + 2, (double *)nullptr);
-        KCHK("loss_reduce_kernel");
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial + nb, nb, h->d_scalar + 3, (double *)nullptr);
-        KCHK("loss_reduce_kernel");
-        double a = 0.0, b = 0.0;
-        CMFTRY(read_scalar(h, 2, &a));
-        CMFTRY(read_scalar(h, 3, &b));
-        ss = a - 2.0 * b + h->data_sumsq;
-        if (ss < 0.0) ss = 0.0;
-    } else {
-        CMFTRY(loss_partial_impl(h, &ss)); // exact: conv with the fused loss (mult.jl:55-57)
-    }
-    *loss = std::sqrt(ss) / h->data_norm;
-    return CMF_OK;
-}
-
-// ---- PGD (src/algs/pgd.jl) ---------------------------------------------------------------------
-static int pgd_check(cmf_handle_s *h)
-{
-    if (h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "sharded handle: attach a communicator first (cmf_comm_init_rccl / cmf_comm_init_callbacks)");
-    if (h->pgd_cur_loss < 0.0) h->pgd_cur_loss = h->data_norm; // pgd.jl:151 (the norm, not its square)
-    return CMF_OK;
-}
-
-// pgd.jl:245-253: est (here the residual) with the new factors, loss = norm(data - est)^2, step adaptation
-static int pgd_finish(cmf_handle_s *h, double *step)
-{
-    double loss = 0.0;
-    CMFTRY(resid_and_loss(h, &loss, h->M != nullptr, h->pgd_loss_abs != 0));
-    *step *= (loss < h->pgd_cur_loss) ? 1.05 : 0.70;
-    h->pgd_cur_loss = loss;
-    return CMF_OK;
-}
-
-// UnitNormConstraint (pgd.jl:100-110) on the freshly stepped factor: per-component norms, then the scaling
-static int pgd_unit_norm(cmf_handle_s *h, bool is_W)
-{
-    const CmfDims &d = h->d;
-    if (!h->pgd_knorm) CMFTRY(dalloc_zero(&h->pgd_knorm, (size_t)d.K32));
-    if (is_W) {
-        hipLaunchKernelGGL(pgd_w_knorm_kernel, dim3(d.K), dim3(256), 0, h->stream, h->Wt, h->pgd_knorm, d.N, d.L, d.Np, d.K32);
-        KCHK("pgd_w_knorm_kernel");
-        hipLaunchKernelGGL(pgd_w_kscale_kernel, dim3(1024), dim3(256), 0, h->stream, h->Wt, h->Wn, h->pgd_knorm, d.N, d.K, d.L, d.Np, d.K32);
-        KCHK("pgd_w_kscale_kernel");
-    } else {
-        hipLaunchKernelGGL(pgd_h_knorm_kernel, dim3(d.K), dim3(256), 0, h->stream, h->Ht, h->pgd_knorm, d.Tl, d.TP, d.PADL);
-        KCHK("pgd_h_knorm_kernel");
-        hipLaunchKernelGGL(pgd_h_kscale_kernel, dim3(1024), dim3(256), 0, h->stream, h->H, h->Ht, h->pgd_knorm, d.Tl, d.K, d.K32, d.TP, d.PADL);
-        KCHK("pgd_h_kscale_kernel");
-    }
-    return CMF_OK;
-}
-
-static int pgd_w_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg)
-{
-    const CmfDims &d = h->d;
-    CMFTRY(pgd_check(h));
-    if (nonneg < 0 || nonneg > 2) return fail(CMF_ERR_ARG, "constraint must be 0 (none), 1 (NonnegConstraint) or 2 (UnitNormConstraint)");
-    const float gscale = h->pgd_loss_abs ? 1.f : 2.f; // pgd.jl:31-33 vs :42-44
-    const size_t LKN = (size_t)d.L * d.K32 * d.Np;
-    CMFTRY(ensure_resid(h, h->M != nullptr, h->pgd_loss_abs != 0));                                                            // pgd.jl:230 (:64-67 with a mask)
-    CMFTRY(hxt_contract(h, h->est, h->est, 1, h->numden)); // pgd.jl:206-214
-    dim3 grid(d.Np / 64, d.KB, d.L);
-    const int nblk = (d.Np / 64) * d.KB * d.L;
-    if ((size_t)nblk > n_partial(h)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
-    hipLaunchKernelGGL(pgd_w_grad_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->numden, h->numden + LKN, h->partial,
-                       d.N, d.K, d.Np, d.K32, (float)pen_sq, (float)pen_abs, gscale);                    // pgd.jl:231-234
-    KCHK("pgd_w_grad_kernel");
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nblk, h->d_scalar + 1, (double *)nullptr);
-    KCHK("loss_reduce_kernel");
-    hipLaunchKernelGGL(pgd_w_apply_kernel, grid, dim3(256), 0, h->stream, h->Wt, h->Wn, h->numden + LKN, h->d_scalar + 1,
-                       d.N, d.K, d.Np, d.K32, (float)h->pgd_stepW, nonneg == 1);                         // pgd.jl:237-241
-    KCHK("pgd_w_apply_kernel");
-    if (nonneg == 2) CMFTRY(pgd_unit_norm(h, true));                                                     // pgd.jl:100-110
-    set_est(h, 0);
-    return pgd_finish(h, &h->pgd_stepW);
-}
-
-static int pgd_h_impl(cmf_handle_s *h, double pen_sq, double pen_abs, int nonneg, double *loss)
-{
-    const CmfDims &d = h->d;
-    CMFTRY(pgd_check(h));
-    if (nonneg < 0 || nonneg > 2) return fail(CMF_ERR_ARG, "constraint must be 0 (none), 1 (NonnegConstraint) or 2 (UnitNormConstraint)");
-    const float gscale = h->pgd_loss_abs ? 1.f : 2.f;
-    if (!h->pgd_gradH) CMFTRY(dalloc_zero(&h->pgd_gradH, (size_t)d.Tl * d.K32));
-    if (h->est_kind == 2 + (h->M ? 1 : 0) + (h->pgd_loss_abs ? 2 : 0)) {
-        // est already holds this residual for the resident W, H (stored by the conv that closed the W phase, pgd.jl:245): the
-        // H phase's est of pgd.jl:230 is the same array, only tensor_transconv wants it transposed
-        hipLaunchKernelGGL(transpose_rows_kernel, dim3(d.Np / 64, (d.Tl + 63) / 64), dim3(256), 0, h->stream, h->est, h->estT, d.Tl, d.Np, d.TP, d.PADL);
-        KCHK("transpose_rows_kernel");
-    } else {
-        h->pgd_loss_abs_now = h->pgd_loss_abs;
-        int rc_conv = h->MT ? launch_conv<7>(h, h->estT, d.Tl, h->conv_gy, h->XT) // (mask .* resid)^T (pgd.jl:64-67)
-                            : launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT); // resid^T (pgd.jl:230), or its sign (pgd.jl:42-44)
-        h->pgd_loss_abs_now = 0;
-        CMFTRY(rc_conv);
-    }
-    CMFTRY(launch_transconv(h, 1, h->estT));                     // pgd.jl:218-221
-    dim3 grid((d.Tl + 63) / 64, d.KB);
-    const int nblk = ((d.Tl + 63) / 64) * d.KB;
-    if ((size_t)nblk > n_partial(h)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
-    hipLaunchKernelGGL(pgd_h_grad_kernel, grid, dim3(256), 0, h->stream, h->H, h->hslabs, h->tc_S1, h->pgd_gradH, h->partial,
-                       d.Tl, d.K, d.K32, d.PADL, (float)pen_sq, (float)pen_abs, gscale);
-    KCHK("pgd_h_grad_kernel");
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->partial, nblk, h->d_scalar + 1, (double *)nullptr);
-    KCHK("loss_reduce_kernel");
-    hipLaunchKernelGGL(pgd_h_apply_kernel, grid, dim3(256), 0, h->stream, h->H, h->Ht, h->pgd_gradH, h->d_scalar + 1,
-                       d.Tl, d.K, d.K32, d.PADL, d.TP, (float)h->pgd_stepH, nonneg == 1);
-    KCHK("pgd_h_apply_kernel");
-    if (nonneg == 2) CMFTRY(pgd_unit_norm(h, false)); // pgd.jl:100-110
-    set_est(h, 0);
-    CMFTRY(wb_after_H(h));
-    CMFTRY(pgd_finish(h, &h->pgd_stepH));
-    *loss = std::sqrt(h->pgd_cur_loss / (h->data_norm * h->data_norm)); // pgd.jl:201
-    return CMF_OK;
-}
-
-// ---- PGD on T-sharded groups (pgd.jl:158-255 with data / est / H cut along T, W replicated) ------------------------------
-// compute_gradW! (pgd.jl:206-214) is the C2 contraction: every shard contracts its own residual columns and ONE all-reduce
-// sums the K x N x L partial gradients; the penalty, norm(grad) and the step are then identical replicated arithmetic.
-// compute_gradH! (:218-221) is tensor_transconv! on the shard's columns plus its right residual halo (the conv covers
-// Tl + halo_r columns, as in the MU rule); norm(gradH)^2, the per-component norms of UnitNormConstraint and the loss are
-// sums over shards, combined in rank order on the host (exact: doubles travel as two 32-bit words).  The step-size state
-// machine (stepW, stepH, cur_loss; :139-154, :248-253) is replicated: every rank takes the same decisions from the same sums.
-
-// n doubles at device address ptr[i] of every local shard -> their sum over ALL ranks (rank order), written back to every shard
-static int group_sum_doubles(cmf_group_s *g, const std::vector<double *> &ptr, int n, std::vector<double> *host_out = nullptr)
-{
-    const size_t nl = g->sh.size();
-    std::vector<std::vector<double>> local(nl, std::vector<double>((size_t)n));
-    for (size_t i = 0; i < nl; ++i) {
-        cmf_handle_s *s = g->sh[i];
-        CMFTRY(group_use(s));
-        HIPCHK(hipMemcpyAsync(local[i].data(), ptr[i], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));
-    }
-    std::vector<double> total((size_t)n, 0.0);
-    if (g->one_process) {
-        for (int r = 0; r < g->nranks; ++r)
-            for (size_t i = 0; i < nl; ++i)
-                if (g->rank[i] == r)
-                    for (int j = 0; j < n; ++j) total[(size_t)j] += local[i][(size_t)j];
-    } else { // one all-gather of n doubles per rank, summed in rank order
-        std::vector<double> all;
-        CMFTRY(group_gather_doubles(g, local[0], all, n));
-        for (int r = 0; r < g->nranks; ++r)
-            for (int j = 0; j < n; ++j) total[(size_t)j] += all[(size_t)r * n + j];
-    }
-    for (size_t i = 0; i < nl; ++i) {
-        cmf_handle_s *s = g->sh[i];
-        CMFTRY(group_use(s));
-        HIPCHK(hipMemcpyAsync(ptr[i], total.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream)); // `total` is pageable host memory: finish before it goes out of scope
-    }
-    if (host_out) *host_out = total;
-    return CMF_OK;
-}
-
-static bool group_masked(const cmf_group_s *g) { return g->sh[0]->M != nullptr; }
-
-// pgd.jl:245-253 on the group: the residual with the new factors on every shard, loss = sum over shards
-static int group_pgd_finish(cmf_handle_s *st, cmf_group_s *g, double *step)
-{
-    std::vector<double *> ptr;
-    for (cmf_handle_s *s : g->sh) {
-        CMFTRY(group_use(s));
-        CMFTRY(resid_and_loss(s, nullptr, group_masked(g), st->pgd_loss_abs != 0));
-        ptr.push_back(s->d_scalar);
-    }
-    std::vector<double> tot;
-    CMFTRY(group_sum_doubles(g, ptr, 1, &tot));
-    const double loss = tot[0];
-    *step *= (loss < st->pgd_cur_loss) ? 1.05 : 0.70;
-    st->pgd_cur_loss = loss;
-    return CMF_OK;
-}
-
-static int group_pgd_prepare(cmf_handle_s *st, cmf_group_s *g, int nonneg)
-{
-    if (nonneg < 0 || nonneg > 2) return fail(CMF_ERR_ARG, "constraint must be 0 (none), 1 (NonnegConstraint) or 2 (UnitNormConstraint)");
-    if (g->gram || g->overlap) return fail(CMF_ERR_STATE, "the PGD rule runs on a group with the options gram and allreduce_overlap off");
-    if (st->pgd_cur_loss < 0.0) st->pgd_cur_loss = g->data_norm; // pgd.jl:151 (the norm, not its square)
-    for (cmf_handle_s *s : g->sh) {
-        s->pgd_loss_abs = st->pgd_loss_abs;
-        s->carry = CmfLossCarry{};
-    }
-    if (!g->halos_current) CMFTRY(group_exchange_halos(g));
-    return CMF_OK;
-}
-
-static int group_pgd_w(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double pen_abs, int nonneg)
-{
-    GroupInline scope(g);
-    CMFTRY(scope.rc);
-    CMFTRY(group_pgd_prepare(st, g, nonneg));
-    const CmfDims &d0 = g->sh[0]->d;
-    const float gscale = st->pgd_loss_abs ? 1.f : 2.f; // pgd.jl:31-33 vs :42-44
-    const size_t LKN = (size_t)d0.L * d0.K32 * d0.Np;
-    for (cmf_handle_s *s : g->sh) {
-        CMFTRY(group_use(s));
-        CMFTRY(ensure_resid(s, group_masked(g), st->pgd_loss_abs != 0));                                 // pgd.jl:230 on the shard's columns
-        CMFTRY(hxt_contract(s, s->est, s->est, 1, s->numden)); // pgd.jl:206-214, partial over t
-    }
-    CMFTRY(group_allreduce(g, g->red, 0, LKN)); // the one bulk exchange: K x N x L partial gradients
-    for (cmf_handle_s *s : g->sh) {
-        const CmfDims &d = s->d;
-        CMFTRY(group_use(s));
-        dim3 grid(d.Np / 64, d.KB, d.L);
-        const int nblk = (d.Np / 64) * d.KB * d.L;
-        if ((size_t)nblk > n_partial(s)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
-        hipLaunchKernelGGL(pgd_w_grad_kernel, grid, dim3(256), 0, s->stream, s->Wt, s->numden, s->numden + LKN, s->partial,
-                           d.N, d.K, d.Np, d.K32, (float)pen_sq, (float)pen_abs, gscale);                // pgd.jl:231-234 (replicated)
-        KCHK("pgd_w_grad_kernel");
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s->stream, s->partial, nblk, s->d_scalar + 1, (double *)nullptr);
-        KCHK("loss_reduce_kernel");
-        hipLaunchKernelGGL(pgd_w_apply_kernel, grid, dim3(256), 0, s->stream, s->Wt, s->Wn, s->numden + LKN, s->d_scalar + 1,
-                           d.N, d.K, d.Np, d.K32, (float)st->pgd_stepW, nonneg == 1);                    // pgd.jl:237-241
-        KCHK("pgd_w_apply_kernel");
-        if (nonneg == 2) CMFTRY(pgd_unit_norm(s, true));                                                 // pgd.jl:100-110 (W is replicated)
-        set_est(s, 0);
-    }
-    return group_pgd_finish(st, g, &st->pgd_stepW);
-}
-
-static int group_pgd_h(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double pen_abs, int nonneg, double *loss)
-{
-    GroupInline scope(g);
-    CMFTRY(scope.rc);
-    CMFTRY(group_pgd_prepare(st, g, nonneg));
-    const float gscale = st->pgd_loss_abs ? 1.f : 2.f;
-    std::vector<double *> nrm;
-    for (cmf_handle_s *s : g->sh) {
-        const CmfDims &d = s->d;
-        CMFTRY(group_use(s));
-        if (!s->pgd_gradH) CMFTRY(dalloc_zero(&s->pgd_gradH, (size_t)d.Tl * d.K32));
-        // the transposed residual on the shard's columns AND its right lag halo (transconv reads est[:, t .. t+L-1])
-        if (s->est_kind == 2 + (s->M ? 1 : 0) + (st->pgd_loss_abs ? 2 : 0)) {
-            // the shard's own columns are in est already (the conv that closed the W phase): transposed, not convolved again;
-            // the <= L-1 halo columns are formed directly (resid_halo_kernel)
-            hipLaunchKernelGGL(transpose_rows_kernel, dim3(d.Np / 64, (d.Tl + 63) / 64), dim3(256), 0, s->stream, s->est, s->estT, d.Tl, d.Np, d.TP, d.PADL);
-            KCHK("transpose_rows_kernel");
-            if (s->halo_r > 0) {
-                hipLaunchKernelGGL(resid_halo_kernel, dim3(d.Np / 128, s->halo_r), dim3(128), 0, s->stream, s->Wt, s->H, s->XT, s->MT, s->estT,
-                                   d.Tl, d.K, d.L, d.K32, d.Np, d.TP, d.PADL, st->pgd_loss_abs);
-                KCHK("resid_halo_kernel");
-            }
-        } else {
-            s->pgd_loss_abs_now = st->pgd_loss_abs;
-            int rc_conv = s->MT ? launch_conv<7>(s, s->estT, d.Tl + s->halo_r, s->conv_gy_ext, s->XT)
-                                : launch_conv<5>(s, s->estT, d.Tl + s->halo_r, s->conv_gy_ext, s->XT);
-            s->pgd_loss_abs_now = 0;
-            CMFTRY(rc_conv);
-        }
-        CMFTRY(launch_transconv(s, 1, s->estT));                                                         // pgd.jl:218-221
-        dim3 grid((d.Tl + 63) / 64, d.KB);
-        const int nblk = ((d.Tl + 63) / 64) * d.KB;
-        if ((size_t)nblk > n_partial(s)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
-        hipLaunchKernelGGL(pgd_h_grad_kernel, grid, dim3(256), 0, s->stream, s->H, s->hslabs, s->tc_S1, s->pgd_gradH, s->partial,
-                           d.Tl, d.K, d.K32, d.PADL, (float)pen_sq, (float)pen_abs, gscale);
-        KCHK("pgd_h_grad_kernel");
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s->stream, s->partial, nblk, s->d_scalar + 1, (double *)nullptr);
-        KCHK("loss_reduce_kernel");
-        nrm.push_back(s->d_scalar + 1);
-    }
-    CMFTRY(group_sum_doubles(g, nrm, 1)); // norm(gradH)^2 over all shards (pgd.jl:236)
-    std::vector<double *> kn;
-    for (cmf_handle_s *s : g->sh) {
-        const CmfDims &d = s->d;
-        CMFTRY(group_use(s));
-        dim3 grid((d.Tl + 63) / 64, d.KB);
-        hipLaunchKernelGGL(pgd_h_apply_kernel, grid, dim3(256), 0, s->stream, s->H, s->Ht, s->pgd_gradH, s->d_scalar + 1,
-                           d.Tl, d.K, d.K32, d.PADL, d.TP, (float)st->pgd_stepH, nonneg == 1);
-        KCHK("pgd_h_apply_kernel");
-        if (nonneg == 2) { // pgd.jl:100-110: the norm of a component runs over all of T
-            if (!s->pgd_knorm) CMFTRY(dalloc_zero(&s->pgd_knorm, (size_t)d.K32));
-            hipLaunchKernelGGL(pgd_h_knorm_kernel, dim3(d.K), dim3(256), 0, s->stream, s->Ht, s->pgd_knorm, d.Tl, d.TP, d.PADL);
-            KCHK("pgd_h_knorm_kernel");
-            kn.push_back(s->pgd_knorm);
-        }
-        set_est(s, 0);
-    }
-    if (nonneg == 2) {
-        CMFTRY(group_sum_doubles(g, kn, g->sh[0]->d.K));
-        for (cmf_handle_s *s : g->sh) {
-            const CmfDims &d = s->d;
-            CMFTRY(group_use(s));
-            hipLaunchKernelGGL(pgd_h_kscale_kernel, dim3(1024), dim3(256), 0, s->stream, s->H, s->Ht, s->pgd_knorm, d.Tl, d.K, d.K32, d.TP, d.PADL);
-            KCHK("pgd_h_kscale_kernel");
-        }
-    }
-    for (cmf_handle_s *s : g->sh) { // (an armed write-back: every shard's block of H is final here)
-        CMFTRY(group_use(s));
-        CMFTRY(wb_after_H(s));
-    }
-    CMFTRY(group_exchange_halos(g));
-    CMFTRY(group_pgd_finish(st, g, &st->pgd_stepH));
-    *loss = std::sqrt(st->pgd_cur_loss / (g->data_norm * g->data_norm)); // pgd.jl:201
-    return CMF_OK;
-}
-
-// MaskedLoss on a group: the mask is cut like data -- shard r holds its own columns in both layouts and the right lag halo
-// in the transposed one.  One process: `mask` is the whole N x T matrix; one process per shard: the block of data_local.
-static int group_set_mask(cmf_group_s *g, const double *mask)
-{
-    CMFTRY(group_sync(g));
-    for (size_t i = 0; i < g->sh.size(); ++i) {
-        cmf_handle_s *s = g->sh[i];
-        const CmfDims &d = s->d;
-        CMFTRY(group_use(s));
-        set_est(s, 0);
-        if (!mask) {
-            if (s->M) (void)hipFree(s->M);
-            if (s->MT) (void)hipFree(s->MT);
-            s->M = s->MT = nullptr;
-            continue;
-        }
-        const size_t TPNp = (size_t)d.TP * d.Np;
-        if (!s->M) CMFTRY(dalloc_zero(&s->M, TPNp));
-        if (!s->MT) CMFTRY(dalloc_zero(&s->MT, TPNp));
-        const double *m = g->one_process ? mask + (size_t)g->t0[(size_t)g->rank[i]] * d.N : mask;
-        CMFTRY(upload_cols(s, m, 0, d.Tl, true, false, s->M, s->MT));
-        if (s->halo_r > 0) CMFTRY(upload_cols(s, m + (size_t)d.Tl * d.N, d.Tl, s->halo_r, false, false, s->M, s->MT));
-    }
-    return CMF_OK;
-}
-
 // ---- stand-alone primitives ----------------------------------------------------------------
 static int download_rows(cmf_handle_s *h, double *out, const float *buf, int row0, int64_t nrows, int width, int stride)
 {
@@ -3816,4 +2133,3 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
     return CMF_OK;
 }
 
-} // extern "C"

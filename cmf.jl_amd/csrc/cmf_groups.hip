@@ -1,76 +1,7 @@
-// cmf_group.h -- T-sharded groups behind the C ABI (included by cmf_api.hip).
-//
-// A *group* is R contiguous column blocks ("shards") of one problem: data / est / H are partitioned along T, W is
-// replicated.  The caller holds ONE handle and makes the reference's two calls per iteration
-// (update_motifs! / update_feature_maps!, alternating.jl:52,54); the library runs the sharded iteration:
-//
-//   update_motifs!        per shard: est = conv(W,H) (reused), [numW | denomW] partial sums        (mult.jl:28-34)
-//                         ONE all-reduce(sum) of [numW | denomW | tail]   <- the only bulk exchange; the tail carries
-//                                                                            the previous loss scalar of every rank
-//                         per shard: the identical W update                                        (mult.jl:37-38)
-//   update_feature_maps!  per shard: est (new W) on own columns + right lag halo, numH, denomH, H  (mult.jl:44-52)
-//                         ONE all-gather of every shard's [first | last] L-1 columns of H (2 x 2.4 KB per shard)
-//                         per shard: loss conv, sum((est - data)^2) -> the tail of the next all-reduce (mult.jl:55-57)
-//
-// Two ways to form a group:
-//   cmf_create_multi       one process drives all shards (ndev devices, per-device streams; RCCL communicators from
-//                          ncclCommInitAll, collectives inside ncclGroupStart/End) -- what a Julia caller of `fit` gets;
-//   cmf_create_shard + cmf_comm_init_rccl / cmf_comm_init_callbacks
-//                          one process per shard (torchrun-style launchers; bench.py --gpus N).
-// Transports: RCCL over xGMI (the product path), "loopback" (all shards of a cmf_create_multi group on ONE device:
-// the collectives are plain kernels -- exercises middle-rank shards on a one-GPU box), and host callbacks (the
-// library stages the buffers through pinned host memory and the host performs the collective, e.g. gloo in the tests).
-//
-// Who enqueues (one-process groups with a stream per shard -- RCCL, peer, loopback-streams): by default one ENQUEUE WORKER
-// thread per shard, bound to the shard's device, takes the shard's whole share of an iteration -- its kernels and its
-// collective calls -- from a small queue, so the calling thread only posts (and polls the pinned loss words): eight shards
-// are enqueued in parallel instead of one after the other.  Each worker calls ncclAllReduce / ncclAllGather on ITS
-// communicator from ITS thread, without ncclGroupStart/End: that is RCCL's one-thread-per-device mode, in which no thread
-// ever manages two devices -- chosen over "workers meet at a barrier, the caller issues one grouped call" because the
-// barrier would put a host round trip back into every collective (two per iteration), which is exactly what the workers
-// are there to remove.  Option "enqueue_threads" = 0 (or CMF_ENQUEUE_THREADS=0) restores the single-thread form with
-// grouped RCCL calls.  The phases are written once, as lists of per-shard segments and collectives (GroupStep), and run
-// either way.
-#pragma once
-#include <dlfcn.h>
-#include <memory>
-#include <mutex>
-#include "cmf_workers.h"
+// cmf_groups.hip -- T-sharded groups behind the C ABI: transports, the sharded MU / PGD iteration, group construction.
+#include "cmf_internal.h"
 
-// The handful of RCCL types this file passes through function pointers, declared here (values as in rccl.h of ROCm 7:
-// the NCCL ABI these have had since NCCL 2.0) so that the library builds -- and loads -- on hosts without the RCCL
-// development package; RCCL itself is bound with dlopen below.
-extern "C" {
-typedef struct ncclComm *ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-typedef enum { ncclSuccess = 0 } ncclResult_t;      // non-zero codes are only ever turned into text by ncclGetErrorString
-typedef enum { ncclFloat32 = 7 } ncclDataType_t;
-typedef enum { ncclSum = 0 } ncclRedOp_t;
-}
-
-// ---- RCCL, bound at run time --------------------------------------------------------------------------------------
-// librccl is opened with dlopen the first time a communicator is needed: the library then loads on hosts without
-// RCCL, and when the process already holds an RCCL (e.g. PyTorch's bundled copy, same SONAME) that copy is reused
-// instead of a second one being mapped.
-struct RcclApi {
-    void *dl = nullptr;
-    std::string path;
-    ncclResult_t (*GetVersion)(int *) = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // optional
-    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr; // optional
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-};
-static RcclApi g_rccl;
-
-static int rccl_load()
+int rccl_load()
 {
     static std::mutex mu; // handles are per-thread, but this table is per process
     std::lock_guard<std::mutex> lock(mu);
@@ -111,68 +42,6 @@ static int rccl_load()
     return CMF_OK;
 }
 
-#define RCCLCHK(expr)                                                                                          \
-    do {                                                                                                       \
-        ncclResult_t r_ = (expr);                                                                              \
-        if (r_ != ncclSuccess) return fail(CMF_ERR_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));   \
-    } while (0)
-
-// ---- the group ----------------------------------------------------------------------------------------------------
-enum { CMF_TR_LOOPBACK = 0, CMF_TR_RCCL = 1, CMF_TR_CALLBACKS = 2, CMF_TR_PEER = 3 };
-enum { CMF_ERR_ECHO = -1000 }; // internal: a worker that gave up because ANOTHER shard's job failed (never crosses the ABI)
-
-// ---- enqueue workers ----------------------------------------------------------------------------------------------
-// One thread per local shard of a one-process group (see the file comment); the queue, the meeting point and the abort
-// protocol live in cmf_workers.h (free of HIP: stress-tested under ThreadSanitizer on the CPU).
-struct cmf_group_s {
-    int nranks = 1;
-    int transport = CMF_TR_LOOPBACK;
-    bool one_process = false;            // cmf_create_multi: all shards are local, H crosses the ABI as the global K x T matrix
-    std::vector<cmf_handle_s *> sh;      // local shards
-    std::vector<int> rank;               // global rank of each local shard
-    std::vector<ncclComm_t> comm;        // RCCL communicators (one per local shard)
-    std::vector<ncclComm_t> comm2;       // ... of the communication stream ("lane 1": the overlap form's bulk all-reduce never shares a
-                                         // communicator with a collective of the main stream); created when the overlap form is switched on
-    cmf_allreduce_fn ar_cb = nullptr;    // host-callback transport
-    cmf_allgather_fn ag_cb = nullptr;
-    void *cb_user = nullptr;
-    float *cb_host = nullptr;            // pinned staging of the callback transport
-    size_t cb_host_elems = 0;
-    // device buffers, one per local shard
-    std::vector<float *> red;            // [LKN2 + tail]: numW | denomW | loss tail  (the shard's numden points here)
-    std::vector<float *> halo_send;      // [2 * HC]: own first | last L-1 columns of H
-    std::vector<float *> halo_all;       // [nranks * 2 * HC]: every rank's send block (the shard's receive halos point inside)
-    std::vector<float *> loss_all;       // [tail]: gathered (hi, lo) loss pairs of the synchronous path
-    float *h_tail = nullptr;             // pinned host: 2 ring slots (the late loss read-back: pairs + stamp) + 1 for the synchronous one
-    int64_t slot_len = 0;                // floats per slot
-    int64_t LKN2 = 0, tail = 0, HC = 0;
-    int64_t HHsz = 0;                    // floats of HH = H_unfold H_unfold' ((L*Kpad) x its 128-padded pitch): the Gram form's share
-    int gram = 0;                        // option "gram" on a group: the all-reduce carries [numW | HH | tail] instead of [numW | denomW | tail]
-    int64_t N = 0, T = 0, K = 0, L = 0;
-    std::vector<int64_t> t0, t1;         // column block of every rank
-    double data_sumsq = 0.0, data_norm = 0.0;
-    bool overlap = false;                // option "allreduce_overlap": numW contracted + all-reduced under the loss conv
-    bool num_ready = false;              // overlap form: the numW half belongs to the current H and is reduced (or in flight)
-    bool halos_current = false;
-    // loopback with one stream PER SHARD (CMF_COMM_LOOPBACK_STREAMS): the collectives keep RCCL's stream semantics -- the
-    // operation starts when every shard's stream has reached it and every shard's stream continues when it is done --
-    // through events, so a missing dependency between shards cannot hide behind a shared stream (tests on a one-GPU box)
-    std::vector<float *> gbuf;           // scratch of group_gather_doubles (one per local shard)
-    size_t gbuf_words = 0;
-    bool loop_ms = false;
-    hipEvent_t ev_in[2][CMF_MAX_LOCAL] = {};  // [main | comm stream][shard]
-    hipEvent_t ev_out[2] = {nullptr, nullptr};
-    // peer transport: events of the stream fences around its kernels, [lane][before | after the kernel][shard]
-    hipEvent_t ev_peer[2][2][CMF_MAX_LOCAL] = {};
-    // enqueue workers (empty: the calling thread enqueues every shard itself)
-    CmfWorkerPool pool;
-    int test_fail_shard = -1;             // test hook CMF_TEST_FAIL_SHARD (group_check_ready)
-    int64_t enqueue_ns = 0, enqueue_iters = 0; // cmf_iterate: time the calling thread spent enqueueing / posting, and the iterations it covers
-    int force_inline = 0;                // > 0: step lists run on the calling thread although workers exist (GroupInline)
-    bool failed = false;                 // a wait for the group ran out (or a collective reported an error): streams and communicators
-                                         // may never drain -- destruction aborts the communicators and does not wait for the streams
-};
-
 static void group_partition(int64_t T, int R, int64_t L, std::vector<int64_t> &t0, std::vector<int64_t> &t1)
 {
     const int64_t base = (T + R - 1) / R;
@@ -187,9 +56,8 @@ static void group_partition(int64_t T, int R, int64_t L, std::vector<int64_t> &t
 
 // Where the loss tail starts in the all-reduce buffer: behind [numW | denomW], or behind [numW | HH] in the Gram form --
 // either way the buffer that travels is ONE contiguous range that ends with the tail.
-static inline size_t group_tail_off(const cmf_group_s *g) { return (size_t)(g->gram ? g->LKN2 / 2 + g->HHsz : g->LKN2); }
 
-static int group_use(cmf_handle_s *s)
+int group_use(cmf_handle_s *s)
 {
     HIPCHK(hipSetDevice(s->device));
     return CMF_OK;
@@ -202,7 +70,7 @@ static bool group_enqueued(const cmf_group_s *g) { return cmf_pool_idle(g->pool)
 // Wait until every worker has run every posted job; the first failure (in shard order) becomes this thread's error.
 // Bounded like every wait of the group (CMF_WAIT_TIMEOUT_S): a worker that does not come back from a collective call ends
 // in CMF_ERR_COMM and a group marked failed, not in a hang.
-static int group_join(cmf_group_s *g)
+int group_join(cmf_group_s *g)
 {
     if (g->pool.empty()) return CMF_OK;
     if (!cmf_pool_wait(g->pool, wait_timeout_s())) {
@@ -219,14 +87,6 @@ static int group_join(cmf_group_s *g)
     return rc;
 }
 
-// The entries that are not on the MU hot path (PGD, masks, stand-alone timings, ...) enqueue from the calling thread as they
-// always did: inside this scope the workers are idle and every step list runs in line.
-struct GroupInline {
-    cmf_group_s *g;
-    int rc;
-    explicit GroupInline(cmf_group_s *g_) : g(g_), rc(group_join(g_)) { ++g->force_inline; }
-    ~GroupInline() { --g->force_inline; }
-};
 
 // Meeting point of the workers inside a collective of the event-ordered transports (an event must have been recorded before
 // another stream is told to wait for it).  Gives up when any job of the group has failed.
@@ -236,7 +96,6 @@ static int group_barrier(cmf_group_s *g)
     return rc == 0 ? CMF_OK : fail(CMF_ERR_ECHO, "another shard of the group failed");
 }
 
-static size_t group_stop_workers(cmf_group_s *g) { return cmf_pool_stop(g->pool, g->failed); }
 
 static bool group_wants_workers(const cmf_group_s *g)
 {
@@ -248,7 +107,7 @@ static bool group_wants_workers(const cmf_group_s *g)
     return g->transport == CMF_TR_RCCL || g->transport == CMF_TR_PEER || (g->transport == CMF_TR_LOOPBACK && g->loop_ms);
 }
 
-static int group_start_workers(cmf_group_s *g)
+int group_start_workers(cmf_group_s *g)
 {
     if (!g->pool.empty() || !group_wants_workers(g)) return CMF_OK;
     std::vector<int> devs;
@@ -382,7 +241,7 @@ static int peer_allreduce_launch(cmf_group_s *g, size_t i, const CmfPtrTable &ta
 // ---- collectives, issued by the calling thread for all local shards -------------------------------------------------
 // In-place sum over all ranks of `count` floats at offset `off` of every local shard's buffer `bufs[i]`, ordered on the
 // shards' main streams (lane 0) or communication streams (lane 1).
-static int group_allreduce(cmf_group_s *g, const std::vector<float *> &bufs, size_t off, size_t count, int lane = 0)
+int group_allreduce(cmf_group_s *g, const std::vector<float *> &bufs, size_t off, size_t count, int lane)
 {
     const size_t nl = g->sh.size();
     if (g->nranks == 1 && g->transport != CMF_TR_RCCL) return CMF_OK;
@@ -434,7 +293,7 @@ static int group_allreduce(cmf_group_s *g, const std::vector<float *> &bufs, siz
 }
 
 // recv[i] (nranks * count floats) = every rank's send block (count floats at send[i]), in rank order
-static int group_allgather(cmf_group_s *g, const std::vector<float *> &send, const std::vector<float *> &recv, size_t count)
+int group_allgather(cmf_group_s *g, const std::vector<float *> &send, const std::vector<float *> &recv, size_t count)
 {
     const size_t nl = g->sh.size();
     switch (g->transport) {
@@ -651,7 +510,7 @@ static double group_decode_tail(const cmf_group_s *g, const float *tail)
 
 // n doubles per rank -> all of them on every rank (exact: the 8 bytes of a double travel through the all-gather as two
 // 32-bit words).  Every local shard contributes vals[i*n .. i*n+n); out[r*n + j] for all ranks r.  Synchronises.
-static int group_gather_doubles(cmf_group_s *g, const std::vector<double> &vals, std::vector<double> &out, int n = 1)
+int group_gather_doubles(cmf_group_s *g, const std::vector<double> &vals, std::vector<double> &out, int n)
 {
     const size_t nl = g->sh.size();
     out.assign((size_t)g->nranks * n, 0.0);
@@ -690,7 +549,7 @@ static int group_gather_doubles(cmf_group_s *g, const std::vector<double> &vals,
     return CMF_OK;
 }
 
-static int group_check_ready(cmf_group_s *g)
+int group_check_ready(cmf_group_s *g)
 {
     if (g->failed) return fail(CMF_ERR_COMM, "this group has failed (a collective did not complete, or a communicator reported an error): destroy the handle");
     // test hook (honoured only with CMF_TEST_HOOKS=1): that shard's next all-reduce call fails.  The environment is read HERE, by
@@ -704,7 +563,7 @@ static int group_check_ready(cmf_group_s *g)
     return CMF_OK;
 }
 
-static int group_sync(cmf_group_s *g)
+int group_sync(cmf_group_s *g)
 {
     CMFTRY(group_join(g));
     for (cmf_handle_s *s : g->sh) {
@@ -891,7 +750,7 @@ static void build_update_motifs(cmf_group_s *g, StepList &st, double l1W, double
         return w_apply_impl(s, l1W, l2W);
     });
 }
-static int group_update_motifs(cmf_group_s *g, double l1W, double l2W)
+int group_update_motifs(cmf_group_s *g, double l1W, double l2W)
 {
     StepList st;
     build_update_motifs(g, st, l1W, l2W);
@@ -912,14 +771,14 @@ static void build_update_feature_maps(cmf_group_s *g, StepList &st, double l1H, 
     build_loss_partials(g, st, defer && !(g->gram && g->overlap));
 }
 // sumsq != NULL: also reduce the loss now (synchronises)
-static int group_update_feature_maps(cmf_group_s *g, double l1H, double l2H, double *sumsq)
+int group_update_feature_maps(cmf_group_s *g, double l1H, double l2H, double *sumsq)
 {
     StepList st;
     build_update_feature_maps(g, st, l1H, l2H, sumsq == nullptr);
     return sumsq ? group_loss_now(g, std::move(st), sumsq) : group_run(g, std::move(st));
 }
 
-static int group_compute_loss(cmf_group_s *g, double *loss)
+int group_compute_loss(cmf_group_s *g, double *loss)
 {
     StepList st;
     if (!g->halos_current) build_exchange_halos(g, st);
@@ -934,7 +793,7 @@ static int group_compute_loss(cmf_group_s *g, double *loss)
 // iteration i+1's all-reduce and is read from pinned memory after iteration i+1 has been enqueued, so the host never
 // stalls the device between iterations; the last loss is flushed with the small all-gather.  stamps (optional):
 // host seconds since entry at which each loss became known.
-static int group_iterate(cmf_group_s *g, int64_t n, int eval_mode, double l1W, double l2W, double l1H, double l2H,
+int group_iterate(cmf_group_s *g, int64_t n, int eval_mode, double l1W, double l2W, double l1H, double l2H,
                          double *losses, double *stamps)
 {
     const auto t_begin = std::chrono::steady_clock::now();
@@ -995,7 +854,7 @@ static int group_iterate(cmf_group_s *g, int64_t n, int eval_mode, double l1W, d
     return ds->finish(stamps, n);
 }
 
-static int group_set_factors(cmf_group_s *g, const double *W, const double *H)
+int group_set_factors(cmf_group_s *g, const double *W, const double *H)
 {
     CMFTRY(group_join(g));
     for (size_t i = 0; i < g->sh.size(); ++i) {
@@ -1010,7 +869,7 @@ static int group_set_factors(cmf_group_s *g, const double *W, const double *H)
     return group_join(g);
 }
 
-static int group_get_factors(cmf_group_s *g, double *W, double *H)
+int group_get_factors(cmf_group_s *g, double *W, double *H)
 {
     CMFTRY(group_sync(g));
     for (size_t i = 0; i < g->sh.size(); ++i) {
@@ -1035,7 +894,7 @@ static void bounded_stream_sync(hipStream_t st, bool failed)
 
 // false: a worker had to be abandoned inside a job that never returned -- its job holds pointers to the group and its shards, so
 // NOTHING of them is freed (leaked on purpose: a late wake-up must not find freed memory); the caller leaves the handles alone too.
-static bool group_destroy(cmf_group_s *g)
+bool group_destroy(cmf_group_s *g)
 {
     if (!g) return true;
     if (!g->failed) (void)group_join(g); // (bounded; marks the group failed when a worker is stuck in a collective call)
@@ -1102,7 +961,7 @@ static int group_prepare_shard(cmf_handle_s *s)
 
 // The communication stream's own communicators (lane 1).  One process: a second ncclCommInitAll over the same devices;
 // one process per shard: cmf_comm_init_overlap hands in a second ncclUniqueId.  Other transports have nothing to create.
-static int group_ensure_lane1(cmf_group_s *g, const void *id128 = nullptr)
+int group_ensure_lane1(cmf_group_s *g, const void *id128)
 {
     if (g->transport != CMF_TR_RCCL || g->comm2.size() == g->sh.size()) return CMF_OK;
     CMFTRY(group_join(g));
@@ -1135,3 +994,429 @@ static int group_finish_norm(cmf_group_s *g)
     for (cmf_handle_s *s : g->sh) s->data_norm = g->data_norm;
     return CMF_OK;
 }
+
+// ---- groups: construction ---------------------------------------------------------------------------------------
+int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transport,
+                     int64_t N, int64_t T, int64_t K, int64_t L, const double *data)
+{
+    if (!out) return fail(CMF_ERR_ARG, "handle pointer is NULL");
+    *out = nullptr;
+    if (!devices || !data) return fail(CMF_ERR_ARG, "NULL argument");
+    if (ndev < 1 || ndev > CMF_MAX_LOCAL) return fail(CMF_ERR_ARG, "ndev must be 1..%d (got %d)", CMF_MAX_LOCAL, ndev);
+    if (N < 1 || T < 1 || K < 1 || L < 1) return fail(CMF_ERR_ARG, "N, T, K, L must all be >= 1");
+    bool all_same = true, distinct = true;
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j) {
+            if (devices[i] != devices[j]) all_same = false;
+            else distinct = false;
+        }
+    int tr;
+    if (transport == CMF_COMM_AUTO) tr = (ndev > 1 && distinct) ? CMF_TR_RCCL : CMF_TR_LOOPBACK;
+    else if (transport == CMF_COMM_RCCL) tr = CMF_TR_RCCL;
+    else if (transport == CMF_COMM_LOOPBACK || transport == CMF_COMM_LOOPBACK_STREAMS) tr = CMF_TR_LOOPBACK;
+    else if (transport == CMF_COMM_PEER) tr = CMF_TR_PEER;
+    else return fail(CMF_ERR_ARG, "unknown transport %d", transport);
+    if (tr == CMF_TR_RCCL && !distinct) return fail(CMF_ERR_ARG, "RCCL needs distinct devices (a device is listed twice)");
+    if (tr == CMF_TR_LOOPBACK && !all_same) return fail(CMF_ERR_ARG, "the loopback transport needs all shards on one device; list distinct devices for RCCL");
+    if (tr == CMF_TR_PEER && !(distinct || all_same)) return fail(CMF_ERR_ARG, "the peer transport takes distinct devices, or one device for every shard (rehearsal)");
+    if (tr == CMF_TR_PEER && ndev > 1 && distinct) {
+        // every device maps every other one's memory (xGMI): the transport's kernels read and write the peers' buffers directly
+        for (int i = 0; i < ndev; ++i) {
+            HIPCHK(hipSetDevice(devices[i]));
+            for (int j = 0; j < ndev; ++j) {
+                if (i == j) continue;
+                int can = 0;
+                HIPCHK(hipDeviceCanAccessPeer(&can, devices[i], devices[j]));
+                if (!can) return fail(CMF_ERR_COMM, "device %d cannot access device %d's memory: the peer transport needs peer access between all devices of the group", devices[i], devices[j]);
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(CMF_ERR_HIP, "hipDeviceEnablePeerAccess(%d) on device %d failed: %s", devices[j], devices[i], hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+        }
+    }
+    std::vector<int64_t> t0, t1;
+    group_partition(T, ndev, L, t0, t1);
+    for (int r = 0; r < ndev; ++r)
+        if (ndev > 1 && t1[r] - t0[r] < std::max<int64_t>(L - 1, 1))
+            return fail(CMF_ERR_UNSUPPORTED, "T=%lld is too short to shard over %d devices with L=%lld (every shard needs >= L-1 columns)",
+                        (long long)T, ndev, (long long)L);
+
+    cmf_group_s *g = new cmf_group_s();
+    cmf_handle_s *root = new cmf_handle_s();
+    root->root_only = true;
+    root->group = g;
+    root->device = devices[0];
+    g->nranks = ndev;
+    g->transport = tr;
+    g->one_process = true;
+    g->N = N; g->T = T; g->K = K; g->L = L;
+    g->t0 = t0; g->t1 = t1;
+    auto bail = [&](int rc) { cmf_destroy(root); return rc; };
+    for (int r = 0; r < ndev; ++r) {
+        cmf_handle_s *s = nullptr;
+        // column-major N x T: the block [t0, t1 + halo_r) is contiguous
+        int rc = create_impl(&s, devices[r], N, t1[r] - t0[r], K, L, data + (size_t)t0[r] * N, t0[r], T, ndev > 1);
+        if (rc != CMF_OK) return bail(rc);
+        g->sh.push_back(s);
+        g->rank.push_back(r);
+        s->group = g;
+        rc = group_prepare_shard(s);
+        if (rc != CMF_OK) return bail(rc);
+    }
+    // CMF_LOOPBACK_STREAMS=1 turns every loopback group of the process into the stream-per-shard form (tests)
+    g->loop_ms = tr == CMF_TR_LOOPBACK && transport == CMF_COMM_LOOPBACK_STREAMS;
+    if (tr == CMF_TR_LOOPBACK && !g->loop_ms) // one device: every shard works on shard 0's streams, so the kernels of the loopback collectives are ordered
+        for (cmf_handle_s *s : g->sh) { s->stream = g->sh[0]->stream; s->comm_stream = g->sh[0]->comm_stream; }
+    if (tr == CMF_TR_RCCL) {
+        int rc = rccl_load();
+        if (rc != CMF_OK) return bail(rc);
+        g->comm.assign((size_t)ndev, nullptr);
+        (void)hipGetLastError(); // RCCL reports a stale (already handled) HIP error of this thread as its own
+        ncclResult_t r_ = g_rccl.CommInitAll(g->comm.data(), ndev, devices);
+        if (r_ != ncclSuccess) return bail(fail(CMF_ERR_COMM, "ncclCommInitAll failed: %s (RCCL from %s; if the process holds two HIP runtimes -- e.g. PyTorch imported after this library -- import torch first)", g_rccl.GetErrorString(r_), g_rccl.path.c_str()));
+    }
+    int rc = group_alloc_buffers(g);
+    if (rc == CMF_OK) rc = group_finish_norm(g);
+    // an enqueue worker per shard wherever every shard has its own stream (cmf_group.h); CMF_ENQUEUE_THREADS=0: the calling
+    // thread enqueues all shards (option "enqueue_threads" switches later)
+    const char *et = getenv("CMF_ENQUEUE_THREADS");
+    if (rc == CMF_OK && !(et && atoi(et) == 0)) rc = group_start_workers(g);
+    if (rc != CMF_OK) return bail(rc);
+    *out = root;
+    return CMF_OK;
+}
+
+// The overlap form's communication stream gets a communicator of its own (cmf_group.h, lane 1).  One process per shard:
+// every rank calls this with the SAME second id (rank 0's cmf_comm_unique_id, handed over like the first); groups from
+// cmf_create_multi create theirs themselves when the option is switched on and need not call it (id128 may be NULL).
+int cmf_comm_init_overlap(cmf_handle h, const void *id128)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (!h->group) return fail(CMF_ERR_STATE, "the handle belongs to no group");
+    if (h->group->transport != CMF_TR_RCCL) return CMF_OK; // the other transports order their lanes with events
+    if (!h->group->one_process && !id128) return fail(CMF_ERR_ARG, "id128 is NULL");
+    return group_ensure_lane1(h->group, id128);
+}
+
+int cmf_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(CMF_ERR_ARG, "id128 is NULL");
+    CMFTRY(rccl_load());
+    ncclUniqueId id;
+    RCCLCHK(g_rccl.GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    return CMF_OK;
+}
+
+static int comm_attach(cmf_handle_s *h, int nranks, int rank, int transport, const void *id128,
+                       cmf_allreduce_fn ar, cmf_allgather_fn ag, void *user)
+{
+    if (!h) return fail(CMF_ERR_ARG, "handle is NULL");
+    if (h->group) return fail(CMF_ERR_STATE, "the handle already belongs to a group");
+    if (!h->sharded) return fail(CMF_ERR_STATE, "cmf_comm_init_* needs a handle from cmf_create_shard");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(CMF_ERR_ARG, "bad rank %d of %d", rank, nranks);
+    const CmfDims &d = h->d;
+    // the shard's place in the global partition must match what the other ranks assume
+    std::vector<int64_t> t0, t1;
+    group_partition(h->T_global, nranks, d.L, t0, t1);
+    if (t0[(size_t)rank] != h->t_offset || t1[(size_t)rank] - t0[(size_t)rank] != d.Tl)
+        return fail(CMF_ERR_ARG, "rank %d of %d must own columns [%lld, %lld) of T=%lld, the handle owns [%lld, %lld)", rank, nranks,
+                    (long long)t0[(size_t)rank], (long long)t1[(size_t)rank], (long long)h->T_global,
+                    (long long)h->t_offset, (long long)(h->t_offset + d.Tl));
+    CMFTRY(group_use(h));
+    cmf_group_s *g = new cmf_group_s();
+    g->nranks = nranks;
+    g->transport = transport;
+    g->one_process = false;
+    g->N = d.N; g->T = h->T_global; g->K = d.K; g->L = d.L;
+    g->t0 = t0; g->t1 = t1;
+    g->sh.push_back(h);
+    g->rank.push_back(rank);
+    g->ar_cb = ar; g->ag_cb = ag; g->cb_user = user;
+    auto bail = [&](int rc) { (void)group_destroy(g); h->group = nullptr; return rc; };
+    int rc = group_prepare_shard(h);
+    if (rc != CMF_OK) return bail(rc);
+    if (transport == CMF_TR_RCCL) {
+        rc = rccl_load();
+        if (rc != CMF_OK) return bail(rc);
+        ncclUniqueId id;
+        std::memcpy(&id, id128, sizeof(id));
+        g->comm.assign(1, nullptr);
+        (void)hipGetLastError(); // RCCL reports a stale (already handled) HIP error of this thread as its own
+        ncclResult_t r_ = g_rccl.CommInitRank(&g->comm[0], nranks, id, rank);
+        if (r_ != ncclSuccess) return bail(fail(CMF_ERR_COMM, "ncclCommInitRank failed: %s (RCCL from %s; if the process holds two HIP runtimes -- e.g. PyTorch imported after this library -- import torch first)", g_rccl.GetErrorString(r_), g_rccl.path.c_str()));
+    }
+    rc = group_alloc_buffers(g);
+    if (rc == CMF_OK) rc = group_finish_norm(g);
+    if (rc != CMF_OK) return bail(rc);
+    h->group = g;
+    if (h->factors_set) { // factors were set before the communicator existed: the neighbours' halos are still missing
+        g->halos_current = false;
+        set_est(h, 0);
+    }
+    return CMF_OK;
+}
+
+int cmf_comm_init_rccl(cmf_handle h, int nranks, int rank, const void *id128)
+{
+    if (!id128) return fail(CMF_ERR_ARG, "id128 is NULL");
+    return comm_attach(h, nranks, rank, CMF_TR_RCCL, id128, nullptr, nullptr, nullptr);
+}
+
+int cmf_comm_init_callbacks(cmf_handle h, int nranks, int rank, cmf_allreduce_fn allreduce, cmf_allgather_fn allgather, void *user)
+{
+    if (!allreduce || !allgather) return fail(CMF_ERR_ARG, "NULL callback");
+    return comm_attach(h, nranks, rank, CMF_TR_CALLBACKS, nullptr, allreduce, allgather, user);
+}
+
+int cmf_comm_info(cmf_handle h, char *buf, int64_t len)
+{
+    if (!h || !buf || len < 1) return fail(CMF_ERR_ARG, "bad argument");
+    char tmp[1024];
+    if (!h->group) {
+        snprintf(tmp, sizeof(tmp), "transport=none nranks=1");
+    } else {
+        const cmf_group_s *g = h->group;
+        std::string ranks;
+        for (size_t i = 0; i < g->rank.size(); ++i) ranks += (i ? "," : "") + std::to_string(g->rank[i]) + "@dev" + std::to_string(g->sh[i]->device);
+        const char *enq = g->pool.empty() ? "caller" : "threads"; // who enqueues the shards (cmf_group.h)
+        const int lanes = (g->transport == CMF_TR_RCCL && g->comm2.size() == g->sh.size()) ? 2 : 1; // communicators per shard
+        if (g->transport == CMF_TR_RCCL) {
+            int v = 0;
+            (void)g_rccl.GetVersion(&v);
+            snprintf(tmp, sizeof(tmp), "transport=rccl version=%d lib=%s nranks=%d local=%zu ranks=%s overlap=%d enqueue=%s lanes=%d failed=%d", v,
+                     g_rccl.path.c_str(), g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap, enq, lanes, (int)g->failed);
+        } else {
+            snprintf(tmp, sizeof(tmp), "transport=%s nranks=%d local=%zu ranks=%s overlap=%d enqueue=%s lanes=%d failed=%d",
+                     g->transport == CMF_TR_LOOPBACK ? (g->loop_ms ? "loopback-streams" : "loopback") : (g->transport == CMF_TR_PEER ? "peer" : "callbacks"),
+                     g->nranks, g->sh.size(), ranks.c_str(), (int)g->overlap, enq, lanes, (int)g->failed);
+        }
+    }
+    snprintf(buf, (size_t)len, "%s", tmp);
+    return CMF_OK;
+}
+
+int cmf_shard_bounds(cmf_handle h, int rank, int64_t *t0, int64_t *t1)
+{
+    if (!h || !t0 || !t1) return fail(CMF_ERR_ARG, "NULL argument");
+    if (!h->group) {
+        *t0 = h->t_offset;
+        *t1 = h->t_offset + h->d.Tl;
+        return CMF_OK;
+    }
+    if (rank < 0 || rank >= h->group->nranks) return fail(CMF_ERR_ARG, "rank %d out of range", rank);
+    *t0 = h->group->t0[(size_t)rank];
+    *t1 = h->group->t1[(size_t)rank];
+    return CMF_OK;
+}
+
+// ---- PGD on T-sharded groups (pgd.jl:158-255 with data / est / H cut along T, W replicated) ------------------------------
+// compute_gradW! (pgd.jl:206-214) is the C2 contraction: every shard contracts its own residual columns and ONE all-reduce
+// sums the K x N x L partial gradients; the penalty, norm(grad) and the step are then identical replicated arithmetic.
+// compute_gradH! (:218-221) is tensor_transconv! on the shard's columns plus its right residual halo (the conv covers
+// Tl + halo_r columns, as in the MU rule); norm(gradH)^2, the per-component norms of UnitNormConstraint and the loss are
+// sums over shards, combined in rank order on the host (exact: doubles travel as two 32-bit words).  The step-size state
+// machine (stepW, stepH, cur_loss; :139-154, :248-253) is replicated: every rank takes the same decisions from the same sums.
+
+// n doubles at device address ptr[i] of every local shard -> their sum over ALL ranks (rank order), written back to every shard
+static int group_sum_doubles(cmf_group_s *g, const std::vector<double *> &ptr, int n, std::vector<double> *host_out = nullptr)
+{
+    const size_t nl = g->sh.size();
+    std::vector<std::vector<double>> local(nl, std::vector<double>((size_t)n));
+    for (size_t i = 0; i < nl; ++i) {
+        cmf_handle_s *s = g->sh[i];
+        CMFTRY(group_use(s));
+        HIPCHK(hipMemcpyAsync(local[i].data(), ptr[i], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    std::vector<double> total((size_t)n, 0.0);
+    if (g->one_process) {
+        for (int r = 0; r < g->nranks; ++r)
+            for (size_t i = 0; i < nl; ++i)
+                if (g->rank[i] == r)
+                    for (int j = 0; j < n; ++j) total[(size_t)j] += local[i][(size_t)j];
+    } else { // one all-gather of n doubles per rank, summed in rank order
+        std::vector<double> all;
+        CMFTRY(group_gather_doubles(g, local[0], all, n));
+        for (int r = 0; r < g->nranks; ++r)
+            for (int j = 0; j < n; ++j) total[(size_t)j] += all[(size_t)r * n + j];
+    }
+    for (size_t i = 0; i < nl; ++i) {
+        cmf_handle_s *s = g->sh[i];
+        CMFTRY(group_use(s));
+        HIPCHK(hipMemcpyAsync(ptr[i], total.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream)); // `total` is pageable host memory: finish before it goes out of scope
+    }
+    if (host_out) *host_out = total;
+    return CMF_OK;
+}
+
+static bool group_masked(const cmf_group_s *g) { return g->sh[0]->M != nullptr; }
+
+// pgd.jl:245-253 on the group: the residual with the new factors on every shard, loss = sum over shards
+static int group_pgd_finish(cmf_handle_s *st, cmf_group_s *g, double *step)
+{
+    std::vector<double *> ptr;
+    for (cmf_handle_s *s : g->sh) {
+        CMFTRY(group_use(s));
+        CMFTRY(resid_and_loss(s, nullptr, group_masked(g), st->pgd_loss_abs != 0));
+        ptr.push_back(s->d_scalar);
+    }
+    std::vector<double> tot;
+    CMFTRY(group_sum_doubles(g, ptr, 1, &tot));
+    const double loss = tot[0];
+    *step *= (loss < st->pgd_cur_loss) ? 1.05 : 0.70;
+    st->pgd_cur_loss = loss;
+    return CMF_OK;
+}
+
+static int group_pgd_prepare(cmf_handle_s *st, cmf_group_s *g, int nonneg)
+{
+    if (nonneg < 0 || nonneg > 2) return fail(CMF_ERR_ARG, "constraint must be 0 (none), 1 (NonnegConstraint) or 2 (UnitNormConstraint)");
+    if (g->gram || g->overlap) return fail(CMF_ERR_STATE, "the PGD rule runs on a group with the options gram and allreduce_overlap off");
+    if (st->pgd_cur_loss < 0.0) st->pgd_cur_loss = g->data_norm; // pgd.jl:151 (the norm, not its square)
+    for (cmf_handle_s *s : g->sh) {
+        s->pgd_loss_abs = st->pgd_loss_abs;
+        s->carry = CmfLossCarry{};
+    }
+    if (!g->halos_current) CMFTRY(group_exchange_halos(g));
+    return CMF_OK;
+}
+
+int group_pgd_w(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double pen_abs, int nonneg)
+{
+    GroupInline scope(g);
+    CMFTRY(scope.rc);
+    CMFTRY(group_pgd_prepare(st, g, nonneg));
+    const CmfDims &d0 = g->sh[0]->d;
+    const float gscale = st->pgd_loss_abs ? 1.f : 2.f; // pgd.jl:31-33 vs :42-44
+    const size_t LKN = (size_t)d0.L * d0.K32 * d0.Np;
+    for (cmf_handle_s *s : g->sh) {
+        CMFTRY(group_use(s));
+        CMFTRY(ensure_resid(s, group_masked(g), st->pgd_loss_abs != 0));                                 // pgd.jl:230 on the shard's columns
+        CMFTRY(hxt_contract(s, s->est, s->est, 1, s->numden)); // pgd.jl:206-214, partial over t
+    }
+    CMFTRY(group_allreduce(g, g->red, 0, LKN)); // the one bulk exchange: K x N x L partial gradients
+    for (cmf_handle_s *s : g->sh) {
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        dim3 grid(d.Np / 64, d.KB, d.L);
+        const int nblk = (d.Np / 64) * d.KB * d.L;
+        if ((size_t)nblk > n_partial(s)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
+        hipLaunchKernelGGL(pgd_w_grad_kernel, grid, dim3(256), 0, s->stream, s->Wt, s->numden, s->numden + LKN, s->partial,
+                           d.N, d.K, d.Np, d.K32, (float)pen_sq, (float)pen_abs, gscale);                // pgd.jl:231-234 (replicated)
+        KCHK("pgd_w_grad_kernel");
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s->stream, s->partial, nblk, s->d_scalar + 1, (double *)nullptr);
+        KCHK("loss_reduce_kernel");
+        hipLaunchKernelGGL(pgd_w_apply_kernel, grid, dim3(256), 0, s->stream, s->Wt, s->Wn, s->numden + LKN, s->d_scalar + 1,
+                           d.N, d.K, d.Np, d.K32, (float)st->pgd_stepW, nonneg == 1);                    // pgd.jl:237-241
+        KCHK("pgd_w_apply_kernel");
+        if (nonneg == 2) CMFTRY(pgd_unit_norm(s, true));                                                 // pgd.jl:100-110 (W is replicated)
+        set_est(s, 0);
+    }
+    return group_pgd_finish(st, g, &st->pgd_stepW);
+}
+
+int group_pgd_h(cmf_handle_s *st, cmf_group_s *g, double pen_sq, double pen_abs, int nonneg, double *loss)
+{
+    GroupInline scope(g);
+    CMFTRY(scope.rc);
+    CMFTRY(group_pgd_prepare(st, g, nonneg));
+    const float gscale = st->pgd_loss_abs ? 1.f : 2.f;
+    std::vector<double *> nrm;
+    for (cmf_handle_s *s : g->sh) {
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        if (!s->pgd_gradH) CMFTRY(dalloc_zero(&s->pgd_gradH, (size_t)d.Tl * d.K32));
+        // the transposed residual on the shard's columns AND its right lag halo (transconv reads est[:, t .. t+L-1])
+        if (s->est_kind == 2 + (s->M ? 1 : 0) + (st->pgd_loss_abs ? 2 : 0)) {
+            // the shard's own columns are in est already (the conv that closed the W phase): transposed, not convolved again;
+            // the <= L-1 halo columns are formed directly (resid_halo_kernel)
+            hipLaunchKernelGGL(transpose_rows_kernel, dim3(d.Np / 64, (d.Tl + 63) / 64), dim3(256), 0, s->stream, s->est, s->estT, d.Tl, d.Np, d.TP, d.PADL);
+            KCHK("transpose_rows_kernel");
+            if (s->halo_r > 0) {
+                hipLaunchKernelGGL(resid_halo_kernel, dim3(d.Np / 128, s->halo_r), dim3(128), 0, s->stream, s->Wt, s->H, s->XT, s->MT, s->estT,
+                                   d.Tl, d.K, d.L, d.K32, d.Np, d.TP, d.PADL, st->pgd_loss_abs);
+                KCHK("resid_halo_kernel");
+            }
+        } else {
+            s->pgd_loss_abs_now = st->pgd_loss_abs;
+            int rc_conv = s->MT ? launch_conv<7>(s, s->estT, d.Tl + s->halo_r, s->conv_gy_ext, s->XT)
+                                : launch_conv<5>(s, s->estT, d.Tl + s->halo_r, s->conv_gy_ext, s->XT);
+            s->pgd_loss_abs_now = 0;
+            CMFTRY(rc_conv);
+        }
+        CMFTRY(launch_transconv(s, 1, s->estT));                                                         // pgd.jl:218-221
+        dim3 grid((d.Tl + 63) / 64, d.KB);
+        const int nblk = ((d.Tl + 63) / 64) * d.KB;
+        if ((size_t)nblk > n_partial(s)) return fail(CMF_ERR_UNSUPPORTED, "PGD: partial buffer too small");
+        hipLaunchKernelGGL(pgd_h_grad_kernel, grid, dim3(256), 0, s->stream, s->H, s->hslabs, s->tc_S1, s->pgd_gradH, s->partial,
+                           d.Tl, d.K, d.K32, d.PADL, (float)pen_sq, (float)pen_abs, gscale);
+        KCHK("pgd_h_grad_kernel");
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s->stream, s->partial, nblk, s->d_scalar + 1, (double *)nullptr);
+        KCHK("loss_reduce_kernel");
+        nrm.push_back(s->d_scalar + 1);
+    }
+    CMFTRY(group_sum_doubles(g, nrm, 1)); // norm(gradH)^2 over all shards (pgd.jl:236)
+    std::vector<double *> kn;
+    for (cmf_handle_s *s : g->sh) {
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        dim3 grid((d.Tl + 63) / 64, d.KB);
+        hipLaunchKernelGGL(pgd_h_apply_kernel, grid, dim3(256), 0, s->stream, s->H, s->Ht, s->pgd_gradH, s->d_scalar + 1,
+                           d.Tl, d.K, d.K32, d.PADL, d.TP, (float)st->pgd_stepH, nonneg == 1);
+        KCHK("pgd_h_apply_kernel");
+        if (nonneg == 2) { // pgd.jl:100-110: the norm of a component runs over all of T
+            if (!s->pgd_knorm) CMFTRY(dalloc_zero(&s->pgd_knorm, (size_t)d.K32));
+            hipLaunchKernelGGL(pgd_h_knorm_kernel, dim3(d.K), dim3(256), 0, s->stream, s->Ht, s->pgd_knorm, d.Tl, d.TP, d.PADL);
+            KCHK("pgd_h_knorm_kernel");
+            kn.push_back(s->pgd_knorm);
+        }
+        set_est(s, 0);
+    }
+    if (nonneg == 2) {
+        CMFTRY(group_sum_doubles(g, kn, g->sh[0]->d.K));
+        for (cmf_handle_s *s : g->sh) {
+            const CmfDims &d = s->d;
+            CMFTRY(group_use(s));
+            hipLaunchKernelGGL(pgd_h_kscale_kernel, dim3(1024), dim3(256), 0, s->stream, s->H, s->Ht, s->pgd_knorm, d.Tl, d.K, d.K32, d.TP, d.PADL);
+            KCHK("pgd_h_kscale_kernel");
+        }
+    }
+    for (cmf_handle_s *s : g->sh) { // (an armed write-back: every shard's block of H is final here)
+        CMFTRY(group_use(s));
+        CMFTRY(wb_after_H(s));
+    }
+    CMFTRY(group_exchange_halos(g));
+    CMFTRY(group_pgd_finish(st, g, &st->pgd_stepH));
+    *loss = std::sqrt(st->pgd_cur_loss / (g->data_norm * g->data_norm)); // pgd.jl:201
+    return CMF_OK;
+}
+
+// MaskedLoss on a group: the mask is cut like data -- shard r holds its own columns in both layouts and the right lag halo
+// in the transposed one.  One process: `mask` is the whole N x T matrix; one process per shard: the block of data_local.
+int group_set_mask(cmf_group_s *g, const double *mask)
+{
+    CMFTRY(group_sync(g));
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        cmf_handle_s *s = g->sh[i];
+        const CmfDims &d = s->d;
+        CMFTRY(group_use(s));
+        set_est(s, 0);
+        if (!mask) {
+            if (s->M) (void)hipFree(s->M);
+            if (s->MT) (void)hipFree(s->MT);
+            s->M = s->MT = nullptr;
+            continue;
+        }
+        const size_t TPNp = (size_t)d.TP * d.Np;
+        if (!s->M) CMFTRY(dalloc_zero(&s->M, TPNp));
+        if (!s->MT) CMFTRY(dalloc_zero(&s->MT, TPNp));
+        const double *m = g->one_process ? mask + (size_t)g->t0[(size_t)g->rank[i]] * d.N : mask;
+        CMFTRY(upload_cols(s, m, 0, d.Tl, true, false, s->M, s->MT));
+        if (s->halo_r > 0) CMFTRY(upload_cols(s, m + (size_t)d.Tl * d.N, d.Tl, s->halo_r, false, false, s->M, s->MT));
+    }
+    return CMF_OK;
+}
+

@@ -1401,7 +1401,7 @@ __device__ __forceinline__ float cmf_mu(float x, float num, float den, float l1,
 // tail_src / tail_dst (may be NULL): block (0,0,0) also copies `tail_n` (<= 256) floats -- the loss pairs behind the
 // [numW | denomW] all-reduce buffer of a sharded group -- to pinned host memory that the host has filled with a
 // sentinel pattern and polls, so the read-back costs neither a launch nor an event (see loss_reduce_kernel).
-__global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, const float *num_p, const float *den_p,
+static __global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, const float *num_p, const float *den_p,
                                                         int N, int K, int L, int Np, int K32, float l1, float two_l2,
                                                         const float *tail_src, float *tail_dst, int tail_n)
 {
@@ -1443,7 +1443,7 @@ __global__ __launch_bounds__(256) void w_update_kernel(float *Wt, float *Wn, con
 // num / den: Snum / Sden partial-sum slabs of [Tl][K32] floats, `num_stride` / `den_stride` floats apart (the two-source
 // transconv writes [S][2][Tl][K32]: num = slabs, den = slabs + Tl*K32, both strides 2*Tl*K32; the Gram form has the S1
 // slabs of the one-source launch for num and ONE array for den).
-__global__ __launch_bounds__(256) void h_update_kernel(float *H, float *Ht, const float *nump, size_t num_stride, int Snum,
+static __global__ __launch_bounds__(256) void h_update_kernel(float *H, float *Ht, const float *nump, size_t num_stride, int Snum,
                                                         const float *denp, size_t den_stride, int Sden,
                                                         int Tl, int K, int K32, int PADL, int TP, float l1, float two_l2)
 {
@@ -1544,7 +1544,7 @@ struct CmfHxtTail {
 
 // out[i] = sum_s in[s*stride + i]  (deterministic slab combine; float4 lanes); the last block also performs a carried
 // loss reduction (same summation order as loss_reduce_kernel / loss_tail_kernel)
-__global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *in, int nslabs, size_t stride, size_t n4, CmfLossCarry carry,
+static __global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *in, int nslabs, size_t stride, size_t n4, CmfLossCarry carry,
                                                         CmfHxtTail tail)
 {
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1597,7 +1597,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *
 // the conv just stored) and idle the device for ~6 us between this kernel and the next.
 #define CMF_SENTINEL64 0xFFFFFFFFFFFFFFFFull
 #define CMF_SENTINEL32 0xFFFFFFFFu
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial, int n, double *out, double *host_out = nullptr)
+static __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial, int n, double *out, double *host_out = nullptr)
 {
     __shared__ double red[256];
     double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1645,7 +1645,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial,
 // HX[r][c] = c < K32 ? H[r][c] : 0 : H in the row pitch hxt wants for its X operand.   grid-stride over TP * K32
 // Only the handle's own rows [PADL, PADL + Tl) are copied: as the X operand the rows behind them must read as zero (the
 // C2 kernel rounds its time chunks up past Tl), and on a shard those rows of H hold the right neighbour's halo.
-__global__ void hals_hx_kernel(const float *H, float *HX, int TP, int K32, int NpC, int PADL, int Tl)
+static __global__ void hals_hx_kernel(const float *H, float *HX, int TP, int K32, int NpC, int PADL, int Tl)
 {
     const size_t total = (size_t)TP * K32;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1659,7 +1659,7 @@ __global__ void hals_hx_kernel(const float *H, float *HX, int TP, int K32, int N
 // columns only (with the left H halo); the entry is then this shard's additive share of HH -- C as it is, minus the cut
 // terms on the shard that holds the global right edge (is_last; the columns u - d >= Tl - 2(L-1) they read are the
 // shard's own or its left halo) -- and the shares are summed by the group's all-reduce.
-__global__ void hals_hh_kernel(const float *C, const float *H, float *HH, int Tl, int L, int K, int K32, int NpC, int NpH, int PADL,
+static __global__ void hals_hh_kernel(const float *C, const float *H, float *HH, int Tl, int L, int K, int K32, int NpC, int NpH, int PADL,
                                int sharded, int is_last)
 {
     const int LK = L * K32;
@@ -1798,7 +1798,7 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
 
 // PT[k][t] = sum_s of the transconv slabs [S][1][Tl][K32] (of the residual), or, with `den` ([Tl][K32]) given,
 // den[t][k] - that sum (the projection as denomH - numH: slabs of transconv(W, data));   grid (ceil(Tl/64), KB), block 256
-__global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float *slabs, const float *den, int S, int Tl, int K32, int TPp)
+static __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float *slabs, const float *den, int S, int Tl, int K32, int TPp)
 {
     __shared__ float tile[32][65];
     const int tid = threadIdx.x;
@@ -1837,7 +1837,7 @@ __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float
 // (Round 2 ran one wave per ordered pair: L*L waves of N/2 dependent MFMAs each -- 27 us of MFMA issue per wave at
 // N = 2000 whatever the chip does, 55 us measured, independent of T.)
 #define PW_NW 8
-__global__ __launch_bounds__(64 * PW_NW) void hals_pw_kernel(const float *Wn, float *PW, int N, int L, int Np, int K32, int KB)
+static __global__ __launch_bounds__(64 * PW_NW) void hals_pw_kernel(const float *Wn, float *PW, int N, int L, int Np, int K32, int KB)
 {
     __shared__ float part[PW_NW][16][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (scalar: uniform loop bounds)
@@ -1904,7 +1904,7 @@ __global__ __launch_bounds__(64 * PW_NW) void hals_pw_kernel(const float *Wn, fl
 // table separately: 23 us at K = 32, L = 20, independent of T.)
 // GWt (optional): the full-window taps once more as [k'][e][k] with the tap count padded to Ep = 2L (gram_h_mfma_kernel's B
 // operand; a separate transposing launch until round 4).
-__global__ void hals_gw_kernel(const float *PW, float *GW, float *GE, int L, int K32, int ne, int Tl, int t_edge0, float *GWt, int Ep)
+static __global__ void hals_gw_kernel(const float *PW, float *GW, float *GE, int L, int K32, int ne, int Tl, int t_edge0, float *GWt, int Ep)
 {
     const int E = 2 * L - 1;
     const size_t total = (size_t)K32 * K32 * E;
@@ -2371,7 +2371,7 @@ __device__ __forceinline__ bool hals_segment(const HalsStageParams &sp, int k, i
     return true;
 }
 
-__global__ __launch_bounds__(256) void hals_h_stage_kernel(HalsStageParams sp)
+static __global__ __launch_bounds__(256) void hals_h_stage_kernel(HalsStageParams sp)
 {
     const int bx = blockIdx.x;
     if (bx < sp.K) {
@@ -2417,7 +2417,7 @@ struct HalsPersistParams {
     unsigned long long *stamps; // debug: [K][nblk] sweeper block-end times, then [K][nblk][4] puller phase times; or NULL
 };
 
-__global__ __launch_bounds__(1024) void hals_h_persist_kernel(HalsPersistParams pp)
+static __global__ __launch_bounds__(1024) void hals_h_persist_kernel(HalsPersistParams pp)
 {
     extern __shared__ float hp_smem[];
     const int tid = threadIdx.x;
@@ -2573,7 +2573,7 @@ __global__ __launch_bounds__(1024) void hals_h_persist_kernel(HalsPersistParams 
 // new w (hals.jl:104-110) in every thread, and adds (w_new - w_old) * HH[j][j'] to the entries j' that later steps of
 // this sweep still read (the HH row comes from L2: all N workgroups walk the same rows).
 // grid N, block 256, dynamic LDS: L*K32 floats.
-__global__ __launch_bounds__(256) void hals_w_sweep_gen_kernel(float *Wt, float *Wn, const float *G, const float *Gsub, const float *HH,
+static __global__ __launch_bounds__(256) void hals_w_sweep_gen_kernel(float *Wt, float *Wn, const float *G, const float *Gsub, const float *HH,
                                                                 int N, int K, int L, int Np, int K32, int NpH, float l1, float l2)
 {
     extern __shared__ float gen_g[];
@@ -2609,7 +2609,7 @@ __global__ __launch_bounds__(256) void hals_w_sweep_gen_kernel(float *Wt, float 
 // pushes P[k][t + e] += (x - h_old) * taps[e], e = 1 .. Lt - 1 (full-window taps GW[k][k], or the edge column's own GE).
 // Writes H (both layouts) and the per-column change D[t]; the cross-row terms follow in hals_h_push_gen_kernel.
 // grid 1, block 64, dynamic LDS: (M + L) floats.
-__global__ __launch_bounds__(64) void hals_h_row_gen_kernel(HalsRowParams q)
+static __global__ __launch_bounds__(64) void hals_h_row_gen_kernel(HalsRowParams q)
 {
     extern __shared__ float gen_ring[];
     const int lane = threadIdx.x;
@@ -2659,7 +2659,7 @@ __global__ __launch_bounds__(64) void hals_h_row_gen_kernel(HalsRowParams q)
 // Cross-row terms of row k's changes for any L: PT[kp][tp] += sum_e D[tp - e] * taps(tp - e)[k][kp][e], kp > k
 // (hals.jl:146 for the other components; source columns in the right edge use their own taps GE).
 // grid (ceil(Tl / 256), K - 1 - k), block 256: blockIdx.y -> kp = k + 1 + blockIdx.y
-__global__ __launch_bounds__(256) void hals_h_push_gen_kernel(float *PT, const float *D, const float *GW, const float *GE,
+static __global__ __launch_bounds__(256) void hals_h_push_gen_kernel(float *PT, const float *D, const float *GW, const float *GE,
                                                                int k, int Tl, int L, int K32, int TPp, int ne, int t_edge0)
 {
     const int tp = blockIdx.x * 256 + threadIdx.x, kp = k + 1 + blockIdx.y;
@@ -2689,7 +2689,7 @@ __device__ __forceinline__ float cmf_sign(float x) { return (x > 0.f) ? 1.f : ((
 // layout tensor_transconv wants.  The H phase of a PGD iteration needs exactly the residual the W phase's closing conv has
 // just stored (same W, same H; pgd.jl:245 and :230), so it is transposed (0.8 GB of traffic) instead of convolved again.
 // grid (Np / 64, ceil(Tl / 64)), block 256
-__global__ __launch_bounds__(256) void transpose_rows_kernel(const float *in, float *outT, int Tl, int Np, int TP, int PADL)
+static __global__ __launch_bounds__(256) void transpose_rows_kernel(const float *in, float *outT, int Tl, int Np, int TP, int PADL)
 {
     __shared__ float tile[64][65];
     const int tid = threadIdx.x;
@@ -2717,7 +2717,7 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const float *in, fl
 // residual must not hold: the C2 kernel reads the rows behind Tl as zero padding): est there from W and the H halo directly,
 // minus the data halo, masked / as a sign like the conv epilogue does it.  halo <= L - 1 columns: 2*K*L FMAs per output.
 // grid (Np / 128, halo), block 128
-__global__ __launch_bounds__(128) void resid_halo_kernel(const float *Wt, const float *H, const float *XT, const float *MT, float *outT,
+static __global__ __launch_bounds__(128) void resid_halo_kernel(const float *Wt, const float *H, const float *XT, const float *MT, float *outT,
                                                           int Tl, int K, int L, int K32, int Np, int TP, int PADL, int loss_abs)
 {
     const int n = blockIdx.x * 128 + threadIdx.x, t = Tl + blockIdx.y;
@@ -2735,7 +2735,7 @@ __global__ __launch_bounds__(128) void resid_halo_kernel(const float *Wt, const 
 // grad[idx] = gscale*G + 2*pen_sq*w + pen_abs*sign(w) over the valid entries of the Wt layout (gscale: 2 for SquareLoss,
 // whose stored residual is est - data; 1 for AbsoluteLoss, whose stored quantity already is the gradient sign(est - data));
 // block partials of sum(g^2).  grid (Np/64, KB, L), block 256
-__global__ __launch_bounds__(256) void pgd_w_grad_kernel(const float *Wt, const float *G, float *grad, double *partial,
+static __global__ __launch_bounds__(256) void pgd_w_grad_kernel(const float *Wt, const float *G, float *grad, double *partial,
                                                           int N, int K, int Np, int K32, float pen_sq, float pen_abs, float gscale)
 {
     const int tid = threadIdx.x;
@@ -2762,7 +2762,7 @@ __global__ __launch_bounds__(256) void pgd_w_grad_kernel(const float *Wt, const 
 }
 
 // W <- proj(W - alpha*grad), alpha = step / (sqrt(*sumsq) + eps); refreshes Wn.  grid (Np/64, KB, L), block 256
-__global__ __launch_bounds__(256) void pgd_w_apply_kernel(float *Wt, float *Wn, const float *grad, const double *sumsq,
+static __global__ __launch_bounds__(256) void pgd_w_apply_kernel(float *Wt, float *Wn, const float *grad, const double *sumsq,
                                                            int N, int K, int Np, int K32, float step, int nonneg)
 {
     __shared__ float tile[32][65];
@@ -2796,7 +2796,7 @@ __global__ __launch_bounds__(256) void pgd_w_apply_kernel(float *Wt, float *Wn, 
 }
 
 // grad[t][k] = gscale*sum_s slabs[s][t][k] + 2*pen_sq*h + pen_abs*sign(h); grid (ceil(Tl/64), KB), block 256
-__global__ __launch_bounds__(256) void pgd_h_grad_kernel(const float *H, const float *slabs, int S, float *grad, double *partial,
+static __global__ __launch_bounds__(256) void pgd_h_grad_kernel(const float *H, const float *slabs, int S, float *grad, double *partial,
                                                           int Tl, int K, int K32, int PADL, float pen_sq, float pen_abs, float gscale)
 {
     const int tid = threadIdx.x;
@@ -2829,7 +2829,7 @@ __global__ __launch_bounds__(256) void pgd_h_grad_kernel(const float *H, const f
 }
 
 // H <- proj(H - alpha*grad); refreshes Ht.  grid (ceil(Tl/64), KB), block 256
-__global__ __launch_bounds__(256) void pgd_h_apply_kernel(float *H, float *Ht, const float *grad, const double *sumsq,
+static __global__ __launch_bounds__(256) void pgd_h_apply_kernel(float *H, float *Ht, const float *grad, const double *sumsq,
                                                            int Tl, int K, int K32, int PADL, int TP, float step, int nonneg)
 {
     __shared__ float tile[32][65];
@@ -2867,7 +2867,7 @@ __global__ __launch_bounds__(256) void pgd_h_apply_kernel(float *H, float *Ht, c
 
 // UnitNormConstraint (pgd.jl:100-110): every component k whose slice (W[k, :, :] or H[k, :]) has norm > 1 is scaled to
 // norm 1.  Pass 1: ss[k] = sum of squares of the slice (one block per k, fp64); pass 2: scale both layouts.
-__global__ __launch_bounds__(256) void pgd_w_knorm_kernel(const float *Wt, double *ss, int N, int L, int Np, int K32)
+static __global__ __launch_bounds__(256) void pgd_w_knorm_kernel(const float *Wt, double *ss, int N, int L, int Np, int K32)
 {
     __shared__ double red[256];
     const int k = blockIdx.x;
@@ -2885,7 +2885,7 @@ __global__ __launch_bounds__(256) void pgd_w_knorm_kernel(const float *Wt, doubl
     }
     if (threadIdx.x == 0) ss[k] = red[0];
 }
-__global__ __launch_bounds__(256) void pgd_h_knorm_kernel(const float *Ht, double *ss, int Tl, int TP, int PADL)
+static __global__ __launch_bounds__(256) void pgd_h_knorm_kernel(const float *Ht, double *ss, int Tl, int TP, int PADL)
 {
     __shared__ double red[256];
     const int k = blockIdx.x;
@@ -2907,7 +2907,7 @@ __device__ __forceinline__ float cmf_unit_scale(double ss)
     const double mag = sqrt(ss);
     return mag > 1.0 ? (float)(1.0 / mag) : 1.f;
 }
-__global__ void pgd_w_kscale_kernel(float *Wt, float *Wn, const double *ss, int N, int K, int L, int Np, int K32)
+static __global__ void pgd_w_kscale_kernel(float *Wt, float *Wn, const double *ss, int N, int K, int L, int Np, int K32)
 {
     const size_t total = (size_t)L * K * N;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -2921,7 +2921,7 @@ __global__ void pgd_w_kscale_kernel(float *Wt, float *Wn, const double *ss, int 
         }
     }
 }
-__global__ void pgd_h_kscale_kernel(float *H, float *Ht, const double *ss, int Tl, int K, int K32, int TP, int PADL)
+static __global__ void pgd_h_kscale_kernel(float *H, float *Ht, const double *ss, int Tl, int K, int K32, int TP, int PADL)
 {
     const size_t total = (size_t)Tl * K;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -3022,7 +3022,7 @@ __global__ __launch_bounds__(256) void gram_w_kernel(const float *HH, const floa
 // out[t][k] = sum_{k',e} taps(t)[k][k'][e] * Ht[k'][PADL + t + e];  taps = GW (full window) or GE (edge columns)
 // grid (ceil(Tl/64), K32/4), block 256: wave w -> k = blockIdx.y*4 + w, lane -> t = t0 + lane
 // dynamic LDS: K32 * (64 + 2*(L-1)) floats
-__global__ __launch_bounds__(256) void gram_h_kernel(const float *Ht, const float *GW, const float *GE, float *out,
+static __global__ __launch_bounds__(256) void gram_h_kernel(const float *Ht, const float *GW, const float *GE, float *out,
                                                       int Tl, int K, int L, int K32, int TP, int PADL, int ne, int t_edge0, int block0)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
@@ -3105,7 +3105,7 @@ __device__ __forceinline__ void gram_h_edge(const float *Ht, const float *GW, co
 // dynamic LDS: K32 * (128 / fw + 2*(L-1)) floats for the H window (+ 4096 floats for the partial sums when fw > 1).
 // grid: n_tiles * KB workgroups of the MFMA form (tile fastest) + the edge workgroups behind them (GramEdge: one launch and
 // one kernel boundary less, and the latency-bound edge waves run beside the MFMA tiles instead of after them).
-__global__ __launch_bounds__(256) void gram_h_mfma_kernel(const float *Ht, const float *GWt, float *out, int K, int L, int K32, int TP, int PADL, int Ep,
+static __global__ __launch_bounds__(256) void gram_h_mfma_kernel(const float *Ht, const float *GWt, float *out, int K, int L, int K32, int TP, int PADL, int Ep,
                                                            int fw, int n_tiles, GramEdge edge)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
@@ -3191,7 +3191,7 @@ __global__ __launch_bounds__(256) void gram_h_mfma_kernel(const float *Ht, const
 }
 
 // partial[b] = sum H*den, partial[nb + b] = sum H*num over the block's (t, k); grid ceil(Tl*K32/1024), block 256
-__global__ __launch_bounds__(256) void gram_dot_kernel(const float *H, const float *num, const float *den, double *partial,
+static __global__ __launch_bounds__(256) void gram_dot_kernel(const float *H, const float *num, const float *den, double *partial,
                                                         int Tl, int K, int K32, int PADL, int nb)
 {
     const size_t total = (size_t)Tl * K32;
@@ -3227,7 +3227,7 @@ __global__ __launch_bounds__(256) void gram_dot_kernel(const float *H, const flo
 // ---------------------------------------------------------------------------------------------
 // in: cols [tc, tc+ncols) of an N x * column-major fp64 matrix (in[n + N*(t - tc)]).
 // Writes X[(PADL+t)][n] and XT[n][PADL+t].  grid (ceil(N/32), ceil(ncols/32)), block (32, 8)
-__global__ void pack_cols_kernel(const double *in, int N, int tc, int ncols, float *X, float *XT, int Np, int TP, int PADL)
+static __global__ void pack_cols_kernel(const double *in, int N, int tc, int ncols, float *X, float *XT, int Np, int TP, int PADL)
 {
     __shared__ float tile[32][33];
     const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -3250,7 +3250,7 @@ __global__ void pack_cols_kernel(const double *in, int N, int tc, int ncols, flo
 }
 
 // W fp64 [L][N][K] (k fastest) -> Wt[l][k][n], Wn[l][n][k]
-__global__ void pack_W_kernel(const double *in, int N, int K, int L, float *Wt, float *Wn, int Np, int K32)
+static __global__ void pack_W_kernel(const double *in, int N, int K, int L, float *Wt, float *Wn, int Np, int K32)
 {
     size_t total = (size_t)L * N * K;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -3274,7 +3274,7 @@ __global__ void unpack_W_kernel(O *out, int N, int K, int L, const float *Wn, in
     }
 }
 // H fp64 [T][K] (k fastest) -> H[(PADL+t)][k], Ht[k][PADL+t]
-__global__ void pack_H_kernel(const double *in, int Tl, int K, float *H, float *Ht, int K32, int TP, int PADL)
+static __global__ void pack_H_kernel(const double *in, int Tl, int K, float *H, float *Ht, int K32, int TP, int PADL)
 {
     size_t total = (size_t)Tl * K;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -3296,7 +3296,7 @@ __global__ void unpack_H_kernel(O *out, int Tl, int K, const float *H, int K32, 
     }
 }
 // rows [tc, tc+ncols) of a [*][stride] fp32 row-major buffer (row offset row0) -> fp64 out[c*width + j]
-__global__ void unpack_rows_kernel(double *out, const float *in, int row0, int tc, int ncols, int width, int stride)
+static __global__ void unpack_rows_kernel(double *out, const float *in, int row0, int tc, int ncols, int width, int stride)
 {
     size_t total = (size_t)ncols * width;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -3308,7 +3308,7 @@ __global__ void unpack_rows_kernel(double *out, const float *in, int row0, int t
 
 // H halo rows <-> contiguous staging buffers ((L-1) x K32 floats)
 // dir 0: buf <- H rows [r0, r0+rows)   dir 1: H rows <- buf (and Ht columns)
-__global__ void halo_copy_kernel(float *H, float *Ht, float *buf, int r0, int rows, int K32, int TP, int dir)
+static __global__ void halo_copy_kernel(float *H, float *Ht, float *buf, int r0, int rows, int K32, int TP, int dir)
 {
     int total = rows * K32;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -3324,7 +3324,7 @@ __global__ void halo_copy_kernel(float *H, float *Ht, float *buf, int r0, int ro
 
 // init_rand's scale factor (model.jl:120): per-block partial sums of <data, est> and <est, est> over the padded layouts
 // (padding is zero in both).  partial[b] = dot, partial[gridDim.x + b] = norm^2; fp64 accumulation of fp32 products.
-__global__ __launch_bounds__(256) void init_dot_kernel(const float *est, const float *X, size_t n4, double *partial)
+static __global__ __launch_bounds__(256) void init_dot_kernel(const float *est, const float *X, size_t n4, double *partial)
 {
     __shared__ double red[2][256];
     double sd = 0.0, sn = 0.0;
@@ -3351,7 +3351,7 @@ __global__ __launch_bounds__(256) void init_dot_kernel(const float *est, const f
 }
 
 // sum of squares of a fp64 array -> *out (one block; used for data_norm on a staged chunk)
-__global__ __launch_bounds__(256) void sumsq_f64_kernel(const double *in, size_t n, double *out_accum)
+static __global__ __launch_bounds__(256) void sumsq_f64_kernel(const double *in, size_t n, double *out_accum)
 {
     __shared__ double red[256];
     double s = 0.0;
@@ -3369,7 +3369,7 @@ __global__ __launch_bounds__(256) void sumsq_f64_kernel(const double *in, size_t
 // T-sharded groups: small kernels around the collectives
 // =============================================================================================
 // Both H halo send blocks in one launch: buf = [own first `rows` rows | own last `rows` rows] of H
-__global__ void halo_pack2_kernel(const float *H, float *buf, int r_first, int r_last, int rows, int K32)
+static __global__ void halo_pack2_kernel(const float *H, float *buf, int r_first, int r_last, int rows, int K32)
 {
     const int total = rows * K32;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * total; idx += gridDim.x * blockDim.x) {
@@ -3380,7 +3380,7 @@ __global__ void halo_pack2_kernel(const float *H, float *buf, int r_first, int r
 
 // Both receive halos in one launch: left (rows [r_left, r_left+rows)) from `left`, right from `right`; a NULL
 // source (no neighbour: the global edge) leaves the zeros in place.  Writes H and its transposed copy Ht.
-__global__ void halo_unpack2_kernel(float *H, float *Ht, const float *left, const float *right, int r_left, int r_right,
+static __global__ void halo_unpack2_kernel(float *H, float *Ht, const float *left, const float *right, int r_left, int r_right,
                                     int rows, int K32, int TP)
 {
     const int total = rows * K32;
@@ -3400,7 +3400,7 @@ __global__ void halo_unpack2_kernel(float *H, float *Ht, const float *left, cons
 // this rank's own slots, zeros in every other rank's slots -- the sum over ranks of the tail is then exact (x + 0 + ...)
 // and every rank can add the per-rank doubles in rank order after the next all-reduce (the loss scalar rides on the
 // single bulk collective).
-__global__ __launch_bounds__(256) void loss_tail_kernel(const double *partial, int n, double *out, float *tail, int tail_len, int rank)
+static __global__ __launch_bounds__(256) void loss_tail_kernel(const double *partial, int n, double *out, float *tail, int tail_len, int rank)
 {
     __shared__ double red[256];
     double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -3427,7 +3427,7 @@ __global__ __launch_bounds__(256) void loss_tail_kernel(const double *partial, i
 // box): the collectives are plain kernels over the shards' buffers.  Sums are taken in rank order.
 #define CMF_MAX_LOCAL 16
 struct CmfPtrTable { float *p[CMF_MAX_LOCAL]; };
-__global__ __launch_bounds__(256) void loopback_allreduce_kernel(CmfPtrTable bufs, int R, size_t count)
+static __global__ __launch_bounds__(256) void loopback_allreduce_kernel(CmfPtrTable bufs, int R, size_t count)
 {
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < count; idx += (size_t)gridDim.x * blockDim.x) {
         float s = bufs.p[0][idx];
@@ -3435,7 +3435,7 @@ __global__ __launch_bounds__(256) void loopback_allreduce_kernel(CmfPtrTable buf
         for (int r = 0; r < R; ++r) bufs.p[r][idx] = s;
     }
 }
-__global__ __launch_bounds__(256) void loopback_allgather_kernel(CmfPtrTable send, CmfPtrTable recv, int R, int count)
+static __global__ __launch_bounds__(256) void loopback_allgather_kernel(CmfPtrTable send, CmfPtrTable recv, int R, int count)
 {
     const int total = R * count;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -3452,7 +3452,7 @@ __global__ __launch_bounds__(256) void loopback_allgather_kernel(CmfPtrTable sen
 // reduce-scatter by reading the peers and an all-gather by writing them, 1/R of the payload per link and direction
 // (1.3 MB of the 10.5 MB at R = 8) where a ring moves (R-1)/R of it through every link, twice.  No two shards touch the
 // same slice, so the R kernels need no order among themselves.
-__global__ __launch_bounds__(256) void peer_allreduce_kernel(CmfPtrTable bufs, int R, int me, size_t count, size_t per, int vec4)
+static __global__ __launch_bounds__(256) void peer_allreduce_kernel(CmfPtrTable bufs, int R, int me, size_t count, size_t per, int vec4)
 {
     const size_t lo = (size_t)me * per, hi = lo + per < count ? lo + per : count;
     if (lo >= hi) return;
@@ -3486,7 +3486,7 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(CmfPtrTable bufs, i
     }
 }
 // all-gather of the peer transport: shard `me` pulls every rank's send block into its own receive buffer
-__global__ __launch_bounds__(256) void peer_allgather_kernel(CmfPtrTable send, float *recv, int R, int count)
+static __global__ __launch_bounds__(256) void peer_allgather_kernel(CmfPtrTable send, float *recv, int R, int count)
 {
     const int total = R * count;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x)

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, MBW > 6 ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_sma
 
 // out[src][l][k][n] = sum over the slabs of in[slab][src][l*K+k][n]; rows k >= K of out are written as zeros.  The last
 // block also performs a carried loss reduction, like slab_sum_kernel.  grid.x covers nsrc * L * K32 * Np / 4 float4 words.
-__global__ __launch_bounds__(256) void slab_sum_small_kernel(float *out, const float *in, int nslabs, int nsrc, int L, int K, int K32, int Np, int JP,
+static __global__ __launch_bounds__(256) void slab_sum_small_kernel(float *out, const float *in, int nslabs, int nsrc, int L, int K, int K32, int Np, int JP,
                                                               CmfLossCarry carry)
 {
     const size_t n4 = (size_t)nsrc * L * K32 * Np / 4;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void slab_sum_small_kernel(float *out, const f
 // slab (all loads of a thread independent and in flight together) and are combined in a fixed order through LDS, so the result does
 // not depend on timing.  (The first form -- one workgroup per lag, the slabs added one after the other by each thread -- was 80
 // workgroups of dependent loads: 14 us, as long as the three launches it replaced.)
-__global__ __launch_bounds__(256) void w_update_small_kernel(float *Wt, float *Wn, float *Wj, const float *slabs, int nslabs,
+static __global__ __launch_bounds__(256) void w_update_small_kernel(float *Wt, float *Wn, float *Wj, const float *slabs, int nslabs,
                                                               int N, int K, int L, int Np, int K32, int JP, int Kg, int GR, int JP3,
                                                               float l1, float two_l2, CmfLossCarry carry)
 {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void w_update_small_kernel(float *Wt, float *W
 // (component g*Kg + kl, lag l), padded with zero rows to 32*MBW -- k-major, so that the L rows a folded output needs lie next to
 // each other (at most three components per 32-row block at L = 20) and no output is shared between two row groups.
 // Wj[n][g*32*MBW + kl*L + l] = W[l][n][g*Kg + kl], from Wn [Lp][Np][K32]: the A operand of the C3 GEMM, rows contiguous per n.
-__global__ __launch_bounds__(256) void wj_pack_kernel(const float *Wn, float *Wj, int Np, int K, int L, int K32, int Kg, int GR, int JP)
+static __global__ __launch_bounds__(256) void wj_pack_kernel(const float *Wn, float *Wj, int Np, int K, int L, int K32, int Kg, int GR, int JP)
 {
     const size_t total = (size_t)Np * JP;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {

@@ -1,6 +1,6 @@
 """T-sharded multiplicative-update rule, one process per GPU (torchrun-style launchers; bench.py --gpus N).
 
-The sharded iteration itself lives in libcmf_hip.so (csrc/cmf_group.h): rank r owns a contiguous block of
+The sharded iteration itself lives in libcmf_hip.so (csrc/cmf_groups.hip): rank r owns a contiguous block of
 columns of ``data`` and ``H``, ``W`` is replicated, and per MU iteration the ranks meet twice -- ONE RCCL
 all-reduce of the [numW | denomW] partial sums (its tail carries every rank's loss partial of the previous
 iteration) and one all-gather of the (L-1)-column H halos.  This module only

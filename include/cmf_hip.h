@@ -65,8 +65,8 @@ int cmf_abi_version(void);
 
 /* Library / build identification: "cmf_hip gfx950 <version> abi=<n> src=<digest>". */
 const char *cmf_version(void);
-/* Hex SHA-256 prefix (16 characters) of the sources this library was compiled from (csrc/cmf_api.hip, csrc/cmf_kernels.h,
- * csrc/cmf_small_k.h, csrc/cmf_group.h, csrc/cmf_workers.h, csrc/cmf_writeback.h, csrc/cmf_rng.h, include/cmf_hip.h, in that order, each preceded by its base name and a newline).
+/* Hex SHA-256 prefix (16 characters) of the sources this library was compiled from (csrc/cmf_api.hip, cmf_rules.hip, cmf_groups.hip,
+ * cmf_small.hip, cmf_internal.h, cmf_kernels.h, cmf_small_k.h, cmf_workers.h, cmf_writeback.h, cmf_rng.h, include/cmf_hip.h, in that order, each preceded by its base name and a newline).
  * A loader that has the tree at hand recomputes it and refuses (or rebuilds) a stale binary -- cmf.jl_amd/_lib.py does;
  * "unknown" when the library was built without the build script. */
 const char *cmf_source_digest(void);

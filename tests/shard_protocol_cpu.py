@@ -1,11 +1,11 @@
 """CPU mirror of the library's T-sharded group iteration (TEST INFRASTRUCTURE).
 
-csrc/cmf_group.h runs the sharded MU iteration on the GPU; it cannot execute where there is no GPU.  This file
+csrc/cmf_groups.hip runs the sharded MU iteration on the GPU; it cannot execute where there is no GPU.  This file
 states the same protocol step by step in Python over torch.distributed (gloo), with the numpy stand-in engine of
 tests/shard_engine_cpu.py computing each rank's block, so that the partition, the single all-reduce of
 [numW | denomW | tail], the H halo all-gather, the (hi, lo) own-slot encoding of the loss scalar and the one-
 iteration-late loss read-out of cmf_iterate are checked against the unsharded oracle on CPU-only machines.
-Function names follow cmf_group.h (group_update_motifs, group_update_feature_maps, group_iterate ...).
+Function names follow cmf_groups.hip (group_update_motifs, group_update_feature_maps, group_iterate ...).
 """
 import math
 

@@ -1,5 +1,5 @@
 """CPU mirrors of the group rules beyond the plain MU iteration (TEST INFRASTRUCTURE): the Gram form of the MU iteration
-and the PGD rule on T-sharded groups, as csrc/cmf_group.h / cmf_api.hip run them, stated in numpy over torch.distributed
+and the PGD rule on T-sharded groups, as csrc/cmf_groups.hip / cmf_api.hip run them, stated in numpy over torch.distributed
 (gloo) so that the sharded ALGEBRA -- which sums are local, which are all-reduced, where the halos enter, what only the last
 shard does -- is checked against the unsharded oracle on machines without a GPU.
 

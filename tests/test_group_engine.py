@@ -1,4 +1,4 @@
-"""The group engine of round 4 (csrc/cmf_group.h) on what a one-GPU box can run:
+"""The group engine of round 4 (csrc/cmf_groups.hip) on what a one-GPU box can run:
 
 * enqueue workers -- one thread per shard issuing that shard's kernels and collective calls -- against the calling thread
   enqueueing every shard itself: bitwise the same results, call by call and as pipelined cmf_iterate batches, plain /

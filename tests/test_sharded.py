@@ -2,7 +2,7 @@
 
 CPU (gloo, world_size 2 and 3): the Python mirror of the library's group protocol (tests/shard_protocol_cpu.py)
 with a numpy stand-in for the per-rank engine, against the unsharded oracle.
-GPU: the library's own group iteration (csrc/cmf_group.h) through the C ABI --
+GPU: the library's own group iteration (csrc/cmf_groups.hip) through the C ABI --
   * one process, several shards on GPU 0 (cmf_create_multi, loopback transport): middle-rank shards, config-3 shard size;
   * one process, RCCL transport with a single device (all a one-GPU box can form);
   * one process per shard (cmf_create_shard + cmf_comm_init_*): gloo ranks sharing GPU 0 through the host-callback

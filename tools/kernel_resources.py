@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel register / scratch / LDS figures of the gfx950 code object csrc/cmf_api.hip compiles to (no GPU needed).
+"""Per-kernel register / scratch / LDS figures of the gfx950 code objects the four csrc/*.hip translation units compile to (no GPU needed).
 
     python tools/kernel_resources.py            # all kernels; lines starting with SCRATCH use private memory
     python tools/kernel_resources.py --check    # exit 1 if any kernel has a private segment or spills VGPRs
@@ -17,14 +17,21 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def kernel_table():
+    notes = ""
+    csrc = os.path.join(ROOT, "cmf.jl_amd", "csrc")
     with tempfile.TemporaryDirectory() as tmp:
-        obj, co = os.path.join(tmp, "dev.o"), os.path.join(tmp, "gfx950.co")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-c", "--cuda-device-only",
-                               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cmf.jl_amd", "csrc"),
-                               os.path.join(ROOT, "cmf.jl_amd", "csrc", "cmf_api.hip"), "-o", obj])
-        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={obj}",
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
-        notes = subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", co]).decode()
+        jobs = []
+        for src in sorted(f for f in os.listdir(csrc) if f.endswith(".hip")):  # the translation units, side by side
+            obj = os.path.join(tmp, src + ".o")
+            jobs.append((src, obj, subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-c", "--cuda-device-only",
+                                                     "-I", os.path.join(ROOT, "include"), "-I", csrc, os.path.join(csrc, src), "-o", obj])))
+        for src, obj, proc in jobs:
+            if proc.wait() != 0:
+                raise RuntimeError(f"hipcc failed on {src}")
+            co = obj + ".co"
+            subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={obj}",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+            notes += subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", co]).decode()
     rows = []
     for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
         g = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", blk).group(1))  # noqa: E731
