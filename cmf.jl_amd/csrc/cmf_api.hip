@@ -336,8 +336,11 @@ int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64_t K, i
     struct Want { void **pp; size_t bytes; };
     std::vector<Want> wants;
     int want_rc = CMF_OK;
+    // (test hook CMF_TEST_NO_ARENA=1: every buffer an allocation of its own, so that an overrun of one cannot land silently in a live
+    // neighbour -- tests/test_small_k.py runs once in that form)
+    const bool no_arena = test_hook("CMF_TEST_NO_ARENA", 0) == 1;
     auto want = [&](auto **pp, size_t n) {
-        if (n * sizeof(**pp) >= ((size_t)32 << 20)) { if (want_rc == CMF_OK) want_rc = dalloc_zero(pp, n); }
+        if (no_arena || n * sizeof(**pp) >= ((size_t)32 << 20)) { if (want_rc == CMF_OK) want_rc = dalloc_zero(pp, std::max<size_t>(n, 1)); }
         else wants.push_back({reinterpret_cast<void **>(pp), n * sizeof(**pp)});
     };
     const size_t TPNp = (size_t)d.TP * d.Np;

@@ -334,7 +334,7 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
 };
-static RcclApi g_rccl;
+inline RcclApi g_rccl; // (one table for the whole library: C++17 inline variable)
 
 #define RCCLCHK(expr)                                                                                          \
     do {                                                                                                       \

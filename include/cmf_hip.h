@@ -22,7 +22,7 @@
  *   - There is no CPU fallback: without a usable HIP device every compute
  *     entry fails with CMF_ERR_HIP.
  *   - Environment.  Everything that selects a code path is an OPTION (cmf_set_option; cmf_option_names lists them).  The library
- *     reads these variables and no others:
+ *     reads these ten variables and no others:
  *         CMF_WAIT_TIMEOUT_S     bound of every host-side wait (loss words, helper threads, collectives): seconds, default 300
  *         CMF_WRITEBACK_THREADS  widening helpers of cmf_arm_writeback: default 4, at most 16
  *         CMF_ENQUEUE_THREADS    0: the calling thread enqueues every shard of a one-process group (see cmf_create_multi)
@@ -33,6 +33,7 @@
  *           CMF_MAX_COLUMNS        columns one handle holds before cmf_create cuts the recording into shards (tests of that path)
  *           CMF_TEST_FORCE_WORKERS 1: an enqueue worker for a ONE-shard RCCL group too
  *           CMF_TEST_FAIL_SHARD    that shard's next all-reduce call fails (tests of the failure path)
+ *           CMF_TEST_NO_ARENA      1: every buffer of a handle is an allocation of its own (an overrun cannot hide in a neighbour)
  */
 #ifndef CMF_HIP_H
 #define CMF_HIP_H

@@ -117,7 +117,7 @@ def option_names(lib):
     return buf.value.decode().split(",")
 
 
-def test_every_code_path_choice_is_a_documented_option_and_the_environment_is_nine_variables(cmf):
+def test_every_code_path_choice_is_a_documented_option_and_the_environment_is_ten_variables(cmf):
     """Round 6: the measurement knobs read from the environment are gone.  Whatever selects a code path is a cmf_set_option name
     that the header documents (cmf_option_names is the table), and the sources read exactly the variables the header lists."""
     lib = cmf.load_library()
@@ -134,7 +134,7 @@ def test_every_code_path_choice_is_a_documented_option_and_the_environment_is_ni
     read = set(re.findall(r'getenv\("(CMF_[A-Z_]+)"\)', code)) | set(re.findall(r'test_hook\("(CMF_[A-Z_]+)"', code))
     listed = set(re.findall(r"^ \*\s+(CMF_[A-Z_]+)\s", hdr[: hdr.index("#ifndef CMF_HIP_H")], flags=re.M))
     assert read == listed, (sorted(read - listed), sorted(listed - read))
-    assert len(read) == 9
+    assert len(read) == 10
     # ... and nothing else in the repository still sets a variable the library no longer reads
     stale = re.compile(r"CMF_(HALS_[A-Z]+|CONV_[A-Z_]+|SK_[A-Z_0-9]+|GRAM_FW|PGD_TRANSPOSE|LOSS_POLL|SPECULATE_W|SMALL_K\b|HXT_EXACT|LOOPBACK_[A-Z_]+|EXP_CU_MASK)")
     for sub in ("tests", "tools", "cmf.jl_amd", "."):

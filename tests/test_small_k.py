@@ -148,3 +148,32 @@ def test_reference_protocol_shape_full_size(cmf, oracle):
         np.testing.assert_allclose(ls, lr, rtol=REL_LOSS)
         assert frob_rel(out[small][1], Wr) < REL_FACTORS and frob_rel(out[small][2], Hr) < REL_FACTORS
     print("small_k vs general kernels: relW", frob_rel(out[1][1], out[0][1]), "relH", frob_rel(out[1][2], out[0][2]))
+
+
+def test_every_shape_with_every_buffer_an_allocation_of_its_own(cmf):
+    """The small buffers of a handle (H, W, slabs, numerators, halos, partials: about twenty) live in ONE allocation at 256-byte
+    granules, so an overrun of one -- the few-component kernels have slab spills, VALU rows and quarter-piece partial indices to get
+    wrong -- would land in a live neighbour and could pass unnoticed.  Test hook CMF_TEST_NO_ARENA=1 gives every buffer its own
+    allocation: the same iterations must give bit for bit the same factors and losses as with the arena (what ran above)."""
+    import os
+
+    for (N, T, K, L) in SHAPES:
+        rng = np.random.default_rng(N * 7 + T)
+        data = rng.random((N, T))
+        W0 = np.asfortranarray(rng.random((K, N, L)))
+        H0 = np.asfortranarray(rng.random((K, T)))
+        out = []
+        for no_arena in (False, True):
+            if no_arena:
+                os.environ.update(CMF_TEST_HOOKS="1", CMF_TEST_NO_ARENA="1")
+            try:
+                rule = cmf.MultUpdate(data, W0, H0)
+            finally:
+                os.environ.pop("CMF_TEST_HOOKS", None)
+                os.environ.pop("CMF_TEST_NO_ARENA", None)
+            rule.set_option("small_k", 2)
+            ls = rule.iterate(2, l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2)
+            out.append((ls,) + rule.download())
+            rule.close()
+        for a, b in zip(*out):
+            assert np.array_equal(a, b), (N, T, K, L)
