@@ -26,7 +26,7 @@ ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ct
 # every symbol include/cmf_hip.h declares (tests check the library exports each one)
 SYMBOLS = [
     "cmf_abi_version", "cmf_version", "cmf_source_digest", "cmf_last_error", "cmf_device_count",
-    "cmf_create", "cmf_create_shard", "cmf_create_multi", "cmf_destroy", "cmf_synchronize", "cmf_set_stream",
+    "cmf_create", "cmf_create_shard", "cmf_shard_set_left_data", "cmf_create_multi", "cmf_destroy", "cmf_synchronize", "cmf_set_stream",
     "cmf_rccl_version", "cmf_get_counter",
     "cmf_comm_unique_id", "cmf_comm_init_rccl", "cmf_comm_init_overlap", "cmf_comm_init_callbacks", "cmf_comm_info", "cmf_shard_bounds",
     "cmf_set_option", "cmf_option_names", "cmf_get_data_sumsq",
@@ -98,6 +98,7 @@ def load():
     sig("cmf_comm_init_callbacks", [vp, cint, cint, ALLREDUCE_FN, ALLGATHER_FN, vp])
     sig("cmf_comm_info", [vp, ctypes.c_char_p, i64])
     sig("cmf_shard_bounds", [vp, cint, pi64, pi64])
+    sig("cmf_shard_set_left_data", [vp, pd])
     sig("cmf_destroy", [vp])
     sig("cmf_set_stream", [vp, vp])
     sig("cmf_set_option", [vp, ctypes.c_char_p, cint])

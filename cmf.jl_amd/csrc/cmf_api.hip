@@ -88,9 +88,9 @@ void plan(cmf_handle_s *h, int n_cu)
     // C3 (transconv): the chunk units of all (t block, k block, source) pairs are dealt out evenly to the resident
     // waves (2 workgroups of 4 waves per CU); F = the largest number of waves that share one pair
     h->tc_LT = d.L <= 32 ? (int)rup(d.L, 4) : 32;
-    auto tc_plan = [&](int nsrc, int *Wout, int *Fout, std::vector<int4> &tab) {
+    auto tc_plan = [&](int nsrc, int *Wout, int *Fout, std::vector<int4> &tab, int extra_blocks) {
         const long long C = rup(d.N, 8) / 8;
-        const long long pairs = (long long)((d.Tl + 127) / 128) * d.KB * nsrc;
+        const long long pairs = (long long)((d.Tl + 127) / 128 + extra_blocks) * d.KB * nsrc;
         const long long U = pairs * C;
         // 2 workgroups of 4 waves per CU; 12 (the register limit with the LDS-DMA staging) measured the same
         // 1.73 ms at config 2 and costs more fragment slabs
@@ -122,8 +122,9 @@ void plan(cmf_handle_s *h, int n_cu)
         *Wout = (int)W;
         *Fout = F;
     };
-    tc_plan(2, &h->tc_W, &h->tc_S, h->tc_tab_host[0]);
-    tc_plan(1, &h->tc_W1, &h->tc_S1, h->tc_tab_host[1]);
+    tc_plan(2, &h->tc_W, &h->tc_S, h->tc_tab_host[0], 0);
+    tc_plan(1, &h->tc_W1, &h->tc_S1, h->tc_tab_host[1], 0);
+    if (h->halo_ext) tc_plan(2, &h->tc_W2, &h->tc_S2, h->tc_tab_host[2], 1); // (one more 128-column block, in front of the own columns)
     h->tc_S_full = h->tc_S;
     h->tc_S1_full = h->tc_S1;
     // few components: J = L*K rows on the MFMA axes (cmf_small_k.h)
@@ -214,7 +215,7 @@ static void destroy_impl(cmf_handle_s *h)
                       h->gram_numden_h, h->pgd_gradH, h->M, h->MT, h->hals_snap, h->hals_HX, h->hals_cslabs, h->hals_C, h->hals_HH, h->hals_PT, h->hals_D, h->hals_PW, h->hals_GW, h->hals_GE, h->hals_GWt};
     for (float *p : fbufs)
         if (mine(p)) (void)hipFree(p);
-    for (int v = 0; v < 2; ++v)
+    for (int v = 0; v < 3; ++v)
         if (h->tc_tab[v]) (void)hipFree(h->tc_tab[v]);
     if (mine(h->partial)) (void)hipFree(h->partial);
     for (hipStream_t st : {h->hals_sA, h->hals_sB})
@@ -301,6 +302,11 @@ int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64_t K, i
     d.KB = (int)((K + 31) / 32);
     d.K32 = 32 * d.KB;
     d.PADL = (int)rup(L - 1, 32) + 32;
+    // A shard with a left neighbour may carry the halo of H in the W-phase all-reduce (cmf_groups.hip): it then updates the L-1 columns
+    // in front of its own itself -- one conv tile row at columns [-64, 0) and one transconv block at [-128, 0), from an H that is valid
+    // 2(L-1) columns out -- which needs 128 columns of padding in front of every time axis (K a multiple of 32: the one-wave conv tiles)
+    h->halo_ext = (sharded && t_offset > 0 && K % 32 == 0 && L - 1 >= 1 && L - 1 <= 64) ? (int)(L - 1) : 0;
+    if (h->halo_ext) d.PADL += 64;
     d.TP = d.PADL + (int)rup(Tl + L, 512) + 256;
     d.Lp = L <= 32 ? (int)rup(L, 4) : (int)rup(L, 32);
     if ((double)d.Lp * d.Np * d.K32 * 4.0 >= 2147483648.0 || (double)d.TP * d.K32 * 4.0 >= 2147483648.0 ||
@@ -354,7 +360,8 @@ int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64_t K, i
     want(&h->estT, TPNp);
     want(&h->wslabs, (size_t)std::max(2 * hxt_nslabs(h->hxt_nchunks), hxt_nslabs(h->hxt_nchunks1)) * d.L * d.K32 * d.Np);
     want(&h->numden_own, (size_t)2 * d.L * d.K32 * d.Np);
-    want(&h->hslabs, (size_t)std::max(2 * std::max(h->tc_S, 2 * h->sk3_NS), std::max(h->tc_S1, 2 * h->sk3_NS)) * d.Tl * d.K32); // (the few-component C3 writes 2 slabs per piece of its reduction)
+    want(&h->hslabs, std::max((size_t)std::max(2 * std::max(h->tc_S, 2 * h->sk3_NS), std::max(h->tc_S1, 2 * h->sk3_NS)) * d.Tl * d.K32,
+                              h->halo_ext ? (size_t)2 * h->tc_S2 * (d.Tl + 128) * d.K32 : (size_t)0)); // (the few-component C3 writes 2 slabs per piece of its reduction)
     if (h->small_k_ok) {
         want(&h->sk_slabs, (size_t)h->sk_ngroups * 2 * h->sk_JP * d.Np);
         want(&h->sk_Wj, (size_t)d.Np * h->sk3_JP);
@@ -362,7 +369,8 @@ int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64_t K, i
         h->sk_tc = h->small_k && h->sk_tc_ok;
         if (h->sk_tc) h->tc_S = h->tc_S1 = 2 * h->sk3_NS;
     }
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < 3; ++v) {
+        if (h->tc_tab_host[v].empty()) continue;
         HIPB(hipMalloc(&h->tc_tab[v], h->tc_tab_host[v].size() * sizeof(int4)));
         HIPB(hipMemcpy(h->tc_tab[v], h->tc_tab_host[v].data(), h->tc_tab_host[v].size() * sizeof(int4), hipMemcpyHostToDevice));
     }
@@ -435,7 +443,7 @@ static int launch_hxt(cmf_handle_s *h)
     return launch_hxt_on(h, h->X, h->est, h->d.Np, 2, h->wslabs, h->hxt_nchunks, h->hxt_chunk_len, h->hxt_main);
 }
 
-int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0)
+int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0, bool front_block)
 {
     if (h->sk_tc) return launch_transconv_small(h, nsrc, xt0);
     ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_TRANSCONV_1);
@@ -449,6 +457,13 @@ int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0)
     p.W = nsrc == 2 ? h->tc_W : h->tc_W1;
     p.F = nsrc == 2 ? h->tc_S : h->tc_S1;
     p.wtab = h->tc_tab[nsrc == 2 ? 0 : 1];
+    p.t_first = 0;
+    p.slab_rows = d.Tl;
+    if (front_block) { // (two sources; a shard that also updates the columns in front of its own: h_update_impl)
+        p.W = h->tc_W2; p.F = h->tc_S2; p.wtab = h->tc_tab[2];
+        p.t_first = -128;
+        p.slab_rows = d.Tl + 128;
+    }
     dim3 grid((p.W + 3) / 4), block(256);
     switch (h->tc_LT) {
 #define CASE(LT_) case LT_: hipLaunchKernelGGL((transconv_kernel<LT_>), grid, block, 0, h->stream, p); break;
@@ -595,10 +610,27 @@ static int w_apply_impl_(cmf_handle_s *h, double l1W, double l2W, const float *t
     return CMF_OK;
 }
 
-int h_update_impl(cmf_handle_s *h, double l1H, double l2H)
+// front: a shard whose group carries the halo of H in the W-phase all-reduce (cmf_groups.hip) also updates the hx = L-1 columns in
+// FRONT of its own -- its left neighbour's last ones, which its loss conv and its next W phase read -- from an H that is valid 2 hx
+// columns out: one more conv tile row (columns [-64, 0)), one more transconv block ([-128, 0)), the element-wise update from -hx on.
+int h_update_impl(cmf_handle_s *h, double l1H, double l2H, bool front)
 {
     const CmfDims &d = h->d;
     CMFTRY(launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext)); // mult.jl:44 (est with the new W)
+    if (front) {
+        if (!h->halo_ext || !h->left_data) return fail(CMF_ERR_STATE, "internal: this shard cannot update the columns in front of its own");
+        int np = 0;
+        CMFTRY(launch_conv_rows<1>(h, h->estT, -1, 1, 0, h->n_cu, nullptr, nullptr, nullptr, &np));
+        CMFTRY(launch_transconv(h, 2, nullptr, true));                    // mult.jl:47-48 on columns [-128, Tl)
+        const int hx = h->halo_ext, R = d.Tl + 128;
+        dim3 gridx((d.Tl + hx + HUPD_T - 1) / HUPD_T, d.KB);
+        const float *num = h->hslabs + (size_t)(128 - hx) * d.K32;        // slab row r holds column r - 128: the update starts at column -hx
+        hipLaunchKernelGGL(h_update_kernel, gridx, dim3(256), 0, h->stream, h->H, h->Ht, num, (size_t)2 * R * d.K32, h->tc_S2, num + (size_t)R * d.K32,
+                           (size_t)2 * R * d.K32, h->tc_S2, d.Tl + hx, d.K, d.K32, d.PADL - hx, d.TP, (float)l1H, (float)(2.0 * l2H)); // mult.jl:51-52
+        KCHK("h_update_kernel");
+        set_est(h, 0);
+        return wb_after_H(h);
+    }
     CMFTRY(launch_transconv(h, 2));                                         // mult.jl:47-48
     dim3 grid((d.Tl + HUPD_T - 1) / HUPD_T, d.KB);
     const size_t TK = (size_t)d.Tl * d.K32;
@@ -1069,6 +1101,18 @@ int cmf_create_shard(cmf_handle *h, int device, int64_t N, int64_t T_local, int6
     return create_impl(h, device, N, T_local, K, L, data_local, t_offset, T_global, true);
 }
 
+int cmf_shard_set_left_data(cmf_handle h, const double *cols)
+{
+    if (!h || !cols) return fail(CMF_ERR_ARG, "NULL argument");
+    if (h->group) return fail(CMF_ERR_STATE, "call cmf_shard_set_left_data before the shard joins its group (cmf_comm_init_*)");
+    if (!h->sharded) return fail(CMF_ERR_STATE, "cmf_shard_set_left_data needs a handle from cmf_create_shard");
+    if (!h->halo_ext) return CMF_OK; // (the first shard, or a shape on which the halo keeps its own all-gather: nothing to keep)
+    HIPCHK(hipSetDevice(h->device));
+    CMFTRY(upload_cols(h, cols, -h->halo_ext, h->halo_ext, false, false)); // data' only: the operand of the transconv's front block
+    h->left_data = true;
+    return CMF_OK;
+}
+
 int cmf_destroy(cmf_handle h)
 {
     if (h && h->group) {
@@ -1119,6 +1163,9 @@ int cmf_get_counter(cmf_handle h, const char *name, int64_t *value)
     if (std::strcmp(name, "writeback_overlapped") == 0) { *value = h->wb ? h->wb->hooked_calls : 0; return CMF_OK; }     // ... served by the copy stream behind the H update
     if (h->group) { // host cost of the pipelined iterations of a group (reading a counter resets nothing)
         cmf_group_s *g = h->group;
+        if (std::strcmp(name, "allreduce_calls") == 0) { *value = g->n_allreduce; return CMF_OK; } // collectives this handle has issued since it was made
+        if (std::strcmp(name, "allgather_calls") == 0) { *value = g->n_allgather; return CMF_OK; } // (per shard: every rank makes each of them once)
+        if (std::strcmp(name, "halo_in_allreduce") == 0) { *value = (g->halo_opt && g->halo_can && !g->gram && g->nranks > 1) ? 1 : 0; return CMF_OK; }
         if (std::strcmp(name, "enqueue_ns") == 0) { *value = g->enqueue_ns; return CMF_OK; }       // calling thread: enqueueing / posting
         if (std::strcmp(name, "enqueue_iters") == 0) { *value = g->enqueue_iters; return CMF_OK; } // ... over this many iterations
         if (std::strcmp(name, "worker_ns") == 0) {                                                  // busiest enqueue worker: time inside its jobs
@@ -1149,7 +1196,7 @@ int cmf_set_stream(cmf_handle h, void *hip_stream)
 // every name cmf_set_option knows (cmf_option_names; tests/test_library_abi.py walks the table)
 static const char *const kOptionNames[] = {"reuse_est", "speculate", "gram", "conv_kernel", "conv_split", "small_k", "hals_prepare", "hals_gram",
                                            "hals_persist", "hals_general", "hals_seg", "hals_lag", "hals_debug", "hals_chase", "profile", "profile_mask",
-                                           "allreduce_overlap", "enqueue_threads"};
+                                           "allreduce_overlap", "enqueue_threads", "halo_in_allreduce"};
 int cmf_option_names(char *buf, int64_t len)
 {
     if (!buf || len < 1) return fail(CMF_ERR_ARG, "bad buffer");
@@ -1170,6 +1217,15 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
             CMFTRY(group_sync(g));
             if (value) CMFTRY(group_ensure_lane1(g)); // the communication stream gets a communicator of its own
             g->overlap = value != 0;
+            g->num_ready = false;
+            return CMF_OK;
+        }
+        if (std::strcmp(name, "halo_in_allreduce") == 0) { // 1 (default): the halo of H travels in the W-phase all-reduce where every shard can (cmf_groups.hip)
+            CMFTRY(group_sync(g));
+            g->halo_opt = value != 0;
+            g->halos_current = false; // (the next phase starts from a whole exchange in the form that is now in force)
+            g->halos_pending = false;
+            g->halo_wide = false;
             g->num_ready = false;
             return CMF_OK;
         }
@@ -1214,7 +1270,7 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
         g->num_ready = false;
         return CMF_OK;
     }
-    if (std::strcmp(name, "allreduce_overlap") == 0 || std::strcmp(name, "enqueue_threads") == 0) return CMF_OK; // single GPU: nothing to overlap, nobody else to enqueue
+    if (std::strcmp(name, "allreduce_overlap") == 0 || std::strcmp(name, "enqueue_threads") == 0 || std::strcmp(name, "halo_in_allreduce") == 0) return CMF_OK; // single GPU: nothing to overlap, nobody else to enqueue
     if (std::strcmp(name, "gram") == 0) {
         if (value < 0 || value > 2) return fail(CMF_ERR_ARG, "gram must be 0, 1 or 2");
         if (value && h->sharded && h->T_global != h->d.Tl) return fail(CMF_ERR_STATE, "the Gram form is not available on sharded handles");
@@ -1992,6 +2048,7 @@ int cmf_time_kernel(cmf_handle h, const char *name, int reps, double *avg_ms, do
         *avg_ms = (double)ms / reps;
         *flops = (double)count * sizeof(float);
         g->num_ready = false;
+        g->halos_current = g->halos_pending = g->halo_wide = false; // (the buffers are scratch here: halo slots waiting in the tail are gone -- the next phase exchanges afresh)
         return CMF_OK;
     }
     if (h && h->root_only) h = h->group->sh[0]; // shard 0 stands for the group

@@ -126,11 +126,14 @@ static int group_alloc_buffers(cmf_group_s *g)
     g->tail = rup(2 * g->nranks, 64);
     g->HC = (int64_t)std::max(1, d.L - 1) * d.K32;
     g->HHsz = (int64_t)d.L * d.K32 * rup((int64_t)d.L * d.K32, 128);
-    const size_t red_elems = (size_t)std::max(g->LKN2, g->LKN2 / 2 + g->HHsz) + (size_t)g->tail;
+    g->halo_len = (int64_t)g->nranks * 3 * g->HC;
+    const size_t red_elems = (size_t)std::max(g->LKN2, g->LKN2 / 2 + g->HHsz) + (size_t)g->tail + (size_t)g->halo_len;
     const size_t nl = g->sh.size();
     g->red.assign(nl, nullptr);
     g->halo_send.assign(nl, nullptr);
     g->halo_all.assign(nl, nullptr);
+    g->halo3_send.assign(nl, nullptr);
+    g->halo3_all.assign(nl, nullptr);
     g->loss_all.assign(nl, nullptr);
     for (size_t i = 0; i < nl; ++i) {
         cmf_handle_s *s = g->sh[i];
@@ -138,6 +141,8 @@ static int group_alloc_buffers(cmf_group_s *g)
         CMFTRY(dalloc_zero(&g->red[i], red_elems));
         CMFTRY(dalloc_zero(&g->halo_send[i], (size_t)(2 * g->HC)));
         CMFTRY(dalloc_zero(&g->halo_all[i], (size_t)(g->nranks * 2 * g->HC)));
+        CMFTRY(dalloc_zero(&g->halo3_send[i], (size_t)(3 * g->HC)));
+        CMFTRY(dalloc_zero(&g->halo3_all[i], (size_t)g->halo_len));
         CMFTRY(dalloc_zero(&g->loss_all[i], (size_t)(2 * g->tail))); // [gathered pairs | send scratch]
         s->numden = g->red[i];
         const int r = g->rank[i];
@@ -448,16 +453,21 @@ static void step_seg(StepList &st, const char *name, std::function<int(size_t)> 
     s.seg = std::move(fn);
     st.push_back(std::move(s));
 }
+// is the halo of H carried in the W-phase all-reduce on this group, in its current formulation?  (cmf_group_s::halo_opt)
+static inline bool halo_in_ar(const cmf_group_s *g) { return g->halo_opt && g->halo_can && !g->gram && g->nranks > 1; }
+
 static void step_allreduce(cmf_group_s *g, StepList &st, const char *name, const std::vector<float *> &bufs, size_t off, size_t count, int lane = 0)
 {
     if (g->nranks == 1 && g->transport != CMF_TR_RCCL) return;
+    g->n_allreduce += 1;
     GroupStep s;
     s.name = name;
     s.coll = 1; s.a = bufs; s.off = off; s.count = count; s.lane = lane;
     st.push_back(std::move(s));
 }
-static void step_allgather(StepList &st, const char *name, const std::vector<float *> &send, const std::vector<float *> &recv, size_t count)
+static void step_allgather(cmf_group_s *g, StepList &st, const char *name, const std::vector<float *> &send, const std::vector<float *> &recv, size_t count)
 {
+    g->n_allgather += 1;
     GroupStep s;
     s.name = name;
     s.coll = 2; s.a = send; s.b = recv; s.count = count;
@@ -611,7 +621,29 @@ static void build_exchange_halos(cmf_group_s *g, StepList &st)
     cmf_handle_s *s0 = g->sh[0];
     const int rows = s0->d.L - 1;
     g->halos_current = true;
+    g->halos_pending = false;
+    g->halo_wide = false;
     if (rows < 1 || g->nranks == 1) return;
+    if (halo_in_ar(g)) { // the wide exchange (last 2(L-1) | first L-1 columns of every rank), here as an all-gather of the slots
+        g->halo_wide = true;
+        step_seg(st, "cmf:halo pack (wide)", [g, rows](size_t i) {
+            cmf_handle_s *s = g->sh[i];
+            const CmfDims &d = s->d;
+            hipLaunchKernelGGL(halo_pack3_kernel, dim3(8), dim3(256), 0, s->stream, s->H, g->halo3_send[i], d.PADL, d.Tl, rows, d.K32, 0, 1);
+            KCHK("halo_pack3_kernel");
+            return CMF_OK;
+        });
+        step_allgather(g, st, "cmf:all-gather of the H halos (wide)", g->halo3_send, g->halo3_all, (size_t)(3 * g->HC));
+        step_seg(st, "cmf:halo unpack (wide)", [g, rows](size_t i) {
+            cmf_handle_s *s = g->sh[i];
+            const CmfDims &d = s->d;
+            hipLaunchKernelGGL(halo_unpack3_kernel, dim3(8), dim3(256), 0, s->stream, s->H, s->Ht, g->halo3_all[i], d.PADL, d.Tl, rows, d.K32, d.TP,
+                               g->rank[i], g->nranks);
+            KCHK("halo_unpack3_kernel");
+            return CMF_OK;
+        });
+        return;
+    }
     step_seg(st, "cmf:halo pack", [g, rows](size_t i) {
         cmf_handle_s *s = g->sh[i];
         const CmfDims &d = s->d;
@@ -619,7 +651,7 @@ static void build_exchange_halos(cmf_group_s *g, StepList &st)
         KCHK("halo_pack2_kernel");
         return CMF_OK;
     });
-    step_allgather(st, "cmf:all-gather of the H halos", g->halo_send, g->halo_all, (size_t)(2 * g->HC));
+    step_allgather(g, st, "cmf:all-gather of the H halos", g->halo_send, g->halo_all, (size_t)(2 * g->HC));
     step_seg(st, "cmf:halo unpack", [g, rows](size_t i) {
         cmf_handle_s *s = g->sh[i];
         const CmfDims &d = s->d;
@@ -668,7 +700,7 @@ static int group_loss_now(cmf_group_s *g, StepList &&st, double *sumsq)
     }
     std::vector<float *> send(nl);
     for (size_t i = 0; i < nl; ++i) send[i] = g->red[i] + group_tail_off(g) + 2 * g->rank[i];
-    step_allgather(st, "cmf:all-gather of the loss pairs", send, g->loss_all, 2);
+    step_allgather(g, st, "cmf:all-gather of the loss pairs", send, g->loss_all, 2);
     CMFTRY(group_run(g, std::move(st)));
     CMFTRY(group_join(g));
     CMFTRY(group_use(s));
@@ -708,17 +740,20 @@ static void build_start_num(cmf_group_s *g, StepList &st)
 // iteration's loss pairs of every rank) is copied to pinned host slot `ring_slot`, which the host polls.
 static void build_update_motifs(cmf_group_s *g, StepList &st, double l1W, double l2W, int ring_slot = -1)
 {
-    if (!g->halos_current) build_exchange_halos(g, st);
+    if (!g->halos_current && !g->halos_pending) build_exchange_halos(g, st); // (pending: the L-1 columns in front are valid -- all this phase reads)
     const size_t half = (size_t)g->LKN2 / 2;
     const size_t toff = group_tail_off(g);
     const int gram = g->gram;
+    // the halos of the H phase before ride behind the loss tail (they were packed there by that phase)
+    const bool carry_halo = halo_in_ar(g) && g->halos_pending;
+    const size_t hcount = carry_halo ? (size_t)g->halo_len : 0;
     if (g->overlap) {
         if (!g->num_ready) build_start_num(g, st);
         if (gram) { // the bulk is in flight on the communication stream: only the loss tail is left for this stream
             step_allreduce(g, st, "cmf:all-reduce of the loss tail", g->red, toff, (size_t)g->tail);
         } else {
             step_seg(st, "cmf:denomW contraction", [g](size_t i) { return w_partial_half_impl(g->sh[i], 1); });
-            step_allreduce(g, st, "cmf:all-reduce of [denomW | tail]", g->red, half, half + (size_t)g->tail);
+            step_allreduce(g, st, "cmf:all-reduce of [denomW | tail | halos]", g->red, half, half + (size_t)g->tail + hcount);
         }
         step_seg(st, "cmf:wait for the communication stream", [g](size_t i) {
             cmf_handle_s *s = g->sh[i];
@@ -732,7 +767,7 @@ static void build_update_motifs(cmf_group_s *g, StepList &st, double l1W, double
             if (gram) return gram_w_partial(s, s->numden + half); // [numW | this shard's share of HH | tail]
             return w_partial_impl(s);
         });
-        step_allreduce(g, st, "cmf:all-reduce of [numW | denomW | tail]", g->red, 0, toff + (size_t)g->tail);
+        step_allreduce(g, st, "cmf:all-reduce of [numW | denomW | tail | halos]", g->red, 0, toff + (size_t)g->tail + hcount);
     }
     float *ring = nullptr;
     if (ring_slot >= 0) { // shard 0's W update also drops the reduced loss pairs + a stamp into the pinned ring slot
@@ -749,6 +784,20 @@ static void build_update_motifs(cmf_group_s *g, StepList &st, double l1W, double
         if (gram) return gram_w_finish(s, s->numden + half, l1W, l2W);
         return w_apply_impl(s, l1W, l2W);
     });
+    if (carry_halo) { // every rank's outer columns of the new H have arrived with the sums: the halos are whole again, 2(L-1) columns out on the left
+        const int rows = g->sh[0]->d.L - 1;
+        step_seg(st, "cmf:halo unpack (from the all-reduce)", [g, rows, toff](size_t i) {
+            cmf_handle_s *s = g->sh[i];
+            const CmfDims &d = s->d;
+            hipLaunchKernelGGL(halo_unpack3_kernel, dim3(8), dim3(256), 0, s->stream, s->H, s->Ht, g->red[i] + toff + (size_t)g->tail, d.PADL, d.Tl, rows,
+                               d.K32, d.TP, g->rank[i], g->nranks);
+            KCHK("halo_unpack3_kernel");
+            return CMF_OK;
+        });
+        g->halos_current = true;
+        g->halos_pending = false;
+        g->halo_wide = true;
+    }
 }
 int group_update_motifs(cmf_group_s *g, double l1W, double l2W)
 {
@@ -761,11 +810,28 @@ int group_update_motifs(cmf_group_s *g, double l1W, double l2W)
 // tail of the all-reduce buffer and ride on the next update_motifs!.
 static void build_update_feature_maps(cmf_group_s *g, StepList &st, double l1H, double l2H, bool defer)
 {
-    if (!g->halos_current) build_exchange_halos(g, st);
+    const bool in_ar = halo_in_ar(g);
+    if (!g->halos_current || (in_ar && !g->halo_wide)) build_exchange_halos(g, st);
     const int gram = g->gram;
-    step_seg(st, "cmf:H phase (mult.jl:44-52)", [g, gram, l1H, l2H](size_t i) { return gram ? gram_h_update(g->sh[i], l1H, l2H) : h_update_impl(g->sh[i], l1H, l2H); });
+    step_seg(st, "cmf:H phase (mult.jl:44-52)", [g, gram, in_ar, l1H, l2H](size_t i) {
+        return gram ? gram_h_update(g->sh[i], l1H, l2H) : h_update_impl(g->sh[i], l1H, l2H, in_ar && g->rank[i] > 0);
+    });
     g->num_ready = false;
-    build_exchange_halos(g, st);
+    if (in_ar) { // no exchange here: the loss conv and the next W phase read the L-1 columns in front, which this shard has just updated itself
+        const size_t toff = group_tail_off(g);
+        const int rows = g->sh[0]->d.L - 1;
+        step_seg(st, "cmf:halo pack (into the all-reduce tail)", [g, rows, toff](size_t i) {
+            cmf_handle_s *s = g->sh[i];
+            const CmfDims &d = s->d;
+            hipLaunchKernelGGL(halo_pack3_kernel, dim3(16), dim3(256), 0, s->stream, s->H, g->red[i] + toff + (size_t)g->tail, d.PADL, d.Tl, rows, d.K32,
+                               g->rank[i], g->nranks);
+            KCHK("halo_pack3_kernel");
+            return CMF_OK;
+        });
+        g->halos_current = false;
+        g->halos_pending = true;
+        g->halo_wide = false;
+    } else build_exchange_halos(g, st);
     if (g->overlap) build_start_num(g, st); // for the next update_motifs!: H and its halos are final now
     // (Gram + overlap: the next W phase has no slab sum left on this stream for a deferred reduction to ride on)
     build_loss_partials(g, st, defer && !(g->gram && g->overlap));
@@ -781,7 +847,7 @@ int group_update_feature_maps(cmf_group_s *g, double l1H, double l2H, double *su
 int group_compute_loss(cmf_group_s *g, double *loss)
 {
     StepList st;
-    if (!g->halos_current) build_exchange_halos(g, st);
+    if (!g->halos_current && !g->halos_pending) build_exchange_halos(g, st); // (pending: the L-1 columns in front, all the conv reads, are valid)
     build_loss_partials(g, st);
     double ss = 0.0;
     CMFTRY(group_loss_now(g, std::move(st), &ss));
@@ -865,6 +931,8 @@ int group_set_factors(cmf_group_s *g, const double *W, const double *H)
     }
     g->num_ready = false;
     g->halos_current = false;
+    g->halos_pending = false;
+    g->halo_wide = false;
     CMFTRY(group_exchange_halos(g));
     return group_join(g);
 }
@@ -930,6 +998,8 @@ bool group_destroy(cmf_group_s *g)
         if (i < g->red.size() && g->red[i]) (void)hipFree(g->red[i]);
         if (i < g->halo_send.size() && g->halo_send[i]) (void)hipFree(g->halo_send[i]);
         if (i < g->halo_all.size() && g->halo_all[i]) (void)hipFree(g->halo_all[i]);
+        if (i < g->halo3_send.size() && g->halo3_send[i]) (void)hipFree(g->halo3_send[i]);
+        if (i < g->halo3_all.size() && g->halo3_all[i]) (void)hipFree(g->halo3_all[i]);
         if (i < g->loss_all.size() && g->loss_all[i]) (void)hipFree(g->loss_all[i]);
     }
     if (g->h_tail && !g->failed) (void)hipHostFree(g->h_tail);
@@ -985,11 +1055,24 @@ int group_ensure_lane1(cmf_group_s *g, const void *id128)
 
 static int group_finish_norm(cmf_group_s *g)
 {
-    std::vector<double> vals(g->sh.size()), all;
-    for (size_t i = 0; i < g->sh.size(); ++i) vals[i] = g->sh[i]->data_sumsq;
-    CMFTRY(group_gather_doubles(g, vals, all));
+    // ... and, in the same exchange, whether EVERY shard can run the H phase on the L-1 columns in front of its own (the halo of H then
+    // travels in the W-phase all-reduce: cmf_group_s::halo_opt): K a multiple of 32, 1 <= L-1 <= 64, at least 2(L-1) own columns, and the
+    // L-1 columns of data in front resident (cmf_create_multi uploads them; one process per shard: cmf_shard_set_left_data)
+    std::vector<double> vals(2 * g->sh.size()), all;
+    for (size_t i = 0; i < g->sh.size(); ++i) {
+        const cmf_handle_s *s = g->sh[i];
+        const int hx = s->d.L - 1;
+        const bool shape_ok = s->d.K % 32 == 0 && hx >= 1 && hx <= 64 && s->d.Tl >= 2 * hx;
+        vals[2 * i] = s->data_sumsq;
+        vals[2 * i + 1] = (shape_ok && (s->t_offset == 0 || (s->halo_ext == hx && s->left_data))) ? 1.0 : 0.0;
+    }
+    CMFTRY(group_gather_doubles(g, vals, all, 2));
     g->data_sumsq = 0.0;
-    for (double v : all) g->data_sumsq += v; // rank order: identical on every rank
+    g->halo_can = g->nranks > 1;
+    for (int r = 0; r < g->nranks; ++r) {
+        g->data_sumsq += all[(size_t)2 * r]; // rank order: identical on every rank
+        if (all[(size_t)2 * r + 1] != 1.0) g->halo_can = false;
+    }
     g->data_norm = std::sqrt(g->data_sumsq);  // mult.jl:13 over all shards
     for (cmf_handle_s *s : g->sh) s->data_norm = g->data_norm;
     return CMF_OK;
@@ -1057,6 +1140,10 @@ int cmf_create_multi(cmf_handle *out, int ndev, const int *devices, int transpor
         cmf_handle_s *s = nullptr;
         // column-major N x T: the block [t0, t1 + halo_r) is contiguous
         int rc = create_impl(&s, devices[r], N, t1[r] - t0[r], K, L, data + (size_t)t0[r] * N, t0[r], T, ndev > 1);
+        if (rc == CMF_OK && s->halo_ext) { // the L-1 columns of data in front of the shard (data' only: the operand of its transconv's front block)
+            rc = upload_cols(s, data + (size_t)(t0[r] - s->halo_ext) * N, -s->halo_ext, s->halo_ext, false, false);
+            s->left_data = rc == CMF_OK;
+        }
         if (rc != CMF_OK) return bail(rc);
         g->sh.push_back(s);
         g->rank.push_back(r);
@@ -1153,6 +1240,8 @@ static int comm_attach(cmf_handle_s *h, int nranks, int rank, int transport, con
     h->group = g;
     if (h->factors_set) { // factors were set before the communicator existed: the neighbours' halos are still missing
         g->halos_current = false;
+        g->halos_pending = false;
+        g->halo_wide = false;
         set_est(h, 0);
     }
     return CMF_OK;

@@ -162,8 +162,12 @@ struct cmf_handle_s {
     int hxt_LP = 1, hxt_groups = 1, hxt_nchunks = 1, hxt_chunk_len = 2;
     int tc_LT = 4, tc_S = 1, tc_W = 4;   // fragment slabs and participating waves of the two-source transconv
     int tc_S1 = 1, tc_W1 = 4;            // ... when only one source is contracted
-    std::vector<int4> tc_tab_host[2];    // per-wave work tables of the two variants ([0]: two sources, [1]: one)
-    int4 *tc_tab[2] = {nullptr, nullptr};
+    int tc_S2 = 1, tc_W2 = 4;            // ... two sources with one more 128-column block in FRONT of the own columns (shards that carry the halo of H in
+                                         // the W-phase all-reduce update the L-1 columns in front of their own themselves: cmf_groups.hip)
+    int halo_ext = 0;                    // that form is possible on this handle: L-1 (a shard with a left neighbour, the one-wave conv tiles, L-1 <= 64), else 0
+    bool left_data = false;              // the L-1 columns of data in front of the own block are resident (data' only: the transconv's operand)
+    std::vector<int4> tc_tab_host[3];    // per-wave work tables of the variants ([0]: two sources, [1]: one, [2]: two sources + the block in front)
+    int4 *tc_tab[3] = {nullptr, nullptr, nullptr};
     int hxt_nchunks1 = 1, hxt_chunk_len1 = 6; // time chunks when only one source is contracted
     int hxt_main = 0, hxt_main1 = 0;          // rows the C2 kernel contracts in the two forms; the < 6*LP rows behind them are added by the slab sum
     // few components (K <= 16): the contractions on the flattened (lag, component) index (cmf_small_k.h)
@@ -379,6 +383,18 @@ struct cmf_group_s {
     bool overlap = false;                // option "allreduce_overlap": numW contracted + all-reduced under the loss conv
     bool num_ready = false;              // overlap form: the numW half belongs to the current H and is reduced (or in flight)
     bool halos_current = false;
+    // The halo of H in the tail of the W-phase all-reduce (option "halo_in_allreduce", default on where every shard can: K a multiple of
+    // 32, 1 <= L-1 <= 64, the L-1 columns of data in front of every shard resident; the default formulation): no collective between the
+    // H update and the loss conv -- ONE collective per iteration.  Every shard with a left neighbour updates the L-1 columns in front
+    // of its own itself (h_update_impl, front = true), from an H that is valid 2(L-1) columns out on the left; its own outer columns
+    // (last 2(L-1), first L-1) travel in per-rank slots behind the loss tail of the NEXT all-reduce.
+    bool halo_opt = true, halo_can = false;
+    bool halos_pending = false;          // the H phase has run in that form: the L-1 columns in front are locally valid, everything else of
+                                         // the halos is stale until the next all-reduce has brought the slots (halos_current is false meanwhile)
+    bool halo_wide = false;              // the left halo is valid 2(L-1) columns out (set by the wide exchanges only)
+    int64_t halo_len = 0;                // floats of the slots: nranks * 3 * HC
+    std::vector<float *> halo3_send, halo3_all; // the same exchange as an all-gather (set-up, and whenever no all-reduce follows an H phase)
+    int64_t n_allreduce = 0, n_allgather = 0;   // collectives built into step lists (cmf_get_counter "allreduce_calls" / "allgather_calls")
     // loopback with one stream PER SHARD (CMF_COMM_LOOPBACK_STREAMS): the collectives keep RCCL's stream semantics -- the
     // operation starts when every shard's stream has reached it and every shard's stream continues when it is done --
     // through events, so a missing dependency between shards cannot hide behind a shared stream (tests on a one-GPU box)
@@ -436,7 +452,7 @@ int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64_t K, i
                        const double *data, int64_t t_offset, int64_t T_global, bool sharded);
 int launch_hxt_on(cmf_handle_s *h, const float *X0, const float *X1, int NpX, int nsrc, float *slabs, int nchunks, int chunk_len,
                          int main_rows = -1);
-int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullptr);
+int launch_transconv(cmf_handle_s *h, int nsrc, const float *xt0 = nullptr, bool front_block = false);
 int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nslabs, size_t stride, bool take_carry = false,
                            CmfHxtTail tail = CmfHxtTail{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0});
 int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int nsrc, float *out, bool take_carry = false, bool slabs_only = false);
@@ -447,7 +463,7 @@ int w_partial_impl(cmf_handle_s *h);
 int w_partial_half_impl(cmf_handle_s *h, int den);
 int w_apply_impl(cmf_handle_s *h, double l1W, double l2W, const float *tail_src = nullptr, float *tail_dst = nullptr, int tail_n = 0,
                         const float *den = nullptr);
-int h_update_impl(cmf_handle_s *h, double l1H, double l2H);
+int h_update_impl(cmf_handle_s *h, double l1H, double l2H, bool front = false);
 int launch_loss_conv(cmf_handle_s *h);
 int loss_partial_impl(cmf_handle_s *h, double *sumsq, bool readback = true, double *host_out = nullptr, bool speculate = false);
 int set_factors_impl(cmf_handle_s *h, const double *W, const double *H);
@@ -619,7 +635,7 @@ template <int MODE>
 static int launch_conv_rows(cmf_handle_s *h, float *out, int row0, int nrows, int pidx0, int n_cu, const int *gate, int *abort_word,
                             int *host_status, int *npartials)
 {
-    ProfScope prof_(h, PROF_CONV_RESID);
+    ProfScope prof_(h, MODE == 1 ? PROF_CONV_T : MODE == 3 ? PROF_CONV_LOSS_STORE : PROF_CONV_RESID);
     const CmfDims &d = h->d;
     ConvParams p;
     p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = h->X; p.partial = h->partial; p.mask = h->M;

@@ -1218,6 +1218,9 @@ struct TcParams {
     int TP, PADL, K32, KB, L, Tl;
     int nsrc;         // 1: only XT0 (stand-alone transconv), 2: both
     int C;            // chunks (8 rows of n) per pair = roundup(N, 8) / 8: XT rows beyond are all zero
+    int t_first;      // first column of pair block 0: 0, or -128 on a shard that also updates the L-1 columns in front of its own (the halo
+                      // then travels in the W-phase all-reduce: cmf_groups.hip); slab row r holds column t_first + r
+    int slab_rows;    // rows per slab (Tl - t_first)
     int W;            // waves that share the work (grid = ceil(W/4) workgroups)
     int F;            // fragment slabs
     const int4 *wtab; // [W] per wave: {first pair, first chunk in it, number of chunk units, fragment index of the first segment}
@@ -1304,7 +1307,7 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
         const int c1 = (left < p.C - c0) ? c0 + left : p.C;
         const int src = pr % p.nsrc;
         const int kb = (pr / p.nsrc) % p.KB;
-        const int t0 = (pr / (p.nsrc * p.KB)) * 128;
+        const int t0 = p.t_first + (pr / (p.nsrc * p.KB)) * 128;
         const float *XT = src ? p.XT1 : p.XT0;
         const int nlo = 8 * c0;
         const int nchunks = c1 - c0;
@@ -1357,8 +1360,8 @@ __global__ __launch_bounds__(256, 2) void transconv_kernel(TcParams p)
             }
         }
         // fragment index = position of this wave among the waves sharing the pair (0 for a pair it starts)
-        const size_t slabstride = (size_t)p.nsrc * p.Tl * K32;
-        float *slab = p.slabs + ((size_t)frag * p.nsrc + src) * p.Tl * K32;
+        const size_t slabstride = (size_t)p.nsrc * p.slab_rows * K32;
+        float *slab = p.slabs + (((size_t)frag * p.nsrc + src) * p.slab_rows - p.t_first) * K32; // (row t - t_first)
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
@@ -3390,6 +3393,40 @@ static __global__ void halo_unpack2_kernel(float *H, float *Ht, const float *lef
         if (!src) continue;
         const int k = j % K32, r = (w ? r_right : r_left) + j / K32;
         const float v = src[j];
+        H[(size_t)r * K32 + k] = v;
+        Ht[(size_t)k * TP + r] = v;
+    }
+}
+
+// The halo of H in the tail of the W-phase all-reduce (cmf_groups.hip, "halo in the all-reduce"): every rank writes, into its OWN
+// slot of `slots` ([nranks][3 * rows * K32]), its last 2*rows columns of H followed by its first `rows` columns, and zeros into every
+// other rank's slot -- the sum over the ranks is then every rank's columns, exactly (x + 0 + ...).
+static __global__ void halo_pack3_kernel(const float *H, float *slots, int r_own0, int Tl, int rows, int K32, int rank, int nranks)
+{
+    const int per = 3 * rows * K32;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nranks * per; idx += gridDim.x * blockDim.x) {
+        const int r = idx / per, j = idx - r * per;
+        float v = 0.f;
+        if (r == rank) {
+            const int c = j / K32, k = j - c * K32; // columns 0 .. 2 rows - 1: the last 2 rows own columns; then the first `rows`
+            const int t = c < 2 * rows ? Tl - 2 * rows + c : c - 2 * rows;
+            v = (t >= 0 && t < Tl) ? H[(size_t)(r_own0 + t) * K32 + k] : 0.f;
+        }
+        slots[idx] = v;
+    }
+}
+// ... and back: H[-2 rows, 0) from the left neighbour's last columns, H[Tl, Tl + rows) from the right neighbour's first ones (a rank
+// without that neighbour -- the global edge -- keeps its zeros); H and its transposed copy.
+static __global__ void halo_unpack3_kernel(float *H, float *Ht, const float *slots, int r_own0, int Tl, int rows, int K32, int TP, int rank, int nranks)
+{
+    const int per = 3 * rows * K32;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += gridDim.x * blockDim.x) {
+        const int c = idx / K32, k = idx - c * K32;
+        int src_rank, r;
+        if (c < 2 * rows) { src_rank = rank - 1; r = r_own0 - 2 * rows + c; }
+        else { src_rank = rank + 1; r = r_own0 + Tl + (c - 2 * rows); }
+        if (src_rank < 0 || src_rank >= nranks) continue;
+        const float v = slots[(size_t)src_rank * per + idx];
         H[(size_t)r * K32 + k] = v;
         Ht[(size_t)k * TP + r] = v;
     }

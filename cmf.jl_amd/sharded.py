@@ -83,7 +83,16 @@ class ShardedMultUpdate(MultUpdate):
         self._lib = lib = _lib.load()
         self._h = ctypes.c_void_p()
         data_local = farr(data[:, t0:t1 + halo_r])
-        check(lib.cmf_create_shard(ctypes.byref(self._h), self.device, N, t1 - t0, K, L, ptr(data_local), t0, T))
+        # the L-1 columns of data in front of the shard: with them resident on every rank the group carries the halo of H in its W-phase
+        # all-reduce (one collective per iteration) instead of in an all-gather of its own (cmf_shard_set_left_data)
+        data_left = farr(data[:, t0 - (L - 1):t0]) if (t0 >= L - 1 > 0) else None
+
+        def make_shard():
+            check(lib.cmf_create_shard(ctypes.byref(self._h), self.device, N, t1 - t0, K, L, ptr(data_local), t0, T))
+            if data_left is not None:
+                check(lib.cmf_shard_set_left_data(self._h, ptr(data_left)))
+
+        make_shard()
         self.transport_fallback = None
         try:
             if self.transport == "rccl":
@@ -97,7 +106,7 @@ class ShardedMultUpdate(MultUpdate):
                     self.transport_fallback = bad[0]
                     lib.cmf_destroy(self._h)
                     self._h = ctypes.c_void_p()
-                    check(lib.cmf_create_shard(ctypes.byref(self._h), self.device, N, t1 - t0, K, L, ptr(data_local), t0, T))
+                    make_shard()
                     self.transport = "host"
                     self._attach()
             else:

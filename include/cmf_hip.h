@@ -58,7 +58,7 @@ typedef struct cmf_handle_s *cmf_handle;
  * cmf_h_update, cmf_loss_partial*, cmf_halo_*, cmf_numden_ptr, cmf_set_data_norm) are gone -- a sharded iteration
  * runs behind the rule entries of a group handle (cmf_create_multi / cmf_comm_init_*); cmf_abi_version,
  * cmf_source_digest, cmf_synchronize, cmf_rccl_version, cmf_get_counter are new.  5 (round 5): cmf_arm_writeback.  6 (round 6):
- * cmf_fingerprint, cmf_option_names; cmf_set_factors takes one NULL factor; the measurement variables of the environment are gone
+ * cmf_fingerprint, cmf_option_names, cmf_shard_set_left_data; cmf_set_factors takes one NULL factor; the measurement variables of the environment are gone
  * (CMF_HALS_*, CMF_CONV_*, CMF_SK_*, CMF_GRAM_FW, CMF_PGD_TRANSPOSE, CMF_LOSS_POLL, CMF_SPECULATE_W, CMF_SMALL_K, CMF_HXT_EXACT,
  * CMF_LOOPBACK_*): what tests still select is an option. */
 #define CMF_ABI_VERSION 6
@@ -96,12 +96,24 @@ int cmf_create(cmf_handle *h, int device, int64_t N, int64_t T, int64_t K, int64
  * cmf_comm_init_callbacks (below), which also all-reduces data_norm. */
 int cmf_create_shard(cmf_handle *h, int device, int64_t N, int64_t T_local, int64_t K, int64_t L,
                      const double *data_local, int64_t t_offset, int64_t T_global);
+/* The L-1 columns of data in FRONT of a shard (N x (L-1), columns [t_offset - (L-1), t_offset); the shard with t_offset = 0 has none and
+ * need not call this).  With them resident on every shard -- call it between cmf_create_shard and cmf_comm_init_* -- the group carries
+ * the halo of H in the tail of its W-phase all-reduce (ONE collective per iteration; see the group section below) instead of in an
+ * all-gather of its own behind every H update.  cmf_create_multi does this itself.  No reference counterpart. */
+int cmf_shard_set_left_data(cmf_handle h, const double *cols);
 
 /* ---- T-sharded groups: the same rule on several GPUs of one node -----------------
  * The T axis of data / est / H is cut into contiguous column blocks (shard r owns columns
- * [r*ceil(T/R), min(T, (r+1)*ceil(T/R)))), W is replicated.  Per MU iteration the shards meet twice: ONE RCCL
- * all-reduce of the [numW | denomW] partial sums (2*L*Kpad*Npad floats + a tail that carries every shard's loss
- * partial of the previous iteration) and one all-gather of the (L-1)-column H halos (2 x 2.4 KB per shard).
+ * [r*ceil(T/R), min(T, (r+1)*ceil(T/R)))), W is replicated.  Per MU iteration the shards meet ONCE: one RCCL
+ * all-reduce of the [numW | denomW] partial sums (2*L*Kpad*Npad floats) + a tail that carries every shard's loss
+ * partial of the previous iteration and -- since round 6 -- every shard's outer columns of the new H (its last 2(L-1) and
+ * first L-1: 7.3 KB per rank at config 2), so that no exchange stands between the H update and the loss conv: every shard
+ * with a left neighbour updates the L-1 columns in front of its own itself (0.6 - 2 % redundant work on a T/8 shard).
+ * That form (option "halo_in_allreduce", default on) needs K a multiple of 32, 1 <= L-1 <= 64, shards of at least 2(L-1)
+ * columns and the default formulation; otherwise, and for the Gram form and the PGD rule, the (L-1)-column halos travel in
+ * an all-gather of their own behind every H update (2 x 2.4 KB per shard), as they did until round 5.
+ * cmf_get_counter "allreduce_calls" / "allgather_calls" count the collectives a handle has issued, "halo_in_allreduce" says
+ * which form is in force.
  * On a group handle cmf_set_factors / cmf_get_factors / cmf_update_motifs / cmf_update_feature_maps /
  * cmf_compute_loss / cmf_iterate / cmf_fit run the whole sharded iteration including the collectives, so the
  * reference's `fit` loop (src/algs/alternating.jl:44-67: one update_motifs! and one update_feature_maps! per
@@ -239,6 +251,8 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *   "profile_mask" (bits): the kernel classes "profile" times -- bit i = the i-th name of cmf_kernel_times ("conv", "conv_t",
  *       "conv_loss", "conv_loss_store", "hxt", "transconv", ...); 0 (default) = all.  (An event pair idles the device a few
  *       microseconds: bench.py times only the dominant kernel inside its timed steps.)
+ *   "halo_in_allreduce" (group handles, default 1): 0 = the halo of H in an all-gather of its own behind every H update (the form of
+ *       rounds 1-5) even where the all-reduce could carry it (see the group section above).
  *   "allreduce_overlap" (group handles, default 0): 1 = numW (which needs H only) is contracted and all-reduced on a
  *       second stream right after the H update, underneath the loss conv and the denominator contraction, so only
  *       the denomW half of the all-reduce stays exposed; costs a second C2 launch per iteration. */
