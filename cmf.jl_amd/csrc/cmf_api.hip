@@ -616,11 +616,12 @@ static int w_apply_impl_(cmf_handle_s *h, double l1W, double l2W, const float *t
 int h_update_impl(cmf_handle_s *h, double l1H, double l2H, bool front)
 {
     const CmfDims &d = h->d;
-    CMFTRY(launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext)); // mult.jl:44 (est with the new W)
     if (front) {
         if (!h->halo_ext || !h->left_data) return fail(CMF_ERR_STATE, "internal: this shard cannot update the columns in front of its own");
+        // mult.jl:44 on columns [-64, Tl + halo_r): ONE launch of the one-wave tiles from tile row -1 on (a launch of its own for the
+        // row in front cost 10 us per shard and iteration: profiles/r06_halo_in_allreduce_cost.txt)
         int np = 0;
-        CMFTRY(launch_conv_rows<1>(h, h->estT, -1, 1, 0, h->n_cu, nullptr, nullptr, nullptr, &np));
+        CMFTRY(launch_conv_rows<1>(h, h->estT, -1, 1 + (d.Tl + h->halo_r + 63) / 64, 0, h->n_cu, nullptr, nullptr, nullptr, &np, d.Tl + h->halo_r));
         CMFTRY(launch_transconv(h, 2, nullptr, true));                    // mult.jl:47-48 on columns [-128, Tl)
         const int hx = h->halo_ext, R = d.Tl + 128;
         dim3 gridx((d.Tl + hx + HUPD_T - 1) / HUPD_T, d.KB);
@@ -631,6 +632,7 @@ int h_update_impl(cmf_handle_s *h, double l1H, double l2H, bool front)
         set_est(h, 0);
         return wb_after_H(h);
     }
+    CMFTRY(launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext)); // mult.jl:44 (est with the new W)
     CMFTRY(launch_transconv(h, 2));                                         // mult.jl:47-48
     dim3 grid((d.Tl + HUPD_T - 1) / HUPD_T, d.KB);
     const size_t TK = (size_t)d.Tl * d.K32;

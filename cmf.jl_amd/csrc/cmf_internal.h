@@ -633,15 +633,16 @@ static int launch_conv(cmf_handle_s *h, float *out, int T_store, int gy, const f
 // HALS row pipeline's last progress flag) and reads H with agent-scope loads.  Loss partials pidx0 ... pidx0 + *npartials - 1.
 template <int MODE>
 static int launch_conv_rows(cmf_handle_s *h, float *out, int row0, int nrows, int pidx0, int n_cu, const int *gate, int *abort_word,
-                            int *host_status, int *npartials)
+                            int *host_status, int *npartials, int T_store = -1)
 {
     ProfScope prof_(h, MODE == 1 ? PROF_CONV_T : MODE == 3 ? PROF_CONV_LOSS_STORE : PROF_CONV_RESID);
     const CmfDims &d = h->d;
     ConvParams p;
     p.Ht = h->Ht; p.Wt = h->Wt; p.out = out; p.data = h->X; p.partial = h->partial; p.mask = h->M;
-    p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = d.Tl;
+    p.Np = d.Np; p.TP = d.TP; p.PADL = d.PADL; p.K = d.K; p.KB = d.KB; p.L = d.L; p.T_store = T_store >= 0 ? T_store : d.Tl;
     p.N = d.N;
     p.loss_abs = 0;
+    if (MODE == 5 || MODE == 7) p.data = h->XT;
     const int gx3 = d.Np / 64, tiles3 = gx3 * nrows, slots3 = 12 * n_cu;
     const int rem3 = tiles3 % slots3;
     int cut = 0;
@@ -653,8 +654,10 @@ static int launch_conv_rows(cmf_handle_s *h, float *out, int row0, int nrows, in
     const int n_full = tiles3 - cut;
     const int pieces = (cut > 0 && cut < n_cu && h->conv_split != 4) ? 16 : 4;
     const int grid = n_full + pieces * cut;
-    if ((size_t)(pidx0 + grid) > n_partial(h)) return fail(CMF_ERR_STATE, "internal: loss partial buffer too small for a split conv");
-    hipLaunchKernelGGL((conv3_chase_kernel<MODE>), dim3(grid), dim3(64), 0, h->stream, p, gx3, n_full, pieces, row0, pidx0, gate, abort_word, host_status);
+    constexpr bool LOSS = (MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6); // (the other modes write no per-tile sums)
+    if (LOSS && (size_t)(pidx0 + grid) > n_partial(h)) return fail(CMF_ERR_STATE, "internal: loss partial buffer too small for a split conv");
+    if (gate) hipLaunchKernelGGL((conv3_chase_kernel<MODE, true>), dim3(grid), dim3(64), 0, h->stream, p, gx3, n_full, pieces, row0, pidx0, gate, abort_word, host_status);
+    else hipLaunchKernelGGL((conv3_chase_kernel<MODE, false>), dim3(grid), dim3(64), 0, h->stream, p, gx3, n_full, pieces, row0, pidx0, gate, abort_word, host_status);
     KCHK("conv3_chase_kernel");
     *npartials = grid;
     return CMF_OK;

@@ -958,7 +958,8 @@ __global__ __launch_bounds__(64, 3) void conv3_kernel(ConvParams p, int gx, int 
 // every wait of the pipeline -- until *gate >= r + 1, then reads the strip with agent-scope loads.  A wait that runs out, or a
 // pipeline that has aborted, ends the workgroup without output: the host sees the status word and redoes sweep and conv.
 // gate == NULL: plain offset tiles (the part of the conv that runs behind the pipeline).  pidx0: first loss partial of this launch.
-template <int MODE>
+// SC1: the strips are read with agent-scope loads (the chasing launch); false: plain loads (tile rows at an offset, nothing concurrent).
+template <int MODE, bool SC1>
 __global__ __launch_bounds__(64, 3) void conv3_chase_kernel(ConvParams p, int gx, int n_full, int pieces, int row0, int pidx0,
                                                             const int *gate, int *abort_word, int *host_status)
 {
@@ -984,14 +985,14 @@ __global__ __launch_bounds__(64, 3) void conv3_chase_kernel(ConvParams p, int gx
         }
     }
     if (b < n_full) {
-        if (n0 + 32 < p.N) conv3_tile<MODE, 2, 16, false, true>(p, Hs, row * 64, n0, threadIdx.x, pidx0 + b);
-        else conv3_tile<MODE, 1, 16, false, true>(p, Hs, row * 64, n0, threadIdx.x, pidx0 + b);
+        if (n0 + 32 < p.N) conv3_tile<MODE, 2, 16, false, SC1>(p, Hs, row * 64, n0, threadIdx.x, pidx0 + b);
+        else conv3_tile<MODE, 1, 16, false, SC1>(p, Hs, row * 64, n0, threadIdx.x, pidx0 + b);
     } else if (pieces == 4) {
         const int sub = (b - n_full) & 3;
-        conv3_quarter<MODE, 16, true>(p, Hs, row * 64 + (sub >> 1) * 32, n0 + (sub & 1) * 32, threadIdx.x, pidx0 + b);
+        conv3_quarter<MODE, 16, SC1>(p, Hs, row * 64 + (sub >> 1) * 32, n0 + (sub & 1) * 32, threadIdx.x, pidx0 + b);
     } else {
         const int sub = (b - n_full) & 15;
-        conv3_sixteenth<MODE, true>(p, Hs, row * 64 + (sub >> 2) * 16, n0 + (sub & 3) * 16, threadIdx.x, pidx0 + b);
+        conv3_sixteenth<MODE, SC1>(p, Hs, row * 64 + (sub >> 2) * 16, n0 + (sub & 3) * 16, threadIdx.x, pidx0 + b);
     }
 }
 

@@ -62,7 +62,8 @@ def main():
         from shard_engine_cpu import OracleShardEngine
         from shard_protocol_cpu import ProtocolShardedMultUpdate
 
-        rule = ProtocolShardedMultUpdate(data, W0, H0, OracleShardEngine, overlap=overlap)
+        rule = ProtocolShardedMultUpdate(data, W0, H0, OracleShardEngine, overlap=overlap,
+                                         halo_in_allreduce=os.environ.get("CMF_TEST_HALO_IN_AR", "1") == "1")
     elif engine.startswith("hip_pgd"):
         import cmf_jl_amd as cmf
         from cmf_jl_amd.sharded import ShardedPGDUpdate
@@ -97,6 +98,7 @@ def main():
         want = float(np.linalg.norm(data))
         assert abs(rule.data_norm - want) <= 1e-9 * want, f"rank {rank}: data_norm {rule.data_norm} != {want}"
     losses = [rule.compute_loss()]
+    coll0 = dict(getattr(rule, "collectives", {}))  # (the CPU mirror counts the collectives it issues)
     if mode == "iterate":
         losses += list(rule.iterate(iters, **kw))
     elif mode == "fit_timed" and engine == "hip":
@@ -117,10 +119,13 @@ def main():
         for _ in range(iters):
             rule.update_motifs(l1W=kw["l1W"], l2W=kw["l2W"])
             losses.append(rule.update_feature_maps(l1H=kw["l1H"], l2H=kw["l2H"]))
+    coll1 = dict(getattr(rule, "collectives", {}))
     W, H = rule.download()
     rule.close()
     if rank == 0:
-        np.savez(out, W=W, H=H, loss_hist=np.asarray(losses), bounds=np.asarray(rule.bounds), info=np.asarray(info))
+        np.savez(out, W=W, H=H, loss_hist=np.asarray(losses), bounds=np.asarray(rule.bounds), info=np.asarray(info),
+                 all_reduces=np.asarray(coll1.get("all_reduce", 0) - coll0.get("all_reduce", 0)),
+                 all_gathers=np.asarray(coll1.get("all_gather", 0) - coll0.get("all_gather", 0)))
     dist.barrier()
     dist.destroy_process_group()
 

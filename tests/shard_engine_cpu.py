@@ -12,7 +12,7 @@ EPS = float(np.finfo(np.float64).eps)
 
 
 class OracleShardEngine:
-    def __init__(self, data_local, W, H_local, t_offset, T_global, device):
+    def __init__(self, data_local, W, H_local, t_offset, T_global, device, data_left=None):
         K, N, L = W.shape
         self.K, self.N, self.L = K, N, L
         self.Tl = H_local.shape[1]
@@ -23,6 +23,11 @@ class OracleShardEngine:
         self.W = np.array(W, dtype=np.float64)
         self.Hl = np.zeros((K, max(L - 1, 0)))                           # left halo (zeros at the global edge)
         self.Hr = np.zeros((K, max(L - 1, 0)))                           # right halo
+        # "halo in the all-reduce" (cmf_groups.hip, round 6): the shard also updates the L-1 columns in front of its own, from an H
+        # that is valid 2(L-1) columns out on the left (Hl2 = columns [-2(L-1), -(L-1))) and the L-1 columns of data in front
+        self.Hl2 = np.zeros((K, max(L - 1, 0)))
+        self.data_left = None if data_left is None else np.array(data_left, dtype=np.float64)
+        self.slot_count = max(3 * (L - 1) * K, 1)
         self.H = np.array(H_local, dtype=np.float64)
         self.numden = torch.zeros(2 * K * N * L, dtype=torch.float64)
         self.halo_count = max((L - 1) * K, 1)
@@ -105,6 +110,54 @@ class OracleShardEngine:
             den[:, :w] += self.W[:, :, l] @ est_ext[:, l: l + w]
         self.H *= num / (((den + l1H) + (2.0 * l2H) * self.H) + EPS)
         np.maximum(self.H, EPS, out=self.H)
+
+    def h_update_front(self, l1H, l2H):
+        """h_update_impl(..., front = true): mult.jl:44-52 on columns [-(L-1), Tl) of the shard."""
+        K, N, L = self.W.shape
+        h = L - 1
+        Hext = np.concatenate([self.Hl2, self.Hl, self.H, self.Hr], axis=1)   # column j <-> local t = j - 2h
+        ncols = h + self.Tl + self.halo_r                                     # est on t in [-h, Tl + halo_r)
+        est = np.zeros((N, ncols))
+        for l in range(L):
+            est += self.W[:, :, l].T @ Hext[:, h - l: h - l + ncols]            # H[t - l], t = -h + i  ->  j = h - l + i
+        X = np.concatenate([self.data_left, self.data_ext], axis=1)            # column i <-> t = -h + i
+        nupd = h + self.Tl
+        num = np.zeros((K, nupd))
+        den = np.zeros((K, nupd))
+        for l in range(L):
+            w = min(nupd, ncols - l)                                           # t + l must exist (own or right halo)
+            if w <= 0:
+                continue
+            num[:, :w] += self.W[:, :, l] @ X[:, l: l + w]
+            den[:, :w] += self.W[:, :, l] @ est[:, l: l + w]
+        Hc = np.concatenate([self.Hl, self.H], axis=1)
+        Hc *= num / (((den + l1H) + (2.0 * l2H) * Hc) + EPS)
+        np.maximum(Hc, EPS, out=Hc)
+        self.Hl[...] = Hc[:, :h]
+        self.H[...] = Hc[:, h:]
+
+    def halo_pack3(self):
+        """halo_pack3_kernel: [last 2(L-1) | first L-1] own columns of H (zeros where the shard is shorter)."""
+        L, K = self.L, self.K
+        h = L - 1
+        out = np.zeros((3 * h, K))
+        for c in range(3 * h):
+            t = self.Tl - 2 * h + c if c < 2 * h else c - 2 * h
+            if 0 <= t < self.Tl:
+                out[c] = self.H[:, t]
+        return torch.from_numpy(out.ravel().copy())
+
+    def halo_unpack3(self, left_slot, right_slot):
+        """halo_unpack3_kernel: H[-2(L-1), 0) from the left neighbour's last columns, H[Tl, Tl + L-1) from the right neighbour's first."""
+        L, K = self.L, self.K
+        h = L - 1
+        if left_slot is not None:
+            a = left_slot.numpy().reshape(3 * h, K)
+            self.Hl2[...] = a[:h].T
+            self.Hl[...] = a[h:2 * h].T
+        if right_slot is not None:
+            a = right_slot.numpy().reshape(3 * h, K)
+            self.Hr[...] = a[2 * h:].T
 
     def attach_gathered_halos(self, gathered, rank, world):
         c = self.halo_count

@@ -82,7 +82,7 @@ class ProtocolShardedGram(ProtocolShardedMultUpdate):
     """group_update_motifs / group_update_feature_maps with option gram = 1: the all-reduce carries [numW | HH | tail]."""
 
     def __init__(self, data, W, H, group=None):
-        super().__init__(data, W, H, GramShardEngine, group=group)
+        super().__init__(data, W, H, GramShardEngine, group=group, halo_in_allreduce=False)  # (the Gram form keeps the halo all-gather)
         K, N, L = self.K, self.N, self.L
         self.LKN, self.HHsz = K * N * L, (L * K) ** 2
         self.gred = torch.zeros(self.LKN + self.HHsz + self.tail, dtype=torch.float64)
@@ -122,7 +122,7 @@ class ProtocolShardedPGD(ProtocolShardedMultUpdate):
     step-size state machine is replicated.  loss: "square" | "abs"; mask: the GLOBAL mask or None."""
 
     def __init__(self, data, W, H, mask=None, loss="square", group=None):
-        super().__init__(data, W, H, OracleShardEngine, group=group)
+        super().__init__(data, W, H, OracleShardEngine, group=group, halo_in_allreduce=False)  # (the PGD rule keeps the halo all-gather)
         self.loss_kind = loss
         e = self.engine
         self.mask_ext = None if mask is None else np.asarray(mask, dtype=np.float64)[:, self.t0:self.t1 + e.halo_r]

@@ -29,7 +29,7 @@ def _free_port():
 
 
 def run_ranks(world, engine, out, N, T, K, L, iters, reg, timeout=300, backend="gloo", overlap=False, mode="calls", transport="",
-              fallback=False, rank_env=None, distinct_devices=False):
+              fallback=False, rank_env=None, distinct_devices=False, halo_in_ar=True):
     """rank_env: {rank: {VAR: value}} extra environment of single ranks; distinct_devices: rank r works on GPU r
     (LOCAL_RANK=r) instead of all ranks sharing GPU 0."""
     port = _free_port()
@@ -38,7 +38,7 @@ def run_ranks(world, engine, out, N, T, K, L, iters, reg, timeout=300, backend="
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r) if distinct_devices else "0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", CMF_TEST_BACKEND=backend,
                    CMF_TEST_OVERLAP="1" if overlap else "0", CMF_TEST_MODE=mode, CMF_TEST_TRANSPORT=transport,
-                   CMF_TEST_FALLBACK="1" if fallback else "0")
+                   CMF_TEST_FALLBACK="1" if fallback else "0", CMF_TEST_HALO_IN_AR="1" if halo_in_ar else "0")
         env.update((rank_env or {}).get(r, {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), engine, out,
                                        str(N), str(T), str(K), str(L), str(iters), str(int(reg))],
@@ -95,16 +95,23 @@ def test_loss_scalar_own_slot_encoding():
         assert np.float32(hi) == hi and np.float32(lo) == lo  # both are representable floats
 
 
-@pytest.mark.parametrize("world,reg,overlap,mode", [(2, 0, False, "calls"), (3, 1, False, "calls"), (2, 1, True, "calls"),
-                                                      (3, 0, False, "iterate"), (2, 1, True, "iterate")])
-def test_sharded_protocol_cpu_gloo(oracle, tmp_path, world, reg, overlap, mode):
+@pytest.mark.parametrize("world,reg,overlap,mode,halo_in_ar", [(2, 0, False, "calls", True), (3, 1, False, "calls", True), (2, 1, True, "calls", True),
+                                                                 (3, 0, False, "iterate", True), (2, 1, True, "iterate", True),
+                                                                 (3, 1, False, "iterate", False), (2, 0, False, "calls", False), (4, 1, True, "iterate", True)])
+def test_sharded_protocol_cpu_gloo(oracle, tmp_path, world, reg, overlap, mode, halo_in_ar):
     """overlap=True is the two-step form of the W partial sums (numW started right after the H update); mode
-    "iterate" reads every loss one iteration late from the tail of the next all-reduce (cmf_iterate)."""
+    "iterate" reads every loss one iteration late from the tail of the next all-reduce (cmf_iterate); halo_in_ar: the halo of H in
+    the tail of the W-phase all-reduce (round 6: ONE collective per iteration; every shard with a left neighbour updates the L-1
+    columns in front of its own) or, False, in an all-gather of its own behind every H update (rounds 1-5)."""
     N, T, K, L, iters = 17, 101, 3, 6, 8
     out = str(tmp_path / "res.npz")
-    got = run_ranks(world, "cpu", out, N, T, K, L, iters, reg, overlap=overlap, mode=mode)
+    got = run_ranks(world, "cpu", out, N, T, K, L, iters, reg, overlap=overlap, mode=mode, halo_in_ar=halo_in_ar)
     _, _, _, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, reg)
     assert len(got["bounds"]) == world
+    # the collectives of the `iters` iterations: the bulk all-reduce (two in the overlap form); all-gathers = the halo exchange of the
+    # old form (one per iteration) + the loss read-out (call by call: one per iteration; cmf_iterate: one flush at the end)
+    assert int(got["all_reduces"]) == (2 * iters + 1 if overlap else iters)  # (overlap: numW of the NEXT iteration starts behind every H update)
+    assert int(got["all_gathers"]) == (0 if halo_in_ar else iters) + (iters if mode == "calls" else 1)
     np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-10)
     np.testing.assert_allclose(got["W"], Wr, rtol=1e-8, atol=1e-13)
     np.testing.assert_allclose(got["H"], Hr, rtol=1e-8, atol=1e-13)
