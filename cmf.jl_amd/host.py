@@ -146,7 +146,8 @@ class MultUpdate(AbstractCFUpdate):
 
     ``devices=[d0, d1, ...]`` builds the rule as a T-sharded group on several GPUs of this node, driven by this one
     process (cmf_create_multi): the rule methods keep their meaning and the library runs the sharded iteration --
-    one RCCL all-reduce of [numW | denomW] and one H-halo all-gather per iteration.  Listing
+    ONE RCCL all-reduce of [numW | denomW | loss tail | H halos] per iteration (the Gram form and PGD keep
+    an H-halo all-gather of their own).  Listing
     one device several times puts that many shards on it (loopback transport; tests).
     """
 

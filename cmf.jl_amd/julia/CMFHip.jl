@@ -50,7 +50,8 @@ between calls and are written back into the caller's arrays after every `update_
 
 With `devices` the rule is a T-sharded group on several GPUs of the node (`cmf_create_multi`): this one Julia
 task keeps making the same two calls per iteration (alternating.jl:52,54) and the library runs the sharded
-iteration -- one RCCL all-reduce of [numW | denomW] and one H-halo all-gather per iteration, enqueued by one worker thread
+iteration -- ONE RCCL all-reduce of [numW | denomW | loss tail | H halos] per iteration (round 6; the Gram form and PGD keep an
+H-halo all-gather of their own), enqueued by one worker thread
 per GPU inside the library.  `transport` (include/cmf_hip.h: CMF_COMM_*): 0 = RCCL for distinct devices (default),
 4 = direct peer access over xGMI instead of RCCL (opt-in).  `set_option!(rule, "allreduce_overlap", 1)` etc. forward to
 cmf_set_option.
