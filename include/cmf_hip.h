@@ -333,8 +333,8 @@ int cmf_fit(cmf_handle h, int64_t max_itr, double max_time,
  * skips the motif update like :51) n_iter times, losses[i] = the loss update_feature_maps! returned in iteration i.
  * The host does not stall the device between iterations: the loss of iteration i is read one iteration late from
  * pinned memory (on a group handle it travels in the tail of iteration i+1's all-reduce, so an iteration costs one
-
- * all-reduce -- which also carries the halos of H, see the group section -- and one host wait).  stamps (may be NULL): seconds since entry at which each loss
+ * all-reduce -- which also carries the halos of H, see the group section -- and one host wait).  stamps (may be NULL):
+ * seconds since entry at which each loss
  * became known to the host.  cmf_fit uses this loop when check_convergence is 0 and max_time is infinite. */
 int cmf_iterate(cmf_handle h, int64_t n_iter, int eval_mode, double l1W, double l2W, double l1H, double l2H,
                 double *losses, double *stamps);
