@@ -921,7 +921,23 @@ def measure(args, form, progress):
     progress["phase"] = "timed steps"
     prof.set_option("profile_mask", (1 << PROF_CLASSES.index(dom_class)) if one_class else 0)
     prof.set_option("profile", 4 if alg == "mult" else 1)  # every 4th launch of each class (HALS: every span)
+    coll0 = None
+    if sharded:
+        try:  # the collectives this rank's handle issues over the timed steps (cmf_get_counter): the north star asks for ONE per iteration
+            coll0 = (rule.counter("allreduce_calls"), rule.counter("allgather_calls"))
+        except Exception:  # noqa: BLE001
+            coll0 = None
     dt, losses = timed(0, args.steps)
+    coll_per_step = None
+    if coll0 is not None:
+        try:
+            coll_per_step = {"allreduce": (rule.counter("allreduce_calls") - coll0[0]) / max(1, args.steps),
+                             "allgather": (rule.counter("allgather_calls") - coll0[1]) / max(1, args.steps),
+                             "halo_in_allreduce": rule.counter("halo_in_allreduce"),
+                             "note": "per iteration over the timed steps; the all-gathers are the flush of the batch's last loss (one per "
+                                     "cmf_iterate call) and, in the all-gather form of the halo exchange (halo_in_allreduce = 0), one per iteration"}
+        except Exception as e:  # noqa: BLE001
+            coll_per_step = {"error": repr(e)}
     progress.setdefault("partial", {}).update(ms_per_step=1e3 * dt / args.steps, iters_per_s=args.steps / dt, loss_last=float(losses[-1]) if len(losses) else None)
     progress["phase"] = "side measurements after the timed steps"
     names = ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "hxt_num", "hxt_den", "transconv", "hals_h_pipeline", "hals_w_sweep")
@@ -1072,6 +1088,7 @@ def measure(args, form, progress):
                 comm["rccl"] = {"error": repr(e)}
             comm["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
             comm["allreduce"] = allreduce
+            comm["collectives_per_step"] = coll_per_step
             comm["collectives"] = collectives
         else:
             comm = None
