@@ -43,8 +43,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_PROFILE = "r05_pmc_summary.json"  # rocprofv3 --pmc passes of this round's kernels (profiles/README.md)
-PMC_FALLBACK = "r04_pmc_summary.json"
+PMC_PROFILE = "r06_pmc_summary.json"  # rocprofv3 --pmc passes of this round's kernels (profiles/README.md)
+PMC_FALLBACK = "r05_pmc_summary.json"
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 CONFIGS = {
     1: dict(N=500, T=2000, K=5, L=10),
@@ -904,6 +904,8 @@ def measure(args, form, progress):
     prof = rule
     one_class = alg == "mult" and form == "single"
     progress["phase"] = "warm-up steps"
+    if sharded and os.environ.get("CMF_BENCH_HALO_IN_ALLREDUCE") == "0":  # (the all-gather form of the halo exchange: to time both on a node)
+        rule.set_option("halo_in_allreduce", 0)
     # which kernel is the dominant one is MEASURED, not assumed: the warm-up steps run with every class bracketed and the class with the
     # largest mean duration is the one the timed steps bracket (bit i of "profile_mask" = the i-th class name of cmf_kernel_times)
     PROF_CLASSES = ("conv", "conv_t", "conv_loss", "conv_loss_store", "hxt", "transconv", "hxt_num", "hxt_den")

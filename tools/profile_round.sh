@@ -19,6 +19,7 @@ rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_
 echo "sq done"
 python3 tools/pmc_summary.py $out/${tag}_pmc_summary.json $out/${tag}_pmc_fetch $out/${tag}_pmc_write $out/${tag}_pmc_sq > $out/${tag}_pmc_summary.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_hals_stats -o t -- python3 bench.py --config 5 --cpu-seconds 0 --steps 5 --warmup 1 > $out/${tag}_hals_bench_under_rocprof.json 2> $out/${tag}_hals_stats.err
+python3 tools/trace_gaps.py $out/${tag}_hals_stats hals_w_sweep > $out/${tag}_hals_timeline.txt   # (the chasing conv launch starts INSIDE the pipeline's span)
 echo "hals done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_shard8_stats -o t -- $B --T 6250 --steps 40 --warmup 3 > $out/${tag}_shard8_bench_under_rocprof.json 2> $out/${tag}_shard8_stats.err
 python3 tools/trace_gaps.py $out/${tag}_shard8_stats > $out/${tag}_shard8_timeline.txt
