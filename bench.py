@@ -229,7 +229,7 @@ def other_configs(cmf, rule, data, W0, H0, N, T, K, L, with_config3, device):
             hr.set_option("profile", 0)
             res["configs[4]"] = {"workload": "N=2000 T=50000 K=32 L=20 alg=:hals", "steps": 10, "warmup": 2, "ms_per_step": 1e3 * dt,
                                  "ms_per_step_bracketed": 1e3 * dt_prof,
-                                 "chase": "the first 65 % of the residual conv's tile rows chase the H row pipeline on the CUs it leaves free "
+                                 "chase": "the first ~64 % of the residual conv's tile rows chase the H row pipeline on the CUs it leaves free "
                                           "(option hals_chase; conv_resid below averages the chasing launch and the rest)",
                                  "iters_per_s": 1.0 / dt, "loss_last": float(ls[-1]), "metric": "HALS iters/sec",
                                  "pipeline_reruns": hr.counter("hals_pipeline_reruns"),

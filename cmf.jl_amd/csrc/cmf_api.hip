@@ -1293,7 +1293,7 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
     }
     if (std::strcmp(name, "hals_persist") == 0 || std::strcmp(name, "hals_general") == 0 || std::strcmp(name, "hals_seg") == 0 ||
         std::strcmp(name, "hals_lag") == 0 || std::strcmp(name, "hals_debug") == 0 || std::strcmp(name, "hals_chase") == 0) {
-        if (value < 0) return fail(CMF_ERR_ARG, "%s must be >= 0", name);
+        if (value < 0 && !(name[5] == 'c' && value == -1)) return fail(CMF_ERR_ARG, "%s must be >= 0", name);
         if (name[5] == 'd') { // "hals_debug": results are wrong by design -- tests of the bounded waits only
             if (value && !test_hooks_on()) return fail(CMF_ERR_STATE, "hals_debug needs CMF_TEST_HOOKS=1");
             h->hals_debug = value;

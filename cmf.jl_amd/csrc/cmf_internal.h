@@ -208,7 +208,7 @@ struct cmf_handle_s {
     // The residual conv CHASING the row pipeline (option "hals_chase" = per cent of its tile rows, 0 = off): the pipeline runs on a
     // stream masked to the CUs its K + (K-1)P workgroups need, the first tile rows of the conv on a stream masked to the other CUs,
     // each tile waiting for the last row's progress flag (conv3_chase_kernel); the rest of the conv follows on the whole chip.
-    int hals_opt_chase = 65;
+    int hals_opt_chase = -1;             // (-1: the share is estimated from the shape, hals_chase_rows)
     hipStream_t hals_sA = nullptr, hals_sB = nullptr; // CU-masked: pipeline | chasing conv (created at the first chased sweep)
     hipEvent_t hals_ev[3] = {nullptr, nullptr, nullptr}; // fork, pipeline done, chasing part done
     int hals_mask_aper = 0;                 // CUs per XCD the pipeline's stream is masked to (the streams are remade when the plan changes)

@@ -100,7 +100,7 @@ void hals_plan(cmf_handle_s *h)
         // With the residual conv chasing the pipeline (hals_chase_rows) a CU is worth more on the conv's side: three pullers per row
         // instead of four cost the pipeline 1 % (1.44 -> 1.455 ms at config 5; two: 2.07 ms) and give the chasing launch 128 CUs
         // instead of 96 (profiles/r06_hals_chase.txt: 4.35 -> 4.27 ms per iteration)
-        if (P == 4 && h->hals_opt_persist == 1 && h->hals_opt_chase > 0 && d.K % 32 == 0 && !h->small_k && d.Tl >= 4096) P = 3;
+        if (P == 4 && h->hals_opt_persist == 1 && h->hals_opt_chase != 0 && d.K % 32 == 0 && !h->small_k && d.Tl >= 4096) P = 3;
     }
     h->hals_pullers = P;
 }
@@ -330,13 +330,24 @@ int hals_persist_launch(cmf_handle_s *h, const HalsRowParams &q, int debug, bool
 static int hals_chase_rows(cmf_handle_s *h)
 {
     const CmfDims &d = h->d;
-    if (h->hals_opt_chase <= 0 || h->hals_pullers <= 0 || d.K % 32 != 0 || h->small_k || h->hals_gram == 1 || h->hals_debug == 1 || h->hals_debug == 2) return 0;
+    if (h->hals_opt_chase == 0 || h->hals_pullers <= 0 || d.K % 32 != 0 || h->small_k || h->hals_gram == 1 || h->hals_debug == 1 || h->hals_debug == 2) return 0;
     if (h->n_cu % 8 != 0 || h->n_cu > 256) return 0;
     const int per_xcd = h->n_cu / 8, need = (d.K + (d.K - 1) * h->hals_pullers + 7) / 8;
     if (per_xcd - need < 4) return 0;
     const int rows_t = (d.Tl + 63) / 64;
     if (rows_t < 64) return 0; // (short recordings: the pipeline's span is a few tile rows of conv)
-    return std::min(rows_t, (int)((long long)rows_t * std::min(h->hals_opt_chase, 100) / 100));
+    int pct = h->hals_opt_chase;
+    if (pct < 0) {
+        // auto: the share the chasing launch can finish while the pipeline runs.  The conv at 0.87 of the fp32 MFMA roof on the whole chip,
+        // the pipeline at 0.63 of its dependency floor (43 cycles a step at 2.4 GHz), its last row starting a quarter of the span in; the
+        // chasing stream has (per_xcd - need) / per_xcd of the CUs; 10 % on top, because the rest of the conv starts beside the chasing
+        // launch's tail.  Config 5: 64 % (swept: 60-70 % is the flat optimum, profiles/r06_hals_chase.txt).
+        const double conv_ms = 2.0 * d.K * (double)d.N * ((double)d.L * d.Tl) / (0.87 * 157.3e12) * 1e3;
+        const double pipe_ms = ((double)d.Tl + (double)(d.K - 1) * (d.L - 1)) * 43.0 / 2.4e9 / 0.63 * 1e3;
+        const double share = (double)(per_xcd - need) / per_xcd * (0.76 * pipe_ms) / conv_ms;
+        pct = (int)std::max(10.0, std::min(95.0, 110.0 * share));
+    }
+    return std::min(rows_t, (int)((long long)rows_t * std::min(pct, 100) / 100));
 }
 
 // The persistent sweep with the first `ra` tile rows of the residual conv (hals.jl:41's residual, the loss fused) chasing it.

@@ -234,7 +234,7 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       tests compare them); they exist for tests and measurements.  "hals_debug" (needs CMF_TEST_HOOKS=1; results are WRONG by
  *       design): 3 = the pullers of the persistent launch leave at once, so that every bounded wait runs out (the test of that
  *       path); 1 / 2 = no gating / pullers skip their work (timing).
- *   "hals_chase" (default 65; 0 = off): per cent of the tile rows of the residual conv behind the H sweep (hals.jl:41: the residual
+ *   "hals_chase" (default -1 = a share estimated from the shape, 64 at config 5; 0 = off; 1..100 = that share): per cent of the tile rows of the residual conv behind the H sweep (hals.jl:41: the residual
  *       and the loss) that CHASE the persistent row pipeline instead of waiting for it: the pipeline (K + 4 (K-1) workgroups, VALU
  *       only) runs on a stream masked to the CUs it needs, those tile rows on a stream masked to the others, each tile waiting for
  *       the last row's progress flag; the rest of the conv follows on the whole chip (the pipeline then runs with three pullers per row instead of four: +1 % of its
