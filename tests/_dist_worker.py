@@ -94,7 +94,7 @@ def main():
         rule = ShardedMultUpdate(data, W0, H0, device=int(os.environ.get("LOCAL_RANK", "0")), overlap=overlap,
                                  transport=os.environ.get("CMF_TEST_TRANSPORT") or None,
                                  fallback_to_host=os.environ.get("CMF_TEST_FALLBACK", "0") == "1")
-        info = rule.comm_info() + (" FALLBACK" if rule.transport_fallback else "")
+        info = rule.comm_info() + (" FALLBACK" if rule.transport_fallback else "") + f" halo_in_allreduce={rule.counter('halo_in_allreduce')}"
         want = float(np.linalg.norm(data))
         assert abs(rule.data_norm - want) <= 1e-9 * want, f"rank {rank}: data_norm {rule.data_norm} != {want}"
     losses = [rule.compute_loss()]

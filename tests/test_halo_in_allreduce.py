@@ -33,9 +33,9 @@ def problem(oracle, N, T, K, L, seed=11):
     return data, W0, H0
 
 
-@pytest.mark.parametrize("R,transport,N,T,K,L", [(2, 2, 70, 900, 32, 8), (3, 3, 40, 1000, 32, 20), (8, 2, 33, 2100, 64, 7), (4, 4, 50, 1300, 32, 33),
-                                                 (5, 3, 24, 700, 32, 2)])
-def test_one_collective_per_iteration_and_the_oracles_results(cmf, oracle, R, transport, N, T, K, L):
+@pytest.mark.parametrize("R,transport,N,T,K,L,threads", [(2, 2, 70, 900, 32, 8, 1), (3, 3, 40, 1000, 32, 20, 1), (8, 2, 33, 2100, 64, 7, 1), (4, 4, 50, 1300, 32, 33, 1),
+                                                         (5, 3, 24, 700, 32, 2, 1), (3, 3, 40, 1000, 32, 20, 0), (4, 4, 50, 1300, 32, 12, 0)])
+def test_one_collective_per_iteration_and_the_oracles_results(cmf, oracle, R, transport, N, T, K, L, threads):
     data, W0, H0 = problem(oracle, N, T, K, L)
     reg = dict(l1W=0.05, l2W=0.1, l1H=0.05, l2H=0.1)
     n = 6
@@ -46,6 +46,8 @@ def test_one_collective_per_iteration_and_the_oracles_results(cmf, oracle, R, tr
         try:
             rule.set_option("halo_in_allreduce", form)
             assert rule.counter("halo_in_allreduce") == form
+            if transport != 2:
+                rule.set_option("enqueue_threads", threads)  # an enqueue worker per shard, or the calling thread for all of them
             rule.iterate(1, **reg)  # (the first iteration starts from the set-up exchange)
             ar0, ag0 = rule.counter("allreduce_calls"), rule.counter("allgather_calls")
             ls = list(rule.iterate(n - 2, **reg))

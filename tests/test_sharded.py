@@ -287,6 +287,9 @@ def test_sharded_processes_host_callbacks(oracle, tmp_path, world, N, T, K, L, r
     out = str(tmp_path / "res.npz")
     got = run_ranks(world, "hip", out, N, T, K, L, iters, reg, overlap=overlap, mode=mode)
     assert "transport=callbacks" in str(got["info"]) and f"nranks={world}" in str(got["info"])
+    # every rank handed the library the L-1 columns of data in front of its shard (cmf_shard_set_left_data): where the shape allows it the
+    # halo of H travels in the W-phase all-reduce (one collective per iteration), and every rank agreed on that when it joined
+    assert f"halo_in_allreduce={1 if K % 32 == 0 else 0}" in str(got["info"])
     _, _, _, Wr, Hr, lr = oracle_fit(oracle, N, T, K, L, iters, reg)
     np.testing.assert_allclose(got["loss_hist"], lr, rtol=1e-4)
     assert frob_rel(got["W"], Wr) < 1e-4
