@@ -166,7 +166,7 @@ def hals_roofline(T, K, L, spans, ms_per_step):
             "pipeline_span_ms": pipe_ms, "pipeline_spans_timed": n_pipe, "pipeline_floor_ms": 1e3 * crit_steps / peak_steps,
             "share_of_step": pipe_ms / ms_per_step if ms_per_step else None,
             "w_sweep_ms": wsw_ms,
-            "timing": "HIP event pair around the whole pipeline inside the timed region (option profile)"}
+            "timing": "HIP event pair around the whole pipeline (option profile), over a bracketed pass of the steps behind the timed ones"}
 
 
 def hals_steps(rule, n, reg_kw):
@@ -922,7 +922,9 @@ def measure(args, form, progress):
         timed(args.warmup, 0)
     progress["phase"] = "timed steps"
     prof.set_option("profile_mask", (1 << PROF_CLASSES.index(dom_class)) if one_class else 0)
-    prof.set_option("profile", 4 if alg == "mult" else 1)  # every 4th launch of each class (HALS: every span)
+    # (HALS: the timed steps carry no event pairs at all -- one around each of an iteration's ~20 launches idles the device ~0.2 ms per
+    # iteration; the two sweeps' spans of the roofline block come from a bracketed pass of the same steps right behind the timed one)
+    prof.set_option("profile", 4 if alg == "mult" else 0)  # every 4th launch of the bracketed class
     coll0 = None
     if sharded:
         try:  # the collectives this rank's handle issues over the timed steps (cmf_get_counter): the north star asks for ONE per iteration
@@ -952,6 +954,13 @@ def measure(args, form, progress):
     prof.set_option("profile_mask", 0)
     hals_spans = {}
     if alg != "mult":
+        prof.set_option("profile", 1)
+        timed(0, min(args.steps, 5))
+        for name in names:
+            kms, n = prof.kernel_times(name)
+            if n:
+                inloop[name] = (kms, n)
+        prof.set_option("profile", 0)
         hals_spans, inloop = inloop, {}
     dt_allpairs = None
     if one_class:  # second pass: every contraction kernel bracketed (the dominant kernel keeps its figure from the timed steps)
