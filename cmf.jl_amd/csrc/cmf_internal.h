@@ -193,7 +193,7 @@ struct cmf_handle_s {
     // HALS scratch (allocated on first use)
     bool hals_ready = false;
     bool gram_ready = false;                // the scratch the Gram form and HALS share (gram_ensure)
-    int hals_NpH = 0, hals_NpC = 0, hals_TPp = 0, hals_ne = 0, hals_t_edge0 = 0, hals_nch = 1, hals_clen = 6;
+    int hals_NpH = 0, hals_NpC = 0, hals_TPp = 0, hals_ne = 0, hals_t_edge0 = 0, hals_corr_R = 4;
     float *hals_HX = nullptr, *hals_cslabs = nullptr, *hals_C = nullptr, *hals_HH = nullptr, *hals_PT = nullptr, *hals_D = nullptr;
     float *hals_PW = nullptr, *hals_GW = nullptr, *hals_GE = nullptr, *hals_GWt = nullptr;
     int hals_seg = 256, hals_nseg = 1;      // column segments of the pipelined H sweep

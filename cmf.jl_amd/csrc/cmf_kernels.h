@@ -1646,18 +1646,91 @@ static __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *p
 // with C[d][a][b] = sum_t H[a][t-d] * H[b][t], which is the C2 contraction (hxt_kernel) of H with ITSELF as the X
 // operand: K32 columns (padded to 128) instead of the L*K32 columns of a materialised H_unfold' -- a fifth of the MFMA
 // work of round 1's form at K = 32, L = 20, and no 128 MB H_unfold' to build.
-// HX[r][c] = c < K32 ? H[r][c] : 0 : H in the row pitch hxt wants for its X operand.   grid-stride over TP * K32
-// Only the handle's own rows [PADL, PADL + Tl) are copied: as the X operand the rows behind them must read as zero (the
-// C2 kernel rounds its time chunks up past Tl), and on a shard those rows of H hold the right neighbour's halo.
-static __global__ void hals_hx_kernel(const float *H, float *HX, int TP, int K32, int NpC, int PADL, int Tl)
+// The lag correlations themselves (round 6; until round 5 the general C2 kernel ran with H packed as its own X operand: K32 columns in a
+// 128-column pitch, 2048 waves of a few hundred MFMAs each and 64 slabs behind them -- 72 + 12 us for 2 GFLOP at config 5):
+//   C[d][a][b] = sum_{t in [0, Tl)} H[t - d][a] * H[t][b]     d < L;  a, b < K32   (H[t - d] for t < d: the left halo / the zero padding)
+// grid (G, KB * KB), 256 threads: workgroup g owns the time rows [g R, (g+1) R), its 4 waves own the lags d = wave, wave + 4, ... --
+// five accumulator blocks per pass, ceil(L / 20) passes -- and both MFMA operands are rows of H read in operand layout (A: lane i of
+// half h = H[t0 + h - d][a0 + i], B: H[t0 + h][b0 + i]), one step of two time rows ahead.  Partial sums to slab g ([L][K32][K32],
+// compact); hals_corr_sum_kernel adds the slabs in order (deterministic) into C's [L][K32][NpC] layout.
+#define HALS_CORR_LPW 5
+static __global__ __launch_bounds__(256) void hals_corr_kernel(const float *H, float *slabs, int K32, int KB, int PADL, int Tl, int L, int R)
 {
-    const size_t total = (size_t)TP * K32;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = idx / K32;
-        const int c = (int)(idx - r * K32);
-        HX[r * NpC + c] = ((int)r >= PADL && (int)r < PADL + Tl) ? H[idx] : 0.f;
+    extern __shared__ float hc_rows[]; // [R + L - 1 (+ 4: the read-ahead)][K32]: rows t_begin - (L-1) .. t_end - 1 of H, zeros behind t_end
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int ab = blockIdx.y / KB, bb = blockIdx.y % KB;
+    const int t_begin = blockIdx.x * R, t_end = (t_begin + R < Tl) ? t_begin + R : Tl;
+    float *slab = slabs + (size_t)blockIdx.x * L * K32 * K32;
+    {   // stage the rows once (the operands were read from L2 row by row in the first form of this kernel: one wave per SIMD cannot
+        // hide that latency -- 80 us, no better than the C2 kernel it replaced)
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(H + (size_t)(PADL + t_begin - (L - 1)) * K32);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(hc_rows);
+        const int nlive = (t_end - t_begin + L - 1) * K32 / 4, nall = (R + L - 1 + 4) * K32 / 4;
+        for (int e = tid; e < nall; e += 256) dst[e] = e < nlive ? src[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const float *Hs = hc_rows + (size_t)(L - 1) * K32; // row t - t_begin of the workgroup's own range
+    const int nsteps = (t_end - t_begin + 3) / 4;       // steps of four rows (the rows behind t_end are zero)
+    for (int d0 = wave; d0 < L; d0 += 4 * HALS_CORR_LPW) { // this pass: lags d0, d0 + 4, ..., d0 + 4 (LPW - 1)
+        f32x16 acc[HALS_CORR_LPW];
+#pragma unroll
+        for (int q = 0; q < HALS_CORR_LPW; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        // lane (i, half h): A = H[t + h - d][a0 + i], B = H[t + h][b0 + i]; lags beyond L read lag 0's rows and are not stored
+        const float *pb = Hs + h * K32 + bb * 32 + i;
+        const float *pa[HALS_CORR_LPW];
+#pragma unroll
+        for (int q = 0; q < HALS_CORR_LPW; ++q) pa[q] = Hs + (h - ((d0 + 4 * q < L) ? d0 + 4 * q : 0)) * K32 + ab * 32 + i;
+        float a0[HALS_CORR_LPW], a1[HALS_CORR_LPW], b0 = pb[0], b1;
+#pragma unroll
+        for (int q = 0; q < HALS_CORR_LPW; ++q) a0[q] = pa[q][0];
+        for (int s = 0; s < nsteps; ++s) {
+            const int o = s * 4 * K32;
+            b1 = pb[o + 2 * K32];
+#pragma unroll
+            for (int q = 0; q < HALS_CORR_LPW; ++q) a1[q] = pa[q][o + 2 * K32];
+#pragma unroll
+            for (int q = 0; q < HALS_CORR_LPW; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0, acc[q], 0, 0, 0);
+            b0 = pb[o + 4 * K32]; // (the last step reads the four zero rows of the read-ahead)
+#pragma unroll
+            for (int q = 0; q < HALS_CORR_LPW; ++q) a0[q] = pa[q][o + 4 * K32];
+#pragma unroll
+            for (int q = 0; q < HALS_CORR_LPW; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b1, acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < HALS_CORR_LPW; ++q) {
+            const int d = d0 + 4 * q;
+            if (d < L)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[((size_t)d * K32 + ab * 32 + cmf_crow(r, h)) * K32 + bb * 32 + i] = acc[q][r];
+        }
     }
 }
+// C[d][a][b] (pitch NpC) = sum over the G slabs.  A workgroup = 64 consecutive entries x 16 waves: wave j adds the slabs g = j, j + 16, ...
+// (coalesced 256-byte reads, all in flight), the 16 partial sums meet in LDS and are added in wave order -- a fixed order, the same
+// result on every run.  (One thread per entry walking all G slabs was 30 us of latency for 21 MB.)   grid: L * K32 * K32 / 64
+static __global__ __launch_bounds__(1024) void hals_corr_sum_kernel(const float *slabs, float *C, int G, int L, int K32, int NpC)
+{
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t n = (size_t)L * K32 * K32, idx = (size_t)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (idx < n)
+        for (int g = wave; g < G; g += 16) s += slabs[(size_t)g * n + idx];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && idx < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tot += part[j][lane];
+        const size_t da = idx / K32, b = idx - da * K32;
+        C[da * NpC + b] = tot;
+    }
+}
+
 // HH[(l*K32+k) * NpH + l'*K32+k'] from C [L][K32][NpC] and the last columns of H ([TP][K32]).  One thread per entry.
 // sharded != 0: this handle owns one column block of a T-sharded problem and C holds the lag correlations over ITS
 // columns only (with the left H halo); the entry is then this shard's additive share of HH -- C as it is, minus the cut

@@ -35,22 +35,17 @@ int gram_ensure(cmf_handle_s *h)
     h->hals_NpC = (int)rup(d.K32, 128); // pitch of H as the X operand of its own lag correlations (compute_hh)
     if ((double)d.L * d.K32 * h->hals_NpH * 4.0 >= 2147483648.0 || (double)d.TP * h->hals_NpC * 4.0 >= 2147483648.0)
         return fail(CMF_ERR_UNSUPPORTED, "Gram form: (L*K)^2 or T*K exceeds the 2 GiB the kernels' 32-bit buffer offsets address");
-    {   // time chunks of that launch: fill the resident wave slots -- but no chunk shorter than two rotations of the C2
-        // kernel's register ring, and the chunk count a multiple of 4 so that four chunks are added inside a workgroup
-        // (trailing chunks that start behind Tl do nothing): at K = 32 the launch has 8 waves per chunk, and one rotation
-        // per chunk meant 209 slabs of one chunk each at T = 6250 for the slab sum to walk through (30 us)
-        const int slots = 4 * h->n_cu * (h->hxt_LP <= 5 ? 2 : 1);
-        int64_t wpc = (int64_t)(h->hals_NpC / 32) * d.KB * h->hxt_groups;
-        int nch = (int)std::max<int64_t>(1, (slots + wpc / 2) / wpc);
-        int64_t clen = std::max<int64_t>(rup((d.Tl + nch - 1) / nch, 6 * h->hxt_LP), 12 * h->hxt_LP);
-        h->hals_clen = (int)clen;
-        nch = (int)((d.Tl + clen - 1) / clen);
-        h->hals_nch = nch >= 4 ? (int)rup(nch, 4) : nch;
+    {   // time rows per workgroup of the lag-correlation kernel (hals_corr_kernel): about one workgroup per CU and (a, b) block pair,
+        // whole steps of four rows
+        const int G = std::max(1, h->n_cu / (d.KB * d.KB));
+        int64_t R = std::max<int64_t>(4, rup((d.Tl + G - 1) / G, 4));
+        const int64_t fit = ((int64_t)64 * 1024 / (d.K32 * 4) - (d.L - 1) - 4) / 4 * 4; // rows of H (+ L - 1 in front, 4 behind) in 64 KB of LDS
+        if (fit < 4) return fail(CMF_ERR_UNSUPPORTED, "Gram form / HALS: K * L too large for the lag-correlation kernel's LDS window");
+        h->hals_corr_R = (int)std::min(R, fit);
     }
     const size_t LKN = (size_t)d.L * d.K32 * h->hals_NpH;
     const size_t LKC = (size_t)d.L * d.K32 * h->hals_NpC;
-    CMFTRY(dalloc_zero(&h->hals_HX, (size_t)d.TP * h->hals_NpC));
-    CMFTRY(dalloc_zero(&h->hals_cslabs, (size_t)hxt_nslabs(h->hals_nch) * LKC));
+    CMFTRY(dalloc_zero(&h->hals_cslabs, (size_t)((d.Tl + h->hals_corr_R - 1) / h->hals_corr_R) * d.L * d.K32 * d.K32)); // one compact slab per workgroup
     CMFTRY(dalloc_zero(&h->hals_C, LKC));
     CMFTRY(dalloc_zero(&h->hals_HH, LKN));
     CMFTRY(dalloc_zero(&h->hals_PW, (size_t)d.L * d.L * d.K32 * d.K32));
@@ -150,10 +145,16 @@ static int compute_hh(cmf_handle_s *h, float *out = nullptr)
 {
     const CmfDims &d = h->d;
     const bool shard = h->sharded && h->T_global != d.Tl; // out = this shard's additive share of HH (hals_hh_kernel)
-    hipLaunchKernelGGL(hals_hx_kernel, dim3(1024), dim3(256), 0, h->stream, h->H, h->hals_HX, d.TP, d.K32, h->hals_NpC, d.PADL, d.Tl);
-    KCHK("hals_hx_kernel");
-    CMFTRY(launch_hxt_on(h, h->hals_HX, h->hals_HX, h->hals_NpC, 1, h->hals_cslabs, h->hals_nch, h->hals_clen));
-    CMFTRY(launch_slab_sum(h, h->hals_C, h->hals_cslabs, hxt_nslabs(h->hals_nch), (size_t)d.L * d.K32 * h->hals_NpC));
+    {   // the lag correlations C[d][a][b] = sum_t H[t - d][a] H[t][b] over the handle's own columns (hals_corr_kernel), slabs added in order
+        ProfScope prof_(h, PROF_HXT_HH);
+        const int R = h->hals_corr_R, G = (d.Tl + R - 1) / R;
+        const size_t lds = (size_t)(R + d.L - 1 + 4) * d.K32 * sizeof(float);
+        hipLaunchKernelGGL(hals_corr_kernel, dim3(G, d.KB * d.KB), dim3(256), lds, h->stream, h->H, h->hals_cslabs, d.K32, d.KB, d.PADL, d.Tl, d.L, R);
+        KCHK("hals_corr_kernel");
+        hipLaunchKernelGGL(hals_corr_sum_kernel, dim3((unsigned)(((size_t)d.L * d.K32 * d.K32 + 63) / 64)), dim3(1024), 0, h->stream,
+                           h->hals_cslabs, h->hals_C, G, d.L, d.K32, h->hals_NpC);
+        KCHK("hals_corr_sum_kernel");
+    }
     hipLaunchKernelGGL(hals_hh_kernel, dim3(1024), dim3(256), 0, h->stream, h->hals_C, h->H, out ? out : h->hals_HH, d.Tl, d.L, d.K, d.K32,
                        h->hals_NpC, h->hals_NpH, d.PADL, shard ? 1 : 0, (h->t_offset + d.Tl == h->T_global) ? 1 : 0);
     KCHK("hals_hh_kernel");

@@ -50,7 +50,8 @@ for arg in sys.argv[1:] or ["0", "30", "40", "45", "50", "55", "60"]:
     pipe, _ = rule.kernel_times("hals_h_pipeline")
     conv, nconv = rule.kernel_times("conv_resid")
     wsw, _ = rule.kernel_times("hals_w_sweep")
-    print(f"hals_chase={arg:>5s}: {1e3 * dt:.3f} ms per HALS iteration; W sweep {wsw:.3f} ms, pipeline {pipe:.3f} ms, conv launches {conv:.3f} ms (mean of {nconv}); "
+    hh, _ = rule.kernel_times("hxt_hh")
+    print(f"hals_chase={arg:>5s}: {1e3 * dt:.3f} ms per HALS iteration; lag correlations {hh:.3f} ms, W sweep {wsw:.3f} ms, pipeline {pipe:.3f} ms, conv launches {conv:.3f} ms (mean of {nconv}); "
           f"first 3 iterations against the first run: loss {dl:.1e}, W {dw:.1e}, H {dh:.1e}; reruns {rule.counter('hals_pipeline_reruns')}; loss {loss:.6f}",
           flush=True)
     rule.close()
