@@ -763,6 +763,11 @@ int reduce_partials(cmf_handle_s *h, const double *partial, int n, int slot, dou
     }
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, h->stream, partial, n, h->d_scalar + slot, host_out);
     KCHK("loss_reduce_kernel");
+    if (h->after_reduce) { // (enqueued behind the reduction: the sum does not wait for it -- the HALS rule's speculated W-phase contraction)
+        std::function<int()> f = std::move(h->after_reduce);
+        h->after_reduce = nullptr;
+        if (v) CMFTRY(f());
+    }
     if (!v) return CMF_OK;
     if (!host_out) return read_scalar(h, slot, v);
     CMFTRY(wait_words<unsigned long long>(h->stream, reinterpret_cast<volatile unsigned long long *>(host_out), 1, CMF_SENTINEL64, nullptr, nullptr));
@@ -1190,6 +1195,7 @@ int cmf_set_stream(cmf_handle h, void *hip_stream)
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
         h->spec_gen = -1;
+        h->hals_spec_gen = -1;
     }
     h->stream = (hipStream_t)hip_stream;
     return CMF_OK;
@@ -1518,6 +1524,7 @@ int cmf_hals_update_motifs(cmf_handle h, double l1W, double l2W)
 {
     if (h && h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
     CMFTRY(check_ready(h, true));
+    h->last_rule_call = 1;
     return hals_w_impl(h, l1W, l2W);
 }
 
@@ -1526,9 +1533,14 @@ static int hals_update_feature_maps_body(cmf_handle h, double l1H, double l2H, d
     if (h && h->group) return fail(CMF_ERR_STATE, "this rule needs a single-GPU handle (its sweeps / step control do not shard over T)");
     if (!loss) return fail(CMF_ERR_ARG, "loss is NULL");
     CMFTRY(check_ready(h, true));
+    const bool speculate = h->speculate && h->last_rule_call == 1; // the caller alternates (alternating.jl:51-54): update_motifs! comes next
+    h->last_rule_call = 2;
     CMFTRY(hals_h_impl(h, l1H, l2H));
     double ss = 0.0;
     for (int attempt = 0; attempt < 2; ++attempt) {
+        // ... whose contraction on the residual and lag correlations (they need H and the residual only; l1W, l2W enter in the sweep) go
+        // out behind the loss reduction, so that the device works while the loss travels and the caller's loop comes round
+        if (speculate && attempt == 0 && h->hals_gram != 1) h->after_reduce = [h]() { return hals_w_speculate(h); };
         if (h->hals_gram == 1) { // hals.jl:41: norm(resids)/data_norm -- the conv with the loss fused in its epilogue, nothing stored
             CMFTRY(launch_conv<2>(h, nullptr, h->d.Tl, h->conv_gy));
             CMFTRY(reduce_partials(h, h->partial, h->conv_partials, 0, &ss));
@@ -1538,6 +1550,7 @@ static int hals_update_feature_maps_body(cmf_handle h, double l1H, double l2H, d
         }
         // (the loss has arrived: every kernel in front of its reduction has completed)  A bounded wait of the persistent H pipeline ran out:
         // redo the sweep from the snapshot on the stage pipeline and take the loss again; counted in "hals_pipeline_reruns"
+        h->after_reduce = nullptr;
         if (attempt == 0 && h->hals_status && *h->hals_status) CMFTRY(hals_h_rerun(h));
         else break;
     }

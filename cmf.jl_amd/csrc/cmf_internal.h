@@ -252,6 +252,8 @@ struct cmf_handle_s {
     int64_t spec_gen = -1;  // est_gen for which the C2 contraction of the NEXT update_motifs! has already been enqueued (w_speculate); -1: none
     int last_rule_call = 0; // 1: cmf_update_motifs, 2: cmf_update_feature_maps (MU rule, single handle): speculation follows the alternation only
     bool speculate = true;  // option "speculate"
+    std::function<int()> after_reduce;  // run once by the next reduce_partials between its launch and its wait for the sum (the HALS rule's speculation)
+    int64_t hals_spec_gen = -1; // est_gen for which G (the C2 contraction on the residual) and HH of the NEXT HALS update_motifs! have been enqueued; -1: none
     int64_t spec_hits = 0;  // update_motifs! calls that found their contraction done (cmf_get_counter "speculated_contractions")
 
     // T-sharded groups (cmf_group.h): the handle the caller holds fronts a group when `group` is set
@@ -426,6 +428,7 @@ static inline void set_est(cmf_handle_s *h, int kind) // every change of what es
 int wb_after_H(cmf_handle_s *h); // hook: the kernels that make H final have been enqueued (cmf_writeback.h)
 int gram_ensure(cmf_handle_s *h);
 int hals_w_impl(cmf_handle_s *h, double l1W, double l2W);
+int hals_w_speculate(cmf_handle_s *h);
 int resid_and_loss(cmf_handle_s *h, double *sumsq, bool masked = false, bool loss_abs = false);
 int hals_resid_and_loss(cmf_handle_s *h, double *sumsq);
 int gram_w_impl(cmf_handle_s *h, double l1W, double l2W);

@@ -1875,7 +1875,10 @@ __global__ __launch_bounds__(256) void hals_w_sweep_reg_kernel(float *Wt, float 
 
 // PT[k][t] = sum_s of the transconv slabs [S][1][Tl][K32] (of the residual), or, with `den` ([Tl][K32]) given,
 // den[t][k] - that sum (the projection as denomH - numH: slabs of transconv(W, data));   grid (ceil(Tl/64), KB), block 256
-static __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float *slabs, const float *den, int S, int Tl, int K32, int TPp)
+// snap (may be NULL): the launch in front of the persistent row pipeline also takes the pipeline's snapshot of H and H' (own columns;
+// [2][TP][K32]: two 6.4 MB blit copies of 14 + 9 us at config 5 before) and clears its nflags progress flags (a 6 us fill before).
+static __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, const float *slabs, const float *den, int S, int Tl, int K32, int TPp,
+                                                                 const float *H, const float *Ht, float *snap, int TP, int PADL, int *flags, int nflags)
 {
     __shared__ float tile[32][65];
     const int tid = threadIdx.x;
@@ -1891,6 +1894,7 @@ static __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, cons
                 size_t idx = (size_t)t * K32 + kb * 32 + kk;
                 for (int s = 0; s < S; ++s) v += slabs[(size_t)s * TK + idx];
                 if (den) v = den[idx] - v;
+                if (snap) snap[(size_t)(PADL + t) * K32 + kb * 32 + kk] = H[(size_t)(PADL + t) * K32 + kb * 32 + kk];
             }
             tile[kk][tt] = v;
         }
@@ -1902,8 +1906,14 @@ static __global__ __launch_bounds__(256) void hals_p_init_kernel(float *PT, cons
         for (int q = 0; q < 8; ++q) {
             int kk = q * 4 + (tid >> 6);
             PT[(size_t)(kb * 32 + kk) * TPp + t0 + tt] = tile[kk][tt]; // t0 + tt < TPp (padded)
+            if (snap && t0 + tt < Tl) {
+                const size_t at = (size_t)(kb * 32 + kk) * TP + PADL + t0 + tt;
+                snap[(size_t)TP * K32 + at] = Ht[at];
+            }
         }
     }
+    if (flags && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int e = tid; e < nflags; e += 256) flags[e] = 0;
 }
 
 // PW[l][l'][k][k'] = sum_n Wn[l][n][k] * Wn[l'][n][k'] on the MFMA pipe: one WORKGROUP per (l <= l', k block, k' block),

@@ -161,6 +161,17 @@ static int compute_hh(cmf_handle_s *h, float *out = nullptr)
     return CMF_OK;
 }
 
+// Behind the loss reduction of update_feature_maps! (the residual is current, H final): G = resid * H_unfold' and HH of the NEXT
+// update_motifs! (hals.jl:56-60, 104-110), like the MU rule's w_speculate.  Taken by hals_w_impl if nothing has passed set_est since.
+int hals_w_speculate(cmf_handle_s *h)
+{
+    if (h->est_kind != 2 || h->hals_gram == 1 || h->group) return CMF_OK;
+    CMFTRY(hxt_contract(h, h->est, h->est, 1, h->numden));
+    CMFTRY(compute_hh(h));
+    h->hals_spec_gen = h->est_gen;
+    return CMF_OK;
+}
+
 int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
 {
     const CmfDims &d = h->d;
@@ -179,9 +190,15 @@ int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
         G = h->numden + LKN;
         Gsub = h->numden;
     } else {
-        CMFTRY(ensure_resid(h));
-        CMFTRY(hxt_contract(h, h->est, h->est, 1, h->numden));
-        CMFTRY(compute_hh(h));
+        // (both already enqueued behind the loss of the update_feature_maps! before, for exactly this state: hals_w_speculate)
+        const bool spec = h->hals_spec_gen >= 0 && h->hals_spec_gen == h->est_gen && h->est_kind == 2;
+        h->hals_spec_gen = -1;
+        if (spec) h->spec_hits += 1;
+        else {
+            CMFTRY(ensure_resid(h));
+            CMFTRY(hxt_contract(h, h->est, h->est, 1, h->numden));
+            CMFTRY(compute_hh(h));
+        }
     }
     // the K*L sequential column updates, k outer / lag inner (hals.jl:90-97)
     if (h->hals_w_general) { // L * Kpad beyond the register-resident sweep: one workgroup per unit, the state in LDS
@@ -223,10 +240,20 @@ int hals_w_impl(cmf_handle_s *h, double l1W, double l2W)
 // H sweep's short recurrences (L-1 columns) do not amplify the cancellation: H stays within the residual form's test
 // bars (1.8e-5 against the fp64 restatement where the residual form has 1.2e-5).  hals_gram = 0: P as one C3 contraction
 // on the transposed residual.  `contract` = false repeats only the last step (P from the slabs that are still there).
-static int hals_h_project(cmf_handle_s *h, bool contract)
+// snapshot: the launch that forms P also takes the persistent pipeline's snapshot of H / H' and clears its flags (hals_p_init_kernel).
+static int hals_h_project(cmf_handle_s *h, bool contract, bool snapshot = false)
 {
     const CmfDims &d = h->d;
     const size_t TK = (size_t)d.Tl * d.K32;
+    float *snap = nullptr;
+    int *flags = nullptr;
+    int nflags = 0;
+    if (snapshot) {
+        if (!h->hals_snap) CMFTRY(dalloc_zero(&h->hals_snap, (size_t)2 * d.TP * d.K32)); // (zero like the padding of H and H': only own columns are copied)
+        snap = h->hals_snap;
+        flags = h->hals_flags;
+        nflags = (int)((size_t)(d.K + d.K * h->hals_pullers + 1) * HALS_FLAG_STRIDE);
+    }
     const bool gram = h->hals_gram && (size_t)d.K32 * (64 + 2 * (d.L - 1)) * sizeof(float) <= 96 * 1024; // (gram_denom_h's LDS window)
     if (gram) {
         if (!h->gram_numden_h) CMFTRY(dalloc_zero(&h->gram_numden_h, 2 * TK));
@@ -235,14 +262,14 @@ static int hals_h_project(cmf_handle_s *h, bool contract)
             CMFTRY(gram_denom_h(h, h->gram_numden_h + TK));
         }
         hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, h->gram_numden_h + TK,
-                           h->tc_S1, d.Tl, d.K32, h->hals_TPp);
+                           h->tc_S1, d.Tl, d.K32, h->hals_TPp, h->H, h->Ht, snap, d.TP, d.PADL, flags, nflags);
     } else {
         if (contract) {
             CMFTRY(launch_conv<5>(h, h->estT, d.Tl, h->conv_gy, h->XT));
             CMFTRY(launch_transconv(h, 1, h->estT));
         }
         hipLaunchKernelGGL(hals_p_init_kernel, dim3((d.Tl + 63) / 64, d.KB), dim3(256), 0, h->stream, h->hals_PT, h->hslabs, (const float *)nullptr,
-                           h->tc_S1, d.Tl, d.K32, h->hals_TPp);
+                           h->tc_S1, d.Tl, d.K32, h->hals_TPp, h->H, h->Ht, snap, d.TP, d.PADL, flags, nflags);
     }
     KCHK("hals_p_init_kernel");
     return CMF_OK;
@@ -375,8 +402,7 @@ static int hals_persist_chased(cmf_handle_s *h, const HalsRowParams &q, int ra)
         h->hals_mask_aper = a_per;
     }
     hipStream_t keep = h->stream;
-    const size_t nflags = (size_t)(d.K + d.K * h->hals_pullers + 1) * HALS_FLAG_STRIDE;
-    HIPCHK(hipMemsetAsync(h->hals_flags, 0, nflags * sizeof(int), keep)); // (in front of the fork: both launches see cleared flags)
+    // (the flags were cleared by the projection launch, in front of the fork: both launches see them cleared)
     HIPCHK(hipEventRecord(h->hals_ev[0], keep));
     HIPCHK(hipStreamWaitEvent(h->hals_sA, h->hals_ev[0], 0));
     HIPCHK(hipStreamWaitEvent(h->hals_sB, h->hals_ev[0], 0));
@@ -420,7 +446,8 @@ static int hals_h_enqueue(cmf_handle_s *h, double l1H, double l2H)
     CMFTRY(hals_ensure(h));
     // the lag-Gram taps of W (GW, and GE for the truncated windows at the right edge)
     CMFTRY(gram_tables(h));
-    CMFTRY(hals_h_project(h, true));
+    const bool persist = !h->hals_h_general && h->hals_pullers > 0;
+    CMFTRY(hals_h_project(h, true, persist)); // (+ the snapshot the persistent pipeline starts from, and its flags cleared)
     const HalsRowParams q = hals_row_params(h, l1H, l2H);
     h->hals_l1 = l1H; h->hals_l2 = l2H;
     set_est(h, 0);
@@ -432,13 +459,9 @@ static int hals_h_enqueue(cmf_handle_s *h, double l1H, double l2H)
         // Its workgroups wait for each other and every wait is bounded; if one runs out (the grid did not become resident:
         // another process or stream holds CUs) the sweep is redone from this snapshot on the stage pipeline
         // (cmf_hals_update_feature_maps looks at the status word once the stream has drained).
-        const size_t nH = (size_t)d.TP * d.K32;
-        if (!h->hals_snap) CMFTRY(dalloc_zero(&h->hals_snap, 2 * nH));
-        HIPCHK(hipMemcpyAsync(h->hals_snap, h->H, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->hals_snap + nH, h->Ht, nH * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         h->hals_chased_rows = h->hals_chased_partials = 0;
         if (const int ra = hals_chase_rows(h)) return hals_persist_chased(h, q, ra);
-        CMFTRY(hals_persist_launch(h, q, h->hals_debug));
+        CMFTRY(hals_persist_launch(h, q, h->hals_debug, false)); // (flags cleared by the projection launch)
         return CMF_OK;
     }
     ProfScope prof_(h, PROF_HALS_PIPE); // the whole row pipeline (nstages launches) as one timed span

@@ -98,14 +98,16 @@ def test_small_k_off_in_between(cmf):
         assert np.array_equal(np.asarray(a), np.asarray(b))
 
 
-def test_other_rules_do_not_speculate(cmf):
+def test_what_the_other_rules_speculate(cmf):
     data, W0, H0 = problem(cmf, 64, 1200, 8, 6)
     for cls in (cmf.HALSUpdate, cmf.PGDUpdate):
         rule = cls(data, W0, H0)
         for _ in range(3):
             rule.update_motifs()
             rule.update_feature_maps()
-        assert rule.counter("speculated_contractions") == 0
+        # (round 6: the HALS rule speculates its own W-phase contraction -- test_hals_speculates_the_next_w_phase_too; PGD's depends on
+        # the step it has just accepted or rejected: nothing to send ahead)
+        assert rule.counter("speculated_contractions") == (2 if cls is cmf.HALSUpdate else 0)
         rule.close()
 
 
@@ -142,3 +144,40 @@ def test_stream_switch_between_the_two_calls(cmf):
         rule.close()
         for st in streams:
             hip.hipStreamDestroy(st)
+
+
+@pytest.mark.parametrize("N,T,K,L", [(60, 700, 5, 10), (130, 9000, 32, 20)])
+def test_hals_speculates_the_next_w_phase_too(cmf, N, T, K, L):
+    """The HALS rule (round 6): G = resid * H_unfold' and the lag correlations of the next update_motifs! (hals.jl:56-60, 104-110) go
+    out behind the loss reduction of update_feature_maps! when the caller alternates the two calls -- identical results whatever happens
+    in between, and the work is taken only when nothing has touched H, W or the residual."""
+    data, W0, H0 = problem(cmf, N, T, K, L)
+    script = ["W", "H", "W", "H", "get", "W", "H", "set", "W", "H", "H", "W", "loss", "W2", "H", "W", "H"]
+    out = {}
+    for spec in (1, 0):
+        rule = cmf.HALSUpdate(data, W0, H0)
+        rule.set_option("speculate", spec)
+        res = []
+        try:
+            for step in script:
+                if step == "W":
+                    rule.update_motifs(l1W=0.05, l2W=0.1)
+                elif step == "W2":
+                    rule.update_motifs(l1W=0.5, l2W=0.0)
+                elif step == "H":
+                    res.append(rule.update_feature_maps(l1H=0.02, l2H=0.3))
+                elif step == "get":
+                    res.extend(rule.download())
+                elif step == "set":
+                    W, H = rule.download()
+                    rule.upload(np.asfortranarray(W * 0.5 + 0.01), np.asfortranarray(H * 2.0))
+                elif step == "loss":
+                    res.append(rule.compute_loss())
+            res.extend(rule.download())
+            out[spec] = (res, rule.counter("speculated_contractions"))
+        finally:
+            rule.close()
+    for a, b in zip(out[1][0], out[0][0]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    # taken: after W-H (x2: "get" reads only), after the H that follows "set"+W ... not after "set" (new factors), not after H-H
+    assert out[0][1] == 0 and out[1][1] >= 3
