@@ -209,6 +209,7 @@ static void destroy_impl(cmf_handle_s *h)
     };
     for (float *q : {h->sk_slabs, h->sk_Wj})
         if (mine(q)) (void)hipFree(q);
+    if (mine(h->sk_cnt)) (void)hipFree(h->sk_cnt);
     (void)hipSetDevice(h->device);
     float *fbufs[] = {h->H, h->Ht, h->Wt, h->Wn, h->X, h->XT, h->est, h->estT, h->wslabs, h->numden_own, h->hslabs,
                       h->halo_own[0], h->halo_own[1], h->halo_own[2], h->halo_own[3],
@@ -365,6 +366,7 @@ int create_impl(cmf_handle *out, int device, int64_t N, int64_t Tl, int64_t K, i
     if (h->small_k_ok) {
         want(&h->sk_slabs, (size_t)h->sk_ngroups * 2 * h->sk_JP * d.Np);
         want(&h->sk_Wj, (size_t)d.Np * h->sk3_JP);
+        want(&h->sk_cnt, (size_t)h->sk_TG / 128 + 4);
         h->small_k = true; // (option "small_k": 0 = the general kernels for every K)
         h->sk_tc = h->small_k && h->sk_tc_ok;
         if (h->sk_tc) h->tc_S = h->tc_S1 = 2 * h->sk3_NS;
@@ -633,6 +635,12 @@ int h_update_impl(cmf_handle_s *h, double l1H, double l2H, bool front)
         return wb_after_H(h);
     }
     CMFTRY(launch_conv<1>(h, h->estT, d.Tl + h->halo_r, h->conv_gy_ext)); // mult.jl:44 (est with the new W)
+    if (sk_can_fuse_h(h)) { // few components: mult.jl:47-48 and :51-52 in ONE launch (whoever completes a block's slabs updates the block)
+        CMFTRY(launch_transconv_small(h, 2, nullptr, true, (float)l1H, (float)(2.0 * l2H)));
+        ++h->sk_fused_h;
+        set_est(h, 0);
+        return wb_after_H(h);
+    }
     CMFTRY(launch_transconv(h, 2));                                         // mult.jl:47-48
     dim3 grid((d.Tl + HUPD_T - 1) / HUPD_T, d.KB);
     const size_t TK = (size_t)d.Tl * d.K32;
@@ -1167,6 +1175,7 @@ int cmf_get_counter(cmf_handle h, const char *name, int64_t *value)
     if (std::strcmp(name, "hals_pipeline_reruns") == 0) { *value = h->hals_reruns; return CMF_OK; }
     if (std::strcmp(name, "writeback_calls") == 0) { *value = h->wb ? h->wb->armed_calls : 0; return CMF_OK; }            // cmf_arm_writeback calls
     if (std::strcmp(name, "speculated_contractions") == 0) { *value = h->spec_hits; return CMF_OK; }                         // update_motifs! calls whose C2 contraction was already enqueued
+    if (std::strcmp(name, "small_k_fused_h_updates") == 0) { *value = h->sk_fused_h; return CMF_OK; }                       // H updates that ran inside the few-component C3 launch
     if (std::strcmp(name, "writeback_overlapped") == 0) { *value = h->wb ? h->wb->hooked_calls : 0; return CMF_OK; }     // ... served by the copy stream behind the H update
     if (h->group) { // host cost of the pipelined iterations of a group (reading a counter resets nothing)
         cmf_group_s *g = h->group;
@@ -1202,7 +1211,7 @@ int cmf_set_stream(cmf_handle h, void *hip_stream)
 }
 
 // every name cmf_set_option knows (cmf_option_names; tests/test_library_abi.py walks the table)
-static const char *const kOptionNames[] = {"reuse_est", "speculate", "gram", "conv_kernel", "conv_split", "small_k", "hals_prepare", "hals_gram",
+static const char *const kOptionNames[] = {"reuse_est", "speculate", "gram", "conv_kernel", "conv_split", "small_k", "small_k_fuse", "hals_prepare", "hals_gram",
                                            "hals_persist", "hals_general", "hals_seg", "hals_lag", "hals_debug", "hals_chase", "profile", "profile_mask",
                                            "allreduce_overlap", "enqueue_threads", "halo_in_allreduce"};
 int cmf_option_names(char *buf, int64_t len)
@@ -1328,6 +1337,11 @@ int cmf_set_option(cmf_handle h, const char *name, int value)
     if (std::strcmp(name, "conv_split") == 0) { // 0 = never cut the one-wave conv kernel's last round into quarter tiles
         h->conv_split = value;
         set_est(h, 0);
+        return CMF_OK;
+    }
+    if (std::strcmp(name, "small_k_fuse") == 0) { // few components: 1 (default) = the element-wise update of H inside the C3 launch, 0 = a launch of its own
+        if (value < 0 || value > 2) return fail(CMF_ERR_ARG, "small_k_fuse must be 0, 1 or 2");
+        h->sk_fuse = value; // (2: also on one-round launches, where it is slower)
         return CMF_OK;
     }
     if (std::strcmp(name, "small_k") == 0) { // K <= 16: 1 = the few-component kernels (cmf_small_k.h; default), 0 = the general kernels

@@ -180,6 +180,9 @@ struct cmf_handle_s {
     int sk3_NS = 1, sk3_RPS = 1;            // short recordings: C3's reduction over n in sk3_NS pieces of sk3_RPS rounds of 8 rows (2 slabs per piece)
     int sk3_GR = 128, sk3_RV = 0;           // rows of a row group in Wj (32-row blocks); the last sk3_RV live rows on the VALU (sk3_MBW then counts the MFMA blocks only)
     float *sk_slabs = nullptr, *sk_Wj = nullptr;
+    int *sk_cnt = nullptr;                  // ticket counters of the fused few-component launches (one per 128-column block of H; zero between launches)
+    int64_t sk_fused_h = 0;                 // cmf_get_counter "small_k_fused_h_updates"
+    int sk_fuse = 1;                        // option "small_k_fuse": 1 = the element-wise update of H runs inside the C3 launch (cmf_small_k.h)
     int64_t sk_wj_gen = -1;                 // est_gen at which sk_Wj was packed from the resident W (w_update_small_kernel, wj_pack_kernel): every writer of W
                                             // passes through set_est, so a stale operand cannot be taken for a fresh one (-1: never packed)
     int tc_S_full = 1, tc_S1_full = 1;      // fragment slabs of the general transconv kernel (tc_S / tc_S1 are 1 while small_k is on)
@@ -460,7 +463,8 @@ int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nslabs, si
                            CmfHxtTail tail = CmfHxtTail{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0});
 int hxt_contract(cmf_handle_s *h, const float *X0, const float *X1, int nsrc, float *out, bool take_carry = false, bool slabs_only = false);
 int hxt_contract_small(cmf_handle_s *h, const float *X0, const float *X1, int nsrc, float *out, bool take_carry, bool slabs_only); // cmf_small.hip
-int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0);                                                          // cmf_small.hip
+bool sk_can_fuse_h(const cmf_handle_s *h); // cmf_small.hip
+int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0, bool update_h = false, float l1 = 0.f, float two_l2 = 0.f);                                                          // cmf_small.hip
 int read_scalar(cmf_handle_s *h, int slot, double *v);
 int w_partial_impl(cmf_handle_s *h);
 int w_partial_half_impl(cmf_handle_s *h, int den);
@@ -675,13 +679,18 @@ static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel
             if (p[j] == sentinel) return false;
         return true;
     };
+    // The liveness checks below are made after 50 ms of waiting and every 50 ms from then on, not every few thousand polls:
+    // hipStreamQuery makes the runtime put a marker packet (a barrier with a system-scope release) into the stream when the last
+    // command carries no signal, and the device paid for it -- 5.9 us between the loss conv and the next iteration's first
+    // contraction, every iteration whose loss took longer than the first 4096 polls (profiles/r06_stream_query_gap.txt).
     const auto t_begin = std::chrono::steady_clock::now();
+    auto next_check = t_begin + std::chrono::milliseconds(50);
     for (unsigned spins = 1;; ++spins) {
         if (all_there()) {
             std::atomic_thread_fence(std::memory_order_acquire);
             return CMF_OK;
         }
-        if ((spins & 0xFFF) == 0) {
+        if ((spins & 0x3FF) == 0 && std::chrono::steady_clock::now() >= next_check) {
             // (enqueue workers that are still posting leave the stream idle: only a stream that has been given all its work
             // and has drained it proves that the words will never come)
             const hipError_t e = (enqueued && !(*enqueued)()) ? hipErrorNotReady : hipStreamQuery(stream);
@@ -691,8 +700,8 @@ static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel
             }
             if (e != hipErrorNotReady) return fail(CMF_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
             if (health) CMFTRY((*health)());
-            if ((spins & 0xFFFFF) == 0 &&
-                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > wait_timeout_s())
+            next_check = std::chrono::steady_clock::now() + std::chrono::milliseconds(50);
+            if (std::chrono::duration<double>(next_check - t_begin).count() > wait_timeout_s())
                 return fail(health ? CMF_ERR_COMM : CMF_ERR_HIP, "no loss arrived within %.0f s (CMF_WAIT_TIMEOUT_S): %s", wait_timeout_s(),
                             health ? "a collective of the group did not complete -- is every rank / device of the group still running?"
                                    : "the device did not finish the iteration");

@@ -37,8 +37,18 @@ int hxt_contract_small(cmf_handle_s *h, const float *X0, const float *X1, int ns
 }
 
 // C3 for few components: Wj pack, then ONE launch that forms G = Wf x XT (a plain GEMM over n) tile by tile and folds the lag sum
-// out[t][k] = sum_l G[(k, l)][t + l] on chip, into hslabs [2][nsrc][Tl][K32]
-int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
+// out[t][k] = sum_l G[(k, l)][t + l] on chip, into hslabs [2][nsrc][Tl][K32].  update_h (sk_can_fuse_h): mult.jl:51-52 in the same launch.
+// By default only where the launch is several rounds of workgroups long (no split of the reduction over n): the update of a block
+// then hides behind other workgroups' MFMA loops (N = 250, T = 50000, K = 5: the iteration 0.2006 -> 0.1935 ms), while on a
+// one-round launch every block completes at the end and the chain drain -> ticket -> slab loads is longer than a launch boundary
+// (BASELINE configs[0], 8 pieces: 36.5 -> 45.8 us; option small_k_fuse = 2 fuses there too -- tests).
+bool sk_can_fuse_h(const cmf_handle_s *h)
+{
+    return h->sk_tc && h->sk_fuse && (h->sk3_NS == 1 || h->sk_fuse == 2) && h->sk_cnt && h->sk3_MG == 1 &&
+           (double)4 * h->sk3_NS * h->d.Tl * h->d.K32 * 4.0 < 2147483648.0;
+}
+
+int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0, bool update_h, float l1, float two_l2)
 {
     ProfScope prof_(h, nsrc == 2 ? PROF_TRANSCONV : PROF_TRANSCONV_1);
     const CmfDims &d = h->d;
@@ -53,6 +63,11 @@ int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0)
     p.TP = d.TP; p.PADL = d.PADL; p.JP = h->sk3_JP; p.MG = h->sk3_MG; p.TG = h->sk_TG; p.N2 = (int)rup(d.N, 2); p.Np = d.Np; p.nsrc = nsrc;
     p.Tl = d.Tl; p.K = d.K; p.L = d.L; p.K32 = d.K32; p.Kg = h->sk3_Kg; p.RV = h->sk3_RV;
     p.NS = h->sk3_NS; p.RPS = h->sk3_RPS;
+    p.H = nullptr; p.Ht = nullptr; p.cnt = nullptr; p.target = 0; p.l1 = l1; p.two_l2 = two_l2;
+    if (update_h) {
+        if (nsrc != 2 || !sk_can_fuse_h(h)) return fail(CMF_ERR_STATE, "internal: this handle cannot update H inside the C3 launch");
+        p.H = h->H; p.Ht = h->Ht; p.cnt = h->sk_cnt; p.target = 2 * nsrc * h->sk3_NS;
+    }
     const dim3 grid(h->sk_TG / 128 + 1, nsrc * h->sk3_MG * h->sk3_NS);
     switch (h->sk3_MBW) {
 #define CASE(M_) case M_: if (h->sk3_RV) hipLaunchKernelGGL((g_gemm_fold_small_kernel<(M_ <= 3 ? M_ : 3), SK_RVT>), grid, dim3(256), 0, h->stream, p); /* (1-3 MFMA blocks + VALU rows) */ \

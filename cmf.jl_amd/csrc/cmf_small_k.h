@@ -363,7 +363,94 @@ struct SkGemmParams {
     int Tl, K, L, K32, Kg;
     int RV;           // rows [32 * MBW, 32 * MBW + RV) of the (single) row group are contracted on the VALU (RVT kernels)
     int NS, RPS;      // short recordings: the reduction over n is cut into NS pieces of RPS rounds (8 rows of n each), piece q writes slabs 2q, 2q + 1
+    // H != NULL (two sources, one row group): the element-wise update of H (mult.jl:51-52) runs INSIDE this launch -- whichever
+    // workgroup completes a 128-column block's slabs updates that block (sk_h_update_block)
+    float *H, *Ht;    // [TP][K32], [K32][TP]
+    int *cnt;         // a ticket counter per 128-column block, zero between launches (the last arriver resets its own)
+    int target;       // arrivals per block: 2 * nsrc * NS (its own tile's workgroups and the next tile's, whose spill it takes)
+    float l1, two_l2;
 };
+
+// 16-byte agent-scope (sc1, write-through) accesses of the slabs that change hands inside the launch (cdna_hip_programming.md
+// section 6 Guideline 16, R1: the storing waves drain, one lane draws the ticket)
+typedef unsigned int sk_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sk_store4_sc1(__amdgpu_buffer_rsrc_t r, int voff, int soff, f32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sk_u32x4, v), r, voff, soff, 16);
+}
+__device__ __forceinline__ f32x4 sk_load4_sc1(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));
+}
+
+// mult.jl:51-52 on the 128 columns of block b, by the workgroup whose ticket completed the block: num / den = the sums of the
+// 2 NS slabs of either source in h_update_kernel's order (four partial sums over every fourth slab, then ((p0 + p1) + p2) + p3:
+// bit for bit the separate launch's H), H row by row, H' through LDS (stage: 16 rows of 129 floats).
+__device__ __forceinline__ void sk_h_update_block(const SkGemmParams &p, int b, float *stage, int tid)
+{
+    const int nk4 = (p.K + 3) >> 2, t0 = b * 128, S = 2 * p.NS;
+    const int slab_bytes = p.Tl * p.K32 * 4; // (the host takes this form only while all slabs lie below 2 GiB)
+    const __amdgpu_buffer_rsrc_t rs = cmf_rsrc(p.out, (size_t)S * 2 * slab_bytes);
+    for (int e = tid; e < 128 * nk4; e += 256) {
+        const int tt = e / nk4, k4 = e - tt * nk4, t = t0 + tt;
+        f32x4 hn = {0.f, 0.f, 0.f, 0.f};
+        if (t < p.Tl) {
+            const int voff = (t * p.K32 + 4 * k4) * 4;
+            f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0, n2 = n0, n3 = n0, d0 = n0, d1 = n0, d2 = n0, d3 = n0;
+            for (int s = 0; s < S; s += 4) { // (S is even: slabs s, s + 1 exist)
+                const f32x4 a0 = sk_load4_sc1(rs, voff, (2 * s) * slab_bytes), b0 = sk_load4_sc1(rs, voff, (2 * s + 1) * slab_bytes);
+                const f32x4 a1 = sk_load4_sc1(rs, voff, (2 * s + 2) * slab_bytes), b1 = sk_load4_sc1(rs, voff, (2 * s + 3) * slab_bytes);
+                n0 += a0; d0 += b0; n1 += a1; d1 += b1;
+                if (s + 2 < S) {
+                    const f32x4 a2 = sk_load4_sc1(rs, voff, (2 * s + 4) * slab_bytes), b2 = sk_load4_sc1(rs, voff, (2 * s + 5) * slab_bytes);
+                    const f32x4 a3 = sk_load4_sc1(rs, voff, (2 * s + 6) * slab_bytes), b3 = sk_load4_sc1(rs, voff, (2 * s + 7) * slab_bytes);
+                    n2 += a2; d2 += b2; n3 += a3; d3 += b3;
+                }
+            }
+            const f32x4 num = ((n0 + n1) + n2) + n3, den = ((d0 + d1) + d2) + d3;
+            f32x4 *hp = reinterpret_cast<f32x4 *>(p.H + (size_t)(p.PADL + t) * p.K32 + 4 * k4);
+            const f32x4 x = *hp;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hn[c] = (4 * k4 + c < p.K) ? cmf_mu(x[c], num[c], den[c], p.l1, p.two_l2) : 0.f;
+            *hp = hn;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) stage[(4 * k4 + c) * 129 + tt] = hn[c];
+    }
+    __syncthreads();
+    for (int e = tid; e < 4 * nk4 * 128; e += 256) {
+        const int kk = e >> 7, tt = e & 127;
+        if (t0 + tt < p.Tl) p.Ht[(size_t)kk * p.TP + p.PADL + t0 + tt] = stage[kk * 129 + tt];
+    }
+    __syncthreads();
+}
+
+// The end of a workgroup of the fused form: its slab stores (all sc1) drained by every wave, one lane draws a ticket on its own
+// block and on the block in front (whose last L - 1 columns it has just completed); a ticket that is the block's last makes this
+// workgroup the one that updates the block.  lds: at least 16 * 129 floats nobody else uses any more.
+__device__ __forceinline__ void sk_tickets_and_updates(const SkGemmParams &p, bool own, float *lds, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave
+    __syncthreads();
+    int *word = reinterpret_cast<int *>(lds);
+    if (tid < 2) { // lane 0: the own block's ticket, lane 1: the ticket of the block in front -- both in flight together
+        const int b = (int)blockIdx.x - tid;
+        int last = 0;
+        if (tid == 0 ? own : b >= 0) {
+            last = __hip_atomic_fetch_add(p.cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.target - 1;
+            if (last) __hip_atomic_store(p.cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (zero again for the next launch)
+        }
+        // No acquire: every load of a slab in this launch is an sc1 load (sk_h_update_block; they are L2-served), every slab byte was
+        // stored sc1 and drained before its workgroup's tickets, and nothing has read these lines since the launch began, so neither
+        // this CU's L1 nor this XCD's L2 can hold an older copy (cdna_hip_programming.md section 6 Guideline 16, Rule).
+        word[tid] = last;
+    }
+    __syncthreads();
+    const int lo = word[0], lp = word[1];
+    __syncthreads(); // (the words are read before the staging below overwrites them)
+    if (lp) sk_h_update_block(p, (int)blockIdx.x - 1, lds, tid);
+    if (lo) sk_h_update_block(p, (int)blockIdx.x, lds, tid);
+}
 
 // One staged block of the G tile folded into outs: thread (output column t = c0 - (L-1) + tid) adds rows row0 .. row0 + nrows of the
 // group -- row r is (component, lag) = (r / L, r % L), the same for every thread, so the bookkeeping is scalar -- at columns
@@ -436,6 +523,16 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
     float *slab0 = p.out + ((size_t)2 * q * p.nsrc + src) * Tl * K32 + kbase;
     float *slab1 = slab0 + (size_t)p.nsrc * Tl * K32;
     if (c0 >= p.TG) { // nothing spills into the last block
+        if (p.H) { // (fused form: kw is a multiple of 4)
+            const __amdgpu_buffer_rsrc_t r1 = cmf_rsrc(slab1, (size_t)Tl * K32 * 4);
+            const int nk4 = kw >> 2;
+            for (int e = tid; e < 128 * nk4; e += 256) {
+                const int tt = e / nk4, k4 = e - tt * nk4, t = c0 - 128 + tt;
+                if (t >= 0 && t < Tl) sk_store4_sc1(r1, (t * K32 + 4 * k4) * 4, 0, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+            sk_tickets_and_updates(p, false, tile, tid);
+            return;
+        }
         for (int e = tid; e < 128 * kw; e += 256) {
             const int tt = e / kw, kk = e - tt * kw, t = c0 - 128 + tt;
             if (t >= 0 && t < Tl) slab1[(size_t)t * K32 + kk] = 0.f;
@@ -539,6 +636,27 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
         }
     }
     __syncthreads();
+    if (p.H) { // the slabs change hands inside the launch: 16-byte sc1 stores, then the tickets (kw is a multiple of 4, one row group)
+        const __amdgpu_buffer_rsrc_t r0 = cmf_rsrc(slab0, (size_t)Tl * K32 * 4), r1 = cmf_rsrc(slab1, (size_t)Tl * K32 * 4);
+        const int nk4 = kw >> 2, spill0 = 128 - (L - 1);
+        for (int e = tid; e < 128 * nk4; e += 256) {
+            const int tt = e / nk4, k4 = e - tt * nk4;
+            const int ts = tt >= spill0 ? tt - spill0 : 0;
+            f32x4 v0, v1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int kk = 4 * k4 + c, kc = kk < kn ? kk : 0;
+                const float o0 = outs[kc * SK_FOLD_COLS + tt + (L - 1)], o1 = outs[kc * SK_FOLD_COLS + ts];
+                v0[c] = kk < kn ? o0 : 0.f;
+                v1[c] = (kk < kn && tt >= spill0) ? o1 : 0.f;
+            }
+            const int t = c0 + tt, tp = t - 128;
+            if (t < Tl) sk_store4_sc1(r0, (t * K32 + 4 * k4) * 4, 0, v0);
+            if (tp >= 0 && tp < Tl) sk_store4_sc1(r1, (tp * K32 + 4 * k4) * 4, 0, v1);
+        }
+        sk_tickets_and_updates(p, true, tile, tid);
+        return;
+    }
     for (int e = tid; e < 128 * kw; e += 256) {
         const int tt = e / kw, kk = e - tt * kw;
         const int t = c0 + tt; // own block: slab 0

@@ -181,7 +181,8 @@ int cmf_synchronize(cmf_handle h);
  * code (e.g. 22703) and, when path != NULL, the file it was loaded from.  CMF_ERR_COMM when no RCCL can be loaded. */
 int cmf_rccl_version(int *version, char *path, int64_t path_len);
 /* Event counters of a handle.  "hals_pipeline_reruns": H sweeps whose persistent pipeline ran out of a bounded wait and
- * were redone from the snapshot on the stage pipeline (cmf_hals_update_feature_maps).  Group handles: "enqueue_ns" /
+ * were redone from the snapshot on the stage pipeline (cmf_hals_update_feature_maps).  "small_k_fused_h_updates": H updates of
+ * the MU rule that ran inside the few-component contraction launch (option "small_k_fuse").  Group handles: "enqueue_ns" /
  * "enqueue_iters" = nanoseconds the calling thread spent enqueueing (or posting to the enqueue workers) the pipelined
  * iterations of cmf_iterate, and how many iterations that covers; "worker_ns" = time the busiest enqueue worker spent
  * inside its jobs (0 without workers). */
@@ -225,6 +226,10 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       the shapes the reference publishes on (README.md K = 5; figures/fast_bcd/synthetic_comparison.jl:58-64) run 2-3 times
  *       faster.  tensor_transconv keeps the general kernel when T is too short to fill the chip with its GEMM form; 2 = the
  *       few-component form whatever T is; 0 = the general kernels for every K.  Same arithmetic, another summation order.
+ *   "small_k_fuse" (default 1): with the few-component kernels the element-wise update of H (mult.jl:51-52) runs inside the
+ *       launch of the contraction before it -- the workgroup that completes a 128-column block's partial sums updates the
+ *       block -- instead of in a launch of its own, where that launch is several rounds of workgroups long; bit for bit the
+ *       same H (0 = the separate launch always; 2 = the fused form also on short launches, where it is slower; tests compare).
  *   "hals_prepare": allocate the HALS rule's scratch and check its shape limits now (see the HALS entries).
  *   "hals_persist" (default 1): how the H sweep of the HALS rule runs.  1 = as ONE persistent launch where its grid fits the chip
  *       (K sweepers + 4 (K-1) pullers, one workgroup per CU), 0 = one launch per pipeline stage, n > 1 = the persistent launch with at

@@ -150,7 +150,7 @@ def test_every_option_name_is_accepted_and_unknown_names_are_refused(cmf, oracle
     data, _, _ = oracle.c_gen_synthetic(N=24, T=200, K=3, L=6, seed=2)
     W0, H0 = oracle.c_init_rand(data, L=6, K=4, seed=1)
     lib = cmf.load_library()
-    defaults = {"reuse_est": 1, "speculate": 1, "gram": 0, "conv_kernel": 0, "conv_split": 1, "small_k": 1, "hals_prepare": 1, "hals_gram": 2,
+    defaults = {"reuse_est": 1, "speculate": 1, "gram": 0, "conv_kernel": 0, "conv_split": 1, "small_k": 1, "small_k_fuse": 1, "hals_prepare": 1, "hals_gram": 2,
                 "hals_persist": 1, "hals_general": 0, "hals_seg": 384, "hals_lag": 2, "hals_debug": 0, "hals_chase": -1, "profile": 0, "profile_mask": 0,
                 "allreduce_overlap": 0, "enqueue_threads": 1, "halo_in_allreduce": 1}
     assert sorted(defaults) == sorted(option_names(lib))

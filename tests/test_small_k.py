@@ -177,3 +177,42 @@ def test_every_shape_with_every_buffer_an_allocation_of_its_own(cmf):
             rule.close()
         for a, b in zip(*out):
             assert np.array_equal(a, b), (N, T, K, L)
+
+
+def test_h_update_inside_the_c3_launch_is_bitwise_the_separate_launch(cmf):
+    """Option small_k_fuse (default 1): the workgroup whose ticket completes a 128-column block's slabs (its own tile's and the next
+    tile's spill, every piece of the reduction over n) runs mult.jl:51-52 on that block inside g_gemm_fold_small_kernel -- sc1 slab
+    stores, drained, agent-scope tickets, an acquire and sc1 loads on the updating side -- with h_update_kernel's summation order: the
+    same bits as the launch of its own, on every shape (1 .. 8 pieces, T below / across 128-column blocks, the last block empty),
+    iteration after iteration (the counters must be back at zero), also while another handle keeps the chip unevenly busy."""
+    busy_data = np.random.default_rng(5).random((300, 30000))
+    busy = cmf.MultUpdate(busy_data, *cmf.init_rand(busy_data, L=12, K=32, seed=3))
+    fused_somewhere = 0
+    try:
+        for (N, T, K, L) in SHAPES + [(250, 50000, 5, 20), (64, 128 * 7 - 3, 5, 4), (64, 128 * 7 + 1, 8, 2)]:
+            rng = np.random.default_rng(N * 7 + T)
+            data = rng.random((N, T))
+            W0 = np.asfortranarray(rng.random((K, N, L)))
+            H0 = np.asfortranarray(rng.random((K, T)))
+            out = []
+            for fuse in (1, 0):
+                rule = cmf.MultUpdate(data, W0, H0)
+                rule.set_option("small_k", 2)
+                rule.set_option("small_k_fuse", 2 * fuse)  # (2: also where the reduction over n is cut into pieces)
+                ls = []
+                for rep in range(3):
+                    if fuse:
+                        busy.update_motifs()  # (asynchronous: the other handle's launches run beside this one's)
+                    ls += list(rule.iterate(2, l1W=0.1, l2W=0.5, l1H=0.1, l2H=0.2))
+                    rule.update_motifs(l1W=0.1)
+                    ls.append(rule.update_feature_maps(l2H=0.3))
+                ls += list(rule.iterate(2, eval_mode=True))  # H updates in a row
+                out.append((np.array(ls),) + rule.download())
+                if fuse:
+                    fused_somewhere += rule.counter("small_k_fused_h_updates") > 0
+                rule.close()
+            for a, b in zip(*out):
+                assert np.array_equal(a, b), (N, T, K, L)
+    finally:
+        busy.close()
+    assert fused_somewhere >= 20  # (shapes with more than one row group of components keep the separate launch)
