@@ -591,7 +591,7 @@ static int w_phase_impl(cmf_handle_s *h, double l1W, double l2W)
         carry = h->carry;
         h->carry = CmfLossCarry{};
     }
-    hipLaunchKernelGGL(w_update_small_kernel, dim3(d.Np / 64, d.L, d.K), dim3(256), 0, h->stream, h->Wt, h->Wn, h->sk_tc ? h->sk_Wj : nullptr, h->sk_slabs,
+    hipLaunchKernelGGL(w_update_small_kernel, dim3(d.Np / 64 + 1, d.L, d.K), dim3(256), 0, h->stream, h->Wt, h->Wn, h->sk_tc ? h->sk_Wj : nullptr, h->sk_slabs,
                        h->sk_ngroups, d.N, d.K, d.L, d.Np, d.K32, h->sk_JP, h->sk3_Kg, h->sk3_GR, h->sk3_JP,
                        (float)l1W, (float)(2.0 * l2W), carry); // mult.jl:37-38
     KCHK("w_update_small_kernel");

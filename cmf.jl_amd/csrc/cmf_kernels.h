@@ -1462,10 +1462,26 @@ static __global__ __launch_bounds__(256) void h_update_kernel(float *H, float *H
     const f32x4 *sd = reinterpret_cast<const f32x4 *>(denp);
     const size_t ns4 = num_stride / 4, ds4 = den_stride / 4;
     f32x4 num = {0.f, 0.f, 0.f, 0.f}, den = {0.f, 0.f, 0.f, 0.f};
+    f32x4 *hp = reinterpret_cast<f32x4 *>(H + (size_t)(PADL + (t < Tl ? t : 0)) * K32 + (k < K ? k : 0));
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (g == 0 && t < Tl && k < K) x = *hp; // (requested with the slabs, not behind their sum)
     if (t < Tl && k < K) { // (a group of four components that lies wholly in the padding of the k block reads nothing: K = 5 of 32)
         const size_t idx = ((size_t)t * K32 + k) / 4;
-        for (int s = g; s < Snum; s += 4) num += sn[(size_t)s * ns4 + idx];
-        for (int s = g; s < Sden; s += 4) den += sd[(size_t)s * ds4 + idx];
+        // (up to four slabs of either sum in flight per thread, added in slab order: one at a time the loop is a chain of round trips)
+        for (int s0 = g; s0 < Snum || s0 < Sden; s0 += 16) {
+            f32x4 vn[4], vd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sl = s0 + 4 * u;
+                vn[u] = sn[(size_t)(sl < Snum ? sl : 0) * ns4 + idx];
+                vd[u] = sd[(size_t)(sl < Sden ? sl : 0) * ds4 + idx];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (s0 + 4 * u < Snum) num += vn[u];
+                if (s0 + 4 * u < Sden) den += vd[u];
+            }
+        }
     }
     if (g > 0) {
         red[g - 1][e][0] = num;
@@ -1480,8 +1496,6 @@ static __global__ __launch_bounds__(256) void h_update_kernel(float *H, float *H
         }
         f32x4 hn = {0.f, 0.f, 0.f, 0.f};
         if (t < Tl && k < K) { // (the padding stays the zero it is)
-            f32x4 *hp = reinterpret_cast<f32x4 *>(H + (size_t)(PADL + t) * K32 + k);
-            const f32x4 x = *hp;
 #pragma unroll
             for (int c = 0; c < 4; ++c) hn[c] = (k + c < K) ? cmf_mu(x[c], num[c], den[c], l1, two_l2) : 0.f;
             *hp = hn;
@@ -1513,12 +1527,21 @@ __device__ __forceinline__ void cmf_block_loss_reduce(const CmfLossCarry &c)
 {
     __shared__ double red[256];
     double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int base = threadIdx.x; base < c.n; base += 8 * 256) {
-        double v[8];
+    // four passes of eight loads in flight together (a pass at a time this was a chain of round trips -- 6000 partials are three of
+    // them, on the critical path of a 5 us launch); added pass after pass: the sums of the one-pass loop, bit for bit
+    for (int base = threadIdx.x; base < c.n; base += 4 * 8 * 256) {
+        double v[4][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (base + 256 * u < c.n) ? c.partial[base + 256 * u] : 0.0;
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s[u] += v[u];
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + 2048 * q + 256 * u;
+                v[q][u] = c.partial[e < c.n ? e : 0];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += (base + 2048 * q + 256 * u < c.n) ? v[q][u] : 0.0;
     }
     red[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();

@@ -285,7 +285,7 @@ static __global__ __launch_bounds__(256) void slab_sum_small_kernel(float *out, 
 // updated (mult.jl:37-38) in both layouts, and the A operand of the C3 GEMM (Wj, layout of wj_pack_kernel) is written from the same
 // values -- the slab sum, the update and the pack were three launches of 5-8 us each on a 250 us iteration.  The last block also
 // performs a loss reduction deferred by cmf_iterate.  slabs: [nslabs][2][JP][Np].
-// grid (Np/64, L, K), block 256: one (lag, component) row and 64 units per workgroup; its four 64-thread groups each sum every fourth
+// grid (Np/64 + 1, L, K), block 256: one (lag, component) row and 64 units per workgroup (the last column: the loss reduction); its four 64-thread groups each sum every fourth
 // slab (all loads of a thread independent and in flight together) and are combined in a fixed order through LDS, so the result does
 // not depend on timing.  (The first form -- one workgroup per lag, the slabs added one after the other by each thread -- was 80
 // workgroups of dependent loads: 14 us, as long as the three launches it replaced.)
@@ -294,10 +294,16 @@ static __global__ __launch_bounds__(256) void w_update_small_kernel(float *Wt, f
                                                               float l1, float two_l2, CmfLossCarry carry)
 {
     __shared__ float red[3][64][2];
+    if (blockIdx.x == gridDim.x - 1) { // the extra column of the grid: one of its blocks performs the carried loss reduction, beside the others
+        if (carry.partial && blockIdx.y == 0 && blockIdx.z == 0) cmf_block_loss_reduce(carry); // (behind a block's own update it was the launch's critical path)
+        return;
+    }
     const int nn = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + nn, l = blockIdx.y, k = blockIdx.z;
     const size_t sstride = (size_t)2 * JP * Np;
     const float *bn = slabs + (size_t)(l * K + k) * Np + n, *bd = bn + (size_t)JP * Np;
+    const size_t it = ((size_t)l * K32 + k) * Np + n;
+    const float w_old = (g == 0) ? Wt[it] : 0.f; // (requested with the slabs, not behind their sum)
     float num = 0.f, den = 0.f;
     for (int s0 = g; s0 < nslabs; s0 += 32) { // eight slabs of this group per pass
         float a[8], b[8];
@@ -323,8 +329,7 @@ static __global__ __launch_bounds__(256) void w_update_small_kernel(float *Wt, f
             num += red[q][nn][0];
             den += red[q][nn][1];
         }
-        const size_t it = ((size_t)l * K32 + k) * Np + n;
-        const float wn = (n < N) ? cmf_mu(Wt[it], num, den, l1, two_l2) : 0.f;
+        const float wn = (n < N) ? cmf_mu(w_old, num, den, l1, two_l2) : 0.f;
         Wt[it] = wn;
         Wn[((size_t)l * Np + n) * K32 + k] = wn;
         if (Wj) {
@@ -332,7 +337,6 @@ static __global__ __launch_bounds__(256) void w_update_small_kernel(float *Wt, f
             Wj[(size_t)n * JP3 + gq * GR + (k - gq * Kg) * L + l] = wn;
         }
     }
-    if (carry.partial && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) cmf_block_loss_reduce(carry);
 }
 
 // C3 puts whole components into a row group: group g holds the components [g*Kg, (g+1)*Kg), its row kl*L + l is
