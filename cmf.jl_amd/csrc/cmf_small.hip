@@ -63,6 +63,9 @@ int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0, bool upd
     p.TP = d.TP; p.PADL = d.PADL; p.JP = h->sk3_JP; p.MG = h->sk3_MG; p.TG = h->sk_TG; p.N2 = (int)rup(d.N, 2); p.Np = d.Np; p.nsrc = nsrc;
     p.Tl = d.Tl; p.K = d.K; p.L = d.L; p.K32 = d.K32; p.Kg = h->sk3_Kg; p.RV = h->sk3_RV;
     p.NS = h->sk3_NS; p.RPS = h->sk3_RPS;
+    p.TS = std::max(SK_TILE_STRIDE, (int)rup(128 + 2 * (d.L - 1), 4)); // (a staged row: L - 1 zeros, 128 columns, L - 1 zeros)
+    if (p.TS % 32 == 0) p.TS += 4;
+    const size_t lds = (size_t)32 * p.TS * sizeof(float);
     p.H = nullptr; p.Ht = nullptr; p.cnt = nullptr; p.target = 0; p.l1 = l1; p.two_l2 = two_l2;
     if (update_h) {
         if (nsrc != 2 || !sk_can_fuse_h(h)) return fail(CMF_ERR_STATE, "internal: this handle cannot update H inside the C3 launch");
@@ -70,8 +73,8 @@ int launch_transconv_small(cmf_handle_s *h, int nsrc, const float *xt0, bool upd
     }
     const dim3 grid(h->sk_TG / 128 + 1, nsrc * h->sk3_MG * h->sk3_NS);
     switch (h->sk3_MBW) {
-#define CASE(M_) case M_: if (h->sk3_RV) hipLaunchKernelGGL((g_gemm_fold_small_kernel<(M_ <= 3 ? M_ : 3), SK_RVT>), grid, dim3(256), 0, h->stream, p); /* (1-3 MFMA blocks + VALU rows) */ \
-                 else hipLaunchKernelGGL((g_gemm_fold_small_kernel<M_>), grid, dim3(256), 0, h->stream, p); break;
+#define CASE(M_) case M_: if (h->sk3_RV) hipLaunchKernelGGL((g_gemm_fold_small_kernel<(M_ <= 3 ? M_ : 3), SK_RVT>), grid, dim3(256), lds, h->stream, p); /* (1-3 MFMA blocks + VALU rows) */ \
+                 else hipLaunchKernelGGL((g_gemm_fold_small_kernel<M_>), grid, dim3(256), lds, h->stream, p); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6)
 #undef CASE
     default: return fail(CMF_ERR_STATE, "internal: bad m block count %d", h->sk3_MBW);

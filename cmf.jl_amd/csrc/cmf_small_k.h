@@ -354,7 +354,7 @@ static __global__ __launch_bounds__(256) void wj_pack_kernel(const float *Wn, fl
     }
 }
 
-#define SK_TILE_STRIDE 132 // floats between the rows of the staged G block (128 columns + padding)
+#define SK_TILE_STRIDE 132 // least number of floats between the rows of the staged G block (SkGemmParams::TS)
 #define SK_FOLD_COLS 192   // 128 + L - 1 <= 191 output columns of a workgroup (L <= SK_MAXL)
 
 struct SkGemmParams {
@@ -366,6 +366,7 @@ struct SkGemmParams {
     int TP, PADL, JP, MG, TG, N2, Np, nsrc;
     int Tl, K, L, K32, Kg;
     int RV;           // rows [32 * MBW, 32 * MBW + RV) of the (single) row group are contracted on the VALU (RVT kernels)
+    int TS;           // floats between the staged rows of the G tile in LDS: >= 128 + 2 (L - 1) (launch_transconv_small: 32 TS floats of dynamic LDS)
     int NS, RPS;      // short recordings: the reduction over n is cut into NS pieces of RPS rounds (8 rows of n each), piece q writes slabs 2q, 2q + 1
     // H != NULL (two sources, one row group): the element-wise update of H (mult.jl:51-52) runs INSIDE this launch -- whichever
     // workgroup completes a 128-column block's slabs updates that block (sk_h_update_block)
@@ -458,20 +459,20 @@ __device__ __forceinline__ void sk_tickets_and_updates(const SkGemmParams &p, bo
 
 // One staged block of the G tile folded into outs: thread (output column t = c0 - (L-1) + tid) adds rows row0 .. row0 + nrows of the
 // group -- row r is (component, lag) = (r / L, r % L), the same for every thread, so the bookkeeping is scalar -- at columns
-// trel + lag.  All NR reads are issued FIRST, branch-free (column clamped, value masked): as a loop of guarded reads the fold was a
-// chain of NR dependent LDS round trips per block, 13.7 us of a 64 us launch at K = 5, L = 20 (in-kernel stamps, round 5); the
-// sums are taken in the same order as before (bitwise the same result).
+// trel + lag.  All NR reads are issued FIRST, branch-free: as a loop of guarded reads the fold was a chain of NR dependent LDS round
+// trips per block, 13.7 us of a 64 us launch at K = 5, L = 20 (in-kernel stamps, round 5).  Round 6: a staged row carries L - 1 zero
+// columns on either side, so a read needs no range test (clamp + two selects per row before: 8 VALU instructions per row, 2 now --
+// beside other workgroups' fp32 MFMA loops every VALU instruction queues behind a 64-cycle MFMA, and a fold block took 9.3 us there
+// against 1.4 alone: profiles/r06_c3_tail_pieces.txt).  The sums are taken in the same order as ever (bitwise the same result).
 template <int NR>
-__device__ __forceinline__ void sk_fold_rows(const float *tile, float *outs, int trel, int tid, int L, int kn, int row0, int nrows)
+__device__ __forceinline__ void sk_fold_rows(const float *tile, int TS, float *outs, int tid, int L, int kn, int row0, int nrows)
 {
     const int kk0 = row0 / L, ll0 = row0 - kk0 * L;
     float v[NR];
     int ll = ll0;
 #pragma unroll
-    for (int rl = 0; rl < NR; ++rl) {
-        const unsigned col = (unsigned)(trel + ll);
-        const float x = tile[rl * SK_TILE_STRIDE + (col < 128u ? col : 0u)];
-        v[rl] = col < 128u ? x : 0.f;
+    for (int rl = 0; rl < NR; ++rl) { // (row rl, G column t + ll: the L - 1 zero columns on either side of a staged row stand for the columns outside the tile)
+        v[rl] = tile[rl * TS + tid + ll];
         ll = (ll + 1 == L) ? 0 : ll + 1;
     }
     int kk = kk0;
@@ -511,10 +512,11 @@ template <int MBW, int RVT = 0>
 __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kernel(SkGemmParams p)
 {
     static_assert(RVT == 0 || RVT == 4, "the VALU rows are read as one b128");
-    __shared__ __attribute__((aligned(16))) float tile[32 * SK_TILE_STRIDE];
+    extern __shared__ __attribute__((aligned(16))) float tile[]; // 32 staged rows of TS floats: L - 1 zeros | 128 columns of G | L - 1 zeros (| padding)
     __shared__ float outs[16 * SK_FOLD_COLS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
+    const int TS = p.TS;
     const int src = blockIdx.y % p.nsrc, mg = (blockIdx.y / p.nsrc) % p.MG, q = blockIdx.y / (p.nsrc * p.MG);
     const int c0 = blockIdx.x * 128;
     const int L = p.L, K32 = p.K32, Tl = p.Tl;
@@ -618,25 +620,31 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
     }
 
     // the fold: thread c < 128 + L - 1 owns output column t = c0 - (L-1) + c
-    const int trel = tid - (L - 1);
     const bool folder = tid < 128 + L - 1;
 #pragma unroll
     for (int mb = 0; mb < MBW + (RVT > 0 ? 1 : 0); ++mb) {
         __syncthreads(); // (the zero fill of outs / the previous block's reads / the main loops' reads of the VALU rows' operands)
+        if (mb == 0) { // the zero columns on either side of the staged rows (the VALU rows' operands lay here during the main loop)
+            const int m2 = 2 * (L - 1);
+            for (int e = tid; e < 32 * m2; e += 256) {
+                const int r = e / m2, j = e - r * m2;
+                tile[r * TS + (j < L - 1 ? j : 128 + j)] = 0.f;
+            }
+        }
         if (mb < MBW) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tile[cmf_crow(r, h) * SK_TILE_STRIDE + wave * 32 + i] = acc[mb < MBW ? mb : 0][r];
+            for (int r = 0; r < 16; ++r) tile[cmf_crow(r, h) * TS + (L - 1) + wave * 32 + i] = acc[mb < MBW ? mb : 0][r];
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float g = accv[r] + __shfl_xor(accv[r], 32); // the two n parities
-                if (h == 0) tile[r * SK_TILE_STRIDE + wave * 32 + i] = g;
+                if (h == 0) tile[r * TS + (L - 1) + wave * 32 + i] = g;
             }
         }
         __syncthreads();
         if (folder) {
-            if (mb < MBW) sk_fold_rows<32>(tile, outs, trel, tid, L, kn, 32 * mb, 32);
-            else sk_fold_rows<4>(tile, outs, trel, tid, L, kn, 32 * mb, p.RV);
+            if (mb < MBW) sk_fold_rows<32>(tile, TS, outs, tid, L, kn, 32 * mb, 32);
+            else sk_fold_rows<4>(tile, TS, outs, tid, L, kn, 32 * mb, p.RV);
         }
     }
     __syncthreads();
