@@ -43,7 +43,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_PROFILE = "r06_pmc_summary.json"  # rocprofv3 --pmc passes of this round's kernels (profiles/README.md)
+PMC_PROFILE = "r06b_pmc_summary.json"  # rocprofv3 --pmc passes of this round's kernels (profiles/README.md)
 PMC_FALLBACK = "r05_pmc_summary.json"
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 CONFIGS = {
