@@ -464,29 +464,33 @@ __device__ __forceinline__ void sk_tickets_and_updates(const SkGemmParams &p, bo
 // columns on either side, so a read needs no range test (clamp + two selects per row before: 8 VALU instructions per row, 2 now --
 // beside other workgroups' fp32 MFMA loops every VALU instruction queues behind a 64-cycle MFMA, and a fold block took 9.3 us there
 // against 1.4 alone: profiles/r06_c3_tail_pieces.txt).  The sums are taken in the same order as ever (bitwise the same result).
-template <int NR>
+// NB: rows read ahead of their sums (NR, or NR / 2 in the instantiation with the tightest register budget: all NR addresses and values
+// live at once cost it 8 spilled registers)
+template <int NR, int NB = NR>
 __device__ __forceinline__ void sk_fold_rows(const float *tile, int TS, float *outs, int tid, int L, int kn, int row0, int nrows)
 {
-    const int kk0 = row0 / L, ll0 = row0 - kk0 * L;
-    float v[NR];
-    int ll = ll0;
-#pragma unroll
-    for (int rl = 0; rl < NR; ++rl) { // (row rl, G column t + ll: the L - 1 zero columns on either side of a staged row stand for the columns outside the tile)
-        v[rl] = tile[rl * TS + tid + ll];
-        ll = (ll + 1 == L) ? 0 : ll + 1;
-    }
-    int kk = kk0;
-    ll = ll0;
+    static_assert(NR % NB == 0, "whole batches");
+    int kk = row0 / L, ll = row0 - kk * L;
     float s = 0.f;
 #pragma unroll
-    for (int rl = 0; rl < NR; ++rl) {
-        if (rl < nrows) {
-            s += v[rl];
-            if (++ll == L) {
-                if (kk < kn) outs[kk * SK_FOLD_COLS + tid] += s;
-                s = 0.f;
-                ll = 0;
-                ++kk;
+    for (int r0 = 0; r0 < NR; r0 += NB) {
+        float v[NB];
+        int lr = ll;
+#pragma unroll
+        for (int rl = 0; rl < NB; ++rl) { // (row r0 + rl, G column t + lr: the L - 1 zero columns on either side of a staged row stand for the columns outside the tile)
+            v[rl] = tile[(r0 + rl) * TS + tid + lr];
+            lr = (lr + 1 == L) ? 0 : lr + 1;
+        }
+#pragma unroll
+        for (int rl = 0; rl < NB; ++rl) {
+            if (r0 + rl < nrows) {
+                s += v[rl];
+                if (++ll == L) {
+                    if (kk < kn) outs[kk * SK_FOLD_COLS + tid] += s;
+                    s = 0.f;
+                    ll = 0;
+                    ++kk;
+                }
             }
         }
     }
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
         }
         __syncthreads();
         if (folder) {
-            if (mb < MBW) sk_fold_rows<32>(tile, TS, outs, tid, L, kn, 32 * mb, 32);
+            if (mb < MBW) sk_fold_rows<32, (MBW == 4 ? 16 : 32)>(tile, TS, outs, tid, L, kn, 32 * mb, 32);
             else sk_fold_rows<4>(tile, TS, outs, tid, L, kn, 32 * mb, p.RV);
         }
     }

@@ -207,7 +207,8 @@ int cmf_set_stream(cmf_handle h, void *hip_stream);
  *       enqueues the contraction the next update_motifs! starts with (numerator and denominator of mult.jl:31-34 need H, data and
  *       est only; l1W, l2W enter afterwards) behind its loss conv, so that the device works while the loss travels to the host and
  *       the caller's loop comes round; update_motifs! then only applies the update.  Identical results; anything that changes W, H,
- *       est or an option in between discards the work.  Single-GPU handles, MU rule, with "reuse_est".  A caller that stops
+ *       est or an option in between discards the work.  Single-GPU handles, with "reuse_est": the MU rule, and the HALS rule
+ *       (hals.jl:13-38: the contraction of the residual with H_unfold and the lag correlations of H).  A caller that stops
  *       after an update_feature_maps! pays one contraction nobody reads (cmf_get_counter "speculated_contractions" counts the hits).
  *   "gram" (default 0): 1 = form denomW and denomH through Gram matrices (denomW = (H_unfold H_unfold') W,
  *       denomH = lag-Gram taps of W applied to H) instead of through est: exact rewritings of mult.jl:33,48 that
