@@ -1175,7 +1175,12 @@ int cmf_get_counter(cmf_handle h, const char *name, int64_t *value)
     if (std::strcmp(name, "hals_pipeline_reruns") == 0) { *value = h->hals_reruns; return CMF_OK; }
     if (std::strcmp(name, "writeback_calls") == 0) { *value = h->wb ? h->wb->armed_calls : 0; return CMF_OK; }            // cmf_arm_writeback calls
     if (std::strcmp(name, "speculated_contractions") == 0) { *value = h->spec_hits; return CMF_OK; }                         // update_motifs! calls whose C2 contraction was already enqueued
-    if (std::strcmp(name, "small_k_fused_h_updates") == 0) { *value = h->sk_fused_h; return CMF_OK; }                       // H updates that ran inside the few-component C3 launch
+    if (std::strcmp(name, "small_k_fused_h_updates") == 0) { // (a group: over its shards)
+        *value = h->sk_fused_h;
+        if (h->group)
+            for (const cmf_handle_s *s : h->group->sh) *value += (s != h) ? s->sk_fused_h : 0;
+        return CMF_OK;
+    }                       // H updates that ran inside the few-component C3 launch
     if (std::strcmp(name, "writeback_overlapped") == 0) { *value = h->wb ? h->wb->hooked_calls : 0; return CMF_OK; }     // ... served by the copy stream behind the H update
     if (h->group) { // host cost of the pipelined iterations of a group (reading a counter resets nothing)
         cmf_group_s *g = h->group;

@@ -113,6 +113,36 @@ def test_groups_on_the_small_k_kernels(cmf, oracle, R, N, T, K, L):
             np.testing.assert_array_equal(a, b)
 
 
+def test_group_shards_update_h_inside_their_c3_launches(cmf):
+    """Shards long enough for the fused form (the reduction over n uncut): each shard's C3 launch updates its own columns of H --
+    halos on either side, the all-gather of the new halos behind it -- with the same bits as with the separate launch, on every
+    transport of a one-GPU box; and the group agrees with ONE handle to rounding."""
+    from cmf_jl_amd import _lib
+
+    N, T, K, L = 120, 76000, 5, 20
+    rng = np.random.default_rng(9)
+    data = rng.random((N, T))
+    W0 = np.asfortranarray(rng.random((K, N, L)))
+    H0 = np.asfortranarray(rng.random((K, T)))
+    one = cmf.MultUpdate(data, W0, H0)
+    l1 = one.iterate(4, l1H=0.05)
+    W1, H1 = one.download()
+    one.close()
+    for tr in (_lib.CMF_COMM_LOOPBACK, _lib.CMF_COMM_PEER):
+        out = []
+        for fuse in (1, 0):
+            rule = cmf.MultUpdate(data, W0, H0, devices=[0, 0], transport=tr)
+            rule.set_option("small_k_fuse", fuse)
+            ls = rule.iterate(4, l1H=0.05)
+            assert rule.counter("small_k_fused_h_updates") == (8 if fuse else 0)  # 2 shards x 4 iterations
+            out.append((np.asarray(ls),) + rule.download())
+            rule.close()
+        for a, b in zip(*out):
+            assert np.array_equal(a, b)
+        np.testing.assert_allclose(out[0][0], l1, rtol=1e-6)
+        assert frob_rel(out[0][1], W1) < 1e-6 and frob_rel(out[0][2], H1) < 1e-6
+
+
 def test_primitives_and_other_rules_with_few_components(cmf, oracle):
     """tensor_conv / tensor_transconv stand-alone, and the HALS and PGD rules (which share the conv / C2 / C3 launchers) at
     K = 5: against the oracle."""
