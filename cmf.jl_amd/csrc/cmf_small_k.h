@@ -445,9 +445,12 @@ __device__ __forceinline__ void sk_tickets_and_updates(const SkGemmParams &p, bo
             last = __hip_atomic_fetch_add(p.cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.target - 1;
             if (last) __hip_atomic_store(p.cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (zero again for the next launch)
         }
-        // No acquire: every load of a slab in this launch is an sc1 load (sk_h_update_block; they are L2-served), every slab byte was
-        // stored sc1 and drained before its workgroup's tickets, and nothing has read these lines since the launch began, so neither
-        // this CU's L1 nor this XCD's L2 can hold an older copy (cdna_hip_programming.md section 6 Guideline 16, Rule).
+        // The updating side reads every slab with sc1 loads (sk_h_update_block), and nothing has read these lines since the launch began,
+        // so neither this CU's L1 nor this XCD's L2 can hold an older copy; the agent-scope acquire of the last arriver stays
+        // nevertheless (cdna_hip_programming.md section 6 Guideline 16: the measured hand-off table has one workgroup per CU, this
+        // launch three or four) -- it costs about 0.5 % of the iteration here (A / B on one box: 189.4 - 190.3 us with, 188.3 - 189.1 without).
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         word[tid] = last;
     }
     __syncthreads();
