@@ -268,6 +268,9 @@ def other_configs(cmf, rule, data, W0, H0, N, T, K, L, with_config3, device):
                             fl_ = f1_ * (2.0 if nm in ("hxt", "transconv") else 1.0)
                             ks[nm] = {"avg_ms": ms_, "useful_tflops": fl_ / ms_ / 1e9, "frac": fl_ / ms_ / 1e9 / PEAK_FP32_MFMA_TFLOPS}
                         dom = max(ks, key=lambda k_: ks[k_]["avg_ms"])
+                        fused_ = r_.counter("small_k_fused_h_updates") > 0  # (the element-wise H update inside the C3 launch: long launches only)
+                        rec.update(launches_per_step=5 if fused_ else 6,
+                                   launches="C2 | slab sum + W update (+ the carried loss reduction) | conv_t | C3" + (" + H update" if fused_ else " | H update") + " | loss conv")
                         rec.update(ms_per_step=1e3 * dt_, iters_per_s=1.0 / dt_, loss_last=float(ls[-1]), kernels_standalone=ks,
                                    whole_iteration_useful_mfma_frac=6.0 * f1_ / dt_ / (PEAK_FP32_MFMA_TFLOPS * 1e12),
                                    roofline={"bound": "mfma", "kernel": dom + " (few-component kernels; hxt / transconv: both sources, incl. their slab sum / fold)",
