@@ -2090,6 +2090,18 @@ __device__ __forceinline__ float cmf_fma_opaque(float a, float b, float c)
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// Two FMAs in one VALU instruction (v_pk_fma_f32: 4 cycles for the wave, like one v_fma_f32): r = w * b + c for the two rows held in
+// w / c, b = one half of the pair bp (HI = false: bp.x, true: bp.y; op_sel broadcasts it, so two consecutive steps share one
+// register pair).  Opaque to the compiler like cmf_fma_opaque.  Checked against fmaf on the device (tools: see DESIGN.md section 4e).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool HI>
+__device__ __forceinline__ f32x2 cmf_pk_fma_opaque(f32x2 w, f32x2 bp, f32x2 c)
+{
+    f32x2 r;
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(w), "v"(bp), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(w), "v"(bp), "v"(c));
+    return r;
+}
 __device__ __forceinline__ float cmf_lane0(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));

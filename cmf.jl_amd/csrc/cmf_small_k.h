@@ -91,15 +91,16 @@ __global__ __launch_bounds__(256, MBW > 6 ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_sma
         abase[mb] = (j < p.J) ? k * HST + (L - 1) - l + h : K * HST + h;
     }
     for (int c = lane; c < HST; c += 64) Hs[K * HST + c] = Hs[strip + K * HST + c] = 0.f;
-    constexpr int RVN = RVT > 0 ? RVT : 1;
+    constexpr int RVN = RVT > 0 ? RVT : 2; // (the VALU rows go in pairs: one v_pk_fma_f32 per pair and step)
+    static_assert(RVN % 2 == 0, "row pairs");
     int vbase[RVN];
-    float accv[RVN];
+    f32x2 accv[RVN / 2];
 #pragma unroll
     for (int r = 0; r < RVN; ++r) {
         const int j = MBW * 32 + r;
         const int l = j / K, k = j - l * K;
         vbase[r] = (RVT > 0 && r < p.RV && j < p.J) ? k * HST + (L - 1) - l + h : K * HST + h;
-        accv[r] = 0.f;
+        accv[r >> 1][r & 1] = 0.f;
     }
 
     f32x16 acc[MBW];
@@ -118,12 +119,12 @@ __global__ __launch_bounds__(256, MBW > 6 ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_sma
     // element is used by exactly one wave) and one round of MFMAs (2048 cycles) does not cover that latency at two waves per
     // SIMD (round 4 loaded one round ahead and started every 128-row strip with an exposed load).
     constexpr int NS = 4;
-    float bx[NS][8];
+    f32x2 bx[NS][4]; // (a round's 8 X values in register pairs: the VALU rows' packed FMAs take either half)
     const int nrounds = (p.Tl - tc0 <= 0) ? 0 : (((p.chunk_len < p.Tl - tc0 + 15 ? p.chunk_len : ((p.Tl - tc0 + 15) & ~15))) >> 4); // (X rows >= Tl are zero padding: nothing to add behind them)
-    auto xload = [&](float (&b)[8], int rd) {
+    auto xload = [&](f32x2 (&b)[4], int rd) {
         const int rc = (rd < nrounds) ? rd : (nrounds ? nrounds - 1 : 0); // (behind the chunk: a row it owns, never used)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) b[u] = cmf_bload(xr, xoff, (16 * rc + 2 * u) * Np * 4);
+        for (int u = 0; u < 8; ++u) b[u >> 1][u & 1] = cmf_bload(xr, xoff, (16 * rc + 2 * u) * Np * 4);
     };
     // DMA: strip s0 -> buffer dst; two dwords per lane and row k (width <= 127: the second one's lanes behind the width land in the
     // row's padding); 2 K untracked loads, awaited by the counted vmcnt below
@@ -140,32 +141,34 @@ __global__ __launch_bounds__(256, MBW > 6 ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_sma
 #pragma unroll
     for (int q = 0; q < NS - 1; ++q) xload(bx[q], q);
     int dma_s0 = -1, dma_buf = 0; // >= 0: the strip the next round issues behind its first step
-    auto mround = [&](const float (&bc)[8], int r0) { // the MFMAs of one round on strip rows r0 .. r0 + 15
+    auto mround = [&](const f32x2 (&bc)[4], int r0) { // the MFMAs of one round on strip rows r0 .. r0 + 15
         // software-pipelined like conv2_lag: the LDS reads of step u+1 are issued ahead of the MFMAs of step u
-        float a[MBW], va[RVN];
+        float a[MBW];
+        f32x2 va[RVN / 2];
 #pragma unroll
         for (int mb = 0; mb < MBW; ++mb) a[mb] = Hs[abase[mb] + r0];
 #pragma unroll
-        for (int r = 0; r < RVN; ++r) va[r] = RVT > 0 ? Hs[vbase[r] + r0] : 0.f;
+        for (int r = 0; r < RVN; ++r) va[r >> 1][r & 1] = RVT > 0 ? Hs[vbase[r] + r0] : 0.f;
         __builtin_amdgcn_sched_group_barrier(0x100, MBW + RVT, 0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            float an[MBW], van[RVN];
+            float an[MBW];
+            f32x2 van[RVN / 2];
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) an[mb] = 0.f;
 #pragma unroll
-            for (int r = 0; r < RVN; ++r) van[r] = 0.f;
+            for (int r = 0; r < RVN / 2; ++r) van[r] = f32x2{0.f, 0.f};
             if (u + 1 < 8) {
 #pragma unroll
                 for (int mb = 0; mb < MBW; ++mb) an[mb] = Hs[abase[mb] + r0 + 2 * (u + 1)];
                 if (RVT > 0) {
 #pragma unroll
-                    for (int r = 0; r < RVN; ++r) van[r] = Hs[vbase[r] + r0 + 2 * (u + 1)];
+                    for (int r = 0; r < RVN; ++r) van[r >> 1][r & 1] = Hs[vbase[r] + r0 + 2 * (u + 1)];
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, MBW + RVT, 0);
             }
 #pragma unroll
-            for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bc[u], acc[mb], 0, 0, 0);
+            for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], bc[u >> 1][u & 1], acc[mb], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, MBW, 0);
             if (u == 0 && dma_s0 >= 0) { // behind the round's wait for its X set: nothing waits on these loads before the next round's
                 __builtin_amdgcn_sched_barrier(0);
@@ -173,14 +176,14 @@ __global__ __launch_bounds__(256, MBW > 6 ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_sma
                 dma_s0 = -1;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (RVT > 0) { // the VALU rows of this step (operands read a step ago)
-#pragma unroll
-                for (int r = 0; r < RVN; ++r) accv[r] = cmf_fma_opaque(va[r], bc[u], accv[r]); // (opaque: the SLP vectoriser packs plain FMAs into v_pk_fma_f32 and reorders the step around them)
+            if (RVT > 0) { // the VALU rows of this step (operands read a step ago): two rows per instruction -- beside fp32 MFMAs a VALU
+#pragma unroll     // instruction costs the MFMA pipe its four cycles (profiles/r06_c3_tail_pieces.txt) -- opaque to the compiler
+                for (int r = 0; r < RVN / 2; ++r) accv[r] = (u & 1) ? cmf_pk_fma_opaque<true>(va[r], bc[u >> 1], accv[r]) : cmf_pk_fma_opaque<false>(va[r], bc[u >> 1], accv[r]);
             }
 #pragma unroll
             for (int mb = 0; mb < MBW; ++mb) a[mb] = an[mb];
 #pragma unroll
-            for (int r = 0; r < RVN; ++r) va[r] = van[r];
+            for (int r = 0; r < RVN / 2; ++r) va[r] = van[r];
         }
     };
     const int width = SC + L - 1;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256, MBW > 6 ? 2 : (MBW <= 4 ? 4 : 3)) void hxt_sma
     }
     if (RVT > 0) { // the VALU rows: the two time parities of a wave, then the 4 chunks in chunk order
 #pragma unroll
-        for (int r = 0; r < RVN; ++r) red[(wave * 16 + r) * 64 + lane] = accv[r] + __shfl_xor(accv[r], 32);
+        for (int r = 0; r < RVN; ++r) red[(wave * 16 + r) * 64 + lane] = accv[r >> 1][r & 1] + __shfl_xor(accv[r >> 1][r & 1], 32);
         __syncthreads();
         for (int r = wave; r < RVT; r += 4) {
             float sum = red[r * 64 + lane];
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(256, MBW <= 4 ? 4 : 3) void g_gemm_fold_small_kerne
                     for (int mb = 0; mb < MBW; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q % 2][u][mb], b[q % NSB][u], acc[mb], 0, 0, 0);
                     if (RVT > 0) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) accv[r] = cmf_fma_opaque(wv[r], b[q % NSB][u], accv[r]); // (opaque: see hxt_small_kernel)
+                        for (int r = 0; r < 4; ++r) accv[r] = cmf_fma_opaque(wv[r], b[q % NSB][u], accv[r]); // (opaque: see hxt_small_kernel; the packed form is slower here: 60.4 -> 61.2 us)
                         __builtin_amdgcn_sched_barrier(0);
                         wv = wvn;
                     }
