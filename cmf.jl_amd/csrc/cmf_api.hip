@@ -487,7 +487,7 @@ int launch_slab_sum(cmf_handle_s *h, float *out, const float *in, int nslabs, si
         carry = h->carry;
         h->carry = CmfLossCarry{};
     }
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, h->stream, out, in, nslabs, stride, n4, carry, tail);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks + (carry.partial ? 1 : 0)), dim3(256), 0, h->stream, out, in, nslabs, stride, n4, carry, tail);
     KCHK("slab_sum_kernel");
     return CMF_OK;
 }

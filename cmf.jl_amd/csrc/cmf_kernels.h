@@ -1510,6 +1510,30 @@ static __global__ __launch_bounds__(256) void h_update_kernel(float *H, float *H
     }
 }
 
+// A thread's share of the sum of n per-tile loss sums (256 threads; element e goes to thread e % 256, accumulator (e / 256) % 8):
+// four passes of eight loads in flight together, added pass after pass -- bit for bit the sums of the one-pass loop this was (6000
+// partials were three dependent round trips on the critical path of a 5 us launch; config 2's 25 000 twelve, 11.6 us between the
+// loss conv and the host).  Every loss reduction of the library sums in this order.
+__device__ __forceinline__ double cmf_thread_loss_sum(const double *partial, int n)
+{
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int base = threadIdx.x; base < n; base += 4 * 8 * 256) {
+        double v[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + 2048 * q + 256 * u;
+                v[q][u] = partial[e < n ? e : 0];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += (base + 2048 * q + 256 * u < n) ? v[q][u] : 0.0;
+    }
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
 // A loss reduction that rides on another launch (cmf_iterate): the per-tile partials of the loss conv are summed by
 // one block of the NEXT iteration's slab sum instead of by a 4 us launch of their own right behind the conv -- a
 // launch that short in front of the C2 kernel exposes that kernel's dispatch set-up (measured: a 5.6 us hole in an
@@ -1526,24 +1550,7 @@ struct CmfLossCarry {
 __device__ __forceinline__ void cmf_block_loss_reduce(const CmfLossCarry &c)
 {
     __shared__ double red[256];
-    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    // four passes of eight loads in flight together (a pass at a time this was a chain of round trips -- 6000 partials are three of
-    // them, on the critical path of a 5 us launch); added pass after pass: the sums of the one-pass loop, bit for bit
-    for (int base = threadIdx.x; base < c.n; base += 4 * 8 * 256) {
-        double v[4][8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = base + 2048 * q + 256 * u;
-                v[q][u] = c.partial[e < c.n ? e : 0];
-            }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s[u] += (base + 2048 * q + 256 * u < c.n) ? v[q][u] : 0.0;
-    }
-    red[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    red[threadIdx.x] = cmf_thread_loss_sum(c.partial, c.n);
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
@@ -1574,7 +1581,13 @@ struct CmfHxtTail {
 static __global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const float *in, int nslabs, size_t stride, size_t n4, CmfLossCarry carry,
                                                         CmfHxtTail tail)
 {
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * blockDim.x) {
+    // (a carried loss reduction has a block of its own, the FIRST one: behind the last block's share of the sums it was the end of the launch)
+    unsigned bx = blockIdx.x, nbx = gridDim.x;
+    if (carry.partial) {
+        if (bx == 0) { cmf_block_loss_reduce(carry); return; }
+        --bx; --nbx;
+    }
+    for (size_t idx = bx * (size_t)blockDim.x + threadIdx.x; idx < n4; idx += (size_t)nbx * blockDim.x) {
         float4 a = reinterpret_cast<const float4 *>(in)[idx];
         for (int s = 1; s < nslabs; s += 4) { // four loads in flight, added in slab order (one at a time the loop is a chain of HBM round trips)
             float4 b[4];
@@ -1613,7 +1626,6 @@ static __global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const 
         }
         reinterpret_cast<float4 *>(out)[idx] = a;
     }
-    if (carry.partial && blockIdx.x == gridDim.x - 1) cmf_block_loss_reduce(carry);
 }
 
 // *out = sum(partial[0..n))   one block; eight independent loads per thread and round (the one-wave conv kernel
@@ -1627,15 +1639,7 @@ static __global__ __launch_bounds__(256) void slab_sum_kernel(float *out, const 
 static __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *partial, int n, double *out, double *host_out = nullptr)
 {
     __shared__ double red[256];
-    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int base = threadIdx.x; base < n; base += 8 * 256) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (base + 256 * u < n) ? partial[base + 256 * u] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s[u] += v[u];
-    }
-    red[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    red[threadIdx.x] = cmf_thread_loss_sum(partial, n);
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
@@ -3559,15 +3563,7 @@ static __global__ void halo_unpack3_kernel(float *H, float *Ht, const float *slo
 static __global__ __launch_bounds__(256) void loss_tail_kernel(const double *partial, int n, double *out, float *tail, int tail_len, int rank)
 {
     __shared__ double red[256];
-    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int base = threadIdx.x; base < n; base += 8 * 256) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (base + 256 * u < n) ? partial[base + 256 * u] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s[u] += v[u];
-    }
-    red[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    red[threadIdx.x] = cmf_thread_loss_sum(partial, n);
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
