@@ -1175,6 +1175,7 @@ int cmf_get_counter(cmf_handle h, const char *name, int64_t *value)
     if (std::strcmp(name, "hals_pipeline_reruns") == 0) { *value = h->hals_reruns; return CMF_OK; }
     if (std::strcmp(name, "writeback_calls") == 0) { *value = h->wb ? h->wb->armed_calls : 0; return CMF_OK; }            // cmf_arm_writeback calls
     if (std::strcmp(name, "speculated_contractions") == 0) { *value = h->spec_hits; return CMF_OK; }                         // update_motifs! calls whose C2 contraction was already enqueued
+    if (std::strcmp(name, "liveness_checks") == 0) { *value = g_liveness_checks.load(); return CMF_OK; } // (process-wide) stream queries made while waiting for a loss
     if (std::strcmp(name, "small_k_fused_h_updates") == 0) { // (a group: over its shards)
         *value = h->sk_fused_h;
         if (h->group)

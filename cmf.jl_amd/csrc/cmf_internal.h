@@ -670,6 +670,8 @@ static int launch_conv_rows(cmf_handle_s *h, float *out, int row0, int nrows, in
     return CMF_OK;
 }
 
+inline std::atomic<int64_t> g_liveness_checks{0}; // stream queries / health checks made by waits for a loss (process-wide; cmf_get_counter "liveness_checks")
+
 template <typename U>
 static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel, const std::function<int()> *health = nullptr,
                       const std::function<bool()> *enqueued = nullptr)
@@ -693,6 +695,7 @@ static int wait_words(hipStream_t stream, const volatile U *p, int n, U sentinel
         if ((spins & 0x3FF) == 0 && std::chrono::steady_clock::now() >= next_check) {
             // (enqueue workers that are still posting leave the stream idle: only a stream that has been given all its work
             // and has drained it proves that the words will never come)
+            g_liveness_checks.fetch_add(1, std::memory_order_relaxed);
             const hipError_t e = (enqueued && !(*enqueued)()) ? hipErrorNotReady : hipStreamQuery(stream);
             if (e == hipSuccess) { // everything enqueued has run: the words must be there now
                 if (all_there()) return CMF_OK;

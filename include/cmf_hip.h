@@ -181,7 +181,9 @@ int cmf_synchronize(cmf_handle h);
  * code (e.g. 22703) and, when path != NULL, the file it was loaded from.  CMF_ERR_COMM when no RCCL can be loaded. */
 int cmf_rccl_version(int *version, char *path, int64_t path_len);
 /* Event counters of a handle.  "hals_pipeline_reruns": H sweeps whose persistent pipeline ran out of a bounded wait and
- * were redone from the snapshot on the stage pipeline (cmf_hals_update_feature_maps).  "small_k_fused_h_updates": H updates of
+ * were redone from the snapshot on the stage pipeline (cmf_hals_update_feature_maps).  "liveness_checks" (process-wide): stream queries the
+ * waits for a loss have made -- 0 in a healthy run whose losses arrive within 50 ms (a query per iteration cost the device a marker
+ * packet behind every loss conv until round 6).  "small_k_fused_h_updates": H updates of
  * the MU rule that ran inside the few-component contraction launch (option "small_k_fuse").  Group handles: "enqueue_ns" /
  * "enqueue_iters" = nanoseconds the calling thread spent enqueueing (or posting to the enqueue workers) the pipelined
  * iterations of cmf_iterate, and how many iterations that covers; "worker_ns" = time the busiest enqueue worker spent

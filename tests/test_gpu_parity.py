@@ -1048,3 +1048,24 @@ def test_hals_chasing_conv_leaves_when_the_pipeline_aborts(cmf, oracle):
     rule.update_motifs()
     rule.update_feature_maps()  # the handle stays usable
     rule.close()
+
+
+def test_waiting_for_a_loss_puts_nothing_into_the_stream(cmf):
+    """Until round 6 the host's wait for a loss called hipStreamQuery every 4096 polls as its liveness check, and the runtime answered
+    each query by putting a marker packet (a barrier with a system-scope release) into the stream: 5.9 us of idle device behind every
+    loss conv whose loss took longer than those polls (profiles/r06_stream_query_gap.txt).  The checks are now made after 50 ms of
+    waiting: a healthy run makes none (cmf_get_counter "liveness_checks", process-wide)."""
+    rng = np.random.default_rng(3)
+    for (N, T, K, L, n) in [(256, 20000, 5, 20, 300), (512, 6250, 32, 20, 60)]:
+        data = rng.random((N, T))
+        rule = cmf.MultUpdate(data, *cmf.init_rand(data, L=L, K=K, seed=1))
+        try:
+            rule.iterate(5)
+            before = rule.counter("liveness_checks")
+            rule.iterate(n)                       # pipelined: a wait per iteration
+            for _ in range(20):                   # call by call: a wait per update_feature_maps!
+                rule.update_motifs()
+                rule.update_feature_maps()
+            assert rule.counter("liveness_checks") == before
+        finally:
+            rule.close()
